@@ -1,0 +1,122 @@
+"""ctypes binding of libdeeplio_hip.so (the C-ABI declared in include/deeplio_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is absent,
+import fails loudly.  Build it with ``python -m deeplio_amd.build`` (or
+``__graft_entry__.build()``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdeeplio_hip.so")
+
+DLIO_OK, DLIO_EINVAL, DLIO_EUNSUP, DLIO_ELAUNCH, DLIO_EWS = 0, -1, -2, -3, -4
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "N", "Cin", "H", "W", "in_ctot", "in_coff", "Cout", "OH", "OW", "out_ctot", "out_coff",
+        "KH", "KW", "SH", "SW", "PH", "PW", "res_ctot", "res_coff", "in_relu")]
+
+
+_p = C.c_void_p
+_i = C.c_int
+_i64 = C.c_int64
+_u64 = C.c_uint64
+_f = C.c_float
+_d = C.c_double
+_sz = C.c_size_t
+_cd = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); mirrors include/deeplio_hip.h one to one
+SIGNATURES = {
+    "dlio_version": (_i, []),
+    "dlio_arch": (C.c_char_p, []),
+    "dlio_strerror": (C.c_char_p, [_i]),
+    "dlio_prof_enable": (_i, [_i]),
+    "dlio_prof_reset": (_i, []),
+    "dlio_prof_collect": (_i, [_i, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d), C.POINTER(_i64)]),
+    "dlio_conv2d_prep_weight": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "dlio_conv2d_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _cd, _p]),
+    "dlio_conv2d_dgrad_strided": (_i, [_p, _p, _p, _cd, _p]),
+    "dlio_conv2d_wgrad_ws_bytes": (_sz, [_cd]),
+    "dlio_conv2d_wgrad": (_i, [_p, _p, _p, _p, _p, _p, _p, _sz, _cd, _p]),
+    "dlio_chan_stats_ws_bytes": (_sz, [_i, _i, _i]),
+    "dlio_chan_stats": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
+    "dlio_bn_finalize": (_i, [_p, _p, _i, _d, _p, _f, _f, _p, _p, _p, _p, _p, _p]),
+    "dlio_bn_eval_params": (_i, [_p, _p, _p, _f, _i, _p, _p, _p, _p]),
+    "dlio_bn_apply": (_i, [_p, _i, _i, _p, _p, _p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "dlio_bn_bwd_reduce": (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p,
+                               _p, _sz, _p]),
+    "dlio_bn_bwd_apply": (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p,
+                              _i, _i, _i, _i, _i, _i, _p]),
+    "dlio_chan_sum": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _sz, _p]),
+    "dlio_maxpool2d_fwd": (_i, [_p, _p, _p, _p] + [_i] * 11 + [_p]),
+    "dlio_maxpool2d_bwd": (_i, [_p, _p, _p, _p] + [_i] * 11 + [_p]),
+    "dlio_gap_fwd": (_i, [_p, _i, _i, _p, _i, _i, _i, _p]),
+    "dlio_gap_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "dlio_chan_scale_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "dlio_chan_scale_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "dlio_linear_fwd": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
+    "dlio_act_bwd": (_i, [_p, _p, _p, _i64, _i, _p]),
+    "dlio_linear_bwd_data": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "dlio_linear_bwd_weight": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _p]),
+    "dlio_ew_binary": (_i, [_p, _p, _p, _i64, _i, _p]),
+    "dlio_ew_scale": (_i, [_p, _f, _p, _i64, _p]),
+    "dlio_copy2d": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
+    "dlio_dropout_fwd": (_i, [_p, _p, _p, _i64, _f, _u64, _u64, _p]),
+    "dlio_dropout_bwd": (_i, [_p, _p, _p, _i64, _f, _p]),
+    "dlio_nonfinite_flag": (_i, [_p, _i64, _p, _p]),
+    "dlio_rnn_ws_bytes": (_sz, [_i, _i, _i]),
+    "dlio_lstm_seq_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i,
+                              _i, _p, _sz, _p]),
+    "dlio_lstm_seq_bwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i,
+                              _p, _sz, _p]),
+    "dlio_gru_seq_fwd": (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz,
+                             _p]),
+    "dlio_gru_seq_bwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz,
+                             _p]),
+    "dlio_se3_chain_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "dlio_se3_chain_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "dlio_pose_loss_fwd": (_i, [C.POINTER(_p), C.POINTER(_p), C.POINTER(C.c_int32), _p, _p, _f, _i,
+                               _p, _p]),
+    "dlio_pose_loss_bwd": (_i, [C.POINTER(_p), C.POINTER(_p), C.POINTER(C.c_int32), _p, _p, _f, _i,
+                               _p, _p, C.POINTER(_p), _p, _p, _p]),
+    "dlio_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i, _f, _p]),
+    "dlio_sgd_step": (_i, [_p, _p, _p, _i64, _f, _f, _f, _i, _f, _p]),
+    "dlio_sumsq": (_i, [_p, _i64, _p, _p]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "deeplio_amd: %s is missing -- the HIP extension is mandatory (no CPU fallback). "
+            "Run `python -m deeplio_amd.build`." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ImportError("deeplio_amd: symbol %s missing from %s" % (name, LIB_PATH)) from e
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def strerror(code):
+    return lib.dlio_strerror(int(code)).decode()
+
+
+def check(code, what=""):
+    """Map C-ABI status to the reference's error style: ValueError for bad configuration
+    (nets/__init__.py:103,145 raise ValueError on unknown names), RuntimeError otherwise."""
+    if code == DLIO_OK:
+        return
+    msg = "deeplio_hip %s failed: %s (%d)" % (what, strerror(code), code)
+    if code in (DLIO_EINVAL, DLIO_EUNSUP):
+        raise ValueError(msg)
+    raise RuntimeError(msg)

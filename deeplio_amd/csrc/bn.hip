@@ -1,0 +1,373 @@
+// Per-channel statistics and BatchNorm2d (train + eval, forward + backward) over NCHW
+// channel slices.  Memory-bound streaming kernels: float4 loads where HW % 4 == 0,
+// fp64 accumulation (free under the HBM bound) so that E[x^2]-E[x]^2 keeps fp32 accuracy.
+//
+// Replaces nn.BatchNorm2d at pointseg_net.py:19, pointseg_modules.py:98-106,
+// base_net.py:63, resnet.py:38, lidar_feat_nets.py:280-301 and the conv-bias gradient
+// reduction of nn.Conv2d backward.
+#include "common.h"
+
+namespace {
+
+constexpr int RB = 256;  // reduction block
+
+// split the (n, hw) domain of one channel over `splits` blocks.
+// mode 0: stats (sum x', sum x'^2)    mode 1: bn backward (sum g, sum g*xh)   mode 2: sum only
+template <int MODE>
+__global__ __launch_bounds__(RB) void chan_reduce_kernel(
+    const float* __restrict__ a, int a_ctot, int a_coff, const float* __restrict__ x, int x_ctot,
+    int x_coff, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ scale, const float* __restrict__ beta, int N, int C, int HW,
+    int pre_relu, int post_relu, int splits, double* __restrict__ part) {
+  __shared__ double sm[2][16];
+  const int c = blockIdx.x / splits;
+  const int sp = blockIdx.x % splits;
+  double s0 = 0.0, s1 = 0.0;
+  float mu = 0.f, is = 0.f, sc = 0.f, be = 0.f;
+  if (MODE == 1) { mu = mean[c]; is = invstd[c]; sc = scale[c]; be = beta ? beta[c] : 0.f; }
+  const int64_t total = (int64_t)N * HW;
+  const bool vec = (HW & 3) == 0;
+  if (vec) {
+    const int64_t total4 = total >> 2;
+    const int hw4 = HW >> 2;
+    for (int64_t i = (int64_t)sp * RB + threadIdx.x; i < total4; i += (int64_t)splits * RB) {
+      const int n = (int)(i / hw4);
+      const int p = (int)(i - (int64_t)n * hw4) << 2;
+      const float4 av = *reinterpret_cast<const float4*>(a + ((size_t)n * a_ctot + a_coff + c) * HW + p);
+      float ae[4] = {av.x, av.y, av.z, av.w};
+      if (MODE == 1) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + ((size_t)n * x_ctot + x_coff + c) * HW + p);
+        float xe[4] = {xv.x, xv.y, xv.z, xv.w};
+        float f0 = 0.f, f1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float xx = pre_relu ? fmaxf(xe[k], 0.f) : xe[k];
+          const float xh = (xx - mu) * is;
+          float g = ae[k];
+          if (post_relu && !((xx - mu) * sc + be > 0.f)) g = 0.f;
+          f0 += g; f1 += g * xh;
+        }
+        s0 += f0; s1 += f1;
+      } else {
+        float f0 = 0.f, f1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float xx = (MODE == 0 && pre_relu) ? fmaxf(ae[k], 0.f) : ae[k];
+          f0 += xx; f1 += xx * xx;
+        }
+        s0 += f0; s1 += (MODE == 0) ? (double)f1 : 0.0;
+      }
+    }
+  } else {
+    for (int64_t i = (int64_t)sp * RB + threadIdx.x; i < total; i += (int64_t)splits * RB) {
+      const int n = (int)(i / HW);
+      const int p = (int)(i - (int64_t)n * HW);
+      float av = a[((size_t)n * a_ctot + a_coff + c) * HW + p];
+      if (MODE == 1) {
+        float xx = x[((size_t)n * x_ctot + x_coff + c) * HW + p];
+        if (pre_relu) xx = fmaxf(xx, 0.f);
+        const float xh = (xx - mu) * is;
+        if (post_relu && !((xx - mu) * sc + be > 0.f)) av = 0.f;
+        s0 += av; s1 += (double)av * xh;
+      } else {
+        if (MODE == 0 && pre_relu) av = fmaxf(av, 0.f);
+        s0 += av;
+        if (MODE == 0) s1 += (double)av * av;
+      }
+    }
+  }
+  double r0 = block_sum_d(s0, sm[0]);
+  double r1 = block_sum_d(s1, sm[1]);
+  if (threadIdx.x == 0) {
+    part[((size_t)c * splits + sp) * 2 + 0] = r0;
+    part[((size_t)c * splits + sp) * 2 + 1] = r1;
+  }
+}
+
+__global__ void chan_reduce_final(const double* __restrict__ part, int C, int splits,
+                                  double* __restrict__ o0, double* __restrict__ o1,
+                                  float* __restrict__ f0) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int s = 0; s < splits; ++s) {
+    a += part[((size_t)c * splits + s) * 2 + 0];
+    b += part[((size_t)c * splits + s) * 2 + 1];
+  }
+  if (o0) o0[c] = a;
+  if (o1) o1[c] = b;
+  if (f0) f0[c] = (float)a;
+}
+
+int pick_splits(int N, int C, int HW) {
+  int64_t per_chan = (int64_t)N * HW;
+  int64_t want = cdiv64(2048, C);                 // ~2048 blocks in total
+  int64_t max_sp = cdiv64(per_chan, (int64_t)RB * 8);  // >= 8 elements (or float4s) per thread
+  if (want > max_sp) want = max_sp;
+  if (want < 1) want = 1;
+  if (want > 512) want = 512;
+  return (int)want;
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sum, const double* __restrict__ sumsq,
+                                   int C, double count, const float* __restrict__ gamma, float eps,
+                                   float momentum, float* running_mean, float* running_var,
+                                   float* mean, float* invstd, float* scale) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double m = sum[c] / count;
+  double var = sumsq[c] / count - m * m;
+  if (var < 0.0) var = 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  mean[c] = (float)m;
+  invstd[c] = is;
+  scale[c] = (gamma ? gamma[c] : 1.f) * is;
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+  if (running_var) {
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+  }
+}
+
+__global__ void bn_eval_params_kernel(const float* __restrict__ rm, const float* __restrict__ rv,
+                                      const float* __restrict__ gamma, float eps, int C,
+                                      float* mean, float* invstd, float* scale) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float is = 1.0f / sqrtf(rv[c] + eps);
+  mean[c] = rm[c];
+  invstd[c] = is;
+  scale[c] = (gamma ? gamma[c] : 1.f) * is;
+}
+
+// elementwise over (n, c, hw); one block row per (n, c) plane chunk
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_apply_kernel(
+    const float* __restrict__ x, int x_ctot, int x_coff, const float* __restrict__ mean,
+    const float* __restrict__ scale, const float* __restrict__ beta, const float* residual,
+    int r_ctot, int r_coff, float* y, int y_ctot, int y_coff, int N, int C, int HW, int pre_relu,
+    int post_relu) {
+  const int64_t planes = (int64_t)N * C;
+  const int per = VEC ? (HW >> 2) : HW;
+  const int64_t total = planes * per;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pl = i / per;
+    const int p = (int)(i - pl * per);
+    const int n = (int)(pl / C), c = (int)(pl - (int64_t)n * C);
+    const float mu = mean[c], sc = scale[c], be = beta ? beta[c] : 0.f;
+    if (VEC) {
+      const size_t xo = ((size_t)n * x_ctot + x_coff + c) * HW + ((size_t)p << 2);
+      const size_t yo = ((size_t)n * y_ctot + y_coff + c) * HW + ((size_t)p << 2);
+      float4 v = *reinterpret_cast<const float4*>(x + xo);
+      float e[4] = {v.x, v.y, v.z, v.w};
+      float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (residual)
+        rv = *reinterpret_cast<const float4*>(residual + ((size_t)n * r_ctot + r_coff + c) * HW + ((size_t)p << 2));
+      float re[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float xx = pre_relu ? fmaxf(e[k], 0.f) : e[k];
+        float o = (xx - mu) * sc + be;
+        if (post_relu) o = fmaxf(o, 0.f);
+        e[k] = o + re[k];
+      }
+      *reinterpret_cast<float4*>(y + yo) = make_float4(e[0], e[1], e[2], e[3]);
+    } else {
+      const size_t xo = ((size_t)n * x_ctot + x_coff + c) * HW + p;
+      const size_t yo = ((size_t)n * y_ctot + y_coff + c) * HW + p;
+      float xx = x[xo];
+      if (pre_relu) xx = fmaxf(xx, 0.f);
+      float o = (xx - mu) * sc + be;
+      if (post_relu) o = fmaxf(o, 0.f);
+      if (residual) o += residual[((size_t)n * r_ctot + r_coff + c) * HW + p];
+      y[yo] = o;
+    }
+  }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const float* __restrict__ dy, int dy_ctot, int dy_coff, const float* __restrict__ x,
+    int x_ctot, int x_coff, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ scale, const float* __restrict__ beta,
+    const double* __restrict__ sum_g, const double* __restrict__ sum_gx, float* dx, int dx_ctot,
+    int dx_coff, int N, int C, int HW, int pre_relu, int post_relu, int use_batch_stats) {
+  const int64_t planes = (int64_t)N * C;
+  const int per = VEC ? (HW >> 2) : HW;
+  const int64_t total = planes * per;
+  const double inv_cnt = 1.0 / ((double)N * HW);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pl = i / per;
+    const int p = (int)(i - pl * per);
+    const int n = (int)(pl / C), c = (int)(pl - (int64_t)n * C);
+    const float mu = mean[c], is = invstd[c], sc = scale[c], be = beta ? beta[c] : 0.f;
+    float mg = 0.f, mgx = 0.f;
+    if (use_batch_stats) { mg = (float)(sum_g[c] * inv_cnt); mgx = (float)(sum_gx[c] * inv_cnt); }
+    constexpr int V = VEC ? 4 : 1;
+    const size_t off = VEC ? ((size_t)p << 2) : (size_t)p;
+    const size_t go = ((size_t)n * dy_ctot + dy_coff + c) * HW + off;
+    const size_t xo = ((size_t)n * x_ctot + x_coff + c) * HW + off;
+    const size_t oo = ((size_t)n * dx_ctot + dx_coff + c) * HW + off;
+    float ge[4], xe[4];
+    if (VEC) {
+      float4 gv = *reinterpret_cast<const float4*>(dy + go);
+      float4 xv = *reinterpret_cast<const float4*>(x + xo);
+      ge[0] = gv.x; ge[1] = gv.y; ge[2] = gv.z; ge[3] = gv.w;
+      xe[0] = xv.x; xe[1] = xv.y; xe[2] = xv.z; xe[3] = xv.w;
+    } else {
+      ge[0] = dy[go]; xe[0] = x[xo];
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const float xraw = xe[k];
+      const float xx = pre_relu ? fmaxf(xraw, 0.f) : xraw;
+      float g = ge[k];
+      if (post_relu && !((xx - mu) * sc + be > 0.f)) g = 0.f;
+      const float xh = (xx - mu) * is;
+      float o = sc * (g - mg - xh * mgx);
+      if (pre_relu && !(xraw > 0.f)) o = 0.f;
+      ge[k] = o;
+    }
+    if (VEC) *reinterpret_cast<float4*>(dx + oo) = make_float4(ge[0], ge[1], ge[2], ge[3]);
+    else dx[oo] = ge[0];
+  }
+}
+
+__global__ void bn_param_grads_kernel(const double* __restrict__ sum_g,
+                                      const double* __restrict__ sum_gx, float* dgamma,
+                                      float* dbeta, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  if (dgamma) dgamma[c] = (float)sum_gx[c];
+  if (dbeta) dbeta[c] = (float)sum_g[c];
+}
+
+}  // namespace
+
+extern "C" size_t dlio_chan_stats_ws_bytes(int N, int C, int HW) {
+  if (N <= 0 || C <= 0 || HW <= 0) return 0;
+  return (size_t)C * pick_splits(N, C, HW) * 2 * sizeof(double);
+}
+
+static int chan_reduce(int mode, const float* a, int a_ctot, int a_coff, const float* x, int x_ctot,
+                       int x_coff, const float* mean, const float* invstd, const float* scale,
+                       const float* beta, int N, int C, int HW, int pre_relu, int post_relu,
+                       double* o0, double* o1, float* f0, void* ws, size_t ws_bytes,
+                       hipStream_t s) {
+  if (!a || N <= 0 || C <= 0 || HW <= 0 || !ws) return DLIO_EINVAL;
+  const int splits = pick_splits(N, C, HW);
+  if (ws_bytes < (size_t)C * splits * 2 * sizeof(double)) return DLIO_EWS;
+  double* part = reinterpret_cast<double*>(ws);
+  dim3 grid((unsigned)(C * splits));
+  if (mode == 0)
+    hipLaunchKernelGGL(chan_reduce_kernel<0>, grid, dim3(RB), 0, s, a, a_ctot, a_coff, x, x_ctot,
+                       x_coff, mean, invstd, scale, beta, N, C, HW, pre_relu, post_relu, splits, part);
+  else if (mode == 1)
+    hipLaunchKernelGGL(chan_reduce_kernel<1>, grid, dim3(RB), 0, s, a, a_ctot, a_coff, x, x_ctot,
+                       x_coff, mean, invstd, scale, beta, N, C, HW, pre_relu, post_relu, splits, part);
+  else
+    hipLaunchKernelGGL(chan_reduce_kernel<2>, grid, dim3(RB), 0, s, a, a_ctot, a_coff, x, x_ctot,
+                       x_coff, mean, invstd, scale, beta, N, C, HW, pre_relu, post_relu, splits, part);
+  int rc = dlio_check_launch();
+  if (rc) return rc;
+  hipLaunchKernelGGL(chan_reduce_final, dim3(cdiv(C, 128)), dim3(128), 0, s, part, C, splits, o0,
+                     o1, f0);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_chan_stats(const float* x, int N, int ctot, int coff, int C, int HW,
+                               int pre_relu, double* sum, double* sumsq, void* ws,
+                               size_t ws_bytes, dlio_stream_t stream) {
+  if (!sum || !sumsq) return DLIO_EINVAL;
+  return chan_reduce(0, x, ctot, coff, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, N, C, HW,
+                     pre_relu, 0, sum, sumsq, nullptr, ws, ws_bytes, as_stream(stream));
+}
+
+extern "C" int dlio_chan_sum(const float* x, int N, int ctot, int coff, int C, int HW, float* out,
+                             void* ws, size_t ws_bytes, dlio_stream_t stream) {
+  if (!out) return DLIO_EINVAL;
+  return chan_reduce(2, x, ctot, coff, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, N, C, HW,
+                     0, 0, nullptr, nullptr, out, ws, ws_bytes, as_stream(stream));
+}
+
+extern "C" int dlio_bn_bwd_reduce(const float* dy, int dy_ctot, int dy_coff, const float* x,
+                                  int x_ctot, int x_coff, const float* mean, const float* invstd,
+                                  const float* scale, const float* beta, int N, int C, int HW,
+                                  int pre_relu, int post_relu, double* sum_g, double* sum_gx,
+                                  void* ws, size_t ws_bytes, dlio_stream_t stream) {
+  if (!x || !mean || !invstd || !scale || !sum_g || !sum_gx) return DLIO_EINVAL;
+  return chan_reduce(1, dy, dy_ctot, dy_coff, x, x_ctot, x_coff, mean, invstd, scale, beta, N, C,
+                     HW, pre_relu, post_relu, sum_g, sum_gx, nullptr, ws, ws_bytes,
+                     as_stream(stream));
+}
+
+extern "C" int dlio_bn_finalize(const double* sum, const double* sumsq, int C, double count,
+                                const float* gamma, float eps, float momentum,
+                                float* running_mean, float* running_var, float* mean,
+                                float* invstd, float* scale, dlio_stream_t stream) {
+  if (!sum || !sumsq || !mean || !invstd || !scale || C <= 0 || count <= 0) return DLIO_EINVAL;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, as_stream(stream), sum,
+                     sumsq, C, count, gamma, eps, momentum, running_mean, running_var, mean,
+                     invstd, scale);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_bn_eval_params(const float* running_mean, const float* running_var,
+                                   const float* gamma, float eps, int C, float* mean,
+                                   float* invstd, float* scale, dlio_stream_t stream) {
+  if (!running_mean || !running_var || !mean || !invstd || !scale || C <= 0) return DLIO_EINVAL;
+  hipLaunchKernelGGL(bn_eval_params_kernel, dim3(cdiv(C, 128)), dim3(128), 0, as_stream(stream),
+                     running_mean, running_var, gamma, eps, C, mean, invstd, scale);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_bn_apply(const float* x, int x_ctot, int x_coff, const float* mean,
+                             const float* scale, const float* beta, const float* residual,
+                             int r_ctot, int r_coff, float* y, int y_ctot, int y_coff, int N,
+                             int C, int HW, int pre_relu, int post_relu, dlio_stream_t stream) {
+  if (!x || !mean || !scale || !y || N <= 0 || C <= 0 || HW <= 0) return DLIO_EINVAL;
+  const bool vec = (HW & 3) == 0;
+  const int64_t total = (int64_t)N * C * (vec ? HW / 4 : HW);
+  dim3 grid(ew_grid(total, 256));
+  if (vec)
+    hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(256), 0, as_stream(stream), x, x_ctot,
+                       x_coff, mean, scale, beta, residual, r_ctot, r_coff, y, y_ctot, y_coff, N, C,
+                       HW, pre_relu, post_relu);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(256), 0, as_stream(stream), x, x_ctot,
+                       x_coff, mean, scale, beta, residual, r_ctot, r_coff, y, y_ctot, y_coff, N, C,
+                       HW, pre_relu, post_relu);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_bn_bwd_apply(const float* dy, int dy_ctot, int dy_coff, const float* x,
+                                 int x_ctot, int x_coff, const float* mean, const float* invstd,
+                                 const float* scale, const float* beta, const double* sum_g,
+                                 const double* sum_gx, float* dx, int dx_ctot, int dx_coff,
+                                 float* dgamma, float* dbeta, int N, int C, int HW, int pre_relu,
+                                 int post_relu, int use_batch_stats, dlio_stream_t stream) {
+  if (!dy || !x || !mean || !invstd || !scale || !sum_g || !sum_gx || !dx) return DLIO_EINVAL;
+  if (N <= 0 || C <= 0 || HW <= 0) return DLIO_EINVAL;
+  hipStream_t s = as_stream(stream);
+  const bool vec = (HW & 3) == 0;
+  const int64_t total = (int64_t)N * C * (vec ? HW / 4 : HW);
+  dim3 grid(ew_grid(total, 256));
+  if (vec)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(256), 0, s, dy, dy_ctot, dy_coff, x,
+                       x_ctot, x_coff, mean, invstd, scale, beta, sum_g, sum_gx, dx, dx_ctot,
+                       dx_coff, N, C, HW, pre_relu, post_relu, use_batch_stats);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(256), 0, s, dy, dy_ctot, dy_coff, x,
+                       x_ctot, x_coff, mean, invstd, scale, beta, sum_g, sum_gx, dx, dx_ctot,
+                       dx_coff, N, C, HW, pre_relu, post_relu, use_batch_stats);
+  int rc = dlio_check_launch();
+  if (rc) return rc;
+  if (dgamma || dbeta) {
+    hipLaunchKernelGGL(bn_param_grads_kernel, dim3(cdiv(C, 128)), dim3(128), 0, s, sum_g, sum_gx,
+                       dgamma, dbeta, C);
+    rc = dlio_check_launch();
+  }
+  return rc;
+}

@@ -1,0 +1,60 @@
+// Shared helpers for the gfx950 kernels of libdeeplio_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/deeplio_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define DLIO_WAVE 64
+
+static inline hipStream_t as_stream(dlio_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int dlio_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? DLIO_OK : DLIO_ELAUNCH;
+}
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// grid size for grid-stride memory-bound kernels: 256 CUs x 8 blocks
+static inline int ew_grid(int64_t work_items, int block) {
+  int64_t g = cdiv64(work_items, block);
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-wide sum of a double (blockDim.x multiple of 64, <= 1024); result valid in thread 0
+__device__ __forceinline__ double block_sum_d(double v, double* smem /* >= 16 doubles */) {
+  v = wave_sum_d(v);
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) smem[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) {
+    int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) r += smem[i];
+  }
+  return r;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// profiling hooks (prof.hip)
+void dlio_prof_begin(int kind, hipStream_t s, double flops, double bytes);
+void dlio_prof_end(int kind, hipStream_t s);

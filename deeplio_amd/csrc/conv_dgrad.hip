@@ -1,0 +1,55 @@
+// Data gradient of STRIDED convolutions (stride-1 convs go through conv_fwd.hip with
+// tap-reversed weights).  Only the non-PointSeg encoders have strided convs below the stem
+// (FlowNet conv2..conv6, ResNet stage heads + 1x1 downsamples); this is a direct gather
+// kernel: one thread per dx element, coalesced along W.
+// Replaces the input-gradient half of nn.Conv2d backward at base_net.py:55-71, resnet.py
+// (_make_layer strides) for those layers.
+#include "common.h"
+
+namespace {
+__global__ __launch_bounds__(256) void dgrad_strided_kernel(const float* __restrict__ dy,
+                                                            const float* __restrict__ w,
+                                                            float* __restrict__ dx,
+                                                            DlioConvDesc d) {
+  const int64_t total = (int64_t)d.N * d.Cin * d.H * d.W;
+  const int taps = d.KH * d.KW;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int iw = (int)(i % d.W);
+    int64_t t = i / d.W;
+    const int ih = (int)(t % d.H); t /= d.H;
+    const int ci = (int)(t % d.Cin);
+    const int n = (int)(t / d.Cin);
+    float acc = 0.f;
+    for (int ky = 0; ky < d.KH; ++ky) {
+      const int a = ih + d.PH - ky;
+      if (a < 0 || a % d.SH) continue;
+      const int oh = a / d.SH;
+      if (oh >= d.OH) continue;
+      for (int kx = 0; kx < d.KW; ++kx) {
+        const int b = iw + d.PW - kx;
+        if (b < 0 || b % d.SW) continue;
+        const int ow = b / d.SW;
+        if (ow >= d.OW) continue;
+        const float* dyp = dy + (((size_t)n * d.out_ctot + d.out_coff) * d.OH + oh) * d.OW + ow;
+        const float* wp = w + ((size_t)ci * taps) + ky * d.KW + kx;
+        const size_t ohw = (size_t)d.OH * d.OW;
+        const size_t wstride = (size_t)d.Cin * taps;
+        for (int co = 0; co < d.Cout; ++co) acc += dyp[co * ohw] * wp[co * wstride];
+      }
+    }
+    dx[(((size_t)n * d.in_ctot + d.in_coff + ci) * d.H + ih) * d.W + iw] = acc;
+  }
+}
+}  // namespace
+
+extern "C" int dlio_conv2d_dgrad_strided(const float* dy, const float* w, float* dx,
+                                         const DlioConvDesc* dp, dlio_stream_t stream) {
+  if (!dy || !w || !dx || !dp) return DLIO_EINVAL;
+  const DlioConvDesc& d = *dp;
+  const int64_t total = (int64_t)d.N * d.Cin * d.H * d.W;
+  if (total <= 0) return DLIO_EINVAL;
+  hipLaunchKernelGGL(dgrad_strided_kernel, dim3(ew_grid(total, 256)), dim3(256), 0,
+                     as_stream(stream), dy, w, dx, d);
+  return dlio_check_launch();
+}

@@ -1,0 +1,260 @@
+// Implicit-GEMM 2-D convolution, fp32 in / fp32 accumulate, on v_mfma_f32_32x32x2_f32.
+//
+// GEMM orientation (chosen for NCHW): D[co][pixel] = sum_k W[co][k] * X[k][pixel]
+//   A operand = weights, lane l holds W[co = l&31][k + (l>>5)]
+//   B operand = im2col,  lane l holds X[k + (l>>5)][pixel = l&31]  -> 32 consecutive
+//               pixels of one image row: a conflict-free ds_read_b32 from the LDS patch
+//   D: lane = pixel column, 16 regs = 16 output channels -> every store instruction
+//      writes 2 x 128 B contiguous row segments of the NCHW output.
+// K is walked as (ci-chunk) x (tap) x (ci pair); the input patch of CK channels (with
+// halo, zero padding, and the optional fused BN-apply+ReLU of the producer) and the
+// matching weight slab are staged in LDS once per chunk.
+//
+// Replaces nn.Conv2d forward (and, with mode-1 prepped weights, the stride-1 data
+// gradient) on the reference path: pointseg_net.py:18, pointseg_modules.py:96-106,
+// base_net.py:55-71, resnet.py:36, lidar_feat_nets.py:279-304.
+#include "common.h"
+
+namespace {
+
+template <int KH, int KW, int SH, int SW, int CK, int TWN>
+struct ConvCfg {
+  static constexpr int TH = 4;                  // output rows per block
+  static constexpr int TW = 32 * TWN;           // output cols per block
+  static constexpr int MR = 2;                  // 32-channel tiles per wave
+  static constexpr int CO_T = 32 * MR;          // output channels per block
+  static constexpr int NR = TWN;                // pixel tiles per wave (wave = one row)
+  static constexpr int PR = (TH - 1) * SH + KH; // patch rows
+  static constexpr int PC = (TW - 1) * SW + KW; // patch cols
+  static constexpr int PLANE = PR * PC;
+  static constexpr int TAPS = KH * KW;
+  static constexpr int XL = CK * PLANE;         // floats
+  static constexpr int WL = TAPS * CK * CO_T;   // floats
+  static constexpr size_t LDS_BYTES = (size_t)(XL + WL) * 4;
+};
+
+template <int KH, int KW, int SH, int SW, int CK, int TWN>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
+    const float* __restrict__ in_mean, const float* __restrict__ in_scale,
+    const float* __restrict__ in_shift, const float* residual, float* y, DlioConvDesc d,
+    int tiles_w, int tiles_h, int co_tiles) {
+  using C = ConvCfg<KH, KW, SH, SW, CK, TWN>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Xl = smem;
+  float* Wl = smem + C::XL;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;       // = output row inside the tile
+  const int l31 = lane & 31;
+  const int half = lane >> 5;
+
+  // block -> (co tile fastest, then w tile, h tile, image)
+  int bid = blockIdx.x;
+  const int cot = bid % co_tiles; bid /= co_tiles;
+  const int tw = bid % tiles_w;   bid /= tiles_w;
+  const int th = bid % tiles_h;   bid /= tiles_h;
+  const int n = bid;
+
+  const int co0 = cot * C::CO_T;
+  const int oh0 = th * C::TH;
+  const int ow0 = tw * C::TW;
+  const int ih0 = oh0 * SH - d.PH;
+  const int iw0 = ow0 * SW - d.PW;
+
+  f32x16 acc[C::MR][C::NR];
+#pragma unroll
+  for (int m = 0; m < C::MR; ++m)
+#pragma unroll
+    for (int q = 0; q < C::NR; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
+
+  const float* xn = x + ((size_t)n * d.in_ctot + d.in_coff) * (size_t)d.H * d.W;
+  const bool has_aff = in_scale != nullptr;
+
+  for (int c0 = 0; c0 < d.Cin; c0 += CK) {
+    // ---- stage input patch -------------------------------------------------
+    for (int idx = tid; idx < C::XL; idx += 256) {
+      const int c = idx / C::PLANE;
+      const int rem = idx - c * C::PLANE;
+      const int r = rem / C::PC;
+      const int col = rem - r * C::PC;
+      const int ci = c0 + c;
+      const int ih = ih0 + r;
+      const int iw = iw0 + col;
+      float v = 0.f;
+      if (ci < d.Cin && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W) {
+        v = xn[((size_t)ci * d.H + ih) * d.W + iw];
+        if (has_aff) {
+          v = (v - in_mean[ci]) * in_scale[ci] + in_shift[ci];
+          if (d.in_relu) v = fmaxf(v, 0.f);
+        }
+      }
+      Xl[idx] = v;
+    }
+    // ---- stage weight slab: Wl[(tap*CK + c)][co] ---------------------------
+    for (int idx = tid; idx < C::WL; idx += 256) {
+      const int co = idx % C::CO_T;
+      const int kc = idx / C::CO_T;
+      const int c = kc % CK;
+      const int tap = kc / CK;
+      const int ci = c0 + c;
+      float v = 0.f;
+      if (ci < d.Cin && co0 + co < d.Cout)
+        v = wt[((size_t)tap * d.Cin + ci) * d.Cout + co0 + co];
+      Wl[idx] = v;
+    }
+    __syncthreads();
+
+    // ---- MFMA over this chunk ---------------------------------------------
+#pragma unroll
+    for (int dy = 0; dy < KH; ++dy) {
+#pragma unroll
+      for (int dx = 0; dx < KW; ++dx) {
+        const int tap = dy * KW + dx;
+        const float* xrow = Xl + (wave * SH + dy) * C::PC + dx + l31 * SW;
+        const float* wrow = Wl + (size_t)tap * CK * C::CO_T + l31;
+#pragma unroll
+        for (int c2 = 0; c2 < CK; c2 += 2) {
+          const int c = c2 + half;
+          float a[C::MR], b[C::NR];
+#pragma unroll
+          for (int m = 0; m < C::MR; ++m) a[m] = wrow[c * C::CO_T + m * 32];
+#pragma unroll
+          for (int q = 0; q < C::NR; ++q) b[q] = xrow[c * C::PLANE + q * 32 * SW];
+#pragma unroll
+          for (int m = 0; m < C::MR; ++m)
+#pragma unroll
+            for (int q = 0; q < C::NR; ++q)
+              acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[q], acc[m][q], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias + residual, NCHW store ------------------------------
+  const int oh = oh0 + wave;
+  if (oh >= d.OH) return;
+  const size_t ohw = (size_t)d.OH * d.OW;
+#pragma unroll
+  for (int m = 0; m < C::MR; ++m) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (co >= d.Cout) continue;
+      const float bv = bias ? bias[co] : 0.f;
+#pragma unroll
+      for (int q = 0; q < C::NR; ++q) {
+        const int ow = ow0 + q * 32 + l31;
+        if (ow >= d.OW) continue;
+        float v = acc[m][q][r] + bv;
+        const size_t pix = (size_t)oh * d.OW + ow;
+        if (residual)
+          v += residual[((size_t)n * d.res_ctot + d.res_coff + co) * ohw + pix];
+        y[((size_t)n * d.out_ctot + d.out_coff + co) * ohw + pix] = v;
+      }
+    }
+  }
+}
+
+template <int KH, int KW, int SH, int SW, int CK, int TWN>
+int launch(const float* x, const float* wt, const float* bias, const float* in_mean,
+           const float* in_scale, const float* in_shift, const float* residual, float* y,
+           const DlioConvDesc& d, hipStream_t s) {
+  using C = ConvCfg<KH, KW, SH, SW, CK, TWN>;
+  const int tiles_w = cdiv(d.OW, C::TW), tiles_h = cdiv(d.OH, C::TH);
+  const int co_tiles = cdiv(d.Cout, C::CO_T);
+  const int64_t blocks = (int64_t)tiles_w * tiles_h * co_tiles * d.N;
+  if (blocks <= 0 || blocks > 0x7fffffff) return DLIO_EINVAL;
+  auto kern = conv_fwd_kernel<KH, KW, SH, SW, CK, TWN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, s, x, wt, bias,
+                     in_mean, in_scale, in_shift, residual, y, d, tiles_w, tiles_h, co_tiles);
+  return dlio_check_launch();
+}
+
+template <int KH, int KW, int SH, int SW, int CK>
+int launch_tw(const float* x, const float* wt, const float* bias, const float* in_mean,
+              const float* in_scale, const float* in_shift, const float* residual, float* y,
+              const DlioConvDesc& d, hipStream_t s) {
+  if (d.OW > 32)
+    return launch<KH, KW, SH, SW, CK, 2>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
+  return launch<KH, KW, SH, SW, CK, 1>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
+}
+
+__global__ void prep_weight_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout,
+                                   int Cin, int taps, int mode) {
+  const int64_t total = (int64_t)Cout * Cin * taps;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    if (mode == 0) {  // wt[tap][ci][co] = w[co][ci][tap]
+      const int co = i % Cout;
+      const int ci = (i / Cout) % Cin;
+      const int tap = i / ((int64_t)Cout * Cin);
+      wt[i] = w[((int64_t)co * Cin + ci) * taps + tap];
+    } else {          // wt[tap'][co][ci] = w[co][ci][taps-1-tap']
+      const int ci = i % Cin;
+      const int co = (i / Cin) % Cout;
+      const int tap = i / ((int64_t)Cout * Cin);
+      wt[i] = w[((int64_t)co * Cin + ci) * taps + (taps - 1 - tap)];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int dlio_conv2d_prep_weight(const float* w, float* wt, int Cout, int Cin, int KH,
+                                       int KW, int mode, dlio_stream_t stream) {
+  if (!w || !wt || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || (mode != 0 && mode != 1))
+    return DLIO_EINVAL;
+  const int64_t total = (int64_t)Cout * Cin * KH * KW;
+  hipLaunchKernelGGL(prep_weight_kernel, dim3(ew_grid(total, 256)), dim3(256), 0,
+                     as_stream(stream), w, wt, Cout, Cin, KH * KW, mode);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_conv2d_fwd(const float* x, const float* wt, const float* bias,
+                               const float* in_mean, const float* in_scale,
+                               const float* in_shift, const float* residual, float* y,
+                               const DlioConvDesc* dp, dlio_stream_t stream) {
+  if (!x || !wt || !y || !dp) return DLIO_EINVAL;
+  const DlioConvDesc& d = *dp;
+  if (d.N <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.H <= 0 || d.W <= 0) return DLIO_EINVAL;
+  if (d.OH != (d.H + 2 * d.PH - d.KH) / d.SH + 1 && d.OH != (d.H + 2 * d.PH - d.KH + d.SH - 1) / d.SH + 1)
+    return DLIO_EINVAL;
+  if (d.OW != (d.W + 2 * d.PW - d.KW) / d.SW + 1 && d.OW != (d.W + 2 * d.PW - d.KW + d.SW - 1) / d.SW + 1)
+    return DLIO_EINVAL;
+  if (in_scale && (!in_mean || !in_shift)) return DLIO_EINVAL;
+  hipStream_t s = as_stream(stream);
+  const double flops = 2.0 * d.N * (double)d.OH * d.OW * d.Cout * (double)d.Cin * d.KH * d.KW;
+  const double bytes = 4.0 * d.N * ((double)d.Cin * d.H * d.W + (double)d.Cout * d.OH * d.OW *
+                                   (residual ? 2.0 : 1.0));
+  dlio_prof_begin(0, s, flops, bytes);
+  int rc = DLIO_EUNSUP;
+#define CONV_CASE(kh, kw, sh, sw, ck)                                                        \
+  if (d.KH == kh && d.KW == kw && d.SH == sh && d.SW == sw)                                  \
+    rc = launch_tw<kh, kw, sh, sw, ck>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
+  if (d.KH == 1 && d.KW == 1 && d.SH == 1 && d.SW == 1 && (d.Cin % 32) != 0)
+    rc = launch_tw<1, 1, 1, 1, 16>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
+  else CONV_CASE(1, 1, 1, 1, 32)
+  else CONV_CASE(3, 3, 1, 1, 8)
+  else CONV_CASE(3, 5, 1, 2, 4)
+  else CONV_CASE(3, 5, 1, 1, 4)
+  else CONV_CASE(5, 7, 1, 2, 2)
+  else CONV_CASE(5, 7, 1, 1, 2)
+  else CONV_CASE(3, 3, 2, 2, 8)
+  else CONV_CASE(3, 3, 1, 2, 8)
+  else CONV_CASE(1, 1, 1, 2, 32)
+  else CONV_CASE(1, 1, 2, 2, 32)
+#undef CONV_CASE
+  dlio_prof_end(0, s);
+  return rc;
+}

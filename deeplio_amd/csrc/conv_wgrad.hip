@@ -1,0 +1,285 @@
+// Weight gradient of the 2-D convolution on v_mfma_f32_32x32x2_f32.
+//
+// GEMM: dW[co][j] = sum_pixels dY[co][pixel] * X[pixel][j],   j = (ci, tap) flattened with
+// tap fastest, i.e. j is exactly the offset inside a row of the standard
+// [Cout][Cin][KH][KW] weight layout.
+//   A operand: lane l holds dY[co = l&31][pixel + (l>>5)]   (LDS, odd per-channel stride)
+//   B operand: lane l holds X'[pixel + (l>>5)][j = l&31]    (LDS patch + per-lane tap offset)
+// K (= pixels of the whole batch) is split over blocks; the 4 waves of a block take one
+// image row each, their accumulators are summed through LDS and written as one partial
+// slab; a second kernel sums the slabs in a fixed order (deterministic, no atomics).
+//
+// Replaces the weight-gradient half of nn.Conv2d backward for every conv on the path
+// (same reference sites as conv_fwd.hip).
+#include "common.h"
+
+namespace {
+
+template <int KH, int KW, int SH, int SW, int NT>
+struct WgCfg {
+  static constexpr int TH = 4, TW = 32;
+  static constexpr int MR = 2, CO_T = 64;
+  static constexpr int TAPS = KH * KW;
+  static constexpr int CKMAX = (NT * 32) / TAPS;
+  static constexpr int PR = (TH - 1) * SH + KH;
+  static constexpr int PC = (TW - 1) * SW + KW;
+  static constexpr int PLANE = (PR * PC) | 1;     // odd -> lanes (=channels) hit distinct banks
+  static constexpr int DYS = TH * TW + 1;         // odd per-channel stride of the dY tile
+  static constexpr int XL = CKMAX * PLANE;
+  static constexpr int DL = CO_T * DYS;
+  static constexpr int RED = MR * NT * 16 * 64;
+  static constexpr int SM_FLOATS = (XL + DL) > RED ? (XL + DL) : RED;
+  static constexpr size_t LDS_BYTES = (size_t)SM_FLOATS * 4;
+};
+
+template <int KH, int KW, int SH, int SW, int NT>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ wsp,
+    const float* __restrict__ in_mean, const float* __restrict__ in_scale,
+    const float* __restrict__ in_shift, DlioConvDesc d, int co_tiles, int ci_chunks, int splits,
+    int tiles_w, int tiles_h) {
+  using C = WgCfg<KH, KW, SH, SW, NT>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Xl = smem;
+  float* Dl = smem + C::XL;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l31 = lane & 31;
+  const int half = lane >> 5;
+
+  int bid = blockIdx.x;
+  const int split = bid % splits; bid /= splits;
+  const int cic = bid % ci_chunks; bid /= ci_chunks;
+  const int cot = bid;
+  const int co0 = cot * C::CO_T;
+  const int c0 = cic * C::CKMAX;
+  const int ck = min(C::CKMAX, d.Cin - c0);   // live channels in this chunk
+  const int nj = ck * C::TAPS;                // live columns
+
+  // per-lane LDS offset of column j = t*32 + l31
+  int off[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int j = t * 32 + l31;
+    int o = 0;
+    if (j < nj) {
+      const int cl = j / C::TAPS;
+      const int tap = j - cl * C::TAPS;
+      const int ky = tap / KW, kx = tap - ky * KW;
+      o = cl * C::PLANE + ky * C::PC + kx;
+    }
+    off[t] = o;
+  }
+
+  f32x16 acc[C::MR][NT];
+#pragma unroll
+  for (int m = 0; m < C::MR; ++m)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+
+  const bool has_aff = in_scale != nullptr;
+  const int total_tiles = d.N * tiles_h * tiles_w;
+  const size_t ohw = (size_t)d.OH * d.OW;
+
+  for (int tile = split; tile < total_tiles; tile += splits) {
+    int tt = tile;
+    const int tw = tt % tiles_w; tt /= tiles_w;
+    const int th = tt % tiles_h; tt /= tiles_h;
+    const int n = tt;
+    const int oh0 = th * C::TH, ow0 = tw * C::TW;
+    const int ih0 = oh0 * SH - d.PH, iw0 = ow0 * SW - d.PW;
+
+    // ---- stage X' patch [ck][PR][PC] ---------------------------------------
+    const float* xn = x + ((size_t)n * d.in_ctot + d.in_coff + c0) * (size_t)d.H * d.W;
+    for (int idx = tid; idx < C::CKMAX * C::PR * C::PC; idx += 256) {
+      const int c = idx / (C::PR * C::PC);
+      const int rem = idx - c * (C::PR * C::PC);
+      const int r = rem / C::PC;
+      const int col = rem - r * C::PC;
+      const int ih = ih0 + r, iw = iw0 + col;
+      float v = 0.f;
+      if (c < ck && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W) {
+        v = xn[((size_t)c * d.H + ih) * d.W + iw];
+        if (has_aff) {
+          v = (v - in_mean[c0 + c]) * in_scale[c0 + c] + in_shift[c0 + c];
+          if (d.in_relu) v = fmaxf(v, 0.f);
+        }
+      }
+      Xl[c * C::PLANE + r * C::PC + col] = v;
+    }
+    // ---- stage dY tile [CO_T][TH][TW] --------------------------------------
+    const float* dyn = dy + ((size_t)n * d.out_ctot + d.out_coff + co0) * ohw;
+    for (int idx = tid; idx < C::CO_T * C::TH * C::TW; idx += 256) {
+      const int col = idx & 31;
+      const int r = (idx >> 5) & 3;
+      const int co = idx >> 7;
+      const int oh = oh0 + r, ow = ow0 + col;
+      float v = 0.f;
+      if (co0 + co < d.Cout && oh < d.OH && ow < d.OW) v = dyn[(size_t)co * ohw + (size_t)oh * d.OW + ow];
+      Dl[co * C::DYS + r * 32 + col] = v;
+    }
+    __syncthreads();
+
+    // ---- wave = row `wave` of the tile; 16 pixel pairs ------------------------
+    const float* drow = Dl + l31 * C::DYS + wave * 32 + half;
+    const float* xrow = Xl + (wave * SH) * C::PC + half * SW;
+#pragma unroll 4
+    for (int kp = 0; kp < 16; ++kp) {
+      float a[C::MR], b[NT];
+#pragma unroll
+      for (int m = 0; m < C::MR; ++m) a[m] = drow[m * 32 * C::DYS + kp * 2];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) b[t] = xrow[off[t] + kp * 2 * SW];
+#pragma unroll
+      for (int m = 0; m < C::MR; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[t], acc[m][t], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- cross-wave reduction through LDS (fixed order) -------------------------
+  float* red = smem;
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int m = 0; m < C::MR; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int i = ((m * NT + t) * 16 + r) * 64 + lane;
+            if (w == 0) red[i] = acc[m][t][r];
+            else red[i] += acc[m][t][r];
+          }
+    }
+    __syncthreads();
+  }
+
+  // ---- write the partial slab in standard weight layout ------------------------
+  const size_t row_len = (size_t)d.Cin * C::TAPS;
+  float* out = wsp + (size_t)split * d.Cout * row_len;
+  for (int idx = tid; idx < C::CO_T * NT * 32; idx += 256) {
+    const int j = idx % (NT * 32);
+    const int col = idx / (NT * 32);     // local output channel
+    if (j >= nj || co0 + col >= d.Cout) continue;
+    const int m = col >> 5, row = col & 31;
+    const int hf = (row >> 2) & 1;
+    const int r = (row & 3) + 4 * (row >> 3);
+    const int t = j >> 5, lj = j & 31;
+    out[(size_t)(co0 + col) * row_len + (size_t)c0 * C::TAPS + j] =
+        red[((m * NT + t) * 16 + r) * 64 + hf * 32 + lj];
+  }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ wsp, float* __restrict__ dw,
+                                    int64_t n, int splits) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += wsp[(size_t)k * n + i];
+    dw[i] = s;
+  }
+}
+
+struct WgPlan {
+  int nt, ckmax, co_tiles, ci_chunks, tiles_w, tiles_h, splits;
+  size_t ws_bytes;
+};
+
+int nt_for(const DlioConvDesc& d) {
+  return (d.KH == 1 && d.KW == 1) ? 2 : 5;
+}
+
+bool make_plan(const DlioConvDesc& d, WgPlan& p) {
+  p.nt = nt_for(d);
+  const int taps = d.KH * d.KW;
+  p.ckmax = (p.nt * 32) / taps;
+  if (p.ckmax < 1) return false;
+  p.co_tiles = cdiv(d.Cout, 64);
+  p.ci_chunks = cdiv(d.Cin, p.ckmax);
+  p.tiles_w = cdiv(d.OW, 32);
+  p.tiles_h = cdiv(d.OH, 4);
+  const int64_t total_tiles = (int64_t)d.N * p.tiles_w * p.tiles_h;
+  int64_t pairs = (int64_t)p.co_tiles * p.ci_chunks;
+  int64_t splits = cdiv64(768, pairs);
+  if (splits > total_tiles) splits = total_tiles;
+  const size_t slab = (size_t)d.Cout * d.Cin * taps * 4;
+  const size_t cap = (size_t)96 << 20;
+  if (splits * slab > cap) splits = (int64_t)(cap / slab);
+  if (splits < 1) splits = 1;
+  p.splits = (int)splits;
+  p.ws_bytes = (size_t)p.splits * slab;
+  return true;
+}
+
+template <int KH, int KW, int SH, int SW, int NT>
+int launch(const float* x, const float* dy, float* dw, const float* in_mean,
+           const float* in_scale, const float* in_shift, float* wsp, const DlioConvDesc& d,
+           const WgPlan& p, hipStream_t s) {
+  using C = WgCfg<KH, KW, SH, SW, NT>;
+  auto kern = conv_wgrad_kernel<KH, KW, SH, SW, NT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+    attr_set = true;
+  }
+  const int blocks = p.co_tiles * p.ci_chunks * p.splits;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), C::LDS_BYTES, s, x, dy, wsp, in_mean,
+                     in_scale, in_shift, d, p.co_tiles, p.ci_chunks, p.splits, p.tiles_w,
+                     p.tiles_h);
+  int rc = dlio_check_launch();
+  if (rc) return rc;
+  const int64_t n = (int64_t)d.Cout * d.Cin * KH * KW;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, s, wsp, dw, n,
+                     p.splits);
+  return dlio_check_launch();
+}
+
+}  // namespace
+
+extern "C" size_t dlio_conv2d_wgrad_ws_bytes(const DlioConvDesc* d) {
+  WgPlan p;
+  if (!d || !make_plan(*d, p)) return 0;
+  return p.ws_bytes;
+}
+
+extern "C" int dlio_conv2d_wgrad(const float* x, const float* dy, float* dw,
+                                 const float* in_mean, const float* in_scale,
+                                 const float* in_shift, void* ws, size_t ws_bytes,
+                                 const DlioConvDesc* dp, dlio_stream_t stream) {
+  if (!x || !dy || !dw || !dp || !ws) return DLIO_EINVAL;
+  const DlioConvDesc& d = *dp;
+  if (in_scale && (!in_mean || !in_shift)) return DLIO_EINVAL;
+  WgPlan p;
+  if (!make_plan(d, p)) return DLIO_EUNSUP;
+  if (ws_bytes < p.ws_bytes) return DLIO_EWS;
+  hipStream_t s = as_stream(stream);
+  float* wsp = reinterpret_cast<float*>(ws);
+  const double flops = 2.0 * d.N * (double)d.OH * d.OW * d.Cout * (double)d.Cin * d.KH * d.KW;
+  const double bytes = 4.0 * d.N * ((double)d.Cin * d.H * d.W + (double)d.Cout * d.OH * d.OW);
+  dlio_prof_begin(1, s, flops, bytes);
+  int rc = DLIO_EUNSUP;
+#define WG_CASE(kh, kw, sh, sw, nt)                                                \
+  if (d.KH == kh && d.KW == kw && d.SH == sh && d.SW == sw)                        \
+    rc = launch<kh, kw, sh, sw, nt>(x, dy, dw, in_mean, in_scale, in_shift, wsp, d, p, s);
+  WG_CASE(1, 1, 1, 1, 2)
+  else WG_CASE(3, 3, 1, 1, 5)
+  else WG_CASE(3, 5, 1, 2, 5)
+  else WG_CASE(3, 5, 1, 1, 5)
+  else WG_CASE(5, 7, 1, 2, 5)
+  else WG_CASE(5, 7, 1, 1, 5)
+  else WG_CASE(3, 3, 2, 2, 5)
+  else WG_CASE(3, 3, 1, 2, 5)
+  else WG_CASE(1, 1, 1, 2, 2)
+  else WG_CASE(1, 1, 2, 2, 2)
+#undef WG_CASE
+  dlio_prof_end(1, s);
+  return rc;
+}

@@ -1,0 +1,342 @@
+// Dense (nn.Linear-shaped) layers with skinny M (M = B*S = 16 on the headline config; the
+// weights, not the activations, are the HBM traffic), activations, dropout and small
+// elementwise helpers.  Weight-streaming kernels: every weight byte is read once per
+// 8/16-row tile of M in 1 KiB wave-wide float4 requests; no atomics, fixed summation
+// order (deterministic).
+//
+// Replaces nn.Linear / F.relu / F.leaky_relu / torch.sigmoid / nn.Dropout at
+// lidar_feat_nets.py:66,94-97, pointseg_modules.py:209-214, imu_feat_nets.py:27-49,
+// fusion_nets.py:59-73, odom_feat_nets.py:18-37, deeplio_nets.py:57-90 and the input /
+// recurrent projections of nn.LSTM / nn.GRU (imu_feat_nets.py:63-70, odom_feat_nets.py:61-68).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float act_fwd(float v, int act) {
+  switch (act) {
+    case 1: return fmaxf(v, 0.f);
+    case 2: return v > 0.f ? v : 0.01f * v;
+    case 3: return 1.0f / (1.0f + expf(-v));
+    case 4: return tanhf(v);
+    default: return v;
+  }
+}
+
+// ---- forward: one wave per output feature n, 8 rows of M per pass -------------
+constexpr int MT = 8;
+
+__global__ __launch_bounds__(256) void linear_fwd_kernel(
+    const float* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ b,
+    const float* __restrict__ addend, int ldadd, float* __restrict__ y, int ldy, int M, int N,
+    int K, int act) {
+  const int lane = threadIdx.x & 63;
+  const int wave_in_blk = threadIdx.x >> 6;
+  const int waves_total = gridDim.x * 4;
+  const bool vec = ((K & 3) == 0) && ((ldx & 3) == 0);
+  for (int n = blockIdx.x * 4 + wave_in_blk; n < N; n += waves_total) {
+    const float* wr = w + (size_t)n * K;
+    const float bv = b ? b[n] : 0.f;
+    for (int m0 = 0; m0 < M; m0 += MT) {
+      float acc[MT];
+#pragma unroll
+      for (int j = 0; j < MT; ++j) acc[j] = 0.f;
+      if (vec) {
+        for (int k = lane * 4; k < K; k += 256) {
+          const float4 wv = *reinterpret_cast<const float4*>(wr + k);
+#pragma unroll
+          for (int j = 0; j < MT; ++j) {
+            if (m0 + j < M) {
+              const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)(m0 + j) * ldx + k);
+              acc[j] += wv.x * xv.x + wv.y * xv.y + wv.z * xv.z + wv.w * xv.w;
+            }
+          }
+        }
+      } else {
+        for (int k = lane; k < K; k += 64) {
+          const float wv = wr[k];
+#pragma unroll
+          for (int j = 0; j < MT; ++j)
+            if (m0 + j < M) acc[j] += wv * x[(size_t)(m0 + j) * ldx + k];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < MT; ++j) acc[j] = wave_sum(acc[j]);
+      if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+          const int m = m0 + j;
+          if (m < M) {
+            float v = acc[j] + bv;
+            if (addend) v += addend[(size_t)m * ldadd + n];
+            y[(size_t)m * ldy + n] = act_fwd(v, act);
+          }
+        }
+      }
+    }
+  }
+}
+
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                               float* __restrict__ dz, int64_t n, int act) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float g = dy[i], o = y[i];
+    float r;
+    switch (act) {
+      case 1: r = o > 0.f ? g : 0.f; break;
+      case 2: r = o > 0.f ? g : 0.01f * g; break;
+      case 3: r = g * o * (1.f - o); break;
+      case 4: r = g * (1.f - o * o); break;
+      default: r = g;
+    }
+    dz[i] = r;
+  }
+}
+
+// ---- data gradient: block = 64 columns of K x all N, 4 waves interleave n --------
+constexpr int BM = 16;
+
+__global__ __launch_bounds__(256) void linear_bwd_data_kernel(
+    const float* __restrict__ dz, int lddz, const float* __restrict__ w, float* __restrict__ dx,
+    int lddx, int M, int N, int K, int accumulate) {
+  __shared__ float red[4][BM][64];
+  const int tx = threadIdx.x & 63;
+  const int ty = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int k = blockIdx.x * 64 + tx;
+  const int m0 = blockIdx.y * BM;
+  float acc[BM];
+#pragma unroll
+  for (int j = 0; j < BM; ++j) acc[j] = 0.f;
+  if (k < K) {
+    for (int n = ty; n < N; n += 4) {
+      const float wv = w[(size_t)n * K + k];
+#pragma unroll
+      for (int j = 0; j < BM; ++j)
+        if (m0 + j < M) acc[j] += dz[(size_t)(m0 + j) * lddz + n] * wv;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < BM; ++j) red[ty][j][tx] = acc[j];
+  __syncthreads();
+  // fixed-order sum of the 4 partials; 256 threads cover BM*64 = 1024 outputs
+  for (int o = threadIdx.x; o < BM * 64; o += 256) {
+    const int j = o >> 6, c = o & 63;
+    const int kk = blockIdx.x * 64 + c, m = m0 + j;
+    if (kk < K && m < M) {
+      float v = ((red[0][j][c] + red[1][j][c]) + red[2][j][c]) + red[3][j][c];
+      float* p = dx + (size_t)m * lddx + kk;
+      *p = accumulate ? *p + v : v;
+    }
+  }
+}
+
+// ---- weight gradient: thread per (4 n, k) --------------------------------------
+__global__ __launch_bounds__(256) void linear_bwd_weight_kernel(
+    const float* __restrict__ dz, int lddz, const float* __restrict__ x, int ldx,
+    float* __restrict__ dw, int M, int N, int K, int accumulate) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int n0 = blockIdx.y * 4;
+  if (k >= K) return;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int m = 0; m < M; ++m) {
+    const float xv = x[(size_t)m * ldx + k];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (n0 + j < N) acc[j] += dz[(size_t)m * lddz + n0 + j] * xv;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (n0 + j < N) {
+      float* p = dw + (size_t)(n0 + j) * K + k;
+      *p = accumulate ? *p + acc[j] : acc[j];
+    }
+  }
+}
+
+__global__ void col_sum_kernel(const float* __restrict__ dz, int lddz, float* __restrict__ db,
+                               int M, int N, int accumulate) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int m = 0; m < M; ++m) s += dz[(size_t)m * lddz + n];
+  db[n] = accumulate ? db[n] + s : s;
+}
+
+__global__ void ew_binary_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                 float* __restrict__ y, int64_t n, int op) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float u = a[i], v = b[i];
+    y[i] = op == 0 ? u + v : (op == 1 ? u - v : u * v);
+  }
+}
+
+__global__ void ew_scale_kernel(const float* __restrict__ a, float alpha, float* __restrict__ y,
+                                int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = alpha * a[i];
+}
+
+__global__ void copy2d_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst,
+                              int ldd, int rows, int cols, int accumulate) {
+  const int64_t total = (int64_t)rows * cols;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+    const float v = src[(size_t)r * lds + c];
+    float* p = dst + (size_t)r * ldd + c;
+    *p = accumulate ? *p + v : v;
+  }
+}
+
+// Philox4x32-10 (Salmon et al. 2011), counter = (offset + i/4), key = seed
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+__global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                   uint8_t* __restrict__ mask, int64_t n, float p, uint64_t seed,
+                                   uint64_t offset) {
+  const float inv = 1.0f / (1.0f - p);
+  const int64_t groups = (n + 3) >> 2;
+  for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < groups;
+       g += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t ctr = offset + (uint64_t)g;
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t i = g * 4 + j;
+      if (i < n) {
+        const float u = (float)(c[j] >> 8) * (1.0f / 16777216.0f);  // [0,1)
+        const uint8_t keep = u >= p ? 1 : 0;
+        mask[i] = keep;
+        y[i] = keep ? x[i] * inv : 0.f;
+      }
+    }
+  }
+}
+
+__global__ void dropout_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ mask,
+                                   float* __restrict__ dx, int64_t n, float p) {
+  const float inv = 1.0f / (1.0f - p);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    dx[i] = mask[i] ? dy[i] * inv : 0.f;
+}
+
+__global__ void nonfinite_kernel(const float* __restrict__ x, int64_t n, int32_t* flag) {
+  bool bad = false;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    bad |= !(fabsf(v) <= 3.402823466e38f);  // NaN or Inf
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+}  // namespace
+
+extern "C" int dlio_linear_fwd(const float* x, int ldx, const float* w, const float* b,
+                               const float* addend, int ldadd, float* y, int ldy, int M, int N,
+                               int K, int act, dlio_stream_t stream) {
+  if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0 || ldx < K || ldy < N || act < 0 || act > 4)
+    return DLIO_EINVAL;
+  int grid = cdiv(N, 4);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, ldx, w, b,
+                     addend, ldadd, y, ldy, M, N, K, act);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_act_bwd(const float* dy, const float* y, float* dz, int64_t n, int act,
+                            dlio_stream_t stream) {
+  if (!dy || !y || !dz || n <= 0 || act < 0 || act > 4) return DLIO_EINVAL;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, as_stream(stream), dy, y,
+                     dz, n, act);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_linear_bwd_data(const float* dz, int lddz, const float* w, float* dx, int lddx,
+                                    int M, int N, int K, int accumulate, dlio_stream_t stream) {
+  if (!dz || !w || !dx || M <= 0 || N <= 0 || K <= 0 || lddz < N || lddx < K) return DLIO_EINVAL;
+  hipLaunchKernelGGL(linear_bwd_data_kernel, dim3(cdiv(K, 64), cdiv(M, BM)), dim3(256), 0,
+                     as_stream(stream), dz, lddz, w, dx, lddx, M, N, K, accumulate);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_linear_bwd_weight(const float* dz, int lddz, const float* x, int ldx,
+                                      float* dw, float* db, int M, int N, int K, int accumulate,
+                                      dlio_stream_t stream) {
+  if (!dz || !x || !dw || M <= 0 || N <= 0 || K <= 0 || lddz < N || ldx < K) return DLIO_EINVAL;
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(linear_bwd_weight_kernel, dim3(cdiv(K, 256), cdiv(N, 4)), dim3(256), 0, s, dz,
+                     lddz, x, ldx, dw, M, N, K, accumulate);
+  int rc = dlio_check_launch();
+  if (rc) return rc;
+  if (db) {
+    hipLaunchKernelGGL(col_sum_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, dz, lddz, db, M, N,
+                       accumulate);
+    rc = dlio_check_launch();
+  }
+  return rc;
+}
+
+extern "C" int dlio_ew_binary(const float* a, const float* b, float* y, int64_t n, int op,
+                              dlio_stream_t stream) {
+  if (!a || !b || !y || n <= 0 || op < 0 || op > 2) return DLIO_EINVAL;
+  hipLaunchKernelGGL(ew_binary_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, as_stream(stream), a,
+                     b, y, n, op);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_ew_scale(const float* a, float alpha, float* y, int64_t n,
+                             dlio_stream_t stream) {
+  if (!a || !y || n <= 0) return DLIO_EINVAL;
+  hipLaunchKernelGGL(ew_scale_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, as_stream(stream), a,
+                     alpha, y, n);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_copy2d(const float* src, int lds, float* dst, int ldd, int rows, int cols,
+                           int accumulate, dlio_stream_t stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0 || lds < cols || ldd < cols) return DLIO_EINVAL;
+  hipLaunchKernelGGL(copy2d_kernel, dim3(ew_grid((int64_t)rows * cols, 256)), dim3(256), 0,
+                     as_stream(stream), src, lds, dst, ldd, rows, cols, accumulate);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_dropout_fwd(const float* x, float* y, uint8_t* mask, int64_t n, float p,
+                                uint64_t seed, uint64_t offset, dlio_stream_t stream) {
+  if (!x || !y || !mask || n <= 0 || !(p >= 0.f && p < 1.f)) return DLIO_EINVAL;
+  hipLaunchKernelGGL(dropout_fwd_kernel, dim3(ew_grid((n + 3) / 4, 256)), dim3(256), 0,
+                     as_stream(stream), x, y, mask, n, p, seed, offset);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, int64_t n,
+                                float p, dlio_stream_t stream) {
+  if (!dy || !mask || !dx || n <= 0 || !(p >= 0.f && p < 1.f)) return DLIO_EINVAL;
+  hipLaunchKernelGGL(dropout_bwd_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, as_stream(stream),
+                     dy, mask, dx, n, p);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_nonfinite_flag(const float* x, int64_t n, int32_t* flag,
+                                   dlio_stream_t stream) {
+  if (!x || !flag || n <= 0) return DLIO_EINVAL;
+  hipLaunchKernelGGL(nonfinite_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, as_stream(stream), x,
+                     n, flag);
+  return dlio_check_launch();
+}

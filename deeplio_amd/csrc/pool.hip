@@ -1,0 +1,204 @@
+// Max pooling (3x3, floor or ceil output size, ATen "first max wins" tie rule), global
+// average pooling and the SELayer channel re-weighting.  HBM-bound streaming kernels.
+//
+// Replaces nn.MaxPool2d at pointseg_net.py:21-46, resnet.py:40, lidar_feat_nets.py:281-299;
+// adaptive_avg_pool2d at lidar_feat_nets.py:84-85,258, resnet.py:49, pointseg_modules.py:218;
+// the SELayer product pointseg_modules.py:220.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ xs, float* __restrict__ y,
+    uint8_t* __restrict__ idx, int N, int C, int H, int W, int OH, int OW, int K, int SH, int SW,
+    int PH, int PW) {
+  const int64_t total = (int64_t)N * C * OH * OW;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int ow = (int)(i % OW);
+    int64_t t = i / OW;
+    const int oh = (int)(t % OH);
+    const int64_t pl = t / OH;
+    const float* xp = x + (size_t)pl * H * W;
+    const float s = xs ? xs[pl] : 1.f;
+    float best = -INFINITY;
+    int bi = 0;
+    bool first = true;
+    for (int ky = 0; ky < K; ++ky) {
+      const int ih = oh * SH - PH + ky;
+      if (ih < 0 || ih >= H) continue;
+      for (int kx = 0; kx < K; ++kx) {
+        const int iw = ow * SW - PW + kx;
+        if (iw < 0 || iw >= W) continue;
+        float v = xp[(size_t)ih * W + iw];
+        if (xs) v *= s;
+        if (first || v > best || v != v) { best = v; bi = ky * K + kx; first = false; }
+      }
+    }
+    y[i] = best;
+    if (idx) idx[i] = (uint8_t)bi;
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(
+    const float* __restrict__ dy, const uint8_t* __restrict__ idx, const float* __restrict__ xs,
+    float* __restrict__ dx, int N, int C, int H, int W, int OH, int OW, int K, int SH, int SW,
+    int PH, int PW) {
+  const int64_t total = (int64_t)N * C * H * W;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int iw = (int)(i % W);
+    int64_t t = i / W;
+    const int ih = (int)(t % H);
+    const int64_t pl = t / H;
+    const float* dyp = dy + (size_t)pl * OH * OW;
+    const uint8_t* ip = idx + (size_t)pl * OH * OW;
+    // windows covering (ih, iw): oh*SH - PH <= ih <= oh*SH - PH + K - 1
+    int oh_lo = ih + PH - K + 1;
+    oh_lo = oh_lo <= 0 ? 0 : (oh_lo + SH - 1) / SH;
+    int oh_hi = (ih + PH) / SH;
+    if (oh_hi > OH - 1) oh_hi = OH - 1;
+    int ow_lo = iw + PW - K + 1;
+    ow_lo = ow_lo <= 0 ? 0 : (ow_lo + SW - 1) / SW;
+    int ow_hi = (iw + PW) / SW;
+    if (ow_hi > OW - 1) ow_hi = OW - 1;
+    float g = 0.f;
+    for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+      const int ky = ih + PH - oh * SH;
+      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+        const int kx = iw + PW - ow * SW;
+        if (ip[(size_t)oh * OW + ow] == (uint8_t)(ky * K + kx)) g += dyp[(size_t)oh * OW + ow];
+      }
+    }
+    if (xs) g *= xs[pl];
+    dx[i] = g;
+  }
+}
+
+// one block per (n, c) plane
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const float* __restrict__ x, int ctot,
+                                                      int coff, float* __restrict__ out, int N,
+                                                      int C, int HW) {
+  __shared__ double sm[16];
+  for (int pl = blockIdx.x; pl < N * C; pl += gridDim.x) {
+    const int n = pl / C, c = pl - n * C;
+    const float* xp = x + ((size_t)n * ctot + coff + c) * HW;
+    double s = 0.0;
+    if ((HW & 3) == 0) {
+      for (int i = threadIdx.x; i < (HW >> 2); i += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(xp + ((size_t)i << 2));
+        s += (double)((v.x + v.y) + (v.z + v.w));
+      }
+    } else {
+      for (int i = threadIdx.x; i < HW; i += 256) s += xp[i];
+    }
+    const double r = block_sum_d(s, sm);
+    if (threadIdx.x == 0) out[pl] = (float)(r / (double)HW);
+  }
+}
+
+__global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ dout,
+                                                      float* __restrict__ dx, int64_t planes,
+                                                      int HW, int accumulate) {
+  const int64_t total = planes * HW;
+  const float inv = 1.0f / (float)HW;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float g = dout[i / HW] * inv;
+    dx[i] = accumulate ? dx[i] + g : g;
+  }
+}
+
+__global__ __launch_bounds__(256) void chan_scale_fwd_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ s,
+                                                             float* __restrict__ y,
+                                                             int64_t planes, int HW) {
+  const int64_t total = planes * HW;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = x[i] * s[i / HW];
+}
+
+// one block per plane: dx = dy*s, ds = sum dy*x
+__global__ __launch_bounds__(256) void chan_scale_bwd_kernel(const float* __restrict__ dy,
+                                                             const float* __restrict__ x,
+                                                             const float* __restrict__ s,
+                                                             float* __restrict__ dx,
+                                                             float* __restrict__ ds, int planes,
+                                                             int HW) {
+  __shared__ double sm[16];
+  for (int pl = blockIdx.x; pl < planes; pl += gridDim.x) {
+    const float sv = s[pl];
+    const float* gp = dy + (size_t)pl * HW;
+    const float* xp = x + (size_t)pl * HW;
+    float* op = dx + (size_t)pl * HW;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+      const float g = gp[i];
+      acc += (double)(g * xp[i]);
+      op[i] = g * sv;
+    }
+    const double r = block_sum_d(acc, sm);
+    if (threadIdx.x == 0) ds[pl] = (float)r;
+  }
+}
+
+}  // namespace
+
+extern "C" int dlio_maxpool2d_fwd(const float* x, const float* x_scale, float* y, uint8_t* idx,
+                                  int N, int C, int H, int W, int OH, int OW, int K, int SH,
+                                  int SW, int PH, int PW, dlio_stream_t stream) {
+  if (!x || !y || N <= 0 || C <= 0 || K <= 0 || K > 15) return DLIO_EINVAL;
+  const int64_t total = (int64_t)N * C * OH * OW;
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(total, 256)), dim3(256), 0,
+                     as_stream(stream), x, x_scale, y, idx, N, C, H, W, OH, OW, K, SH, SW, PH, PW);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_maxpool2d_bwd(const float* dy, const uint8_t* idx, const float* x_scale,
+                                  float* dx, int N, int C, int H, int W, int OH, int OW, int K,
+                                  int SH, int SW, int PH, int PW, dlio_stream_t stream) {
+  if (!dy || !idx || !dx || N <= 0 || C <= 0 || K <= 0) return DLIO_EINVAL;
+  const int64_t total = (int64_t)N * C * H * W;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(total, 256)), dim3(256), 0,
+                     as_stream(stream), dy, idx, x_scale, dx, N, C, H, W, OH, OW, K, SH, SW, PH, PW);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_gap_fwd(const float* x, int ctot, int coff, float* out, int N, int C, int HW,
+                            dlio_stream_t stream) {
+  if (!x || !out || N <= 0 || C <= 0 || HW <= 0) return DLIO_EINVAL;
+  int grid = N * C;
+  if (grid > 65535) grid = 65535;
+  hipLaunchKernelGGL(gap_fwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, ctot, coff,
+                     out, N, C, HW);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_gap_bwd(const float* dout, float* dx, int N, int C, int HW, int accumulate,
+                            dlio_stream_t stream) {
+  if (!dout || !dx || N <= 0 || C <= 0 || HW <= 0) return DLIO_EINVAL;
+  const int64_t total = (int64_t)N * C * HW;
+  hipLaunchKernelGGL(gap_bwd_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, as_stream(stream),
+                     dout, dx, (int64_t)N * C, HW, accumulate);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_chan_scale_fwd(const float* x, const float* s, float* y, int N, int C, int HW,
+                                   dlio_stream_t stream) {
+  if (!x || !s || !y || N <= 0 || C <= 0 || HW <= 0) return DLIO_EINVAL;
+  const int64_t total = (int64_t)N * C * HW;
+  hipLaunchKernelGGL(chan_scale_fwd_kernel, dim3(ew_grid(total, 256)), dim3(256), 0,
+                     as_stream(stream), x, s, y, (int64_t)N * C, HW);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_chan_scale_bwd(const float* dy, const float* x, const float* s, float* dx,
+                                   float* ds, int N, int C, int HW, dlio_stream_t stream) {
+  if (!dy || !x || !s || !dx || !ds || N <= 0 || C <= 0 || HW <= 0) return DLIO_EINVAL;
+  int grid = N * C;
+  if (grid > 65535) grid = 65535;
+  hipLaunchKernelGGL(chan_scale_bwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream), dy, x, s,
+                     dx, ds, N * C, HW);
+  return dlio_check_launch();
+}

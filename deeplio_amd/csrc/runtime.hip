@@ -1,0 +1,81 @@
+// Library info, error strings, and the optional per-launch hipEvent profiler used by
+// bench.py's roofline leg (events are recorded on the launch stream, so the measured
+// interval is the kernel's own duration).
+#include "common.h"
+#include <mutex>
+#include <vector>
+
+namespace {
+struct ProfKind {
+  std::vector<hipEvent_t> start, stop;
+  size_t used = 0;
+  double flops = 0.0, bytes = 0.0;
+};
+ProfKind g_prof[4];
+bool g_prof_on = false;
+std::mutex g_mu;
+}  // namespace
+
+void dlio_prof_begin(int kind, hipStream_t s, double flops, double bytes) {
+  if (!g_prof_on || kind < 0 || kind >= 4) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  ProfKind& k = g_prof[kind];
+  if (k.used == k.start.size()) {
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    k.start.push_back(a);
+    k.stop.push_back(b);
+  }
+  hipEventRecord(k.start[k.used], s);
+  k.flops += flops;
+  k.bytes += bytes;
+}
+
+void dlio_prof_end(int kind, hipStream_t s) {
+  if (!g_prof_on || kind < 0 || kind >= 4) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  ProfKind& k = g_prof[kind];
+  hipEventRecord(k.stop[k.used], s);
+  k.used++;
+}
+
+extern "C" int dlio_prof_enable(int on) {
+  g_prof_on = on != 0;
+  return DLIO_OK;
+}
+
+extern "C" int dlio_prof_reset(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto& k : g_prof) { k.used = 0; k.flops = 0.0; k.bytes = 0.0; }
+  return DLIO_OK;
+}
+
+extern "C" int dlio_prof_collect(int kind, double* ms, double* flops, double* bytes,
+                                 int64_t* launches) {
+  if (kind < 0 || kind >= 4 || !ms || !flops || !bytes || !launches) return DLIO_EINVAL;
+  std::lock_guard<std::mutex> lk(g_mu);
+  ProfKind& k = g_prof[kind];
+  double total = 0.0;
+  for (size_t i = 0; i < k.used; ++i) {
+    if (hipEventSynchronize(k.stop[i]) != hipSuccess) return DLIO_ELAUNCH;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, k.start[i], k.stop[i]) != hipSuccess) return DLIO_ELAUNCH;
+    total += t;
+  }
+  *ms = total; *flops = k.flops; *bytes = k.bytes; *launches = (int64_t)k.used;
+  return DLIO_OK;
+}
+
+extern "C" int dlio_version(void) { return 100; }
+extern "C" const char* dlio_arch(void) { return "gfx950"; }
+extern "C" const char* dlio_strerror(int code) {
+  switch (code) {
+    case DLIO_OK: return "ok";
+    case DLIO_EINVAL: return "invalid argument (shape / null pointer)";
+    case DLIO_EUNSUP: return "unsupported configuration";
+    case DLIO_ELAUNCH: return "HIP launch/runtime error";
+    case DLIO_EWS: return "workspace too small";
+    default: return "unknown error";
+  }
+}

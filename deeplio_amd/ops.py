@@ -1,0 +1,439 @@
+"""Thin tensor-level wrappers over the C-ABI (no autograd, no math): they extract device
+pointers from torch storage, pass the current HIP stream, own the scratch workspace and
+translate status codes.  torch is used here only for device memory and streams.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check, lib
+
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, dtype=torch.float32):
+    if not t.is_cuda:
+        raise RuntimeError("deeplio_amd ops need HIP device tensors (got %s); there is no CPU "
+                           "fallback" % t.device)
+    if t.dtype != dtype:
+        raise ValueError("expected %s tensor, got %s" % (dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("expected a contiguous tensor")
+    return t
+
+
+_WS = {}
+
+
+def workspace(nbytes, device, slot=0):
+    """Caller-owned scratch handed to the library (grown geometrically, reused).  One slot
+    per (device, stream, slot) so concurrent streams never share scratch."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream().cuda_stream, slot)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        size = max(int(nbytes * 1.25), 1 << 20)
+        buf = torch.empty(size, dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+# ----------------------------------------------------------------------------- conv
+def conv_desc(N, Cin, H, W, Cout, KH, KW, SH, SW, PH, PW, OH=None, OW=None, in_ctot=None,
+              in_coff=0, out_ctot=None, out_coff=0, res_ctot=0, res_coff=0, in_relu=0):
+    if OH is None:
+        OH = (H + 2 * PH - KH) // SH + 1
+    if OW is None:
+        OW = (W + 2 * PW - KW) // SW + 1
+    d = ConvDesc()
+    d.N, d.Cin, d.H, d.W = N, Cin, H, W
+    d.in_ctot, d.in_coff = (Cin if in_ctot is None else in_ctot), in_coff
+    d.Cout, d.OH, d.OW = Cout, OH, OW
+    d.out_ctot, d.out_coff = (Cout if out_ctot is None else out_ctot), out_coff
+    d.KH, d.KW, d.SH, d.SW, d.PH, d.PW = KH, KW, SH, SW, PH, PW
+    d.res_ctot, d.res_coff, d.in_relu = res_ctot, res_coff, in_relu
+    return d
+
+
+def conv2d_prep_weight(w, mode, out=None):
+    _chk(w)
+    Cout, Cin, KH, KW = w.shape
+    if out is None:
+        out = torch.empty(KH * KW * Cin * Cout, dtype=torch.float32, device=w.device)
+    check(lib.dlio_conv2d_prep_weight(_ptr(w), _ptr(out), Cout, Cin, KH, KW, mode, _stream()),
+          "conv2d_prep_weight")
+    return out
+
+
+def conv2d_fwd(x, wt, bias, y, desc, in_aff=None, residual=None):
+    """in_aff = (mean, scale, shift) per input channel or None."""
+    m = s = b = None
+    if in_aff is not None:
+        m, s, b = in_aff
+    check(lib.dlio_conv2d_fwd(_ptr(x), _ptr(wt), _ptr(bias), _ptr(m), _ptr(s), _ptr(b),
+                              _ptr(residual), _ptr(y), C.byref(desc), _stream()), "conv2d_fwd")
+    return y
+
+
+def conv2d_dgrad_strided(dy, w, dx, desc):
+    check(lib.dlio_conv2d_dgrad_strided(_ptr(dy), _ptr(w), _ptr(dx), C.byref(desc), _stream()),
+          "conv2d_dgrad_strided")
+    return dx
+
+
+def conv2d_wgrad(x, dy, dw, desc, in_aff=None):
+    m = s = b = None
+    if in_aff is not None:
+        m, s, b = in_aff
+    nbytes = lib.dlio_conv2d_wgrad_ws_bytes(C.byref(desc))
+    ws = workspace(nbytes, x.device)
+    check(lib.dlio_conv2d_wgrad(_ptr(x), _ptr(dy), _ptr(dw), _ptr(m), _ptr(s), _ptr(b), _ptr(ws),
+                                ws.numel(), C.byref(desc), _stream()), "conv2d_wgrad")
+    return dw
+
+
+# ----------------------------------------------------------------------------- batch norm
+def _stats_ws(N, C_, HW, device):
+    nbytes = lib.dlio_chan_stats_ws_bytes(N, C_, HW)
+    return workspace(nbytes, device, slot=1)
+
+
+def chan_stats(x, N, ctot, coff, C_, HW, pre_relu=False):
+    s = torch.empty(2, C_, dtype=torch.float64, device=x.device)
+    ws = _stats_ws(N, C_, HW, x.device)
+    check(lib.dlio_chan_stats(_ptr(x), N, ctot, coff, C_, HW, int(pre_relu), _ptr(s[0]), _ptr(s[1]),
+                              _ptr(ws), ws.numel(), _stream()), "chan_stats")
+    return s
+
+
+def bn_finalize(stats, count, gamma, eps, momentum, running_mean, running_var):
+    """-> params [3][C]: mean, invstd, scale"""
+    C_ = stats.shape[1]
+    prm = torch.empty(3, C_, dtype=torch.float32, device=stats.device)
+    check(lib.dlio_bn_finalize(_ptr(stats[0]), _ptr(stats[1]), C_, float(count), _ptr(gamma),
+                               float(eps), float(momentum), _ptr(running_mean), _ptr(running_var),
+                               _ptr(prm[0]), _ptr(prm[1]), _ptr(prm[2]), _stream()), "bn_finalize")
+    return prm
+
+
+def bn_eval_params(running_mean, running_var, gamma, eps):
+    C_ = running_mean.numel()
+    prm = torch.empty(3, C_, dtype=torch.float32, device=running_mean.device)
+    check(lib.dlio_bn_eval_params(_ptr(running_mean), _ptr(running_var), _ptr(gamma), float(eps),
+                                  C_, _ptr(prm[0]), _ptr(prm[1]), _ptr(prm[2]), _stream()),
+          "bn_eval_params")
+    return prm
+
+
+def bn_apply(x, x_ctot, x_coff, prm, beta, y, y_ctot, y_coff, N, C_, HW, pre_relu, post_relu,
+             residual=None, r_ctot=0, r_coff=0):
+    check(lib.dlio_bn_apply(_ptr(x), x_ctot, x_coff, _ptr(prm[0]), _ptr(prm[2]), _ptr(beta),
+                            _ptr(residual), r_ctot, r_coff, _ptr(y), y_ctot, y_coff, N, C_, HW,
+                            int(pre_relu), int(post_relu), _stream()), "bn_apply")
+    return y
+
+
+def bn_bwd(dy, dy_ctot, dy_coff, x, x_ctot, x_coff, prm, beta, dx, dx_ctot, dx_coff, N, C_, HW,
+           pre_relu, post_relu, use_batch_stats, dgamma=None, dbeta=None):
+    sums = torch.empty(2, C_, dtype=torch.float64, device=x.device)
+    ws = _stats_ws(N, C_, HW, x.device)
+    check(lib.dlio_bn_bwd_reduce(_ptr(dy), dy_ctot, dy_coff, _ptr(x), x_ctot, x_coff, _ptr(prm[0]),
+                                 _ptr(prm[1]), _ptr(prm[2]), _ptr(beta), N, C_, HW, int(pre_relu),
+                                 int(post_relu), _ptr(sums[0]), _ptr(sums[1]), _ptr(ws), ws.numel(),
+                                 _stream()), "bn_bwd_reduce")
+    check(lib.dlio_bn_bwd_apply(_ptr(dy), dy_ctot, dy_coff, _ptr(x), x_ctot, x_coff, _ptr(prm[0]),
+                                _ptr(prm[1]), _ptr(prm[2]), _ptr(beta), _ptr(sums[0]),
+                                _ptr(sums[1]), _ptr(dx), dx_ctot, dx_coff, _ptr(dgamma), _ptr(dbeta),
+                                N, C_, HW, int(pre_relu), int(post_relu), int(use_batch_stats),
+                                _stream()), "bn_bwd_apply")
+    return dx
+
+
+def chan_sum(x, N, ctot, coff, C_, HW, out=None):
+    if out is None:
+        out = torch.empty(C_, dtype=torch.float32, device=x.device)
+    ws = _stats_ws(N, C_, HW, x.device)
+    check(lib.dlio_chan_sum(_ptr(x), N, ctot, coff, C_, HW, _ptr(out), _ptr(ws), ws.numel(),
+                            _stream()), "chan_sum")
+    return out
+
+
+# ----------------------------------------------------------------------------- pooling
+def pool_out(size, k, s, p, ceil_mode):
+    if ceil_mode:
+        o = -(-(size + 2 * p - k) // s) + 1
+        if (o - 1) * s >= size + p:  # last window must start inside input or left padding
+            o -= 1
+        return o
+    return (size + 2 * p - k) // s + 1
+
+
+def maxpool2d_fwd(x, k, sh, sw, ph, pw, ceil_mode=False, x_scale=None, want_idx=True):
+    N, C_, H, W = x.shape
+    OH, OW = pool_out(H, k, sh, ph, ceil_mode), pool_out(W, k, sw, pw, ceil_mode)
+    y = torch.empty(N, C_, OH, OW, dtype=torch.float32, device=x.device)
+    idx = torch.empty(N, C_, OH, OW, dtype=torch.uint8, device=x.device) if want_idx else None
+    check(lib.dlio_maxpool2d_fwd(_ptr(x), _ptr(x_scale), _ptr(y), _ptr(idx), N, C_, H, W, OH, OW, k,
+                                 sh, sw, ph, pw, _stream()), "maxpool2d_fwd")
+    return y, idx
+
+
+def maxpool2d_bwd(dy, idx, in_shape, k, sh, sw, ph, pw, x_scale=None):
+    N, C_, H, W = in_shape
+    OH, OW = dy.shape[2], dy.shape[3]
+    dx = torch.empty(N, C_, H, W, dtype=torch.float32, device=dy.device)
+    check(lib.dlio_maxpool2d_bwd(_ptr(dy), _ptr(idx), _ptr(x_scale), _ptr(dx), N, C_, H, W, OH, OW,
+                                 k, sh, sw, ph, pw, _stream()), "maxpool2d_bwd")
+    return dx
+
+
+def gap_fwd(x, N, ctot, coff, C_, HW):
+    out = torch.empty(N, C_, dtype=torch.float32, device=x.device)
+    check(lib.dlio_gap_fwd(_ptr(x), ctot, coff, _ptr(out), N, C_, HW, _stream()), "gap_fwd")
+    return out
+
+
+def gap_bwd(dout, dx, N, C_, HW, accumulate=False):
+    check(lib.dlio_gap_bwd(_ptr(dout), _ptr(dx), N, C_, HW, int(accumulate), _stream()), "gap_bwd")
+    return dx
+
+
+def chan_scale_fwd(x, s, y=None):
+    N, C_, H, W = x.shape
+    if y is None:
+        y = torch.empty_like(x)
+    check(lib.dlio_chan_scale_fwd(_ptr(x), _ptr(s), _ptr(y), N, C_, H * W, _stream()),
+          "chan_scale_fwd")
+    return y
+
+
+def chan_scale_bwd(dy, x, s):
+    N, C_, H, W = x.shape
+    dx = torch.empty_like(x)
+    ds = torch.empty(N, C_, dtype=torch.float32, device=x.device)
+    check(lib.dlio_chan_scale_bwd(_ptr(dy), _ptr(x), _ptr(s), _ptr(dx), _ptr(ds), N, C_, H * W,
+                                  _stream()), "chan_scale_bwd")
+    return dx, ds
+
+
+# ----------------------------------------------------------------------------- dense
+def linear_fwd(x, w, b, act=ACT_NONE, addend=None, out=None, M=None, ldx=None, ldadd=0, ldy=None):
+    N_, K = w.shape
+    if M is None:
+        M = x.numel() // K
+    if ldx is None:
+        ldx = K
+    if out is None:
+        out = torch.empty(M, N_, dtype=torch.float32, device=x.device)
+    if ldy is None:
+        ldy = N_
+    if addend is not None and ldadd == 0:
+        ldadd = N_
+    check(lib.dlio_linear_fwd(_ptr(x), ldx, _ptr(w), _ptr(b), _ptr(addend), ldadd, _ptr(out), ldy,
+                              M, N_, K, act, _stream()), "linear_fwd")
+    return out
+
+
+def act_bwd(dy, y, act, out=None):
+    if out is None:
+        out = torch.empty_like(dy)
+    check(lib.dlio_act_bwd(_ptr(dy), _ptr(y), _ptr(out), dy.numel(), act, _stream()), "act_bwd")
+    return out
+
+
+def linear_bwd_data(dz, w, M, out=None, lddz=None, lddx=None, accumulate=False):
+    N_, K = w.shape
+    if out is None:
+        out = torch.empty(M, K, dtype=torch.float32, device=dz.device)
+    check(lib.dlio_linear_bwd_data(_ptr(dz), N_ if lddz is None else lddz, _ptr(w), _ptr(out),
+                                   K if lddx is None else lddx, M, N_, K, int(accumulate),
+                                   _stream()), "linear_bwd_data")
+    return out
+
+
+def linear_bwd_weight(dz, x, M, N_, K, dw=None, db=None, want_bias=True, lddz=None, ldx=None,
+                      accumulate=False):
+    if dw is None:
+        dw = torch.empty(N_, K, dtype=torch.float32, device=dz.device)
+    if db is None and want_bias:
+        db = torch.empty(N_, dtype=torch.float32, device=dz.device)
+    check(lib.dlio_linear_bwd_weight(_ptr(dz), N_ if lddz is None else lddz, _ptr(x),
+                                     K if ldx is None else ldx, _ptr(dw), _ptr(db), M, N_, K,
+                                     int(accumulate), _stream()), "linear_bwd_weight")
+    return dw, db
+
+
+def ew_binary(a, b, op, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    check(lib.dlio_ew_binary(_ptr(a), _ptr(b), _ptr(out), a.numel(), op, _stream()), "ew_binary")
+    return out
+
+
+def ew_scale(a, alpha, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    check(lib.dlio_ew_scale(_ptr(a), float(alpha), _ptr(out), a.numel(), _stream()), "ew_scale")
+    return out
+
+
+def copy2d(src, lds, dst, ldd, rows, cols, accumulate=False, src_off=0, dst_off=0):
+    sp = C.c_void_p(src.data_ptr() + 4 * src_off)
+    dp = C.c_void_p(dst.data_ptr() + 4 * dst_off)
+    check(lib.dlio_copy2d(sp, lds, dp, ldd, rows, cols, int(accumulate), _stream()), "copy2d")
+    return dst
+
+
+def dropout_fwd(x, p, seed, offset):
+    y = torch.empty_like(x)
+    mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    check(lib.dlio_dropout_fwd(_ptr(x), _ptr(y), _ptr(mask), x.numel(), float(p), int(seed),
+                               int(offset), _stream()), "dropout_fwd")
+    return y, mask
+
+
+def dropout_bwd(dy, mask, p):
+    dx = torch.empty_like(dy)
+    check(lib.dlio_dropout_bwd(_ptr(dy), _ptr(mask), _ptr(dx), dy.numel(), float(p), _stream()),
+          "dropout_bwd")
+    return dx
+
+
+def nonfinite_flag(x, flag):
+    check(lib.dlio_nonfinite_flag(_ptr(x), x.numel(), _ptr(flag), _stream()), "nonfinite_flag")
+
+
+# ----------------------------------------------------------------------------- rnn
+def _rnn_ws(T, B, H, device):
+    return workspace(lib.dlio_rnn_ws_bytes(T, B, H), device, slot=2)
+
+
+def _off(t, off_floats):
+    return C.c_void_p(t.data_ptr() + 4 * off_floats)
+
+
+def lstm_seq_fwd(gx, w_hh, b_hh, h0, c0, hs, hs_off, ldhs, cs, hp, gates, hT, cT, T, B, H, rst,
+                 rsb, reverse):
+    ws = _rnn_ws(T, B, H, gx.device)
+    check(lib.dlio_lstm_seq_fwd(_ptr(gx), _ptr(w_hh), _ptr(b_hh), _ptr(h0), _ptr(c0),
+                                _off(hs, hs_off), ldhs, _ptr(cs), _ptr(hp), _ptr(gates), _ptr(hT),
+                                _ptr(cT), T, B, H, rst, rsb, int(reverse), _ptr(ws), ws.numel(),
+                                _stream()), "lstm_seq_fwd")
+
+
+def lstm_seq_bwd(dhs, dhs_off, lddhs, dhT, dcT, gates, cs, c0, w_hh, dgates, dh0, dc0, T, B, H,
+                 rst, rsb, reverse):
+    ws = _rnn_ws(T, B, H, gates.device)
+    dp = None if dhs is None else _off(dhs, dhs_off)
+    check(lib.dlio_lstm_seq_bwd(dp, lddhs, _ptr(dhT), _ptr(dcT), _ptr(gates), _ptr(cs), _ptr(c0),
+                                _ptr(w_hh), _ptr(dgates), _ptr(dh0), _ptr(dc0), T, B, H, rst, rsb,
+                                int(reverse), _ptr(ws), ws.numel(), _stream()), "lstm_seq_bwd")
+
+
+def gru_seq_fwd(gx, w_hh, b_hh, h0, hs, hs_off, ldhs, hp, gates, hT, T, B, H, rst, rsb, reverse):
+    ws = _rnn_ws(T, B, H, gx.device)
+    check(lib.dlio_gru_seq_fwd(_ptr(gx), _ptr(w_hh), _ptr(b_hh), _ptr(h0), _off(hs, hs_off), ldhs,
+                               _ptr(hp), _ptr(gates), _ptr(hT), T, B, H, rst, rsb, int(reverse),
+                               _ptr(ws), ws.numel(), _stream()), "gru_seq_fwd")
+
+
+def gru_seq_bwd(dhs, dhs_off, lddhs, dhT, gates, hp, w_hh, dgx, dgh, dh0, T, B, H, rst, rsb,
+                reverse):
+    ws = _rnn_ws(T, B, H, gates.device)
+    dp = None if dhs is None else _off(dhs, dhs_off)
+    check(lib.dlio_gru_seq_bwd(dp, lddhs, _ptr(dhT), _ptr(gates), _ptr(hp), _ptr(w_hh), _ptr(dgx),
+                               _ptr(dgh), _ptr(dh0), T, B, H, rst, rsb, int(reverse), _ptr(ws),
+                               ws.numel(), _stream()), "gru_seq_bwd")
+
+
+# ----------------------------------------------------------------------------- pose
+def se3_chain_fwd(t, w, order=0, status=None):
+    B, S, _ = t.shape
+    p = torch.empty(B, S, 3, dtype=torch.float32, device=t.device)
+    q = torch.empty(B, S, 4, dtype=torch.float32, device=t.device)
+    R = torch.empty(B, S, 9, dtype=torch.float32, device=t.device)
+    check(lib.dlio_se3_chain_fwd(_ptr(t), _ptr(w), _ptr(p), _ptr(q), _ptr(R), _ptr(status), B, S,
+                                 order, _stream()), "se3_chain_fwd")
+    return p, q, R
+
+
+def se3_chain_bwd(t, w, R, dp, dq, order=0):
+    B, S, _ = t.shape
+    dt = torch.empty_like(t)
+    dw = torch.empty_like(w)
+    check(lib.dlio_se3_chain_bwd(_ptr(t), _ptr(w), _ptr(R), _ptr(dp), _ptr(dq), _ptr(dt), _ptr(dw),
+                                 B, S, order, _stream()), "se3_chain_bwd")
+    return dt, dw
+
+
+def _ptr_array(ts):
+    arr = (C.c_void_p * 4)()
+    for i, t in enumerate(ts):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+def pose_loss_fwd(preds, gts, sx, sq, beta, mode):
+    n = (C.c_int32 * 4)(*[0 if p is None else p.numel() for p in preds])
+    dev = next(p for p in preds if p is not None).device
+    out = torch.empty(5, dtype=torch.float32, device=dev)
+    check(lib.dlio_pose_loss_fwd(_ptr_array(preds), _ptr_array(gts), n, _ptr(sx), _ptr(sq),
+                                 float(beta), mode, _ptr(out), _stream()), "pose_loss_fwd")
+    return out
+
+
+def pose_loss_bwd(preds, gts, sx, sq, beta, mode, out, gscale):
+    n = (C.c_int32 * 4)(*[0 if p is None else p.numel() for p in preds])
+    dpreds = [None if p is None else torch.empty_like(p) for p in preds]
+    dev = out.device
+    dsx = torch.empty((), dtype=torch.float32, device=dev) if mode == 0 else None
+    dsq = torch.empty((), dtype=torch.float32, device=dev) if mode == 0 else None
+    check(lib.dlio_pose_loss_bwd(_ptr_array(preds), _ptr_array(gts), n, _ptr(sx), _ptr(sq),
+                                 float(beta), mode, _ptr(out), _ptr(gscale), _ptr_array(dpreds),
+                                 _ptr(dsx), _ptr(dsq), _stream()), "pose_loss_bwd")
+    return dpreds, dsx, dsq
+
+
+# ----------------------------------------------------------------------------- optimizer
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+    check(lib.dlio_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(beta1),
+                             float(beta2), float(eps), float(wd), int(step), float(grad_scale),
+                             _stream()), "adam_step")
+
+
+def sgd_step(p, g, buf, lr, momentum, wd, step, grad_scale=1.0):
+    check(lib.dlio_sgd_step(_ptr(p), _ptr(g), _ptr(buf), p.numel(), float(lr), float(momentum),
+                            float(wd), int(step), float(grad_scale), _stream()), "sgd_step")
+
+
+def sumsq(g):
+    out = torch.empty(1, dtype=torch.float64, device=g.device)
+    check(lib.dlio_sumsq(_ptr(g), g.numel(), _ptr(out), _stream()), "sumsq")
+    return out
+
+
+# ----------------------------------------------------------------------------- profiling
+def prof_enable(on):
+    lib.dlio_prof_enable(int(bool(on)))
+
+
+def prof_reset():
+    lib.dlio_prof_reset()
+
+
+def prof_collect(kind):
+    ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+    check(lib.dlio_prof_collect(kind, C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)),
+          "prof_collect")
+    return dict(ms=ms.value, flops=fl.value, bytes=by.value, launches=n.value)

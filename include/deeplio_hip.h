@@ -1,0 +1,281 @@
+/*
+ * deeplio_hip.h -- C-ABI of libdeeplio_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (ArashJavan/DeepLIO) has no FFI: every op on its training hot
+ * path is a stock torch.nn call.  This header declares the device entry points
+ * that replace those calls, one group per reference site (file:line relative
+ * to the reference checkout).  A maintainer binds them with ctypes exactly as
+ * deeplio_amd/_lib.py does.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned storage (the Python
+ *     host passes torch storage); the library never allocates or frees.
+ *   - workspace is caller-owned; query its size with the *_ws_bytes call.
+ *   - all tensors are fp32, NCHW contiguous.  A "channel slice" (ctot, coff, C)
+ *     addresses channels [coff, coff+C) of a buffer that has ctot channels, so
+ *     that concat (torch.cat(dim=1)) never materialises a copy.
+ *   - `stream` is a hipStream_t passed as void* (0 = null stream); kernels are
+ *     enqueued, never synchronised.
+ *   - return 0 on success, negative DLIO_E* otherwise.
+ */
+#ifndef DEEPLIO_HIP_H
+#define DEEPLIO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DLIO_OK 0
+#define DLIO_EINVAL (-1)   /* bad shape / null pointer            -> ValueError   */
+#define DLIO_EUNSUP (-2)   /* unsupported configuration           -> ValueError   */
+#define DLIO_ELAUNCH (-3)  /* hipGetLastError() after launch      -> RuntimeError */
+#define DLIO_EWS (-4)      /* workspace too small                 -> RuntimeError */
+
+typedef void* dlio_stream_t;
+
+/* ---- library info ---------------------------------------------------- */
+int dlio_version(void);
+const char* dlio_arch(void);           /* "gfx950" */
+const char* dlio_strerror(int code);
+
+/* ---- profiling hooks (bench.py roofline leg) ---------------------------
+ * When enabled, the conv launchers bracket each launch with hipEvents on the
+ * launch stream.  dlio_prof_collect synchronises those events and returns the
+ * summed milliseconds / algorithmic FLOPs / launch count per kernel kind
+ * (0 = conv fwd/dgrad MFMA kernel, 1 = conv wgrad MFMA kernel). */
+int dlio_prof_enable(int on);
+int dlio_prof_reset(void);
+int dlio_prof_collect(int kind, double* ms, double* flops, double* bytes, int64_t* launches);
+
+/* ---- convolution ------------------------------------------------------
+ * replaces nn.Conv2d forward/backward at: pointseg_net.py:18 (conv1a),
+ * pointseg_modules.py:96-106 (Fire squeeze/expand), base_net.py:55-71
+ * (FlowNet conv), resnet.py:36 + torchvision BasicBlock, lidar_feat_nets.py:
+ * 279-304 (Simple-1). */
+typedef struct DlioConvDesc {
+  int32_t N, Cin, H, W;          /* logical input                         */
+  int32_t in_ctot, in_coff;      /* channel slice of the input buffer     */
+  int32_t Cout, OH, OW;          /* logical output                        */
+  int32_t out_ctot, out_coff;    /* channel slice of the output buffer    */
+  int32_t KH, KW, SH, SW, PH, PW;
+  int32_t res_ctot, res_coff;    /* channel slice of the residual buffer  */
+  int32_t in_relu;               /* with in_scale: x' = max(0, affine(x)) */
+} DlioConvDesc;
+
+/* w [Cout][Cin][KH][KW] -> wt [KH*KW][Cin][Cout]  (mode 0, forward layout)
+ * w [Cout][Cin][KH][KW] -> wt [KH*KW][Cout][Cin] with taps reversed
+ *                          (mode 1, data-gradient layout for stride-1 convs) */
+int dlio_conv2d_prep_weight(const float* w, float* wt, int Cout, int Cin, int KH, int KW,
+                            int mode, dlio_stream_t stream);
+
+/* y[n,co,oh,ow] = bias[co] + residual[n,co,oh,ow]
+ *               + sum_{ci,dy,dx} wt[dy*KW+dx][ci][co] * x'[n,ci,oh*SH-PH+dy,ow*SW-PW+dx]
+ * x' = x, or max(0,(x-in_mean[ci])*in_scale[ci]+in_shift[ci]) when in_scale != NULL
+ * (zero padding is applied AFTER the transform).  bias/residual/in_* may be NULL.
+ * residual may alias y (accumulate).  Implicit GEMM on v_mfma_f32_32x32x2_f32. */
+int dlio_conv2d_fwd(const float* x, const float* wt, const float* bias,
+                    const float* in_mean, const float* in_scale, const float* in_shift,
+                    const float* residual, float* y, const DlioConvDesc* d,
+                    dlio_stream_t stream);
+
+/* strided data gradient (any stride): dx[n,ci,ih,iw] = sum_{co,dy,dx} dy[...] * w[co][ci][dy][dx]
+ * w in the STANDARD [Cout][Cin][KH][KW] layout.  d describes the forward conv. */
+int dlio_conv2d_dgrad_strided(const float* dy, const float* w, float* dx,
+                              const DlioConvDesc* d, dlio_stream_t stream);
+
+/* dw[co][ci][dy][dx] = sum_{n,oh,ow} dy[n,co,oh,ow] * x'[n,ci,oh*SH-PH+dy,ow*SW-PW+dx]
+ * standard weight layout; deterministic two-stage split-K through ws. */
+size_t dlio_conv2d_wgrad_ws_bytes(const DlioConvDesc* d);
+int dlio_conv2d_wgrad(const float* x, const float* dy, float* dw,
+                      const float* in_mean, const float* in_scale, const float* in_shift,
+                      void* ws, size_t ws_bytes, const DlioConvDesc* d, dlio_stream_t stream);
+
+/* ---- per-channel reductions / batch norm --------------------------------
+ * replaces nn.BatchNorm2d (train + eval) at pointseg_net.py:19,
+ * pointseg_modules.py:98-106, base_net.py:63, resnet.py:38, lidar_feat_nets.py:
+ * 280-301 and the conv bias gradient.
+ * Statistics are accumulated in fp64. */
+size_t dlio_chan_stats_ws_bytes(int N, int C, int HW);
+/* sum[c] = sum x, sumsq[c] = sum x^2 over (n, hw) of channel slice; x' = relu(x) if pre_relu */
+int dlio_chan_stats(const float* x, int N, int ctot, int coff, int C, int HW, int pre_relu,
+                    double* sum, double* sumsq, void* ws, size_t ws_bytes, dlio_stream_t stream);
+/* mean/var(biased)/invstd, scale=gamma*invstd; running stats updated in place
+ * with momentum and the unbiased variance (nn.BatchNorm2d semantics). */
+int dlio_bn_finalize(const double* sum, const double* sumsq, int C, double count,
+                     const float* gamma, float eps, float momentum,
+                     float* running_mean, float* running_var,
+                     float* mean, float* invstd, float* scale, dlio_stream_t stream);
+/* eval mode: mean=running_mean, invstd=rsqrt(running_var+eps), scale=gamma*invstd */
+int dlio_bn_eval_params(const float* running_mean, const float* running_var, const float* gamma,
+                        float eps, int C, float* mean, float* invstd, float* scale,
+                        dlio_stream_t stream);
+/* y = post( (pre(x) - mean[c]) * scale[c] + beta[c] ) + residual
+ * pre = relu if pre_relu, post = relu if post_relu.  y may alias x. */
+int dlio_bn_apply(const float* x, int x_ctot, int x_coff, const float* mean, const float* scale,
+                  const float* beta, const float* residual, int r_ctot, int r_coff,
+                  float* y, int y_ctot, int y_coff, int N, int C, int HW,
+                  int pre_relu, int post_relu, dlio_stream_t stream);
+/* backward reductions: g = dy * [post_relu ? y>0 : 1];  xh = (pre(x)-mean)*invstd
+ * sum_g[c] = sum g, sum_gx[c] = sum g*xh */
+int dlio_bn_bwd_reduce(const float* dy, int dy_ctot, int dy_coff, const float* x, int x_ctot,
+                       int x_coff, const float* mean, const float* invstd, const float* scale,
+                       const float* beta, int N, int C, int HW, int pre_relu, int post_relu,
+                       double* sum_g, double* sum_gx, void* ws, size_t ws_bytes,
+                       dlio_stream_t stream);
+/* dgamma = sum_gx, dbeta = sum_g (fp32 out);  train: dx = scale*(g - sum_g/M - xh*sum_gx/M)
+ * eval (use_batch_stats=0): dx = scale*g.  pre_relu masks dx by x>0. */
+int dlio_bn_bwd_apply(const float* dy, int dy_ctot, int dy_coff, const float* x, int x_ctot,
+                      int x_coff, const float* mean, const float* invstd, const float* scale,
+                      const float* beta, const double* sum_g, const double* sum_gx,
+                      float* dx, int dx_ctot, int dx_coff, float* dgamma, float* dbeta,
+                      int N, int C, int HW, int pre_relu, int post_relu, int use_batch_stats,
+                      dlio_stream_t stream);
+/* out[c] (fp32) = sum over (n,hw) of channel slice -- conv bias gradient */
+int dlio_chan_sum(const float* x, int N, int ctot, int coff, int C, int HW, float* out,
+                  void* ws, size_t ws_bytes, dlio_stream_t stream);
+
+/* ---- pooling ---------------------------------------------------------
+ * nn.MaxPool2d(kernel 3) at pointseg_net.py:21-46, resnet.py:40,
+ * lidar_feat_nets.py:281-299 (ceil_mode); adaptive_avg_pool2d(1,1) at
+ * lidar_feat_nets.py:84-85,258, resnet.py:49, pointseg_modules.py:218.
+ * idx holds the argmax window position (dy*KW+dx) as uint8, first max wins
+ * (ATen tie rule).  x_scale (nullable, [N][C]) multiplies the input plane
+ * (fused SELayer channel re-weighting: pointseg_modules.py:220). */
+int dlio_maxpool2d_fwd(const float* x, const float* x_scale, float* y, uint8_t* idx,
+                       int N, int C, int H, int W, int OH, int OW, int K, int SH, int SW,
+                       int PH, int PW, dlio_stream_t stream);
+int dlio_maxpool2d_bwd(const float* dy, const uint8_t* idx, const float* x_scale, float* dx,
+                       int N, int C, int H, int W, int OH, int OW, int K, int SH, int SW,
+                       int PH, int PW, dlio_stream_t stream);
+/* out[n][c] = mean over HW of channel slice */
+int dlio_gap_fwd(const float* x, int ctot, int coff, float* out, int N, int C, int HW,
+                 dlio_stream_t stream);
+/* dx[n][c][hw] (+)= dout[n][c] / HW */
+int dlio_gap_bwd(const float* dout, float* dx, int N, int C, int HW, int accumulate,
+                 dlio_stream_t stream);
+/* SELayer scale (pointseg_modules.py:220): y = x * s[n][c] */
+int dlio_chan_scale_fwd(const float* x, const float* s, float* y, int N, int C, int HW,
+                        dlio_stream_t stream);
+/* dx = dy * s ; ds[n][c] = sum_hw dy*x */
+int dlio_chan_scale_bwd(const float* dy, const float* x, const float* s, float* dx, float* ds,
+                        int N, int C, int HW, dlio_stream_t stream);
+
+/* ---- dense layers -----------------------------------------------------
+ * nn.Linear at lidar_feat_nets.py:66, pointseg_modules.py:209-214,
+ * imu_feat_nets.py:27-30, fusion_nets.py:59, odom_feat_nets.py:18-20,
+ * deeplio_nets.py:57-58 and the LSTM/GRU input/recurrent projections.
+ * act: 0 none, 1 relu, 2 leaky_relu(0.01), 3 sigmoid, 4 tanh.
+ * y[m][n] = act( sum_k x[m*ldx+k] * w[n*K+k] + b[n] + addend[m*ldadd+n] ) */
+int dlio_linear_fwd(const float* x, int ldx, const float* w, const float* b,
+                    const float* addend, int ldadd, float* y, int ldy,
+                    int M, int N, int K, int act, dlio_stream_t stream);
+/* dz = dy * act'(y) (in terms of the OUTPUT y); dz may alias dy */
+int dlio_act_bwd(const float* dy, const float* y, float* dz, int64_t n, int act,
+                 dlio_stream_t stream);
+/* dx[m][k] (+)= sum_n dz[m*lddz+n] * w[n*K+k] */
+int dlio_linear_bwd_data(const float* dz, int lddz, const float* w, float* dx, int lddx,
+                         int M, int N, int K, int accumulate, dlio_stream_t stream);
+/* dw[n][k] (+)= sum_m dz[m][n]*x[m][k];  db[n] (+)= sum_m dz[m][n]  (db may be NULL) */
+int dlio_linear_bwd_weight(const float* dz, int lddz, const float* x, int ldx, float* dw,
+                           float* db, int M, int N, int K, int accumulate,
+                           dlio_stream_t stream);
+
+/* ---- elementwise helpers ---------------------------------------------- */
+/* op: 0 a+b, 1 a-b, 2 a*b */
+int dlio_ew_binary(const float* a, const float* b, float* y, int64_t n, int op,
+                   dlio_stream_t stream);
+/* y = alpha*a */
+int dlio_ew_scale(const float* a, float alpha, float* y, int64_t n, dlio_stream_t stream);
+/* strided 2-D copy: dst[r*ldd + c] = src[r*lds + c] (concat / split along features) */
+int dlio_copy2d(const float* src, int lds, float* dst, int ldd, int rows, int cols,
+                int accumulate, dlio_stream_t stream);
+/* nn.Dropout: mask from Philox4x32-10(seed, offset); y = x*mask/(1-p); mask saved as u8 */
+int dlio_dropout_fwd(const float* x, float* y, uint8_t* mask, int64_t n, float p,
+                     uint64_t seed, uint64_t offset, dlio_stream_t stream);
+int dlio_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, int64_t n, float p,
+                     dlio_stream_t stream);
+/* trainer.py:221-243 NaN/Inf guards: flag[0] |= 1 if any non-finite */
+int dlio_nonfinite_flag(const float* x, int64_t n, int32_t* flag, dlio_stream_t stream);
+
+/* ---- recurrent layers ---------------------------------------------------
+ * nn.LSTM / nn.GRU at imu_feat_nets.py:63-70 (state carried over sub-
+ * sequences, :79-83) and odom_feat_nets.py:61-68.  One call = one layer, one
+ * direction, one sequence.  gx = x W_ih^T + b_ih is computed by dlio_linear_fwd
+ * beforehand.  Gate order i,f,g,o (LSTM) / r,z,n (GRU), G = 4 / 3.
+ * Sequence tensors are addressed by ROW r(t,b) = t*rst + b*rsb (batch-first:
+ * rst=1, rsb=T; time-major: rst=B, rsb=1):
+ *   gx, dgates : [rows][G*H]      gates (saved, post-activation) : [rows][4*H]
+ *   cs, hp     : [rows][H]        (c_t, and the h that ENTERED step t)
+ *   hs / dhs   : row stride ldhs / lddhs floats (one half of a bidirectional
+ *                [rows][2H] buffer)
+ * Persistent single-workgroup kernel (W_hh resident in registers, h/c/gates in
+ * LDS) when H is 32, 64 or 128; per-step streamed kernels otherwise.
+ * GRU saves r,z,n in gates[..][0..3H) and hn = W_hn h + b_hn in [3H..4H). */
+size_t dlio_rnn_ws_bytes(int T, int B, int H);
+int dlio_lstm_seq_fwd(const float* gx, const float* w_hh, const float* b_hh,
+                      const float* h0, const float* c0, float* hs, int ldhs, float* cs,
+                      float* hp, float* gates, float* hT, float* cT, int T, int B, int H,
+                      int rst, int rsb, int reverse, void* ws, size_t ws_bytes,
+                      dlio_stream_t stream);
+/* dhs: gradient wrt every h_t as seen by the consumer; dhT/dcT: gradient wrt
+ * the final state (nullable).  Outputs dgates (pre-activation gate grads, same
+ * row addressing as gx), dh0, dc0. */
+int dlio_lstm_seq_bwd(const float* dhs, int lddhs, const float* dhT, const float* dcT,
+                      const float* gates, const float* cs, const float* c0,
+                      const float* w_hh, float* dgates, float* dh0, float* dc0,
+                      int T, int B, int H, int rst, int rsb, int reverse, void* ws,
+                      size_t ws_bytes, dlio_stream_t stream);
+int dlio_gru_seq_fwd(const float* gx, const float* w_hh, const float* b_hh, const float* h0,
+                     float* hs, int ldhs, float* hp, float* gates, float* hT, int T, int B,
+                     int H, int rst, int rsb, int reverse, void* ws, size_t ws_bytes,
+                     dlio_stream_t stream);
+/* outputs dgx[rows][3H] (grad wrt gx) and dgh[rows][3H] (grad wrt W_hh h + b_hh), dh0 */
+int dlio_gru_seq_bwd(const float* dhs, int lddhs, const float* dhT, const float* gates,
+                     const float* hp, const float* w_hh, float* dgx, float* dgh, float* dh0,
+                     int T, int B, int H, int rst, int rsb, int reverse, void* ws,
+                     size_t ws_bytes, dlio_stream_t stream);
+
+/* ---- pose chain + loss --------------------------------------------------
+ * Trainer.se3_to_SE3 (trainer.py:324-351): per batch element chain
+ * R_s = R_{s-1} exp(w_s), t_s = R_{s-1} t + t_{s-1}; q_s = quat_wxyz(R_s)
+ * (tester.py:223-251 variant: order=1 -> xyzw).  status[0] is set to 1 when a
+ * determinant check (|det-1| > 1e-5+1e-8) fails, mirroring the ValueError.
+ * R_all [B][S][9] is saved for backward. */
+int dlio_se3_chain_fwd(const float* t, const float* w, float* p, float* q, float* R_all,
+                       int32_t* status, int B, int S, int order, dlio_stream_t stream);
+int dlio_se3_chain_bwd(const float* t, const float* w, const float* R_all, const float* dp,
+                       const float* dq, float* dt, float* dw, int B, int S, int order,
+                       dlio_stream_t stream);
+/* HWSLoss / LWSLoss (losses/losses.py:21-39, 68-86).  Eight [B][S*][D] inputs
+ * are passed as 4 (pred, gt) pairs with element counts n[4] (0 = term off).
+ * mode 0: HWS with sx,sq;  mode 1: LWS with beta.  out: loss[0], mse[1..4].
+ * Order of pairs: f2f_t, f2f_w, f2g_p, f2g_q. */
+int dlio_pose_loss_fwd(const float* const* pred, const float* const* gt, const int32_t* n,
+                       const float* sx, const float* sq, float beta, int mode, float* out,
+                       dlio_stream_t stream);
+/* dpred[i] = gscale * d loss / d pred[i]; dsx, dsq (HWS only, nullable) */
+int dlio_pose_loss_bwd(const float* const* pred, const float* const* gt, const int32_t* n,
+                       const float* sx, const float* sq, float beta, int mode,
+                       const float* out, const float* gscale, float* const* dpred,
+                       float* dsx, float* dsq, dlio_stream_t stream);
+
+/* ---- optimizer ----------------------------------------------------------
+ * torch.optim.Adam / SGD(momentum) as built by create_optimizer
+ * (optimizer.py:4-16) over ONE flat parameter buffer: weight decay is L2 added
+ * to the gradient.  step is the 1-based step count. grad_scale multiplies g
+ * first (data-parallel averaging). */
+int dlio_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int step,
+                   float grad_scale, dlio_stream_t stream);
+int dlio_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, float momentum,
+                  float weight_decay, int step, float grad_scale, dlio_stream_t stream);
+/* out[0] = sum g^2 (fp64) -- calc_grad_norm, trainer.py:481-486 */
+int dlio_sumsq(const float* g, int64_t n, double* out, dlio_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPLIO_HIP_H */

@@ -1,0 +1,423 @@
+"""-m gpu parity tests of every primitive of the C-ABI against the oracle's functional
+references (oracle/ref_ops.py, oracle/se3.py) on seeded inputs.  Tolerance: 1e-4 relative to
+the tensor scale in fp32 (north_star), bit-exact for index maps (maxpool argmax)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _g(seed):
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return g
+
+
+CONV_CASES = [
+    # N, Cin, H, W, Cout, KH, KW, SH, SW, PH, PW
+    (2, 10, 16, 64, 64, 3, 5, 1, 2, 1, 2),     # PointSeg conv1a
+    (2, 64, 8, 64, 16, 1, 1, 1, 1, 0, 0),      # Fire squeeze
+    (2, 16, 8, 64, 64, 3, 3, 1, 1, 1, 1),      # Fire expand3x3
+    (2, 16, 8, 64, 64, 1, 1, 1, 1, 0, 0),      # Fire expand1x1 (Cin % 32 != 0)
+    (1, 48, 12, 40, 192, 3, 3, 1, 1, 1, 1),    # ragged H/W, Cin=48
+    (2, 80, 8, 32, 384, 3, 3, 1, 1, 1, 1),     # blk5
+    (1, 6, 16, 64, 64, 5, 7, 1, 2, 2, 3),      # FlowNet / Simple conv1
+    (1, 6, 8, 64, 64, 5, 7, 1, 1, 2, 3),       # ResNet conv1
+    (1, 64, 8, 65, 128, 3, 5, 1, 1, 1, 2),     # Simple conv2 (odd width)
+    (1, 64, 8, 64, 128, 3, 5, 1, 2, 1, 2),     # FlowNet conv2
+    (1, 32, 16, 32, 64, 3, 3, 2, 2, 1, 1),     # FlowNet conv4-style
+    (1, 32, 8, 64, 48, 3, 3, 1, 2, 1, 1),      # ResNet layer1 first block
+    (1, 32, 8, 64, 48, 1, 1, 1, 2, 0, 0),      # ResNet downsample (1,2)
+    (1, 32, 8, 64, 48, 1, 1, 2, 2, 0, 0),      # ResNet downsample (2,2)
+    (1, 128, 17, 17, 64, 3, 3, 1, 1, 1, 1),    # Simple-1 odd 17x17
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_wgrad_dgrad(dev, case):
+    from deeplio_amd import ops
+    N, Cin, H, W, Cout, KH, KW, SH, SW, PH, PW = case
+    g = _g(1)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, KH, KW, generator=g) / math.sqrt(Cin * KH * KW)
+    b = torch.randn(Cout, generator=g)
+    y_ref = F.conv2d(x.double(), w.double(), b.double(), stride=(SH, SW), padding=(PH, PW))
+    OH, OW = y_ref.shape[2:]
+    d = ops.conv_desc(N, Cin, H, W, Cout, KH, KW, SH, SW, PH, PW)
+    assert (d.OH, d.OW) == (OH, OW)
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+    wt = ops.conv2d_prep_weight(wd, 0)
+    y = torch.full((N, Cout, OH, OW), float("nan"), device=dev)
+    ops.conv2d_fwd(xd, wt, bd, y, d)
+    assert rel_err(y, y_ref) < TOL
+
+    # weight gradient
+    dy = torch.randn(N, Cout, OH, OW, generator=g)
+    xr = x.double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    F.conv2d(xr, wr, None, stride=(SH, SW), padding=(PH, PW)).backward(dy.double())
+    dw = torch.full_like(wd, float("nan"))
+    ops.conv2d_wgrad(xd, dy.to(dev), dw, d)
+    assert rel_err(dw, wr.grad) < TOL
+
+    # data gradient
+    dx = torch.full_like(xd, float("nan"))
+    if SH == 1 and SW == 1:
+        wt2 = ops.conv2d_prep_weight(wd, 1)
+        dd = ops.conv_desc(N, Cout, OH, OW, Cin, KH, KW, 1, 1, KH - 1 - PH, KW - 1 - PW)
+        assert (dd.OH, dd.OW) == (H, W)
+        ops.conv2d_fwd(dy.to(dev), wt2, None, dx, dd)
+    else:
+        ops.conv2d_dgrad_strided(dy.to(dev), wd, dx, d)
+    assert rel_err(dx, xr.grad) < TOL
+
+
+def test_conv_slices_residual_affine(dev):
+    """channel-sliced in/out buffers (concat without copy), residual add, fused producer
+    BN-apply+ReLU on load, for both the forward and the weight-gradient kernels."""
+    from deeplio_amd import ops
+    g = _g(2)
+    N, H, W = 2, 8, 64
+    xbuf = torch.randn(N, 40, H, W, generator=g)          # use channels 8..23
+    w = torch.randn(24, 16, 3, 3, generator=g) / 12
+    b = torch.randn(24, generator=g)
+    res = torch.randn(N, 30, H, W, generator=g)           # residual channels 3..26
+    mean, scale, shift = torch.randn(16, generator=g), torch.rand(16, generator=g) + .5, torch.randn(16, generator=g)
+    xin = F.relu((xbuf[:, 8:24] - mean.view(1, -1, 1, 1)) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    y_ref = F.conv2d(xin.double(), w.double(), b.double(), padding=1) + res[:, 3:27].double()
+    ybuf = torch.zeros(N, 50, H, W)
+    d = ops.conv_desc(N, 16, H, W, 24, 3, 3, 1, 1, 1, 1, in_ctot=40, in_coff=8, out_ctot=50,
+                      out_coff=20, res_ctot=30, res_coff=3, in_relu=1)
+    yd = ybuf.to(dev)
+    aff = (mean.to(dev), scale.to(dev), shift.to(dev))
+    ops.conv2d_fwd(xbuf.to(dev), ops.conv2d_prep_weight(w.to(dev), 0), b.to(dev), yd, d,
+                   in_aff=aff, residual=res.to(dev))
+    assert rel_err(yd[:, 20:44], y_ref) < TOL
+    assert float(yd[:, :20].abs().max()) == 0 and float(yd[:, 44:].abs().max()) == 0
+    # wgrad with sliced dy and fused affine input
+    dybuf = torch.randn(N, 50, H, W, generator=g)
+    wr = w.double().requires_grad_(True)
+    F.conv2d(xin.double(), wr, None, padding=1).backward(dybuf[:, 20:44].double())
+    dw = torch.empty(24, 16, 3, 3, device=dev)
+    ops.conv2d_wgrad(xbuf.to(dev), dybuf.to(dev), dw, d, in_aff=aff)
+    assert rel_err(dw, wr.grad) < TOL
+
+
+@pytest.mark.parametrize("shape", [(3, 24, 8, 64), (2, 7, 17, 17)])
+@pytest.mark.parametrize("pre_relu,post_relu", [(0, 1), (1, 0), (0, 0)])
+def test_batchnorm_train_eval_backward(dev, shape, pre_relu, post_relu):
+    from deeplio_amd import ops
+    from oracle import ref_ops
+    g = _g(3)
+    N, C_, H, W = shape
+    HW = H * W
+    x = torch.randn(shape, generator=g) * 2 + 0.7
+    gamma, beta = torch.rand(C_, generator=g) + 0.5, torch.randn(C_, generator=g)
+    rm, rv = torch.randn(C_, generator=g), torch.rand(C_, generator=g) + 0.5
+    resid = torch.randn(shape, generator=g)
+    dy = torch.randn(shape, generator=g)
+    for training in (True, False):
+        xr = x.double().requires_grad_(True)
+        gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+        xin = F.relu(xr) if pre_relu else xr
+        if training:
+            y_ref, rm_ref, rv_ref = ref_ops.bn_train(xin, gr, br, rm.double(), rv.double(), 0.1, 1e-5)
+        else:
+            y_ref = ref_ops.bn_eval(xin, gr, br, rm.double(), rv.double(), 1e-5)
+        if post_relu:
+            y_ref = F.relu(y_ref)
+        y_ref = y_ref + resid.double()
+        y_ref.backward(dy.double())
+
+        xd = x.to(dev)
+        rmd, rvd = rm.to(dev).clone(), rv.to(dev).clone()
+        if training:
+            st = ops.chan_stats(xd, N, C_, 0, C_, HW, pre_relu)
+            prm = ops.bn_finalize(st, N * HW, gamma.to(dev), 1e-5, 0.1, rmd, rvd)
+            assert rel_err(rmd, rm_ref) < 1e-5 and rel_err(rvd, rv_ref) < 1e-5
+        else:
+            prm = ops.bn_eval_params(rmd, rvd, gamma.to(dev), 1e-5)
+        y = torch.empty_like(xd)
+        ops.bn_apply(xd, C_, 0, prm, beta.to(dev), y, C_, 0, N, C_, HW, pre_relu, post_relu,
+                     residual=resid.to(dev), r_ctot=C_, r_coff=0)
+        assert rel_err(y, y_ref) < TOL
+        dx = torch.empty_like(xd)
+        dgam, dbet = torch.empty(C_, device=dev), torch.empty(C_, device=dev)
+        ops.bn_bwd(dy.to(dev), C_, 0, xd, C_, 0, prm, beta.to(dev), dx, C_, 0, N, C_, HW, pre_relu,
+                   post_relu, training, dgam, dbet)
+        assert rel_err(dx, xr.grad) < TOL
+        assert rel_err(dgam, gr.grad) < TOL and rel_err(dbet, br.grad) < TOL
+    cs = ops.chan_sum(dy.to(dev), N, C_, 0, C_, HW)
+    assert rel_err(cs, dy.double().sum((0, 2, 3))) < 1e-5
+
+
+POOL_CASES = [((2, 5, 8, 64), 3, 1, 2, 1, 1, False), ((2, 5, 8, 64), 3, 2, 2, 1, 1, False),
+              ((1, 3, 16, 129), 3, 1, 2, 1, 1, True), ((1, 3, 33, 33), 3, 2, 2, 1, 1, True),
+              ((1, 3, 64, 65), 3, 2, 2, 1, 1, True)]
+
+
+@pytest.mark.parametrize("case", POOL_CASES)
+def test_maxpool_bit_exact_with_ties(dev, case):
+    """post-ReLU inputs have many exact ties (zeros): argmax routing must follow ATen's
+    first-max rule, so values AND gradients are bit-exact."""
+    from deeplio_amd import ops
+    shape, k, sh, sw, ph, pw, ceil = case
+    g = _g(4)
+    x = F.relu(torch.randn(shape, generator=g))
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.max_pool2d(xr, k, (sh, sw), (ph, pw), ceil_mode=ceil)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    y, idx = ops.maxpool2d_fwd(x.to(dev), k, sh, sw, ph, pw, ceil)
+    assert y.shape == y_ref.shape
+    assert torch.equal(y.cpu(), y_ref.detach())
+    dx = ops.maxpool2d_bwd(dy.to(dev), idx, shape, k, sh, sw, ph, pw)
+    assert rel_err(dx, xr.grad) < 1e-6
+
+
+def test_gap_and_channel_scale(dev):
+    from deeplio_amd import ops
+    g = _g(5)
+    xb = torch.randn(3, 20, 8, 32, generator=g)
+    out = ops.gap_fwd(xb.to(dev), 3, 20, 4, 12, 256)
+    assert rel_err(out, xb[:, 4:16].double().mean((2, 3))) < 1e-6
+    x = torch.randn(3, 12, 8, 32, generator=g)
+    s = torch.rand(3, 12, generator=g)
+    y = ops.chan_scale_fwd(x.to(dev), s.to(dev))
+    assert rel_err(y, x * s.view(3, 12, 1, 1)) < 1e-6
+    dy = torch.randn_like(x)
+    dx, ds = ops.chan_scale_bwd(dy.to(dev), x.to(dev), s.to(dev))
+    assert rel_err(dx, dy * s.view(3, 12, 1, 1)) < 1e-6
+    assert rel_err(ds, (dy.double() * x.double()).sum((2, 3))) < 1e-5
+    dgx = torch.zeros(3, 12, 8, 32, device=dev)
+    ops.gap_bwd(s.to(dev), dgx, 3, 12, 256)
+    assert rel_err(dgx, (s / 256).view(3, 12, 1, 1).expand(3, 12, 8, 32)) < 1e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(16, 128, 768), (16, 4096, 256), (5, 3, 1024), (100, 64, 6),
+                                   (37, 130, 50)])
+@pytest.mark.parametrize("act", [0, 1, 2, 3, 4])
+def test_linear_fwd_bwd(dev, M, N, K, act):
+    from deeplio_amd import ops
+    from oracle import ref_ops
+    g = _g(6)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    y_ref = ref_ops.linear(xr, wr, br, act)
+    dy = torch.randn(M, N, generator=g)
+    y_ref.backward(dy.double())
+    y = ops.linear_fwd(x.to(dev), w.to(dev), b.to(dev), act)
+    assert rel_err(y, y_ref) < TOL
+    dz = ops.act_bwd(dy.to(dev), y, act)
+    dx = ops.linear_bwd_data(dz, w.to(dev), M)
+    dw, db = ops.linear_bwd_weight(dz, x.to(dev), M, N, K)
+    assert rel_err(dx, xr.grad) < TOL
+    assert rel_err(dw, wr.grad) < TOL
+    assert rel_err(db, br.grad) < TOL
+
+
+def test_elementwise_dropout_nonfinite(dev):
+    from deeplio_amd import ops
+    g = _g(7)
+    a, b = torch.randn(1000, generator=g), torch.randn(1000, generator=g)
+    for op, ref in ((0, a + b), (1, a - b), (2, a * b)):
+        assert torch.equal(ops.ew_binary(a.to(dev), b.to(dev), op).cpu(), ref)
+    x = torch.randn(200000, generator=g).to(dev)
+    y, mask = ops.dropout_fwd(x, 0.25, 1234, 0)
+    keep = mask.float().mean().item()
+    assert abs(keep - 0.75) < 0.01
+    assert torch.allclose(y.cpu(), (x * mask / 0.75).cpu())
+    y2, mask2 = ops.dropout_fwd(x, 0.25, 1234, 0)
+    assert torch.equal(mask, mask2)                      # counter-based: reproducible
+    y3, mask3 = ops.dropout_fwd(x, 0.25, 1234, 50000)
+    assert not torch.equal(mask, mask3)
+    dx = ops.dropout_bwd(y, mask, 0.25)
+    assert torch.allclose(dx.cpu(), (y * mask / 0.75).cpu())
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.nonfinite_flag(x, flag)
+    assert int(flag.item()) == 0
+    x[777] = float("inf")
+    ops.nonfinite_flag(x, flag)
+    assert int(flag.item()) == 1
+
+
+def _run_rnn(dev, kind, T, B, I, H, reverse, batch_first):
+    """one layer, one direction of nn.LSTM / nn.GRU with initial state, against torch CPU."""
+    from deeplio_amd import ops
+    g = _g(8)
+    G = 4 if kind == "lstm" else 3
+    x = torch.randn(B, T, I, generator=g)
+    rnn = (torch.nn.LSTM if kind == "lstm" else torch.nn.GRU)(I, H, 1, batch_first=True).double()
+    h0 = torch.randn(1, B, H, generator=g).double().requires_grad_(True)
+    c0 = torch.randn(1, B, H, generator=g).double().requires_grad_(True)
+    xr = x.double().requires_grad_(True)
+    xin = torch.flip(xr, [1]) if reverse else xr
+    if kind == "lstm":
+        out, (hT, cT) = rnn(xin, (h0, c0))
+    else:
+        out, hT = rnn(xin, h0)
+        cT = None
+    if reverse:
+        out = torch.flip(out, [1])
+    dout = torch.randn(B, T, H, generator=g).double()
+    dhT = torch.randn(1, B, H, generator=g).double()
+    dcT = torch.randn(1, B, H, generator=g).double()
+    loss = (out * dout).sum() + (hT * dhT).sum()
+    if cT is not None:
+        loss = loss + (cT * dcT).sum()
+    loss.backward()
+
+    f = lambda t: t.detach().float().contiguous().to(dev)
+    w_ih, w_hh, b_ih, b_hh = (f(getattr(rnn, n + "_l0")) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
+    rows = B * T
+    if batch_first:
+        rst, rsb = 1, T
+        x_rows = f(x).view(rows, I)
+        to_bt = lambda t: t.view(B, T, -1)
+    else:
+        rst, rsb = B, 1
+        x_rows = f(x.transpose(0, 1)).view(rows, I)
+        to_bt = lambda t: t.view(T, B, -1).transpose(0, 1)
+    gx = ops.linear_fwd(x_rows, w_ih, b_ih)
+    hs = torch.full((rows, 2 * H), float("nan"), device=dev)   # use the second half (ld = 2H)
+    cs = torch.empty(rows, H, device=dev)
+    hp = torch.empty(rows, H, device=dev)
+    gates = torch.empty(rows, 4 * H, device=dev)
+    hTd, cTd = torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)
+    dhs = torch.zeros(rows, 2 * H, device=dev)
+    if batch_first:
+        dhs[:, H:] = f(dout).view(rows, H)
+    else:
+        dhs[:, H:] = f(dout.transpose(0, 1)).view(rows, H)
+    dh0, dc0 = torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)
+    if kind == "lstm":
+        ops.lstm_seq_fwd(gx, w_hh, b_hh, f(h0[0]), f(c0[0]), hs, H, 2 * H, cs, hp, gates, hTd, cTd,
+                         T, B, H, rst, rsb, reverse)
+        assert rel_err(cTd, cT[0]) < TOL
+        dg = torch.empty(rows, 4 * H, device=dev)
+        ops.lstm_seq_bwd(dhs, H, 2 * H, f(dhT[0]), f(dcT[0]), gates, cs, f(c0[0]), w_hh, dg, dh0,
+                         dc0, T, B, H, rst, rsb, reverse)
+        dgx = dgh = dg
+        assert rel_err(dc0, c0.grad[0]) < TOL
+    else:
+        ops.gru_seq_fwd(gx, w_hh, b_hh, f(h0[0]), hs, H, 2 * H, hp, gates, hTd, T, B, H, rst, rsb,
+                        reverse)
+        dgx, dgh = torch.empty(rows, 3 * H, device=dev), torch.empty(rows, 3 * H, device=dev)
+        ops.gru_seq_bwd(dhs, H, 2 * H, f(dhT[0]), gates, hp, w_hh, dgx, dgh, dh0, T, B, H, rst, rsb,
+                        reverse)
+    assert rel_err(to_bt(hs[:, H:]), out) < TOL
+    assert rel_err(hTd, hT[0]) < TOL
+    assert rel_err(dh0, h0.grad[0]) < TOL
+    dx = ops.linear_bwd_data(dgx, w_ih, rows)
+    assert rel_err(to_bt(dx), xr.grad) < TOL
+    dw_ih, db_ih = ops.linear_bwd_weight(dgx, x_rows, rows, G * H, I)
+    dw_hh, db_hh = ops.linear_bwd_weight(dgh, hp, rows, G * H, H)
+    assert rel_err(dw_ih, rnn.weight_ih_l0.grad) < TOL
+    assert rel_err(db_ih, rnn.bias_ih_l0.grad) < TOL
+    assert rel_err(dw_hh, rnn.weight_hh_l0.grad) < TOL
+    assert rel_err(db_hh, rnn.bias_hh_l0.grad) < TOL
+
+
+@pytest.mark.parametrize("H", [8, 32, 128])        # streamed / persistent / persistent(IMU size)
+@pytest.mark.parametrize("reverse", [False, True])
+@pytest.mark.parametrize("batch_first", [True, False])
+def test_lstm_layer(dev, H, reverse, batch_first):
+    _run_rnn(dev, "lstm", T=7, B=3, I=6, H=H, reverse=reverse, batch_first=batch_first)
+
+
+def test_lstm_layer_large_batch_long_seq(dev):
+    _run_rnn(dev, "lstm", T=50, B=11, I=6, H=128, reverse=False, batch_first=True)
+    _run_rnn(dev, "lstm", T=3, B=4, I=256, H=1024, reverse=True, batch_first=True)
+
+
+@pytest.mark.parametrize("H", [8, 128])
+@pytest.mark.parametrize("reverse", [False, True])
+def test_gru_layer(dev, H, reverse):
+    _run_rnn(dev, "gru", T=7, B=3, I=6, H=H, reverse=reverse, batch_first=True)
+
+
+@pytest.mark.parametrize("order", [0, 1])
+def test_se3_chain_and_loss(dev, order):
+    from deeplio_amd import ops
+    from oracle import se3
+    g = _g(9)
+    B, S = 6, 4
+    t = torch.randn(B, S, 3, generator=g)
+    w = torch.randn(B, S, 3, generator=g) * 0.3
+    w[0, 0] = torch.tensor([1e-8, -2e-8, 3e-9])          # small-angle branch
+    w[1, 1] = torch.tensor([0., 0., 0.])
+    w[2, 0] = torch.tensor([math.pi - 1e-4, 0., 0.])     # near-pi: qw -> 0 fallback territory
+    tr, wr = t.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    p_ref, q_ref = se3.se3_to_SE3(tr, wr, "wxyz" if order == 0 else "xyzw")
+    dp, dq = torch.randn(B, S, 3, generator=g), torch.randn(B, S, 4, generator=g)
+    ((p_ref * dp).sum() + (q_ref * dq).sum()).backward()
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    p, q, R = ops.se3_chain_fwd(t.to(dev), w.to(dev), order, status)
+    assert int(status.item()) & 1 == 0
+    assert rel_err(p, p_ref) < TOL and rel_err(q, q_ref) < TOL
+    dt, dw = ops.se3_chain_bwd(t.to(dev), w.to(dev), R, dp.to(dev), dq.to(dev), order)
+    assert rel_err(dt, tr.grad) < TOL
+    assert rel_err(dw, wr.grad) < 2e-4
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_pose_loss(dev, mode):
+    from deeplio_amd import ops
+    g = _g(10)
+    shapes = [(4, 3, 3), (4, 3, 3), (4, 2, 3), (4, 2, 4)]
+    preds = [torch.randn(s, generator=g) for s in shapes]
+    gts = [torch.randn(s, generator=g) for s in shapes]
+    sx, sq = torch.tensor(0.3), torch.tensor(-3.0)
+    pr = [p.clone().requires_grad_(True) for p in preds]
+    sxr, sqr = sx.clone().requires_grad_(True), sq.clone().requires_grad_(True)
+    L = [F.mse_loss(a, b) for a, b in zip(pr, gts)]
+    if mode == 0:
+        ref = (L[2] + L[0]) * torch.exp(-sxr) + sxr + (L[3] + L[1]) * torch.exp(-sqr) + sqr
+    else:
+        ref = (L[2] + L[0]) + 1125. * (L[3] + L[1])
+    (ref * 0.7).backward()
+    pd, gd = [p.to(dev) for p in preds], [t.to(dev) for t in gts]
+    out = ops.pose_loss_fwd(pd, gd, sx.to(dev), sq.to(dev), 1125., mode)
+    assert rel_err(out[0], ref) < 1e-5
+    gs = torch.tensor(0.7, device=dev)
+    dps, dsx, dsq = ops.pose_loss_bwd(pd, gd, sx.to(dev), sq.to(dev), 1125., mode, out, gs)
+    for a, b in zip(dps, pr):
+        assert rel_err(a, b.grad) < 1e-5
+    if mode == 0:
+        assert rel_err(dsx, sxr.grad) < 1e-5 and rel_err(dsq, sqr.grad) < 1e-5
+
+
+def test_adam_sgd_match_torch_optim(dev):
+    from deeplio_amd import ops
+    g = _g(11)
+    n = 10007
+    p0 = torch.randn(n, generator=g)
+    grads = [torch.randn(n, generator=g) * (10 ** -i) for i in range(5)]
+    pr = p0.clone().double().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-3, weight_decay=1e-4)
+    p = p0.clone().to(dev)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for i, gr in enumerate(grads):
+        pr.grad = gr.double()
+        opt.step()
+        ops.adam_step(p, gr.to(dev), m, v, 1e-3, 0.9, 0.999, 1e-8, 1e-4, i + 1)
+        assert rel_err(p, pr) < 1e-5
+    pr = p0.clone().double().requires_grad_(True)
+    opt = torch.optim.SGD([pr], lr=1e-2, weight_decay=1e-4, momentum=0.9)
+    p = p0.clone().to(dev)
+    buf = torch.zeros_like(p)
+    for i, gr in enumerate(grads):
+        pr.grad = gr.double()
+        opt.step()
+        ops.sgd_step(p, gr.to(dev), buf, 1e-2, 0.9, 1e-4, i + 1)
+        assert rel_err(p, pr) < 1e-5
+    ss = ops.sumsq(grads[0].to(dev))
+    assert rel_err(ss, (grads[0].double() ** 2).sum()) < 1e-6
