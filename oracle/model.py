@@ -338,14 +338,19 @@ class ImuFeatFC(_Feat):
         self.output_shape = [1, ctx.seq_size, hs[-1]]
 
     def forward(self, x):
-        if not torch.is_tensor(x):
-            x = torch.stack([torch.stack(list(xb)) for xb in x])
-        y = x
-        for m in self.net:
-            y = F.leaky_relu(m(y), 0.01)
-        if self.p > 0.:
-            y = self.dropout(y)
-        return y.sum(2)
+        # per-(b, s) loops as in the reference: a batched restatement is mathematically equal
+        # but rounds differently, and Adam amplifies that to 1e-3 within five steps
+        outs = []
+        nb, ns = len(x), len(x[0])
+        for b in range(nb):
+            for s in range(ns):
+                y = x[b][s]
+                for m in self.net:
+                    y = F.leaky_relu(m(y), 0.01)
+                if self.p > 0.:
+                    y = self.dropout(y)
+                outs.append(torch.sum(y, dim=0))
+        return torch.stack(outs).view(nb, ns, -1)
 
 
 def _make_rnn(cfg, input_size, p):

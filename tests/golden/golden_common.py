@@ -1,0 +1,107 @@
+"""Shared by make_golden.py (runs where /root/reference exists) and the parity tests (run
+anywhere): deterministic weight filling, synthetic batches, checksums, golden case table."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from deeplio_amd.config import make_config  # noqa: E402
+
+
+def fill_state(module, seed):
+    """Overwrite every state_dict tensor from numpy's PCG64 (platform-stable), seeded per KEY
+    (seed, crc32(key)) so the values do not depend on module registration order.
+    >=2-D: N(0,1)/sqrt(fan_in); BN gamma (1-D '.weight'): 1+0.1N; running_var: U(0.5,1.5);
+    other 1-D: 0.1N; integer buffers: 0."""
+    import zlib
+    sd = module.state_dict()
+    with torch.no_grad():
+        for key in sd:
+            t = sd[key]
+            rng = np.random.default_rng([seed, zlib.crc32(key.encode())])
+            if not t.dtype.is_floating_point:
+                t.zero_()
+                continue
+            shape = tuple(t.shape)
+            if t.dim() >= 2:
+                v = rng.standard_normal(shape) / np.sqrt(float(np.prod(shape[1:])))
+            elif key.endswith("running_var"):
+                v = rng.uniform(0.5, 1.5, shape)
+            elif t.dim() == 1 and key.endswith(".weight"):
+                v = 1.0 + 0.1 * rng.standard_normal(shape)
+            else:
+                v = 0.1 * rng.standard_normal(shape)
+            t.copy_(torch.from_numpy(np.asarray(v, dtype=np.float32)).reshape(shape))
+    return module
+
+
+def make_batch(seed, B, S, C, H, W, T):
+    """Synthetic batch in the reference's model-input layout (trainer.py:453-458)."""
+    rng = np.random.default_rng(seed)
+    f = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32))
+    xyz = f(rng.standard_normal((B, S, 2, C, H, W)))
+    nrm = f(rng.standard_normal((B, S, 2, C, H, W)))
+    imu = f(rng.uniform(0, 1, (B, S, T, 6)))
+    gt_f2f = f(np.concatenate([0.1 * rng.standard_normal((B, S, 3)), 0.01 * rng.standard_normal((B, S, 3))], -1))
+    q = rng.standard_normal((B, S, 4))
+    q /= np.linalg.norm(q, axis=-1, keepdims=True)
+    gt_f2g = f(np.concatenate([rng.standard_normal((B, S, 3)), q], -1))
+    return xyz, nrm, imu, gt_f2f, gt_f2g
+
+
+def checksum(t):
+    """(sum, abs-sum, first 4, last 4 elements) as float64."""
+    a = t.detach().double().flatten()
+    head = torch.zeros(4, dtype=torch.float64)
+    tail = torch.zeros(4, dtype=torch.float64)
+    n = min(4, a.numel())
+    head[:n] = a[:n]
+    tail[:n] = a[-n:]
+    return torch.cat([a.sum()[None], a.abs().sum()[None], head, tail]).numpy()
+
+
+# name -> (cfg kwargs, geometry) -- G2 whole-model cases at tiny geometry + BASELINE cfg1 geometry
+NO_DROP = {'deeplio/dropout': 0., 'lidar-feat-pointseg/dropout': 0., 'lidar-feat-resnet/dropout': 0.,
+           'lidar-feat-simple-1/dropout': 0., 'lidar-feat-flownet/dropout': 0., 'imu-feat-rnn/dropout': 0.}
+SMALL_RNN = {'imu-feat-rnn/hidden-size': 32, 'odom-feat-rnn/hidden-size': 64}
+
+
+def _ov(*ds):
+    o = {}
+    for d in ds:
+        o.update(d)
+    return o
+
+
+MODEL_CASES = {
+    # PointSeg + bi-LSTM (BASELINE config 2 architecture), fusion-layer-cat keeps backward defined (Q2)
+    "pointseg_lstm_cat": dict(cfg=dict(lidar="lidar-feat-pointseg", imu="imu-feat-rnn", fusion="fusion-layer-cat",
+                                       odom="odom-feat-rnn", seq=2, overrides=_ov(NO_DROP, SMALL_RNN)),
+                              geom=dict(B=2, S=2, C=5, H=16, W=64, T=7)),
+    "pointseg_lstm_soft_sub": dict(cfg=dict(lidar="lidar-feat-pointseg", imu="imu-feat-rnn", fusion="fusion-layer-soft",
+                                            odom="odom-feat-rnn", seq=3,
+                                            overrides=_ov(NO_DROP, SMALL_RNN, {'lidar-feat-pointseg/fusion': 'sub'})),
+                                   geom=dict(B=2, S=3, C=3, H=16, W=64, T=5)),
+    "flownet_gru_cat": dict(cfg=dict(lidar="lidar-feat-flownet", imu="imu-feat-rnn", fusion="fusion-layer-cat",
+                                     odom="odom-feat-rnn", seq=2,
+                                     overrides=_ov(NO_DROP, SMALL_RNN, {'imu-feat-rnn/type': 'gru'})),
+                            geom=dict(B=2, S=2, C=3, H=16, W=64, T=7)),
+    "resnet_lstm_cat": dict(cfg=dict(lidar="lidar-feat-resnet", imu="imu-feat-rnn", fusion="fusion-layer-cat",
+                                     odom="odom-feat-fc", seq=2, overrides=_ov(NO_DROP, SMALL_RNN)),
+                            geom=dict(B=2, S=2, C=3, H=16, W=64, T=7)),
+    # BASELINE config 1: simple-1 + imu-fc at 64x512, C=2 (soft fusion works with leaky-ReLU features)
+    "simple1_fc_soft_cfg1": dict(cfg=dict(lidar="lidar-feat-simple-1", imu="imu-feat-fc", fusion="fusion-layer-soft",
+                                          odom="odom-feat-rnn", seq=2,
+                                          overrides=_ov(NO_DROP, {'odom-feat-rnn/hidden-size': 64})),
+                                 geom=dict(B=2, S=2, C=2, H=64, W=512, T=10)),
+}
+
+
+def case_cfg(name):
+    return make_config(**MODEL_CASES[name]['cfg'])

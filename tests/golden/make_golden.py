@@ -1,0 +1,323 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/*.npz by importing the REFERENCE itself.
+
+Runs only where /root/reference exists (the build container); nothing here travels in
+compiled or source form -- only the .npz input/output vectors are committed.
+
+Recipe: six third-party imports of the reference are absent from this
+image and are registered as stand-in modules BEFORE importing it:
+  open3d, tensorboardX, torch.utils.tensorboard, pytorch_model_summary,
+  torchvision.utils                                                -> inert
+  torchvision.models.resnet.{BasicBlock,conv1x1,conv3x3}           -> oracle.model.BasicBlock
+  liegroups.torch.SO3                                              -> oracle.se3
+The last two carry arithmetic, so goldens that flow through them (ResNet family, SE(3)
+chain, GT transform) pin the reference's OWN code around a restated dependency; the
+restated SO(3) maths is cross-checked against the reference's in-tree
+deeplio/common/spatial.py (golden `spatial`).
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import golden_common as gc  # noqa: E402
+
+from oracle import model as omodel  # noqa: E402
+from oracle import se3 as ose3  # noqa: E402
+
+REF = "/root/reference"
+
+
+def install_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Any:
+        def __init__(self, *a, **k):
+            pass
+
+        def __getattr__(self, n):
+            return lambda *a, **k: None
+
+    mod("open3d")
+    mod("tensorboardX", SummaryWriter=_Any)
+    tb = mod("torch.utils.tensorboard", SummaryWriter=_Any)   # tester.py:15 (tensorboard pkg absent)
+    import torch.utils
+    torch.utils.tensorboard = tb
+    mod("pytorch_model_summary", summary=lambda *a, **k: "")
+
+    class _BB(omodel.BasicBlock):
+        def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1, base_width=64,
+                     dilation=1, norm_layer=None):
+            super().__init__(inplanes, planes, stride, downsample)
+
+    def conv3x3(i, o, stride=1, groups=1, dilation=1):
+        return torch.nn.Conv2d(i, o, 3, stride, dilation, bias=False)
+
+    def conv1x1(i, o, stride=1):
+        return torch.nn.Conv2d(i, o, 1, stride, bias=False)
+
+    tv = mod("torchvision")
+    tv.models = mod("torchvision.models")
+    tv.utils = mod("torchvision.utils", make_grid=lambda x, *a, **k: x)
+    tv.models.resnet = mod("torchvision.models.resnet", BasicBlock=_BB, Bottleneck=type("Bottleneck", (), {}),
+                           conv1x1=conv1x1, conv3x3=conv3x3)
+
+    class SO3:
+        def __init__(self, mat):
+            self.mat = mat
+
+        @classmethod
+        def exp(cls, phi):
+            return cls(ose3.so3_exp(phi))
+
+        @classmethod
+        def from_matrix(cls, mat, normalize=False):
+            if normalize and not ose3.is_valid_rotation(mat.detach()):
+                mat = ose3.normalize_rotation(mat)
+            return cls(mat)
+
+        def as_matrix(self):
+            return self.mat
+
+        def log(self):
+            return ose3.so3_log(self.mat)
+
+        def to_quaternion(self, ordering="wxyz"):
+            return ose3.rot_to_quat(self.mat, ordering)
+
+    lg = mod("liegroups")
+    lg.torch = mod("liegroups.torch", SO3=SO3, utils=mod("liegroups.torch.utils"))
+
+
+def ref_model(cfg, input_shape):
+    from deeplio.models import nets
+    from deeplio.models.misc import build_config_container
+    args = types.SimpleNamespace(device="cpu", batch_size=2)
+    build_config_container(cfg, args)
+    return nets.get_model(input_shape, cfg, "cpu")
+
+
+def ref_train_forward(model, criterion, batch):
+    """the reference's own step pieces: trainer.py:238-263"""
+    from deeplio.models.trainer import Trainer
+    xyz, nrm, imu, gt_f2f, gt_f2g = batch
+    pt, pw = model([[xyz, nrm], imu])
+    dummy = types.SimpleNamespace(device="cpu")
+    pp, pq = Trainer.se3_to_SE3(dummy, pt, pw)
+    loss = criterion(pt, pw, pp[:, 1:3], pq[:, 1:3], gt_f2f[:, :, 0:3], gt_f2f[:, :, 3:],
+                     gt_f2g[:, 1:3, 0:3], gt_f2g[:, 1:3, 3:7])
+    return pt, pw, pp, pq, loss
+
+
+def golden_models(out):
+    from deeplio import losses as rlosses
+    for name, case in gc.MODEL_CASES.items():
+        g = case['geom']
+        cfg = gc.case_cfg(name)
+        torch.manual_seed(0)
+        model = ref_model(cfg, (g['C'], g['H'], g['W']))
+        gc.fill_state(model, seed=1000)
+        batch = gc.make_batch(2000, g['B'], g['S'], g['C'], g['H'], g['W'], g['T'])
+        res = {}
+        model.eval()
+        with torch.no_grad():
+            pos, ori = model([[batch[0].clone(), batch[1].clone()], batch[2].clone()])
+        res['eval_pos'], res['eval_ori'] = pos.numpy(), ori.numpy()
+        # train-mode forward / backward (batch statistics, dropout 0)
+        model.train()
+        crit = rlosses.get_loss_function(cfg, "cpu")
+        try:
+            pt, pw, pp, pq, loss = ref_train_forward(model, crit, tuple(t.clone() for t in batch))
+            res['train_pos'], res['train_ori'] = pt.detach().numpy(), pw.detach().numpy()
+            res['f2g_p'], res['f2g_q'] = pp.detach().numpy(), pq.detach().numpy()
+            res['loss'] = np.asarray(loss.item())
+            loss.backward()
+            keys, sums = [], []
+            for k, p in list(model.named_parameters()) + [("criterion.sx", crit.sx), ("criterion.sq", crit.sq)]:
+                if p.grad is not None:
+                    keys.append(k)
+                    sums.append(gc.checksum(p.grad))
+            res['grad_keys'] = np.asarray(keys)
+            res['grad_sums'] = np.stack(sums)
+            bk, bs = [], []
+            for k, b in model.named_buffers():
+                if k.endswith("running_mean") or k.endswith("running_var"):
+                    bk.append(k)
+                    bs.append(gc.checksum(b))
+            if bk:
+                res['buf_keys'], res['buf_sums'] = np.asarray(bk), np.stack(bs)
+            res['has_bwd'] = np.asarray(1)
+        except RuntimeError as e:      # in-place soft fusion breaks autograd
+            assert "inplace" in str(e), e
+            res['has_bwd'] = np.asarray(0)
+        out["model_" + name] = res
+        print("model", name, "eval_pos", res['eval_pos'].flatten()[:3], "bwd", int(res['has_bwd']))
+
+
+def golden_train_trajectory(out):
+    """G6: 5 Adam steps (lr 1e-3, wd 1e-4) of the reference's own step on a fixed batch."""
+    from deeplio import losses as rlosses
+    from deeplio.models.optimizer import create_optimizer
+    for name in ("simple1_fc_soft_cfg1", "pointseg_lstm_cat"):
+        g = gc.MODEL_CASES[name]['geom']
+        cfg = gc.case_cfg(name)
+        model = ref_model(cfg, (g['C'], g['H'], g['W']))
+        gc.fill_state(model, seed=1000)
+        model.train()
+        crit = rlosses.get_loss_function(cfg, "cpu")
+        args = types.SimpleNamespace(lr=1e-3, weight_decay=1e-4, momentum=0.9)
+        opt = create_optimizer([{'params': model.parameters()}, {'params': crit.parameters()}], cfg, args)
+        batch = gc.make_batch(2000, g['B'], g['S'], g['C'], g['H'], g['W'], g['T'])
+        losses = []
+        for _ in range(5):
+            *_, loss = ref_train_forward(model, crit, tuple(t.clone() for t in batch))
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        out["traj_" + name] = dict(losses=np.asarray(losses), sx=np.asarray(crit.sx.item()),
+                                   sq=np.asarray(crit.sq.item()))
+        print("traj", name, losses)
+
+
+def golden_se3_loss(out):
+    from deeplio import losses as rlosses
+    from deeplio.models.tester import Tester
+    from deeplio.models.trainer import Trainer
+    rng = np.random.default_rng(3000)
+    B, S = 16, 4
+    t = torch.from_numpy(rng.standard_normal((B, S, 3)).astype(np.float32))
+    w = torch.from_numpy((0.4 * rng.standard_normal((B, S, 3))).astype(np.float32))
+    w[0, 0] = torch.tensor([1e-8, -2e-8, 3e-9])
+    w[1, 2] = 0.
+    dummy = types.SimpleNamespace(device="cpu")
+    tr, wr = t.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    p, q = Trainer.se3_to_SE3(dummy, tr, wr)
+    dp = torch.from_numpy(rng.standard_normal((B, S, 3)).astype(np.float32))
+    dq = torch.from_numpy(rng.standard_normal((B, S, 4)).astype(np.float32))
+    ((p * dp).sum() + (q * dq).sum()).backward()
+    p2, q2 = Tester.se3_to_SE3(dummy, t, w)            # xyzw variant through spatial.py
+    out["se3"] = dict(t=t.numpy(), w=w.numpy(), p=p.detach().numpy(), q=q.detach().numpy(), dp=dp.numpy(),
+                      dq=dq.numpy(), dt=tr.grad.numpy(), dw=wr.grad.numpy(), q_tester_xyzw=q2.numpy())
+    # losses (G4)
+    cfg = gc.make_config()
+    res = {}
+    shapes = [(4, 3, 3), (4, 3, 3), (4, 2, 3), (4, 2, 4)]
+    preds = [torch.from_numpy(rng.standard_normal(s).astype(np.float32)) for s in shapes]
+    gts = [torch.from_numpy(rng.standard_normal(s).astype(np.float32)) for s in shapes]
+    for i in range(4):
+        res["pred%d" % i], res["gt%d" % i] = preds[i].numpy(), gts[i].numpy()
+    for active in ("hwsloss", "lwsloss"):
+        for lt in ("local", "global", "local+global"):
+            cfg['losses']['active'], cfg['losses']['loss-type'] = active, lt
+            crit = rlosses.get_loss_function(cfg, "cpu")
+            pr = [x.clone().requires_grad_(True) for x in preds]
+            loss = crit(*pr, *gts)
+            loss.backward()
+            tag = "%s_%s" % (active, lt.replace("+", "_"))
+            res[tag + "_loss"] = np.asarray(loss.item())
+            for i in range(4):
+                gr = pr[i].grad
+                res[tag + "_d%d" % i] = (gr if gr is not None else torch.zeros_like(pr[i])).numpy()
+            if active == "hwsloss":
+                res[tag + "_dsx"], res[tag + "_dsq"] = np.asarray(crit.sx.grad.item()), np.asarray(crit.sq.grad.item())
+    out["loss"] = res
+
+
+def golden_spatial(out):
+    """reference in-tree SO(3) functions (deeplio/common/spatial.py) on random rotations:
+    the second oracle for the restated liegroups maths."""
+    from deeplio.common import spatial
+    rng = np.random.default_rng(4000)
+    w = torch.from_numpy((0.5 * rng.standard_normal((256, 3))).astype(np.float32))
+    R = spatial.rotation_matrix_log_to_exp(w)                     # [N,3,3]
+    out["spatial"] = dict(w=w.numpy(), R=R.numpy(),
+                          log=spatial.rotation_matrix_exp_to_log(R).numpy(),
+                          quat_xyzw=spatial.rotation_matrix_to_quaternion(R).numpy())
+
+
+def golden_gt_and_lr(out):
+    from deeplio.models.misc import DataCombiCreater, PolynomialLRDecay, build_config_container
+    cfg = gc.make_config(seq=3)
+    build_config_container(cfg, types.SimpleNamespace(device="cpu", batch_size=2))
+    rng = np.random.default_rng(5000)
+    S1 = 4
+    gts = []
+    R, t = torch.eye(3), torch.zeros(3)
+    for i in range(S1):
+        R = R @ ose3.so3_exp(torch.from_numpy((0.05 * rng.standard_normal(3)).astype(np.float32)))
+        t = t + torch.from_numpy(rng.standard_normal(3).astype(np.float32))
+        gts.append(torch.cat([t, R.flatten(), torch.zeros(3)]))
+    gts = torch.stack(gts)
+    dc = DataCombiCreater(combinations=np.array(cfg['datasets']['combinations']), device="cpu")
+    f2f, f2g = dc.process_ground_turth(gts)
+    res = dict(gts=gts.numpy(), f2f=f2f.numpy(), f2g=f2g.numpy())
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=1e-3)
+    sch = PolynomialLRDecay(opt, max_decay_steps=30, end_learning_rate=1e-6, power=2.0)
+    lrs = []
+    for _ in range(33):
+        lrs.append(opt.param_groups[0]['lr'])
+        opt.step()
+        sch.step()
+    res['lr_table'] = np.asarray(lrs)
+    out["gt_lr"] = res
+
+
+def golden_projection(out):
+    """G8 ('next' row 1): LaserScan.do_range_projection / do_normal_projection on a seeded
+    synthetic cloud (no exact depth ties; numpy argsort is unstable)."""
+    from deeplio.common.laserscan import LaserScan
+    rng = np.random.default_rng(6000)
+    n = 20000
+    az = rng.uniform(-np.pi, np.pi, n)
+    el = np.deg2rad(rng.uniform(-24.5, 2.5, n))
+    r = rng.uniform(2.0, 60.0, n)
+    pts = np.stack([r * np.cos(el) * np.cos(az), r * np.cos(el) * np.sin(az), r * np.sin(el)], 1).astype(np.float32)
+    rem = rng.uniform(0, 1, n).astype(np.float32)
+    scan = LaserScan(project=False, H=64, W=512, fov_up=3.0, fov_down=-25.0)
+    scan.set_points(pts, rem)
+    scan.do_range_projection()
+    normals = scan.do_normal_projection()
+    out["projection"] = dict(points=pts, remissions=rem, proj_x=scan.proj_x, proj_y=scan.proj_y,
+                             proj_idx=scan.proj_idx, proj_range=scan.proj_range, proj_xyz=scan.proj_xyz,
+                             proj_remission=scan.proj_remission, normals=normals.astype(np.float32))
+
+
+def main():
+    assert os.path.isdir(REF), "the reference checkout is required to regenerate goldens"
+    install_stubs()
+    sys.path.insert(0, REF)
+    torch.set_num_threads(8)
+    out = {}
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)        # the reference's logger writes ./deeplio.txt
+        try:
+            golden_spatial(out)
+            golden_se3_loss(out)
+            golden_gt_and_lr(out)
+            golden_projection(out)
+            golden_models(out)
+            golden_train_trajectory(out)
+        finally:
+            os.chdir(cwd)
+    for name, d in out.items():
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **d)
+        print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()
