@@ -62,6 +62,8 @@ SIGNATURES = {
     "dlio_linear_bwd_data": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p]),
     "dlio_linear_bwd_weight": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _p]),
     "dlio_ew_binary": (_i, [_p, _p, _p, _i64, _i, _p]),
+    "dlio_seg_sum_fwd": (_i, [_p, _p, _i, _i, _i, _p]),
+    "dlio_seg_sum_bwd": (_i, [_p, _p, _i, _i, _i, _p]),
     "dlio_ew_scale": (_i, [_p, _f, _p, _i64, _p]),
     "dlio_copy2d": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
     "dlio_dropout_fwd": (_i, [_p, _p, _p, _i64, _f, _u64, _u64, _p]),

@@ -167,7 +167,31 @@ __global__ void ew_binary_kernel(const float* __restrict__ a, const float* __res
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
     const float u = a[i], v = b[i];
-    y[i] = op == 0 ? u + v : (op == 1 ? u - v : u * v);
+    y[i] = op == 0 ? u + v : (op == 1 ? u - v : (op == 2 ? u * v : fmaxf(u + v, 0.f)));
+  }
+}
+
+// y[g][c] = sum_r x[g][r][c]   /   dx[g][r][c] = dy[g][c]
+__global__ void seg_sum_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int groups,
+                                   int rows, int cols) {
+  const int64_t total = (int64_t)groups * cols;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i / cols), c = (int)(i - (int64_t)g * cols);
+    const float* p = x + (size_t)g * rows * cols + c;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += p[(size_t)r * cols];
+    y[i] = s;
+  }
+}
+__global__ void seg_sum_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int groups,
+                                   int rows, int cols) {
+  const int64_t total = (int64_t)groups * rows * cols;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cols);
+    const int g = (int)(i / ((int64_t)rows * cols));
+    dx[i] = dy[(size_t)g * cols + c];
   }
 }
 
@@ -295,9 +319,25 @@ extern "C" int dlio_linear_bwd_weight(const float* dz, int lddz, const float* x,
 
 extern "C" int dlio_ew_binary(const float* a, const float* b, float* y, int64_t n, int op,
                               dlio_stream_t stream) {
-  if (!a || !b || !y || n <= 0 || op < 0 || op > 2) return DLIO_EINVAL;
+  if (!a || !b || !y || n <= 0 || op < 0 || op > 3) return DLIO_EINVAL;
   hipLaunchKernelGGL(ew_binary_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, as_stream(stream), a,
                      b, y, n, op);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_seg_sum_fwd(const float* x, float* y, int groups, int rows, int cols,
+                                dlio_stream_t stream) {
+  if (!x || !y || groups <= 0 || rows <= 0 || cols <= 0) return DLIO_EINVAL;
+  hipLaunchKernelGGL(seg_sum_fwd_kernel, dim3(ew_grid((int64_t)groups * cols, 256)), dim3(256), 0,
+                     as_stream(stream), x, y, groups, rows, cols);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_seg_sum_bwd(const float* dy, float* dx, int groups, int rows, int cols,
+                                dlio_stream_t stream) {
+  if (!dy || !dx || groups <= 0 || rows <= 0 || cols <= 0) return DLIO_EINVAL;
+  hipLaunchKernelGGL(seg_sum_bwd_kernel, dim3(ew_grid((int64_t)groups * rows * cols, 256)),
+                     dim3(256), 0, as_stream(stream), dy, dx, groups, rows, cols);
   return dlio_check_launch();
 }
 

@@ -1,0 +1,553 @@
+"""torch.autograd.Function wrappers that compose the C-ABI kernels into the layers of the
+DeepLIO hot path.  Every forward/backward below is a sequence of libdeeplio_hip launches on
+the current HIP stream; torch supplies storage, views and the autograd tape only.
+
+Activations are fp32 NCHW.  Concatenations (Fire's expand1x1 || expand3x3) are never
+materialised by a copy: both convolutions write channel slices of one buffer.
+"""
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+_E = torch.empty
+
+
+def _new(shape, like):
+    return _E(shape, dtype=torch.float32, device=like.device)
+
+
+# =============================================================================== conv + BN + ReLU
+class _CBR:
+    """conv (+bias) -> [ReLU] -> BatchNorm -> [ReLU] over channel slices, forward and backward.
+    pre_relu  = conv->ReLU->BN  (FeatureNetSimple1, lidar_feat_nets.py:308-309)
+    post_relu = conv->BN->ReLU  (everything else)."""
+
+    @staticmethod
+    def forward(x, x_ctot, x_coff, Cin, H, W, weight, bias, gamma, beta, rmean, rvar, stride, pad,
+                training, momentum, eps, pre_relu, post_relu, raw, raw_ctot, raw_coff, out, out_ctot,
+                out_coff, N, residual=None, r_ctot=0, r_coff=0):
+        Cout, _, KH, KW = weight.shape
+        d = ops.conv_desc(N, Cin, H, W, Cout, KH, KW, stride[0], stride[1], pad[0], pad[1],
+                          in_ctot=x_ctot, in_coff=x_coff, out_ctot=raw_ctot, out_coff=raw_coff)
+        wt = ops.conv2d_prep_weight(weight, 0)
+        ops.conv2d_fwd(x, wt, bias, raw, d)
+        OHW = d.OH * d.OW
+        if training:
+            st = ops.chan_stats(raw, N, raw_ctot, raw_coff, Cout, OHW, pre_relu)
+            prm = ops.bn_finalize(st, N * OHW, gamma, eps, momentum, rmean, rvar)
+        else:
+            prm = ops.bn_eval_params(rmean, rvar, gamma, eps)
+        ops.bn_apply(raw, raw_ctot, raw_coff, prm, beta, out, out_ctot, out_coff, N, Cout, OHW,
+                     pre_relu, post_relu, residual, r_ctot, r_coff)
+        return d, prm
+
+    @staticmethod
+    def backward(dy, dy_ctot, dy_coff, x, d, weight, has_bias, prm, beta, raw, training, pre_relu,
+                 post_relu, draw, need_dx, dx=None, dx_ctot=0, dx_coff=0, dx_residual=None,
+                 dxr_ctot=0, dxr_coff=0, dx_accumulate=False):
+        """dy: grad wrt the activated output (slice).  draw: scratch [N,Cout,OH,OW] (contiguous).
+        Returns (dweight, dbias, dgamma, dbeta); writes dx (slice) if need_dx:
+        dx = dgrad (+ dx_residual) (+ previous dx when dx_accumulate)."""
+        N, Cout, OHW = d.N, d.Cout, d.OH * d.OW
+        dgamma, dbeta = _new((Cout,), dy), _new((Cout,), dy)
+        ops.bn_bwd(dy, dy_ctot, dy_coff, raw, d.out_ctot, d.out_coff, prm, beta, draw, Cout, 0, N,
+                   Cout, OHW, pre_relu, post_relu, training, dgamma, dbeta)
+        dbias = ops.chan_sum(draw, N, Cout, 0, Cout, OHW) if has_bias else None
+        dw = _new(tuple(weight.shape), dy)
+        dd = ops.conv_desc(N, d.Cin, d.H, d.W, Cout, d.KH, d.KW, d.SH, d.SW, d.PH, d.PW, OH=d.OH,
+                           OW=d.OW, in_ctot=d.in_ctot, in_coff=d.in_coff, out_ctot=Cout, out_coff=0)
+        ops.conv2d_wgrad(x, draw, dw, dd)
+        if need_dx:
+            conv_dgrad(draw, weight, d, dx, dx_ctot, dx_coff, dx_residual, dxr_ctot, dxr_coff,
+                       dx_accumulate)
+        return dw, dbias, dgamma, dbeta
+
+
+def conv_dgrad(dy, weight, d, dx, dx_ctot, dx_coff, residual=None, r_ctot=0, r_coff=0,
+               accumulate=False):
+    """dy: contiguous [N,Cout,OH,OW] -> dx channel slice.  Stride-1 convs reuse the MFMA
+    forward kernel with tap-reversed, transposed weights."""
+    N, Cin, Cout = d.N, d.Cin, d.Cout
+    if accumulate:
+        residual, r_ctot, r_coff = dx, dx_ctot, dx_coff
+    if d.SH == 1 and d.SW == 1:
+        wt2 = ops.conv2d_prep_weight(weight, 1)
+        g = ops.conv_desc(N, Cout, d.OH, d.OW, Cin, d.KH, d.KW, 1, 1, d.KH - 1 - d.PH,
+                          d.KW - 1 - d.PW, OH=d.H, OW=d.W, in_ctot=Cout, in_coff=0, out_ctot=dx_ctot,
+                          out_coff=dx_coff, res_ctot=r_ctot, res_coff=r_coff)
+        ops.conv2d_fwd(dy, wt2, None, dx, g, residual=residual)
+    else:
+        if residual is not None or dx_ctot != Cin or dx_coff != 0:
+            raise ValueError("strided dgrad supports plain outputs only")
+        g = ops.conv_desc(N, Cin, d.H, d.W, Cout, d.KH, d.KW, d.SH, d.SW, d.PH, d.PW, OH=d.OH,
+                          OW=d.OW, in_ctot=Cin, in_coff=0, out_ctot=Cout, out_coff=0)
+        ops.conv2d_dgrad_strided(dy, weight, dx, g)
+    return dx
+
+
+class ConvBnAct(Function):
+    """One conv+BN(+ReLU) layer.  Used by the PointSeg stem (pointseg_net.py:18-20), FlowNet
+    conv() blocks (base_net.py:55-71), ResNet (resnet.py:36-38 + BasicBlock) and Simple-1."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, rmean, rvar, stride, pad, training, momentum,
+                eps, pre_relu, post_relu):
+        x = x.contiguous()
+        N, Cin, H, W = x.shape
+        Cout, _, KH, KW = weight.shape
+        OH = (H + 2 * pad[0] - KH) // stride[0] + 1
+        OW = (W + 2 * pad[1] - KW) // stride[1] + 1
+        raw = _new((N, Cout, OH, OW), x)
+        out = _new((N, Cout, OH, OW), x)
+        d, prm = _CBR.forward(x, Cin, 0, Cin, H, W, weight, bias, gamma, beta, rmean, rvar, stride,
+                              pad, training, momentum, eps, pre_relu, post_relu, raw, Cout, 0, out,
+                              Cout, 0, N)
+        ctx.save_for_backward(x, weight, beta, raw, prm)
+        ctx.cfg = (d, bias is not None, training, pre_relu, post_relu)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, beta, raw, prm = ctx.saved_tensors
+        d, has_bias, training, pre_relu, post_relu = ctx.cfg
+        dy = dy.contiguous()
+        draw = torch.empty_like(raw)
+        need_dx = ctx.needs_input_grad[0]
+        dx = torch.empty_like(x) if need_dx else None
+        dw, db, dg, dbt = _CBR.backward(dy, d.Cout, 0, x, d, weight, has_bias, prm, beta, raw,
+                                        training, pre_relu, post_relu, draw, need_dx, dx, d.Cin, 0)
+        return (dx, dw, db, dg, dbt) + (None,) * 9
+
+
+# =============================================================================== Fire
+class FireFn(Function):
+    """Fire block (pointseg_modules.py:116-142) as ONE tape node: squeeze CBR, then the two
+    expand convolutions write the halves of the concatenated output; 'simple' bypass is the
+    residual operand of the BN-apply kernels."""
+
+    @staticmethod
+    def forward(ctx, x, sw, sb, sg, sbe, srm, srv, e1w, e1b, e1g, e1be, e1rm, e1rv, e3w, e3b, e3g,
+                e3be, e3rm, e3rv, training, momentum, eps, bypass):
+        x = x.contiguous()
+        N, Cin, H, W = x.shape
+        S_, E1, E3 = sw.shape[0], e1w.shape[0], e3w.shape[0]
+        CE = E1 + E3
+        raw_s, act_s = _new((N, S_, H, W), x), _new((N, S_, H, W), x)
+        d_s, prm_s = _CBR.forward(x, Cin, 0, Cin, H, W, sw, sb, sg, sbe, srm, srv, (1, 1), (0, 0),
+                                  training, momentum, eps, False, True, raw_s, S_, 0, act_s, S_, 0, N)
+        raw_e, out = _new((N, CE, H, W), x), _new((N, CE, H, W), x)
+        res = x if bypass else None
+        d_1, prm_1 = _CBR.forward(act_s, S_, 0, S_, H, W, e1w, e1b, e1g, e1be, e1rm, e1rv, (1, 1),
+                                  (0, 0), training, momentum, eps, False, True, raw_e, CE, 0, out,
+                                  CE, 0, N, res, Cin, 0)
+        d_3, prm_3 = _CBR.forward(act_s, S_, 0, S_, H, W, e3w, e3b, e3g, e3be, e3rm, e3rv, (1, 1),
+                                  (1, 1), training, momentum, eps, False, True, raw_e, CE, E1, out,
+                                  CE, E1, N, res, Cin, E1)
+        ctx.save_for_backward(x, sw, sbe, e1w, e1be, e3w, e3be, raw_s, act_s, raw_e, prm_s, prm_1,
+                              prm_3)
+        ctx.cfg = (d_s, d_1, d_3, training, bypass)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x, sw, sbe, e1w, e1be, e3w, e3be, raw_s, act_s, raw_e, prm_s, prm_1, prm_3) = ctx.saved_tensors
+        d_s, d_1, d_3, training, bypass = ctx.cfg
+        dout = dout.contiguous()
+        N, Cin, H, W = x.shape
+        S_, E1, E3 = sw.shape[0], e1w.shape[0], e3w.shape[0]
+        CE = E1 + E3
+        dact_s = _new((N, S_, H, W), x)
+        draw1 = _new((N, E1, H, W), x)
+        g1 = _CBR.backward(dout, CE, 0, act_s, d_1, e1w, True, prm_1, e1be, raw_e, training, False,
+                           True, draw1, True, dact_s, S_, 0)
+        del draw1
+        draw3 = _new((N, E3, H, W), x)
+        g3 = _CBR.backward(dout, CE, E1, act_s, d_3, e3w, True, prm_3, e3be, raw_e, training, False,
+                           True, draw3, True, dact_s, S_, 0, dx_accumulate=True)
+        del draw3
+        need_dx = ctx.needs_input_grad[0]
+        dx = torch.empty_like(x) if need_dx else None
+        draw_s = _new((N, S_, H, W), x)
+        gs = _CBR.backward(dact_s, S_, 0, x, d_s, sw, True, prm_s, sbe, raw_s, training, False, True,
+                           draw_s, need_dx, dx, Cin, 0, dout if bypass else None, CE, 0)
+        return (dx, gs[0], gs[1], gs[2], gs[3], None, None, g1[0], g1[1], g1[2], g1[3], None, None,
+                g3[0], g3[1], g3[2], g3[3], None, None, None, None, None, None)
+
+
+# =============================================================================== pooling / SE
+class MaxPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x, k, stride, pad, ceil_mode):
+        x = x.contiguous()
+        y, idx = ops.maxpool2d_fwd(x, k, stride[0], stride[1], pad[0], pad[1], ceil_mode)
+        ctx.save_for_backward(idx)
+        ctx.cfg = (tuple(x.shape), k, stride, pad)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        shape, k, stride, pad = ctx.cfg
+        dx = ops.maxpool2d_bwd(dy.contiguous(), idx, shape, k, stride[0], stride[1], pad[0], pad[1])
+        return dx, None, None, None, None
+
+
+class SEPoolFn(Function):
+    """SELayer (pointseg_modules.py:216-221) fused with the MaxPool2d that always follows it in
+    PSEncoder (pointseg_net.py:27-46): the channel re-weighting is applied while pooling, so the
+    scaled full-resolution tensor is never written.  pool=None gives the plain SELayer."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, pool):
+        x = x.contiguous()
+        N, C_, H, W = x.shape
+        g = ops.gap_fwd(x, N, C_, 0, C_, H * W)
+        h = ops.linear_fwd(g, w1, None, ops.ACT_RELU)
+        s = ops.linear_fwd(h, w2, None, ops.ACT_SIGMOID)
+        if pool is None:
+            y, idx = ops.chan_scale_fwd(x, s), None
+        else:
+            k, stride, pad = pool
+            y, idx = ops.maxpool2d_fwd(x, k, stride[0], stride[1], pad[0], pad[1], False, x_scale=s)
+        ctx.save_for_backward(x, w1, w2, g, h, s, idx)
+        ctx.pool = pool
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, w2, g, h, s, idx = ctx.saved_tensors
+        N, C_, H, W = x.shape
+        dy = dy.contiguous()
+        if ctx.pool is None:
+            dxs = dy
+        else:
+            k, stride, pad = ctx.pool
+            dxs = ops.maxpool2d_bwd(dy, idx, tuple(x.shape), k, stride[0], stride[1], pad[0], pad[1])
+        dx, ds = ops.chan_scale_bwd(dxs, x, s)
+        dz2 = ops.act_bwd(ds, s, ops.ACT_SIGMOID)
+        dw2, _ = ops.linear_bwd_weight(dz2, h, N, w2.shape[0], w2.shape[1], want_bias=False)
+        dh = ops.linear_bwd_data(dz2, w2, N)
+        dz1 = ops.act_bwd(dh, h, ops.ACT_RELU)
+        dw1, _ = ops.linear_bwd_weight(dz1, g, N, w1.shape[0], w1.shape[1], want_bias=False)
+        dg = ops.linear_bwd_data(dz1, w1, N)
+        ops.gap_bwd(dg, dx, N, C_, H * W, accumulate=True)
+        return dx, dw1, dw2, None
+
+
+class GapFn(Function):
+    """adaptive_avg_pool2d(x, (1,1)).flatten(1)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        N, C_, H, W = x.shape
+        ctx.shape = (N, C_, H, W)
+        return ops.gap_fwd(x, N, C_, 0, C_, H * W)
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, C_, H, W = ctx.shape
+        dx = _new(ctx.shape, dy)
+        ops.gap_bwd(dy.contiguous(), dx, N, C_, H * W)
+        return dx
+
+
+# =============================================================================== small dense ops
+class LinearFn(Function):
+    """act(x W^T + b) over the last dimension."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        x = x.contiguous()
+        K = w.shape[1]
+        M = x.numel() // K
+        y = ops.linear_fwd(x, w, b, act, M=M)
+        ctx.save_for_backward(x, w, y)
+        ctx.cfg = (act, b is not None, M)
+        return y.view(x.shape[:-1] + (w.shape[0],))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        act, has_b, M = ctx.cfg
+        dy = dy.contiguous()
+        dz = ops.act_bwd(dy, y, act) if act else dy
+        dx = ops.linear_bwd_data(dz, w, M).view(x.shape) if ctx.needs_input_grad[0] else None
+        dw, db = ops.linear_bwd_weight(dz, x, M, w.shape[0], w.shape[1], want_bias=has_b)
+        return dx, dw, db, None
+
+
+class BinaryFn(Function):
+    """op: 0 a+b, 1 a-b, 2 a*b, 3 relu(a+b)"""
+
+    @staticmethod
+    def forward(ctx, a, b, op):
+        a, b = a.contiguous(), b.contiguous()
+        y = ops.ew_binary(a, b, op)
+        ctx.op = op
+        if op == 2:
+            ctx.save_for_backward(a, b)
+        elif op == 3:
+            ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        op = ctx.op
+        if op == 0:
+            return dy, dy, None
+        if op == 1:
+            return dy, ops.ew_scale(dy, -1.0), None
+        if op == 2:
+            a, b = ctx.saved_tensors
+            return ops.ew_binary(dy, b, 2), ops.ew_binary(dy, a, 2), None
+        (y,) = ctx.saved_tensors
+        g = ops.act_bwd(dy, y, ops.ACT_RELU)
+        return g, g, None
+
+
+class Cat2Fn(Function):
+    """torch.cat((a, b), dim=-1) for [.., Fa] / [.., Fb]"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        Fa, Fb = a.shape[-1], b.shape[-1]
+        rows = a.numel() // Fa
+        out = _new(a.shape[:-1] + (Fa + Fb,), a)
+        ops.copy2d(a, Fa, out, Fa + Fb, rows, Fa)
+        ops.copy2d(b, Fb, out, Fa + Fb, rows, Fb, dst_off=Fa)
+        ctx.cfg = (tuple(a.shape), tuple(b.shape), rows)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        sa, sb, rows = ctx.cfg
+        dy = dy.contiguous()
+        Fa, Fb = sa[-1], sb[-1]
+        da, db = _new(sa, dy), _new(sb, dy)
+        ops.copy2d(dy, Fa + Fb, da, Fa, rows, Fa)
+        ops.copy2d(dy, Fa + Fb, db, Fb, rows, Fb, src_off=Fa)
+        return da, db
+
+
+class SegSumFn(Function):
+    """x [G, R, C] -> sum over R (imu_feat_nets.py:49)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        G, R, C_ = x.shape
+        ctx.shape = (G, R, C_)
+        return ops.seg_sum_fwd(x, G, R, C_)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.seg_sum_bwd(dy.contiguous(), *ctx.shape)
+
+
+_DROPOUT_STATE = {"seed": 0x5EED, "offset": 0}
+
+
+def manual_seed(seed):
+    """Seed of the Philox stream used by every dropout on the path (one stream per process;
+    the counter advances by the number of generated groups)."""
+    _DROPOUT_STATE["seed"] = int(seed)
+    _DROPOUT_STATE["offset"] = 0
+
+
+class DropoutFn(Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        x = x.contiguous()
+        off = _DROPOUT_STATE["offset"]
+        _DROPOUT_STATE["offset"] = off + (x.numel() + 3) // 4
+        y, mask = ops.dropout_fwd(x, p, _DROPOUT_STATE["seed"], off)
+        ctx.save_for_backward(mask)
+        ctx.p = p
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        return ops.dropout_bwd(dy.contiguous(), mask, ctx.p), None
+
+
+def dropout(x, p, training):
+    if not training or p <= 0.:
+        return x
+    return DropoutFn.apply(x, p)
+
+
+# =============================================================================== recurrent nets
+class RNNFn(Function):
+    """Multi-layer (bi)directional LSTM/GRU over `Sg` consecutive sub-sequences whose state is
+    carried from one to the next (ImufeatRNN0.forward, imu_feat_nets.py:75-83; with Sg=1 it is
+    a plain nn.LSTM/nn.GRU call as in OdomFeatRNN.forward, odom_feat_nets.py:72-83).
+
+    x [B, Sg, T, I] -> top-layer outputs [B, Sg, T, D*H].  Weights per (layer, direction):
+    w_ih, w_hh, b_ih, b_hh in nn.LSTM order.  Inter-layer dropout as in nn.LSTM (train only)."""
+
+    @staticmethod
+    def forward(ctx, x, mode, H, L, D, p, training, *weights):
+        x = x.contiguous()
+        B, Sg, T, I = x.shape
+        G = 4 if mode == "lstm" else 3
+        dev = x
+        rows = B * T
+        W = [[weights[(l * D + d) * 4:(l * D + d) * 4 + 4] for d in range(D)] for l in range(L)]
+        state_h = [[None] * D for _ in range(L)]
+        state_c = [[None] * D for _ in range(L)]
+        saved = []          # per segment: per layer: dict
+        tops = _new((B, Sg, T, D * H), x)
+        for s in range(Sg):
+            inp = x[:, s].contiguous().view(rows, I)
+            seg = []
+            for l in range(L):
+                out_l = _new((rows, D * H), dev)
+                rec = {"inp": inp, "dirs": []}
+                for d in range(D):
+                    w_ih, w_hh, b_ih, b_hh = W[l][d]
+                    gx = ops.linear_fwd(inp, w_ih, b_ih, M=rows)
+                    hp = _new((rows, H), dev)
+                    gates = _new((rows, 4 * H), dev)
+                    hT = _new((B, H), dev)
+                    h0 = state_h[l][d]
+                    if mode == "lstm":
+                        cs, cT = _new((rows, H), dev), _new((B, H), dev)
+                        c0 = state_c[l][d]
+                        ops.lstm_seq_fwd(gx, w_hh, b_hh, h0, c0, out_l, d * H, D * H, cs, hp, gates,
+                                         hT, cT, T, B, H, 1, T, d == 1)
+                        rec["dirs"].append({"gates": gates, "cs": cs, "hp": hp, "c0": c0})
+                        state_c[l][d] = cT
+                    else:
+                        ops.gru_seq_fwd(gx, w_hh, b_hh, h0, out_l, d * H, D * H, hp, gates, hT, T, B,
+                                        H, 1, T, d == 1)
+                        rec["dirs"].append({"gates": gates, "hp": hp})
+                    state_h[l][d] = hT
+                rec["out"] = out_l
+                if l + 1 < L and training and p > 0.:
+                    off = _DROPOUT_STATE["offset"]
+                    _DROPOUT_STATE["offset"] = off + (out_l.numel() + 3) // 4
+                    inp, mask = ops.dropout_fwd(out_l, p, _DROPOUT_STATE["seed"], off)
+                    rec["mask"] = mask
+                else:
+                    inp = out_l
+                seg.append(rec)
+            ops.copy2d(seg[-1]["out"].view(B, T * D * H), T * D * H, tops, Sg * T * D * H, B, T * D * H,
+                       dst_off=s * T * D * H)
+            saved.append(seg)
+        ctx.saved = saved
+        ctx.weights = weights
+        ctx.cfg = (mode, H, L, D, p, B, Sg, T, I)
+        return tops
+
+    @staticmethod
+    def backward(ctx, dtops):
+        mode, H, L, D, p, B, Sg, T, I = ctx.cfg
+        weights, saved = ctx.weights, ctx.saved
+        G = 4 if mode == "lstm" else 3
+        rows = B * T
+        dtops = dtops.contiguous()
+        dev = dtops
+        W = [[weights[(l * D + d) * 4:(l * D + d) * 4 + 4] for d in range(D)] for l in range(L)]
+        grads = [None] * len(weights)
+        first = [True] * len(weights)
+
+        def acc_w(slot, dz, lddz, xin, ldx, N_, K, with_bias_slot):
+            wi = slot
+            if grads[wi] is None:
+                grads[wi] = _new((N_, K), dev)
+                grads[with_bias_slot] = _new((N_,), dev)
+            ops.linear_bwd_weight(dz, xin, rows, N_, K, dw=grads[wi], db=grads[with_bias_slot],
+                                  lddz=lddz, ldx=ldx, accumulate=not first[wi])
+            first[wi] = False
+
+        dstate_h = [[None] * D for _ in range(L)]
+        dstate_c = [[None] * D for _ in range(L)]
+        dx = _new((B, Sg, T, I), dev) if ctx.needs_input_grad[0] else None
+        for s in reversed(range(Sg)):
+            seg = saved[s]
+            dout = _new((rows, D * H), dev)
+            ops.copy2d(dtops, Sg * T * D * H, dout.view(B, T * D * H), T * D * H, B, T * D * H,
+                       src_off=s * T * D * H)
+            for l in reversed(range(L)):
+                rec = seg[l]
+                K_in = rec["inp"].shape[1]
+                need_dinp = l > 0 or dx is not None
+                dinp = _new((rows, K_in), dev) if need_dinp else None
+                for d in range(D):
+                    w_ih, w_hh, b_ih, b_hh = W[l][d]
+                    base = (l * D + d) * 4
+                    sv = rec["dirs"][d]
+                    dh0 = _new((B, H), dev)
+                    if mode == "lstm":
+                        dg = _new((rows, 4 * H), dev)
+                        dc0 = _new((B, H), dev)
+                        ops.lstm_seq_bwd(dout, d * H, D * H, dstate_h[l][d], dstate_c[l][d],
+                                         sv["gates"], sv["cs"], sv["c0"], w_hh, dg, dh0, dc0, T, B,
+                                         H, 1, T, d == 1)
+                        dgx = dgh = dg
+                        dstate_c[l][d] = dc0
+                    else:
+                        dgx, dgh = _new((rows, 3 * H), dev), _new((rows, 3 * H), dev)
+                        ops.gru_seq_bwd(dout, d * H, D * H, dstate_h[l][d], sv["gates"], sv["hp"],
+                                        w_hh, dgx, dgh, dh0, T, B, H, 1, T, d == 1)
+                    dstate_h[l][d] = dh0
+                    acc_w(base + 0, dgx, G * H, rec["inp"], K_in, G * H, K_in, base + 2)
+                    acc_w(base + 1, dgh, G * H, sv["hp"], H, G * H, H, base + 3)
+                    if need_dinp:
+                        ops.linear_bwd_data(dgx, w_ih, rows, out=dinp, accumulate=d > 0)
+                if l > 0:
+                    prev = seg[l - 1]
+                    dout = ops.dropout_bwd(dinp, prev["mask"], p) if "mask" in prev else dinp
+                elif dx is not None:
+                    ops.copy2d(dinp.view(B, T * I), T * I, dx, Sg * T * I, B, T * I, dst_off=s * T * I)
+        ctx.saved = None
+        return (dx, None, None, None, None, None, None) + tuple(grads)
+
+
+# =============================================================================== pose chain / loss
+class SE3ChainFn(Function):
+    """Trainer.se3_to_SE3 (trainer.py:324-351): f2f increments -> f2g (p, q).  order 0 = wxyz
+    (trainer), 1 = xyzw (tester.py:249).  `status` (int32[1], optional) collects the
+    determinant / orthonormality checks without a host sync."""
+
+    @staticmethod
+    def forward(ctx, t, w, order, status):
+        t, w = t.contiguous(), w.contiguous()
+        p, q, R = ops.se3_chain_fwd(t, w, order, status)
+        ctx.save_for_backward(t, w, R)
+        ctx.order = order
+        return p, q
+
+    @staticmethod
+    def backward(ctx, dp, dq):
+        t, w, R = ctx.saved_tensors
+        dt, dw = ops.se3_chain_bwd(t, w, R, dp.contiguous(), dq.contiguous(), ctx.order)
+        return dt, dw, None, None
+
+
+class PoseLossFn(Function):
+    """HWSLoss / LWSLoss forward+backward in one launch each (losses/losses.py:21-39,68-86)."""
+
+    @staticmethod
+    def forward(ctx, sx, sq, beta, mode, use_local, use_global, pt, pw, pp, pq, gt, gw, gp, gq):
+        preds = [pt.contiguous() if use_local else None, pw.contiguous() if use_local else None,
+                 pp.contiguous() if use_global else None, pq.contiguous() if use_global else None]
+        gts = [gt.contiguous() if use_local else None, gw.contiguous() if use_local else None,
+               gp.contiguous() if use_global else None, gq.contiguous() if use_global else None]
+        out = ops.pose_loss_fwd(preds, gts, sx, sq, beta, mode)
+        ctx.saved = (preds, gts, sx, sq, out)
+        ctx.cfg = (beta, mode)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        preds, gts, sx, sq, out = ctx.saved
+        beta, mode = ctx.cfg
+        dps, dsx, dsq = ops.pose_loss_bwd(preds, gts, sx, sq, beta, mode, out, g.contiguous())
+        ctx.saved = None
+        return (dsx, dsq, None, None, None, None) + tuple(dps) + (None,) * 4

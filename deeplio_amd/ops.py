@@ -281,6 +281,18 @@ def ew_binary(a, b, op, out=None):
     return out
 
 
+def seg_sum_fwd(x, groups, rows, cols):
+    y = torch.empty(groups, cols, dtype=torch.float32, device=x.device)
+    check(lib.dlio_seg_sum_fwd(_ptr(x), _ptr(y), groups, rows, cols, _stream()), "seg_sum_fwd")
+    return y
+
+
+def seg_sum_bwd(dy, groups, rows, cols):
+    dx = torch.empty(groups, rows, cols, dtype=torch.float32, device=dy.device)
+    check(lib.dlio_seg_sum_bwd(_ptr(dy), _ptr(dx), groups, rows, cols, _stream()), "seg_sum_bwd")
+    return dx
+
+
 def ew_scale(a, alpha, out=None):
     if out is None:
         out = torch.empty_like(a)

@@ -1,0 +1,126 @@
+"""Mirror of deeplio/models/optimizer.py:4-16 (`create_optimizer(params, cfg, args)`), built for
+MI355X: all parameters of all groups are re-homed into ONE flat fp32 buffer (grads into a
+second one), so the optimizer step is a single HBM-bound kernel over 41-65 M floats and the
+data-parallel gradient exchange is a single large RCCL all-reduce over xGMI
+(deeplio_amd.dist).  Weight decay is L2 added to the gradient, as torch.optim does."""
+import torch
+
+from . import ops
+
+ALIGN = 16  # floats (64 B): every parameter view stays float4-aligned
+
+
+class FlatOptimizer:
+    def __init__(self, params, lr, weight_decay):
+        groups = list(params)
+        if groups and not isinstance(groups[0], dict):
+            groups = [{'params': groups}]
+        self.param_groups = []
+        plist = []
+        for g in groups:
+            ps = [p for p in g['params']]
+            self.param_groups.append({'params': ps, 'lr': g.get('lr', lr),
+                                      'weight_decay': g.get('weight_decay', weight_decay)})
+            plist += ps
+        seen, uniq = set(), []
+        for p in plist:
+            if id(p) not in seen:
+                seen.add(id(p))
+                uniq.append(p)
+        self.params = uniq
+        if not uniq:
+            raise ValueError("optimizer got an empty parameter list")
+        dev = uniq[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("deeplio_amd optimizers need parameters on the HIP device")
+        offs, total = [], 0
+        for p in uniq:
+            offs.append(total)
+            total += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o in zip(uniq, offs):
+                view = self.flat[o:o + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+        self.offsets = offs
+        self.step_count = 0
+        self.grad_scale = 1.0
+
+    def zero_grad(self, set_to_none=False):
+        self.grad.zero_()
+        for p, o in zip(self.params, self.offsets):   # keep .grad views attached
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+    def _hyper(self):
+        g0 = self.param_groups[0]
+        for g in self.param_groups[1:]:
+            if g['lr'] != g0['lr'] or g['weight_decay'] != g0['weight_decay']:
+                raise ValueError("flat optimizer needs identical hyper-parameters in all groups "
+                                 "(the reference uses one lr / weight-decay for model and criterion)")
+        return g0['lr'], g0['weight_decay']
+
+    def grad_norm(self):
+        """calc_grad_norm (trainer.py:481-486) without per-tensor launches"""
+        return float(ops.sumsq(self.grad).sqrt().item())
+
+    def state_dict(self):
+        return {'step': self.step_count, 'state': {k: v for k, v in self._state().items()},
+                'param_groups': [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self.step_count = sd['step']
+        for k, v in sd['state'].items():
+            self._state()[k].copy_(v)
+        for g, s in zip(self.param_groups, sd['param_groups']):
+            g.update(s)
+
+
+class Adam(FlatOptimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.):
+        super().__init__(params, lr, weight_decay)
+        self.betas, self.eps = betas, eps
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+
+    def _state(self):
+        return {'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq}
+
+    @torch.no_grad()
+    def step(self):
+        lr, wd = self._hyper()
+        self.step_count += 1
+        ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, lr, self.betas[0],
+                      self.betas[1], self.eps, wd, self.step_count, self.grad_scale)
+
+
+class SGD(FlatOptimizer):
+    def __init__(self, params, lr, momentum=0., weight_decay=0.):
+        super().__init__(params, lr, weight_decay)
+        self.momentum = momentum
+        self.buf = torch.zeros_like(self.flat)
+
+    def _state(self):
+        return {'momentum_buffer': self.buf}
+
+    @torch.no_grad()
+    def step(self):
+        lr, wd = self._hyper()
+        self.step_count += 1
+        ops.sgd_step(self.flat, self.grad, self.buf, lr, self.momentum, wd, self.step_count,
+                     self.grad_scale)
+
+
+def create_optimizer(params, cfg, args, **kwargs):
+    optim_type = cfg['optimizer'].lower()
+    if optim_type == 'sgd':
+        return SGD(params, lr=args.lr, weight_decay=args.weight_decay, momentum=args.momentum, **kwargs)
+    if optim_type == 'adam':
+        return Adam(params, lr=args.lr, weight_decay=args.weight_decay, **kwargs)
+    if optim_type in ('rmsprop', 'adadelta'):
+        raise ValueError("Optimizer {} has no HIP kernel in this build (adam and sgd are on the "
+                         "hot path)".format(optim_type))
+    raise ValueError("Optimizer {} not supported!".format(optim_type))

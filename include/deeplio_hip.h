@@ -184,9 +184,13 @@ int dlio_linear_bwd_weight(const float* dz, int lddz, const float* x, int ldx, f
                            dlio_stream_t stream);
 
 /* ---- elementwise helpers ---------------------------------------------- */
-/* op: 0 a+b, 1 a-b, 2 a*b */
+/* op: 0 a+b, 1 a-b, 2 a*b, 3 relu(a+b) (BasicBlock tail) */
 int dlio_ew_binary(const float* a, const float* b, float* y, int64_t n, int op,
                    dlio_stream_t stream);
+/* torch.sum(y, dim=0) per IMU window (imu_feat_nets.py:49): y[g][c] = sum_r x[g][r][c];
+ * backward broadcasts dy over r */
+int dlio_seg_sum_fwd(const float* x, float* y, int groups, int rows, int cols, dlio_stream_t stream);
+int dlio_seg_sum_bwd(const float* dy, float* dx, int groups, int rows, int cols, dlio_stream_t stream);
 /* y = alpha*a */
 int dlio_ew_scale(const float* a, float alpha, float* y, int64_t n, dlio_stream_t stream);
 /* strided 2-D copy: dst[r*ldd + c] = src[r*lds + c] (concat / split along features) */
