@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Training-throughput bench of the DeepLIO hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
+lidar-feat-pointseg (encoder, fusion=add, bypass simple, dropout .1) + imu-feat-rnn
+bi-LSTM 128x2 + fusion-layer-soft + odom-feat-rnn bi-LSTM 1024x2, HWS loss local+global,
+Adam(lr 1e-3, wd 1e-4); synthetic 64x2048x5 range-image pairs + 50-step IMU windows,
+per-GPU batch 8, S=2 pairs per sample (weak scaling over GPUs).  One "step" = forward,
+SE(3) chain, loss, backward, (gradient all-reduce), optimizer step over one batch of
+B*S frame pairs already resident in HBM.
+
+Prints ONE JSON line on rank 0 (see the contract in the task description) with two extra
+objects: `roofline` for the dominant kernel (hipEvent-timed inside the timed region) and
+`cpu_baseline` (the oracle = CPU port of the reference path, timed on this box's host cores on
+a bounded sample, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_batch(seed, B, S, C, H, W, T, device):
+    """xyz, normals ~ N(0,1); imu ~ U[0,1); GT f2f_t ~ N(0,.1^2), f2f_w ~ N(0,.01^2),
+    f2g_p ~ N(0,1), f2g_q unit-normalised N(0,1)^4."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    xyz = torch.randn(B, S, 2, C, H, W, generator=g)
+    nrm = torch.randn(B, S, 2, C, H, W, generator=g)
+    imu = torch.rand(B, S, T, 6, generator=g)
+    f2f = torch.cat([0.1 * torch.randn(B, S, 3, generator=g), 0.01 * torch.randn(B, S, 3, generator=g)], -1)
+    q = torch.randn(B, S, 4, generator=g)
+    f2g = torch.cat([torch.randn(B, S, 3, generator=g), q / q.norm(dim=-1, keepdim=True)], -1)
+    return tuple(t.to(device) for t in (xyz, nrm, imu, f2f, f2g))
+
+
+def cpu_baseline(cfg, C, H, W, T, S, sample_B, steps):
+    """The oracle (CPU port of the reference's path) on this box's host cores: full training
+    step on a bounded sample of the same workload."""
+    from oracle import model as om
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    model = om.get_model((C, H, W), cfg)
+    model.train()
+    crit = om.get_loss_function(cfg)
+    opt = om.create_optimizer([{'params': model.parameters()}, {'params': crit.parameters()}], cfg,
+                              lr=1e-3, weight_decay=1e-4)
+    batch = synth_batch(99, sample_B, S, C, H, W, T, "cpu")
+    om.train_step(model, crit, opt, batch)            # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        om.train_step(model, crit, opt, batch)
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(sample_B * S / dt, 4), "unit": "frame-pairs/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "oracle (torch-CPU port of the reference path), same model/loss/Adam step, "
+                      "B=%d S=%d 64x2048x%d T=%d, %d timed steps after 1 warm-up, %.2f s/step"
+                      % (sample_B, S, C, T, steps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (BASELINE: 8)")
+    ap.add_argument("--seq", type=int, default=2, help="frame pairs per sample (S)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=1)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    from deeplio_amd import dist as ddist
+    from deeplio_amd import ops
+    from deeplio_amd.config import make_config
+    from deeplio_amd.trainer import TrainStep
+
+    world, rank, local = ddist.init()
+    if world != args.gpus:
+        if rank == 0 and world > 1:
+            print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    C, H, W, T, S, B = 5, 64, 2048, 50, args.seq, args.batch
+    cfg = make_config(lidar="lidar-feat-pointseg", imu="imu-feat-rnn", fusion="fusion-layer-soft",
+                      odom="odom-feat-rnn", seq=S)
+    ts = TrainStep(cfg, (C, H, W), device, B)
+    sync = ddist.GradSync(ts.optimizer.flat, ts.optimizer.grad, ts.optimizer)
+    sync.broadcast_parameters()
+    ts.grad_sync = sync if world > 1 else None
+    batch = synth_batch(1234 + rank, B, S, C, H, W, T, device)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ts.step(*batch)
+    ts.check()
+    barrier()
+    ops.prof_reset()
+    ops.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = ts.step(*batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.prof_enable(False)
+    ts.check()
+    dt = sync.max_over_ranks(dt)
+    ms_per_step = 1e3 * dt / args.steps
+    value = world * B * S / (dt / args.steps)
+
+    if rank == 0:
+        kinds = {0: "conv2d_fwd_mfma (forward + stride-1 data-gradient)", 1: "conv2d_wgrad_mfma"}
+        prof = {k: ops.prof_collect(k) for k in kinds}
+        dom = max(prof, key=lambda k: prof[k]["ms"])
+        p = prof[dom]
+        achieved = p["flops"] / (p["ms"] * 1e-3) / 1e12 if p["ms"] > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": kinds[dom], "achieved": round(achieved, 2),
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": p["launches"] / args.steps,
+                    "avg_launch_ms": round(p["ms"] / max(p["launches"], 1), 5),
+                    "ms_per_step_in_kernel": round(p["ms"] / args.steps, 3),
+                    "other": {kinds[k]: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] else 0,
+                                         "ms_per_step": round(v["ms"] / args.steps, 3)}
+                              for k, v in prof.items() if k != dom}}
+        out = {
+            "metric": "frame-pairs/sec training, 64x2048x5 range-img + 50-step IMU, bs=8, 1/2/4/8 GPU",
+            "value": round(value, 3), "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: lidar-feat-pointseg(add)+imu-feat-rnn bi-LSTM-128x2"
+                                   "+fusion-layer-soft+odom-feat-rnn bi-LSTM-1024x2, HWS local+global, Adam; "
+                                   "64x2048x5, T=50, S=%d, per-GPU batch %d" % (S, B),
+                       "global_batch": world * B, "frame_pairs_per_step": world * B * S,
+                       "parallelism": "dp%d" % world, "loss": float(loss.item())},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, C, H, W, T, S, args.cpu_batch, args.cpu_steps)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

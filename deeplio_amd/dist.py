@@ -1,0 +1,71 @@
+"""Data-parallel execution of the hot path: one process per GPU, torch.distributed with the
+"nccl" backend (= RCCL on ROCm) over xGMI.  The reference is single-device (no DataParallel,
+no torch.distributed anywhere); batches of frame-pair sequences are independent, so the only
+exchange is the gradient all-reduce, issued as ONE collective over the flat gradient buffer
+(165 MB fp32 for the PointSeg model) -- ring time ~1.9 ms on 7 x 153 GB/s links against a
+>= 11 ms compute step, so it is not bucketed/overlapped in this round.
+
+BatchNorm statistics are per replica (the throughput configuration); the averaged gradient is
+exact for everything else.  Works on CPU tensors with the "gloo" backend, which is how the
+-m "not gpu" tests cover the world_size > 1 path.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), \
+        int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend=None):
+    """Initialise the default process group from the torchrun environment (MASTER_ADDR,
+    MASTER_PORT, RANK, WORLD_SIZE).  Returns (world, rank, local_rank)."""
+    world, rank, local = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return world, rank, local
+
+
+def shard_batch(global_batch, world, rank):
+    """contiguous split of sample indices [0, global_batch) over ranks (B/world each)"""
+    if global_batch % world:
+        raise ValueError("global batch %d is not divisible by world size %d" % (global_batch, world))
+    per = global_batch // world
+    return range(rank * per, (rank + 1) * per)
+
+
+class GradSync:
+    """Keeps replicas identical: broadcast of the flat parameter buffer at start, one
+    all-reduce(sum) of the flat gradient buffer per step; the optimizer divides by world
+    through its `grad_scale` (no extra pass over the gradients)."""
+
+    def __init__(self, flat_param, flat_grad, optimizer=None):
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.flat_param, self.flat_grad = flat_param, flat_grad
+        if optimizer is not None:
+            optimizer.grad_scale = 1.0 / self.world
+
+    def broadcast_parameters(self, extra=()):
+        if self.world > 1:
+            dist.broadcast(self.flat_param, src=0)
+            for t in extra:
+                dist.broadcast(t, src=0)
+
+    def all_reduce_grads(self):
+        if self.world > 1:
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
+
+    def max_over_ranks(self, value):
+        """max of a python float over ranks (bench timing)"""
+        if self.world == 1:
+            return value
+        t = torch.tensor([value], dtype=torch.float64, device=self.flat_grad.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())

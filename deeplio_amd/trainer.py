@@ -1,0 +1,64 @@
+"""The per-iteration body of Trainer.train (trainer.py:213-281) on the HIP path: forward,
+SE(3) chain, loss, backward, (data-parallel gradient exchange), optimizer step -- with the
+reference's ten NaN/Inf host syncs per step replaced by device-side flags that the caller
+reads when it wants to (check())."""
+import types
+
+import torch
+
+from . import ops
+from .losses import get_loss_function
+from .misc import build_config_container
+from .nets import get_model
+from .optimizer import create_optimizer
+from .se3 import se3_to_SE3
+
+
+class TrainStep:
+    def __init__(self, cfg, input_shape, device, batch_size, lr=1e-3, weight_decay=1e-4, momentum=0.9,
+                 max_glob_seq=2, grad_sync=None):
+        self.cfg, self.device = cfg, torch.device(device)
+        self.args = types.SimpleNamespace(device=str(device), batch_size=batch_size, lr=lr,
+                                          weight_decay=weight_decay, momentum=momentum)
+        build_config_container(cfg, self.args)
+        self.model = get_model(input_shape, cfg, self.device)
+        self.criterion = get_loss_function(cfg, self.device)
+        self.optimizer = create_optimizer([{'params': self.model.parameters()},
+                                           {'params': self.criterion.parameters()}], cfg, self.args)
+        self.max_glob_seq = max_glob_seq            # trainer.py:42
+        self.flags = torch.zeros(2, dtype=torch.int32, device=self.device)   # [nonfinite, se3 status]
+        self.grad_sync = grad_sync
+        self.model.train()
+        self.criterion.train()
+
+    def step(self, imgs, normals, imus, gts_f2f, gts_f2g):
+        gt_f2f_t, gt_f2f_w = gts_f2f[:, :, 0:3], gts_f2f[:, :, 3:]
+        gt_f2g_p, gt_f2g_q = gts_f2g[:, :, 0:3], gts_f2g[:, :, 3:7]
+        pred_f2f_t, pred_f2f_w = self.model([[imgs, normals], imus])
+        ops.nonfinite_flag(pred_f2f_t, self.flags[0:1])        # trainer.py:240-243, no host sync
+        ops.nonfinite_flag(pred_f2f_w, self.flags[0:1])
+        pred_f2g_p, pred_f2g_q = se3_to_SE3(pred_f2f_t, pred_f2f_w, status=self.flags[1:2])
+        lt = self.criterion.loss_Types
+        if lt[0] and not lt[1]:
+            pred_f2g_p, pred_f2g_q = pred_f2g_p.detach(), pred_f2g_q.detach()
+        elif lt[1] and not lt[0]:
+            pred_f2f_t, pred_f2f_w = pred_f2f_t.detach(), pred_f2f_w.detach()
+        sl = slice(1, self.max_glob_seq + 1)
+        loss = self.criterion(pred_f2f_t, pred_f2f_w, pred_f2g_p[:, sl, :], pred_f2g_q[:, sl, :],
+                              gt_f2f_t, gt_f2f_w, gt_f2g_p[:, sl, :], gt_f2g_q[:, sl, :])
+        self.optimizer.zero_grad()
+        loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync.all_reduce_grads()
+        self.optimizer.step()
+        return loss.detach()
+
+    def check(self):
+        """raise like trainer.py:240-243 / :341-348 if any step since the last check went bad"""
+        f = self.flags.tolist()
+        self.flags.zero_()
+        if f[0]:
+            raise ValueError("pred_f2f: non-finite model output")
+        if f[1] & 1:
+            raise ValueError("Det error: chained rotation with det != 1")
+        return f

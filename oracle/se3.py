@@ -86,11 +86,11 @@ def se3_to_SE3(f2f_x, f2f_r, ordering="wxyz", check=True):
         qb, xb = [], []
         for s in range(S):
             R_cur = so3_exp(f2f_r[b, s])
-            if check and not torch.isclose(torch.det(R_cur), torch.ones(())):
+            if check and not torch.isclose(torch.det(R_cur), torch.ones((), dtype=R_cur.dtype)):
                 raise ValueError("Det error:\nR\n{}\nq:\n{}".format(R_cur, f2f_r[b, s]))
             t_prev = R_prev @ f2f_x[b, s] + t_prev
             R_prev = R_prev @ R_cur
-            if check and not torch.isclose(torch.det(R_prev), torch.ones(())):
+            if check and not torch.isclose(torch.det(R_prev), torch.ones((), dtype=R_prev.dtype)):
                 raise ValueError("Det error:\nR\n{}".format(R_prev))
             Rn = R_prev if is_valid_rotation(R_prev.detach()) else normalize_rotation(R_prev)
             qb.append(rot_to_quat(Rn, ordering))

@@ -1,0 +1,215 @@
+"""-m gpu parity tests of the composed layers (Fire, conv+BN(+ReLU), SE(+pool), BasicBlock,
+RNN stacks, soft fusion) against the oracle's modules: forward, input gradient and every
+parameter gradient at 1e-4 of the tensor scale."""
+import os
+import sys
+import types
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import golden_common as gc  # noqa: E402
+from conftest import rel_err  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _ctx(dev, seq=2):
+    from deeplio_amd import misc
+    from deeplio_amd.config import make_config
+    cfg = make_config(seq=seq)
+    misc.build_config_container(cfg, types.SimpleNamespace(device=str(dev), batch_size=2))
+    return cfg
+
+
+class _DecisionMargin:
+    """Records, during an fp64 oracle forward, how close any ReLU input / max-pool runner-up
+    comes to its decision boundary (relative to the tensor's scale).  A gradient comparison is
+    only meaningful where no decision can flip under fp32 rounding: ONE flipped ReLU among 1e6
+    activations moves a whole weight-gradient row by 1e-2 (measured: tools/debug_cbr2.py)."""
+
+    def __enter__(self):
+        self.margin = float("inf")
+        self._relu, self._pool = F.relu, F.max_pool2d
+
+        def relu(x, inplace=False):
+            if x.numel():
+                nz = x.detach().abs()
+                nz = nz[nz > 0]
+                if nz.numel():
+                    self.margin = min(self.margin, float(nz.min()) / max(float(x.detach().abs().max()), 1e-30))
+            return self._relu(x)
+
+        def pool(x, k, stride=None, padding=0, **kw):
+            y = self._pool(x, k, stride, padding, **kw)
+            pad = padding if isinstance(padding, tuple) else (padding, padding)
+            st = stride if isinstance(stride, tuple) else (stride, stride)
+            u = F.unfold(F.pad(x.detach(), (pad[1], pad[1], pad[0], pad[0]), value=float("-inf")), k, stride=st)
+            u = u.view(x.shape[0], x.shape[1], k * k, -1)
+            top2 = u.topk(2, dim=2).values
+            gap = (top2[:, :, 0] - top2[:, :, 1])
+            gap = gap[(gap > 0) & torch.isfinite(gap)]
+            if gap.numel():
+                self.margin = min(self.margin, float(gap.min()) / max(float(x.detach().abs().max()), 1e-30))
+            return y
+
+        F.relu, F.max_pool2d = relu, pool
+        return self
+
+    def __exit__(self, *a):
+        F.relu, F.max_pool2d = self._relu, self._pool
+
+
+def compare(hip, ora, x, dev, train=True, tol=TOL, fwd=None, ofwd=None, margin=2e-6):
+    """same weights (by key), same input; checks y, dx and all parameter grads against the
+    fp64 oracle at `tol` of each tensor's scale.  Weight seeds are advanced until the oracle
+    forward is decision-stable (no ReLU input / pool runner-up within `margin` of its boundary),
+    so the comparison does not depend on which side of zero fp32 rounding lands."""
+    ora.double()
+    xo = x.clone().double().requires_grad_(True)
+    for seed in range(77, 177):
+        gc.fill_state(ora, seed)
+        ora.train(train)
+        snap = {k: v.clone() for k, v in ora.state_dict().items()}
+        with _DecisionMargin() as dm:
+            yo = (ofwd or ora)(xo)
+        if dm.margin > margin:
+            break
+    else:
+        raise AssertionError("no decision-stable seed found; shrink the case")
+    hip.load_state_dict({k: v.float() if v.dtype.is_floating_point else v for k, v in snap.items()})
+    hip.to(dev).train(train)
+    xh = x.clone().to(dev).requires_grad_(True)
+    yh = (fwd or hip)(xh)
+    assert rel_err(yh, yo) < tol, ("fwd", rel_err(yh, yo))
+    g = torch.randn(yo.shape, generator=torch.Generator().manual_seed(5))
+    yh.backward(g.to(dev))
+    yo.backward(g.double())
+    op = dict(ora.named_parameters())
+    gmax = max(float(p.grad.abs().max()) for p in op.values() if p.grad is not None)
+    errs = {"dx": rel_err(xh.grad, xo.grad)}
+    for k, p in hip.named_parameters():
+        if op[k].grad is None:
+            continue
+        a, b = p.grad.double().cpu(), op[k].grad
+        # |err| <= 1e-4 * own scale + 1e-6 * largest gradient of the module: the second term lets
+        # analytically-zero gradients pass (conv bias in front of a train-mode BN is pure
+        # rounding noise, ~1e-7 * gmax, in the reference's arithmetic as well)
+        errs[k] = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-2 * gmax)
+    bad = {k: v for k, v in errs.items() if not v < tol}
+    assert not bad, bad
+    ob = dict(ora.named_buffers())
+    for k, b in hip.named_buffers():
+        if "running" in k:
+            assert rel_err(b, ob[k]) < 1e-5, k
+
+
+FIRE_CASES = [(4, 768, 80, 384, 4, 1, None), (4, 512, 80, 384, 4, 1, "simple"), (2, 64, 16, 64, 8, 32, "simple"),
+              (2, 128, 16, 64, 8, 32, "simple"), (3, 256, 48, 192, 5, 9, None), (1, 512, 64, 256, 8, 16, "simple")]
+
+
+@pytest.mark.parametrize("case", FIRE_CASES)
+@pytest.mark.parametrize("train", [True, False])
+def test_fire(dev, case, train):
+    from deeplio_amd import nets
+    from oracle import model as om
+    N, cin, sq, e, H, W, byp = case
+    x = torch.randn(N, cin, H, W, generator=torch.Generator().manual_seed(1))
+    compare(nets.Fire(cin, sq, e, e, bypass=byp), om.Fire(cin, sq, e, e, 0.1, byp), x, dev, train)
+
+
+CBR_CASES = [  # N, cin, cout, k, stride, pad, H, W, pre_relu, bias
+    (1, 40, 72, 3, 1, 1, 33, 33, True, True), (2, 72, 64, 3, 1, 1, 17, 17, True, True),
+    (2, 10, 64, (3, 5), (1, 2), (1, 2), 16, 64, False, True), (2, 6, 64, (5, 7), (1, 2), (2, 3), 16, 64, False, False),
+    (2, 64, 128, (3, 5), (1, 2), (1, 2), 16, 32, False, False), (2, 256, 512, 3, 2, 1, 8, 16, False, False),
+    (2, 64, 128, 1, (1, 2), 0, 8, 32, False, False), (1, 24, 24, 3, 1, 1, 64, 65, True, True),
+]
+
+
+class _OraCBR(nn.Module):
+    def __init__(self, cin, cout, k, s, p, pre_relu, bias):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, s, p, bias=bias)
+        self.bn = nn.BatchNorm2d(cout)
+        self.pre = pre_relu
+
+    def forward(self, x):
+        return self.bn(F.relu(self.conv(x))) if self.pre else F.relu(self.bn(self.conv(x)))
+
+
+class _HipCBR(_OraCBR):
+    def forward(self, x):
+        from deeplio_amd import nets
+        return nets._cbr(x, self.conv, self.bn, self.training, pre_relu=self.pre, post_relu=not self.pre)
+
+
+@pytest.mark.parametrize("case", CBR_CASES)
+def test_conv_bn_act(dev, case):
+    N, cin, cout, k, s, p, H, W, pre, bias = case
+    x = torch.randn(N, cin, H, W, generator=torch.Generator().manual_seed(2))
+    compare(_HipCBR(cin, cout, k, s, p, pre, bias), _OraCBR(cin, cout, k, s, p, pre, bias), x, dev, True)
+    compare(_HipCBR(cin, cout, k, s, p, pre, bias), _OraCBR(cin, cout, k, s, p, pre, bias), x, dev, False)
+
+
+@pytest.mark.parametrize("pool", [None, (3, (1, 2), (1, 1)), (3, (2, 2), (1, 1))])
+def test_se_layer_with_fused_pool(dev, pool):
+    from deeplio_amd import nets
+    from oracle import model as om
+    x = F.relu(torch.randn(2, 32, 8, 16, generator=torch.Generator().manual_seed(3)))
+    hip, ora = nets.SELayer(32, 2), om.SELayer(32, 2)
+    ofwd = (lambda t: ora(t)) if pool is None else (lambda t: F.max_pool2d(ora(t), pool[0], pool[1], pool[2]))
+    compare(hip, ora, x, dev, True, fwd=lambda t: hip(t, pool), ofwd=ofwd)
+
+
+def test_basic_block_and_encoders(dev):
+    from deeplio_amd import nets
+    from oracle import model as om
+    x = torch.randn(2, 64, 8, 32, generator=torch.Generator().manual_seed(4))
+    down_h = nn.Sequential(nn.Conv2d(64, 128, 1, (1, 2), bias=False), nn.BatchNorm2d(128))
+    down_o = nn.Sequential(nn.Conv2d(64, 128, 1, (1, 2), bias=False), nn.BatchNorm2d(128))
+    compare(nets.BasicBlock(64, 128, (1, 2), down_h), om.BasicBlock(64, 128, (1, 2), down_o), x, dev)
+    compare(nets.BasicBlock(64, 64), om.BasicBlock(64, 64), x, dev)
+    _ctx(dev)
+    xe = torch.randn(2, 10, 16, 64, generator=torch.Generator().manual_seed(5))
+    # whole encoder: 40 layers deep with 16-sample batch statistics at the end -> forward only at
+    # 3e-4 vs fp64 (torch's own fp32 forward is 1.5e-4 from fp64 here); gradients are covered per layer
+    hip, ora = nets.PSEncoder((10, 16, 64), {'bypass': 'simple'}), om.PSEncoder(10, 'simple')
+    gc.fill_state(ora, 77)
+    hip.load_state_dict(ora.state_dict())
+    yh = hip.to(dev).train()(xe.to(dev))
+    yo = ora.double().train()(xe.double())
+    assert rel_err(yh, yo) < 3e-4
+
+
+@pytest.mark.parametrize("mode", ["lstm", "gru"])
+@pytest.mark.parametrize("H,L,bidir", [(32, 2, True), (8, 2, True), (16, 1, False)])
+def test_imu_rnn_with_state_carry(dev, mode, H, L, bidir):
+    from deeplio_amd import nets
+    from oracle import model as om
+    cfg = _ctx(dev, seq=3)
+    rc = {'type': mode, 'input-size': 6, 'hidden-size': H, 'num-layers': L, 'bidirectional': bidir, 'dropout': 0.}
+    x = torch.rand(3, 3, 5, 6, generator=torch.Generator().manual_seed(6))
+    compare(nets.ImufeatRNN0(rc), om.ImufeatRNN0(rc, om.Ctx(cfg)), x, dev)
+
+
+def test_odom_rnn_fc_softfusion_imufc(dev):
+    from deeplio_amd import nets
+    from oracle import model as om
+    cfg = _ctx(dev, seq=3)
+    ctx = om.Ctx(cfg)
+    x = torch.randn(3, 3, 48, generator=torch.Generator().manual_seed(7))
+    rc = {'type': 'lstm', 'hidden-size': 1024, 'num-layers': 2, 'bidirectional': True, 'dropout': 0.}
+    compare(nets.OdomFeatRNN(48, rc), om.OdomFeatRNN(48, rc, ctx), x, dev)
+    compare(nets.OdomFeatFC(48, {'dropout': 0.}), om.OdomFeatFC(48, {'dropout': 0.}, ctx), x, dev)
+    shapes = [[1, 3, 32], [1, 3, 16]]
+    hip, ora = nets.DeepLIOFusionSoft(shapes, {}), om.DeepLIOFusionSoft(shapes, {}, ctx)
+    compare(hip, ora, x, dev, fwd=lambda t: hip([t[..., :32], t[..., 32:]]),
+            ofwd=lambda t: ora([t[..., :32], t[..., 32:]]))
+    fc = {'input-size': 6, 'hidden-size': [16, 32, 8], 'dropout': 0.}
+    xi = torch.rand(3, 3, 7, 6, generator=torch.Generator().manual_seed(8))
+    compare(nets.ImuFeatFC(fc), om.ImuFeatFC(fc, ctx), xi, dev)
