@@ -45,11 +45,31 @@ def synth_batch(seed, B, S, C, H, W, T, device):
     return tuple(t.to(device) for t in (xyz, nrm, imu, f2f, f2g))
 
 
+def usable_cores():
+    """cores this process may actually use: affinity mask capped by the cgroup CPU quota
+    (os.cpu_count() reports the host's cores inside a container)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(cfg, C, H, W, T, S, sample_B, steps):
     """The oracle (CPU port of the reference's path) on this box's host cores: full training
     step on a bounded sample of the same workload."""
     from oracle import model as om
-    ncores = os.cpu_count() or 1
+    ncores = usable_cores()
     torch.set_num_threads(ncores)
     model = om.get_model((C, H, W), cfg)
     model.train()
@@ -80,6 +100,9 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=1)
     ap.add_argument("--cpu-steps", type=int, default=3)
     args = ap.parse_args()
+    if os.environ.get("DLIO_BENCH_WATCHDOG"):
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["DLIO_BENCH_WATCHDOG"]), exit=True)
 
     from deeplio_amd import dist as ddist
     from deeplio_amd import ops

@@ -6,9 +6,10 @@ Host-side mirror of the reference's Python surface over a C-ABI HIP library:
     deeplio_amd.optimizer.create_optimizer(params, cfg, args) <- deeplio.models.optimizer
     deeplio_amd.se3.se3_to_SE3(f2f_x, f2f_r)                  <- Trainer.se3_to_SE3
     deeplio_amd.misc.build_config_container(cfg, args)        <- deeplio.models.misc
-Importing this package loads libdeeplio_hip.so and fails loudly if it is missing.
+Importing any of those modules loads libdeeplio_hip.so (deeplio_amd._lib) and fails loudly if
+the library or one of its symbols is missing -- there is no CPU fallback.  Only
+`deeplio_amd.build` and `deeplio_amd.config` are importable without the library.
 """
-from . import _lib  # noqa: F401  (mandatory HIP extension; no CPU fallback)
 
 __version__ = "0.1.0"
 

@@ -33,6 +33,7 @@ SIGNATURES = {
     "dlio_version": (_i, []),
     "dlio_arch": (C.c_char_p, []),
     "dlio_strerror": (C.c_char_p, [_i]),
+    "dlio_last_hip_error_string": (C.c_char_p, []),
     "dlio_prof_enable": (_i, [_i]),
     "dlio_prof_reset": (_i, []),
     "dlio_prof_collect": (_i, [_i, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d), C.POINTER(_i64)]),
@@ -59,7 +60,8 @@ SIGNATURES = {
     "dlio_chan_scale_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "dlio_linear_fwd": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "dlio_act_bwd": (_i, [_p, _p, _p, _i64, _i, _p]),
-    "dlio_linear_bwd_data": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "dlio_linear_bwd_data_ws_bytes": (_sz, [_i, _i, _i]),
+    "dlio_linear_bwd_data": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "dlio_linear_bwd_weight": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _p]),
     "dlio_ew_binary": (_i, [_p, _p, _p, _i64, _i, _p]),
     "dlio_seg_sum_fwd": (_i, [_p, _p, _i, _i, _i, _p]),
@@ -119,6 +121,8 @@ def check(code, what=""):
     if code == DLIO_OK:
         return
     msg = "deeplio_hip %s failed: %s (%d)" % (what, strerror(code), code)
+    if code == DLIO_ELAUNCH:
+        msg += " [%s]" % lib.dlio_last_hip_error_string().decode()
     if code in (DLIO_EINVAL, DLIO_EUNSUP):
         raise ValueError(msg)
     raise RuntimeError(msg)

@@ -9,10 +9,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define DLIO_WAVE 64
 
-static inline hipStream_t as_stream(dlio_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+// Every launcher converts its stream argument first; use that point to drop any stale
+// (non-sticky) error left in this thread by an earlier runtime call of the host framework,
+// so that dlio_check_launch() reports only OUR launch.
+static inline hipStream_t as_stream(dlio_stream_t s) {
+  (void)hipGetLastError();
+  return reinterpret_cast<hipStream_t>(s);
+}
 
+extern thread_local int dlio_last_hip_error;   // runtime.hip
 static inline int dlio_check_launch() {
   hipError_t e = hipGetLastError();
+  if (e != hipSuccess) dlio_last_hip_error = (int)e;
   return e == hipSuccess ? DLIO_OK : DLIO_ELAUNCH;
 }
 

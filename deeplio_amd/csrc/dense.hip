@@ -130,6 +130,61 @@ __global__ __launch_bounds__(256) void linear_bwd_data_kernel(
   }
 }
 
+// ---- data gradient, weight-streaming form for large N*K (the 1024-wide odometry LSTM):
+// every block walks a chunk of W's rows (coalesced float4 row reads, each weight byte read
+// once) and keeps its partial dx[16][4 columns per thread] in registers; partials go to the
+// caller's workspace and are summed in a fixed order.
+__global__ __launch_bounds__(256) void linear_bwd_data_split_kernel(
+    const float* __restrict__ dz, int lddz, const float* __restrict__ w, float* __restrict__ part,
+    int M, int N, int K, int m0, int nsplit) {
+  const int k = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int sp = blockIdx.y;
+  const int per = (N + nsplit - 1) / nsplit;
+  const int n_lo = sp * per, n_hi = min(N, n_lo + per);
+  float acc[BM][4];
+#pragma unroll
+  for (int j = 0; j < BM; ++j) { acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.f; }
+  if (k < K) {
+    for (int n = n_lo; n < n_hi; ++n) {
+      const float4 wv = *reinterpret_cast<const float4*>(w + (size_t)n * K + k);
+#pragma unroll
+      for (int j = 0; j < BM; ++j) {
+        if (m0 + j < M) {
+          const float a = dz[(size_t)(m0 + j) * lddz + n];
+          acc[j][0] += a * wv.x; acc[j][1] += a * wv.y; acc[j][2] += a * wv.z; acc[j][3] += a * wv.w;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BM; ++j)
+      *reinterpret_cast<float4*>(part + ((size_t)sp * BM + j) * K + k) =
+          make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+  }
+}
+
+__global__ void linear_bwd_data_reduce_kernel(const float* __restrict__ part, float* __restrict__ dx,
+                                              int lddx, int M, int K, int m0, int nsplit,
+                                              int accumulate) {
+  const int total = BM * K;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int j = i / K, k = i - j * K;
+    if (m0 + j >= M) continue;
+    float s = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) s += part[((size_t)sp * BM + j) * K + k];
+    float* p = dx + (size_t)(m0 + j) * lddx + k;
+    *p = accumulate ? *p + s : s;
+  }
+}
+
+static int bwd_data_nsplit(int N, int K) {
+  if ((K & 3) != 0 || (int64_t)N * K < (1 << 18)) return 0;   // small problems: direct kernel
+  const int kblocks = (K / 4 + 255) / 256;
+  int ns = 768 / kblocks;
+  if (ns > N / 8) ns = N / 8;
+  if (ns > 256) ns = 256;
+  return ns < 2 ? 0 : ns;
+}
+
 // ---- weight gradient: thread per (4 n, k) --------------------------------------
 __global__ __launch_bounds__(256) void linear_bwd_weight_kernel(
     const float* __restrict__ dz, int lddz, const float* __restrict__ x, int ldx,
@@ -292,11 +347,31 @@ extern "C" int dlio_act_bwd(const float* dy, const float* y, float* dz, int64_t 
   return dlio_check_launch();
 }
 
+extern "C" size_t dlio_linear_bwd_data_ws_bytes(int M, int N, int K) {
+  (void)M;
+  const int ns = bwd_data_nsplit(N, K);
+  return ns ? (size_t)ns * BM * K * sizeof(float) : 0;
+}
+
 extern "C" int dlio_linear_bwd_data(const float* dz, int lddz, const float* w, float* dx, int lddx,
-                                    int M, int N, int K, int accumulate, dlio_stream_t stream) {
+                                    int M, int N, int K, int accumulate, void* ws, size_t ws_bytes,
+                                    dlio_stream_t stream) {
   if (!dz || !w || !dx || M <= 0 || N <= 0 || K <= 0 || lddz < N || lddx < K) return DLIO_EINVAL;
-  hipLaunchKernelGGL(linear_bwd_data_kernel, dim3(cdiv(K, 64), cdiv(M, BM)), dim3(256), 0,
-                     as_stream(stream), dz, lddz, w, dx, lddx, M, N, K, accumulate);
+  hipStream_t s = as_stream(stream);
+  const int ns = bwd_data_nsplit(N, K);
+  const bool aligned = ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
+  if (ns && aligned && ws && ws_bytes >= (size_t)ns * BM * K * sizeof(float)) {
+    float* part = reinterpret_cast<float*>(ws);
+    for (int m0 = 0; m0 < M; m0 += BM) {
+      hipLaunchKernelGGL(linear_bwd_data_split_kernel, dim3((K / 4 + 255) / 256, ns), dim3(256), 0, s,
+                         dz, lddz, w, part, M, N, K, m0, ns);
+      hipLaunchKernelGGL(linear_bwd_data_reduce_kernel, dim3(cdiv(BM * K, 256)), dim3(256), 0, s, part,
+                         dx, lddx, M, K, m0, ns, accumulate);
+    }
+    return dlio_check_launch();
+  }
+  hipLaunchKernelGGL(linear_bwd_data_kernel, dim3(cdiv(K, 64), cdiv(M, BM)), dim3(256), 0, s, dz, lddz,
+                     w, dx, lddx, M, N, K, accumulate);
   return dlio_check_launch();
 }
 

@@ -348,7 +348,9 @@ int ew_blocks(int n) { return n < 256 ? 1 : (n + 255) / 256 > 1024 ? 1024 : (n +
 extern "C" size_t dlio_rnn_ws_bytes(int T, int B, int H) {
   (void)T;
   if (B <= 0 || H <= 0) return 0;
-  return (size_t)B * H * 16 * sizeof(float);
+  // state + gate scratch (16 B*H floats) followed by the weight-streaming scratch of the
+  // recurrent data-gradient GEMV
+  return (size_t)B * H * 16 * sizeof(float) + dlio_linear_bwd_data_ws_bytes(B, 4 * H, H);
 }
 
 extern "C" int dlio_lstm_seq_fwd(const float* gx, const float* w_hh, const float* b_hh,
@@ -425,7 +427,8 @@ extern "C" int dlio_lstm_seq_bwd(const float* dhs, int lddhs, const float* dhT, 
     hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, dhs, lddhs,
                        dhrec, dccur, gates, cs, c0, dgates, dG, t, tprev, first_fwd, B, H, rst,
                        rsb);
-    int rc = dlio_linear_bwd_data(dG, 4 * H, w_hh, dhrec, H, B, 4 * H, H, 0, stream);
+    int rc = dlio_linear_bwd_data(dG, 4 * H, w_hh, dhrec, H, B, 4 * H, H, 0, f + (size_t)16 * B * H,
+                                  ws_bytes - (size_t)16 * B * H * sizeof(float), stream);
     if (rc) return rc;
   }
   if (dh0) hipLaunchKernelGGL(init_state_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, dhrec, dh0, n);
@@ -473,7 +476,8 @@ extern "C" int dlio_gru_seq_bwd(const float* dhs, int lddhs, const float* dhT, c
     const int t = reverse ? step : T - 1 - step;
     hipLaunchKernelGGL(gru_cell_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, dhs, lddhs, dhcur,
                        gates, hp, dgx, dgh, dGh, t, B, H, rst, rsb);
-    int rc = dlio_linear_bwd_data(dGh, 3 * H, w_hh, dhcur, H, B, 3 * H, H, 1, stream);
+    int rc = dlio_linear_bwd_data(dGh, 3 * H, w_hh, dhcur, H, B, 3 * H, H, 1, f + (size_t)16 * B * H,
+                                  ws_bytes - (size_t)16 * B * H * sizeof(float), stream);
     if (rc) return rc;
   }
   if (dh0) hipLaunchKernelGGL(init_state_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, dhcur, dh0, n);

@@ -67,6 +67,12 @@ extern "C" int dlio_prof_collect(int kind, double* ms, double* flops, double* by
   return DLIO_OK;
 }
 
+thread_local int dlio_last_hip_error = 0;
+
+extern "C" const char* dlio_last_hip_error_string(void) {
+  return hipGetErrorString((hipError_t)dlio_last_hip_error);
+}
+
 extern "C" int dlio_version(void) { return 100; }
 extern "C" const char* dlio_arch(void) { return "gfx950"; }
 extern "C" const char* dlio_strerror(int code) {

@@ -256,9 +256,12 @@ def linear_bwd_data(dz, w, M, out=None, lddz=None, lddx=None, accumulate=False):
     N_, K = w.shape
     if out is None:
         out = torch.empty(M, K, dtype=torch.float32, device=dz.device)
+    nbytes = lib.dlio_linear_bwd_data_ws_bytes(M, N_, K)
+    ws = workspace(nbytes, dz.device, slot=3) if nbytes else None
     check(lib.dlio_linear_bwd_data(_ptr(dz), N_ if lddz is None else lddz, _ptr(w), _ptr(out),
                                    K if lddx is None else lddx, M, N_, K, int(accumulate),
-                                   _stream()), "linear_bwd_data")
+                                   _ptr(ws), ws.numel() if ws is not None else 0, _stream()),
+          "linear_bwd_data")
     return out
 
 

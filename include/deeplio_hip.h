@@ -40,6 +40,8 @@ typedef void* dlio_stream_t;
 int dlio_version(void);
 const char* dlio_arch(void);           /* "gfx950" */
 const char* dlio_strerror(int code);
+/* hipGetErrorString of the HIP error behind the last DLIO_ELAUNCH in this thread */
+const char* dlio_last_hip_error_string(void);
 
 /* ---- profiling hooks (bench.py roofline leg) ---------------------------
  * When enabled, the conv launchers bracket each launch with hipEvents on the
@@ -175,9 +177,12 @@ int dlio_linear_fwd(const float* x, int ldx, const float* w, const float* b,
 /* dz = dy * act'(y) (in terms of the OUTPUT y); dz may alias dy */
 int dlio_act_bwd(const float* dy, const float* y, float* dz, int64_t n, int act,
                  dlio_stream_t stream);
-/* dx[m][k] (+)= sum_n dz[m*lddz+n] * w[n*K+k] */
+/* dx[m][k] (+)= sum_n dz[m*lddz+n] * w[n*K+k].  With a workspace of
+ * dlio_linear_bwd_data_ws_bytes the large weight-streaming form is used (ws may be NULL). */
+size_t dlio_linear_bwd_data_ws_bytes(int M, int N, int K);
 int dlio_linear_bwd_data(const float* dz, int lddz, const float* w, float* dx, int lddx,
-                         int M, int N, int K, int accumulate, dlio_stream_t stream);
+                         int M, int N, int K, int accumulate, void* ws, size_t ws_bytes,
+                         dlio_stream_t stream);
 /* dw[n][k] (+)= sum_m dz[m][n]*x[m][k];  db[n] (+)= sum_m dz[m][n]  (db may be NULL) */
 int dlio_linear_bwd_weight(const float* dz, int lddz, const float* x, int ldx, float* dw,
                            float* db, int M, int N, int K, int accumulate,
