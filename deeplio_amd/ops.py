@@ -229,6 +229,7 @@ def chan_scale_bwd(dy, x, s):
 
 # ----------------------------------------------------------------------------- dense
 def linear_fwd(x, w, b, act=ACT_NONE, addend=None, out=None, M=None, ldx=None, ldadd=0, ldy=None):
+    _chk(w)
     N_, K = w.shape
     if M is None:
         M = x.numel() // K

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 --kernel-trace rocpd database (results.db) into a per-kernel table
+(count, total ms, avg us, share) -- the `--stats` view, written as markdown under profiles/."""
+import re
+import sqlite3
+import sys
+
+
+def main(db_path, out_path, steps, note=""):
+    cur = sqlite3.connect(db_path).cursor()
+    rows = cur.execute("select name, count(*), sum(end-start)/1e6, avg(end-start)/1e3, min(end-start)/1e3, "
+                       "max(end-start)/1e3 from kernels group by name order by 3 desc").fetchall()
+    tot = sum(r[2] for r in rows)
+    with open(out_path, "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats summary\n\n%s\n\n" % note)
+        f.write("total kernel time %.1f ms over %d steps (incl. warm-up) = %.1f ms/step\n\n" % (tot, steps, tot / steps))
+        f.write("| kernel | calls | total ms | avg us | min us | max us | % |\n|---|---|---|---|---|---|---|\n")
+        for n, c, s, a, mn, mx in rows:
+            n = re.sub(r"\(anonymous namespace\)::|void ", "", n)
+            n = re.sub(r"\(.*", "", n)
+            f.write("| `%s` | %d | %.2f | %.1f | %.1f | %.1f | %.1f |\n" % (n[:90], c, s, a, mn, mx, 100 * s / tot))
+    print("wrote", out_path)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]), " ".join(sys.argv[4:]))
