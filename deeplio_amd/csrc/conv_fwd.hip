@@ -19,20 +19,26 @@ namespace {
 
 template <int KH, int KW, int SH, int SW, int CK, int TWN>
 struct ConvCfg {
-  static constexpr int TH = 4;                  // output rows per block
+  static constexpr int TH = 4;                  // output rows per block (one per wave)
   static constexpr int TW = 32 * TWN;           // output cols per block
   static constexpr int MR = 2;                  // 32-channel tiles per wave
   static constexpr int CO_T = 32 * MR;          // output channels per block
-  static constexpr int NR = TWN;                // pixel tiles per wave (wave = one row)
+  static constexpr int NR = TWN;                // pixel tiles per wave
   static constexpr int PR = (TH - 1) * SH + KH; // patch rows
   static constexpr int PC = (TW - 1) * SW + KW; // patch cols
   static constexpr int PLANE = PR * PC;
+  static constexpr int NPOS = (PLANE + 255) / 256;   // patch positions per thread
   static constexpr int TAPS = KH * KW;
-  static constexpr int XL = CK * PLANE;         // floats
-  static constexpr int WL = TAPS * CK * CO_T;   // floats
-  static constexpr size_t LDS_BYTES = (size_t)(XL + WL) * 4;
+  static constexpr int XL = CK * PLANE;         // floats per LDS buffer
+  static constexpr size_t LDS_BYTES = (size_t)2 * XL * 4;   // double buffered
 };
 
+// Pipeline per CK-channel chunk: the global loads of chunk i+1 (patch with halo, zero padding
+// and the optional fused producer BN-apply+ReLU) are issued into registers, the MFMAs of chunk
+// i run out of LDS buffer i&1 with the weight operand read straight from L1/L2 (all four waves
+// of a block read the same [k][co] rows), then the registers are written to buffer (i+1)&1 and
+// ONE barrier closes the iteration.  A thread owns the same NPOS patch positions for every
+// channel, so the per-element index arithmetic is done once per block.
 template <int KH, int KW, int SH, int SW, int CK, int TWN>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
@@ -41,8 +47,6 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(
     int tiles_w, int tiles_h, int co_tiles) {
   using C = ConvCfg<KH, KW, SH, SW, CK, TWN>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Xl = smem;
-  float* Wl = smem + C::XL;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -50,7 +54,6 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(
   const int l31 = lane & 31;
   const int half = lane >> 5;
 
-  // block -> (co tile fastest, then w tile, h tile, image)
   int bid = blockIdx.x;
   const int cot = bid % co_tiles; bid /= co_tiles;
   const int tw = bid % tiles_w;   bid /= tiles_w;
@@ -62,6 +65,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(
   const int ow0 = tw * C::TW;
   const int ih0 = oh0 * SH - d.PH;
   const int iw0 = ow0 * SW - d.PW;
+  const int Cin = d.Cin, Cout = d.Cout;
+  const size_t HW = (size_t)d.H * d.W;
 
   f32x16 acc[C::MR][C::NR];
 #pragma unroll
@@ -71,57 +76,71 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
 
-  const float* xn = x + ((size_t)n * d.in_ctot + d.in_coff) * (size_t)d.H * d.W;
+  // patch positions owned by this thread (same for every channel and chunk)
+  int poff[C::NPOS];
+  bool pval[C::NPOS];
+#pragma unroll
+  for (int j = 0; j < C::NPOS; ++j) {
+    const int pos = tid + j * 256;
+    const int r = pos / C::PC;
+    const int col = pos - r * C::PC;
+    const int ih = ih0 + r, iw = iw0 + col;
+    pval[j] = pos < C::PLANE && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W;
+    poff[j] = pval[j] ? ih * d.W + iw : 0;
+  }
+  const float* xn = x + ((size_t)n * d.in_ctot + d.in_coff) * HW;
   const bool has_aff = in_scale != nullptr;
+  // clamped weight columns (rows >= Cout are dropped at the store)
+  int cc[C::MR];
+#pragma unroll
+  for (int m = 0; m < C::MR; ++m) cc[m] = min(co0 + m * 32 + l31, Cout - 1);
 
-  for (int c0 = 0; c0 < d.Cin; c0 += CK) {
-    // ---- stage input patch -------------------------------------------------
-    for (int idx = tid; idx < C::XL; idx += 256) {
-      const int c = idx / C::PLANE;
-      const int rem = idx - c * C::PLANE;
-      const int r = rem / C::PC;
-      const int col = rem - r * C::PC;
+  float reg[CK][C::NPOS];
+  auto load_chunk = [&](int c0) {
+#pragma unroll
+    for (int c = 0; c < CK; ++c) {
       const int ci = c0 + c;
-      const int ih = ih0 + r;
-      const int iw = iw0 + col;
-      float v = 0.f;
-      if (ci < d.Cin && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W) {
-        v = xn[((size_t)ci * d.H + ih) * d.W + iw];
-        if (has_aff) {
-          v = (v - in_mean[ci]) * in_scale[ci] + in_shift[ci];
-          if (d.in_relu) v = fmaxf(v, 0.f);
+      const bool cv = ci < Cin;
+      const float* xc = xn + (size_t)(cv ? ci : 0) * HW;
+#pragma unroll
+      for (int j = 0; j < C::NPOS; ++j) {
+        float v = 0.f;
+        if (cv && pval[j]) {
+          v = xc[poff[j]];
+          if (has_aff) {
+            v = (v - in_mean[ci]) * in_scale[ci] + in_shift[ci];
+            if (d.in_relu) v = fmaxf(v, 0.f);
+          }
         }
+        reg[c][j] = v;
       }
-      Xl[idx] = v;
     }
-    // ---- stage weight slab: Wl[(tap*CK + c)][co] ---------------------------
-    for (int idx = tid; idx < C::WL; idx += 256) {
-      const int co = idx % C::CO_T;
-      const int kc = idx / C::CO_T;
-      const int c = kc % CK;
-      const int tap = kc / CK;
-      const int ci = c0 + c;
-      float v = 0.f;
-      if (ci < d.Cin && co0 + co < d.Cout)
-        v = wt[((size_t)tap * d.Cin + ci) * d.Cout + co0 + co];
-      Wl[idx] = v;
-    }
-    __syncthreads();
-
-    // ---- MFMA over this chunk ---------------------------------------------
+  };
+  auto store_chunk = [&](float* Xl) {
+#pragma unroll
+    for (int c = 0; c < CK; ++c)
+#pragma unroll
+      for (int j = 0; j < C::NPOS; ++j) {
+        const int pos = tid + j * 256;
+        if (pos < C::PLANE) Xl[c * C::PLANE + pos] = reg[c][j];
+      }
+  };
+  auto mfma_chunk = [&](const float* Xl, int c0) {
 #pragma unroll
     for (int dy = 0; dy < KH; ++dy) {
 #pragma unroll
       for (int dx = 0; dx < KW; ++dx) {
         const int tap = dy * KW + dx;
         const float* xrow = Xl + (wave * SH + dy) * C::PC + dx + l31 * SW;
-        const float* wrow = Wl + (size_t)tap * CK * C::CO_T + l31;
 #pragma unroll
         for (int c2 = 0; c2 < CK; c2 += 2) {
           const int c = c2 + half;
+          // channels past Cin are zero in LDS, so a clamped (finite) weight is enough
+          const int ci = min(c0 + c, Cin - 1);
+          const float* wrow = wt + ((size_t)tap * Cin + ci) * Cout;
           float a[C::MR], b[C::NR];
 #pragma unroll
-          for (int m = 0; m < C::MR; ++m) a[m] = wrow[c * C::CO_T + m * 32];
+          for (int m = 0; m < C::MR; ++m) a[m] = wrow[cc[m]];
 #pragma unroll
           for (int q = 0; q < C::NR; ++q) b[q] = xrow[c * C::PLANE + q * 32 * SW];
 #pragma unroll
@@ -132,6 +151,18 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(
         }
       }
     }
+  };
+
+  const int nch = (Cin + CK - 1) / CK;
+  load_chunk(0);
+  store_chunk(smem);
+  __syncthreads();
+  for (int i = 0; i < nch; ++i) {
+    float* cur = smem + (i & 1) * C::XL;
+    float* nxt = smem + ((i + 1) & 1) * C::XL;
+    if (i + 1 < nch) load_chunk((i + 1) * CK);
+    mfma_chunk(cur, i * CK);
+    if (i + 1 < nch) store_chunk(nxt);
     __syncthreads();
   }
 
@@ -144,7 +175,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (co >= d.Cout) continue;
+      if (co >= Cout) continue;
       const float bv = bias ? bias[co] : 0.f;
 #pragma unroll
       for (int q = 0; q < C::NR; ++q) {
@@ -188,6 +219,123 @@ int launch_tw(const float* x, const float* wt, const float* bias, const float* i
   if (d.OW > 32)
     return launch<KH, KW, SH, SW, CK, 2>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
   return launch<KH, KW, SH, SW, CK, 1>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
+}
+
+// ---------------------------------------------------------------------------------------
+// 1x1, stride 1: pointwise GEMM over the flattened pixel axis.  No LDS and no barriers: the
+// input is used exactly once per output-channel tile, so staging it would only add a round
+// trip.  The MFMA B operand (2 channels x 32 consecutive pixels) is loaded straight from HBM
+// as two coalesced 128-B rows per wave instruction, the A operand (weights, [Cin][Cout]) from
+// L1/L2; the k loop is unrolled so >= 8 loads per lane are in flight.  Waves are independent,
+// so 4 blocks/CU hide the HBM latency.  Squeeze layers (Cout 16..80) are HBM-bound here,
+// expand1x1 / squeeze-dgrad (Cout 64..768) write-bound.
+template <int MR, bool AFF>
+__global__ __launch_bounds__(256) void conv1x1_direct_kernel(
+    const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
+    const float* __restrict__ in_mean, const float* __restrict__ in_scale,
+    const float* __restrict__ in_shift, const float* residual, float* y, DlioConvDesc d,
+    int pix_blocks, int co_tiles) {
+  constexpr int NR = 2;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int l31 = lane & 31;
+  const int half = lane >> 5;
+  int bid = blockIdx.x;
+  const int cot = bid % co_tiles; bid /= co_tiles;
+  const int pb = bid % pix_blocks; bid /= pix_blocks;
+  const int n = bid;
+  const int P = d.OH * d.OW;
+  const int co0 = cot * 32 * MR;
+  const int p0 = (pb * 4 + wave) * (32 * NR);
+  if (p0 >= P) return;
+
+  f32x16 acc[MR][NR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
+
+  // clamped addresses + masks instead of divergent guards
+  int pc[NR];
+  float pm[NR];
+#pragma unroll
+  for (int q = 0; q < NR; ++q) {
+    const int p = p0 + q * 32 + l31;
+    pm[q] = p < P ? 1.f : 0.f;
+    pc[q] = p < P ? p : P - 1;
+  }
+  int cc[MR];
+  float cm[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    const int co = co0 + m * 32 + l31;
+    cm[m] = co < d.Cout ? 1.f : 0.f;
+    cc[m] = co < d.Cout ? co : d.Cout - 1;
+  }
+  const float* xn = x + ((size_t)n * d.in_ctot + d.in_coff) * (size_t)P;
+  const int Cin = d.Cin;
+#pragma unroll 8
+  for (int k = 0; k < Cin; k += 2) {
+    const int kk = k + half;
+    const bool kv = kk < Cin;
+    const int kc = kv ? kk : Cin - 1;
+    const float km = kv ? 1.f : 0.f;
+    float a[MR], b[NR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) a[m] = wt[(size_t)kc * d.Cout + cc[m]] * (cm[m] * km);
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      float v = xn[(size_t)kc * P + pc[q]];
+      if (AFF) {
+        v = (v - in_mean[kc]) * in_scale[kc] + in_shift[kc];
+        if (d.in_relu) v = fmaxf(v, 0.f);
+      }
+      b[q] = v * pm[q];
+    }
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+      for (int q = 0; q < NR; ++q)
+        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[q], acc[m][q], 0, 0, 0);
+  }
+
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (co >= d.Cout) continue;
+      const float bv = bias ? bias[co] : 0.f;
+#pragma unroll
+      for (int q = 0; q < NR; ++q) {
+        const int p = p0 + q * 32 + l31;
+        if (p >= P) continue;
+        float v = acc[m][q][r] + bv;
+        if (residual) v += residual[((size_t)n * d.res_ctot + d.res_coff + co) * P + p];
+        y[((size_t)n * d.out_ctot + d.out_coff + co) * P + p] = v;
+      }
+    }
+  }
+}
+
+template <int MR>
+int launch_1x1(const float* x, const float* wt, const float* bias, const float* in_mean,
+               const float* in_scale, const float* in_shift, const float* residual, float* y,
+               const DlioConvDesc& d, hipStream_t s) {
+  const int P = d.OH * d.OW;
+  const int pix_blocks = cdiv(P, 256);
+  const int co_tiles = cdiv(d.Cout, 32 * MR);
+  const int64_t blocks = (int64_t)pix_blocks * co_tiles * d.N;
+  if (blocks <= 0 || blocks > 0x7fffffff) return DLIO_EINVAL;
+  if (in_scale)
+    hipLaunchKernelGGL((conv1x1_direct_kernel<MR, true>), dim3((unsigned)blocks), dim3(256), 0, s, x,
+                       wt, bias, in_mean, in_scale, in_shift, residual, y, d, pix_blocks, co_tiles);
+  else
+    hipLaunchKernelGGL((conv1x1_direct_kernel<MR, false>), dim3((unsigned)blocks), dim3(256), 0, s, x,
+                       wt, bias, in_mean, in_scale, in_shift, residual, y, d, pix_blocks, co_tiles);
+  return dlio_check_launch();
 }
 
 __global__ void prep_weight_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout,
@@ -242,18 +390,22 @@ extern "C" int dlio_conv2d_fwd(const float* x, const float* wt, const float* bia
 #define CONV_CASE(kh, kw, sh, sw, ck)                                                        \
   if (d.KH == kh && d.KW == kw && d.SH == sh && d.SW == sw)                                  \
     rc = launch_tw<kh, kw, sh, sw, ck>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
-  if (d.KH == 1 && d.KW == 1 && d.SH == 1 && d.SW == 1 && (d.Cin % 32) != 0)
-    rc = launch_tw<1, 1, 1, 1, 16>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
-  else CONV_CASE(1, 1, 1, 1, 32)
-  else CONV_CASE(3, 3, 1, 1, 8)
+  if (d.KH == 1 && d.KW == 1 && d.SH == 1 && d.SW == 1 && d.PH == 0 && d.PW == 0) {
+    if (d.Cout <= 32) rc = launch_1x1<1>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
+    else if (d.Cout > 64 && d.Cout <= 96)
+      rc = launch_1x1<3>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
+    else rc = launch_1x1<2>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
+  }
+  else CONV_CASE(1, 1, 1, 1, 16)
+  else CONV_CASE(3, 3, 1, 1, 16)
   else CONV_CASE(3, 5, 1, 2, 4)
-  else CONV_CASE(3, 5, 1, 1, 4)
+  else CONV_CASE(3, 5, 1, 1, 8)
   else CONV_CASE(5, 7, 1, 2, 2)
-  else CONV_CASE(5, 7, 1, 1, 2)
+  else CONV_CASE(5, 7, 1, 1, 4)
   else CONV_CASE(3, 3, 2, 2, 8)
   else CONV_CASE(3, 3, 1, 2, 8)
-  else CONV_CASE(1, 1, 1, 2, 32)
-  else CONV_CASE(1, 1, 2, 2, 32)
+  else CONV_CASE(1, 1, 1, 2, 16)
+  else CONV_CASE(1, 1, 2, 2, 16)
 #undef CONV_CASE
   dlio_prof_end(0, s);
   return rc;
