@@ -20,18 +20,31 @@ struct WgCfg {
   static constexpr int TH = 4, TW = 32;
   static constexpr int MR = 2, CO_T = 64;
   static constexpr int TAPS = KH * KW;
-  static constexpr int CKMAX = (NT * 32) / TAPS;
+  // channels per chunk; halved for the 1x1 stride-(2,2) patch so two pipeline stages fit in LDS
+  static constexpr int CKMAX = ((NT * 32) / TAPS) / ((TAPS == 1 && SH * SW == 4) ? 2 : 1);
   static constexpr int PR = (TH - 1) * SH + KH;
   static constexpr int PC = (TW - 1) * SW + KW;
-  static constexpr int PLANE = (PR * PC) | 1;     // odd -> lanes (=channels) hit distinct banks
+  static constexpr int PRPC = PR * PC;
+  static constexpr int PLANE = PRPC | 1;          // odd -> lanes (=channels) hit distinct banks
   static constexpr int DYS = TH * TW + 1;         // odd per-channel stride of the dY tile
   static constexpr int XL = CKMAX * PLANE;
   static constexpr int DL = CO_T * DYS;
+  static constexpr int BUF = XL + DL;             // one pipeline stage
   static constexpr int RED = MR * NT * 16 * 64;
-  static constexpr int SM_FLOATS = (XL + DL) > RED ? (XL + DL) : RED;
+  static constexpr int SM_FLOATS = 2 * BUF > RED ? 2 * BUF : RED;
   static constexpr size_t LDS_BYTES = (size_t)SM_FLOATS * 4;
+  // X staging: LPP threads cover one channel plane, CPAR channels in parallel
+  static constexpr int LPP = PRPC <= 128 ? 128 : 256;
+  static constexpr int CPAR = 256 / LPP;
+  static constexpr int NPOSX = (PRPC + LPP - 1) / LPP;
+  static constexpr int NCX = (CKMAX + CPAR - 1) / CPAR;
+  static constexpr int NDY = CO_T / 2;            // dY elements per thread
 };
 
+// Software pipeline over the block's pixel tiles: global loads of tile t+1 (dY tile and X'
+// patch) are issued into registers, the MFMAs of tile t run out of LDS stage t&1, the registers
+// are written to stage (t+1)&1, one barrier per tile.  The kernel runs one workgroup per CU
+// (160 accumulator registers), so this in-block overlap is what hides the HBM latency.
 template <int KH, int KW, int SH, int SW, int NT>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ wsp,
@@ -40,8 +53,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     int tiles_w, int tiles_h) {
   using C = WgCfg<KH, KW, SH, SW, NT>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Xl = smem;
-  float* Dl = smem + C::XL;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -84,49 +95,86 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   const bool has_aff = in_scale != nullptr;
   const int total_tiles = d.N * tiles_h * tiles_w;
   const size_t ohw = (size_t)d.OH * d.OW;
+  const size_t HW = (size_t)d.H * d.W;
 
-  for (int tile = split; tile < total_tiles; tile += splits) {
+  // thread-constant staging coordinates
+  const int dy_r = (tid >> 5) & 3, dy_col = tid & 31, dy_co = tid >> 7;   // co = dy_co + 2*i
+  const int xp = tid % C::LPP, xcph = tid / C::LPP;                      // c = xcph + CPAR*i
+  int xr[C::NPOSX], xc[C::NPOSX];
+#pragma unroll
+  for (int j = 0; j < C::NPOSX; ++j) {
+    const int pos = xp + j * C::LPP;
+    xr[j] = pos / C::PC;
+    xc[j] = pos - xr[j] * C::PC;
+  }
+
+  float rdy[C::NDY];
+  float rx[C::NCX][C::NPOSX];
+  auto load_tile = [&](int tile) {
     int tt = tile;
     const int tw = tt % tiles_w; tt /= tiles_w;
     const int th = tt % tiles_h; tt /= tiles_h;
     const int n = tt;
     const int oh0 = th * C::TH, ow0 = tw * C::TW;
     const int ih0 = oh0 * SH - d.PH, iw0 = ow0 * SW - d.PW;
-
-    // ---- stage X' patch [ck][PR][PC] ---------------------------------------
-    const float* xn = x + ((size_t)n * d.in_ctot + d.in_coff + c0) * (size_t)d.H * d.W;
-    for (int idx = tid; idx < C::CKMAX * C::PR * C::PC; idx += 256) {
-      const int c = idx / (C::PR * C::PC);
-      const int rem = idx - c * (C::PR * C::PC);
-      const int r = rem / C::PC;
-      const int col = rem - r * C::PC;
-      const int ih = ih0 + r, iw = iw0 + col;
-      float v = 0.f;
-      if (c < ck && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W) {
-        v = xn[((size_t)c * d.H + ih) * d.W + iw];
-        if (has_aff) {
-          v = (v - in_mean[c0 + c]) * in_scale[c0 + c] + in_shift[c0 + c];
-          if (d.in_relu) v = fmaxf(v, 0.f);
+    {
+      const int oh = oh0 + dy_r, ow = ow0 + dy_col;
+      const bool pv = oh < d.OH && ow < d.OW;
+      const float* p = dy + ((size_t)n * d.out_ctot + d.out_coff + co0) * ohw +
+                       (pv ? (size_t)oh * d.OW + ow : 0);
+#pragma unroll
+      for (int i = 0; i < C::NDY; ++i) {
+        const int co = dy_co + 2 * i;
+        rdy[i] = (pv && co0 + co < d.Cout) ? p[(size_t)co * ohw] : 0.f;
+      }
+    }
+    const float* xn = x + ((size_t)n * d.in_ctot + d.in_coff + c0) * HW;
+    int po[C::NPOSX];
+    bool pv[C::NPOSX];
+#pragma unroll
+    for (int j = 0; j < C::NPOSX; ++j) {
+      const int ih = ih0 + xr[j], iw = iw0 + xc[j];
+      pv[j] = (xp + j * C::LPP) < C::PRPC && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W;
+      po[j] = pv[j] ? ih * d.W + iw : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < C::NCX; ++i) {
+      const int c = xcph + C::CPAR * i;
+      const bool cv = c < ck;
+#pragma unroll
+      for (int j = 0; j < C::NPOSX; ++j) {
+        float v = 0.f;
+        if (cv && pv[j]) {
+          v = xn[(size_t)c * HW + po[j]];
+          if (has_aff) {
+            v = (v - in_mean[c0 + c]) * in_scale[c0 + c] + in_shift[c0 + c];
+            if (d.in_relu) v = fmaxf(v, 0.f);
+          }
+        }
+        rx[i][j] = v;
+      }
+    }
+  };
+  auto store_tile = [&](float* buf) {
+    float* Xl = buf;
+    float* Dl = buf + C::XL;
+#pragma unroll
+    for (int i = 0; i < C::NDY; ++i) Dl[(dy_co + 2 * i) * C::DYS + dy_r * 32 + dy_col] = rdy[i];
+#pragma unroll
+    for (int i = 0; i < C::NCX; ++i) {
+      const int c = xcph + C::CPAR * i;
+      if (c < C::CKMAX) {
+#pragma unroll
+        for (int j = 0; j < C::NPOSX; ++j) {
+          const int pos = xp + j * C::LPP;
+          if (pos < C::PRPC) Xl[c * C::PLANE + pos] = rx[i][j];
         }
       }
-      Xl[c * C::PLANE + r * C::PC + col] = v;
     }
-    // ---- stage dY tile [CO_T][TH][TW] --------------------------------------
-    const float* dyn = dy + ((size_t)n * d.out_ctot + d.out_coff + co0) * ohw;
-    for (int idx = tid; idx < C::CO_T * C::TH * C::TW; idx += 256) {
-      const int col = idx & 31;
-      const int r = (idx >> 5) & 3;
-      const int co = idx >> 7;
-      const int oh = oh0 + r, ow = ow0 + col;
-      float v = 0.f;
-      if (co0 + co < d.Cout && oh < d.OH && ow < d.OW) v = dyn[(size_t)co * ohw + (size_t)oh * d.OW + ow];
-      Dl[co * C::DYS + r * 32 + col] = v;
-    }
-    __syncthreads();
-
-    // ---- wave = row `wave` of the tile; 16 pixel pairs ------------------------
-    const float* drow = Dl + l31 * C::DYS + wave * 32 + half;
-    const float* xrow = Xl + (wave * SH) * C::PC + half * SW;
+  };
+  auto mfma_tile = [&](const float* buf) {
+    const float* drow = buf + C::XL + l31 * C::DYS + wave * 32 + half;
+    const float* xrow = buf + (wave * SH) * C::PC + half * SW;
 #pragma unroll 4
     for (int kp = 0; kp < 16; ++kp) {
       float a[C::MR], b[NT];
@@ -140,6 +188,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
         for (int t = 0; t < NT; ++t)
           acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[t], acc[m][t], 0, 0, 0);
     }
+  };
+
+  if (split < total_tiles) {
+    load_tile(split);
+    store_tile(smem);
+  }
+  __syncthreads();
+  int it = 0;
+  for (int tile = split; tile < total_tiles; tile += splits, ++it) {
+    float* cur = smem + (it & 1) * C::BUF;
+    float* nxt = smem + ((it + 1) & 1) * C::BUF;
+    const bool more = tile + splits < total_tiles;
+    if (more) load_tile(tile + splits);
+    mfma_tile(cur);
+    if (more) store_tile(nxt);
     __syncthreads();
   }
 
@@ -193,13 +256,15 @@ struct WgPlan {
 };
 
 int nt_for(const DlioConvDesc& d) {
-  return (d.KH == 1 && d.KW == 1) ? 2 : 5;
+  if (d.KH == 1 && d.KW == 1) return (d.SH == 1 && d.SW == 1) ? 2 : 1;
+  return 5;
 }
 
 bool make_plan(const DlioConvDesc& d, WgPlan& p) {
   p.nt = nt_for(d);
   const int taps = d.KH * d.KW;
   p.ckmax = (p.nt * 32) / taps;
+  if (taps == 1 && d.SH * d.SW == 4) p.ckmax /= 2;
   if (p.ckmax < 1) return false;
   p.co_tiles = cdiv(d.Cout, 64);
   p.ci_chunks = cdiv(d.Cin, p.ckmax);
@@ -277,8 +342,8 @@ extern "C" int dlio_conv2d_wgrad(const float* x, const float* dy, float* dw,
   else WG_CASE(5, 7, 1, 1, 5)
   else WG_CASE(3, 3, 2, 2, 5)
   else WG_CASE(3, 3, 1, 2, 5)
-  else WG_CASE(1, 1, 1, 2, 2)
-  else WG_CASE(1, 1, 2, 2, 2)
+  else WG_CASE(1, 1, 1, 2, 1)
+  else WG_CASE(1, 1, 2, 2, 1)
 #undef WG_CASE
   dlio_prof_end(1, s);
   return rc;
