@@ -272,7 +272,7 @@ bool make_plan(const DlioConvDesc& d, WgPlan& p) {
   p.tiles_h = cdiv(d.OH, 4);
   const int64_t total_tiles = (int64_t)d.N * p.tiles_w * p.tiles_h;
   int64_t pairs = (int64_t)p.co_tiles * p.ci_chunks;
-  int64_t splits = cdiv64(768, pairs);
+  int64_t splits = cdiv64(512, pairs);   // one workgroup per CU -> two block waves
   if (splits > total_tiles) splits = total_tiles;
   const size_t slab = (size_t)d.Cout * d.Cin * taps * 4;
   const size_t cap = (size_t)96 << 20;

@@ -75,6 +75,103 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(
   }
 }
 
+// ---- 3x3 / pad 1 / stride (SH,2) fast paths (every pool on the PointSeg and ResNet paths) ----
+// forward: one thread = 2 adjacent outputs = input columns 4b-1 .. 4b+3: per window row one
+// aligned float4 + one scalar instead of 6 scalar loads; same scan order as the generic kernel
+// (ky major, kx minor, strict '>'), so values and argmax are identical.
+template <int SH>
+__global__ __launch_bounds__(256) void maxpool3_fwd_sw2(const float* __restrict__ x,
+                                                        const float* __restrict__ xs,
+                                                        float* __restrict__ y,
+                                                        uint8_t* __restrict__ idx, int64_t planes,
+                                                        int H, int W, int OH, int OW) {
+  const int OW2 = OW >> 1;
+  const int64_t total = planes * OH * OW2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i % OW2);
+    int64_t t = i / OW2;
+    const int oh = (int)(t % OH);
+    const int64_t pl = t / OH;
+    const float* xp = x + (size_t)pl * H * W;
+    const float s = xs ? xs[pl] : 1.f;
+    float best[2] = {-INFINITY, -INFINITY};
+    int bi[2] = {0, 0};
+    bool first[2] = {true, true};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int ih = oh * SH - 1 + ky;
+      if (ih < 0 || ih >= H) continue;
+      const float* row = xp + (size_t)ih * W + 4 * b;
+      const float4 v4 = *reinterpret_cast<const float4*>(row);
+      float v[5];
+      v[0] = b > 0 ? row[-1] : 0.f;
+      v[1] = v4.x; v[2] = v4.y; v[3] = v4.z; v[4] = v4.w;
+      if (xs) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] *= s;
+      }
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int c = 2 * o + kx;          // column index into v (input col 4b-1+c)
+          if (c == 0 && b == 0) continue;    // left padding
+          const float val = v[c];
+          if (first[o] || val > best[o] || val != val) { best[o] = val; bi[o] = ky * 3 + kx; first[o] = false; }
+        }
+      }
+    }
+    const size_t oo = ((size_t)pl * OH + oh) * OW + 2 * b;
+    *reinterpret_cast<float2*>(y + oo) = make_float2(best[0], best[1]);
+    if (idx) { idx[oo] = (uint8_t)bi[0]; idx[oo + 1] = (uint8_t)bi[1]; }
+  }
+}
+
+// backward: one thread = 4 adjacent input columns 4b..4b+3 <- output columns 2b, 2b+1, 2b+2
+template <int SH>
+__global__ __launch_bounds__(256) void maxpool3_bwd_sw2(const float* __restrict__ dy,
+                                                        const uint8_t* __restrict__ idx,
+                                                        const float* __restrict__ xs,
+                                                        float* __restrict__ dx, int64_t planes, int H,
+                                                        int W, int OH, int OW) {
+  const int W4 = W >> 2;
+  const int64_t total = planes * H * W4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i % W4);
+    int64_t t = i / W4;
+    const int ih = (int)(t % H);
+    const int64_t pl = t / H;
+    const float* dyp = dy + (size_t)pl * OH * OW;
+    const uint8_t* ip = idx + (size_t)pl * OH * OW;
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+    int ohs[3], kys[3], nc;
+    if (SH == 1) { nc = 3; ohs[0] = ih - 1; kys[0] = 2; ohs[1] = ih; kys[1] = 1; ohs[2] = ih + 1; kys[2] = 0; }
+    else if ((ih & 1) == 0) { nc = 1; ohs[0] = ih >> 1; kys[0] = 1; ohs[1] = ohs[2] = -1; kys[1] = kys[2] = 0; }
+    else { nc = 2; ohs[0] = ih >> 1; kys[0] = 2; ohs[1] = (ih >> 1) + 1; kys[1] = 0; ohs[2] = -1; kys[2] = 0; }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      if (q >= nc) continue;
+      const int oh = ohs[q];
+      if (oh < 0 || oh >= OH) continue;
+      const int base = kys[q] * 3;
+      const size_t ro = (size_t)oh * OW + 2 * b;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if (2 * b + c >= OW) continue;
+        const int kx = (int)ip[ro + c] - base;
+        const float v = dyp[ro + c];
+        if (c == 0) { if (kx == 1) g[0] += v; else if (kx == 2) g[1] += v; }
+        else if (c == 1) { if (kx == 0) g[1] += v; else if (kx == 1) g[2] += v; else if (kx == 2) g[3] += v; }
+        else { if (kx == 0) g[3] += v; }
+      }
+    }
+    if (xs) { const float s = xs[pl]; g[0] *= s; g[1] *= s; g[2] *= s; g[3] *= s; }
+    *reinterpret_cast<float4*>(dx + ((size_t)pl * H + ih) * W + 4 * b) = make_float4(g[0], g[1], g[2], g[3]);
+  }
+}
+
 // one block per (n, c) plane
 __global__ __launch_bounds__(256) void gap_fwd_kernel(const float* __restrict__ x, int ctot,
                                                       int coff, float* __restrict__ out, int N,
@@ -150,6 +247,17 @@ extern "C" int dlio_maxpool2d_fwd(const float* x, const float* x_scale, float* y
                                   int SW, int PH, int PW, dlio_stream_t stream) {
   if (!x || !y || N <= 0 || C <= 0 || K <= 0 || K > 15) return DLIO_EINVAL;
   const int64_t total = (int64_t)N * C * OH * OW;
+  if (K == 3 && SW == 2 && PH == 1 && PW == 1 && (SH == 1 || SH == 2) && (W & 3) == 0 && OW * 2 == W &&
+      OH == (H + 2 - 3) / SH + 1) {
+    const int64_t work = total / 2;
+    if (SH == 1)
+      hipLaunchKernelGGL(maxpool3_fwd_sw2<1>, dim3(ew_grid(work, 256)), dim3(256), 0, as_stream(stream),
+                         x, x_scale, y, idx, (int64_t)N * C, H, W, OH, OW);
+    else
+      hipLaunchKernelGGL(maxpool3_fwd_sw2<2>, dim3(ew_grid(work, 256)), dim3(256), 0, as_stream(stream),
+                         x, x_scale, y, idx, (int64_t)N * C, H, W, OH, OW);
+    return dlio_check_launch();
+  }
   hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(total, 256)), dim3(256), 0,
                      as_stream(stream), x, x_scale, y, idx, N, C, H, W, OH, OW, K, SH, SW, PH, PW);
   return dlio_check_launch();
@@ -160,6 +268,17 @@ extern "C" int dlio_maxpool2d_bwd(const float* dy, const uint8_t* idx, const flo
                                   int SH, int SW, int PH, int PW, dlio_stream_t stream) {
   if (!dy || !idx || !dx || N <= 0 || C <= 0 || K <= 0) return DLIO_EINVAL;
   const int64_t total = (int64_t)N * C * H * W;
+  if (K == 3 && SW == 2 && PH == 1 && PW == 1 && (SH == 1 || SH == 2) && (W & 3) == 0 && OW * 2 == W &&
+      OH == (H + 2 - 3) / SH + 1) {
+    const int64_t work = total / 4;
+    if (SH == 1)
+      hipLaunchKernelGGL(maxpool3_bwd_sw2<1>, dim3(ew_grid(work, 256)), dim3(256), 0, as_stream(stream),
+                         dy, idx, x_scale, dx, (int64_t)N * C, H, W, OH, OW);
+    else
+      hipLaunchKernelGGL(maxpool3_bwd_sw2<2>, dim3(ew_grid(work, 256)), dim3(256), 0, as_stream(stream),
+                         dy, idx, x_scale, dx, (int64_t)N * C, H, W, OH, OW);
+    return dlio_check_launch();
+  }
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(total, 256)), dim3(256), 0,
                      as_stream(stream), dy, idx, x_scale, dx, N, C, H, W, OH, OW, K, SH, SW, PH, PW);
   return dlio_check_launch();

@@ -583,6 +583,8 @@ class DeepLIO(BaseNet):
         self.input_shape = input_shape
         self.lidar_feat_net = self.imu_feat_net = self.fusion_net = self.odom_feat_net = None
         self.drop = self.fc_pos = self.fc_ori = None
+        self.side_stream = True      # overlap the IMU branch with the lidar branch
+        self._side = None
 
     def initialize(self):
         last = next(n for n in (self.odom_feat_net, self.fusion_net, self.imu_feat_net,
@@ -598,9 +600,26 @@ class DeepLIO(BaseNet):
         last = feat_l = feat_i = None
         if self.training and getattr(self, "_bn_counters", None) is not None:
             self._bn_counters += 1
+        # The IMU branch (latency-bound persistent RNN kernels, 2 workgroups) is independent of the
+        # lidar branch until the fusion layer: run it on a second HIP stream so it overlaps the
+        # convolutions; autograd replays each backward node on its forward stream.
+        side = None
+        if (self.lidar_feat_net is not None and self.imu_feat_net is not None and torch.is_tensor(imu_meas)
+                and imu_meas.is_cuda and self.side_stream):
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=imu_meas.device)
+            side = self._side
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                feat_i = self.imu_feat_net(imu_meas)
         if self.lidar_feat_net is not None:
             last = feat_l = self.lidar_feat_net(lidar_imgs)
-        if self.imu_feat_net is not None:
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+            feat_i.record_stream(torch.cuda.current_stream())
+            last = feat_i
+        elif self.imu_feat_net is not None:
             last = feat_i = self.imu_feat_net(imu_meas)
         if self.fusion_net is not None:
             last = self.fusion_net([feat_l, feat_i])

