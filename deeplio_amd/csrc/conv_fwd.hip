@@ -3,49 +3,84 @@
 // GEMM orientation (chosen for NCHW): D[co][pixel] = sum_k W[co][k] * X[k][pixel]
 //   A operand = weights, lane l holds W[co = l&31][k + (l>>5)]
 //   B operand = im2col,  lane l holds X[k + (l>>5)][pixel = l&31]  -> 32 consecutive
-//               pixels of one image row: a conflict-free ds_read_b32 from the LDS patch
+//               pixels of one image row
 //   D: lane = pixel column, 16 regs = 16 output channels -> every store instruction
 //      writes 2 x 128 B contiguous row segments of the NCHW output.
-// K is walked as (ci-chunk) x (tap) x (ci pair); the input patch of CK channels (with
-// halo, zero padding, and the optional fused BN-apply+ReLU of the producer) and the
-// matching weight slab are staged in LDS once per chunk.
+// Two kernels:
+//   conv_fwd_kernel        general taps/strides: input patch (halo, zero padding, optional fused
+//                          producer BN-apply+ReLU) double-buffered in LDS with register prefetch
+//                          of the next channel chunk; weights straight from L1/L2.
+//   conv1x1_direct_kernel  1x1 stride 1: no LDS at all, both operands loaded from global with an
+//                          explicit two-stage register pipeline.
 //
 // Replaces nn.Conv2d forward (and, with mode-1 prepped weights, the stride-1 data
 // gradient) on the reference path: pointseg_net.py:18, pointseg_modules.py:96-106,
 // base_net.py:55-71, resnet.py:36, lidar_feat_nets.py:279-304.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
-template <int KH, int KW, int SH, int SW, int CK, int TWN>
+// bias + residual + NCHW store of one wave's MR x NR accumulator tiles.  Residual values are
+// fetched for the whole tile BEFORE the first store so the loads are in flight together
+// (a load->add->store chain per element serialises on memory latency).
+template <int MR, int NR>
+__device__ __forceinline__ void store_tiles(f32x16 (&acc)[MR][NR], const float* __restrict__ bias,
+                                            const float* residual, float* y, const DlioConvDesc& d,
+                                            int n, int co0, int half, bool (&pv)[NR],
+                                            size_t (&pix)[NR], size_t plane) {
+  if (residual) {
+    const float* rb = residual + ((size_t)n * d.res_ctot + d.res_coff) * plane;
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int cc = co < d.Cout ? co : d.Cout - 1;
+#pragma unroll
+        for (int q = 0; q < NR; ++q) acc[m][q][r] += pv[q] ? rb[(size_t)cc * plane + pix[q]] : 0.f;
+      }
+  }
+  float* yb = y + ((size_t)n * d.out_ctot + d.out_coff) * plane;
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (co >= d.Cout) continue;
+      const float bv = bias ? bias[co] : 0.f;
+#pragma unroll
+      for (int q = 0; q < NR; ++q)
+        if (pv[q]) yb[(size_t)co * plane + pix[q]] = acc[m][q][r] + bv;
+    }
+}
+
+template <int KH, int KW, int SH, int SW, int CK, int TWN, int MR>
 struct ConvCfg {
   static constexpr int TH = 4;                  // output rows per block (one per wave)
   static constexpr int TW = 32 * TWN;           // output cols per block
-  static constexpr int MR = 2;                  // 32-channel tiles per wave
   static constexpr int CO_T = 32 * MR;          // output channels per block
   static constexpr int NR = TWN;                // pixel tiles per wave
   static constexpr int PR = (TH - 1) * SH + KH; // patch rows
   static constexpr int PC = (TW - 1) * SW + KW; // patch cols
   static constexpr int PLANE = PR * PC;
   static constexpr int NPOS = (PLANE + 255) / 256;   // patch positions per thread
-  static constexpr int TAPS = KH * KW;
   static constexpr int XL = CK * PLANE;         // floats per LDS buffer
   static constexpr size_t LDS_BYTES = (size_t)2 * XL * 4;   // double buffered
 };
 
-// Pipeline per CK-channel chunk: the global loads of chunk i+1 (patch with halo, zero padding
-// and the optional fused producer BN-apply+ReLU) are issued into registers, the MFMAs of chunk
-// i run out of LDS buffer i&1 with the weight operand read straight from L1/L2 (all four waves
-// of a block read the same [k][co] rows), then the registers are written to buffer (i+1)&1 and
-// ONE barrier closes the iteration.  A thread owns the same NPOS patch positions for every
-// channel, so the per-element index arithmetic is done once per block.
-template <int KH, int KW, int SH, int SW, int CK, int TWN>
+// Pipeline per CK-channel chunk: the global loads of chunk i+1 are issued into registers, the
+// MFMAs of chunk i run out of LDS buffer i&1 with the weight operand read straight from L1/L2
+// (all four waves of a block read the same [k][co] rows), then the registers are written to
+// buffer (i+1)&1 and ONE barrier closes the iteration.  A thread owns the same NPOS patch
+// positions for every channel, so the per-element index arithmetic is done once per block.
+template <int KH, int KW, int SH, int SW, int CK, int TWN, int MR>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
     const float* __restrict__ in_mean, const float* __restrict__ in_scale,
     const float* __restrict__ in_shift, const float* residual, float* y, DlioConvDesc d,
     int tiles_w, int tiles_h, int co_tiles) {
-  using C = ConvCfg<KH, KW, SH, SW, CK, TWN>;
+  using C = ConvCfg<KH, KW, SH, SW, CK, TWN, MR>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x;
@@ -68,9 +103,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(
   const int Cin = d.Cin, Cout = d.Cout;
   const size_t HW = (size_t)d.H * d.W;
 
-  f32x16 acc[C::MR][C::NR];
+  f32x16 acc[MR][C::NR];
 #pragma unroll
-  for (int m = 0; m < C::MR; ++m)
+  for (int m = 0; m < MR; ++m)
 #pragma unroll
     for (int q = 0; q < C::NR; ++q)
 #pragma unroll
@@ -91,9 +126,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(
   const float* xn = x + ((size_t)n * d.in_ctot + d.in_coff) * HW;
   const bool has_aff = in_scale != nullptr;
   // clamped weight columns (rows >= Cout are dropped at the store)
-  int cc[C::MR];
+  int cc[MR];
 #pragma unroll
-  for (int m = 0; m < C::MR; ++m) cc[m] = min(co0 + m * 32 + l31, Cout - 1);
+  for (int m = 0; m < MR; ++m) cc[m] = min(co0 + m * 32 + l31, Cout - 1);
 
   float reg[CK][C::NPOS];
   auto load_chunk = [&](int c0) {
@@ -138,13 +173,13 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(
           // channels past Cin are zero in LDS, so a clamped (finite) weight is enough
           const int ci = min(c0 + c, Cin - 1);
           const float* wrow = wt + ((size_t)tap * Cin + ci) * Cout;
-          float a[C::MR], b[C::NR];
+          float a[MR], b[C::NR];
 #pragma unroll
-          for (int m = 0; m < C::MR; ++m) a[m] = wrow[cc[m]];
+          for (int m = 0; m < MR; ++m) a[m] = wrow[cc[m]];
 #pragma unroll
           for (int q = 0; q < C::NR; ++q) b[q] = xrow[c * C::PLANE + q * 32 * SW];
 #pragma unroll
-          for (int m = 0; m < C::MR; ++m)
+          for (int m = 0; m < MR; ++m)
 #pragma unroll
             for (int q = 0; q < C::NR; ++q)
               acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[q], acc[m][q], 0, 0, 0);
@@ -166,41 +201,28 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(
     __syncthreads();
   }
 
-  // ---- epilogue: bias + residual, NCHW store ------------------------------
   const int oh = oh0 + wave;
-  if (oh >= d.OH) return;
-  const size_t ohw = (size_t)d.OH * d.OW;
+  bool pv[C::NR];
+  size_t pix[C::NR];
 #pragma unroll
-  for (int m = 0; m < C::MR; ++m) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (co >= Cout) continue;
-      const float bv = bias ? bias[co] : 0.f;
-#pragma unroll
-      for (int q = 0; q < C::NR; ++q) {
-        const int ow = ow0 + q * 32 + l31;
-        if (ow >= d.OW) continue;
-        float v = acc[m][q][r] + bv;
-        const size_t pix = (size_t)oh * d.OW + ow;
-        if (residual)
-          v += residual[((size_t)n * d.res_ctot + d.res_coff + co) * ohw + pix];
-        y[((size_t)n * d.out_ctot + d.out_coff + co) * ohw + pix] = v;
-      }
-    }
+  for (int q = 0; q < C::NR; ++q) {
+    const int ow = ow0 + q * 32 + l31;
+    pv[q] = oh < d.OH && ow < d.OW;
+    pix[q] = pv[q] ? (size_t)oh * d.OW + ow : 0;
   }
+  store_tiles<MR, C::NR>(acc, bias, residual, y, d, n, co0, half, pv, pix, (size_t)d.OH * d.OW);
 }
 
-template <int KH, int KW, int SH, int SW, int CK, int TWN>
+template <int KH, int KW, int SH, int SW, int CK, int TWN, int MR>
 int launch(const float* x, const float* wt, const float* bias, const float* in_mean,
            const float* in_scale, const float* in_shift, const float* residual, float* y,
            const DlioConvDesc& d, hipStream_t s) {
-  using C = ConvCfg<KH, KW, SH, SW, CK, TWN>;
+  using C = ConvCfg<KH, KW, SH, SW, CK, TWN, MR>;
   const int tiles_w = cdiv(d.OW, C::TW), tiles_h = cdiv(d.OH, C::TH);
   const int co_tiles = cdiv(d.Cout, C::CO_T);
   const int64_t blocks = (int64_t)tiles_w * tiles_h * co_tiles * d.N;
   if (blocks <= 0 || blocks > 0x7fffffff) return DLIO_EINVAL;
-  auto kern = conv_fwd_kernel<KH, KW, SH, SW, CK, TWN>;
+  auto kern = conv_fwd_kernel<KH, KW, SH, SW, CK, TWN, MR>;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -212,13 +234,21 @@ int launch(const float* x, const float* wt, const float* bias, const float* in_m
   return dlio_check_launch();
 }
 
+// tile shape by problem size: 64-wide pixel tiles when the row is long enough, and 32-channel
+// (MR=1) tiles when 64-channel tiles would leave the 256 CUs with less than ~2 workgroups each
 template <int KH, int KW, int SH, int SW, int CK>
 int launch_tw(const float* x, const float* wt, const float* bias, const float* in_mean,
               const float* in_scale, const float* in_shift, const float* residual, float* y,
               const DlioConvDesc& d, hipStream_t s) {
-  if (d.OW > 32)
-    return launch<KH, KW, SH, SW, CK, 2>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
-  return launch<KH, KW, SH, SW, CK, 1>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
+  const int twn = d.OW > 32 ? 2 : 1;
+  const int64_t blocks2 = (int64_t)cdiv(d.OW, 32 * twn) * cdiv(d.OH, 4) * cdiv(d.Cout, 64) * d.N;
+  const bool small = blocks2 < 512 || d.Cout <= 32;
+  if (twn == 2) {
+    if (small) return launch<KH, KW, SH, SW, CK, 2, 1>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
+    return launch<KH, KW, SH, SW, CK, 2, 2>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
+  }
+  if (small) return launch<KH, KW, SH, SW, CK, 1, 1>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
+  return launch<KH, KW, SH, SW, CK, 1, 2>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -226,16 +256,15 @@ int launch_tw(const float* x, const float* wt, const float* bias, const float* i
 // input is used exactly once per output-channel tile, so staging it would only add a round
 // trip.  The MFMA B operand (2 channels x 32 consecutive pixels) is loaded straight from HBM
 // as two coalesced 128-B rows per wave instruction, the A operand (weights, [Cin][Cout]) from
-// L1/L2; the k loop is unrolled so >= 8 loads per lane are in flight.  Waves are independent,
-// so 4 blocks/CU hide the HBM latency.  Squeeze layers (Cout 16..80) are HBM-bound here,
-// expand1x1 / squeeze-dgrad (Cout 64..768) write-bound.
-template <int MR, bool AFF>
+// L1/L2.  Loads run one group of U k-steps ahead of the MFMAs in a second register set.
+// Squeeze layers (Cout 16..80) are HBM-bound here, expand1x1 / squeeze-dgrad write-bound.
+template <int MR, int NR, bool AFF>
 __global__ __launch_bounds__(256) void conv1x1_direct_kernel(
     const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
     const float* __restrict__ in_mean, const float* __restrict__ in_scale,
     const float* __restrict__ in_shift, const float* residual, float* y, DlioConvDesc d,
     int pix_blocks, int co_tiles) {
-  constexpr int NR = 2;
+  constexpr int U = 4;   // k-steps (= 8 channels) per pipeline group
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int l31 = lane & 31;
@@ -257,85 +286,91 @@ __global__ __launch_bounds__(256) void conv1x1_direct_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
 
-  // clamped addresses + masks instead of divergent guards
-  int pc[NR];
-  float pm[NR];
+  bool pv[NR];
+  size_t pix[NR];
+  const float* xq[NR];
+  const float* xn = x + ((size_t)n * d.in_ctot + d.in_coff) * (size_t)P;
 #pragma unroll
   for (int q = 0; q < NR; ++q) {
     const int p = p0 + q * 32 + l31;
-    pm[q] = p < P ? 1.f : 0.f;
-    pc[q] = p < P ? p : P - 1;
+    pv[q] = p < P;
+    pix[q] = pv[q] ? p : P - 1;       // clamped address; the column is dropped at the store
+    xq[q] = xn + pix[q];
   }
-  int cc[MR];
-  float cm[MR];
+  const float* wq[MR];
 #pragma unroll
-  for (int m = 0; m < MR; ++m) {
-    const int co = co0 + m * 32 + l31;
-    cm[m] = co < d.Cout ? 1.f : 0.f;
-    cc[m] = co < d.Cout ? co : d.Cout - 1;
-  }
-  const float* xn = x + ((size_t)n * d.in_ctot + d.in_coff) * (size_t)P;
-  const int Cin = d.Cin;
-#pragma unroll 8
-  for (int k = 0; k < Cin; k += 2) {
-    const int kk = k + half;
-    const bool kv = kk < Cin;
-    const int kc = kv ? kk : Cin - 1;
-    const float km = kv ? 1.f : 0.f;
-    float a[MR], b[NR];
-#pragma unroll
-    for (int m = 0; m < MR; ++m) a[m] = wt[(size_t)kc * d.Cout + cc[m]] * (cm[m] * km);
-#pragma unroll
-    for (int q = 0; q < NR; ++q) {
-      float v = xn[(size_t)kc * P + pc[q]];
-      if (AFF) {
-        v = (v - in_mean[kc]) * in_scale[kc] + in_shift[kc];
-        if (d.in_relu) v = fmaxf(v, 0.f);
-      }
-      b[q] = v * pm[q];
-    }
-#pragma unroll
-    for (int m = 0; m < MR; ++m)
-#pragma unroll
-      for (int q = 0; q < NR; ++q)
-        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[q], acc[m][q], 0, 0, 0);
-  }
+  for (int m = 0; m < MR; ++m) wq[m] = wt + min(co0 + m * 32 + l31, d.Cout - 1);
+  const int Cin = d.Cin, Cout = d.Cout;
 
+  float a[2][U][MR], b[2][U][NR];
+  auto load_group = [&](int k0, int s) {
 #pragma unroll
-  for (int m = 0; m < MR; ++m) {
+    for (int u = 0; u < U; ++u) {
+      const int kk = k0 + 2 * u + half;
+      const bool kv = kk < Cin;
+      const int kc = kv ? kk : Cin - 1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (co >= d.Cout) continue;
-      const float bv = bias ? bias[co] : 0.f;
+      for (int m = 0; m < MR; ++m) a[s][u][m] = wq[m][(size_t)kc * Cout];
 #pragma unroll
       for (int q = 0; q < NR; ++q) {
-        const int p = p0 + q * 32 + l31;
-        if (p >= P) continue;
-        float v = acc[m][q][r] + bv;
-        if (residual) v += residual[((size_t)n * d.res_ctot + d.res_coff + co) * P + p];
-        y[((size_t)n * d.out_ctot + d.out_coff + co) * P + p] = v;
+        float v = xq[q][(size_t)kc * P];
+        if (AFF) {
+          v = (v - in_mean[kc]) * in_scale[kc] + in_shift[kc];
+          if (d.in_relu) v = fmaxf(v, 0.f);
+        }
+        b[s][u][q] = kv ? v : 0.f;    // channel past Cin contributes nothing
       }
     }
+  };
+  auto mfma_group = [&](int s) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int q = 0; q < NR; ++q)
+          acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][u][m], b[s][u][q], acc[m][q], 0, 0, 0);
+  };
+
+  const int ngroups = (Cin + 2 * U - 1) / (2 * U);
+  load_group(0, 0);
+  for (int g = 0; g < ngroups; g += 2) {
+    if (g + 1 < ngroups) load_group((g + 1) * 2 * U, 1);
+    mfma_group(0);
+    if (g + 2 < ngroups) load_group((g + 2) * 2 * U, 0);
+    if (g + 1 < ngroups) mfma_group(1);
   }
+  store_tiles<MR, NR>(acc, bias, residual, y, d, n, co0, half, pv, pix, (size_t)P);
 }
 
-template <int MR>
+template <int MR, int NR>
 int launch_1x1(const float* x, const float* wt, const float* bias, const float* in_mean,
                const float* in_scale, const float* in_shift, const float* residual, float* y,
                const DlioConvDesc& d, hipStream_t s) {
   const int P = d.OH * d.OW;
-  const int pix_blocks = cdiv(P, 256);
+  const int pix_blocks = cdiv(P, 128 * NR);
   const int co_tiles = cdiv(d.Cout, 32 * MR);
   const int64_t blocks = (int64_t)pix_blocks * co_tiles * d.N;
   if (blocks <= 0 || blocks > 0x7fffffff) return DLIO_EINVAL;
   if (in_scale)
-    hipLaunchKernelGGL((conv1x1_direct_kernel<MR, true>), dim3((unsigned)blocks), dim3(256), 0, s, x,
-                       wt, bias, in_mean, in_scale, in_shift, residual, y, d, pix_blocks, co_tiles);
+    hipLaunchKernelGGL((conv1x1_direct_kernel<MR, NR, true>), dim3((unsigned)blocks), dim3(256), 0, s,
+                       x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, pix_blocks, co_tiles);
   else
-    hipLaunchKernelGGL((conv1x1_direct_kernel<MR, false>), dim3((unsigned)blocks), dim3(256), 0, s, x,
-                       wt, bias, in_mean, in_scale, in_shift, residual, y, d, pix_blocks, co_tiles);
+    hipLaunchKernelGGL((conv1x1_direct_kernel<MR, NR, false>), dim3((unsigned)blocks), dim3(256), 0, s,
+                       x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, pix_blocks, co_tiles);
   return dlio_check_launch();
+}
+
+template <int MR>
+int launch_1x1_nr(const float* x, const float* wt, const float* bias, const float* in_mean,
+                  const float* in_scale, const float* in_shift, const float* residual, float* y,
+                  const DlioConvDesc& d, hipStream_t s) {
+  // 64-pixel waves only when that still gives >= 4 waves per SIMD over the chip
+  const int64_t waves2 = (int64_t)cdiv(d.OH * d.OW, 64) * cdiv(d.Cout, 32 * MR) * d.N;
+  static const int force_nr = getenv("DLIO_1X1_NR") ? atoi(getenv("DLIO_1X1_NR")) : 0;   // tuning knob
+  if (MR < 3 && (force_nr == 2 || (force_nr == 0 && waves2 >= 4096)))
+    return launch_1x1<MR, 2>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
+  return launch_1x1<MR, 1>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
 }
 
 __global__ void prep_weight_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout,
@@ -391,10 +426,10 @@ extern "C" int dlio_conv2d_fwd(const float* x, const float* wt, const float* bia
   if (d.KH == kh && d.KW == kw && d.SH == sh && d.SW == sw)                                  \
     rc = launch_tw<kh, kw, sh, sw, ck>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
   if (d.KH == 1 && d.KW == 1 && d.SH == 1 && d.SW == 1 && d.PH == 0 && d.PW == 0) {
-    if (d.Cout <= 32) rc = launch_1x1<1>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
+    if (d.Cout <= 32) rc = launch_1x1_nr<1>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
     else if (d.Cout > 64 && d.Cout <= 96)
-      rc = launch_1x1<3>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
-    else rc = launch_1x1<2>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
+      rc = launch_1x1_nr<3>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
+    else rc = launch_1x1_nr<2>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
   }
   else CONV_CASE(1, 1, 1, 1, 16)
   else CONV_CASE(3, 3, 1, 1, 16)
