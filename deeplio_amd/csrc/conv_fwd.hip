@@ -160,30 +160,36 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(
         if (pos < C::PLANE) Xl[c * C::PLANE + pos] = reg[c][j];
       }
   };
+  // weight operands of one tap (CK/2 k-steps x MR tiles), fetched one tap ahead of their MFMAs
+  float aw[2][CK / 2][MR];
+  auto load_tap = [&](int tap, int c0, int s) {
+#pragma unroll
+    for (int c2 = 0; c2 < CK; c2 += 2) {
+      // channels past Cin are zero in LDS, so a clamped (finite) weight is enough
+      const int ci = min(c0 + c2 + half, Cin - 1);
+      const float* wrow = wt + ((size_t)tap * Cin + ci) * Cout;
+#pragma unroll
+      for (int m = 0; m < MR; ++m) aw[s][c2 / 2][m] = wrow[cc[m]];
+    }
+  };
   auto mfma_chunk = [&](const float* Xl, int c0) {
+    load_tap(0, c0, 0);
 #pragma unroll
-    for (int dy = 0; dy < KH; ++dy) {
+    for (int tap = 0; tap < KH * KW; ++tap) {
+      const int dy = tap / KW, dx = tap % KW;
+      if (tap + 1 < KH * KW) load_tap(tap + 1, c0, (tap + 1) & 1);
+      const float* xrow = Xl + (wave * SH + dy) * C::PC + dx + l31 * SW;
 #pragma unroll
-      for (int dx = 0; dx < KW; ++dx) {
-        const int tap = dy * KW + dx;
-        const float* xrow = Xl + (wave * SH + dy) * C::PC + dx + l31 * SW;
+      for (int c2 = 0; c2 < CK; c2 += 2) {
+        const int c = c2 + half;
+        float b[C::NR];
 #pragma unroll
-        for (int c2 = 0; c2 < CK; c2 += 2) {
-          const int c = c2 + half;
-          // channels past Cin are zero in LDS, so a clamped (finite) weight is enough
-          const int ci = min(c0 + c, Cin - 1);
-          const float* wrow = wt + ((size_t)tap * Cin + ci) * Cout;
-          float a[MR], b[C::NR];
+        for (int q = 0; q < C::NR; ++q) b[q] = xrow[c * C::PLANE + q * 32 * SW];
 #pragma unroll
-          for (int m = 0; m < MR; ++m) a[m] = wrow[cc[m]];
+        for (int m = 0; m < MR; ++m)
 #pragma unroll
-          for (int q = 0; q < C::NR; ++q) b[q] = xrow[c * C::PLANE + q * 32 * SW];
-#pragma unroll
-          for (int m = 0; m < MR; ++m)
-#pragma unroll
-            for (int q = 0; q < C::NR; ++q)
-              acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[q], acc[m][q], 0, 0, 0);
-        }
+          for (int q = 0; q < C::NR; ++q)
+            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[tap & 1][c2 / 2][m], b[q], acc[m][q], 0, 0, 0);
       }
     }
   };
@@ -242,7 +248,7 @@ int launch_tw(const float* x, const float* wt, const float* bias, const float* i
               const DlioConvDesc& d, hipStream_t s) {
   const int twn = d.OW > 32 ? 2 : 1;
   const int64_t blocks2 = (int64_t)cdiv(d.OW, 32 * twn) * cdiv(d.OH, 4) * cdiv(d.Cout, 64) * d.N;
-  const bool small = blocks2 < 512 || d.Cout <= 32;
+  const bool small = blocks2 < 512;   // (Cout <= 32 measured faster with MR=2 despite the idle tile)
   if (twn == 2) {
     if (small) return launch<KH, KW, SH, SW, CK, 2, 1>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
     return launch<KH, KW, SH, SW, CK, 2, 2>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
@@ -343,6 +349,132 @@ __global__ __launch_bounds__(256) void conv1x1_direct_kernel(
   store_tiles<MR, NR>(acc, bias, residual, y, d, n, co0, half, pv, pix, (size_t)P);
 }
 
+// float4 variant for P % 4 == 0: a wave owns 128 consecutive pixels and lane l loads/stores the
+// four pixels 4l..4l+3 as one 16-byte access.  Component e of the float4 is the B operand of
+// MFMA e, i.e. output tile e holds pixels {4j+e}; at the store the four tiles of a lane are
+// again one float4 -> 512 contiguous bytes per half-wave, a quarter of the load/store
+// instructions of the dword kernel.
+template <int MR, bool AFF>
+__global__ __launch_bounds__(256) void conv1x1_v4_kernel(
+    const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
+    const float* __restrict__ in_mean, const float* __restrict__ in_scale,
+    const float* __restrict__ in_shift, const float* residual, float* y, DlioConvDesc d,
+    int pix_blocks, int co_tiles) {
+  constexpr int U = MR == 3 ? 2 : 4;   // k-steps per pipeline group
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int l31 = lane & 31;
+  const int half = lane >> 5;
+  int bid = blockIdx.x;
+  const int cot = bid % co_tiles; bid /= co_tiles;
+  const int pb = bid % pix_blocks; bid /= pix_blocks;
+  const int n = bid;
+  const int P = d.OH * d.OW;
+  const int co0 = cot * 32 * MR;
+  const int p = (pb * 4 + wave) * 128 + 4 * l31;
+  if ((pb * 4 + wave) * 128 >= P) return;
+  const bool pvalid = p < P;            // P % 4 == 0: a lane's four pixels are all in or all out
+  const size_t pc = pvalid ? p : 0;
+
+  f32x16 acc[MR][4];
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][e][r] = 0.f;
+
+  const float* xq = x + ((size_t)n * d.in_ctot + d.in_coff) * (size_t)P + pc;
+  const float* wq[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) wq[m] = wt + min(co0 + m * 32 + l31, d.Cout - 1);
+  const int Cin = d.Cin, Cout = d.Cout;
+
+  float a[2][U][MR];
+  float4 b[2][U];
+  auto load_group = [&](int k0, int s) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int kk = k0 + 2 * u + half;
+      const bool kv = kk < Cin;
+      const int kc = kv ? kk : Cin - 1;
+#pragma unroll
+      for (int m = 0; m < MR; ++m) a[s][u][m] = wq[m][(size_t)kc * Cout];
+      float4 v = *reinterpret_cast<const float4*>(xq + (size_t)kc * P);
+      if (AFF) {
+        const float mu = in_mean[kc], sc = in_scale[kc], sh = in_shift[kc];
+        v.x = (v.x - mu) * sc + sh; v.y = (v.y - mu) * sc + sh;
+        v.z = (v.z - mu) * sc + sh; v.w = (v.w - mu) * sc + sh;
+        if (d.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      }
+      if (!kv) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      b[s][u] = v;
+    }
+  };
+  auto mfma_group = [&](int s) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int m = 0; m < MR; ++m) {
+        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][u][m], b[s][u].x, acc[m][0], 0, 0, 0);
+        acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][u][m], b[s][u].y, acc[m][1], 0, 0, 0);
+        acc[m][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][u][m], b[s][u].z, acc[m][2], 0, 0, 0);
+        acc[m][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][u][m], b[s][u].w, acc[m][3], 0, 0, 0);
+      }
+  };
+  const int ngroups = (Cin + 2 * U - 1) / (2 * U);
+  load_group(0, 0);
+  for (int g = 0; g < ngroups; g += 2) {
+    if (g + 1 < ngroups) load_group((g + 1) * 2 * U, 1);
+    mfma_group(0);
+    if (g + 2 < ngroups) load_group((g + 2) * 2 * U, 0);
+    if (g + 1 < ngroups) mfma_group(1);
+  }
+
+  if (!pvalid) return;
+  const size_t plane = (size_t)P;
+  float* yb = y + ((size_t)n * d.out_ctot + d.out_coff) * plane + pc;
+  const float* rb = residual ? residual + ((size_t)n * d.res_ctot + d.res_coff) * plane + pc : nullptr;
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    float4 rv[16];
+    if (rb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = min(co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, Cout - 1);
+        rv[r] = *reinterpret_cast<const float4*>(rb + (size_t)co * plane);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (co >= Cout) continue;
+      const float bv = bias ? bias[co] : 0.f;
+      float4 o = make_float4(acc[m][0][r] + bv, acc[m][1][r] + bv, acc[m][2][r] + bv, acc[m][3][r] + bv);
+      if (rb) { o.x += rv[r].x; o.y += rv[r].y; o.z += rv[r].z; o.w += rv[r].w; }
+      *reinterpret_cast<float4*>(yb + (size_t)co * plane) = o;
+    }
+  }
+}
+
+template <int MR>
+int launch_1x1_v4(const float* x, const float* wt, const float* bias, const float* in_mean,
+                  const float* in_scale, const float* in_shift, const float* residual, float* y,
+                  const DlioConvDesc& d, hipStream_t s) {
+  const int P = d.OH * d.OW;
+  const int pix_blocks = cdiv(P, 512);
+  const int co_tiles = cdiv(d.Cout, 32 * MR);
+  const int64_t blocks = (int64_t)pix_blocks * co_tiles * d.N;
+  if (blocks <= 0 || blocks > 0x7fffffff) return DLIO_EINVAL;
+  if (in_scale)
+    hipLaunchKernelGGL((conv1x1_v4_kernel<MR, true>), dim3((unsigned)blocks), dim3(256), 0, s, x, wt,
+                       bias, in_mean, in_scale, in_shift, residual, y, d, pix_blocks, co_tiles);
+  else
+    hipLaunchKernelGGL((conv1x1_v4_kernel<MR, false>), dim3((unsigned)blocks), dim3(256), 0, s, x, wt,
+                       bias, in_mean, in_scale, in_shift, residual, y, d, pix_blocks, co_tiles);
+  return dlio_check_launch();
+}
+
 template <int MR, int NR>
 int launch_1x1(const float* x, const float* wt, const float* bias, const float* in_mean,
                const float* in_scale, const float* in_shift, const float* residual, float* y,
@@ -366,6 +498,13 @@ int launch_1x1_nr(const float* x, const float* wt, const float* bias, const floa
                   const float* in_scale, const float* in_shift, const float* residual, float* y,
                   const DlioConvDesc& d, hipStream_t s) {
   // 64-pixel waves only when that still gives >= 4 waves per SIMD over the chip
+  const int P = d.OH * d.OW;
+  static const int use_v4 = getenv("DLIO_1X1_V4") ? atoi(getenv("DLIO_1X1_V4")) : 1;    // tuning knob
+  const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
+                       reinterpret_cast<uintptr_t>(residual);
+  const int64_t waves4 = (int64_t)cdiv(P, 128) * cdiv(d.Cout, 32 * MR) * d.N;
+  if (use_v4 && (P & 3) == 0 && (al & 15) == 0 && waves4 >= 2048)
+    return launch_1x1_v4<MR>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
   const int64_t waves2 = (int64_t)cdiv(d.OH * d.OW, 64) * cdiv(d.Cout, 32 * MR) * d.N;
   static const int force_nr = getenv("DLIO_1X1_NR") ? atoi(getenv("DLIO_1X1_NR")) : 0;   // tuning knob
   if (MR < 3 && (force_nr == 2 || (force_nr == 0 && waves2 >= 4096)))

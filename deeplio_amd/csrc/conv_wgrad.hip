@@ -45,7 +45,7 @@ struct WgCfg {
 // patch) are issued into registers, the MFMAs of tile t run out of LDS stage t&1, the registers
 // are written to stage (t+1)&1, one barrier per tile.  The kernel runs one workgroup per CU
 // (160 accumulator registers), so this in-block overlap is what hides the HBM latency.
-template <int KH, int KW, int SH, int SW, int NT>
+template <int KH, int KW, int SH, int SW, int NT, bool VEC>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ wsp,
     const float* __restrict__ in_mean, const float* __restrict__ in_scale,
@@ -98,6 +98,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   const size_t HW = (size_t)d.H * d.W;
 
   // thread-constant staging coordinates
+  // VEC (OW % 4 == 0): float4 loads, element f = tid + 256*i -> col4 = f&7, row = (f>>3)&3, ch = f>>5
+  constexpr bool XVEC = VEC && KH == 1 && KW == 1 && SH == 1 && SW == 1;
+  const int v_c4 = tid & 7, v_r = (tid >> 3) & 3, v_ch = tid >> 5;        // ch = v_ch + 8*i
   const int dy_r = (tid >> 5) & 3, dy_col = tid & 31, dy_co = tid >> 7;   // co = dy_co + 2*i
   const int xp = tid % C::LPP, xcph = tid / C::LPP;                      // c = xcph + CPAR*i
   int xr[C::NPOSX], xc[C::NPOSX];
@@ -117,7 +120,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     const int n = tt;
     const int oh0 = th * C::TH, ow0 = tw * C::TW;
     const int ih0 = oh0 * SH - d.PH, iw0 = ow0 * SW - d.PW;
-    {
+    if constexpr (VEC) {
+      const int oh = oh0 + v_r, ow = ow0 + 4 * v_c4;
+      const bool pv = oh < d.OH && ow < d.OW;
+      const float* p = dy + ((size_t)n * d.out_ctot + d.out_coff + co0) * ohw +
+                       (pv ? (size_t)oh * d.OW + ow : 0);
+#pragma unroll
+      for (int i = 0; i < C::NDY / 4; ++i) {
+        const int co = v_ch + 8 * i;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pv && co0 + co < d.Cout) t = *reinterpret_cast<const float4*>(p + (size_t)co * ohw);
+        rdy[4 * i] = t.x; rdy[4 * i + 1] = t.y; rdy[4 * i + 2] = t.z; rdy[4 * i + 3] = t.w;
+      }
+    } else {
       const int oh = oh0 + dy_r, ow = ow0 + dy_col;
       const bool pv = oh < d.OH && ow < d.OW;
       const float* p = dy + ((size_t)n * d.out_ctot + d.out_coff + co0) * ohw +
@@ -129,6 +144,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
       }
     }
     const float* xn = x + ((size_t)n * d.in_ctot + d.in_coff + c0) * HW;
+    if constexpr (XVEC) {
+      const int ih = ih0 + v_r, iw = iw0 + 4 * v_c4;
+      const bool pvx = ih < d.H && iw < d.W;
+      const float* p = xn + (pvx ? (size_t)ih * d.W + iw : 0);
+#pragma unroll
+      for (int i = 0; i < C::CKMAX / 8; ++i) {
+        const int c = v_ch + 8 * i;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pvx && c < ck) {
+          t = *reinterpret_cast<const float4*>(p + (size_t)c * HW);
+          if (has_aff) {
+            const float mu = in_mean[c0 + c], sc = in_scale[c0 + c], sh = in_shift[c0 + c];
+            t.x = (t.x - mu) * sc + sh; t.y = (t.y - mu) * sc + sh;
+            t.z = (t.z - mu) * sc + sh; t.w = (t.w - mu) * sc + sh;
+            if (d.in_relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+          }
+        }
+        rx[4 * i][0] = t.x; rx[4 * i + 1][0] = t.y; rx[4 * i + 2][0] = t.z; rx[4 * i + 3][0] = t.w;
+      }
+      return;
+    }
     int po[C::NPOSX];
     bool pv[C::NPOSX];
 #pragma unroll
@@ -158,8 +194,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   auto store_tile = [&](float* buf) {
     float* Xl = buf;
     float* Dl = buf + C::XL;
+    if constexpr (VEC) {
 #pragma unroll
-    for (int i = 0; i < C::NDY; ++i) Dl[(dy_co + 2 * i) * C::DYS + dy_r * 32 + dy_col] = rdy[i];
+      for (int i = 0; i < C::NDY / 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          Dl[(v_ch + 8 * i) * C::DYS + v_r * 32 + v_c4 * 4 + e] = rdy[4 * i + e];
+    } else {
+#pragma unroll
+      for (int i = 0; i < C::NDY; ++i) Dl[(dy_co + 2 * i) * C::DYS + dy_r * 32 + dy_col] = rdy[i];
+    }
+    if constexpr (XVEC) {
+#pragma unroll
+      for (int i = 0; i < C::CKMAX / 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          Xl[(v_ch + 8 * i) * C::PLANE + v_r * 32 + v_c4 * 4 + e] = rx[4 * i + e][0];
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < C::NCX; ++i) {
       const int c = xcph + C::CPAR * i;
@@ -288,13 +340,14 @@ int launch(const float* x, const float* dy, float* dw, const float* in_mean,
            const float* in_scale, const float* in_shift, float* wsp, const DlioConvDesc& d,
            const WgPlan& p, hipStream_t s) {
   using C = WgCfg<KH, KW, SH, SW, NT>;
-  auto kern = conv_wgrad_kernel<KH, KW, SH, SW, NT>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
-    attr_set = true;
-  }
+  // float4 staging when rows are 16-B aligned (only instantiated for the stride-1 3x3 / 1x1 taps)
+  constexpr bool CAN_VEC = SH == 1 && SW == 1 && ((KH == 1 && KW == 1) || (KH == 3 && KW == 3));
+  const bool vec = CAN_VEC && (d.OW & 3) == 0 && (d.W & 3) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
+  auto kern = (CAN_VEC && vec) ? conv_wgrad_kernel<KH, KW, SH, SW, NT, CAN_VEC>
+                               : conv_wgrad_kernel<KH, KW, SH, SW, NT, false>;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
   const int blocks = p.co_tiles * p.ci_chunks * p.splits;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), C::LDS_BYTES, s, x, dy, wsp, in_mean,
                      in_scale, in_shift, d, p.co_tiles, p.ci_chunks, p.splits, p.tiles_w,
