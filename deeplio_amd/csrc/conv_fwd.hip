@@ -248,7 +248,10 @@ int launch_tw(const float* x, const float* wt, const float* bias, const float* i
               const DlioConvDesc& d, hipStream_t s) {
   const int twn = d.OW > 32 ? 2 : 1;
   const int64_t blocks2 = (int64_t)cdiv(d.OW, 32 * twn) * cdiv(d.OH, 4) * cdiv(d.Cout, 64) * d.N;
-  const bool small = blocks2 < 512;   // (Cout <= 32 measured faster with MR=2 despite the idle tile)
+  static const int force_mr = getenv("DLIO_CONV_MR") ? atoi(getenv("DLIO_CONV_MR")) : 0;   // tuning knob
+  // micro-bench (tools/bench_conv.py): 32-channel tiles win for Cout <= 32 (234 vs 414 us on the
+  // blk1 expand3x3 data gradient) and whenever 64-channel tiles give < 2 workgroups per CU
+  const bool small = force_mr ? force_mr == 1 : (blocks2 < 512 || d.Cout <= 32);
   if (twn == 2) {
     if (small) return launch<KH, KW, SH, SW, CK, 2, 1>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
     return launch<KH, KW, SH, SW, CK, 2, 2>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
