@@ -12,13 +12,14 @@
 // Replaces the weight-gradient half of nn.Conv2d backward for every conv on the path
 // (same reference sites as conv_fwd.hip).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
-template <int KH, int KW, int SH, int SW, int NT>
+template <int KH, int KW, int SH, int SW, int NT, int MRW>
 struct WgCfg {
   static constexpr int TH = 4, TW = 32;
-  static constexpr int MR = 2, CO_T = 64;
+  static constexpr int MR = MRW, CO_T = 32 * MRW;
   static constexpr int TAPS = KH * KW;
   // channels per chunk; halved for the 1x1 stride-(2,2) patch so two pipeline stages fit in LDS
   static constexpr int CKMAX = ((NT * 32) / TAPS) / ((TAPS == 1 && SH * SW == 4) ? 2 : 1);
@@ -45,13 +46,13 @@ struct WgCfg {
 // patch) are issued into registers, the MFMAs of tile t run out of LDS stage t&1, the registers
 // are written to stage (t+1)&1, one barrier per tile.  The kernel runs one workgroup per CU
 // (160 accumulator registers), so this in-block overlap is what hides the HBM latency.
-template <int KH, int KW, int SH, int SW, int NT, bool VEC>
+template <int KH, int KW, int SH, int SW, int NT, int MRW, bool VEC>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ wsp,
     const float* __restrict__ in_mean, const float* __restrict__ in_scale,
     const float* __restrict__ in_shift, DlioConvDesc d, int co_tiles, int ci_chunks, int splits,
     int tiles_w, int tiles_h) {
-  using C = WgCfg<KH, KW, SH, SW, NT>;
+  using C = WgCfg<KH, KW, SH, SW, NT, MRW>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x;
@@ -292,18 +293,33 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ wsp, float* __restrict__ dw,
-                                    int64_t n, int splits) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += wsp[(size_t)k * n + i];
-    dw[i] = s;
+// dw[i] = sum over split slabs, in a fixed order: 4 waves each own every 4th slab of 64
+// consecutive elements (8 independent loads in flight), partials combined through LDS.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ wsp,
+                                                           float* __restrict__ dw, int64_t n,
+                                                           int splits) {
+  __shared__ float red[4][64];
+  const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + e;
+  float s = 0.f;
+  if (i < n) {
+    int k = g;
+    for (; k + 28 < splits; k += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = wsp[(size_t)(k + 4 * u) * n + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < splits; k += 4) s += wsp[(size_t)k * n + i];
   }
+  red[g][e] = s;
+  __syncthreads();
+  if (g == 0 && i < n) dw[i] = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
 }
 
 struct WgPlan {
-  int nt, ckmax, co_tiles, ci_chunks, tiles_w, tiles_h, splits;
+  int nt, mr, ckmax, co_tiles, ci_chunks, tiles_w, tiles_h, splits;
   size_t ws_bytes;
 };
 
@@ -312,13 +328,27 @@ int nt_for(const DlioConvDesc& d) {
   return 5;
 }
 
+// 32-channel tiles (80 accumulator registers -> two workgroups per CU) for the multi-tap kernels;
+// 64-channel tiles for 1x1 where the dY tile is the re-read operand.  DLIO_WGRAD_MR overrides.
+int mr_for(const DlioConvDesc& d) {
+  static const int force = getenv("DLIO_WGRAD_MR") ? atoi(getenv("DLIO_WGRAD_MR")) : 0;
+  const bool has_mr1 = d.SH == 1 && d.SW == 1 && ((d.KH == 1 && d.KW == 1) || (d.KH == 3 && d.KW == 3));
+  if (!has_mr1) return 2;
+  if (force == 1 || force == 2) return force;
+  // micro-bench (tools/bench_conv.py wgrad): 3x3 always faster with 32-channel tiles (2 workgroups
+  // per CU); 1x1 only when Cout <= 32 (otherwise the extra dY re-reads cost more)
+  if (d.KH == 3) return 1;
+  return d.Cout <= 32 ? 1 : 2;
+}
+
 bool make_plan(const DlioConvDesc& d, WgPlan& p) {
   p.nt = nt_for(d);
   const int taps = d.KH * d.KW;
   p.ckmax = (p.nt * 32) / taps;
   if (taps == 1 && d.SH * d.SW == 4) p.ckmax /= 2;
   if (p.ckmax < 1) return false;
-  p.co_tiles = cdiv(d.Cout, 64);
+  p.mr = mr_for(d);
+  p.co_tiles = cdiv(d.Cout, 32 * p.mr);
   p.ci_chunks = cdiv(d.Cin, p.ckmax);
   p.tiles_w = cdiv(d.OW, 32);
   p.tiles_h = cdiv(d.OH, 4);
@@ -335,17 +365,17 @@ bool make_plan(const DlioConvDesc& d, WgPlan& p) {
   return true;
 }
 
-template <int KH, int KW, int SH, int SW, int NT>
-int launch(const float* x, const float* dy, float* dw, const float* in_mean,
-           const float* in_scale, const float* in_shift, float* wsp, const DlioConvDesc& d,
-           const WgPlan& p, hipStream_t s) {
-  using C = WgCfg<KH, KW, SH, SW, NT>;
+template <int KH, int KW, int SH, int SW, int NT, int MRW>
+int launch_mr(const float* x, const float* dy, float* dw, const float* in_mean,
+              const float* in_scale, const float* in_shift, float* wsp, const DlioConvDesc& d,
+              const WgPlan& p, hipStream_t s) {
+  using C = WgCfg<KH, KW, SH, SW, NT, MRW>;
   // float4 staging when rows are 16-B aligned (only instantiated for the stride-1 3x3 / 1x1 taps)
   constexpr bool CAN_VEC = SH == 1 && SW == 1 && ((KH == 1 && KW == 1) || (KH == 3 && KW == 3));
   const bool vec = CAN_VEC && (d.OW & 3) == 0 && (d.W & 3) == 0 &&
                    ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
-  auto kern = (CAN_VEC && vec) ? conv_wgrad_kernel<KH, KW, SH, SW, NT, CAN_VEC>
-                               : conv_wgrad_kernel<KH, KW, SH, SW, NT, false>;
+  auto kern = (CAN_VEC && vec) ? conv_wgrad_kernel<KH, KW, SH, SW, NT, MRW, CAN_VEC>
+                               : conv_wgrad_kernel<KH, KW, SH, SW, NT, MRW, false>;
   hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
   const int blocks = p.co_tiles * p.ci_chunks * p.splits;
@@ -355,9 +385,22 @@ int launch(const float* x, const float* dy, float* dw, const float* in_mean,
   int rc = dlio_check_launch();
   if (rc) return rc;
   const int64_t n = (int64_t)d.Cout * d.Cin * KH * KW;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, s, wsp, dw, n,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(n, 64)), dim3(256), 0, s, wsp, dw, n,
                      p.splits);
   return dlio_check_launch();
+}
+
+template <int KH, int KW, int SH, int SW, int NT>
+int launch(const float* x, const float* dy, float* dw, const float* in_mean,
+           const float* in_scale, const float* in_shift, float* wsp, const DlioConvDesc& d,
+           const WgPlan& p, hipStream_t s) {
+  // the 32-channel variant is only built for the stride-1 3x3 / 1x1 taps (the headline path)
+  constexpr bool HAS_MR1 = SH == 1 && SW == 1 && ((KH == 1 && KW == 1) || (KH == 3 && KW == 3));
+  if constexpr (HAS_MR1) {
+    if (p.mr == 1)
+      return launch_mr<KH, KW, SH, SW, NT, 1>(x, dy, dw, in_mean, in_scale, in_shift, wsp, d, p, s);
+  }
+  return launch_mr<KH, KW, SH, SW, NT, 2>(x, dy, dw, in_mean, in_scale, in_shift, wsp, d, p, s);
 }
 
 }  // namespace
