@@ -86,6 +86,8 @@ SIGNATURES = {
                                _p, _p]),
     "dlio_pose_loss_bwd": (_i, [C.POINTER(_p), C.POINTER(_p), C.POINTER(C.c_int32), _p, _p, _f, _i,
                                _p, _p, C.POINTER(_p), _p, _p, _p]),
+    "dlio_pair_stack": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "dlio_gt_relative": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "dlio_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i, _f, _p]),
     "dlio_sgd_step": (_i, [_p, _p, _p, _i64, _f, _f, _f, _i, _f, _p]),
     "dlio_sumsq": (_i, [_p, _i64, _p, _p]),

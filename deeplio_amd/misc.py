@@ -63,3 +63,58 @@ class PolynomialLRDecay:
 
     def load_state_dict(self, sd):
         self.last_epoch, self.base_lrs = sd['last_epoch'], sd['base_lrs']
+
+
+class DataCombiCreater(object):
+    """Mirror of DataCombiCreater (models/misc.py:9-128): turns a collated batch
+    {'images' [B,S+1,C*,H,W], 'untrans-images', 'imus' [B,S,T,6], 'gts' [B,S+1,15]} into the
+    model inputs and targets (res_imgs / res_normals [B,S,2,3,H,W], res_imu, res_gt_f2f [B,S,6],
+    res_gt_f2g [B,S,7], res_gt_global).  The pair gather + channel split is one streaming HIP
+    kernel per image tensor and the per-sample ground-truth Python loop one launch
+    (deeplio_amd/csrc/batchprep.hip); `untrans-images` is only processed on request
+    (`with_untransformed=True`), the hot loop never reads it."""
+
+    def __init__(self, combinations, device='cpu', with_untransformed=False):
+        import torch
+        self.combinations = combinations
+        self.device = torch.device(device)
+        self.seq_size = get_config_container().seq_size
+        self.with_untransformed = with_untransformed
+        self._comb = torch.as_tensor(np.asarray(combinations), dtype=torch.int32).contiguous().to(self.device)
+        self.flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.res_imgs = self.res_img_org = self.res_normals = self.res_normals_org = None
+        self.res_imu = self.res_gt_f2f = self.res_gt_f2g = self.res_gt_global = None
+
+    def process(self, data):
+        from . import ops
+        imgs = normals = imgs_org = normals_org = []
+        if 'images' in data:
+            imgs, normals = self.process_images(data['images'].to(self.device, non_blocking=True))
+            if self.with_untransformed and 'untrans-images' in data:
+                imgs_org, normals_org = self.process_images(data['untrans-images'].to(self.device, non_blocking=True))
+        imus = data['imus'].to(self.device, non_blocking=True) if 'imus' in data else []
+        gt_global = data['gts'].to(self.device, non_blocking=True).float().contiguous()
+        gt_f2f, gt_f2g = ops.gt_relative(gt_global, self._comb, self.flag)
+        self.res_imgs, self.res_normals = imgs, normals
+        self.res_img_org, self.res_normals_org = imgs_org, normals_org
+        self.res_imu = imus
+        self.res_gt_f2f, self.res_gt_f2g, self.res_gt_global = gt_f2f, gt_f2g, gt_global
+
+    def process_images(self, imgs):
+        from . import ops
+        return ops.pair_stack(imgs.float().contiguous(), self._comb, 3)      # misc.py:66-68: 0:3 | 3:
+
+    def process_ground_turth(self, gts):
+        """single-sample form of the reference API: gts [S+1, 15] -> (f2f [S,6], f2g [S,7])"""
+        from . import ops
+        f2f, f2g = ops.gt_relative(gts.to(self.device).float().contiguous()[None], self._comb, self.flag)
+        return f2f[0], f2g[0]
+
+    def check(self):
+        """raise like misc.py:106-107 if a non-finite f2f target was produced since the last check"""
+        if int(self.flag.item()):
+            self.flag.zero_()
+            raise ValueError("gt-f2f: non-finite relative pose")
+
+    def __call__(self, args):
+        return self.process(args)

@@ -421,6 +421,31 @@ def pose_loss_bwd(preds, gts, sx, sq, beta, mode, out, gscale):
     return dpreds, dsx, dsq
 
 
+# ----------------------------------------------------------------------------- batch prep
+def pair_stack(images, comb, c_split):
+    """images [B,F,Ctot,H,W], comb int32 [S,2] (device) -> xyz [B,S,2,c_split,H,W], normals [...]"""
+    _chk(images)
+    B, F_, Ctot, H, W = images.shape
+    S = comb.shape[0]
+    xyz = torch.empty(B, S, 2, c_split, H, W, dtype=torch.float32, device=images.device)
+    nrm = torch.empty(B, S, 2, Ctot - c_split, H, W, dtype=torch.float32, device=images.device)
+    check(lib.dlio_pair_stack(_ptr(images), _ptr(comb), _ptr(xyz), _ptr(nrm), B, F_, Ctot, c_split, H, W,
+                              S, _stream()), "pair_stack")
+    return xyz, nrm
+
+
+def gt_relative(gts, comb, flag=None):
+    """gts [B,F,15], comb int32 [S,2] -> f2f [B,S,6], f2g [B,S,7]"""
+    _chk(gts)
+    B, F_, _ = gts.shape
+    S = comb.shape[0]
+    f2f = torch.empty(B, S, 6, dtype=torch.float32, device=gts.device)
+    f2g = torch.empty(B, S, 7, dtype=torch.float32, device=gts.device)
+    check(lib.dlio_gt_relative(_ptr(gts), _ptr(comb), _ptr(f2f), _ptr(f2g), _ptr(flag), B, F_, S,
+                               _stream()), "gt_relative")
+    return f2f, f2g
+
+
 # ----------------------------------------------------------------------------- optimizer
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
     check(lib.dlio_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(beta1),

@@ -271,6 +271,19 @@ int dlio_pose_loss_bwd(const float* const* pred, const float* const* gt, const i
                        const float* out, const float* gscale, float* const* dpred,
                        float* dsx, float* dsq, dlio_stream_t stream);
 
+/* ---- batch preparation ----------------------------------------------------
+ * DataCombiCreater.process (models/misc.py:24-125) on the device.
+ * pair_stack: images [B][F][Ctot][H][W], combinations [S][2] (int32, device) ->
+ *   xyz [B][S][2][c_split][H][W] and normals [B][S][2][Ctot-c_split][H][W]
+ *   (misc.py:65-69: imgs[:, combinations] then channel split 0:3 | 3:).  H*W % 4 == 0.
+ * gt_relative: gts [B][F][15] rows [x(3), R(9), v(3)] -> f2f [B][S][6] = [dx, log(R)] of
+ *   T_i^-1 T_{i+1} and f2g [B][S][7] = [p, quat wxyz] of T_0^-1 T_{i+1} (misc.py:83-125);
+ *   flag[0] |= 1 on a non-finite f2f entry (the reference raises ValueError). */
+int dlio_pair_stack(const float* images, const int32_t* combinations, float* xyz, float* normals,
+                    int B, int F, int Ctot, int c_split, int H, int W, int S, dlio_stream_t stream);
+int dlio_gt_relative(const float* gts, const int32_t* combinations, float* f2f, float* f2g,
+                     int32_t* flag, int B, int F, int S, dlio_stream_t stream);
+
 /* ---- optimizer ----------------------------------------------------------
  * torch.optim.Adam / SGD(momentum) as built by create_optimizer
  * (optimizer.py:4-16) over ONE flat parameter buffer: weight decay is L2 added
