@@ -86,7 +86,7 @@ __global__ __launch_bounds__(RB) void chan_reduce_kernel(
 
 __global__ void chan_reduce_final(const double* __restrict__ part, int C, int splits,
                                   double* __restrict__ o0, double* __restrict__ o1,
-                                  float* __restrict__ f0) {
+                                  float* __restrict__ f0, float* __restrict__ f1) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double a = 0.0, b = 0.0;
@@ -97,6 +97,34 @@ __global__ void chan_reduce_final(const double* __restrict__ part, int C, int sp
   if (o0) o0[c] = a;
   if (o1) o1[c] = b;
   if (f0) f0[c] = (float)a;
+  if (f1) f1[c] = (float)b;
+}
+
+// statistics epilogue of a train-mode BatchNorm: sums the split partials of one channel and
+// finalises mean / invstd / scale and the running statistics in the same launch
+__global__ void chan_stats_finalize_kernel(const double* __restrict__ part, int C, int splits,
+                                           double count, const float* __restrict__ gamma, float eps,
+                                           float momentum, float* running_mean, float* running_var,
+                                           float* mean, float* invstd, float* scale) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int s = 0; s < splits; ++s) {
+    a += part[((size_t)c * splits + s) * 2 + 0];
+    b += part[((size_t)c * splits + s) * 2 + 1];
+  }
+  const double m = a / count;
+  double var = b / count - m * m;
+  if (var < 0.0) var = 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  mean[c] = (float)m;
+  invstd[c] = is;
+  scale[c] = (gamma ? gamma[c] : 1.f) * is;
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+  if (running_var) {
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+  }
 }
 
 int pick_splits(int N, int C, int HW) {
@@ -254,7 +282,7 @@ extern "C" size_t dlio_chan_stats_ws_bytes(int N, int C, int HW) {
 static int chan_reduce(int mode, const float* a, int a_ctot, int a_coff, const float* x, int x_ctot,
                        int x_coff, const float* mean, const float* invstd, const float* scale,
                        const float* beta, int N, int C, int HW, int pre_relu, int post_relu,
-                       double* o0, double* o1, float* f0, void* ws, size_t ws_bytes,
+                       double* o0, double* o1, float* f0, float* f1, void* ws, size_t ws_bytes,
                        hipStream_t s) {
   if (!a || N <= 0 || C <= 0 || HW <= 0 || !ws) return DLIO_EINVAL;
   const int splits = pick_splits(N, C, HW);
@@ -273,7 +301,7 @@ static int chan_reduce(int mode, const float* a, int a_ctot, int a_coff, const f
   int rc = dlio_check_launch();
   if (rc) return rc;
   hipLaunchKernelGGL(chan_reduce_final, dim3(cdiv(C, 128)), dim3(128), 0, s, part, C, splits, o0,
-                     o1, f0);
+                     o1, f0, f1);
   return dlio_check_launch();
 }
 
@@ -282,24 +310,46 @@ extern "C" int dlio_chan_stats(const float* x, int N, int ctot, int coff, int C,
                                size_t ws_bytes, dlio_stream_t stream) {
   if (!sum || !sumsq) return DLIO_EINVAL;
   return chan_reduce(0, x, ctot, coff, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, N, C, HW,
-                     pre_relu, 0, sum, sumsq, nullptr, ws, ws_bytes, as_stream(stream));
+                     pre_relu, 0, sum, sumsq, nullptr, nullptr, ws, ws_bytes, as_stream(stream));
+}
+
+extern "C" int dlio_bn_train_stats(const float* x, int N, int ctot, int coff, int C, int HW,
+                                   int pre_relu, const float* gamma, float eps, float momentum,
+                                   float* running_mean, float* running_var, float* mean,
+                                   float* invstd, float* scale, void* ws, size_t ws_bytes,
+                                   dlio_stream_t stream) {
+  if (!x || !mean || !invstd || !scale || N <= 0 || C <= 0 || HW <= 0 || !ws) return DLIO_EINVAL;
+  const int splits = pick_splits(N, C, HW);
+  if (ws_bytes < (size_t)C * splits * 2 * sizeof(double)) return DLIO_EWS;
+  hipStream_t s = as_stream(stream);
+  double* part = reinterpret_cast<double*>(ws);
+  hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3((unsigned)(C * splits)), dim3(RB), 0, s, x, ctot, coff,
+                     (const float*)nullptr, 0, 0, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, N, C, HW, pre_relu, 0, splits, part);
+  int rc = dlio_check_launch();
+  if (rc) return rc;
+  hipLaunchKernelGGL(chan_stats_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, s, part, C, splits,
+                     (double)N * HW, gamma, eps, momentum, running_mean, running_var, mean, invstd,
+                     scale);
+  return dlio_check_launch();
 }
 
 extern "C" int dlio_chan_sum(const float* x, int N, int ctot, int coff, int C, int HW, float* out,
                              void* ws, size_t ws_bytes, dlio_stream_t stream) {
   if (!out) return DLIO_EINVAL;
   return chan_reduce(2, x, ctot, coff, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, N, C, HW,
-                     0, 0, nullptr, nullptr, out, ws, ws_bytes, as_stream(stream));
+                     0, 0, nullptr, nullptr, out, nullptr, ws, ws_bytes, as_stream(stream));
 }
 
 extern "C" int dlio_bn_bwd_reduce(const float* dy, int dy_ctot, int dy_coff, const float* x,
                                   int x_ctot, int x_coff, const float* mean, const float* invstd,
                                   const float* scale, const float* beta, int N, int C, int HW,
                                   int pre_relu, int post_relu, double* sum_g, double* sum_gx,
-                                  void* ws, size_t ws_bytes, dlio_stream_t stream) {
+                                  float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                                  dlio_stream_t stream) {
   if (!x || !mean || !invstd || !scale || !sum_g || !sum_gx) return DLIO_EINVAL;
   return chan_reduce(1, dy, dy_ctot, dy_coff, x, x_ctot, x_coff, mean, invstd, scale, beta, N, C,
-                     HW, pre_relu, post_relu, sum_g, sum_gx, nullptr, ws, ws_bytes,
+                     HW, pre_relu, post_relu, sum_g, sum_gx, dbeta, dgamma, ws, ws_bytes,
                      as_stream(stream));
 }
 

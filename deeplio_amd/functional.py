@@ -34,8 +34,8 @@ class _CBR:
         ops.conv2d_fwd(x, wt, bias, raw, d)
         OHW = d.OH * d.OW
         if training:
-            st = ops.chan_stats(raw, N, raw_ctot, raw_coff, Cout, OHW, pre_relu)
-            prm = ops.bn_finalize(st, N * OHW, gamma, eps, momentum, rmean, rvar)
+            prm = ops.bn_train_stats(raw, N, raw_ctot, raw_coff, Cout, OHW, pre_relu, gamma, eps,
+                                     momentum, rmean, rvar)
         else:
             prm = ops.bn_eval_params(rmean, rvar, gamma, eps)
         ops.bn_apply(raw, raw_ctot, raw_coff, prm, beta, out, out_ctot, out_coff, N, Cout, OHW,
@@ -53,7 +53,14 @@ class _CBR:
         dgamma, dbeta = _new((Cout,), dy), _new((Cout,), dy)
         ops.bn_bwd(dy, dy_ctot, dy_coff, raw, d.out_ctot, d.out_coff, prm, beta, draw, Cout, 0, N,
                    Cout, OHW, pre_relu, post_relu, training, dgamma, dbeta)
-        dbias = ops.chan_sum(draw, N, Cout, 0, Cout, OHW) if has_bias else None
+        dbias = None
+        if has_bias:
+            if training and not pre_relu:
+                # bias in front of a train-mode BN: d/db = sum(draw) = -scale*mean(g*xh)*sum(xh) and
+                # sum(xh) = 0 identically -- the reference computes rounding noise (~1e-7) here
+                dbias = torch.zeros(Cout, dtype=torch.float32, device=dy.device)
+            else:
+                dbias = ops.chan_sum(draw, N, Cout, 0, Cout, OHW)
         dw = _new(tuple(weight.shape), dy)
         dd = ops.conv_desc(N, d.Cin, d.H, d.W, Cout, d.KH, d.KW, d.SH, d.SW, d.PH, d.PW, OH=d.OH,
                            OW=d.OW, in_ctot=d.in_ctot, in_coff=d.in_coff, out_ctot=Cout, out_coff=0)

@@ -127,6 +127,17 @@ def bn_finalize(stats, count, gamma, eps, momentum, running_mean, running_var):
     return prm
 
 
+def bn_train_stats(x, N, ctot, coff, C_, HW, pre_relu, gamma, eps, momentum, running_mean, running_var):
+    """batch statistics + finalize (+ running-stat update) -> params [3][C]: mean, invstd, scale"""
+    prm = torch.empty(3, C_, dtype=torch.float32, device=x.device)
+    ws = _stats_ws(N, C_, HW, x.device)
+    check(lib.dlio_bn_train_stats(_ptr(x), N, ctot, coff, C_, HW, int(pre_relu), _ptr(gamma), float(eps),
+                                  float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(prm[0]),
+                                  _ptr(prm[1]), _ptr(prm[2]), _ptr(ws), ws.numel(), _stream()),
+          "bn_train_stats")
+    return prm
+
+
 def bn_eval_params(running_mean, running_var, gamma, eps):
     C_ = running_mean.numel()
     prm = torch.empty(3, C_, dtype=torch.float32, device=running_mean.device)
@@ -150,11 +161,11 @@ def bn_bwd(dy, dy_ctot, dy_coff, x, x_ctot, x_coff, prm, beta, dx, dx_ctot, dx_c
     ws = _stats_ws(N, C_, HW, x.device)
     check(lib.dlio_bn_bwd_reduce(_ptr(dy), dy_ctot, dy_coff, _ptr(x), x_ctot, x_coff, _ptr(prm[0]),
                                  _ptr(prm[1]), _ptr(prm[2]), _ptr(beta), N, C_, HW, int(pre_relu),
-                                 int(post_relu), _ptr(sums[0]), _ptr(sums[1]), _ptr(ws), ws.numel(),
-                                 _stream()), "bn_bwd_reduce")
+                                 int(post_relu), _ptr(sums[0]), _ptr(sums[1]), _ptr(dgamma), _ptr(dbeta),
+                                 _ptr(ws), ws.numel(), _stream()), "bn_bwd_reduce")
     check(lib.dlio_bn_bwd_apply(_ptr(dy), dy_ctot, dy_coff, _ptr(x), x_ctot, x_coff, _ptr(prm[0]),
                                 _ptr(prm[1]), _ptr(prm[2]), _ptr(beta), _ptr(sums[0]),
-                                _ptr(sums[1]), _ptr(dx), dx_ctot, dx_coff, _ptr(dgamma), _ptr(dbeta),
+                                _ptr(sums[1]), _ptr(dx), dx_ctot, dx_coff, None, None,
                                 N, C_, HW, int(pre_relu), int(post_relu), int(use_batch_stats),
                                 _stream()), "bn_bwd_apply")
     return dx

@@ -110,6 +110,11 @@ int dlio_bn_finalize(const double* sum, const double* sumsq, int C, double count
                      const float* gamma, float eps, float momentum,
                      float* running_mean, float* running_var,
                      float* mean, float* invstd, float* scale, dlio_stream_t stream);
+/* dlio_chan_stats + dlio_bn_finalize in two launches instead of three (count = N*HW) */
+int dlio_bn_train_stats(const float* x, int N, int ctot, int coff, int C, int HW, int pre_relu,
+                        const float* gamma, float eps, float momentum, float* running_mean,
+                        float* running_var, float* mean, float* invstd, float* scale, void* ws,
+                        size_t ws_bytes, dlio_stream_t stream);
 /* eval mode: mean=running_mean, invstd=rsqrt(running_var+eps), scale=gamma*invstd */
 int dlio_bn_eval_params(const float* running_mean, const float* running_var, const float* gamma,
                         float eps, int C, float* mean, float* invstd, float* scale,
@@ -121,12 +126,12 @@ int dlio_bn_apply(const float* x, int x_ctot, int x_coff, const float* mean, con
                   float* y, int y_ctot, int y_coff, int N, int C, int HW,
                   int pre_relu, int post_relu, dlio_stream_t stream);
 /* backward reductions: g = dy * [post_relu ? y>0 : 1];  xh = (pre(x)-mean)*invstd
- * sum_g[c] = sum g, sum_gx[c] = sum g*xh */
+ * sum_g[c] = sum g, sum_gx[c] = sum g*xh; optional fp32 copies dgamma = sum_gx, dbeta = sum_g */
 int dlio_bn_bwd_reduce(const float* dy, int dy_ctot, int dy_coff, const float* x, int x_ctot,
                        int x_coff, const float* mean, const float* invstd, const float* scale,
                        const float* beta, int N, int C, int HW, int pre_relu, int post_relu,
-                       double* sum_g, double* sum_gx, void* ws, size_t ws_bytes,
-                       dlio_stream_t stream);
+                       double* sum_g, double* sum_gx, float* dgamma, float* dbeta, void* ws,
+                       size_t ws_bytes, dlio_stream_t stream);
 /* dgamma = sum_gx, dbeta = sum_g (fp32 out);  train: dx = scale*(g - sum_g/M - xh*sum_gx/M)
  * eval (use_batch_stats=0): dx = scale*g.  pre_relu masks dx by x>0. */
 int dlio_bn_bwd_apply(const float* dy, int dy_ctot, int dy_coff, const float* x, int x_ctot,
