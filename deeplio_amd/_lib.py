@@ -41,7 +41,7 @@ SIGNATURES = {
     "dlio_conv2d_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _cd, _p]),
     "dlio_conv2d_dgrad_strided": (_i, [_p, _p, _p, _cd, _p]),
     "dlio_conv2d_wgrad_ws_bytes": (_sz, [_cd]),
-    "dlio_conv2d_wgrad": (_i, [_p, _p, _p, _p, _p, _p, _p, _sz, _cd, _p]),
+    "dlio_conv2d_wgrad": (_i, [_p, _p, _p, _p, _p, _p, _p, _sz, _i, _cd, _p]),
     "dlio_chan_stats_ws_bytes": (_sz, [_i, _i, _i]),
     "dlio_chan_stats": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "dlio_bn_finalize": (_i, [_p, _p, _i, _d, _p, _f, _f, _p, _p, _p, _p, _p, _p]),
@@ -49,10 +49,10 @@ SIGNATURES = {
     "dlio_bn_apply": (_i, [_p, _i, _i, _p, _p, _p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dlio_bn_train_stats": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _f, _f, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "dlio_bn_bwd_reduce": (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p,
-                               _p, _p, _p, _sz, _p]),
+                               _p, _p, _i, _p, _sz, _p]),
     "dlio_bn_bwd_apply": (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p,
                               _i, _i, _i, _i, _i, _i, _p]),
-    "dlio_chan_sum": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _sz, _p]),
+    "dlio_chan_sum": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _p, _sz, _p]),
     "dlio_maxpool2d_fwd": (_i, [_p, _p, _p, _p] + [_i] * 11 + [_p]),
     "dlio_maxpool2d_bwd": (_i, [_p, _p, _p, _p] + [_i] * 11 + [_p]),
     "dlio_gap_fwd": (_i, [_p, _i, _i, _p, _i, _i, _i, _p]),

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(RB) void chan_reduce_kernel(
 
 __global__ void chan_reduce_final(const double* __restrict__ part, int C, int splits,
                                   double* __restrict__ o0, double* __restrict__ o1,
-                                  float* __restrict__ f0, float* __restrict__ f1) {
+                                  float* __restrict__ f0, float* __restrict__ f1, int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double a = 0.0, b = 0.0;
@@ -96,8 +96,8 @@ __global__ void chan_reduce_final(const double* __restrict__ part, int C, int sp
   }
   if (o0) o0[c] = a;
   if (o1) o1[c] = b;
-  if (f0) f0[c] = (float)a;
-  if (f1) f1[c] = (float)b;
+  if (f0) f0[c] = accumulate ? f0[c] + (float)a : (float)a;
+  if (f1) f1[c] = accumulate ? f1[c] + (float)b : (float)b;
 }
 
 // statistics epilogue of a train-mode BatchNorm: sums the split partials of one channel and
@@ -282,8 +282,8 @@ extern "C" size_t dlio_chan_stats_ws_bytes(int N, int C, int HW) {
 static int chan_reduce(int mode, const float* a, int a_ctot, int a_coff, const float* x, int x_ctot,
                        int x_coff, const float* mean, const float* invstd, const float* scale,
                        const float* beta, int N, int C, int HW, int pre_relu, int post_relu,
-                       double* o0, double* o1, float* f0, float* f1, void* ws, size_t ws_bytes,
-                       hipStream_t s) {
+                       double* o0, double* o1, float* f0, float* f1, int accumulate, void* ws,
+                       size_t ws_bytes, hipStream_t s) {
   if (!a || N <= 0 || C <= 0 || HW <= 0 || !ws) return DLIO_EINVAL;
   const int splits = pick_splits(N, C, HW);
   if (ws_bytes < (size_t)C * splits * 2 * sizeof(double)) return DLIO_EWS;
@@ -301,7 +301,7 @@ static int chan_reduce(int mode, const float* a, int a_ctot, int a_coff, const f
   int rc = dlio_check_launch();
   if (rc) return rc;
   hipLaunchKernelGGL(chan_reduce_final, dim3(cdiv(C, 128)), dim3(128), 0, s, part, C, splits, o0,
-                     o1, f0, f1);
+                     o1, f0, f1, accumulate);
   return dlio_check_launch();
 }
 
@@ -310,7 +310,7 @@ extern "C" int dlio_chan_stats(const float* x, int N, int ctot, int coff, int C,
                                size_t ws_bytes, dlio_stream_t stream) {
   if (!sum || !sumsq) return DLIO_EINVAL;
   return chan_reduce(0, x, ctot, coff, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, N, C, HW,
-                     pre_relu, 0, sum, sumsq, nullptr, nullptr, ws, ws_bytes, as_stream(stream));
+                     pre_relu, 0, sum, sumsq, nullptr, nullptr, 0, ws, ws_bytes, as_stream(stream));
 }
 
 extern "C" int dlio_bn_train_stats(const float* x, int N, int ctot, int coff, int C, int HW,
@@ -335,21 +335,21 @@ extern "C" int dlio_bn_train_stats(const float* x, int N, int ctot, int coff, in
 }
 
 extern "C" int dlio_chan_sum(const float* x, int N, int ctot, int coff, int C, int HW, float* out,
-                             void* ws, size_t ws_bytes, dlio_stream_t stream) {
+                             int accumulate, void* ws, size_t ws_bytes, dlio_stream_t stream) {
   if (!out) return DLIO_EINVAL;
   return chan_reduce(2, x, ctot, coff, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, N, C, HW,
-                     0, 0, nullptr, nullptr, out, nullptr, ws, ws_bytes, as_stream(stream));
+                     0, 0, nullptr, nullptr, out, nullptr, accumulate, ws, ws_bytes, as_stream(stream));
 }
 
 extern "C" int dlio_bn_bwd_reduce(const float* dy, int dy_ctot, int dy_coff, const float* x,
                                   int x_ctot, int x_coff, const float* mean, const float* invstd,
                                   const float* scale, const float* beta, int N, int C, int HW,
                                   int pre_relu, int post_relu, double* sum_g, double* sum_gx,
-                                  float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
-                                  dlio_stream_t stream) {
+                                  float* dgamma, float* dbeta, int accumulate, void* ws,
+                                  size_t ws_bytes, dlio_stream_t stream) {
   if (!x || !mean || !invstd || !scale || !sum_g || !sum_gx) return DLIO_EINVAL;
   return chan_reduce(1, dy, dy_ctot, dy_coff, x, x_ctot, x_coff, mean, invstd, scale, beta, N, C,
-                     HW, pre_relu, post_relu, sum_g, sum_gx, dbeta, dgamma, ws, ws_bytes,
+                     HW, pre_relu, post_relu, sum_g, sum_gx, dbeta, dgamma, accumulate, ws, ws_bytes,
                      as_stream(stream));
 }
 

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
 // consecutive elements (8 independent loads in flight), partials combined through LDS.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ wsp,
                                                            float* __restrict__ dw, int64_t n,
-                                                           int splits) {
+                                                           int splits, int accumulate) {
   __shared__ float red[4][64];
   const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * 64 + e;
@@ -315,11 +315,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
   red[g][e] = s;
   __syncthreads();
-  if (g == 0 && i < n) dw[i] = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+  if (g == 0 && i < n) {
+    const float v = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+    dw[i] = accumulate ? dw[i] + v : v;
+  }
 }
 
 struct WgPlan {
-  int nt, mr, ckmax, co_tiles, ci_chunks, tiles_w, tiles_h, splits;
+  int nt, mr, ckmax, co_tiles, ci_chunks, tiles_w, tiles_h, splits, accumulate = 0;
   size_t ws_bytes;
 };
 
@@ -386,7 +389,7 @@ int launch_mr(const float* x, const float* dy, float* dw, const float* in_mean,
   if (rc) return rc;
   const int64_t n = (int64_t)d.Cout * d.Cin * KH * KW;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(n, 64)), dim3(256), 0, s, wsp, dw, n,
-                     p.splits);
+                     p.splits, p.accumulate);
   return dlio_check_launch();
 }
 
@@ -413,7 +416,7 @@ extern "C" size_t dlio_conv2d_wgrad_ws_bytes(const DlioConvDesc* d) {
 
 extern "C" int dlio_conv2d_wgrad(const float* x, const float* dy, float* dw,
                                  const float* in_mean, const float* in_scale,
-                                 const float* in_shift, void* ws, size_t ws_bytes,
+                                 const float* in_shift, void* ws, size_t ws_bytes, int accumulate,
                                  const DlioConvDesc* dp, dlio_stream_t stream) {
   if (!x || !dy || !dw || !dp || !ws) return DLIO_EINVAL;
   const DlioConvDesc& d = *dp;
@@ -421,6 +424,7 @@ extern "C" int dlio_conv2d_wgrad(const float* x, const float* dy, float* dw,
   WgPlan p;
   if (!make_plan(d, p)) return DLIO_EUNSUP;
   if (ws_bytes < p.ws_bytes) return DLIO_EWS;
+  p.accumulate = accumulate;
   hipStream_t s = as_stream(stream);
   float* wsp = reinterpret_cast<float*>(ws);
   const double flops = 2.0 * d.N * (double)d.OH * d.OW * d.Cout * (double)d.Cin * d.KH * d.KW;

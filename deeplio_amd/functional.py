@@ -17,6 +17,26 @@ def _new(shape, like):
     return _E(shape, dtype=torch.float32, device=like.device)
 
 
+_SINK = [True]
+
+
+def set_grad_sink(on):
+    """When on (default), parameter gradients are accumulated by the kernels straight into an
+    existing `param.grad` buffer (the optimizer's flat gradient view) and autograd receives None
+    for them: no per-parameter `+=` launches, no extra pass over the gradients."""
+    _SINK[0] = bool(on)
+
+
+def _sink(param, shape, like):
+    """-> (out, accumulate, value_for_autograd)"""
+    g = param.grad if (_SINK[0] and param is not None) else None
+    if (g is not None and g.dtype == torch.float32 and g.is_contiguous() and tuple(g.shape) == tuple(shape)
+            and g.device == like.device):
+        return g, True, None
+    t = _new(tuple(shape), like)
+    return t, False, t
+
+
 # =============================================================================== conv + BN + ReLU
 class _CBR:
     """conv (+bias) -> [ReLU] -> BatchNorm -> [ReLU] over channel slices, forward and backward.
@@ -43,32 +63,39 @@ class _CBR:
         return d, prm
 
     @staticmethod
-    def backward(dy, dy_ctot, dy_coff, x, d, weight, has_bias, prm, beta, raw, training, pre_relu,
+    def backward(dy, dy_ctot, dy_coff, x, d, weight, bias, gamma, prm, beta, raw, training, pre_relu,
                  post_relu, draw, need_dx, dx=None, dx_ctot=0, dx_coff=0, dx_residual=None,
                  dxr_ctot=0, dxr_coff=0, dx_accumulate=False):
         """dy: grad wrt the activated output (slice).  draw: scratch [N,Cout,OH,OW] (contiguous).
         Returns (dweight, dbias, dgamma, dbeta); writes dx (slice) if need_dx:
         dx = dgrad (+ dx_residual) (+ previous dx when dx_accumulate)."""
         N, Cout, OHW = d.N, d.Cout, d.OH * d.OW
-        dgamma, dbeta = _new((Cout,), dy), _new((Cout,), dy)
+        dgamma, acc_g, ret_g = _sink(gamma, (Cout,), dy)
+        dbeta, acc_b, ret_b = _sink(beta, (Cout,), dy)
+        if acc_g != acc_b:           # one flag serves both outputs of the reduce epilogue
+            dgamma, acc_g, ret_g = _new((Cout,), dy), False, None
+            dbeta, acc_b, ret_b = _new((Cout,), dy), False, None
+            ret_g, ret_b = dgamma, dbeta
         ops.bn_bwd(dy, dy_ctot, dy_coff, raw, d.out_ctot, d.out_coff, prm, beta, draw, Cout, 0, N,
-                   Cout, OHW, pre_relu, post_relu, training, dgamma, dbeta)
-        dbias = None
-        if has_bias:
+                   Cout, OHW, pre_relu, post_relu, training, dgamma, dbeta, accumulate=acc_g)
+        ret_bias = None
+        if bias is not None:
+            dbias, acc, ret_bias = _sink(bias, (Cout,), dy)
             if training and not pre_relu:
                 # bias in front of a train-mode BN: d/db = sum(draw) = -scale*mean(g*xh)*sum(xh) and
                 # sum(xh) = 0 identically -- the reference computes rounding noise (~1e-7) here
-                dbias = torch.zeros(Cout, dtype=torch.float32, device=dy.device)
+                if not acc:
+                    dbias.zero_()
             else:
-                dbias = ops.chan_sum(draw, N, Cout, 0, Cout, OHW)
-        dw = _new(tuple(weight.shape), dy)
+                ops.chan_sum(draw, N, Cout, 0, Cout, OHW, out=dbias, accumulate=acc)
+        dw, acc_w, ret_w = _sink(weight, weight.shape, dy)
         dd = ops.conv_desc(N, d.Cin, d.H, d.W, Cout, d.KH, d.KW, d.SH, d.SW, d.PH, d.PW, OH=d.OH,
                            OW=d.OW, in_ctot=d.in_ctot, in_coff=d.in_coff, out_ctot=Cout, out_coff=0)
-        ops.conv2d_wgrad(x, draw, dw, dd)
+        ops.conv2d_wgrad(x, draw, dw, dd, accumulate=acc_w)
         if need_dx:
             conv_dgrad(draw, weight, d, dx, dx_ctot, dx_coff, dx_residual, dxr_ctot, dxr_coff,
                        dx_accumulate)
-        return dw, dbias, dgamma, dbeta
+        return ret_w, ret_bias, ret_g, ret_b
 
 
 def conv_dgrad(dy, weight, d, dx, dx_ctot, dx_coff, residual=None, r_ctot=0, r_coff=0,
@@ -110,19 +137,19 @@ class ConvBnAct(Function):
         d, prm = _CBR.forward(x, Cin, 0, Cin, H, W, weight, bias, gamma, beta, rmean, rvar, stride,
                               pad, training, momentum, eps, pre_relu, post_relu, raw, Cout, 0, out,
                               Cout, 0, N)
-        ctx.save_for_backward(x, weight, beta, raw, prm)
-        ctx.cfg = (d, bias is not None, training, pre_relu, post_relu)
+        ctx.save_for_backward(x, weight, beta, raw, prm, gamma, bias)
+        ctx.cfg = (d, training, pre_relu, post_relu)
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight, beta, raw, prm = ctx.saved_tensors
-        d, has_bias, training, pre_relu, post_relu = ctx.cfg
+        x, weight, beta, raw, prm, gamma, bias = ctx.saved_tensors
+        d, training, pre_relu, post_relu = ctx.cfg
         dy = dy.contiguous()
         draw = torch.empty_like(raw)
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty_like(x) if need_dx else None
-        dw, db, dg, dbt = _CBR.backward(dy, d.Cout, 0, x, d, weight, has_bias, prm, beta, raw,
+        dw, db, dg, dbt = _CBR.backward(dy, d.Cout, 0, x, d, weight, bias, gamma, prm, beta, raw,
                                         training, pre_relu, post_relu, draw, need_dx, dx, d.Cin, 0)
         return (dx, dw, db, dg, dbt) + (None,) * 9
 
@@ -152,13 +179,14 @@ class FireFn(Function):
                                   (1, 1), training, momentum, eps, False, True, raw_e, CE, E1, out,
                                   CE, E1, N, res, Cin, E1)
         ctx.save_for_backward(x, sw, sbe, e1w, e1be, e3w, e3be, raw_s, act_s, raw_e, prm_s, prm_1,
-                              prm_3)
+                              prm_3, sb, sg, e1b, e1g, e3b, e3g)
         ctx.cfg = (d_s, d_1, d_3, training, bypass)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        (x, sw, sbe, e1w, e1be, e3w, e3be, raw_s, act_s, raw_e, prm_s, prm_1, prm_3) = ctx.saved_tensors
+        (x, sw, sbe, e1w, e1be, e3w, e3be, raw_s, act_s, raw_e, prm_s, prm_1, prm_3, sb, sg, e1b, e1g,
+         e3b, e3g) = ctx.saved_tensors
         d_s, d_1, d_3, training, bypass = ctx.cfg
         dout = dout.contiguous()
         N, Cin, H, W = x.shape
@@ -166,17 +194,17 @@ class FireFn(Function):
         CE = E1 + E3
         dact_s = _new((N, S_, H, W), x)
         draw1 = _new((N, E1, H, W), x)
-        g1 = _CBR.backward(dout, CE, 0, act_s, d_1, e1w, True, prm_1, e1be, raw_e, training, False,
+        g1 = _CBR.backward(dout, CE, 0, act_s, d_1, e1w, e1b, e1g, prm_1, e1be, raw_e, training, False,
                            True, draw1, True, dact_s, S_, 0)
         del draw1
         draw3 = _new((N, E3, H, W), x)
-        g3 = _CBR.backward(dout, CE, E1, act_s, d_3, e3w, True, prm_3, e3be, raw_e, training, False,
+        g3 = _CBR.backward(dout, CE, E1, act_s, d_3, e3w, e3b, e3g, prm_3, e3be, raw_e, training, False,
                            True, draw3, True, dact_s, S_, 0, dx_accumulate=True)
         del draw3
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty_like(x) if need_dx else None
         draw_s = _new((N, S_, H, W), x)
-        gs = _CBR.backward(dact_s, S_, 0, x, d_s, sw, True, prm_s, sbe, raw_s, training, False, True,
+        gs = _CBR.backward(dact_s, S_, 0, x, d_s, sw, sb, sg, prm_s, sbe, raw_s, training, False, True,
                            draw_s, need_dx, dx, Cin, 0, dout if bypass else None, CE, 0)
         return (dx, gs[0], gs[1], gs[2], gs[3], None, None, g1[0], g1[1], g1[2], g1[3], None, None,
                 g3[0], g3[1], g3[2], g3[3], None, None, None, None, None, None)
@@ -233,13 +261,15 @@ class SEPoolFn(Function):
             dxs = ops.maxpool2d_bwd(dy, idx, tuple(x.shape), k, stride[0], stride[1], pad[0], pad[1])
         dx, ds = ops.chan_scale_bwd(dxs, x, s)
         dz2 = ops.act_bwd(ds, s, ops.ACT_SIGMOID)
-        dw2, _ = ops.linear_bwd_weight(dz2, h, N, w2.shape[0], w2.shape[1], want_bias=False)
+        dw2, acc2, ret2 = _sink(w2, w2.shape, dy)
+        ops.linear_bwd_weight(dz2, h, N, w2.shape[0], w2.shape[1], dw=dw2, want_bias=False, accumulate=acc2)
         dh = ops.linear_bwd_data(dz2, w2, N)
         dz1 = ops.act_bwd(dh, h, ops.ACT_RELU)
-        dw1, _ = ops.linear_bwd_weight(dz1, g, N, w1.shape[0], w1.shape[1], want_bias=False)
+        dw1, acc1, ret1 = _sink(w1, w1.shape, dy)
+        ops.linear_bwd_weight(dz1, g, N, w1.shape[0], w1.shape[1], dw=dw1, want_bias=False, accumulate=acc1)
         dg = ops.linear_bwd_data(dz1, w1, N)
         ops.gap_bwd(dg, dx, N, C_, H * W, accumulate=True)
-        return dx, dw1, dw2, None
+        return dx, ret1, ret2, None
 
 
 class GapFn(Function):
@@ -270,19 +300,28 @@ class LinearFn(Function):
         K = w.shape[1]
         M = x.numel() // K
         y = ops.linear_fwd(x, w, b, act, M=M)
-        ctx.save_for_backward(x, w, y)
-        ctx.cfg = (act, b is not None, M)
+        ctx.save_for_backward(x, w, y, b)
+        ctx.cfg = (act, M)
         return y.view(x.shape[:-1] + (w.shape[0],))
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, y = ctx.saved_tensors
-        act, has_b, M = ctx.cfg
+        x, w, y, b = ctx.saved_tensors
+        act, M = ctx.cfg
         dy = dy.contiguous()
         dz = ops.act_bwd(dy, y, act) if act else dy
         dx = ops.linear_bwd_data(dz, w, M).view(x.shape) if ctx.needs_input_grad[0] else None
-        dw, db = ops.linear_bwd_weight(dz, x, M, w.shape[0], w.shape[1], want_bias=has_b)
-        return dx, dw, db, None
+        dw, acc_w, ret_w = _sink(w, w.shape, dy)
+        db = ret_b = None
+        if b is not None:
+            db, acc_b, ret_b = _sink(b, b.shape, dy)
+            if acc_b != acc_w:       # one accumulate flag per launch: fall back to fresh buffers
+                dw, acc_w, ret_w = _new(tuple(w.shape), dy), False, None
+                db, ret_b = _new(tuple(b.shape), dy), None
+                ret_w, ret_b = dw, db
+        ops.linear_bwd_weight(dz, x, M, w.shape[0], w.shape[1], dw=dw, db=db, want_bias=b is not None,
+                              accumulate=acc_w)
+        return dx, ret_w, ret_b, None
 
 
 class BinaryFn(Function):
@@ -460,15 +499,23 @@ class RNNFn(Function):
         dtops = dtops.contiguous()
         dev = dtops
         W = [[weights[(l * D + d) * 4:(l * D + d) * 4 + 4] for d in range(D)] for l in range(L)]
-        grads = [None] * len(weights)
+        grads = [None] * len(weights)      # what autograd receives (None when sunk into .grad)
+        outs = [None] * len(weights)       # where the kernels write
         first = [True] * len(weights)
 
         def acc_w(slot, dz, lddz, xin, ldx, N_, K, with_bias_slot):
             wi = slot
-            if grads[wi] is None:
-                grads[wi] = _new((N_, K), dev)
-                grads[with_bias_slot] = _new((N_,), dev)
-            ops.linear_bwd_weight(dz, xin, rows, N_, K, dw=grads[wi], db=grads[with_bias_slot],
+            if outs[wi] is None:
+                ow, aw_, rw = _sink(weights[wi], (N_, K), dev)
+                ob, ab_, rb = _sink(weights[with_bias_slot], (N_,), dev)
+                if aw_ != ab_:
+                    ow, aw_, rw = _new((N_, K), dev), False, None
+                    ob, rb = _new((N_,), dev), None
+                    rw, rb = ow, ob
+                outs[wi], outs[with_bias_slot] = ow, ob
+                grads[wi], grads[with_bias_slot] = rw, rb
+                first[wi] = not aw_        # sunk gradients accumulate from the first call on
+            ops.linear_bwd_weight(dz, xin, rows, N_, K, dw=outs[wi], db=outs[with_bias_slot],
                                   lddz=lddz, ldx=ldx, accumulate=not first[wi])
             first[wi] = False
 

@@ -92,14 +92,14 @@ def conv2d_dgrad_strided(dy, w, dx, desc):
     return dx
 
 
-def conv2d_wgrad(x, dy, dw, desc, in_aff=None):
+def conv2d_wgrad(x, dy, dw, desc, in_aff=None, accumulate=False):
     m = s = b = None
     if in_aff is not None:
         m, s, b = in_aff
     nbytes = lib.dlio_conv2d_wgrad_ws_bytes(C.byref(desc))
     ws = workspace(nbytes, x.device)
     check(lib.dlio_conv2d_wgrad(_ptr(x), _ptr(dy), _ptr(dw), _ptr(m), _ptr(s), _ptr(b), _ptr(ws),
-                                ws.numel(), C.byref(desc), _stream()), "conv2d_wgrad")
+                                ws.numel(), int(accumulate), C.byref(desc), _stream()), "conv2d_wgrad")
     return dw
 
 
@@ -156,13 +156,13 @@ def bn_apply(x, x_ctot, x_coff, prm, beta, y, y_ctot, y_coff, N, C_, HW, pre_rel
 
 
 def bn_bwd(dy, dy_ctot, dy_coff, x, x_ctot, x_coff, prm, beta, dx, dx_ctot, dx_coff, N, C_, HW,
-           pre_relu, post_relu, use_batch_stats, dgamma=None, dbeta=None):
+           pre_relu, post_relu, use_batch_stats, dgamma=None, dbeta=None, accumulate=False):
     sums = torch.empty(2, C_, dtype=torch.float64, device=x.device)
     ws = _stats_ws(N, C_, HW, x.device)
     check(lib.dlio_bn_bwd_reduce(_ptr(dy), dy_ctot, dy_coff, _ptr(x), x_ctot, x_coff, _ptr(prm[0]),
                                  _ptr(prm[1]), _ptr(prm[2]), _ptr(beta), N, C_, HW, int(pre_relu),
                                  int(post_relu), _ptr(sums[0]), _ptr(sums[1]), _ptr(dgamma), _ptr(dbeta),
-                                 _ptr(ws), ws.numel(), _stream()), "bn_bwd_reduce")
+                                 int(accumulate), _ptr(ws), ws.numel(), _stream()), "bn_bwd_reduce")
     check(lib.dlio_bn_bwd_apply(_ptr(dy), dy_ctot, dy_coff, _ptr(x), x_ctot, x_coff, _ptr(prm[0]),
                                 _ptr(prm[1]), _ptr(prm[2]), _ptr(beta), _ptr(sums[0]),
                                 _ptr(sums[1]), _ptr(dx), dx_ctot, dx_coff, None, None,
@@ -171,12 +171,12 @@ def bn_bwd(dy, dy_ctot, dy_coff, x, x_ctot, x_coff, prm, beta, dx, dx_ctot, dx_c
     return dx
 
 
-def chan_sum(x, N, ctot, coff, C_, HW, out=None):
+def chan_sum(x, N, ctot, coff, C_, HW, out=None, accumulate=False):
     if out is None:
         out = torch.empty(C_, dtype=torch.float32, device=x.device)
     ws = _stats_ws(N, C_, HW, x.device)
-    check(lib.dlio_chan_sum(_ptr(x), N, ctot, coff, C_, HW, _ptr(out), _ptr(ws), ws.numel(),
-                            _stream()), "chan_sum")
+    check(lib.dlio_chan_sum(_ptr(x), N, ctot, coff, C_, HW, _ptr(out), int(accumulate), _ptr(ws),
+                            ws.numel(), _stream()), "chan_sum")
     return out
 
 

@@ -89,11 +89,13 @@ int dlio_conv2d_dgrad_strided(const float* dy, const float* w, float* dx,
                               const DlioConvDesc* d, dlio_stream_t stream);
 
 /* dw[co][ci][dy][dx] = sum_{n,oh,ow} dy[n,co,oh,ow] * x'[n,ci,oh*SH-PH+dy,ow*SW-PW+dx]
- * standard weight layout; deterministic two-stage split-K through ws. */
+ * standard weight layout; deterministic two-stage split-K through ws.  accumulate: dw += ...
+ * (gradient written straight into the optimizer's flat gradient buffer). */
 size_t dlio_conv2d_wgrad_ws_bytes(const DlioConvDesc* d);
 int dlio_conv2d_wgrad(const float* x, const float* dy, float* dw,
                       const float* in_mean, const float* in_scale, const float* in_shift,
-                      void* ws, size_t ws_bytes, const DlioConvDesc* d, dlio_stream_t stream);
+                      void* ws, size_t ws_bytes, int accumulate, const DlioConvDesc* d,
+                      dlio_stream_t stream);
 
 /* ---- per-channel reductions / batch norm --------------------------------
  * replaces nn.BatchNorm2d (train + eval) at pointseg_net.py:19,
@@ -130,8 +132,8 @@ int dlio_bn_apply(const float* x, int x_ctot, int x_coff, const float* mean, con
 int dlio_bn_bwd_reduce(const float* dy, int dy_ctot, int dy_coff, const float* x, int x_ctot,
                        int x_coff, const float* mean, const float* invstd, const float* scale,
                        const float* beta, int N, int C, int HW, int pre_relu, int post_relu,
-                       double* sum_g, double* sum_gx, float* dgamma, float* dbeta, void* ws,
-                       size_t ws_bytes, dlio_stream_t stream);
+                       double* sum_g, double* sum_gx, float* dgamma, float* dbeta, int accumulate,
+                       void* ws, size_t ws_bytes, dlio_stream_t stream);
 /* dgamma = sum_gx, dbeta = sum_g (fp32 out);  train: dx = scale*(g - sum_g/M - xh*sum_gx/M)
  * eval (use_batch_stats=0): dx = scale*g.  pre_relu masks dx by x>0. */
 int dlio_bn_bwd_apply(const float* dy, int dy_ctot, int dy_coff, const float* x, int x_ctot,
@@ -142,7 +144,7 @@ int dlio_bn_bwd_apply(const float* dy, int dy_ctot, int dy_coff, const float* x,
                       dlio_stream_t stream);
 /* out[c] (fp32) = sum over (n,hw) of channel slice -- conv bias gradient */
 int dlio_chan_sum(const float* x, int N, int ctot, int coff, int C, int HW, float* out,
-                  void* ws, size_t ws_bytes, dlio_stream_t stream);
+                  int accumulate, void* ws, size_t ws_bytes, dlio_stream_t stream);
 
 /* ---- pooling ---------------------------------------------------------
  * nn.MaxPool2d(kernel 3) at pointseg_net.py:21-46, resnet.py:40,
