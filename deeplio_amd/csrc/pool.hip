@@ -128,11 +128,41 @@ __global__ __launch_bounds__(256) void maxpool3_fwd_sw2(const float* __restrict_
   }
 }
 
-// backward: one thread = 4 adjacent input columns 4b..4b+3 <- output columns 2b, 2b+1, 2b+2
+// backward gather for 4 adjacent input columns 4b..4b+3 of row ih <- output columns 2b..2b+2
+template <int SH>
+__device__ __forceinline__ void pool3_bwd_gather(const float* __restrict__ dyp,
+                                                 const uint8_t* __restrict__ ip, int ih, int b, int OH,
+                                                 int OW, float (&g)[4]) {
+  g[0] = g[1] = g[2] = g[3] = 0.f;
+  int ohs[3], kys[3], nc;
+  if (SH == 1) { nc = 3; ohs[0] = ih - 1; kys[0] = 2; ohs[1] = ih; kys[1] = 1; ohs[2] = ih + 1; kys[2] = 0; }
+  else if ((ih & 1) == 0) { nc = 1; ohs[0] = ih >> 1; kys[0] = 1; ohs[1] = ohs[2] = -1; kys[1] = kys[2] = 0; }
+  else { nc = 2; ohs[0] = ih >> 1; kys[0] = 2; ohs[1] = (ih >> 1) + 1; kys[1] = 0; ohs[2] = -1; kys[2] = 0; }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    if (q >= nc) continue;
+    const int oh = ohs[q];
+    if (oh < 0 || oh >= OH) continue;
+    const int base = kys[q] * 3;
+    const size_t ro = (size_t)oh * OW + 2 * b;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      if (2 * b + c >= OW) continue;
+      const int kx = (int)ip[ro + c] - base;
+      const float v = dyp[ro + c];
+      if (c == 0) { if (kx == 1) g[0] += v; else if (kx == 2) g[1] += v; }
+      else if (c == 1) { if (kx == 0) g[1] += v; else if (kx == 1) g[2] += v; else if (kx == 2) g[3] += v; }
+      else { if (kx == 0) g[3] += v; }
+    }
+  }
+}
+
+// dx = gather * xs[plane] + xadd[plane]   (xs / xadd nullable: SELayer scale, GAP-backward constant)
 template <int SH>
 __global__ __launch_bounds__(256) void maxpool3_bwd_sw2(const float* __restrict__ dy,
                                                         const uint8_t* __restrict__ idx,
                                                         const float* __restrict__ xs,
+                                                        const float* __restrict__ xadd,
                                                         float* __restrict__ dx, int64_t planes, int H,
                                                         int W, int OH, int OW) {
   const int W4 = W >> 2;
@@ -143,32 +173,38 @@ __global__ __launch_bounds__(256) void maxpool3_bwd_sw2(const float* __restrict_
     int64_t t = i / W4;
     const int ih = (int)(t % H);
     const int64_t pl = t / H;
+    float g[4];
+    pool3_bwd_gather<SH>(dy + (size_t)pl * OH * OW, idx + (size_t)pl * OH * OW, ih, b, OH, OW, g);
+    if (xs) { const float s = xs[pl]; g[0] *= s; g[1] *= s; g[2] *= s; g[3] *= s; }
+    if (xadd) { const float a = xadd[pl]; g[0] += a; g[1] += a; g[2] += a; g[3] += a; }
+    *reinterpret_cast<float4*>(dx + ((size_t)pl * H + ih) * W + 4 * b) = make_float4(g[0], g[1], g[2], g[3]);
+  }
+}
+
+// ds[plane] = sum over the plane of gather * x  (the SELayer scale gradient) without ever
+// writing the pooled-gradient plane: one block per plane, fp64 block reduction
+template <int SH>
+__global__ __launch_bounds__(256) void maxpool3_bwd_dot_sw2(const float* __restrict__ dy,
+                                                            const uint8_t* __restrict__ idx,
+                                                            const float* __restrict__ x,
+                                                            float* __restrict__ ds, int planes, int H,
+                                                            int W, int OH, int OW) {
+  __shared__ double sm[16];
+  const int W4 = W >> 2;
+  for (int pl = blockIdx.x; pl < planes; pl += gridDim.x) {
     const float* dyp = dy + (size_t)pl * OH * OW;
     const uint8_t* ip = idx + (size_t)pl * OH * OW;
-    float g[4] = {0.f, 0.f, 0.f, 0.f};
-    int ohs[3], kys[3], nc;
-    if (SH == 1) { nc = 3; ohs[0] = ih - 1; kys[0] = 2; ohs[1] = ih; kys[1] = 1; ohs[2] = ih + 1; kys[2] = 0; }
-    else if ((ih & 1) == 0) { nc = 1; ohs[0] = ih >> 1; kys[0] = 1; ohs[1] = ohs[2] = -1; kys[1] = kys[2] = 0; }
-    else { nc = 2; ohs[0] = ih >> 1; kys[0] = 2; ohs[1] = (ih >> 1) + 1; kys[1] = 0; ohs[2] = -1; kys[2] = 0; }
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      if (q >= nc) continue;
-      const int oh = ohs[q];
-      if (oh < 0 || oh >= OH) continue;
-      const int base = kys[q] * 3;
-      const size_t ro = (size_t)oh * OW + 2 * b;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        if (2 * b + c >= OW) continue;
-        const int kx = (int)ip[ro + c] - base;
-        const float v = dyp[ro + c];
-        if (c == 0) { if (kx == 1) g[0] += v; else if (kx == 2) g[1] += v; }
-        else if (c == 1) { if (kx == 0) g[1] += v; else if (kx == 1) g[2] += v; else if (kx == 2) g[3] += v; }
-        else { if (kx == 0) g[3] += v; }
-      }
+    const float* xp = x + (size_t)pl * H * W;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < H * W4; i += 256) {
+      const int b = i % W4, ih = i / W4;
+      float g[4];
+      pool3_bwd_gather<SH>(dyp, ip, ih, b, OH, OW, g);
+      const float4 xv = *reinterpret_cast<const float4*>(xp + (size_t)ih * W + 4 * b);
+      acc += (double)((g[0] * xv.x + g[1] * xv.y) + (g[2] * xv.z + g[3] * xv.w));
     }
-    if (xs) { const float s = xs[pl]; g[0] *= s; g[1] *= s; g[2] *= s; g[3] *= s; }
-    *reinterpret_cast<float4*>(dx + ((size_t)pl * H + ih) * W + 4 * b) = make_float4(g[0], g[1], g[2], g[3]);
+    const double r = block_sum_d(acc, sm);
+    if (threadIdx.x == 0) ds[pl] = (float)r;
   }
 }
 
@@ -263,9 +299,31 @@ extern "C" int dlio_maxpool2d_fwd(const float* x, const float* x_scale, float* y
   return dlio_check_launch();
 }
 
+static bool pool_fast(int H, int W, int OH, int OW, int K, int SH, int SW, int PH, int PW) {
+  return K == 3 && SW == 2 && PH == 1 && PW == 1 && (SH == 1 || SH == 2) && (W & 3) == 0 && OW * 2 == W &&
+         OH == (H + 2 - 3) / SH + 1;
+}
+
+extern "C" int dlio_maxpool2d_bwd_dot(const float* dy, const uint8_t* idx, const float* x, float* ds,
+                                      int N, int C, int H, int W, int OH, int OW, int K, int SH,
+                                      int SW, int PH, int PW, dlio_stream_t stream) {
+  if (!dy || !idx || !x || !ds || N <= 0 || C <= 0) return DLIO_EINVAL;
+  if (!pool_fast(H, W, OH, OW, K, SH, SW, PH, PW)) return DLIO_EUNSUP;
+  int grid = N * C;
+  if (grid > 65535) grid = 65535;
+  if (SH == 1)
+    hipLaunchKernelGGL(maxpool3_bwd_dot_sw2<1>, dim3(grid), dim3(256), 0, as_stream(stream), dy, idx, x,
+                       ds, N * C, H, W, OH, OW);
+  else
+    hipLaunchKernelGGL(maxpool3_bwd_dot_sw2<2>, dim3(grid), dim3(256), 0, as_stream(stream), dy, idx, x,
+                       ds, N * C, H, W, OH, OW);
+  return dlio_check_launch();
+}
+
 extern "C" int dlio_maxpool2d_bwd(const float* dy, const uint8_t* idx, const float* x_scale,
-                                  float* dx, int N, int C, int H, int W, int OH, int OW, int K,
-                                  int SH, int SW, int PH, int PW, dlio_stream_t stream) {
+                                  const float* x_add, float* dx, int N, int C, int H, int W, int OH,
+                                  int OW, int K, int SH, int SW, int PH, int PW,
+                                  dlio_stream_t stream) {
   if (!dy || !idx || !dx || N <= 0 || C <= 0 || K <= 0) return DLIO_EINVAL;
   const int64_t total = (int64_t)N * C * H * W;
   if (K == 3 && SW == 2 && PH == 1 && PW == 1 && (SH == 1 || SH == 2) && (W & 3) == 0 && OW * 2 == W &&
@@ -273,12 +331,13 @@ extern "C" int dlio_maxpool2d_bwd(const float* dy, const uint8_t* idx, const flo
     const int64_t work = total / 4;
     if (SH == 1)
       hipLaunchKernelGGL(maxpool3_bwd_sw2<1>, dim3(ew_grid(work, 256)), dim3(256), 0, as_stream(stream),
-                         dy, idx, x_scale, dx, (int64_t)N * C, H, W, OH, OW);
+                         dy, idx, x_scale, x_add, dx, (int64_t)N * C, H, W, OH, OW);
     else
       hipLaunchKernelGGL(maxpool3_bwd_sw2<2>, dim3(ew_grid(work, 256)), dim3(256), 0, as_stream(stream),
-                         dy, idx, x_scale, dx, (int64_t)N * C, H, W, OH, OW);
+                         dy, idx, x_scale, x_add, dx, (int64_t)N * C, H, W, OH, OW);
     return dlio_check_launch();
   }
+  if (x_add) return DLIO_EUNSUP;   // the fused add exists on the 3x3 / stride-(.,2) fast path only
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(total, 256)), dim3(256), 0,
                      as_stream(stream), dy, idx, x_scale, dx, N, C, H, W, OH, OW, K, SH, SW, PH, PW);
   return dlio_check_launch();

@@ -254,12 +254,19 @@ class SEPoolFn(Function):
         x, w1, w2, g, h, s, idx = ctx.saved_tensors
         N, C_, H, W = x.shape
         dy = dy.contiguous()
+        fused = False
         if ctx.pool is None:
-            dxs = dy
+            dx, ds = ops.chan_scale_bwd(dy, x, s)
         else:
             k, stride, pad = ctx.pool
-            dxs = ops.maxpool2d_bwd(dy, idx, tuple(x.shape), k, stride[0], stride[1], pad[0], pad[1])
-        dx, ds = ops.chan_scale_bwd(dxs, x, s)
+            fused = ops.pool_fast_path(H, W, dy.shape[2], dy.shape[3], k, stride[0], stride[1], pad[0], pad[1])
+            if fused:
+                # two passes over the full-resolution tensor instead of six: ds from (dy, idx, x) with
+                # the pooled gradient recomputed on the fly; dx written once at the end
+                ds = ops.maxpool2d_bwd_dot(dy, idx, x, k, stride[0], stride[1], pad[0], pad[1])
+            else:
+                dxs = ops.maxpool2d_bwd(dy, idx, tuple(x.shape), k, stride[0], stride[1], pad[0], pad[1])
+                dx, ds = ops.chan_scale_bwd(dxs, x, s)
         dz2 = ops.act_bwd(ds, s, ops.ACT_SIGMOID)
         dw2, acc2, ret2 = _sink(w2, w2.shape, dy)
         ops.linear_bwd_weight(dz2, h, N, w2.shape[0], w2.shape[1], dw=dw2, want_bias=False, accumulate=acc2)
@@ -268,7 +275,12 @@ class SEPoolFn(Function):
         dw1, acc1, ret1 = _sink(w1, w1.shape, dy)
         ops.linear_bwd_weight(dz1, g, N, w1.shape[0], w1.shape[1], dw=dw1, want_bias=False, accumulate=acc1)
         dg = ops.linear_bwd_data(dz1, w1, N)
-        ops.gap_bwd(dg, dx, N, C_, H * W, accumulate=True)
+        if fused:
+            k, stride, pad = ctx.pool
+            dx = ops.maxpool2d_bwd(dy, idx, tuple(x.shape), k, stride[0], stride[1], pad[0], pad[1],
+                                   x_scale=s, x_add=ops.ew_scale(dg, 1.0 / (H * W)))
+        else:
+            ops.gap_bwd(dg, dx, N, C_, H * W, accumulate=True)
         return dx, ret1, ret2, None
 
 

@@ -200,13 +200,28 @@ def maxpool2d_fwd(x, k, sh, sw, ph, pw, ceil_mode=False, x_scale=None, want_idx=
     return y, idx
 
 
-def maxpool2d_bwd(dy, idx, in_shape, k, sh, sw, ph, pw, x_scale=None):
+def maxpool2d_bwd(dy, idx, in_shape, k, sh, sw, ph, pw, x_scale=None, x_add=None):
     N, C_, H, W = in_shape
     OH, OW = dy.shape[2], dy.shape[3]
     dx = torch.empty(N, C_, H, W, dtype=torch.float32, device=dy.device)
-    check(lib.dlio_maxpool2d_bwd(_ptr(dy), _ptr(idx), _ptr(x_scale), _ptr(dx), N, C_, H, W, OH, OW,
-                                 k, sh, sw, ph, pw, _stream()), "maxpool2d_bwd")
+    check(lib.dlio_maxpool2d_bwd(_ptr(dy), _ptr(idx), _ptr(x_scale), _ptr(x_add), _ptr(dx), N, C_, H, W,
+                                 OH, OW, k, sh, sw, ph, pw, _stream()), "maxpool2d_bwd")
     return dx
+
+
+def pool_fast_path(H, W, OH, OW, k, sh, sw, ph, pw):
+    return (k == 3 and sw == 2 and ph == 1 and pw == 1 and sh in (1, 2) and W % 4 == 0 and OW * 2 == W
+            and OH == (H + 2 - 3) // sh + 1)
+
+
+def maxpool2d_bwd_dot(dy, idx, x, k, sh, sw, ph, pw):
+    """ds[n][c] = sum_hw scatter(dy) * x (fast-path shapes)"""
+    N, C_, H, W = x.shape
+    OH, OW = dy.shape[2], dy.shape[3]
+    ds = torch.empty(N, C_, dtype=torch.float32, device=dy.device)
+    check(lib.dlio_maxpool2d_bwd_dot(_ptr(dy), _ptr(idx), _ptr(x), _ptr(ds), N, C_, H, W, OH, OW, k, sh,
+                                     sw, ph, pw, _stream()), "maxpool2d_bwd_dot")
+    return ds
 
 
 def gap_fwd(x, N, ctot, coff, C_, HW):

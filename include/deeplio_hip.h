@@ -156,9 +156,16 @@ int dlio_chan_sum(const float* x, int N, int ctot, int coff, int C, int HW, floa
 int dlio_maxpool2d_fwd(const float* x, const float* x_scale, float* y, uint8_t* idx,
                        int N, int C, int H, int W, int OH, int OW, int K, int SH, int SW,
                        int PH, int PW, dlio_stream_t stream);
-int dlio_maxpool2d_bwd(const float* dy, const uint8_t* idx, const float* x_scale, float* dx,
-                       int N, int C, int H, int W, int OH, int OW, int K, int SH, int SW,
-                       int PH, int PW, dlio_stream_t stream);
+/* dx = scatter(dy) * x_scale[n][c] + x_add[n][c]; x_scale / x_add nullable (x_add only on the
+ * 3x3, pad 1, stride (1|2, 2) fast path: SELayer + pool backward in one pass) */
+int dlio_maxpool2d_bwd(const float* dy, const uint8_t* idx, const float* x_scale,
+                       const float* x_add, float* dx, int N, int C, int H, int W, int OH, int OW,
+                       int K, int SH, int SW, int PH, int PW, dlio_stream_t stream);
+/* ds[n][c] = sum_hw scatter(dy) * x  without materialising scatter(dy) (fast-path shapes only,
+ * DLIO_EUNSUP otherwise) */
+int dlio_maxpool2d_bwd_dot(const float* dy, const uint8_t* idx, const float* x, float* ds, int N,
+                           int C, int H, int W, int OH, int OW, int K, int SH, int SW, int PH,
+                           int PW, dlio_stream_t stream);
 /* out[n][c] = mean over HW of channel slice */
 int dlio_gap_fwd(const float* x, int ctot, int coff, float* out, int N, int C, int HW,
                  dlio_stream_t stream);
