@@ -564,6 +564,7 @@ extern "C" int dlio_conv2d_fwd(const float* x, const float* wt, const float* bia
                                    (residual ? 2.0 : 1.0));
   dlio_prof_begin(0, s, flops, bytes);
   int rc = DLIO_EUNSUP;
+  static const int ck8 = getenv("DLIO_CONV_CK8") ? atoi(getenv("DLIO_CONV_CK8")) : 1;   // tuning knob
 #define CONV_CASE(kh, kw, sh, sw, ck)                                                        \
   if (d.KH == kh && d.KW == kw && d.SH == sh && d.SW == sw)                                  \
     rc = launch_tw<kh, kw, sh, sw, ck>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
@@ -574,6 +575,8 @@ extern "C" int dlio_conv2d_fwd(const float* x, const float* wt, const float* bia
     else rc = launch_1x1_nr<2>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
   }
   else CONV_CASE(1, 1, 1, 1, 16)
+  else if (d.KH == 3 && d.KW == 3 && d.SH == 1 && d.SW == 1 && ck8 && d.Cin <= 16)
+    rc = launch_tw<3, 3, 1, 1, 8>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
   else CONV_CASE(3, 3, 1, 1, 16)
   else CONV_CASE(3, 5, 1, 2, 4)
   else CONV_CASE(3, 5, 1, 1, 8)

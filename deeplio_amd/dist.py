@@ -60,6 +60,9 @@ class GradSync:
 
     def all_reduce_grads(self):
         if self.world > 1:
+            if self.flat_grad.is_cuda:
+                from .functional import join_aux_streams
+                join_aux_streams()      # weight gradients are produced on auxiliary HIP streams
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
 
     def max_over_ranks(self, value):

@@ -8,6 +8,7 @@ torch.nn.Conv2d / BatchNorm2d / Linear instances below are PARAMETER CONTAINERS 
 give the reference's names, shapes and default initialisers); their forward is never called.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -330,14 +331,34 @@ class BaseLidarFeatNet(BaseNet):
         nfeat = self.encoder1.out_channels * (2 if self.fusion == 'cat' else 1)
         self.fc1 = nn.Linear(nfeat, 128)
         self.output_shape = torch.Size([1, self.seq_size, 128])
+        self.two_streams = os.environ.get("DLIO_TWO_STREAMS", "1") != "0"
+        self._side = None
 
     def forward(self, x):
         xyz, nrm = x[0], x[1]
         b, s, t, c, h, w = xyz.shape
-        fa = self.encoder1(xyz.reshape(b * s, t * c, h, w))
-        fb = self.encoder2(nrm.reshape(b * s, t * c, h, w))
-        if fa.dim() == 4:
-            fa, fb = Fh.GapFn.apply(fa), Fh.GapFn.apply(fb)
+        xa, xb = xyz.reshape(b * s, t * c, h, w), nrm.reshape(b * s, t * c, h, w)
+        if xyz.is_cuda and self.two_streams:
+            # The two encoders are independent until the feature fusion: run the normals stream
+            # on a second HIP stream so that its HBM-bound kernels (BN, pools) overlap the
+            # MFMA-bound convolutions of the xyz stream and small layers fill idle CUs.
+            if self._side is None:
+                self._side = Fh.aux_stream(xyz.device, "encoder2")
+            main = torch.cuda.current_stream()
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                fb = self.encoder2(xb)
+                if fb.dim() == 4:
+                    fb = Fh.GapFn.apply(fb)
+            fa = self.encoder1(xa)
+            if fa.dim() == 4:
+                fa = Fh.GapFn.apply(fa)
+            main.wait_stream(self._side)
+            fb.record_stream(main)
+        else:
+            fa, fb = self.encoder1(xa), self.encoder2(xb)
+            if fa.dim() == 4:
+                fa, fb = Fh.GapFn.apply(fa), Fh.GapFn.apply(fb)
         if self.fusion == 'cat':
             y = Fh.Cat2Fn.apply(fa, fb)
         else:
@@ -607,20 +628,21 @@ class DeepLIO(BaseNet):
         if (self.lidar_feat_net is not None and self.imu_feat_net is not None and torch.is_tensor(imu_meas)
                 and imu_meas.is_cuda and self.side_stream):
             if self._side is None:
-                self._side = torch.cuda.Stream(device=imu_meas.device)
+                self._side = Fh.aux_stream(imu_meas.device, "imu")
             side = self._side
             main = torch.cuda.current_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 feat_i = self.imu_feat_net(imu_meas)
+        elif self.imu_feat_net is not None:     # same issue order (dropout counter) as the overlapped path
+            feat_i = self.imu_feat_net(imu_meas)
         if self.lidar_feat_net is not None:
             last = feat_l = self.lidar_feat_net(lidar_imgs)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
             feat_i.record_stream(torch.cuda.current_stream())
+        if feat_i is not None:
             last = feat_i
-        elif self.imu_feat_net is not None:
-            last = feat_i = self.imu_feat_net(imu_meas)
         if self.fusion_net is not None:
             last = self.fusion_net([feat_l, feat_i])
         if self.odom_feat_net is not None:

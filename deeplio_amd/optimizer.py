@@ -10,6 +10,13 @@ from . import ops
 ALIGN = 16  # floats (64 B): every parameter view stays float4-aligned
 
 
+def _join():
+    """gradients are accumulated on auxiliary HIP streams (functional.aux_stream): the stream the
+    step runs on must wait for them"""
+    from .functional import join_aux_streams
+    join_aux_streams()
+
+
 class FlatOptimizer:
     def __init__(self, params, lr, weight_decay):
         groups = list(params)
@@ -91,6 +98,7 @@ class Adam(FlatOptimizer):
 
     @torch.no_grad()
     def step(self):
+        _join()
         lr, wd = self._hyper()
         self.step_count += 1
         ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, lr, self.betas[0],
@@ -108,6 +116,7 @@ class SGD(FlatOptimizer):
 
     @torch.no_grad()
     def step(self):
+        _join()
         lr, wd = self._hyper()
         self.step_count += 1
         ops.sgd_step(self.flat, self.grad, self.buf, lr, self.momentum, wd, self.step_count,

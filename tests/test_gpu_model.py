@@ -186,3 +186,43 @@ def test_headline_shapes_smoke(dev):
         opt.step()
         vals.append(float(loss.item()))
     assert all(np.isfinite(vals)) and vals[-1] < vals[0], vals
+
+
+def test_stream_overlap_is_bit_exact(dev):
+    """The IMU branch, the normals encoder and all weight-gradient kernels run on side HIP streams.  Every kernel on the path
+    is deterministic (fixed-order split reductions, no float atomics), so overlapping them must
+    not change a single bit of the outputs, the loss or any gradient -- a race would."""
+    from deeplio_amd import losses, misc, nets
+    from deeplio_amd.config import make_config
+    cfg = make_config(seq=2)
+    misc.build_config_container(cfg, types.SimpleNamespace(device=str(dev), batch_size=2))
+    batch = tuple(t.to(dev) for t in gc.make_batch(11, 2, 2, 5, 64, 512, 50))
+    res = []
+    for overlap in (True, False, True):
+        model = nets.get_model((5, 64, 512), cfg, dev)
+        gc.fill_state(model, seed=1000)
+        crit = losses.get_loss_function(cfg, dev)
+        model.train()
+        for m in model.modules():
+            if hasattr(m, "two_streams"):
+                m.two_streams = overlap
+            if hasattr(m, "side_stream"):
+                m.side_stream = overlap
+        from deeplio_amd import functional as Fh
+        Fh.manual_seed(5)
+        Fh.set_wgrad_stream(overlap)     # optional fork of the weight-gradient kernels
+        outs = []
+        for _ in range(2):
+            model.zero_grad()
+            pt, pw, pp, pq, loss = hip_step_forward(model, crit, batch)
+            loss.backward()
+            torch.cuda.synchronize()
+            outs.append([loss.detach().clone(), pt.detach().clone()]
+                        + [p.grad.detach().clone() for p in model.parameters() if p.grad is not None])
+        res.append(outs)
+    Fh.set_wgrad_stream(False)
+    for other in res[1:]:
+        for a_step, b_step in zip(res[0], other):
+            assert len(a_step) == len(b_step)
+            for a, b in zip(a_step, b_step):
+                assert torch.equal(a, b)
