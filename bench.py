@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (BASELINE: 8)")
     ap.add_argument("--seq", type=int, default=2, help="frame pairs per sample (S)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=1)
+    ap.add_argument("--cpu-batch", type=int, default=4, help="samples per CPU-baseline step (bounded sample)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-isolated", action="store_true", help="skip the non-overlapped roofline pass")
     ap.add_argument("--iso-steps", type=int, default=3)
@@ -198,6 +198,23 @@ def main():
                     "other": {kinds[k]: {"TFLOP/s": round(tfl(v), 2),
                                          "ms_per_step": round(v["ms"] / args.steps, 3)}
                               for k, v in prof.items() if k != dom}}
+        # PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction of
+        # the guide applied): collected by tools/pmc_traffic.py, committed under profiles/
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc) and B == 8 and S == 2:
+            with open(pmc) as f:
+                t = json.load(f).get({0: "conv2d_fwd_mfma", 1: "conv2d_wgrad_mfma"}[dom])
+            if t:
+                roofline["traffic"] = round(t["hbm_bytes_per_step_corrected"] / (p["launches"] / args.steps))
+                roofline["traffic_unit"] = "HBM bytes per launch (avg), from profiles/r01_pmc_traffic.json"
+        # whole-step view on SURVEY 8(d)'s algorithmic figures: 3 x (36.13 GF conv + 0.124 GF RNN) and
+        # 3 x 957 MB per frame pair
+        pairs_per_s = value
+        roofline["step"] = {
+            "mfma": {"achieved": round(pairs_per_s * 3 * 36.254e9 / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(pairs_per_s * 3 * 36.254e9 / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+            "hbm": {"achieved": round(pairs_per_s * 3 * 957e6 / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(pairs_per_s * 3 * 957e6 / 1e9 / 8000.0, 4)}}
         if prof_iso is not None:
             q = prof_iso[dom]
             roofline["isolated"] = {
