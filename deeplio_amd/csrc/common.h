@@ -63,6 +63,10 @@ __device__ __forceinline__ double block_sum_d(double v, double* smem /* >= 16 do
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// compute units of the current device (cached; 256 on MI355X, also the answer without a device
+// so that workspace queries work on a build host)
+int dlio_num_cus();
+
 // profiling hooks (prof.hip)
 void dlio_prof_begin(int kind, hipStream_t s, double flops, double bytes);
 void dlio_prof_end(int kind, hipStream_t s);

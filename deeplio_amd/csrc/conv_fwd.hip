@@ -55,6 +55,10 @@ __device__ __forceinline__ void store_tiles(f32x16 (&acc)[MR][NR], const float* 
     }
 }
 
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
 template <int KH, int KW, int SH, int SW, int CK, int TWN, int MR>
 struct ConvCfg {
   static constexpr int TH = 4;                  // output rows per block (one per wave)
@@ -74,8 +78,8 @@ struct ConvCfg {
 // (all four waves of a block read the same [k][co] rows), then the registers are written to
 // buffer (i+1)&1 and ONE barrier closes the iteration.  A thread owns the same NPOS patch
 // positions for every channel, so the per-element index arithmetic is done once per block.
-template <int KH, int KW, int SH, int SW, int CK, int TWN, int MR>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(
+template <int KH, int KW, int SH, int SW, int CK, int TWN, int MR, bool AFF>
+__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
     const float* __restrict__ in_mean, const float* __restrict__ in_scale,
     const float* __restrict__ in_shift, const float* residual, float* y, DlioConvDesc d,
@@ -124,31 +128,46 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(
     poff[j] = pval[j] ? ih * d.W + iw : 0;
   }
   const float* xn = x + ((size_t)n * d.in_ctot + d.in_coff) * HW;
-  const bool has_aff = in_scale != nullptr;
+  const size_t xbytes = (size_t)Cin * HW * 4;
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(xn), 0, xbytes > 0xffffffffull ? -1 : (int)xbytes, 0x00020000);
   // clamped weight columns (rows >= Cout are dropped at the store)
-  int cc[MR];
+  unsigned loff[MR];
 #pragma unroll
-  for (int m = 0; m < MR; ++m) cc[m] = min(co0 + m * 32 + l31, Cout - 1);
+  for (int m = 0; m < MR; ++m) loff[m] = 4u * (unsigned)(half * Cout + min(co0 + m * 32 + l31, Cout - 1));
+  const int KP = (Cin + 15) & ~15;
+  // buffer descriptors: per-lane 32-bit voffset + scalar soffset, no 64-bit vector addresses
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(wt), 0, (int)((size_t)KH * KW * KP * Cout * 4), 0x00020000);
 
   float reg[CK][C::NPOS];
+  // branch-free: invalid positions read element 0 of a valid plane and are zeroed by a select
   auto load_chunk = [&](int c0) {
 #pragma unroll
     for (int c = 0; c < CK; ++c) {
       const int ci = c0 + c;
       const bool cv = ci < Cin;
-      const float* xc = xn + (size_t)(cv ? ci : 0) * HW;
+      const unsigned coff = (unsigned)(cv ? ci : 0) * (unsigned)HW * 4u;   // uniform
 #pragma unroll
-      for (int j = 0; j < C::NPOS; ++j) {
-        float v = 0.f;
-        if (cv && pval[j]) {
-          v = xc[poff[j]];
-          if (has_aff) {
-            v = (v - in_mean[ci]) * in_scale[ci] + in_shift[ci];
-            if (d.in_relu) v = fmaxf(v, 0.f);
-          }
+      for (int j = 0; j < C::NPOS; ++j) reg[c][j] = buf_load(xrsrc, (unsigned)poff[j] * 4u, coff);
+    }
+    if constexpr (AFF) {
+#pragma unroll
+      for (int c = 0; c < CK; ++c) {
+        const int ci = min(c0 + c, Cin - 1);
+        const float mu = in_mean[ci], sc = in_scale[ci], sh = in_shift[ci];
+#pragma unroll
+        for (int j = 0; j < C::NPOS; ++j) {
+          float v = (reg[c][j] - mu) * sc + sh;
+          reg[c][j] = d.in_relu ? fmaxf(v, 0.f) : v;
         }
-        reg[c][j] = v;
       }
+    }
+#pragma unroll
+    for (int c = 0; c < CK; ++c) {
+      const bool cv = c0 + c < Cin;
+#pragma unroll
+      for (int j = 0; j < C::NPOS; ++j) reg[c][j] = (cv && pval[j]) ? reg[c][j] : 0.f;
     }
   };
   auto store_chunk = [&](float* Xl) {
@@ -160,37 +179,54 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(
         if (pos < C::PLANE) Xl[c * C::PLANE + pos] = reg[c][j];
       }
   };
-  // weight operands of one tap (CK/2 k-steps x MR tiles), fetched one tap ahead of their MFMAs
+  // weight operands of one tap (CK/2 k-steps x MR tiles), fetched one tap ahead of their MFMAs.
+  // Prepped weights are [tap][KP][Cout] with KP = Cin rounded up to 16 and zero rows behind Cin,
+  // so no clamping: address = uniform (SGPR) row base + per-lane 32-bit byte offset.
   float aw[2][CK / 2][MR];
   auto load_tap = [&](int tap, int c0, int s) {
+    const unsigned tap_off = (unsigned)((tap * KP + c0) * Cout) * 4u;     // uniform -> SGPR soffset
 #pragma unroll
-    for (int c2 = 0; c2 < CK; c2 += 2) {
-      // channels past Cin are zero in LDS, so a clamped (finite) weight is enough
-      const int ci = min(c0 + c2 + half, Cin - 1);
-      const float* wrow = wt + ((size_t)tap * Cin + ci) * Cout;
+    for (int c2 = 0; c2 < CK; c2 += 2)
 #pragma unroll
-      for (int m = 0; m < MR; ++m) aw[s][c2 / 2][m] = wrow[cc[m]];
-    }
+      for (int m = 0; m < MR; ++m)
+        aw[s][c2 / 2][m] = buf_load(wrsrc, loff[m], tap_off + (unsigned)(c2 * Cout) * 4u);
+  };
+  // k-steps of a chunk in issue order: step = tap * CK/2 + c2/2.  The LDS operand of step s+1
+  // is read before the MFMAs of step s (register double buffer), so the ~100-cycle LDS latency
+  // overlaps 4 MFMAs instead of stalling in front of them.
+  constexpr int KS = CK / 2, NSTEP = KH * KW * KS;
+  auto load_b = [&](const float* Xl, int step, float (&b)[C::NR]) {
+    const int tap = step / KS, c = (step % KS) * 2 + half;
+    const int dy = tap / KW, dx = tap % KW;
+    const float* xrow = Xl + (wave * SH + dy) * C::PC + dx + l31 * SW;
+#pragma unroll
+    for (int q = 0; q < C::NR; ++q) b[q] = xrow[c * C::PLANE + q * 32 * SW];
   };
   auto mfma_chunk = [&](const float* Xl, int c0) {
+    float b[2][C::NR];
     load_tap(0, c0, 0);
+    load_b(Xl, 0, b[0]);
 #pragma unroll
     for (int tap = 0; tap < KH * KW; ++tap) {
-      const int dy = tap / KW, dx = tap % KW;
       if (tap + 1 < KH * KW) load_tap(tap + 1, c0, (tap + 1) & 1);
-      const float* xrow = Xl + (wave * SH + dy) * C::PC + dx + l31 * SW;
 #pragma unroll
-      for (int c2 = 0; c2 < CK; c2 += 2) {
-        const int c = c2 + half;
-        float b[C::NR];
-#pragma unroll
-        for (int q = 0; q < C::NR; ++q) b[q] = xrow[c * C::PLANE + q * 32 * SW];
+      for (int k = 0; k < KS; ++k) {
+        const int step = tap * KS + k;
+        if (step + 1 < NSTEP) load_b(Xl, step + 1, b[(step + 1) & 1]);
 #pragma unroll
         for (int m = 0; m < MR; ++m)
 #pragma unroll
           for (int q = 0; q < C::NR; ++q)
-            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[tap & 1][c2 / 2][m], b[q], acc[m][q], 0, 0, 0);
+            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[tap & 1][k][m], b[step & 1][q], acc[m][q], 0, 0, 0);
+        // issue order inside the tap: next step's LDS operand, this step's share of the next
+        // tap's weight loads, then this step's MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, MR, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, MR * C::NR, 0);
       }
+      // keep the scheduler from hoisting every tap's weight loads to the top of the chunk
+      // (245+ VGPRs, one wave per SIMD): exactly one tap of prefetch stays in flight
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -219,7 +255,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(
   store_tiles<MR, C::NR>(acc, bias, residual, y, d, n, co0, half, pv, pix, (size_t)d.OH * d.OW);
 }
 
-template <int KH, int KW, int SH, int SW, int CK, int TWN, int MR>
+template <int KH, int KW, int SH, int SW, int CK, int TWN, int MR, bool AFF = false>
 int launch(const float* x, const float* wt, const float* bias, const float* in_mean,
            const float* in_scale, const float* in_shift, const float* residual, float* y,
            const DlioConvDesc& d, hipStream_t s) {
@@ -228,7 +264,7 @@ int launch(const float* x, const float* wt, const float* bias, const float* in_m
   const int co_tiles = cdiv(d.Cout, C::CO_T);
   const int64_t blocks = (int64_t)tiles_w * tiles_h * co_tiles * d.N;
   if (blocks <= 0 || blocks > 0x7fffffff) return DLIO_EINVAL;
-  auto kern = conv_fwd_kernel<KH, KW, SH, SW, CK, TWN, MR>;
+  auto kern = conv_fwd_kernel<KH, KW, SH, SW, CK, TWN, MR, AFF>;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -246,6 +282,9 @@ template <int KH, int KW, int SH, int SW, int CK>
 int launch_tw(const float* x, const float* wt, const float* bias, const float* in_mean,
               const float* in_scale, const float* in_shift, const float* residual, float* y,
               const DlioConvDesc& d, hipStream_t s) {
+  // fused producer-affine on load (not on the headline path): one small-tile instantiation
+  if (in_scale)
+    return launch<KH, KW, SH, SW, CK, 1, 1, true>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
   const int twn = d.OW > 32 ? 2 : 1;
   const int64_t blocks2 = (int64_t)cdiv(d.OW, 32 * twn) * cdiv(d.OH, 4) * cdiv(d.Cout, 64) * d.N;
   static const int force_mr = getenv("DLIO_CONV_MR") ? atoi(getenv("DLIO_CONV_MR")) : 0;   // tuning knob
@@ -515,32 +554,39 @@ int launch_1x1_nr(const float* x, const float* wt, const float* bias, const floa
   return launch_1x1<MR, 1>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
 }
 
+// wt[tap][k][n], k padded with zero rows to KP = roundup(K, 16)
 __global__ void prep_weight_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout,
                                    int Cin, int taps, int mode) {
-  const int64_t total = (int64_t)Cout * Cin * taps;
+  const int K = mode == 0 ? Cin : Cout, Nn = mode == 0 ? Cout : Cin;
+  const int KPAD = (K + 15) & ~15;
+  const int64_t total = (int64_t)taps * KPAD * Nn;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
-    if (mode == 0) {  // wt[tap][ci][co] = w[co][ci][tap]
-      const int co = i % Cout;
-      const int ci = (i / Cout) % Cin;
-      const int tap = i / ((int64_t)Cout * Cin);
-      wt[i] = w[((int64_t)co * Cin + ci) * taps + tap];
-    } else {          // wt[tap'][co][ci] = w[co][ci][taps-1-tap']
-      const int ci = i % Cin;
-      const int co = (i / Cin) % Cout;
-      const int tap = i / ((int64_t)Cout * Cin);
-      wt[i] = w[((int64_t)co * Cin + ci) * taps + (taps - 1 - tap)];
+    const int nn = i % Nn;
+    const int k = (i / Nn) % KPAD;
+    const int tap = i / ((int64_t)Nn * KPAD);
+    float v = 0.f;
+    if (k < K) {
+      if (mode == 0) v = w[((int64_t)nn * Cin + k) * taps + tap];              // k = ci, n = co
+      else v = w[((int64_t)k * Cin + nn) * taps + (taps - 1 - tap)];           // k = co, n = ci
     }
+    wt[i] = v;
   }
 }
 
 }  // namespace
 
+extern "C" size_t dlio_conv2d_prep_weight_floats(int Cout, int Cin, int KH, int KW, int mode) {
+  if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || (mode != 0 && mode != 1)) return 0;
+  const int K = mode == 0 ? Cin : Cout, Nn = mode == 0 ? Cout : Cin;
+  return (size_t)KH * KW * ((K + 15) & ~15) * Nn;
+}
+
 extern "C" int dlio_conv2d_prep_weight(const float* w, float* wt, int Cout, int Cin, int KH,
                                        int KW, int mode, dlio_stream_t stream) {
   if (!w || !wt || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || (mode != 0 && mode != 1))
     return DLIO_EINVAL;
-  const int64_t total = (int64_t)Cout * Cin * KH * KW;
+  const int64_t total = (int64_t)dlio_conv2d_prep_weight_floats(Cout, Cin, KH, KW, mode);
   hipLaunchKernelGGL(prep_weight_kernel, dim3(ew_grid(total, 256)), dim3(256), 0,
                      as_stream(stream), w, wt, Cout, Cin, KH * KW, mode);
   return dlio_check_launch();

@@ -293,6 +293,142 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   }
 }
 
+// ---- 1x1 stride-1 weight gradient straight from global memory -------------------------------
+// dW[co][ci] = sum_px dY[co][px] * X[ci][px]: both operands are [channel][pixel] rows, so a lane
+// (channel l&31, half l>>5) reads 16 consecutive pixels of its row as 4 float4 (a wave covers 128
+// contiguous bytes of 32 rows) and feeds them to 16 MFMA k-steps -- which pixel sits in which
+// k slot is irrelevant as long as A and B agree.  No LDS staging and no barriers in the loop: each
+// wave strides over 32-pixel segments on its own with a register double buffer, two workgroups
+// per CU keep ~128 KB of loads in flight (the LDS-staged kernel above manages ~40 KB for these
+// layers, which are HBM-bound).  Partial sums: 4 waves through LDS, then the slab reduction.
+__device__ __forceinline__ float f4e(const float4& v, int i) {
+  return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
+}
+
+template <int MR, int NT>
+__global__ __launch_bounds__(256, 2) void wgrad1x1_direct_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ wsp,
+    DlioConvDesc d, int co_tiles, int ci_chunks, int splits, int segs_per_img) {
+  __shared__ float red[MR * NT * 16 * 64];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l31 = lane & 31;
+  const int half = lane >> 5;
+
+  int bid = blockIdx.x;
+  const int split = bid % splits; bid /= splits;
+  const int cic = bid % ci_chunks; bid /= ci_chunks;
+  const int co0 = bid * 32 * MR;
+  const int c0 = cic * 32 * NT;
+  const size_t hw = (size_t)d.H * d.W;
+
+  const float* arow[MR];
+  const float* brow[NT];
+  bool va[MR], vb[NT];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    const int co = co0 + m * 32 + l31;
+    va[m] = co < d.Cout;
+    arow[m] = dy + ((size_t)d.out_coff + (va[m] ? co : 0)) * hw + half * 16;
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int ci = c0 + t * 32 + l31;
+    vb[t] = ci < d.Cin;
+    brow[t] = x + ((size_t)d.in_coff + (vb[t] ? ci : 0)) * hw + half * 16;
+  }
+  const size_t a_img = (size_t)d.out_ctot * hw, b_img = (size_t)d.in_ctot * hw;
+
+  f32x16 acc[MR][NT];
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+
+  float4 a0[MR][4], b0[NT][4], a1[MR][4], b1[NT][4];
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int m = 0; m < MR; ++m) a0[m][q] = a1[m][q] = z4;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) b0[t][q] = b1[t][q] = z4;
+  }
+  auto load = [&](float4 (&a)[MR][4], float4 (&b)[NT][4], int g) {
+    const int n = g / segs_per_img;
+    const size_t o = (size_t)(g - n * segs_per_img) * 32;
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+      if (va[m]) {
+        const float4* p = reinterpret_cast<const float4*>(arow[m] + n * a_img + o);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[m][q] = p[q];
+      }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      if (vb[t]) {
+        const float4* p = reinterpret_cast<const float4*>(brow[t] + n * b_img + o);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[t][q] = p[q];
+      }
+  };
+  auto compute = [&](const float4 (&a)[MR][4], const float4 (&b)[NT][4]) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a[m][e >> 2], e & 3),
+                                                           f4e(b[t][e >> 2], e & 3), acc[m][t], 0, 0, 0);
+  };
+
+  const int total = d.N * segs_per_img;
+  const int stride = splits * 4;
+  int g = split * 4 + wave;
+  if (g < total) load(a0, b0, g);
+  while (g < total) {
+    const int g1 = g + stride;
+    if (g1 < total) load(a1, b1, g1);
+    compute(a0, b0);
+    if (g1 >= total) break;
+    const int g2 = g1 + stride;
+    if (g2 < total) load(a0, b0, g2);
+    compute(a1, b1);
+    g = g2;
+  }
+
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int i = ((m * NT + t) * 16 + r) * 64 + lane;
+            if (w == 0) red[i] = acc[m][t][r];
+            else red[i] += acc[m][t][r];
+          }
+    }
+    __syncthreads();
+  }
+  float* out = wsp + (size_t)split * d.Cout * d.Cin;
+  for (int idx = tid; idx < 32 * MR * 32 * NT; idx += 256) {
+    const int j = idx % (NT * 32);
+    const int col = idx / (NT * 32);
+    if (c0 + j >= d.Cin || co0 + col >= d.Cout) continue;
+    const int m = col >> 5, row = col & 31;
+    const int hf = (row >> 2) & 1;
+    const int r = (row & 3) + 4 * (row >> 3);
+    const int t = j >> 5, lj = j & 31;
+    out[(size_t)(co0 + col) * d.Cin + c0 + j] = red[((m * NT + t) * 16 + r) * 64 + hf * 32 + lj];
+  }
+}
+
 // dw[i] = sum over split slabs, in a fixed order: 4 waves each own every 4th slab of 64
 // consecutive elements (8 independent loads in flight), partials combined through LDS.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ wsp,
@@ -357,7 +493,9 @@ bool make_plan(const DlioConvDesc& d, WgPlan& p) {
   p.tiles_h = cdiv(d.OH, 4);
   const int64_t total_tiles = (int64_t)d.N * p.tiles_w * p.tiles_h;
   int64_t pairs = (int64_t)p.co_tiles * p.ci_chunks;
-  int64_t splits = cdiv64(512, pairs);   // one workgroup per CU -> two block waves
+  static const int tgt = getenv("DLIO_WGRAD_BLOCKS") ? atoi(getenv("DLIO_WGRAD_BLOCKS")) : 512;
+  // floor, not ceil: 2 workgroups per CU = 512 slots, a 513th block costs a whole extra round
+  int64_t splits = tgt / pairs > 0 ? tgt / pairs : 1;
   if (splits > total_tiles) splits = total_tiles;
   const size_t slab = (size_t)d.Cout * d.Cin * taps * 4;
   const size_t cap = (size_t)96 << 20;
@@ -406,11 +544,59 @@ int launch(const float* x, const float* dy, float* dw, const float* in_mean,
   return launch_mr<KH, KW, SH, SW, NT, 2>(x, dy, dw, in_mean, in_scale, in_shift, wsp, d, p, s);
 }
 
+
+// plan of the direct 1x1 kernel (geometry only; pointer alignment is checked at launch and the
+// staged kernel's workspace is never smaller, see dlio_conv2d_wgrad_ws_bytes)
+struct Wg1Plan { int mr, nt, co_tiles, ci_chunks, splits, segs; size_t ws_bytes; };
+
+bool make_plan_1x1(const DlioConvDesc& d, Wg1Plan& p) {
+  static const int off = getenv("DLIO_WGRAD_1X1_DIRECT") ? atoi(getenv("DLIO_WGRAD_1X1_DIRECT")) == 0 : 0;
+  if (off || d.KH != 1 || d.KW != 1 || d.SH != 1 || d.SW != 1 || d.PH || d.PW) return false;
+  const int64_t hw = (int64_t)d.H * d.W;
+  if (hw % 32 || d.OH != d.H || d.OW != d.W) return false;
+  p.mr = d.Cout <= 32 ? 1 : 2;
+  p.nt = d.Cin <= 32 ? 1 : 2;
+  p.co_tiles = cdiv(d.Cout, 32 * p.mr);
+  p.ci_chunks = cdiv(d.Cin, 32 * p.nt);
+  p.segs = (int)(hw / 32);
+  const int64_t total = (int64_t)d.N * p.segs;
+  const int64_t pairs = (int64_t)p.co_tiles * p.ci_chunks;
+  // measured (tools/conv_table.py, blocks 128..768): one workgroup per CU is the sweet spot, both
+  // fewer and more (320: a second, mostly empty round) are 15-50 % slower
+  static const int tgt = getenv("DLIO_WGRAD_1X1_BLOCKS") ? atoi(getenv("DLIO_WGRAD_1X1_BLOCKS")) : dlio_num_cus();
+  int64_t splits = tgt / pairs > 0 ? tgt / pairs : 1;
+  // every wave should stream at least MINSEG segments, or prologue + slab reduction dominate
+  static const int minseg = getenv("DLIO_WGRAD_1X1_MINSEG") ? atoi(getenv("DLIO_WGRAD_1X1_MINSEG")) : 2;
+  if (splits * 4 * minseg > total) splits = cdiv64(total, 4 * minseg);
+  const size_t slab = (size_t)d.Cout * d.Cin * 4;
+  const size_t cap = (size_t)96 << 20;
+  if (splits * slab > cap) splits = (int64_t)(cap / slab);
+  if (splits < 1) splits = 1;
+  p.splits = (int)splits;
+  p.ws_bytes = (size_t)p.splits * slab;
+  return true;
+}
+
+template <int MR, int NT>
+int launch_1x1(const float* x, const float* dy, float* dw, float* wsp, const DlioConvDesc& d,
+               const Wg1Plan& p, int accumulate, hipStream_t s) {
+  hipLaunchKernelGGL((wgrad1x1_direct_kernel<MR, NT>), dim3(p.co_tiles * p.ci_chunks * p.splits),
+                     dim3(256), 0, s, x, dy, wsp, d, p.co_tiles, p.ci_chunks, p.splits, p.segs);
+  int rc = dlio_check_launch();
+  if (rc) return rc;
+  const int64_t n = (int64_t)d.Cout * d.Cin;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(n, 64)), dim3(256), 0, s, wsp, dw, n,
+                     p.splits, accumulate);
+  return dlio_check_launch();
+}
+
 }  // namespace
 
 extern "C" size_t dlio_conv2d_wgrad_ws_bytes(const DlioConvDesc* d) {
   WgPlan p;
   if (!d || !make_plan(*d, p)) return 0;
+  Wg1Plan q;
+  if (make_plan_1x1(*d, q) && q.ws_bytes > p.ws_bytes) return q.ws_bytes;
   return p.ws_bytes;
 }
 
@@ -431,6 +617,16 @@ extern "C" int dlio_conv2d_wgrad(const float* x, const float* dy, float* dw,
   const double bytes = 4.0 * d.N * ((double)d.Cin * d.H * d.W + (double)d.Cout * d.OH * d.OW);
   dlio_prof_begin(1, s, flops, bytes);
   int rc = DLIO_EUNSUP;
+  Wg1Plan q;
+  if (!in_scale && make_plan_1x1(d, q) && ws_bytes >= q.ws_bytes &&
+      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0) {
+    if (q.mr == 1 && q.nt == 1) rc = launch_1x1<1, 1>(x, dy, dw, wsp, d, q, accumulate, s);
+    else if (q.mr == 1) rc = launch_1x1<1, 2>(x, dy, dw, wsp, d, q, accumulate, s);
+    else if (q.nt == 1) rc = launch_1x1<2, 1>(x, dy, dw, wsp, d, q, accumulate, s);
+    else rc = launch_1x1<2, 2>(x, dy, dw, wsp, d, q, accumulate, s);
+    dlio_prof_end(1, s);
+    return rc;
+  }
 #define WG_CASE(kh, kw, sh, sw, nt)                                                \
   if (d.KH == kh && d.KW == kw && d.SH == sh && d.SW == sw)                        \
     rc = launch<kh, kw, sh, sw, nt>(x, dy, dw, in_mean, in_scale, in_shift, wsp, d, p, s);

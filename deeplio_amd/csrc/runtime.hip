@@ -74,6 +74,18 @@ extern "C" const char* dlio_last_hip_error_string(void) {
 }
 
 extern "C" int dlio_version(void) { return 100; }
+int dlio_num_cus() {
+  static int cached = 0;
+  if (cached > 0) return cached;
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) == hipSuccess &&
+      hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+    cached = n;
+  else
+    (void)hipGetLastError();
+  return cached > 0 ? cached : 256;
+}
+
 extern "C" const char* dlio_arch(void) { return "gfx950"; }
 extern "C" const char* dlio_strerror(int code) {
   switch (code) {

@@ -70,7 +70,8 @@ def conv2d_prep_weight(w, mode, out=None):
     _chk(w)
     Cout, Cin, KH, KW = w.shape
     if out is None:
-        out = torch.empty(KH * KW * Cin * Cout, dtype=torch.float32, device=w.device)
+        out = torch.empty(lib.dlio_conv2d_prep_weight_floats(Cout, Cin, KH, KW, mode), dtype=torch.float32,
+                          device=w.device)
     check(lib.dlio_conv2d_prep_weight(_ptr(w), _ptr(out), Cout, Cin, KH, KW, mode, _stream()),
           "conv2d_prep_weight")
     return out

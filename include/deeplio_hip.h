@@ -67,9 +67,11 @@ typedef struct DlioConvDesc {
   int32_t in_relu;               /* with in_scale: x' = max(0, affine(x)) */
 } DlioConvDesc;
 
-/* w [Cout][Cin][KH][KW] -> wt [KH*KW][Cin][Cout]  (mode 0, forward layout)
- * w [Cout][Cin][KH][KW] -> wt [KH*KW][Cout][Cin] with taps reversed
- *                          (mode 1, data-gradient layout for stride-1 convs) */
+/* w [Cout][Cin][KH][KW] -> wt [KH*KW][KP][Cout], KP = Cin  rounded up to 16 (mode 0, forward layout)
+ * w [Cout][Cin][KH][KW] -> wt [KH*KW][KP][Cin],  KP = Cout rounded up to 16, taps reversed
+ *                          (mode 1, data-gradient layout for stride-1 convs)
+ * rows k >= K are zero.  dlio_conv2d_prep_weight_floats = number of floats of wt. */
+size_t dlio_conv2d_prep_weight_floats(int Cout, int Cin, int KH, int KW, int mode);
 int dlio_conv2d_prep_weight(const float* w, float* wt, int Cout, int Cin, int KH, int KW,
                             int mode, dlio_stream_t stream);
 
