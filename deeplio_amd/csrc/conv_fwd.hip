@@ -285,7 +285,10 @@ int launch_tw(const float* x, const float* wt, const float* bias, const float* i
   // fused producer-affine on load (not on the headline path): one small-tile instantiation
   if (in_scale)
     return launch<KH, KW, SH, SW, CK, 1, 1, true>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
-  const int twn = d.OW > 32 ? 2 : 1;
+  static const int force_twn = getenv("DLIO_CONV_TWN") ? atoi(getenv("DLIO_CONV_TWN")) : 0;   // tuning knob
+  // sweep (tools/conv_table.py, DLIO_CONV_TWN x DLIO_CONV_MR): 32-pixel tiles win everywhere
+  // (fewer registers, more resident workgroups) except for the <=32-channel outputs of blk1
+  const int twn = force_twn ? force_twn : ((d.OW > 32 && d.Cout <= 32) ? 2 : 1);
   const int64_t blocks2 = (int64_t)cdiv(d.OW, 32 * twn) * cdiv(d.OH, 4) * cdiv(d.Cout, 64) * d.N;
   static const int force_mr = getenv("DLIO_CONV_MR") ? atoi(getenv("DLIO_CONV_MR")) : 0;   // tuning knob
   // micro-bench (tools/bench_conv.py): 32-channel tiles win for Cout <= 32 (234 vs 414 us on the

@@ -225,21 +225,35 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
       }
     }
   };
+  // 8 steps of 2 k-pairs; the LDS operands of step s+1 are read before the MFMAs of step s
+  // (register double buffer + sched_group_barrier), so LDS latency overlaps the MFMAs
   auto mfma_tile = [&](const float* buf) {
     const float* drow = buf + C::XL + l31 * C::DYS + wave * 32 + half;
     const float* xrow = buf + (wave * SH) * C::PC + half * SW;
-#pragma unroll 4
-    for (int kp = 0; kp < 16; ++kp) {
-      float a[C::MR], b[NT];
+    float a[2][C::MR][2], b[2][NT][2];
+    auto load_ab = [&](int st, float (&av)[C::MR][2], float (&bv)[NT][2]) {
 #pragma unroll
-      for (int m = 0; m < C::MR; ++m) a[m] = drow[m * 32 * C::DYS + kp * 2];
+      for (int e = 0; e < 2; ++e) {
+        const int kp = st * 2 + e;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) b[t] = xrow[off[t] + kp * 2 * SW];
+        for (int m = 0; m < C::MR; ++m) av[m][e] = drow[m * 32 * C::DYS + kp * 2];
 #pragma unroll
-      for (int m = 0; m < C::MR; ++m)
+        for (int t = 0; t < NT; ++t) bv[t][e] = xrow[off[t] + kp * 2 * SW];
+      }
+    };
+    load_ab(0, a[0], b[0]);
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-          acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[t], acc[m][t], 0, 0, 0);
+    for (int st = 0; st < 8; ++st) {
+      if (st + 1 < 8) load_ab(st + 1, a[(st + 1) & 1], b[(st + 1) & 1]);
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int m = 0; m < C::MR; ++m)
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st & 1][m][e], b[st & 1][t][e], acc[m][t], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, C::MR + NT, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * C::MR * NT, 0);
     }
   };
 
