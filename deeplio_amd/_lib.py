@@ -91,6 +91,10 @@ SIGNATURES = {
                                _p, _p, C.POINTER(_p), _p, _p, _p]),
     "dlio_pair_stack": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dlio_gt_relative": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "dlio_scan_project_ws_bytes": (_sz, [_i, _i]),
+    "dlio_scan_project": (_i, [_p, _p, _i, _i, _i, _d, _d, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "dlio_scan_normals": (_i, [_p, _p, _p, _i, _i, _p]),
+    "dlio_velo_image": (_i, [_p, _p, _p, _p, _f, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "dlio_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i, _f, _p]),
     "dlio_sgd_step": (_i, [_p, _p, _p, _i64, _f, _f, _f, _i, _f, _p]),
     "dlio_sumsq": (_i, [_p, _i64, _p, _p]),

@@ -473,6 +473,65 @@ def gt_relative(gts, comb, flag=None):
     return f2f, f2g
 
 
+# ----------------------------------------------------------------------------- lidar scan
+def scan_project(points, remissions, H, W, fov_up, fov_down):
+    """points [N,3] f32 (device), remissions [N] or None -> dict of the LaserScan projection
+    attributes (laserscan.py:122-185), all on the device."""
+    _chk(points)
+    if points.dim() != 2 or points.shape[1] != 3:
+        raise ValueError("points must be [N,3]")
+    if remissions is not None:
+        _chk(remissions)
+        if remissions.numel() != points.shape[0]:
+            raise ValueError("remissions must have one value per point")
+    N, dev = points.shape[0], points.device
+    i32, f32 = torch.int32, torch.float32
+    out = dict(proj_x=torch.empty(N, dtype=i32, device=dev), proj_y=torch.empty(N, dtype=i32, device=dev),
+               unproj_range=torch.empty(N, dtype=f32, device=dev),
+               proj_range=torch.empty(H, W, dtype=f32, device=dev),
+               proj_xyz=torch.empty(H, W, 3, dtype=f32, device=dev),
+               proj_remission=torch.empty(H, W, dtype=f32, device=dev),
+               proj_idx=torch.empty(H, W, dtype=i32, device=dev),
+               proj_mask=torch.empty(H, W, dtype=i32, device=dev))
+    nb = lib.dlio_scan_project_ws_bytes(H, W)
+    ws = workspace(nb, dev, slot=3)
+    check(lib.dlio_scan_project(_ptr(points), _ptr(remissions), N, H, W, float(fov_up), float(fov_down),
+                                _ptr(out["proj_x"]), _ptr(out["proj_y"]), _ptr(out["unproj_range"]),
+                                _ptr(out["proj_range"]), _ptr(out["proj_xyz"]), _ptr(out["proj_remission"]),
+                                _ptr(out["proj_idx"]), _ptr(out["proj_mask"]), _ptr(ws), ws.numel(), _stream()),
+          "scan_project")
+    return out
+
+
+def scan_normals(proj_xyz, proj_range):
+    _chk(proj_xyz)
+    _chk(proj_range)
+    H, W = proj_range.shape
+    out = torch.empty(H, W, 3, dtype=torch.float32, device=proj_xyz.device)
+    check(lib.dlio_scan_normals(_ptr(proj_xyz), _ptr(proj_range), _ptr(out), H, W, _stream()), "scan_normals")
+    return out
+
+
+def velo_image(proj_xyz, proj_remission, normals, proj_range, max_depth, channels, mean=None,
+               crop_top=0, crop_left=0):
+    """-> [len(channels), H-2*crop_top, W-2*crop_left] (kitti.py:83-97 + :345-364)"""
+    for t in (proj_xyz, proj_remission, normals, proj_range):
+        _chk(t)
+    H, W = proj_range.shape
+    ch = (C.c_int32 * len(channels))(*[int(c) for c in channels])
+    mn = None
+    if mean is not None:
+        if len(mean) != 8:
+            raise ValueError("mean must have 8 entries (one per image channel)")
+        mn = (C.c_float * 8)(*[float(m) for m in mean])
+    out = torch.empty(len(channels), H - 2 * crop_top, W - 2 * crop_left, dtype=torch.float32,
+                      device=proj_xyz.device)
+    check(lib.dlio_velo_image(_ptr(proj_xyz), _ptr(proj_remission), _ptr(normals), _ptr(proj_range),
+                              float(max_depth), ch, mn, len(channels), H, W, crop_top, crop_left, _ptr(out),
+                              _stream()), "velo_image")
+    return out
+
+
 # ----------------------------------------------------------------------------- optimizer
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
     check(lib.dlio_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(beta1),

@@ -300,6 +300,35 @@ int dlio_pair_stack(const float* images, const int32_t* combinations, float* xyz
 int dlio_gt_relative(const float* gts, const int32_t* combinations, float* f2f, float* f2g,
                      int32_t* flag, int B, int F, int S, dlio_stream_t stream);
 
+/* ---- lidar scan -> range image (the data step in front of the path) --------
+ * LaserScan.do_range_projection (deeplio/common/laserscan.py:122-185): per point
+ * depth = |p|, yaw = -atan2(y,x), pitch = asin(z/depth),
+ * proj_x = floor(0.5*(yaw/pi+1)*W), proj_y = floor((1-(pitch+|fov_down|)/fov)*H), clamped;
+ * float32 arithmetic in the reference's operation order, atan2/asin correctly rounded.
+ * Pixels take the CLOSEST of their points (the reference scatters in decreasing-depth order);
+ * equal depths: smallest point index.  Empty pixels are 0 in every output (laserscan.py:27-60).
+ * points [N,3], remissions [N] or NULL; proj_x/proj_y/unproj_range [N];
+ * proj_range/proj_remission/proj_idx/proj_mask [H,W], proj_xyz [H,W,3]; proj_mask may be NULL.
+ * ws: dlio_scan_project_ws_bytes(H, W) bytes of scratch. */
+size_t dlio_scan_project_ws_bytes(int H, int W);
+int dlio_scan_project(const float* points, const float* remissions, int N, int H, int W,
+                      double fov_up_deg, double fov_down_deg, int32_t* proj_x, int32_t* proj_y,
+                      float* unproj_range, float* proj_range, float* proj_xyz,
+                      float* proj_remission, int32_t* proj_idx, int32_t* proj_mask, void* ws,
+                      size_t ws_bytes, dlio_stream_t stream);
+/* LaserScan.do_normal_projection (laserscan.py:215-248): range-weighted cross products of the
+ * four neighbour differences, normalised, zero border.  normals [H,W,3]. */
+int dlio_scan_normals(const float* proj_xyz, const float* proj_range, float* normals, int H,
+                      int W, dlio_stream_t stream);
+/* Kitti.get_velo_image (deeplio/datasets/kitti.py:83-97) + transform_images (:345-364):
+ * image = (xyz/max_depth, remission, normal, range) -> crop -> CHW -> minus mean -> channel select.
+ * channels: n_channels HOST ints in 0..7; mean: 8 HOST floats indexed by original channel or
+ * NULL.  out [n_channels][H-2*crop_top][W-2*crop_left]. */
+int dlio_velo_image(const float* proj_xyz, const float* proj_remission, const float* normals,
+                    const float* proj_range, float max_depth, const int32_t* channels,
+                    const float* mean, int n_channels, int H, int W, int crop_top, int crop_left,
+                    float* out, dlio_stream_t stream);
+
 /* ---- optimizer ----------------------------------------------------------
  * torch.optim.Adam / SGD(momentum) as built by create_optimizer
  * (optimizer.py:4-16) over ONE flat parameter buffer: weight decay is L2 added
