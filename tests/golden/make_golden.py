@@ -295,6 +295,41 @@ def golden_projection(out):
                              proj_remission=scan.proj_remission, normals=normals.astype(np.float32))
 
 
+def golden_tester(out):
+    """'next' row 3: OdomSeqRes.add_local_prediction / write_to_file (tester.py:263-326): local->global
+    integration and the KITTI text format.  Inputs: seeded local transforms; outputs: the two text
+    files the reference writes (the PNG plot is stubbed out)."""
+    import deeplio.models.tester as rt
+    rng = np.random.default_rng(7000)
+    n = 40
+    T_local, T_glob = [], []
+    for i in range(n):
+        w = rng.normal(0, 0.05, 3)
+        th = np.linalg.norm(w)
+        K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        R = np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+        T = np.eye(4)
+        T[:3, :3] = R
+        T[:3, 3] = rng.normal(0, 0.5, 3) + np.array([1.0, 0, 0])
+        T_local.append(T)
+        G = np.eye(4)
+        G[:3, :3] = R.T
+        G[:3, 3] = rng.normal(0, 30, 3)
+        T_glob.append(G)
+    ts = np.arange(n) * 0.1 + 1317000000.0
+    loss = rng.uniform(0, 1, n)
+    rt.plt.savefig = lambda *a, **k: None          # plotting is out of scope
+    with tempfile.TemporaryDirectory() as tmp:
+        seq = rt.OdomSeqRes("2011_10_03", "0027", output_dir=tmp)
+        for i in range(n):
+            seq.add_local_prediction(ts[i], loss[i], T_local[i], T_glob[i])
+        seq.write_to_file()
+        gt_txt = open(os.path.join(tmp, "gt_kitti_2011_10_03_0027.txt")).read()
+        pred_txt = open(os.path.join(tmp, "pred_kitti_2011_10_03_0027.txt")).read()
+    out["tester"] = dict(T_local=np.array(T_local), T_glob=np.array(T_glob), timestamps=ts, loss=loss,
+                         gt_txt=np.array(gt_txt), pred_txt=np.array(pred_txt))
+
+
 def main():
     assert os.path.isdir(REF), "the reference checkout is required to regenerate goldens"
     install_stubs()
@@ -309,6 +344,7 @@ def main():
             golden_se3_loss(out)
             golden_gt_and_lr(out)
             golden_projection(out)
+            golden_tester(out)
             golden_models(out)
             golden_train_trajectory(out)
         finally:
