@@ -108,7 +108,20 @@ __global__ __launch_bounds__(256) void linear_bwd_data_kernel(
 #pragma unroll
   for (int j = 0; j < BM; ++j) acc[j] = 0.f;
   if (k < K) {
-    for (int n = ty; n < N; n += 4) {
+    // 8 independent weight loads in flight per thread (the loop is latency-bound otherwise:
+    // 4 workgroups for K = 256), summation order unchanged
+    int n = ty;
+    for (; n + 28 < N; n += 32) {
+      float wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) wv[u] = w[(size_t)(n + 4 * u) * K + k];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int j = 0; j < BM; ++j)
+          if (m0 + j < M) acc[j] += dz[(size_t)(m0 + j) * lddz + n + 4 * u] * wv[u];
+    }
+    for (; n < N; n += 4) {
       const float wv = w[(size_t)n * K + k];
 #pragma unroll
       for (int j = 0; j < BM; ++j)
@@ -170,7 +183,15 @@ __global__ void linear_bwd_data_reduce_kernel(const float* __restrict__ part, fl
     const int j = i / K, k = i - j * K;
     if (m0 + j >= M) continue;
     float s = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) s += part[((size_t)sp * BM + j) * K + k];
+    int sp = 0;
+    for (; sp + 8 <= nsplit; sp += 8) {        // 8 loads in flight, same summation order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[((size_t)(sp + u) * BM + j) * K + k];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; sp < nsplit; ++sp) s += part[((size_t)sp * BM + j) * K + k];
     float* p = dx + (size_t)(m0 + j) * lddx + k;
     *p = accumulate ? *p + s : s;
   }
