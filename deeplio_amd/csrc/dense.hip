@@ -99,33 +99,44 @@ constexpr int BM = 16;
 __global__ __launch_bounds__(256) void linear_bwd_data_kernel(
     const float* __restrict__ dz, int lddz, const float* __restrict__ w, float* __restrict__ dx,
     int lddx, int M, int N, int K, int accumulate) {
+  // dx[m][k] = sum_n dz[m][n] w[n][k].  A block owns 64 columns k and BM rows m; the dz tile of
+  // a 256-wide n chunk is staged in LDS (read back as broadcast float4), the 4 waves take 64
+  // consecutive n each and keep 8 coalesced weight loads in flight; partials are combined in a
+  // fixed order.
+  constexpr int NC = 256;
+  __shared__ __attribute__((aligned(16))) float sdz[BM][NC];
   __shared__ float red[4][BM][64];
   const int tx = threadIdx.x & 63;
   const int ty = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int k = blockIdx.x * 64 + tx;
+  const int kc = k < K ? k : K - 1;
   const int m0 = blockIdx.y * BM;
   float acc[BM];
 #pragma unroll
   for (int j = 0; j < BM; ++j) acc[j] = 0.f;
-  if (k < K) {
-    // 8 independent weight loads in flight per thread (the loop is latency-bound otherwise:
-    // 4 workgroups for K = 256), summation order unchanged
-    int n = ty;
-    for (; n + 28 < N; n += 32) {
+  for (int c0 = 0; c0 < N; c0 += NC) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < BM * NC; i += 256) {
+      const int j = i / NC, n = c0 + (i - j * NC);
+      sdz[j][i - j * NC] = (m0 + j < M && n < N) ? dz[(size_t)(m0 + j) * lddz + n] : 0.f;
+    }
+    __syncthreads();
+    const int nb = ty * 64;
+#pragma unroll 1
+    for (int g = 0; g < 64; g += 8) {
       float wv[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) wv[u] = w[(size_t)(n + 4 * u) * K + k];
+      for (int u = 0; u < 8; ++u) {
+        const int n = c0 + nb + g + u;
+        wv[u] = n < N ? w[(size_t)n * K + kc] : 0.f;
+      }
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-#pragma unroll
-        for (int j = 0; j < BM; ++j)
-          if (m0 + j < M) acc[j] += dz[(size_t)(m0 + j) * lddz + n + 4 * u] * wv[u];
-    }
-    for (; n < N; n += 4) {
-      const float wv = w[(size_t)n * K + k];
-#pragma unroll
-      for (int j = 0; j < BM; ++j)
-        if (m0 + j < M) acc[j] += dz[(size_t)(m0 + j) * lddz + n] * wv;
+      for (int j = 0; j < BM; ++j) {
+        const float4 d0 = *reinterpret_cast<const float4*>(&sdz[j][nb + g]);
+        const float4 d1 = *reinterpret_cast<const float4*>(&sdz[j][nb + g + 4]);
+        acc[j] += d0.x * wv[0]; acc[j] += d0.y * wv[1]; acc[j] += d0.z * wv[2]; acc[j] += d0.w * wv[3];
+        acc[j] += d1.x * wv[4]; acc[j] += d1.y * wv[5]; acc[j] += d1.z * wv[6]; acc[j] += d1.w * wv[7];
+      }
     }
   }
 #pragma unroll
