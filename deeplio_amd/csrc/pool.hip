@@ -5,6 +5,7 @@
 // adaptive_avg_pool2d at lidar_feat_nets.py:84-85,258, resnet.py:49, pointseg_modules.py:218;
 // the SELayer product pointseg_modules.py:220.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -183,6 +184,99 @@ __global__ __launch_bounds__(256) void maxpool3_bwd_sw2(const float* __restrict_
 
 // ds[plane] = sum over the plane of gather * x  (the SELayer scale gradient) without ever
 // writing the pooled-gradient plane: one block per plane, fp64 block reduction
+// ---- stride-(1,2) backward as a rolling vertical window -------------------------------------
+// A thread owns 4 input columns x PR input rows.  Every output row it needs (PR+2 of them) is
+// read ONCE (float2 + 1 halo value, 3 argmax bytes) and routed to up to three of the PR register
+// rows -- the per-element gather above reads each dY element 3x (18 loads per float4 of dX; this
+// form: 4 loads per output row, 40 per 8 float4).  Contributions arrive in the same order
+// (output row ascending, then column), so results are bit-identical to pool3_bwd_gather.
+constexpr int PR = 8;
+
+__device__ __forceinline__ void pool3_strip_s1(const float* __restrict__ dyp,
+                                               const uint8_t* __restrict__ ip, int ih0, int b, int OH,
+                                               int OW, float (&G)[PR][4]) {
+#pragma unroll
+  for (int r = 0; r < PR; ++r) G[r][0] = G[r][1] = G[r][2] = G[r][3] = 0.f;
+  const bool has2 = 2 * b + 2 < OW;
+#pragma unroll
+  for (int j = -1; j <= PR; ++j) {
+    const int oh = ih0 + j;
+    if (oh < 0 || oh >= OH) continue;
+    const size_t ro = (size_t)oh * OW + 2 * b;
+    const float2 v01 = *reinterpret_cast<const float2*>(dyp + ro);
+    const unsigned short k01 = *reinterpret_cast<const unsigned short*>(ip + ro);
+    const float v[3] = {v01.x, v01.y, has2 ? dyp[ro + 2] : 0.f};
+    const int k[3] = {k01 & 0xff, k01 >> 8, has2 ? (int)ip[ro + 2] : 4};   // 4 = (ky 1, kx 1): col 2b+2 -> none
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int ky = k[c] / 3, kx = k[c] - ky * 3;
+#pragma unroll
+      for (int kyv = 0; kyv < 3; ++kyv) {
+        const int r = j - 1 + kyv;                 // input row (compile-time)
+        if (r < 0 || r >= PR) continue;
+        const float val = ky == kyv ? v[c] : 0.f;
+        if (c == 0) { G[r][0] += kx == 1 ? val : 0.f; G[r][1] += kx == 2 ? val : 0.f; }
+        else if (c == 1) { G[r][1] += kx == 0 ? val : 0.f; G[r][2] += kx == 1 ? val : 0.f; G[r][3] += kx == 2 ? val : 0.f; }
+        else if (has2) { G[r][3] += kx == 0 ? val : 0.f; }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool3_bwd_s1_strip(const float* __restrict__ dy,
+                                                             const uint8_t* __restrict__ idx,
+                                                             const float* __restrict__ xs,
+                                                             const float* __restrict__ xadd,
+                                                             float* __restrict__ dx, int64_t planes,
+                                                             int H, int W, int OH, int OW) {
+  const int W4 = W >> 2, strips = (H + PR - 1) / PR;
+  const int64_t total = planes * strips * W4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i % W4);
+    int64_t t = i / W4;
+    const int ih0 = (int)(t % strips) * PR;
+    const int64_t pl = t / strips;
+    float G[PR][4];
+    pool3_strip_s1(dy + (size_t)pl * OH * OW, idx + (size_t)pl * OH * OW, ih0, b, OH, OW, G);
+    const float s = xs ? xs[pl] : 1.f, a = xadd ? xadd[pl] : 0.f;
+#pragma unroll
+    for (int r = 0; r < PR; ++r) {
+      if (ih0 + r >= H) continue;
+      float4 o = make_float4(G[r][0], G[r][1], G[r][2], G[r][3]);
+      if (xs) { o.x *= s; o.y *= s; o.z *= s; o.w *= s; }
+      if (xadd) { o.x += a; o.y += a; o.z += a; o.w += a; }
+      *reinterpret_cast<float4*>(dx + ((size_t)pl * H + ih0 + r) * W + 4 * b) = o;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool3_bwd_dot_s1_strip(const float* __restrict__ dy,
+                                                                 const uint8_t* __restrict__ idx,
+                                                                 const float* __restrict__ x,
+                                                                 float* __restrict__ ds, int planes,
+                                                                 int H, int W, int OH, int OW) {
+  __shared__ double sm[16];
+  const int W4 = W >> 2, strips = (H + PR - 1) / PR;
+  for (int pl = blockIdx.x; pl < planes; pl += gridDim.x) {
+    const float* xp = x + (size_t)pl * H * W;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < strips * W4; i += 256) {
+      const int b = i % W4, ih0 = (i / W4) * PR;
+      float G[PR][4];
+      pool3_strip_s1(dy + (size_t)pl * OH * OW, idx + (size_t)pl * OH * OW, ih0, b, OH, OW, G);
+#pragma unroll
+      for (int r = 0; r < PR; ++r) {
+        if (ih0 + r >= H) continue;
+        const float4 xv = *reinterpret_cast<const float4*>(xp + (size_t)(ih0 + r) * W + 4 * b);
+        acc += (double)((G[r][0] * xv.x + G[r][1] * xv.y) + (G[r][2] * xv.z + G[r][3] * xv.w));
+      }
+    }
+    const double rsum = block_sum_d(acc, sm);
+    if (threadIdx.x == 0) ds[pl] = (float)rsum;
+  }
+}
+
 template <int SH>
 __global__ __launch_bounds__(256) void maxpool3_bwd_dot_sw2(const float* __restrict__ dy,
                                                             const uint8_t* __restrict__ idx,
@@ -311,7 +405,11 @@ extern "C" int dlio_maxpool2d_bwd_dot(const float* dy, const uint8_t* idx, const
   if (!pool_fast(H, W, OH, OW, K, SH, SW, PH, PW)) return DLIO_EUNSUP;
   int grid = N * C;
   if (grid > 65535) grid = 65535;
-  if (SH == 1)
+  static const int strip = getenv("DLIO_POOL_STRIP") ? atoi(getenv("DLIO_POOL_STRIP")) : 1;   // tuning knob
+  if (SH == 1 && strip)
+    hipLaunchKernelGGL(maxpool3_bwd_dot_s1_strip, dim3(grid), dim3(256), 0, as_stream(stream), dy, idx,
+                       x, ds, N * C, H, W, OH, OW);
+  else if (SH == 1)
     hipLaunchKernelGGL(maxpool3_bwd_dot_sw2<1>, dim3(grid), dim3(256), 0, as_stream(stream), dy, idx, x,
                        ds, N * C, H, W, OH, OW);
   else
@@ -329,7 +427,11 @@ extern "C" int dlio_maxpool2d_bwd(const float* dy, const uint8_t* idx, const flo
   if (K == 3 && SW == 2 && PH == 1 && PW == 1 && (SH == 1 || SH == 2) && (W & 3) == 0 && OW * 2 == W &&
       OH == (H + 2 - 3) / SH + 1) {
     const int64_t work = total / 4;
-    if (SH == 1)
+    static const int strip = getenv("DLIO_POOL_STRIP") ? atoi(getenv("DLIO_POOL_STRIP")) : 1;   // tuning knob
+    if (SH == 1 && strip)
+      hipLaunchKernelGGL(maxpool3_bwd_s1_strip, dim3(ew_grid(cdiv64(work, PR), 256)), dim3(256), 0,
+                         as_stream(stream), dy, idx, x_scale, x_add, dx, (int64_t)N * C, H, W, OH, OW);
+    else if (SH == 1)
       hipLaunchKernelGGL(maxpool3_bwd_sw2<1>, dim3(ew_grid(work, 256)), dim3(256), 0, as_stream(stream),
                          dy, idx, x_scale, x_add, dx, (int64_t)N * C, H, W, OH, OW);
     else
