@@ -192,15 +192,18 @@ __global__ __launch_bounds__(256) void maxpool3_bwd_sw2(const float* __restrict_
 // (output row ascending, then column), so results are bit-identical to pool3_bwd_gather.
 constexpr int PR = 8;
 
-__device__ __forceinline__ void pool3_strip_s1(const float* __restrict__ dyp,
-                                               const uint8_t* __restrict__ ip, int ih0, int b, int OH,
-                                               int OW, float (&G)[PR][4]) {
+template <int SH>
+__device__ __forceinline__ void pool3_strip(const float* __restrict__ dyp,
+                                            const uint8_t* __restrict__ ip, int ih0, int b, int OH,
+                                            int OW, float (&G)[PR][4]) {
 #pragma unroll
   for (int r = 0; r < PR; ++r) G[r][0] = G[r][1] = G[r][2] = G[r][3] = 0.f;
   const bool has2 = 2 * b + 2 < OW;
+  // output rows whose 3-row window (input rows oh*SH-1 .. oh*SH+1) meets input rows ih0 .. ih0+PR-1
+  constexpr int J0 = SH == 1 ? -1 : 0, J1 = SH == 1 ? PR : PR / 2;
 #pragma unroll
-  for (int j = -1; j <= PR; ++j) {
-    const int oh = ih0 + j;
+  for (int j = J0; j <= J1; ++j) {
+    const int oh = ih0 / SH + j;
     if (oh < 0 || oh >= OH) continue;
     const size_t ro = (size_t)oh * OW + 2 * b;
     const float2 v01 = *reinterpret_cast<const float2*>(dyp + ro);
@@ -212,7 +215,7 @@ __device__ __forceinline__ void pool3_strip_s1(const float* __restrict__ dyp,
       const int ky = k[c] / 3, kx = k[c] - ky * 3;
 #pragma unroll
       for (int kyv = 0; kyv < 3; ++kyv) {
-        const int r = j - 1 + kyv;                 // input row (compile-time)
+        const int r = j * SH - 1 + kyv;            // input row inside the strip (compile-time)
         if (r < 0 || r >= PR) continue;
         const float val = ky == kyv ? v[c] : 0.f;
         if (c == 0) { G[r][0] += kx == 1 ? val : 0.f; G[r][1] += kx == 2 ? val : 0.f; }
@@ -223,7 +226,8 @@ __device__ __forceinline__ void pool3_strip_s1(const float* __restrict__ dyp,
   }
 }
 
-__global__ __launch_bounds__(256) void maxpool3_bwd_s1_strip(const float* __restrict__ dy,
+template <int SH>
+__global__ __launch_bounds__(256) void maxpool3_bwd_strip(const float* __restrict__ dy,
                                                              const uint8_t* __restrict__ idx,
                                                              const float* __restrict__ xs,
                                                              const float* __restrict__ xadd,
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(256) void maxpool3_bwd_s1_strip(const float* __rest
     const int ih0 = (int)(t % strips) * PR;
     const int64_t pl = t / strips;
     float G[PR][4];
-    pool3_strip_s1(dy + (size_t)pl * OH * OW, idx + (size_t)pl * OH * OW, ih0, b, OH, OW, G);
+    pool3_strip<SH>(dy + (size_t)pl * OH * OW, idx + (size_t)pl * OH * OW, ih0, b, OH, OW, G);
     const float s = xs ? xs[pl] : 1.f, a = xadd ? xadd[pl] : 0.f;
 #pragma unroll
     for (int r = 0; r < PR; ++r) {
@@ -251,7 +255,8 @@ __global__ __launch_bounds__(256) void maxpool3_bwd_s1_strip(const float* __rest
   }
 }
 
-__global__ __launch_bounds__(256) void maxpool3_bwd_dot_s1_strip(const float* __restrict__ dy,
+template <int SH>
+__global__ __launch_bounds__(256) void maxpool3_bwd_dot_strip(const float* __restrict__ dy,
                                                                  const uint8_t* __restrict__ idx,
                                                                  const float* __restrict__ x,
                                                                  float* __restrict__ ds, int planes,
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(256) void maxpool3_bwd_dot_s1_strip(const float* __
     for (int i = threadIdx.x; i < strips * W4; i += 256) {
       const int b = i % W4, ih0 = (i / W4) * PR;
       float G[PR][4];
-      pool3_strip_s1(dy + (size_t)pl * OH * OW, idx + (size_t)pl * OH * OW, ih0, b, OH, OW, G);
+      pool3_strip<SH>(dy + (size_t)pl * OH * OW, idx + (size_t)pl * OH * OW, ih0, b, OH, OW, G);
 #pragma unroll
       for (int r = 0; r < PR; ++r) {
         if (ih0 + r >= H) continue;
@@ -407,7 +412,10 @@ extern "C" int dlio_maxpool2d_bwd_dot(const float* dy, const uint8_t* idx, const
   if (grid > 65535) grid = 65535;
   static const int strip = getenv("DLIO_POOL_STRIP") ? atoi(getenv("DLIO_POOL_STRIP")) : 1;   // tuning knob
   if (SH == 1 && strip)
-    hipLaunchKernelGGL(maxpool3_bwd_dot_s1_strip, dim3(grid), dim3(256), 0, as_stream(stream), dy, idx,
+    hipLaunchKernelGGL(maxpool3_bwd_dot_strip<1>, dim3(grid), dim3(256), 0, as_stream(stream), dy, idx,
+                       x, ds, N * C, H, W, OH, OW);
+  else if (strip && (H & 1) == 0)
+    hipLaunchKernelGGL(maxpool3_bwd_dot_strip<2>, dim3(grid), dim3(256), 0, as_stream(stream), dy, idx,
                        x, ds, N * C, H, W, OH, OW);
   else if (SH == 1)
     hipLaunchKernelGGL(maxpool3_bwd_dot_sw2<1>, dim3(grid), dim3(256), 0, as_stream(stream), dy, idx, x,
@@ -429,7 +437,10 @@ extern "C" int dlio_maxpool2d_bwd(const float* dy, const uint8_t* idx, const flo
     const int64_t work = total / 4;
     static const int strip = getenv("DLIO_POOL_STRIP") ? atoi(getenv("DLIO_POOL_STRIP")) : 1;   // tuning knob
     if (SH == 1 && strip)
-      hipLaunchKernelGGL(maxpool3_bwd_s1_strip, dim3(ew_grid(cdiv64(work, PR), 256)), dim3(256), 0,
+      hipLaunchKernelGGL(maxpool3_bwd_strip<1>, dim3(ew_grid(cdiv64(work, PR), 256)), dim3(256), 0,
+                         as_stream(stream), dy, idx, x_scale, x_add, dx, (int64_t)N * C, H, W, OH, OW);
+    else if (strip && (H & 1) == 0)
+      hipLaunchKernelGGL(maxpool3_bwd_strip<2>, dim3(ew_grid(cdiv64(work, PR), 256)), dim3(256), 0,
                          as_stream(stream), dy, idx, x_scale, x_add, dx, (int64_t)N * C, H, W, OH, OW);
     else if (SH == 1)
       hipLaunchKernelGGL(maxpool3_bwd_sw2<1>, dim3(ew_grid(work, 256)), dim3(256), 0, as_stream(stream),

@@ -159,7 +159,10 @@ def test_batchnorm_train_eval_backward(dev, shape, pre_relu, post_relu):
 
 POOL_CASES = [((2, 5, 8, 64), 3, 1, 2, 1, 1, False), ((2, 5, 8, 64), 3, 2, 2, 1, 1, False),
               ((1, 3, 16, 129), 3, 1, 2, 1, 1, True), ((1, 3, 33, 33), 3, 2, 2, 1, 1, True),
-              ((1, 3, 64, 65), 3, 2, 2, 1, 1, True)]
+              ((1, 3, 64, 65), 3, 2, 2, 1, 1, True),
+              # rolling-window backward: several 8-row strips, a partial last strip, both strides
+              ((2, 3, 20, 64), 3, 1, 2, 1, 1, False), ((2, 3, 28, 32), 3, 2, 2, 1, 1, False),
+              ((1, 2, 64, 128), 3, 1, 2, 1, 1, False), ((1, 2, 64, 128), 3, 2, 2, 1, 1, False)]
 
 
 @pytest.mark.parametrize("case", POOL_CASES)
@@ -179,6 +182,9 @@ def test_maxpool_bit_exact_with_ties(dev, case):
     assert torch.equal(y.cpu(), y_ref.detach())
     dx = ops.maxpool2d_bwd(dy.to(dev), idx, shape, k, sh, sw, ph, pw)
     assert rel_err(dx, xr.grad) < 1e-6
+    if not ceil and shape[3] % 4 == 0:      # fused SELayer backward by-product: sum(dx * x) per plane
+        ds = ops.maxpool2d_bwd_dot(dy.to(dev), idx, x.to(dev), k, sh, sw, ph, pw)
+        assert rel_err(ds.view(shape[0], shape[1]), (xr.grad.double() * x.double()).sum((2, 3))) < 1e-5
 
 
 def test_gap_and_channel_scale(dev):
