@@ -112,6 +112,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     xc[j] = pos - xr[j] * C::PC;
   }
 
+  // All global loads are unconditional buffer loads; an invalid element gets a voffset beyond
+  // num_records and the hardware returns 0.  (Conditional loads compile to branch + load +
+  // s_waitcnt vmcnt(0) per element, which serialises the prefetch.)
+  constexpr unsigned OOB = 0xffffff00u;
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(x), 0, (int)((size_t)d.N * d.in_ctot * HW * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(dy), 0, (int)((size_t)d.N * d.out_ctot * ohw * 4), 0x00020000);
+  auto ld1 = [&](__amdgpu_buffer_rsrc_t r, unsigned vo) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, vo, 0, 0));
+  };
+  auto ld4 = [&](__amdgpu_buffer_rsrc_t r, unsigned vo) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, vo, 0, 0));
+  };
   float rdy[C::NDY];
   float rx[C::NCX][C::NPOSX];
   auto load_tile = [&](int tile) {
@@ -121,72 +135,70 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     const int n = tt;
     const int oh0 = th * C::TH, ow0 = tw * C::TW;
     const int ih0 = oh0 * SH - d.PH, iw0 = ow0 * SW - d.PW;
+    const unsigned yimg = (unsigned)(((size_t)n * d.out_ctot + d.out_coff + co0) * ohw * 4);
+    const unsigned ximg = (unsigned)(((size_t)n * d.in_ctot + d.in_coff + c0) * HW * 4);
     if constexpr (VEC) {
       const int oh = oh0 + v_r, ow = ow0 + 4 * v_c4;
       const bool pv = oh < d.OH && ow < d.OW;
-      const float* p = dy + ((size_t)n * d.out_ctot + d.out_coff + co0) * ohw +
-                       (pv ? (size_t)oh * d.OW + ow : 0);
+      const unsigned po = yimg + (unsigned)(oh * d.OW + ow) * 4u;
 #pragma unroll
       for (int i = 0; i < C::NDY / 4; ++i) {
         const int co = v_ch + 8 * i;
-        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (pv && co0 + co < d.Cout) t = *reinterpret_cast<const float4*>(p + (size_t)co * ohw);
+        const float4 t = ld4(yrsrc, (pv && co0 + co < d.Cout) ? po + (unsigned)co * (unsigned)ohw * 4u : OOB);
         rdy[4 * i] = t.x; rdy[4 * i + 1] = t.y; rdy[4 * i + 2] = t.z; rdy[4 * i + 3] = t.w;
       }
     } else {
       const int oh = oh0 + dy_r, ow = ow0 + dy_col;
       const bool pv = oh < d.OH && ow < d.OW;
-      const float* p = dy + ((size_t)n * d.out_ctot + d.out_coff + co0) * ohw +
-                       (pv ? (size_t)oh * d.OW + ow : 0);
+      const unsigned po = yimg + (unsigned)(oh * d.OW + ow) * 4u;
 #pragma unroll
       for (int i = 0; i < C::NDY; ++i) {
         const int co = dy_co + 2 * i;
-        rdy[i] = (pv && co0 + co < d.Cout) ? p[(size_t)co * ohw] : 0.f;
+        rdy[i] = ld1(yrsrc, (pv && co0 + co < d.Cout) ? po + (unsigned)co * (unsigned)ohw * 4u : OOB);
       }
     }
-    const float* xn = x + ((size_t)n * d.in_ctot + d.in_coff + c0) * HW;
     if constexpr (XVEC) {
       const int ih = ih0 + v_r, iw = iw0 + 4 * v_c4;
       const bool pvx = ih < d.H && iw < d.W;
-      const float* p = xn + (pvx ? (size_t)ih * d.W + iw : 0);
+      const unsigned po = ximg + (unsigned)(ih * d.W + iw) * 4u;
 #pragma unroll
       for (int i = 0; i < C::CKMAX / 8; ++i) {
         const int c = v_ch + 8 * i;
-        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (pvx && c < ck) {
-          t = *reinterpret_cast<const float4*>(p + (size_t)c * HW);
-          if (has_aff) {
-            const float mu = in_mean[c0 + c], sc = in_scale[c0 + c], sh = in_shift[c0 + c];
-            t.x = (t.x - mu) * sc + sh; t.y = (t.y - mu) * sc + sh;
-            t.z = (t.z - mu) * sc + sh; t.w = (t.w - mu) * sc + sh;
-            if (d.in_relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
-          }
+        const bool ok = pvx && c < ck;
+        float4 t = ld4(xrsrc, ok ? po + (unsigned)c * (unsigned)HW * 4u : OOB);
+        if (has_aff) {
+          const int cc = min(c0 + c, d.Cin - 1);
+          const float mu = in_mean[cc], sc = in_scale[cc], sh = in_shift[cc];
+          t.x = (t.x - mu) * sc + sh; t.y = (t.y - mu) * sc + sh;
+          t.z = (t.z - mu) * sc + sh; t.w = (t.w - mu) * sc + sh;
+          if (d.in_relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+          if (!ok) t = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         rx[4 * i][0] = t.x; rx[4 * i + 1][0] = t.y; rx[4 * i + 2][0] = t.z; rx[4 * i + 3][0] = t.w;
       }
       return;
     }
-    int po[C::NPOSX];
-    bool pv[C::NPOSX];
+    unsigned po[C::NPOSX];
 #pragma unroll
     for (int j = 0; j < C::NPOSX; ++j) {
       const int ih = ih0 + xr[j], iw = iw0 + xc[j];
-      pv[j] = (xp + j * C::LPP) < C::PRPC && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W;
-      po[j] = pv[j] ? ih * d.W + iw : 0;
+      const bool pv = (xp + j * C::LPP) < C::PRPC && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W;
+      po[j] = pv ? ximg + (unsigned)(ih * d.W + iw) * 4u : OOB;
     }
 #pragma unroll
     for (int i = 0; i < C::NCX; ++i) {
       const int c = xcph + C::CPAR * i;
       const bool cv = c < ck;
+      const unsigned coff = (unsigned)c * (unsigned)HW * 4u;
 #pragma unroll
       for (int j = 0; j < C::NPOSX; ++j) {
-        float v = 0.f;
-        if (cv && pv[j]) {
-          v = xn[(size_t)c * HW + po[j]];
-          if (has_aff) {
-            v = (v - in_mean[c0 + c]) * in_scale[c0 + c] + in_shift[c0 + c];
-            if (d.in_relu) v = fmaxf(v, 0.f);
-          }
+        const bool ok = cv && po[j] != OOB;
+        float v = ld1(xrsrc, ok ? po[j] + coff : OOB);
+        if (has_aff) {
+          const int cc = min(c0 + c, d.Cin - 1);
+          v = (v - in_mean[cc]) * in_scale[cc] + in_shift[cc];
+          if (d.in_relu) v = fmaxf(v, 0.f);
+          if (!ok) v = 0.f;
         }
         rx[i][j] = v;
       }
@@ -880,6 +892,10 @@ extern "C" int dlio_conv2d_wgrad(const float* x, const float* dy, float* dw,
   WgPlan p;
   if (!make_plan(d, p)) return DLIO_EUNSUP;
   if (ws_bytes < p.ws_bytes) return DLIO_EWS;
+  // the kernels address both operands with 32-bit buffer offsets
+  if ((size_t)d.N * d.in_ctot * d.H * d.W * 4 >= 0xffffff00ull ||
+      (size_t)d.N * d.out_ctot * d.OH * d.OW * 4 >= 0xffffff00ull)
+    return DLIO_EUNSUP;
   p.accumulate = accumulate;
   hipStream_t s = as_stream(stream);
   float* wsp = reinterpret_cast<float*>(ws);
