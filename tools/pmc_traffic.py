@@ -17,7 +17,7 @@ import sys
 
 FAMILIES = {
     "conv2d_fwd_mfma": ("conv_fwd_kernel", "conv1x1_direct_kernel", "conv1x1_v4_kernel"),
-    "conv2d_wgrad_mfma": ("conv_wgrad_kernel", "wgrad_reduce_kernel"),
+    "conv2d_wgrad_mfma": ("wgrad",),
     "batchnorm": ("chan_reduce", "chan_stats", "bn_apply", "bn_bwd"),
     "pool_se": ("maxpool", "gap_", "chan_scale", "pool3"),
 }
