@@ -135,7 +135,7 @@ def main():
     ts = TrainStep(cfg, (C, H, W), device, B)
     sync = ddist.GradSync(ts.optimizer.flat, ts.optimizer.grad, ts.optimizer)
     sync.broadcast_parameters()
-    ts.grad_sync = sync if world > 1 else None
+    ts.set_grad_sync(sync if world > 1 else None)
     batch = synth_batch(1234 + rank, B, S, C, H, W, T, device)
 
     def barrier():

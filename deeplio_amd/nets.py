@@ -606,6 +606,9 @@ class DeepLIO(BaseNet):
         self.drop = self.fc_pos = self.fc_ori = None
         self.side_stream = True      # overlap the IMU branch with the lidar branch
         self._side = None
+        # data parallel: called (from backward) when the gradients of everything behind the
+        # feature nets -- odometry net, heads -- are complete (deeplio_amd.dist.GradSync)
+        self.tail_grads_ready = None
 
     def initialize(self):
         last = next(n for n in (self.odom_feat_net, self.fusion_net, self.imu_feat_net,
@@ -645,6 +648,10 @@ class DeepLIO(BaseNet):
             last = feat_i
         if self.fusion_net is not None:
             last = self.fusion_net([feat_l, feat_i])
+        if (self.tail_grads_ready is not None and self.training and torch.is_tensor(last)
+                and last.requires_grad):
+            cb = self.tail_grads_ready
+            last.register_hook(lambda g: cb())
         if self.odom_feat_net is not None:
             last = self.odom_feat_net(last)
         last = Fh.dropout(last, self.p, self.training)

@@ -27,9 +27,28 @@ class TrainStep:
                                            {'params': self.criterion.parameters()}], cfg, self.args)
         self.max_glob_seq = max_glob_seq            # trainer.py:42
         self.flags = torch.zeros(2, dtype=torch.int32, device=self.device)   # [nonfinite, se3 status]
-        self.grad_sync = grad_sync
+        self.grad_sync = None
         self.model.train()
+        if grad_sync is not None:
+            self.set_grad_sync(grad_sync)
         self.criterion.train()
+
+    def tail_offset(self):
+        """flat-buffer offset of the first parameter behind the feature nets (odometry net, else the
+        heads): everything from there on is final when backward reaches the fusion output"""
+        m = self.model
+        first = next((p for n in (m.odom_feat_net, m.fc_pos) if n is not None for p in n.parameters()), None)
+        if first is None:
+            return None
+        index = {id(p): i for i, p in enumerate(self.optimizer.params)}
+        return self.optimizer.offsets[index[id(first)]]
+
+    def set_grad_sync(self, sync):
+        """data parallel: gradient exchange in two buckets, the tail one overlapped with backward"""
+        self.grad_sync = sync
+        if sync is not None and sync.world > 1:
+            sync.set_tail(self.tail_offset())
+            self.model.tail_grads_ready = sync.reduce_tail_async if sync.tail_lo is not None else None
 
     def step(self, imgs, normals, imus, gts_f2f, gts_f2g):
         gt_f2f_t, gt_f2f_w = gts_f2f[:, :, 0:3], gts_f2f[:, :, 3:]

@@ -169,6 +169,19 @@ sync.broadcast_parameters()
 assert torch.equal(flat, torch.full((1000,), 1.0))          # rank 0's parameters everywhere
 sync.all_reduce_grads()
 assert torch.equal(grad, torch.arange(1000, dtype=torch.float32) * 3) and opt.grad_scale == 0.5
+# two buckets: the tail is reduced asynchronously (as from the backward hook), the head afterwards
+grad2 = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+sync2 = ddist.GradSync(flat, grad2, opt)
+sync2.set_tail(640)
+assert sync2.tail_lo == 640
+sync2.reduce_tail_async()
+sync2.reduce_tail_async()                                   # idempotent within a step
+sync2.all_reduce_grads()
+assert torch.equal(grad2, torch.arange(1000, dtype=torch.float32) * 3) and sync2._tail_work is None
+grad2.copy_(torch.arange(1000, dtype=torch.float32) * (rank + 1))
+sync2.all_reduce_grads()                                    # hook did not fire: one full all-reduce
+assert torch.equal(grad2, torch.arange(1000, dtype=torch.float32) * 3)
+sync2.set_tail(0); assert sync2.tail_lo is None
 assert list(ddist.shard_batch(8, world, rank)) == list(range(rank * 4, rank * 4 + 4))
 assert sync.max_over_ranks(float(rank)) == 1.0
 dist.barrier(); dist.destroy_process_group()

@@ -226,3 +226,43 @@ def test_stream_overlap_is_bit_exact(dev):
             assert len(a_step) == len(b_step)
             for a, b in zip(a_step, b_step):
                 assert torch.equal(a, b)
+
+
+def test_dp_tail_bucket_is_final_when_the_hook_fires(dev):
+    """Data parallel: the all-reduce of the odometry-net / head gradients (87 % of the flat buffer)
+    is started from an autograd hook on the fusion output.  Property that makes this correct: at
+    that point, on the hook's stream, flat_grad[tail:] already holds its final value, and nothing
+    in the head of the buffer aliases it."""
+    from deeplio_amd.config import make_config
+    from deeplio_amd.trainer import TrainStep
+    cfg = make_config(seq=2)
+    ts = TrainStep(cfg, (5, 64, 256), dev, 2)
+    batch = tuple(t.to(dev) for t in gc.make_batch(3, 2, 2, 5, 64, 256, 50))
+    seen = {}
+
+    class FakeSync:
+        world, tail_lo = 2, None
+
+        def set_tail(self, lo):
+            self.tail_lo = lo
+
+        def reduce_tail_async(self):
+            seen['tail'] = ts.optimizer.grad[self.tail_lo:].clone()      # on the hook's stream
+            seen['calls'] = seen.get('calls', 0) + 1
+
+        def all_reduce_grads(self):
+            seen['final'] = ts.optimizer.grad.clone()
+
+    sync = FakeSync()
+    ts.set_grad_sync(sync)
+    lo = sync.tail_lo
+    n = ts.optimizer.grad.numel()
+    assert lo is not None and 0 < lo < n and lo % 16 == 0
+    assert (n - lo) > 0.8 * n                      # the odometry LSTM dominates the parameter count
+    first_odom = next(ts.model.odom_feat_net.parameters())
+    assert first_odom.data_ptr() == ts.optimizer.flat.data_ptr() + 4 * lo
+    ts.step(*batch)
+    torch.cuda.synchronize()
+    assert seen['calls'] == 1
+    assert torch.equal(seen['tail'], seen['final'][lo:])
+    assert float(seen['final'][lo:].abs().max()) > 0 and float(seen['final'][:lo].abs().max()) > 0
