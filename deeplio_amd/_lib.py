@@ -39,6 +39,7 @@ SIGNATURES = {
     "dlio_prof_collect": (_i, [_i, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d), C.POINTER(_i64)]),
     "dlio_conv2d_prep_weight_floats": (_sz, [_i, _i, _i, _i, _i]),
     "dlio_conv2d_prep_weight": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "dlio_conv2d_prep_weights_batched": (_i, [_p, _i, _i64, _p]),
     "dlio_conv2d_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _cd, _p]),
     "dlio_conv2d_dgrad_strided": (_i, [_p, _p, _p, _cd, _p]),
     "dlio_conv2d_wgrad_ws_bytes": (_sz, [_cd]),

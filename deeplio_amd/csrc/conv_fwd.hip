@@ -577,7 +577,41 @@ __global__ void prep_weight_kernel(const float* __restrict__ w, float* __restric
   }
 }
 
+// all convolution weights of a model in ONE launch (146 prep launches per training step before)
+__global__ void prep_weights_batched_kernel(const DlioPrepItem* __restrict__ items, int n_items,
+                                            int64_t total) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int lo = 0, hi = n_items - 1;                 // last item with start <= i
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (items[mid].start <= i) lo = mid; else hi = mid - 1;
+    }
+    const DlioPrepItem it = items[lo];
+    const int64_t e = i - it.start;
+    const int K = it.mode == 0 ? it.Cin : it.Cout, Nn = it.mode == 0 ? it.Cout : it.Cin;
+    const int KPAD = (K + 15) & ~15;
+    const int nn = (int)(e % Nn);
+    const int k = (int)((e / Nn) % KPAD);
+    const int tap = (int)(e / ((int64_t)Nn * KPAD));
+    float v = 0.f;
+    if (k < K) {
+      if (it.mode == 0) v = it.w[((int64_t)nn * it.Cin + k) * it.taps + tap];
+      else v = it.w[((int64_t)k * it.Cin + nn) * it.taps + (it.taps - 1 - tap)];
+    }
+    it.wt[e] = v;
+  }
+}
+
 }  // namespace
+
+extern "C" int dlio_conv2d_prep_weights_batched(const DlioPrepItem* items_dev, int n_items,
+                                                int64_t total_floats, dlio_stream_t stream) {
+  if (!items_dev || n_items <= 0 || total_floats <= 0) return DLIO_EINVAL;
+  hipLaunchKernelGGL(prep_weights_batched_kernel, dim3(ew_grid(total_floats, 256)), dim3(256), 0,
+                     as_stream(stream), items_dev, n_items, total_floats);
+  return dlio_check_launch();
+}
 
 extern "C" size_t dlio_conv2d_prep_weight_floats(int Cout, int Cin, int KH, int KW, int mode) {
   if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || (mode != 0 && mode != 1)) return 0;

@@ -4,6 +4,8 @@ translate status codes.  torch is used here only for device memory and streams.
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib
@@ -75,6 +77,101 @@ def conv2d_prep_weight(w, mode, out=None):
     check(lib.dlio_conv2d_prep_weight(_ptr(w), _ptr(out), Cout, Cin, KH, KW, mode, _stream()),
           "conv2d_prep_weight")
     return out
+
+
+# ---- prepped-weight cache: all conv weights of the model are re-laid-out in ONE launch ----------
+# Weights change once per optimizer step; forward needs layout 0 and backward layout 1 of every
+# conv weight.  Instead of 2 small launches per conv and step (146 for PointSeg), every weight that
+# passes through `conv2d_prepped` is registered, and the first request of a new "weights epoch"
+# refreshes ALL registered buffers with dlio_conv2d_prep_weights_batched.  Staleness is detected by
+# (epoch, tensor._version): the epoch is bumped by our optimizer kernels (`weights_changed`), the
+# version counter by any in-place torch op (load_state_dict, copy_, broadcast).
+import ctypes as _ct
+import weakref as _weakref
+
+
+class _PrepItemC(_ct.Structure):
+    _fields_ = [("w", _ct.c_void_p), ("wt", _ct.c_void_p), ("Cout", _ct.c_int32), ("Cin", _ct.c_int32),
+                ("taps", _ct.c_int32), ("mode", _ct.c_int32), ("start", _ct.c_int64)]
+
+
+class _PrepCache:
+    def __init__(self):
+        self.epoch = 0
+        self.entries = {}        # (device index, data_ptr, shape, mode) -> dict
+        self.tables = {}         # device index -> dict(items_dev, n, total, keys)
+        self.waited = {}         # stream handle -> last refresh event it waited for
+        self.batched = os.environ.get("DLIO_BATCHED_PREP", "1") != "0"
+
+    def get(self, w, mode):
+        dev = w.device.index if w.device.index is not None else torch.cuda.current_device()
+        key = (dev, w.data_ptr(), tuple(w.shape), mode)
+        e = self.entries.get(key)
+        if e is None or e["ref"]() is None:
+            Cout, Cin, KH, KW = w.shape
+            e = dict(ref=_weakref.ref(w), epoch=-1, version=-1, stream=None, event=None,
+                     out=torch.empty(lib.dlio_conv2d_prep_weight_floats(Cout, Cin, KH, KW, mode),
+                                     dtype=torch.float32, device=w.device))
+            self.entries[key] = e
+            self.tables.pop(dev, None)
+        cur = torch.cuda.current_stream()
+        if e["epoch"] != self.epoch or e["version"] != w._version:
+            if self.batched:
+                self._refresh_all(dev, cur)
+            if e["epoch"] != self.epoch or e["version"] != w._version:     # newly registered / batching off
+                Cout, Cin, KH, KW = w.shape
+                check(lib.dlio_conv2d_prep_weight(_ptr(w), _ptr(e["out"]), Cout, Cin, KH, KW, mode, _stream()),
+                      "conv2d_prep_weight")
+                e.update(epoch=self.epoch, version=w._version, stream=cur.cuda_stream, event=None)
+        elif e["stream"] != cur.cuda_stream and e["event"] is not None:
+            # prepped on another stream in this epoch: one wait per (stream, refresh event)
+            if self.waited.get(cur.cuda_stream) is not e["event"]:
+                cur.wait_event(e["event"])
+                self.waited[cur.cuda_stream] = e["event"]
+        return e["out"]
+
+    def _refresh_all(self, dev, cur):
+        t = self.tables.get(dev)
+        if t is None:
+            live = [(k, e) for k, e in self.entries.items() if k[0] == dev and e["ref"]() is not None
+                    and e["epoch"] >= 0]                 # only weights that were used before
+            for k in [k for k, e in self.entries.items() if e["ref"]() is None]:
+                del self.entries[k]
+            if not live:
+                return
+            arr = (_PrepItemC * len(live))()
+            start = 0
+            for i, (k, e) in enumerate(live):
+                w = e["ref"]()
+                Cout, Cin, KH, KW = w.shape
+                arr[i] = _PrepItemC(w.data_ptr(), e["out"].data_ptr(), Cout, Cin, KH * KW, k[3], start)
+                start += e["out"].numel()
+            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
+            t = dict(items=raw.to(torch.device("cuda", dev)), n=len(live), total=start, keys=[k for k, _ in live])
+            self.tables[dev] = t
+        check(lib.dlio_conv2d_prep_weights_batched(_ptr(t["items"]), t["n"], t["total"], _stream()),
+              "conv2d_prep_weights_batched")
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        for k in t["keys"]:
+            e = self.entries.get(k)
+            w = e["ref"]() if e is not None else None
+            if w is not None:
+                e.update(epoch=self.epoch, version=w._version, stream=cur.cuda_stream, event=ev)
+
+
+_PREP = _PrepCache()
+
+
+def weights_changed():
+    """call after parameters were modified through raw pointers (our optimizer kernels)"""
+    _PREP.epoch += 1
+
+
+def conv2d_prepped(w, mode):
+    """cached dlio_conv2d_prep_weight(w, mode); see _PrepCache"""
+    _chk(w)
+    return _PREP.get(w, mode)
 
 
 def conv2d_fwd(x, wt, bias, y, desc, in_aff=None, residual=None):
@@ -534,12 +631,14 @@ def velo_image(proj_xyz, proj_remission, normals, proj_range, max_depth, channel
 
 # ----------------------------------------------------------------------------- optimizer
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+    weights_changed()
     check(lib.dlio_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(beta1),
                              float(beta2), float(eps), float(wd), int(step), float(grad_scale),
                              _stream()), "adam_step")
 
 
 def sgd_step(p, g, buf, lr, momentum, wd, step, grad_scale=1.0):
+    weights_changed()
     check(lib.dlio_sgd_step(_ptr(p), _ptr(g), _ptr(buf), p.numel(), float(lr), float(momentum),
                             float(wd), int(step), float(grad_scale), _stream()), "sgd_step")
 

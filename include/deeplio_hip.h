@@ -72,6 +72,18 @@ typedef struct DlioConvDesc {
  *                          (mode 1, data-gradient layout for stride-1 convs)
  * rows k >= K are zero.  dlio_conv2d_prep_weight_floats = number of floats of wt. */
 size_t dlio_conv2d_prep_weight_floats(int Cout, int Cin, int KH, int KW, int mode);
+/* The same transform for many weight tensors in ONE launch (all convolutions of a model, both
+ * modes, once per optimizer step).  items_dev: DEVICE array; item i covers the floats
+ * [start, start + dlio_conv2d_prep_weight_floats(...)) of the concatenated output index space,
+ * starts ascending from 0; total_floats = end of the last item. */
+typedef struct DlioPrepItem {
+  const float* w;   /* [Cout][Cin][KH][KW] */
+  float* wt;        /* prepped layout, dlio_conv2d_prep_weight_floats floats */
+  int32_t Cout, Cin, taps, mode;
+  int64_t start;
+} DlioPrepItem;
+int dlio_conv2d_prep_weights_batched(const DlioPrepItem* items_dev, int n_items,
+                                     int64_t total_floats, dlio_stream_t stream);
 int dlio_conv2d_prep_weight(const float* w, float* wt, int Cout, int Cin, int KH, int KW,
                             int mode, dlio_stream_t stream);
 
