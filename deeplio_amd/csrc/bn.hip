@@ -272,6 +272,161 @@ __global__ void bn_param_grads_kernel(const double* __restrict__ sum_g,
   if (dbeta) dbeta[c] = (float)sum_g[c];
 }
 
+// ---- plane-structured apply kernels: one workgroup per (n, c) plane (or plane chunk) ---------
+// The workgroup first sums the split partials of ITS channel (<= 512 doubles, fixed order: every
+// workgroup of the channel computes bit-identical statistics) and finalises them itself, so the
+// separate finalise launches (74 + 74 tiny kernels per training step) disappear without any
+// cross-workgroup hand-off; the workgroup of plane (n=0, chunk 0) publishes mean / invstd / scale,
+// the running statistics and dgamma / dbeta.  Optional by-product: the global average of every
+// output plane (the SELayer that follows a Fire block needs it) -- same thread/element mapping
+// and fp64 accumulation as gap_fwd_kernel, so bit-identical to a separate pass.
+__device__ __forceinline__ void plane_partials(const double* __restrict__ part, int c, int splits,
+                                               double* sm0, double* sm1, double& a, double& b) {
+  double ta = 0.0, tb = 0.0;
+  for (int q = threadIdx.x; q < splits; q += 256) {
+    ta += part[((size_t)c * splits + q) * 2 + 0];
+    tb += part[((size_t)c * splits + q) * 2 + 1];
+  }
+  __shared__ double bc[2];
+  ta = block_sum_d(ta, sm0);
+  tb = block_sum_d(tb, sm1);
+  if (threadIdx.x == 0) { bc[0] = ta; bc[1] = tb; }
+  __syncthreads();
+  a = bc[0]; b = bc[1];
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_plane_apply_kernel(
+    const float* __restrict__ x, int x_ctot, int x_coff, const double* __restrict__ part, int splits,
+    double count, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    float momentum, float* running_mean, float* running_var, float* mean_o, float* invstd_o,
+    float* scale_o, const float* residual, int r_ctot, int r_coff, float* y, int y_ctot, int y_coff,
+    int N, int C, int HW, int pre_relu, int post_relu, int chunks, int chunk_len,
+    float* __restrict__ gap_out, int gap_ctot, int gap_coff) {
+  __shared__ double sm[2][16];
+  const int chunk = blockIdx.x % chunks;
+  const int pl = blockIdx.x / chunks;
+  const int n = pl / C, c = pl - n * C;
+  double a, b;
+  plane_partials(part, c, splits, sm[0], sm[1], a, b);
+  const double m = a / count;
+  double var = b / count - m * m;
+  if (var < 0.0) var = 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  const float mu = (float)m, sc = (gamma ? gamma[c] : 1.f) * is, be = beta ? beta[c] : 0.f;
+  if (n == 0 && chunk == 0 && threadIdx.x == 0) {
+    mean_o[c] = mu; invstd_o[c] = is; scale_o[c] = sc;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+    if (running_var) {
+      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+  }
+  const float* xp = x + ((size_t)n * x_ctot + x_coff + c) * HW;
+  float* yp = y + ((size_t)n * y_ctot + y_coff + c) * HW;
+  const float* rp = residual ? residual + ((size_t)n * r_ctot + r_coff + c) * HW : nullptr;
+  const int per = VEC ? (HW >> 2) : HW;
+  const int i1 = min(per, (chunk + 1) * chunk_len);
+  double gs = 0.0;
+  for (int i = chunk * chunk_len + threadIdx.x; i < i1; i += 256) {
+    if (VEC) {
+      const float4 v = *reinterpret_cast<const float4*>(xp + ((size_t)i << 2));
+      float e[4] = {v.x, v.y, v.z, v.w};
+      float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rp) rv = *reinterpret_cast<const float4*>(rp + ((size_t)i << 2));
+      const float re[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float xx = pre_relu ? fmaxf(e[k], 0.f) : e[k];
+        float o = (xx - mu) * sc + be;
+        if (post_relu) o = fmaxf(o, 0.f);
+        e[k] = o + re[k];
+      }
+      *reinterpret_cast<float4*>(yp + ((size_t)i << 2)) = make_float4(e[0], e[1], e[2], e[3]);
+      gs += (double)((e[0] + e[1]) + (e[2] + e[3]));
+    } else {
+      float xx = xp[i];
+      if (pre_relu) xx = fmaxf(xx, 0.f);
+      float o = (xx - mu) * sc + be;
+      if (post_relu) o = fmaxf(o, 0.f);
+      if (rp) o += rp[i];
+      yp[i] = o;
+      gs += o;
+    }
+  }
+  if (gap_out) {                       // chunks == 1 whenever gap_out is set
+    const double r = block_sum_d(gs, sm[0]);
+    if (threadIdx.x == 0) gap_out[(size_t)n * gap_ctot + gap_coff + c] = (float)(r / (double)HW);
+  }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_plane_bwd_kernel(
+    const float* __restrict__ dy, int dy_ctot, int dy_coff, const float* __restrict__ x, int x_ctot,
+    int x_coff, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ scale, const float* __restrict__ beta, const double* __restrict__ part,
+    int splits, float* dx, int dx_ctot, int dx_coff, float* dgamma, float* dbeta, int accumulate,
+    int N, int C, int HW, int pre_relu, int post_relu, int use_batch_stats, int chunks, int chunk_len) {
+  __shared__ double sm[2][16];
+  const int chunk = blockIdx.x % chunks;
+  const int pl = blockIdx.x / chunks;
+  const int n = pl / C, c = pl - n * C;
+  double sg, sgx;
+  plane_partials(part, c, splits, sm[0], sm[1], sg, sgx);
+  if (n == 0 && chunk == 0 && threadIdx.x == 0) {
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)sg : (float)sg;
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)sgx : (float)sgx;
+  }
+  const float mu = mean[c], is = invstd[c], sc = scale[c], be = beta ? beta[c] : 0.f;
+  const double inv_cnt = 1.0 / ((double)N * HW);
+  float mg = 0.f, mgx = 0.f;
+  if (use_batch_stats) { mg = (float)(sg * inv_cnt); mgx = (float)(sgx * inv_cnt); }
+  const float* gp = dy + ((size_t)n * dy_ctot + dy_coff + c) * HW;
+  const float* xp = x + ((size_t)n * x_ctot + x_coff + c) * HW;
+  float* op = dx + ((size_t)n * dx_ctot + dx_coff + c) * HW;
+  const int per = VEC ? (HW >> 2) : HW;
+  const int i1 = min(per, (chunk + 1) * chunk_len);
+  constexpr int V = VEC ? 4 : 1;
+  for (int i = chunk * chunk_len + threadIdx.x; i < i1; i += 256) {
+    float ge[4], xe[4];
+    if (VEC) {
+      const float4 gv = *reinterpret_cast<const float4*>(gp + ((size_t)i << 2));
+      const float4 xv = *reinterpret_cast<const float4*>(xp + ((size_t)i << 2));
+      ge[0] = gv.x; ge[1] = gv.y; ge[2] = gv.z; ge[3] = gv.w;
+      xe[0] = xv.x; xe[1] = xv.y; xe[2] = xv.z; xe[3] = xv.w;
+    } else {
+      ge[0] = gp[i]; xe[0] = xp[i];
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const float xraw = xe[k];
+      const float xx = pre_relu ? fmaxf(xraw, 0.f) : xraw;
+      float g = ge[k];
+      if (post_relu && !((xx - mu) * sc + be > 0.f)) g = 0.f;
+      const float xh = (xx - mu) * is;
+      float o = sc * (g - mg - xh * mgx);
+      if (pre_relu && !(xraw > 0.f)) o = 0.f;
+      ge[k] = o;
+    }
+    if (VEC) *reinterpret_cast<float4*>(op + ((size_t)i << 2)) = make_float4(ge[0], ge[1], ge[2], ge[3]);
+    else op[i] = ge[0];
+  }
+}
+
+// chunks per plane: one when planes alone fill the chip (or the plane average is wanted), else
+// enough for ~2048 workgroups; chunk_len is a multiple of 256 work items
+static void plane_chunks(int planes, int per, bool whole_plane, int& chunks, int& chunk_len) {
+  chunks = 1;
+  if (!whole_plane && planes < 2048) {
+    chunks = cdiv(2048, planes);
+    const int maxc = cdiv(per, 512);
+    if (chunks > maxc) chunks = maxc;
+    if (chunks < 1) chunks = 1;
+  }
+  chunk_len = cdiv(cdiv(per, chunks), 256) * 256;
+  chunks = cdiv(per, chunk_len);
+}
+
 }  // namespace
 
 extern "C" size_t dlio_chan_stats_ws_bytes(int N, int C, int HW) {
@@ -420,4 +575,71 @@ extern "C" int dlio_bn_bwd_apply(const float* dy, int dy_ctot, int dy_coff, cons
     rc = dlio_check_launch();
   }
   return rc;
+}
+
+// ---- statistics + apply / backward in two launches (reduce, plane kernel) --------------------
+extern "C" int dlio_bn_train_apply(const float* x, int N, int x_ctot, int x_coff, int C, int HW,
+                                   int pre_relu, int post_relu, const float* gamma, const float* beta,
+                                   float eps, float momentum, float* running_mean, float* running_var,
+                                   float* mean, float* invstd, float* scale, const float* residual,
+                                   int r_ctot, int r_coff, float* y, int y_ctot, int y_coff,
+                                   float* gap_out, int gap_ctot, int gap_coff, void* ws,
+                                   size_t ws_bytes, dlio_stream_t stream) {
+  if (!x || !y || !mean || !invstd || !scale || N <= 0 || C <= 0 || HW <= 0 || !ws) return DLIO_EINVAL;
+  const int splits = pick_splits(N, C, HW);
+  if (ws_bytes < (size_t)C * splits * 2 * sizeof(double)) return DLIO_EWS;
+  hipStream_t s = as_stream(stream);
+  double* part = reinterpret_cast<double*>(ws);
+  hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3((unsigned)(C * splits)), dim3(RB), 0, s, x, x_ctot, x_coff,
+                     (const float*)nullptr, 0, 0, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, N, C, HW, pre_relu, 0, splits, part);
+  int rc = dlio_check_launch();
+  if (rc) return rc;
+  const bool vec = (HW & 3) == 0;
+  int chunks, chunk_len;
+  plane_chunks(N * C, vec ? HW / 4 : HW, gap_out != nullptr, chunks, chunk_len);
+  const dim3 grid((unsigned)(N * C * chunks));
+  if (vec)
+    hipLaunchKernelGGL(bn_plane_apply_kernel<true>, grid, dim3(256), 0, s, x, x_ctot, x_coff, part, splits,
+                       (double)N * HW, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
+                       scale, residual, r_ctot, r_coff, y, y_ctot, y_coff, N, C, HW, pre_relu, post_relu,
+                       chunks, chunk_len, gap_out, gap_ctot, gap_coff);
+  else
+    hipLaunchKernelGGL(bn_plane_apply_kernel<false>, grid, dim3(256), 0, s, x, x_ctot, x_coff, part, splits,
+                       (double)N * HW, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
+                       scale, residual, r_ctot, r_coff, y, y_ctot, y_coff, N, C, HW, pre_relu, post_relu,
+                       chunks, chunk_len, gap_out, gap_ctot, gap_coff);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_bn_bwd(const float* dy, int dy_ctot, int dy_coff, const float* x, int x_ctot,
+                           int x_coff, const float* mean, const float* invstd, const float* scale,
+                           const float* beta, float* dx, int dx_ctot, int dx_coff, float* dgamma,
+                           float* dbeta, int accumulate, int N, int C, int HW, int pre_relu,
+                           int post_relu, int use_batch_stats, void* ws, size_t ws_bytes,
+                           dlio_stream_t stream) {
+  if (!dy || !x || !mean || !invstd || !scale || !dx || N <= 0 || C <= 0 || HW <= 0 || !ws)
+    return DLIO_EINVAL;
+  const int splits = pick_splits(N, C, HW);
+  if (ws_bytes < (size_t)C * splits * 2 * sizeof(double)) return DLIO_EWS;
+  hipStream_t s = as_stream(stream);
+  double* part = reinterpret_cast<double*>(ws);
+  hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3((unsigned)(C * splits)), dim3(RB), 0, s, dy, dy_ctot,
+                     dy_coff, x, x_ctot, x_coff, mean, invstd, scale, beta, N, C, HW, pre_relu, post_relu,
+                     splits, part);
+  int rc = dlio_check_launch();
+  if (rc) return rc;
+  const bool vec = (HW & 3) == 0;
+  int chunks, chunk_len;
+  plane_chunks(N * C, vec ? HW / 4 : HW, false, chunks, chunk_len);
+  const dim3 grid((unsigned)(N * C * chunks));
+  if (vec)
+    hipLaunchKernelGGL(bn_plane_bwd_kernel<true>, grid, dim3(256), 0, s, dy, dy_ctot, dy_coff, x, x_ctot,
+                       x_coff, mean, invstd, scale, beta, part, splits, dx, dx_ctot, dx_coff, dgamma, dbeta,
+                       accumulate, N, C, HW, pre_relu, post_relu, use_batch_stats, chunks, chunk_len);
+  else
+    hipLaunchKernelGGL(bn_plane_bwd_kernel<false>, grid, dim3(256), 0, s, dy, dy_ctot, dy_coff, x, x_ctot,
+                       x_coff, mean, invstd, scale, beta, part, splits, dx, dx_ctot, dx_coff, dgamma, dbeta,
+                       accumulate, N, C, HW, pre_relu, post_relu, use_batch_stats, chunks, chunk_len);
+  return dlio_check_launch();
 }

@@ -20,6 +20,7 @@ def _new(shape, like):
 
 
 _SINK = [True]
+_PLANE_BN = [os.environ.get("DLIO_PLANE_BN", "1") != "0"]
 
 
 def set_grad_sink(on):
@@ -104,13 +105,19 @@ class _CBR:
     @staticmethod
     def forward(x, x_ctot, x_coff, Cin, H, W, weight, bias, gamma, beta, rmean, rvar, stride, pad,
                 training, momentum, eps, pre_relu, post_relu, raw, raw_ctot, raw_coff, out, out_ctot,
-                out_coff, N, residual=None, r_ctot=0, r_coff=0):
+                out_coff, N, residual=None, r_ctot=0, r_coff=0, gap=None, gap_ctot=0, gap_coff=0):
         Cout, _, KH, KW = weight.shape
         d = ops.conv_desc(N, Cin, H, W, Cout, KH, KW, stride[0], stride[1], pad[0], pad[1],
                           in_ctot=x_ctot, in_coff=x_coff, out_ctot=raw_ctot, out_coff=raw_coff)
         wt = ops.conv2d_prepped(weight, 0)
         ops.conv2d_fwd(x, wt, bias, raw, d)
         OHW = d.OH * d.OW
+        if training and _PLANE_BN[0]:
+            # statistics + finalise + apply (+ the plane averages an SELayer wants) in 2 launches
+            prm = ops.bn_train_apply(raw, raw_ctot, raw_coff, gamma, beta, eps, momentum, rmean, rvar, out,
+                                     out_ctot, out_coff, N, Cout, OHW, pre_relu, post_relu, residual, r_ctot,
+                                     r_coff, gap, gap_ctot, gap_coff)
+            return d, prm
         if training:
             prm = ops.bn_train_stats(raw, N, raw_ctot, raw_coff, Cout, OHW, pre_relu, gamma, eps,
                                      momentum, rmean, rvar)
@@ -134,8 +141,9 @@ class _CBR:
             dgamma, acc_g, ret_g = _new((Cout,), dy), False, None
             dbeta, acc_b, ret_b = _new((Cout,), dy), False, None
             ret_g, ret_b = dgamma, dbeta
-        ops.bn_bwd(dy, dy_ctot, dy_coff, raw, d.out_ctot, d.out_coff, prm, beta, draw, Cout, 0, N,
-                   Cout, OHW, pre_relu, post_relu, training, dgamma, dbeta, accumulate=acc_g)
+        (ops.bn_bwd_fused if _PLANE_BN[0] else ops.bn_bwd)(
+            dy, dy_ctot, dy_coff, raw, d.out_ctot, d.out_coff, prm, beta, draw, Cout, 0, N,
+            Cout, OHW, pre_relu, post_relu, training, dgamma, dbeta, accumulate=acc_g)
         ret_bias = None
         if bias is not None:
             dbias, acc, ret_bias = _sink(bias, (Cout,), dy)
@@ -230,7 +238,7 @@ class FireFn(Function):
 
     @staticmethod
     def forward(ctx, x, sw, sb, sg, sbe, srm, srv, e1w, e1b, e1g, e1be, e1rm, e1rv, e3w, e3b, e3g,
-                e3be, e3rm, e3rv, training, momentum, eps, bypass):
+                e3be, e3rm, e3rv, training, momentum, eps, bypass, want_gap=False):
         x = x.contiguous()
         N, Cin, H, W = x.shape
         S_, E1, E3 = sw.shape[0], e1w.shape[0], e3w.shape[0]
@@ -240,19 +248,28 @@ class FireFn(Function):
                                   training, momentum, eps, False, True, raw_s, S_, 0, act_s, S_, 0, N)
         raw_e, out = _new((N, CE, H, W), x), _new((N, CE, H, W), x)
         res = x if bypass else None
+        # plane averages of the block output for the SELayer behind it: a by-product of the BN
+        # apply kernels in training, one extra pass otherwise
+        fused_gap = want_gap and training and _PLANE_BN[0]
+        gap = _new((N, CE), x) if fused_gap else None
         d_1, prm_1 = _CBR.forward(act_s, S_, 0, S_, H, W, e1w, e1b, e1g, e1be, e1rm, e1rv, (1, 1),
                                   (0, 0), training, momentum, eps, False, True, raw_e, CE, 0, out,
-                                  CE, 0, N, res, Cin, 0)
+                                  CE, 0, N, res, Cin, 0, gap, CE, 0)
         d_3, prm_3 = _CBR.forward(act_s, S_, 0, S_, H, W, e3w, e3b, e3g, e3be, e3rm, e3rv, (1, 1),
                                   (1, 1), training, momentum, eps, False, True, raw_e, CE, E1, out,
-                                  CE, E1, N, res, Cin, E1)
+                                  CE, E1, N, res, Cin, E1, gap, CE, E1)
         ctx.save_for_backward(x, sw, sbe, e1w, e1be, e3w, e3be, raw_s, act_s, raw_e, prm_s, prm_1,
                               prm_3, sb, sg, e1b, e1g, e3b, e3g)
         ctx.cfg = (d_s, d_1, d_3, training, bypass)
-        return out
+        if not want_gap:
+            return out
+        if gap is None:
+            gap = ops.gap_fwd(out, N, CE, 0, CE, H * W)
+        ctx.mark_non_differentiable(gap)      # the SELayer differentiates through `out` itself
+        return out, gap
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, *_unused_dgap):
         (x, sw, sbe, e1w, e1be, e3w, e3be, raw_s, act_s, raw_e, prm_s, prm_1, prm_3, sb, sg, e1b, e1g,
          e3b, e3g) = ctx.saved_tensors
         d_s, d_1, d_3, training, bypass = ctx.cfg
@@ -275,7 +292,7 @@ class FireFn(Function):
         gs = _CBR.backward(dact_s, S_, 0, x, d_s, sw, sb, sg, prm_s, sbe, raw_s, training, False, True,
                            draw_s, need_dx, dx, Cin, 0, dout if bypass else None, CE, 0)
         return (dx, gs[0], gs[1], gs[2], gs[3], None, None, g1[0], g1[1], g1[2], g1[3], None, None,
-                g3[0], g3[1], g3[2], g3[3], None, None, None, None, None, None)
+                g3[0], g3[1], g3[2], g3[3], None, None, None, None, None, None, None)
 
 
 # =============================================================================== pooling / SE
@@ -302,10 +319,10 @@ class SEPoolFn(Function):
     scaled full-resolution tensor is never written.  pool=None gives the plain SELayer."""
 
     @staticmethod
-    def forward(ctx, x, w1, w2, pool):
+    def forward(ctx, x, w1, w2, pool, gap=None):
         x = x.contiguous()
         N, C_, H, W = x.shape
-        g = ops.gap_fwd(x, N, C_, 0, C_, H * W)
+        g = gap if gap is not None else ops.gap_fwd(x, N, C_, 0, C_, H * W)
         h = ops.linear_fwd(g, w1, None, ops.ACT_RELU)
         s = ops.linear_fwd(h, w2, None, ops.ACT_SIGMOID)
         if pool is None:
@@ -349,7 +366,7 @@ class SEPoolFn(Function):
                                    x_scale=s, x_add=ops.ew_scale(dg, 1.0 / (H * W)))
         else:
             ops.gap_bwd(dg, dx, N, C_, H * W, accumulate=True)
-        return dx, ret1, ret2, None
+        return dx, ret1, ret2, None, None
 
 
 class GapFn(Function):

@@ -93,7 +93,8 @@ class Fire(nn.Module):
             raise ValueError("Fire bypass 'complex' (1x1 upsample) is not built by PSEncoder")
         self.residual = bypass == "simple" and same
 
-    def forward(self, x):
+    def forward(self, x, want_gap=False):
+        """want_gap: also return the [N, C] plane averages of the output (for a following SELayer)"""
         tr = self.training
         s, sb, e1, e1b, e3, e3b = (self.squeeze, self.squeeze_bn, self.expand1x1, self.expand1x1_bn,
                                    self.expand3x3, self.expand3x3_bn)
@@ -102,7 +103,7 @@ class Fire(nn.Module):
         return Fh.FireFn.apply(x, s.weight, s.bias, sb.weight, sb.bias, sb.running_mean, sb.running_var,
                                e1.weight, e1.bias, e1b.weight, e1b.bias, e1b.running_mean, e1b.running_var,
                                e3.weight, e3.bias, e3b.weight, e3b.bias, e3b.running_mean, e3b.running_var,
-                               tr, sb.momentum, sb.eps, self.residual)
+                               tr, sb.momentum, sb.eps, self.residual, want_gap)
 
 
 class SELayer(nn.Module):
@@ -113,8 +114,8 @@ class SELayer(nn.Module):
         self.fc = nn.Sequential(nn.Linear(in_features, in_features // reduction, bias=False), nn.ReLU(),
                                 nn.Linear(in_features // reduction, in_features, bias=False), nn.Sigmoid())
 
-    def forward(self, x, pool=None):
-        return Fh.SEPoolFn.apply(x, self.fc[0].weight, self.fc[2].weight, pool)
+    def forward(self, x, pool=None, gap=None):
+        return Fh.SEPoolFn.apply(x, self.fc[0].weight, self.fc[2].weight, pool, gap)
 
 
 class MaxPool(nn.Module):
@@ -168,12 +169,19 @@ class PSEncoder(BaseNet):
         for name, *_ in PS_BLOCKS:
             mods = list(getattr(self, name))
             i = 0
+            gap = None
             while i < len(mods):
                 m = mods[i]
                 if isinstance(m, SELayer) and i + 1 < len(mods) and isinstance(mods[i + 1], MaxPool):
                     p = mods[i + 1]
-                    x = m(x, (p.k, p.stride, p.pad))
+                    x = m(x, (p.k, p.stride, p.pad), gap)
                     i += 2
+                elif isinstance(m, SELayer):
+                    x = m(x, None, gap)
+                    i += 1
+                elif isinstance(m, Fire) and i + 1 < len(mods) and isinstance(mods[i + 1], SELayer):
+                    x, gap = m(x, want_gap=True)       # the SELayer's squeeze comes out of the BN apply
+                    i += 1
                 else:
                     x = m(x)
                     i += 1

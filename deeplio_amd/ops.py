@@ -236,6 +236,31 @@ def bn_train_stats(x, N, ctot, coff, C_, HW, pre_relu, gamma, eps, momentum, run
     return prm
 
 
+def bn_train_apply(x, x_ctot, x_coff, gamma, beta, eps, momentum, running_mean, running_var, y, y_ctot,
+                   y_coff, N, C_, HW, pre_relu, post_relu, residual=None, r_ctot=0, r_coff=0,
+                   gap_out=None, gap_ctot=0, gap_coff=0):
+    """train-mode BN forward (statistics + apply) in two launches -> prm [3][C]"""
+    prm = torch.empty(3, C_, dtype=torch.float32, device=x.device)
+    ws = _stats_ws(N, C_, HW, x.device)
+    check(lib.dlio_bn_train_apply(_ptr(x), N, x_ctot, x_coff, C_, HW, int(pre_relu), int(post_relu),
+                                  _ptr(gamma), _ptr(beta), float(eps), float(momentum), _ptr(running_mean),
+                                  _ptr(running_var), _ptr(prm[0]), _ptr(prm[1]), _ptr(prm[2]),
+                                  _ptr(residual), r_ctot, r_coff, _ptr(y), y_ctot, y_coff, _ptr(gap_out),
+                                  gap_ctot, gap_coff, _ptr(ws), ws.numel(), _stream()), "bn_train_apply")
+    return prm
+
+
+def bn_bwd_fused(dy, dy_ctot, dy_coff, x, x_ctot, x_coff, prm, beta, dx, dx_ctot, dx_coff, N, C_, HW,
+                 pre_relu, post_relu, use_batch_stats, dgamma=None, dbeta=None, accumulate=False):
+    """BN backward (reductions + dx, dgamma, dbeta) in two launches"""
+    ws = _stats_ws(N, C_, HW, x.device)
+    check(lib.dlio_bn_bwd(_ptr(dy), dy_ctot, dy_coff, _ptr(x), x_ctot, x_coff, _ptr(prm[0]), _ptr(prm[1]),
+                          _ptr(prm[2]), _ptr(beta), _ptr(dx), dx_ctot, dx_coff, _ptr(dgamma), _ptr(dbeta),
+                          int(accumulate), N, C_, HW, int(pre_relu), int(post_relu), int(use_batch_stats),
+                          _ptr(ws), ws.numel(), _stream()), "bn_bwd")
+    return dx
+
+
 def bn_eval_params(running_mean, running_var, gamma, eps):
     C_ = running_mean.numel()
     prm = torch.empty(3, C_, dtype=torch.float32, device=running_mean.device)

@@ -312,6 +312,28 @@ int dlio_pair_stack(const float* images, const int32_t* combinations, float* xyz
 int dlio_gt_relative(const float* gts, const int32_t* combinations, float* f2f, float* f2g,
                      int32_t* flag, int B, int F, int S, dlio_stream_t stream);
 
+/* Train-mode BatchNorm forward in two launches: split statistics of x (as dlio_bn_train_stats),
+ * then ONE plane-structured kernel in which every workgroup sums the partials of its own channel,
+ * finalises mean / invstd / scale (+ running statistics, published by the workgroup of plane
+ * n=0) and applies y = post((pre(x)-mean)*scale+beta) + residual like dlio_bn_apply.
+ * gap_out (optional, [N][gap_ctot] with channel offset gap_coff): mean over HW of every OUTPUT
+ * plane, bit-identical to dlio_gap_fwd(y) -- the SELayer behind a Fire block needs it.
+ * ws: dlio_chan_stats_ws_bytes(N, C, HW). */
+int dlio_bn_train_apply(const float* x, int N, int x_ctot, int x_coff, int C, int HW, int pre_relu,
+                        int post_relu, const float* gamma, const float* beta, float eps,
+                        float momentum, float* running_mean, float* running_var, float* mean,
+                        float* invstd, float* scale, const float* residual, int r_ctot, int r_coff,
+                        float* y, int y_ctot, int y_coff, float* gap_out, int gap_ctot, int gap_coff,
+                        void* ws, size_t ws_bytes, dlio_stream_t stream);
+/* BatchNorm backward in two launches: dlio_bn_bwd_reduce's reduction + a plane-structured
+ * dlio_bn_bwd_apply that sums the partials itself; dgamma / dbeta (optional, += when accumulate)
+ * are written by the workgroup of plane n=0. */
+int dlio_bn_bwd(const float* dy, int dy_ctot, int dy_coff, const float* x, int x_ctot, int x_coff,
+                const float* mean, const float* invstd, const float* scale, const float* beta,
+                float* dx, int dx_ctot, int dx_coff, float* dgamma, float* dbeta, int accumulate,
+                int N, int C, int HW, int pre_relu, int post_relu, int use_batch_stats, void* ws,
+                size_t ws_bytes, dlio_stream_t stream);
+
 /* ---- lidar scan -> range image (the data step in front of the path) --------
  * LaserScan.do_range_projection (deeplio/common/laserscan.py:122-185): per point
  * depth = |p|, yaw = -atan2(y,x), pitch = asin(z/depth),

@@ -157,6 +157,68 @@ def test_batchnorm_train_eval_backward(dev, shape, pre_relu, post_relu):
     assert rel_err(cs, dy.double().sum((0, 2, 3))) < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(3, 24, 8, 64), (2, 7, 17, 17), (2, 5, 64, 256)])
+@pytest.mark.parametrize("pre_relu,post_relu", [(0, 1), (1, 0)])
+def test_batchnorm_plane_kernels(dev, shape, pre_relu, post_relu):
+    """the two-launch BN forward / backward (workgroup per plane: sums its channel's partials itself,
+    optional plane-average by-product) against the oracle, on channel slices of wider buffers, and
+    the by-product bit-identical to a separate dlio_gap_fwd pass"""
+    from deeplio_amd import ops
+    from oracle import ref_ops
+    g = _g(13)
+    N, C_, H, W = shape
+    HW = H * W
+    xbuf = torch.randn(N, C_ + 5, H, W, generator=g) * 2 + 0.7          # channels 3 .. 3+C
+    x = xbuf[:, 3:3 + C_]
+    gamma, beta = torch.rand(C_, generator=g) + 0.5, torch.randn(C_, generator=g)
+    rm, rv = torch.randn(C_, generator=g), torch.rand(C_, generator=g) + 0.5
+    resid = torch.randn(shape, generator=g)
+    dy = torch.randn(shape, generator=g)
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    xin = F.relu(xr) if pre_relu else xr
+    y_ref, rm_ref, rv_ref = ref_ops.bn_train(xin, gr, br, rm.double(), rv.double(), 0.1, 1e-5)
+    if post_relu:
+        y_ref = F.relu(y_ref)
+    y_ref = y_ref + resid.double()
+    y_ref.backward(dy.double())
+
+    xd, rmd, rvd = xbuf.to(dev), rm.to(dev).clone(), rv.to(dev).clone()
+    ybuf = torch.zeros(N, C_ + 2, H, W, device=dev)                      # output channels 1 .. 1+C
+    gap = torch.zeros(N, C_ + 4, device=dev)                             # averages at columns 2 .. 2+C
+    prm = ops.bn_train_apply(xd, C_ + 5, 3, gamma.to(dev), beta.to(dev), 1e-5, 0.1, rmd, rvd, ybuf, C_ + 2, 1,
+                             N, C_, HW, pre_relu, post_relu, residual=resid.to(dev), r_ctot=C_, r_coff=0,
+                             gap_out=gap, gap_ctot=C_ + 4, gap_coff=2)
+    y = ybuf[:, 1:1 + C_]
+    assert rel_err(y, y_ref) < TOL
+    assert rel_err(rmd, rm_ref) < 1e-5 and rel_err(rvd, rv_ref) < 1e-5
+    assert float(ybuf[:, 0].abs().max()) == 0 and float(ybuf[:, -1].abs().max()) == 0
+    assert torch.equal(gap[:, 2:2 + C_], ops.gap_fwd(y.contiguous(), N, C_, 0, C_, HW))
+    assert float(gap[:, :2].abs().max()) == 0 and float(gap[:, -2:].abs().max()) == 0
+    # same statistics as the three-launch path
+    st = ops.chan_stats(x.contiguous().to(dev), N, C_, 0, C_, HW, pre_relu)
+    prm2 = ops.bn_finalize(st, N * HW, gamma.to(dev), 1e-5, 0.1, rm.to(dev).clone(), rv.to(dev).clone())
+    assert rel_err(prm, prm2) < 1e-6
+    # without the by-product the planes are chunked
+    y2 = torch.empty(N, C_, H, W, device=dev)
+    ops.bn_train_apply(xd, C_ + 5, 3, gamma.to(dev), beta.to(dev), 1e-5, 0.1, rm.to(dev).clone(), rv.to(dev).clone(),
+                       y2, C_, 0, N, C_, HW, pre_relu, post_relu, residual=resid.to(dev), r_ctot=C_, r_coff=0)
+    assert torch.equal(y2, y)
+    for training in (True, False):
+        dx = torch.empty(N, C_, H, W, device=dev)
+        dgam, dbet = torch.full((C_,), 1.0, device=dev), torch.full((C_,), 2.0, device=dev)
+        ops.bn_bwd_fused(dy.to(dev), C_, 0, xd, C_ + 5, 3, prm, beta.to(dev), dx, C_, 0, N, C_, HW, pre_relu,
+                         post_relu, training, dgam, dbet, accumulate=True)
+        dx3 = torch.empty_like(dx)
+        dg3, db3 = torch.empty(C_, device=dev), torch.empty(C_, device=dev)
+        ops.bn_bwd(dy.to(dev), C_, 0, xd, C_ + 5, 3, prm, beta.to(dev), dx3, C_, 0, N, C_, HW, pre_relu,
+                   post_relu, training, dg3, db3)
+        assert rel_err(dx, dx3) < 1e-6 and rel_err(dgam - 1.0, dg3) < 1e-5 and rel_err(dbet - 2.0, db3) < 1e-5
+        if training:
+            assert rel_err(dx, xr.grad) < TOL
+            assert rel_err(dg3, gr.grad) < TOL and rel_err(db3, br.grad) < TOL
+
+
 POOL_CASES = [((2, 5, 8, 64), 3, 1, 2, 1, 1, False), ((2, 5, 8, 64), 3, 2, 2, 1, 1, False),
               ((1, 3, 16, 129), 3, 1, 2, 1, 1, True), ((1, 3, 33, 33), 3, 2, 2, 1, 1, True),
               ((1, 3, 64, 65), 3, 2, 2, 1, 1, True),
