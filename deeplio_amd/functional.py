@@ -110,6 +110,10 @@ class _CBR:
         d = ops.conv_desc(N, Cin, H, W, Cout, KH, KW, stride[0], stride[1], pad[0], pad[1],
                           in_ctot=x_ctot, in_coff=x_coff, out_ctot=raw_ctot, out_coff=raw_coff)
         wt = ops.conv2d_prepped(weight, 0)
+        if training and d.SH == 1 and d.SW == 1:
+            # data-gradient layout for backward: fetched here, where `weight` is the long-lived
+            # Parameter (the cache identifies weights by object; backward only sees unpacked copies)
+            d.wt2 = ops.conv2d_prepped(weight, 1)
         ops.conv2d_fwd(x, wt, bias, raw, d)
         OHW = d.OH * d.OW
         if training and _PLANE_BN[0]:
@@ -182,7 +186,9 @@ def conv_dgrad(dy, weight, d, dx, dx_ctot, dx_coff, residual=None, r_ctot=0, r_c
     if accumulate:
         residual, r_ctot, r_coff = dx, dx_ctot, dx_coff
     if d.SH == 1 and d.SW == 1:
-        wt2 = ops.conv2d_prepped(weight, 1)
+        wt2 = getattr(d, "wt2", None)
+        if wt2 is None:
+            wt2 = ops.conv2d_prepped(weight, 1)
         g = ops.conv_desc(N, Cout, d.OH, d.OW, Cin, d.KH, d.KW, 1, 1, d.KH - 1 - d.PH,
                           d.KW - 1 - d.PW, OH=d.H, OW=d.W, in_ctot=Cout, in_coff=0, out_ctot=dx_ctot,
                           out_coff=dx_coff, res_ctot=r_ctot, res_coff=r_coff)

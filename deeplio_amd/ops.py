@@ -116,7 +116,7 @@ class _PrepCache:
             self.tables.pop(dev, None)
         cur = torch.cuda.current_stream()
         if e["epoch"] != self.epoch or e["version"] != w._version:
-            if self.batched:
+            if self.batched and e["epoch"] >= 0:          # a known weight went stale: refresh them all
                 self._refresh_all(dev, cur)
             if e["epoch"] != self.epoch or e["version"] != w._version:     # newly registered / batching off
                 Cout, Cin, KH, KW = w.shape
