@@ -107,6 +107,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4, help="samples per CPU-baseline step (bounded sample)")
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--lidar", default="lidar-feat-pointseg", help="informational runs of the other families")
+    ap.add_argument("--imu", default="imu-feat-rnn")
+    ap.add_argument("--fusion", default="fusion-layer-soft")
+    ap.add_argument("--odom", default="odom-feat-rnn")
+    ap.add_argument("--channels", type=int, default=5, help="range-image channels per stream (C)")
     ap.add_argument("--no-isolated", action="store_true", help="skip the non-overlapped roofline pass")
     ap.add_argument("--iso-steps", type=int, default=3)
     args = ap.parse_args()
@@ -128,9 +133,10 @@ def main():
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
 
-    C, H, W, T, S, B = 5, 64, 2048, 50, args.seq, args.batch
-    cfg = make_config(lidar="lidar-feat-pointseg", imu="imu-feat-rnn", fusion="fusion-layer-soft",
-                      odom="odom-feat-rnn", seq=S)
+    C, H, W, T, S, B = args.channels, 64, 2048, 50, args.seq, args.batch
+    cfg = make_config(lidar=args.lidar, imu=args.imu, fusion=args.fusion, odom=args.odom, seq=S)
+    headline = (args.lidar, args.imu, args.fusion, args.odom, C) == (
+        "lidar-feat-pointseg", "imu-feat-rnn", "fusion-layer-soft", "odom-feat-rnn", 5)
     torch.manual_seed(20260928)                     # same random-init weights on every rank / run
     ts = TrainStep(cfg, (C, H, W), device, B)
     sync = ddist.GradSync(ts.optimizer.flat, ts.optimizer.grad, ts.optimizer)
@@ -201,7 +207,7 @@ def main():
         # PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction of
         # the guide applied): collected by tools/pmc_traffic.py, committed under profiles/
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc) and B == 8 and S == 2:
+        if os.path.exists(pmc) and B == 8 and S == 2 and headline:
             with open(pmc) as f:
                 t = json.load(f).get({0: "conv2d_fwd_mfma", 1: "conv2d_wgrad_mfma"}[dom])
             if t:
@@ -210,11 +216,12 @@ def main():
         # whole-step view on SURVEY 8(d)'s algorithmic figures: 3 x (36.13 GF conv + 0.124 GF RNN) and
         # 3 x 957 MB per frame pair
         pairs_per_s = value
-        roofline["step"] = {
-            "mfma": {"achieved": round(pairs_per_s * 3 * 36.254e9 / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(pairs_per_s * 3 * 36.254e9 / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
-            "hbm": {"achieved": round(pairs_per_s * 3 * 957e6 / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(pairs_per_s * 3 * 957e6 / 1e9 / 8000.0, 4)}}
+        if headline:
+          roofline["step"] = {
+              "mfma": {"achieved": round(pairs_per_s * 3 * 36.254e9 / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                       "unit": "TFLOP/s", "frac": round(pairs_per_s * 3 * 36.254e9 / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+              "hbm": {"achieved": round(pairs_per_s * 3 * 957e6 / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                      "frac": round(pairs_per_s * 3 * 957e6 / 1e9 / 8000.0, 4)}}
         if prof_iso is not None:
             q = prof_iso[dom]
             roofline["isolated"] = {
@@ -229,9 +236,11 @@ def main():
             "value": round(value, 3), "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: lidar-feat-pointseg(add)+imu-feat-rnn bi-LSTM-128x2"
-                                   "+fusion-layer-soft+odom-feat-rnn bi-LSTM-1024x2, HWS local+global, Adam; "
-                                   "64x2048x5, T=50, S=%d, per-GPU batch %d" % (S, B),
+            "config": {"workload": ("BASELINE configs[1]: lidar-feat-pointseg(add)+imu-feat-rnn bi-LSTM-128x2"
+                                    "+fusion-layer-soft+odom-feat-rnn bi-LSTM-1024x2, HWS local+global, Adam; "
+                                    "64x2048x5, T=50, S=%d, per-GPU batch %d" % (S, B)) if headline else
+                                   ("informational (not the headline config): %s+%s+%s+%s, 64x2048x%d, T=50, S=%d, "
+                                    "per-GPU batch %d" % (args.lidar, args.imu, args.fusion, args.odom, C, S, B)),
                        "global_batch": world * B, "frame_pairs_per_step": world * B * S,
                        "parallelism": "dp%d" % world, "loss": float(loss.item())},
             "roofline": roofline,

@@ -1,5 +1,8 @@
 // Data gradient of STRIDED convolutions (stride-1 convs go through conv_fwd.hip with
-// tap-reversed weights).  Only the non-PointSeg encoders have strided convs below the stem
+// tap-reversed weights).  Production route: dlio_zero_upsample2d inserts the stride's zeros into
+// dY and the stride-1 MFMA kernel of conv_fwd.hip runs on that (SH*SW x the minimal MFMA work,
+// but ~100 TF/s instead of a scalar gather; FlowNet step 900 -> see DESIGN).  The gather kernel
+// below is kept as the shape-agnostic reference implementation behind the C-ABI.  Only the non-PointSeg encoders have strided convs below the stem
 // (FlowNet conv2..conv6, ResNet stage heads + 1x1 downsamples); this is a direct gather
 // kernel: one thread per dx element, coalesced along W.
 // Replaces the input-gradient half of nn.Conv2d backward at base_net.py:55-71, resnet.py
@@ -41,7 +44,35 @@ __global__ __launch_bounds__(256) void dgrad_strided_kernel(const float* __restr
     dx[(((size_t)n * d.in_ctot + d.in_coff + ci) * d.H + ih) * d.W + iw] = acc;
   }
 }
+// dst[pl][ih][iw] = (ih % SH == 0 && iw % SW == 0 && in range) ? src[pl][ih/SH][iw/SW] : 0
+__global__ void zero_upsample_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                     int64_t planes, int OH, int OW, int HU, int WU, int SH, int SW) {
+  const int64_t total = planes * HU * WU;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int iw = (int)(i % WU);
+    int64_t t = i / WU;
+    const int ih = (int)(t % HU);
+    const int64_t pl = t / HU;
+    float v = 0.f;
+    if (ih % SH == 0 && iw % SW == 0) {
+      const int oh = ih / SH, ow = iw / SW;
+      if (oh < OH && ow < OW) v = src[(pl * OH + oh) * OW + ow];
+    }
+    dst[i] = v;
+  }
+}
 }  // namespace
+
+extern "C" int dlio_zero_upsample2d(const float* src, float* dst, int64_t planes, int OH, int OW,
+                                    int HU, int WU, int SH, int SW, dlio_stream_t stream) {
+  if (!src || !dst || planes <= 0 || OH <= 0 || OW <= 0 || SH <= 0 || SW <= 0 ||
+      HU < (OH - 1) * SH + 1 || WU < (OW - 1) * SW + 1)
+    return DLIO_EINVAL;
+  hipLaunchKernelGGL(zero_upsample_kernel, dim3(ew_grid(planes * HU * WU, 256)), dim3(256), 0,
+                     as_stream(stream), src, dst, planes, OH, OW, HU, WU, SH, SW);
+  return dlio_check_launch();
+}
 
 extern "C" int dlio_conv2d_dgrad_strided(const float* dy, const float* w, float* dx,
                                          const DlioConvDesc* dp, dlio_stream_t stream) {

@@ -110,7 +110,7 @@ class _CBR:
         d = ops.conv_desc(N, Cin, H, W, Cout, KH, KW, stride[0], stride[1], pad[0], pad[1],
                           in_ctot=x_ctot, in_coff=x_coff, out_ctot=raw_ctot, out_coff=raw_coff)
         wt = ops.conv2d_prepped(weight, 0)
-        if training and d.SH == 1 and d.SW == 1:
+        if training:
             # data-gradient layout for backward: fetched here, where `weight` is the long-lived
             # Parameter (the cache identifies weights by object; backward only sees unpacked copies)
             d.wt2 = ops.conv2d_prepped(weight, 1)
@@ -194,11 +194,18 @@ def conv_dgrad(dy, weight, d, dx, dx_ctot, dx_coff, residual=None, r_ctot=0, r_c
                           out_coff=dx_coff, res_ctot=r_ctot, res_coff=r_coff)
         ops.conv2d_fwd(dy, wt2, None, dx, g, residual=residual)
     else:
-        if residual is not None or dx_ctot != Cin or dx_coff != 0:
-            raise ValueError("strided dgrad supports plain outputs only")
-        g = ops.conv_desc(N, Cin, d.H, d.W, Cout, d.KH, d.KW, d.SH, d.SW, d.PH, d.PW, OH=d.OH,
-                          OW=d.OW, in_ctot=Cin, in_coff=0, out_ctot=Cout, out_coff=0)
-        ops.conv2d_dgrad_strided(dy, weight, dx, g)
+        # strided conv: insert the stride's zeros into dy and run the stride-1 MFMA kernel on it
+        # (SH*SW x the minimal MFMA work, still ~50x faster than a scalar gather)
+        HU = (d.OH - 1) * d.SH + 1 + (d.H + 2 * d.PH - d.KH) % d.SH
+        WU = (d.OW - 1) * d.SW + 1 + (d.W + 2 * d.PW - d.KW) % d.SW
+        up = ops.zero_upsample2d(dy, HU, WU, d.SH, d.SW)
+        wt2 = getattr(d, "wt2", None)
+        if wt2 is None:
+            wt2 = ops.conv2d_prepped(weight, 1)
+        g = ops.conv_desc(N, Cout, HU, WU, Cin, d.KH, d.KW, 1, 1, d.KH - 1 - d.PH, d.KW - 1 - d.PW,
+                          OH=d.H, OW=d.W, in_ctot=Cout, in_coff=0, out_ctot=dx_ctot, out_coff=dx_coff,
+                          res_ctot=r_ctot, res_coff=r_coff)
+        ops.conv2d_fwd(up, wt2, None, dx, g, residual=residual)
     return dx
 
 

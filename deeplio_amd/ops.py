@@ -184,6 +184,16 @@ def conv2d_fwd(x, wt, bias, y, desc, in_aff=None, residual=None):
     return y
 
 
+def zero_upsample2d(src, HU, WU, SH, SW):
+    """[N,C,OH,OW] -> [N,C,HU,WU] with the stride's zeros inserted"""
+    _chk(src)
+    N, C_, OH, OW = src.shape
+    dst = torch.empty(N, C_, HU, WU, dtype=torch.float32, device=src.device)
+    check(lib.dlio_zero_upsample2d(_ptr(src), _ptr(dst), N * C_, OH, OW, HU, WU, SH, SW, _stream()),
+          "zero_upsample2d")
+    return dst
+
+
 def conv2d_dgrad_strided(dy, w, dx, desc):
     check(lib.dlio_conv2d_dgrad_strided(_ptr(dy), _ptr(w), _ptr(dx), C.byref(desc), _stream()),
           "conv2d_dgrad_strided")

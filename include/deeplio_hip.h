@@ -97,7 +97,13 @@ int dlio_conv2d_fwd(const float* x, const float* wt, const float* bias,
                     const float* residual, float* y, const DlioConvDesc* d,
                     dlio_stream_t stream);
 
-/* strided data gradient (any stride): dx[n,ci,ih,iw] = sum_{co,dy,dx} dy[...] * w[co][ci][dy][dx]
+/* dst [planes][HU][WU] = src [planes][OH][OW] with SH-1 / SW-1 zeros inserted between rows /
+ * columns (and zero tail rows/columns up to HU, WU): turns the data gradient of a strided
+ * convolution into dlio_conv2d_fwd with stride 1 on the data-gradient weight layout
+ * (HU = (OH-1)*SH+1 + (H+2*PH-KH)%SH, pad KH-1-PH). */
+int dlio_zero_upsample2d(const float* src, float* dst, int64_t planes, int OH, int OW, int HU,
+                         int WU, int SH, int SW, dlio_stream_t stream);
+/* strided data gradient (any stride), scalar reference implementation: dx[n,ci,ih,iw] = sum_{co,dy,dx} dy[...] * w[co][ci][dy][dx]
  * w in the STANDARD [Cout][Cin][KH][KW] layout.  d describes the forward conv. */
 int dlio_conv2d_dgrad_strided(const float* dy, const float* w, float* dx,
                               const DlioConvDesc* d, dlio_stream_t stream);

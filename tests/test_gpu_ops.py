@@ -489,3 +489,31 @@ def test_adam_sgd_match_torch_optim(dev):
         assert rel_err(p, pr) < 1e-5
     ss = ops.sumsq(grads[0].to(dev))
     assert rel_err(ss, (grads[0].double() ** 2).sum()) < 1e-6
+
+
+@pytest.mark.parametrize("case", [((2, 6, 18, 36), 10, 3, 3, 2, 2, 1, 1), ((2, 8, 17, 33), 12, 3, 5, 1, 2, 1, 2),
+                                  ((1, 16, 16, 32), 8, 1, 1, 2, 2, 0, 0), ((2, 5, 9, 20), 7, 3, 3, 1, 2, 1, 1),
+                                  ((1, 4, 15, 15), 6, 5, 7, 1, 2, 2, 3)])
+def test_strided_dgrad_via_zero_upsample(dev, case):
+    """data gradient of strided convs = stride-1 MFMA conv over the zero-upsampled dy (production
+    route), incl. sizes where (H + 2P - K) % S != 0, a residual operand and a channel-sliced dx;
+    checked against torch and against the scalar reference kernel behind the C-ABI"""
+    from deeplio_amd import functional as Fh, ops
+    shape, Cout, KH, KW, SH, SW, PH, PW = case
+    N, Cin, H, W = shape
+    g = _g(21)
+    x = torch.randn(shape, generator=g).double().requires_grad_(True)
+    w = torch.randn(Cout, Cin, KH, KW, generator=g) / (Cin * KH * KW) ** 0.5
+    y = F.conv2d(x, w.double(), None, (SH, SW), (PH, PW))
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    d = ops.conv_desc(N, Cin, H, W, Cout, KH, KW, SH, SW, PH, PW)
+    assert (d.OH, d.OW) == tuple(y.shape[2:])
+    res = torch.randn(N, Cin + 3, H, W, generator=g)
+    dxbuf = torch.zeros(N, Cin + 2, H, W, device=dev)
+    Fh.conv_dgrad(dy.to(dev), w.to(dev), d, dxbuf, Cin + 2, 1, residual=res.to(dev), r_ctot=Cin + 3, r_coff=2)
+    assert rel_err(dxbuf[:, 1:1 + Cin], x.grad + res[:, 2:2 + Cin].double()) < TOL
+    assert float(dxbuf[:, 0].abs().max()) == 0 and float(dxbuf[:, -1].abs().max()) == 0
+    ref = torch.empty(N, Cin, H, W, device=dev)
+    ops.conv2d_dgrad_strided(dy.to(dev), w.to(dev), ref, d)
+    assert rel_err(ref, x.grad) < TOL
