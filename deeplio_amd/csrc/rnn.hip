@@ -11,6 +11,7 @@
 //
 // Replaces nn.LSTM / nn.GRU at imu_feat_nets.py:63-70,79-83 and odom_feat_nets.py:61-68,80.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -341,6 +342,174 @@ __global__ void gru_cell_bwd_kernel(const float* __restrict__ dhs, int lddhs,
   }
 }
 
+// ------------------------------------------------------------------ GRU (persistent)
+// Same scheme as lstm_persist_*: ONE launch per (layer, direction, sequence), 3H threads, thread j
+// keeps row j of W_hh (forward) / a column of one gate block (backward) in registers for all T
+// steps, h and the gate pre-activations live in LDS, the next step's gx is prefetched.
+// gates saved per row: r, z, n, hn (= W_hn h + b_hn), as the streamed cells do.
+template <int H>
+__global__ __launch_bounds__(3 * H) void gru_persist_fwd(
+    const float* __restrict__ gx, const float* __restrict__ w_hh, const float* __restrict__ b_hh,
+    const float* __restrict__ h0, float* __restrict__ hs, int ldhs, float* __restrict__ hp,
+    float* __restrict__ gates, float* __restrict__ hT, int T, int B, int rst, int rsb, int reverse) {
+  constexpr int G = 3 * H;
+  __shared__ __attribute__((aligned(16))) float hl[BC * H];
+  __shared__ __attribute__((aligned(16))) float gl[BC * G];    // r,z: gx+gh ; n: gh only
+  __shared__ float gxn[BC * H];                                // gx of the n gate
+  const int j = threadIdx.x;
+  const int b0 = blockIdx.x * BC;
+  const int nb = min(BC, B - b0);
+
+  float w[H];
+#pragma unroll
+  for (int k = 0; k < H; k += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(w_hh + (size_t)j * H + k);
+    w[k] = v.x; w[k + 1] = v.y; w[k + 2] = v.z; w[k + 3] = v.w;
+  }
+  const float bj = b_hh ? b_hh[j] : 0.f;
+  for (int e = j; e < BC * H; e += G) {
+    const int b = e / H, k = e - b * H;
+    hl[e] = (b < nb && h0) ? h0[(size_t)(b0 + b) * H + k] : 0.f;
+  }
+  float gcur[BC], gnext[BC];
+  {
+    const int t = reverse ? T - 1 : 0;
+#pragma unroll
+    for (int bb = 0; bb < BC; ++bb)
+      gcur[bb] = bb < nb ? gx[((size_t)t * rst + (size_t)(b0 + bb) * rsb) * G + j] : 0.f;
+  }
+  __syncthreads();
+
+  for (int step = 0; step < T; ++step) {
+    const int t = reverse ? T - 1 - step : step;
+    if (step + 1 < T) {
+      const int tn = reverse ? t - 1 : t + 1;
+#pragma unroll
+      for (int bb = 0; bb < BC; ++bb)
+        gnext[bb] = bb < nb ? gx[((size_t)tn * rst + (size_t)(b0 + bb) * rsb) * G + j] : 0.f;
+    }
+    float acc[BC];
+#pragma unroll
+    for (int bb = 0; bb < BC; ++bb) acc[bb] = bj;
+#pragma unroll
+    for (int k = 0; k < H; k += 4) {
+#pragma unroll
+      for (int bb = 0; bb < BC; ++bb) {
+        const float4 hv = *reinterpret_cast<const float4*>(&hl[bb * H + k]);
+        acc[bb] = fmaf(w[k], hv.x, acc[bb]);
+        acc[bb] = fmaf(w[k + 1], hv.y, acc[bb]);
+        acc[bb] = fmaf(w[k + 2], hv.z, acc[bb]);
+        acc[bb] = fmaf(w[k + 3], hv.w, acc[bb]);
+      }
+    }
+    if (j < 2 * H) {
+#pragma unroll
+      for (int bb = 0; bb < BC; ++bb) gl[bb * G + j] = gcur[bb] + acc[bb];
+    } else {
+#pragma unroll
+      for (int bb = 0; bb < BC; ++bb) { gl[bb * G + j] = acc[bb]; gxn[bb * H + j - 2 * H] = gcur[bb]; }
+    }
+    __syncthreads();
+    for (int e = j; e < nb * H; e += G) {
+      const int b = e / H, k = e - b * H;
+      const size_t r = (size_t)t * rst + (size_t)(b0 + b) * rsb;
+      const float rg = sigm(gl[b * G + k]);
+      const float zg = sigm(gl[b * G + H + k]);
+      const float hn = gl[b * G + 2 * H + k];
+      const float ng = tanhf(gxn[e] + rg * hn);
+      const float hprev = hl[e];
+      const float h = (1.f - zg) * ng + zg * hprev;
+      hp[r * H + k] = hprev;
+      float* gr = gates + r * 4 * H;
+      gr[k] = rg; gr[H + k] = zg; gr[2 * H + k] = ng; gr[3 * H + k] = hn;
+      hs[r * ldhs + k] = h;
+      hl[e] = h;
+    }
+#pragma unroll
+    for (int bb = 0; bb < BC; ++bb) gcur[bb] = gnext[bb];
+    __syncthreads();
+  }
+  if (hT)
+    for (int e = j; e < nb * H; e += G) hT[(size_t)(b0 + e / H) * H + e % H] = hl[e];
+}
+
+template <int H>
+__global__ __launch_bounds__(3 * H) void gru_persist_bwd(
+    const float* __restrict__ dhs, int lddhs, const float* __restrict__ dhT,
+    const float* __restrict__ gates, const float* __restrict__ hp, const float* __restrict__ w_hh,
+    float* __restrict__ dgx, float* __restrict__ dgh, float* __restrict__ dh0, int T, int B, int rst,
+    int rsb, int reverse) {
+  constexpr int G = 3 * H;
+  __shared__ __attribute__((aligned(16))) float dGl[BC * G];
+  __shared__ float part[3][BC * H];
+  __shared__ float dhl[BC * H];      // gradient arriving from the later step
+  __shared__ float dir[BC * H];      // dh * z : the path that bypasses W_hh
+  const int tid = threadIdx.x;
+  const int q = tid / H, k = tid - q * H;
+  const int b0 = blockIdx.x * BC;
+  const int nb = min(BC, B - b0);
+
+  float wc[H];  // column k of gate block q:  W_hh[q*H + jj][k]
+#pragma unroll
+  for (int jj = 0; jj < H; ++jj) wc[jj] = w_hh[((size_t)q * H + jj) * H + k];
+  for (int e = tid; e < BC * H; e += G) {
+    const int b = e / H, kk = e - b * H;
+    dhl[e] = (b < nb && dhT) ? dhT[(size_t)(b0 + b) * H + kk] : 0.f;
+    dir[e] = 0.f;
+  }
+  for (int e = tid; e < BC * G; e += G) dGl[e] = 0.f;
+  __syncthreads();
+
+  for (int step = 0; step < T; ++step) {
+    const int t = reverse ? step : T - 1 - step;
+    for (int e = tid; e < nb * H; e += G) {
+      const int b = e / H, kk = e - b * H;
+      const size_t r = (size_t)t * rst + (size_t)(b0 + b) * rsb;
+      const float* gr = gates + r * 4 * H;
+      const float rg = gr[kk], zg = gr[H + kk], ng = gr[2 * H + kk], hn = gr[3 * H + kk];
+      const float hprev = hp[r * H + kk];
+      const float dh = (dhs ? dhs[r * lddhs + kk] : 0.f) + dhl[e];
+      const float dn = dh * (1.f - zg);
+      const float dz = dh * (hprev - ng);
+      const float dan = dn * (1.f - ng * ng);
+      const float dar = dan * hn * rg * (1.f - rg);
+      const float daz = dz * zg * (1.f - zg);
+      const float dhn = dan * rg;
+      float* ox = dgx + r * G;
+      ox[kk] = dar; ox[H + kk] = daz; ox[2 * H + kk] = dan;
+      float* oh = dgh + r * G;
+      oh[kk] = dar; oh[H + kk] = daz; oh[2 * H + kk] = dhn;
+      float* gl = dGl + b * G;
+      gl[kk] = dar; gl[H + kk] = daz; gl[2 * H + kk] = dhn;
+      dir[e] = dh * zg;
+    }
+    __syncthreads();
+    {
+      float acc[BC];
+#pragma unroll
+      for (int bb = 0; bb < BC; ++bb) acc[bb] = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < H; jj += 4) {
+#pragma unroll
+        for (int bb = 0; bb < BC; ++bb) {
+          const float4 gv = *reinterpret_cast<const float4*>(&dGl[bb * G + q * H + jj]);
+          acc[bb] = fmaf(wc[jj], gv.x, acc[bb]);
+          acc[bb] = fmaf(wc[jj + 1], gv.y, acc[bb]);
+          acc[bb] = fmaf(wc[jj + 2], gv.z, acc[bb]);
+          acc[bb] = fmaf(wc[jj + 3], gv.w, acc[bb]);
+        }
+      }
+#pragma unroll
+      for (int bb = 0; bb < BC; ++bb) part[q][bb * H + k] = acc[bb];
+    }
+    __syncthreads();
+    for (int e = tid; e < BC * H; e += G) dhl[e] = dir[e] + ((part[0][e] + part[1][e]) + part[2][e]);
+    __syncthreads();
+  }
+  if (dh0)
+    for (int e = tid; e < nb * H; e += G) dh0[(size_t)(b0 + e / H) * H + e % H] = dhl[e];
+}
+
 int ew_blocks(int n) { return n < 256 ? 1 : (n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256; }
 
 }  // namespace
@@ -442,8 +611,19 @@ extern "C" int dlio_gru_seq_fwd(const float* gx, const float* w_hh, const float*
                                 void* ws, size_t ws_bytes, dlio_stream_t stream) {
   if (!gx || !w_hh || !hs || !hp || !gates || T <= 0 || B <= 0 || H <= 0 || ldhs < H)
     return DLIO_EINVAL;
-  if (!ws || ws_bytes < dlio_rnn_ws_bytes(T, B, H)) return DLIO_EWS;
   hipStream_t s = as_stream(stream);
+  static const int persist = getenv("DLIO_GRU_PERSIST") ? atoi(getenv("DLIO_GRU_PERSIST")) : 1;
+#define GRU_FWD_P(HH)                                                                          \
+  if (persist && H == HH) {                                                                    \
+    hipLaunchKernelGGL(gru_persist_fwd<HH>, dim3(cdiv(B, BC)), dim3(3 * HH), 0, s, gx, w_hh,   \
+                       b_hh, h0, hs, ldhs, hp, gates, hT, T, B, rst, rsb, reverse);            \
+    return dlio_check_launch();                                                                \
+  }
+  GRU_FWD_P(32)
+  GRU_FWD_P(64)
+  GRU_FWD_P(128)
+#undef GRU_FWD_P
+  if (!ws || ws_bytes < dlio_rnn_ws_bytes(T, B, H)) return DLIO_EWS;
   float* f = reinterpret_cast<float*>(ws);
   float* hcur = f;
   float* gh = f + (size_t)B * H;  // [B][3H]
@@ -465,8 +645,19 @@ extern "C" int dlio_gru_seq_bwd(const float* dhs, int lddhs, const float* dhT, c
                                 float* dh0, int T, int B, int H, int rst, int rsb, int reverse,
                                 void* ws, size_t ws_bytes, dlio_stream_t stream) {
   if (!gates || !hp || !w_hh || !dgx || !dgh || T <= 0 || B <= 0 || H <= 0) return DLIO_EINVAL;
-  if (!ws || ws_bytes < dlio_rnn_ws_bytes(T, B, H)) return DLIO_EWS;
   hipStream_t s = as_stream(stream);
+  static const int persist = getenv("DLIO_GRU_PERSIST") ? atoi(getenv("DLIO_GRU_PERSIST")) : 1;
+#define GRU_BWD_P(HH)                                                                          \
+  if (persist && H == HH) {                                                                    \
+    hipLaunchKernelGGL(gru_persist_bwd<HH>, dim3(cdiv(B, BC)), dim3(3 * HH), 0, s, dhs, lddhs, \
+                       dhT, gates, hp, w_hh, dgx, dgh, dh0, T, B, rst, rsb, reverse);          \
+    return dlio_check_launch();                                                                \
+  }
+  GRU_BWD_P(32)
+  GRU_BWD_P(64)
+  GRU_BWD_P(128)
+#undef GRU_BWD_P
+  if (!ws || ws_bytes < dlio_rnn_ws_bytes(T, B, H)) return DLIO_EWS;
   float* f = reinterpret_cast<float*>(ws);
   float* dhcur = f;
   float* dGh = f + (size_t)B * H;  // [B][3H]

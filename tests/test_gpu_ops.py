@@ -412,6 +412,14 @@ def test_gru_layer(dev, H, reverse):
     _run_rnn(dev, "gru", T=7, B=3, I=6, H=H, reverse=reverse, batch_first=True)
 
 
+def test_gru_layer_large_batch_long_seq(dev):
+    """persistent GRU kernels (H in 32/64/128): more than one 8-row batch group, T = the IMU window"""
+    _run_rnn(dev, "gru", T=50, B=11, I=6, H=128, reverse=False, batch_first=True)
+    _run_rnn(dev, "gru", T=9, B=17, I=12, H=64, reverse=True, batch_first=True)
+    _run_rnn(dev, "gru", T=5, B=2, I=6, H=32, reverse=False, batch_first=False)
+    _run_rnn(dev, "gru", T=3, B=4, I=256, H=1024, reverse=True, batch_first=True)      # streamed path
+
+
 @pytest.mark.parametrize("order", [0, 1])
 def test_se3_chain_and_loss(dev, order):
     from deeplio_amd import ops
