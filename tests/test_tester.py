@@ -132,6 +132,28 @@ def test_teststep_matches_eval_model_and_tester_quaternions(dev):
 
 
 @pytest.mark.gpu
+def test_teststep_hipgraph_replay_is_bit_identical(dev):
+    """the captured test-mode forward (three streams inside one hipGraph) returns exactly what the
+    eager forward returns, also for new inputs copied into the static buffers"""
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import golden_common as gc
+    from deeplio_amd.config import make_config
+    from deeplio_amd.tester import TestStep
+    ts = TestStep(make_config(seq=1), (5, 64, 256), dev, batch_size=1)
+    gc.fill_state(ts.model, seed=3)
+    a = tuple(t.to(dev) for t in gc.make_batch(31, 1, 1, 5, 64, 256, 50))
+    b = tuple(t.to(dev) for t in gc.make_batch(32, 1, 1, 5, 64, 256, 50))
+    ts.capture(*a[:3])
+    for batch in (a, b, a):
+        with torch.no_grad():
+            ref = ts.model([[batch[0], batch[1]], batch[2]])
+        got = ts.forward_graph(*batch[:3])
+        torch.cuda.synchronize()
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+
+
+@pytest.mark.gpu
 def test_resume_from_checkpoint_continues_the_trajectory(dev, tmp_path):
     """train 2 steps, checkpoint, train 2 more; a fresh process-state restored from the files and
     trained 2 steps lands on bit-identical parameters (dropout off)."""
