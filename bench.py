@@ -169,7 +169,7 @@ def main():
     # neighbours took.  A second, untimed pass with the overlap switched off measures the
     # same kernels alone ("isolated"); both are reported.
     prof_iso = None
-    if rank == 0 and not args.no_isolated:
+    if world == 1 and not args.no_isolated:      # N>1: extra steps on one rank would unbalance the collectives
         set_overlap(ts.model, False)
         ts.step(*batch)
         torch.cuda.synchronize()
