@@ -130,7 +130,8 @@ def main():
             print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    device = torch.device("cuda", local)
+    # one GPU per rank; the modulo only matters for the 2-ranks-on-1-GPU gloo dry run of this path
+    device = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(device)
 
     C, H, W, T, S, B = args.channels, 64, 2048, 50, args.seq, args.batch
