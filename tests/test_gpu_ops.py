@@ -39,7 +39,25 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", CONV_CASES)
+def _fuzz_cases():
+    """seeded random stride-1 shapes around every fast-path condition: W % 4 == 0 (float4 / buffer-load
+    paths) with OW % 32 != 0, H % 4 != 0, channel counts off the 16 / 17 / 32 / 64 tile sizes,
+    H*W % 32 == 0 (direct 1x1 weight gradient) and not"""
+    import random
+    rnd = random.Random(1234)
+    cases = []
+    for _ in range(14):
+        k = rnd.choice([1, 3, 3])
+        N = rnd.choice([1, 2, 3])
+        Cin = rnd.choice([3, 8, 16, 17, 18, 33, 48, 65, 80])
+        Cout = rnd.choice([5, 16, 24, 32, 33, 64, 70, 96])
+        H = rnd.choice([4, 5, 7, 8, 12, 16])
+        W = rnd.choice([8, 12, 32, 36, 40, 64, 68, 100, 128])
+        cases.append((N, Cin, H, W, Cout, k, k, 1, 1, k // 2, k // 2))
+    return cases
+
+
+@pytest.mark.parametrize("case", CONV_CASES + _fuzz_cases())
 def test_conv_fwd_wgrad_dgrad(dev, case):
     from deeplio_amd import ops
     N, Cin, H, W, Cout, KH, KW, SH, SW, PH, PW = case
