@@ -55,6 +55,13 @@ __device__ __forceinline__ void store_tiles(f32x16 (&acc)[MR][NR], const float* 
     }
 }
 
+// Prepped-weight layout (both modes): wt[tap][k/8][k%2][n][(k/2)%4], k padded with zero rows to a
+// multiple of 16.  A lane of the MFMA A operand (n = output channel, half = k%2) finds the weights
+// of four consecutive k-steps (k = 8g + 2u + half, u = 0..3) in ONE 16-byte load.
+__host__ __device__ __forceinline__ size_t wt_index(int tap, int k, int n, int KPAD, int Nn) {
+  return ((((size_t)tap * (KPAD >> 3) + (k >> 3)) * 2 + (k & 1)) * Nn + n) * 4 + ((k >> 1) & 3);
+}
+
 __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(
   // clamped weight columns (rows >= Cout are dropped at the store)
   unsigned loff[MR];
 #pragma unroll
-  for (int m = 0; m < MR; ++m) loff[m] = 4u * (unsigned)(half * Cout + min(co0 + m * 32 + l31, Cout - 1));
+  for (int m = 0; m < MR; ++m) loff[m] = 16u * (unsigned)(half * Cout + min(co0 + m * 32 + l31, Cout - 1));
   const int KP = (Cin + 15) & ~15;
   // buffer descriptors: per-lane 32-bit voffset + scalar soffset, no 64-bit vector addresses
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -184,12 +191,24 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(
   // so no clamping: address = uniform (SGPR) row base + per-lane 32-bit byte offset.
   float aw[2][CK / 2][MR];
   auto load_tap = [&](int tap, int c0, int s) {
-    const unsigned tap_off = (unsigned)((tap * KP + c0) * Cout) * 4u;     // uniform -> SGPR soffset
+    // one 16-byte (CK >= 8), 8-byte (CK == 4) or 4-byte (CK == 2) load per 4 / 2 / 1 k-steps
+    constexpr int VW = CK / 2 < 4 ? CK / 2 : 4;
+    const unsigned base = (unsigned)((((tap * (KP >> 3) + (c0 >> 3)) * 2) * Cout) * 4 + ((c0 >> 1) & 3)) * 4u;
 #pragma unroll
-    for (int c2 = 0; c2 < CK; c2 += 2)
+    for (int g = 0; g < (CK / 2 + 3) / 4; ++g)
 #pragma unroll
-      for (int m = 0; m < MR; ++m)
-        aw[s][c2 / 2][m] = buf_load(wrsrc, loff[m], tap_off + (unsigned)(c2 * Cout) * 4u);
+      for (int m = 0; m < MR; ++m) {
+        const unsigned so = base + (unsigned)(g * 2 * Cout * 4) * 4u;
+        if constexpr (VW == 4) {
+          const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, loff[m], so, 0));
+          aw[s][4 * g][m] = v.x; aw[s][4 * g + 1][m] = v.y; aw[s][4 * g + 2][m] = v.z; aw[s][4 * g + 3][m] = v.w;
+        } else if constexpr (VW == 2) {
+          const float2 v = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(wrsrc, loff[m], so, 0));
+          aw[s][0][m] = v.x; aw[s][1][m] = v.y;
+        } else {
+          aw[s][0][m] = buf_load(wrsrc, loff[m], so);
+        }
+      }
   };
   // k-steps of a chunk in issue order: step = tap * CK/2 + c2/2.  The LDS operand of step s+1
   // is read before the MFMAs of step s (register double buffer), so the ~100-cycle LDS latency
@@ -221,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(
         // issue order inside the tap: next step's LDS operand, this step's share of the next
         // tap's weight loads, then this step's MFMAs
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, MR, 0);
+        if (k < ((CK / 2 + 3) / 4) * MR) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, MR * C::NR, 0);
       }
       // keep the scheduler from hoisting every tap's weight loads to the top of the chunk
@@ -350,7 +369,7 @@ __global__ __launch_bounds__(256) void conv1x1_direct_kernel(
   }
   const float* wq[MR];
 #pragma unroll
-  for (int m = 0; m < MR; ++m) wq[m] = wt + min(co0 + m * 32 + l31, d.Cout - 1);
+  for (int m = 0; m < MR; ++m) wq[m] = wt + (size_t)min(co0 + m * 32 + l31, d.Cout - 1) * 4;
   const int Cin = d.Cin, Cout = d.Cout;
 
   float a[2][U][MR], b[2][U][NR];
@@ -361,7 +380,7 @@ __global__ __launch_bounds__(256) void conv1x1_direct_kernel(
       const bool kv = kk < Cin;
       const int kc = kv ? kk : Cin - 1;
 #pragma unroll
-      for (int m = 0; m < MR; ++m) a[s][u][m] = wq[m][(size_t)kc * Cout];
+      for (int m = 0; m < MR; ++m) a[s][u][m] = wq[m][wt_index(0, kk, 0, 0, Cout)];   // kk < KP: zero rows behind Cin
 #pragma unroll
       for (int q = 0; q < NR; ++q) {
         float v = xq[q][(size_t)kc * P];
@@ -432,7 +451,7 @@ __global__ __launch_bounds__(256) void conv1x1_v4_kernel(
   const float* xq = x + ((size_t)n * d.in_ctot + d.in_coff) * (size_t)P + pc;
   const float* wq[MR];
 #pragma unroll
-  for (int m = 0; m < MR; ++m) wq[m] = wt + min(co0 + m * 32 + l31, d.Cout - 1);
+  for (int m = 0; m < MR; ++m) wq[m] = wt + (size_t)min(co0 + m * 32 + l31, d.Cout - 1) * 4;
   const int Cin = d.Cin, Cout = d.Cout;
 
   float a[2][U][MR];
@@ -444,7 +463,7 @@ __global__ __launch_bounds__(256) void conv1x1_v4_kernel(
       const bool kv = kk < Cin;
       const int kc = kv ? kk : Cin - 1;
 #pragma unroll
-      for (int m = 0; m < MR; ++m) a[s][u][m] = wq[m][(size_t)kc * Cout];
+      for (int m = 0; m < MR; ++m) a[s][u][m] = wq[m][wt_index(0, kk, 0, 0, Cout)];   // kk < KP: zero rows behind Cin
       float4 v = *reinterpret_cast<const float4*>(xq + (size_t)kc * P);
       if (AFF) {
         const float mu = in_mean[kc], sc = in_scale[kc], sh = in_shift[kc];
@@ -573,7 +592,7 @@ __global__ void prep_weight_kernel(const float* __restrict__ w, float* __restric
       if (mode == 0) v = w[((int64_t)nn * Cin + k) * taps + tap];              // k = ci, n = co
       else v = w[((int64_t)k * Cin + nn) * taps + (taps - 1 - tap)];           // k = co, n = ci
     }
-    wt[i] = v;
+    wt[wt_index(tap, k, nn, KPAD, Nn)] = v;
   }
 }
 
@@ -599,7 +618,7 @@ __global__ void prep_weights_batched_kernel(const DlioPrepItem* __restrict__ ite
       if (it.mode == 0) v = it.w[((int64_t)nn * it.Cin + k) * it.taps + tap];
       else v = it.w[((int64_t)k * it.Cin + nn) * it.taps + (it.taps - 1 - tap)];
     }
-    it.wt[e] = v;
+    it.wt[wt_index(tap, k, nn, KPAD, Nn)] = v;
   }
 }
 
