@@ -76,7 +76,13 @@ struct ConvCfg {
   static constexpr int PC = (TW - 1) * SW + KW; // patch cols
   static constexpr int PLANE = PR * PC;
   static constexpr int NPOS = (PLANE + 255) / 256;   // patch positions per thread
-  static constexpr int XL = CK * PLANE;         // floats per LDS buffer
+  // LDS layout of the input patch.  CK >= 8: position-major [pos][half][k] (channel c = 2k + half)
+  // with a row stride of CK + 4 floats, so that a lane of the B operand finds the values of
+  // four consecutive k-steps in ONE ds_read_b128 (conflict-free: 20-float stride = 8 distinct
+  // 4-bank groups) and the stores are ds_write_b128 as well.  CK < 8: channel-major planes.
+  static constexpr bool PMAJOR = CK >= 8;
+  static constexpr int PS = CK + 4;             // floats per position (position-major)
+  static constexpr int XL = PMAJOR ? PLANE * PS : CK * PLANE;   // floats per LDS buffer
   static constexpr size_t LDS_BYTES = (size_t)2 * XL * 4;   // double buffered
 };
 
@@ -178,13 +184,30 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(
     }
   };
   auto store_chunk = [&](float* Xl) {
-#pragma unroll
-    for (int c = 0; c < CK; ++c)
+    if constexpr (C::PMAJOR) {
 #pragma unroll
       for (int j = 0; j < C::NPOS; ++j) {
         const int pos = tid + j * 256;
-        if (pos < C::PLANE) Xl[c * C::PLANE + pos] = reg[c][j];
+        if (pos < C::PLANE) {
+          float* dst = Xl + pos * C::PS;
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int g = 0; g < CK / 8; ++g)
+              *reinterpret_cast<float4*>(dst + h * (CK / 2) + 4 * g) =
+                  make_float4(reg[2 * (4 * g + 0) + h][j], reg[2 * (4 * g + 1) + h][j],
+                              reg[2 * (4 * g + 2) + h][j], reg[2 * (4 * g + 3) + h][j]);
+        }
       }
+    } else {
+#pragma unroll
+      for (int c = 0; c < CK; ++c)
+#pragma unroll
+        for (int j = 0; j < C::NPOS; ++j) {
+          const int pos = tid + j * 256;
+          if (pos < C::PLANE) Xl[c * C::PLANE + pos] = reg[c][j];
+        }
+    }
   };
   // weight operands of one tap (CK/2 k-steps x MR tiles), fetched one tap ahead of their MFMAs.
   // Prepped weights are [tap][KP][Cout] with KP = Cin rounded up to 16 and zero rows behind Cin,
@@ -221,13 +244,57 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(
 #pragma unroll
     for (int q = 0; q < C::NR; ++q) b[q] = xrow[c * C::PLANE + q * 32 * SW];
   };
-  auto mfma_chunk = [&](const float* Xl, int c0) {
+  // position-major: all KS values of a tap for this lane in KS/4 reads of 16 bytes
+  auto load_b_tap = [&](const float* Xl, int tap, float (&b)[C::NR][KS]) {
+    const int dy = tap / KW, dx = tap % KW;
+    const float* xrow = Xl + ((wave * SH + dy) * C::PC + dx + l31 * SW) * C::PS + half * KS;
+#pragma unroll
+    for (int q = 0; q < C::NR; ++q)
+#pragma unroll
+      for (int g = 0; g < KS / 4; ++g) {
+        const float4 v = *reinterpret_cast<const float4*>(xrow + q * 32 * SW * C::PS + 4 * g);
+        b[q][4 * g] = v.x; b[q][4 * g + 1] = v.y; b[q][4 * g + 2] = v.z; b[q][4 * g + 3] = v.w;
+      }
+  };
+  // `prefetch` issues the global loads of the NEXT chunk.  It is called after the weight loads of
+  // taps 0 and 1 are in flight: loads return in order, so weights queued BEHIND the 2*CK patch
+  // loads would make the first MFMAs of every chunk wait for a full HBM round trip.
+  auto mfma_chunk = [&](const float* Xl, int c0, auto&& prefetch) {
+    if constexpr (C::PMAJOR) {
+      // per tap: KS*MR*NR MFMAs against (KS/4)*NR LDS reads and (KS/4)*MR weight loads, all of
+      // them for the NEXT tap (register double buffers)
+      float b[2][C::NR][KS];
+      load_tap(0, c0, 0);
+      load_b_tap(Xl, 0, b[0]);
+#pragma unroll
+      for (int tap = 0; tap < KH * KW; ++tap) {
+        if (tap + 1 < KH * KW) {
+          load_b_tap(Xl, tap + 1, b[(tap + 1) & 1]);
+          load_tap(tap + 1, c0, (tap + 1) & 1);
+        }
+        if (tap == 0) prefetch();
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+#pragma unroll
+          for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int q = 0; q < C::NR; ++q)
+              acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[tap & 1][k][m], b[tap & 1][q][k], acc[m][q], 0, 0, 0);
+          if (k < (KS / 4) * C::NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          else if (k < (KS / 4) * (C::NR + MR)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, MR * C::NR, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      return;
+    }
     float b[2][C::NR];
     load_tap(0, c0, 0);
     load_b(Xl, 0, b[0]);
 #pragma unroll
     for (int tap = 0; tap < KH * KW; ++tap) {
       if (tap + 1 < KH * KW) load_tap(tap + 1, c0, (tap + 1) & 1);
+      if (tap == 0) prefetch();
 #pragma unroll
       for (int k = 0; k < KS; ++k) {
         const int step = tap * KS + k;
@@ -256,8 +323,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(
   for (int i = 0; i < nch; ++i) {
     float* cur = smem + (i & 1) * C::XL;
     float* nxt = smem + ((i + 1) & 1) * C::XL;
-    if (i + 1 < nch) load_chunk((i + 1) * CK);
-    mfma_chunk(cur, i * CK);
+    mfma_chunk(cur, i * CK, [&]() { if (i + 1 < nch) load_chunk((i + 1) * CK); });
     if (i + 1 < nch) store_chunk(nxt);
     __syncthreads();
   }
