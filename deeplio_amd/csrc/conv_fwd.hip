@@ -440,13 +440,24 @@ __global__ __launch_bounds__(256) void conv1x1_direct_kernel(
 
   float a[2][U][MR], b[2][U][NR];
   auto load_group = [&](int k0, int s) {
+    // the U k-steps of a group are contiguous in the prepped layout: one 16-byte (U = 4) or
+    // 8-byte (U = 2) load per output-channel tile; rows behind Cin are zero (k0 + 2U <= KP)
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      const float* wp = wq[m] + wt_index(0, k0 + half, 0, 0, Cout);
+      if constexpr (U == 4) {
+        const float4 v = *reinterpret_cast<const float4*>(wp);
+        a[s][0][m] = v.x; a[s][1][m] = v.y; a[s][2][m] = v.z; a[s][3][m] = v.w;
+      } else {
+        const float2 v = *reinterpret_cast<const float2*>(wp);
+        a[s][0][m] = v.x; a[s][1][m] = v.y;
+      }
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int kk = k0 + 2 * u + half;
       const bool kv = kk < Cin;
       const int kc = kv ? kk : Cin - 1;
-#pragma unroll
-      for (int m = 0; m < MR; ++m) a[s][u][m] = wq[m][wt_index(0, kk, 0, 0, Cout)];   // kk < KP: zero rows behind Cin
 #pragma unroll
       for (int q = 0; q < NR; ++q) {
         float v = xq[q][(size_t)kc * P];
@@ -523,13 +534,24 @@ __global__ __launch_bounds__(256) void conv1x1_v4_kernel(
   float a[2][U][MR];
   float4 b[2][U];
   auto load_group = [&](int k0, int s) {
+    // the U k-steps of a group are contiguous in the prepped layout: one 16-byte (U = 4) or
+    // 8-byte (U = 2) load per output-channel tile; rows behind Cin are zero (k0 + 2U <= KP)
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      const float* wp = wq[m] + wt_index(0, k0 + half, 0, 0, Cout);
+      if constexpr (U == 4) {
+        const float4 v = *reinterpret_cast<const float4*>(wp);
+        a[s][0][m] = v.x; a[s][1][m] = v.y; a[s][2][m] = v.z; a[s][3][m] = v.w;
+      } else {
+        const float2 v = *reinterpret_cast<const float2*>(wp);
+        a[s][0][m] = v.x; a[s][1][m] = v.y;
+      }
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int kk = k0 + 2 * u + half;
       const bool kv = kk < Cin;
       const int kc = kv ? kk : Cin - 1;
-#pragma unroll
-      for (int m = 0; m < MR; ++m) a[s][u][m] = wq[m][wt_index(0, kk, 0, 0, Cout)];   // kk < KP: zero rows behind Cin
       float4 v = *reinterpret_cast<const float4*>(xq + (size_t)kc * P);
       if (AFF) {
         const float mu = in_mean[kc], sc = in_scale[kc], sh = in_shift[kc];
