@@ -726,6 +726,8 @@ struct WgPlan {
 
 int nt_for(const DlioConvDesc& d) {
   if (d.KH == 1 && d.KW == 1) return (d.SH == 1 && d.SW == 1) ? 2 : 1;
+  static const int nt33 = getenv("DLIO_WGRAD_NT") ? atoi(getenv("DLIO_WGRAD_NT")) : 5;   // tuning knob (4 or 5)
+  if (d.KH == 3 && d.KW == 3 && d.SH == 1 && d.SW == 1 && nt33 == 4) return 4;
   return 5;
 }
 
@@ -917,6 +919,8 @@ extern "C" int dlio_conv2d_wgrad(const float* x, const float* dy, float* dw,
   if (d.KH == kh && d.KW == kw && d.SH == sh && d.SW == sw)                        \
     rc = launch<kh, kw, sh, sw, nt>(x, dy, dw, in_mean, in_scale, in_shift, wsp, d, p, s);
   WG_CASE(1, 1, 1, 1, 2)
+  else if (d.KH == 3 && d.KW == 3 && d.SH == 1 && d.SW == 1 && p.nt == 4)
+    rc = launch<3, 3, 1, 1, 4>(x, dy, dw, in_mean, in_scale, in_shift, wsp, d, p, s);
   else WG_CASE(3, 3, 1, 1, 5)
   else WG_CASE(3, 5, 1, 2, 5)
   else WG_CASE(3, 5, 1, 1, 5)
