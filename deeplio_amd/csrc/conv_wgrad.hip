@@ -351,6 +351,8 @@ struct WgACfg {
   static constexpr int NCX = (CKMAX + CPAR - 1) / CPAR;
 };
 
+constexpr int PF_STEP = 2;     // MFMA step of a tile at which the next tile's global loads are issued
+
 template <int KH, int KW, int NT, int MRW>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_adirect_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ wsp,
@@ -471,7 +473,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_adirect_kernel(
       }
     }
   };
-  auto mfma_tile = [&](const float* Xl, const float4 (&a)[C::MR][4]) {
+  auto mfma_tile = [&](const float* Xl, const float4 (&a)[C::MR][4], auto&& prefetch) {
     const float* xrow = Xl + wave * C::PC + half * 16;
     float b[2][NT][2];
     auto load_b = [&](int st, float (&bv)[NT][2]) {
@@ -484,6 +486,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_adirect_kernel(
 #pragma unroll
     for (int st = 0; st < 8; ++st) {
       if (st + 1 < 8) load_b(st + 1, b[(st + 1) & 1]);
+      if (st == PF_STEP) prefetch();
 #pragma unroll
       for (int e = 0; e < 2; ++e)
 #pragma unroll
@@ -509,8 +512,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_adirect_kernel(
     {
       const int nt_ = tile + splits;
       const bool more = nt_ < total_tiles;
-      if (more) { load_x(nt_); load_a(nt_, a1); }
-      mfma_tile(smem, a0);
+      mfma_tile(smem, a0, [&]() { if (more) { load_x(nt_); load_a(nt_, a1); } });
       if (more) store_x(smem + C::XL);
       __syncthreads();
       if (!more) break;
@@ -519,8 +521,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_adirect_kernel(
     {
       const int nt_ = tile + splits;
       const bool more = nt_ < total_tiles;
-      if (more) { load_x(nt_); load_a(nt_, a0); }
-      mfma_tile(smem + C::XL, a1);
+      mfma_tile(smem + C::XL, a1, [&]() { if (more) { load_x(nt_); load_a(nt_, a0); } });
       if (more) store_x(smem);
       __syncthreads();
       if (!more) break;
