@@ -365,6 +365,7 @@ __global__ __launch_bounds__(256) void bn_plane_bwd_kernel(
     const float* __restrict__ dy, int dy_ctot, int dy_coff, const float* __restrict__ x, int x_ctot,
     int x_coff, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ scale, const float* __restrict__ beta, const double* __restrict__ part,
+    const double* __restrict__ lpart, double inv_cnt,
     int splits, float* dx, int dx_ctot, int dx_coff, float* dgamma, float* dbeta, int accumulate,
     int N, int C, int HW, int pre_relu, int post_relu, int use_batch_stats, int chunks, int chunk_len) {
   __shared__ double sm[2][16];
@@ -373,12 +374,17 @@ __global__ __launch_bounds__(256) void bn_plane_bwd_kernel(
   const int n = pl / C, c = pl - n * C;
   double sg, sgx;
   plane_partials(part, c, splits, sm[0], sm[1], sg, sgx);
-  if (n == 0 && chunk == 0 && threadIdx.x == 0) {
-    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)sg : (float)sg;
-    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)sgx : (float)sgx;
+  if (n == 0 && chunk == 0) {
+    // dgamma / dbeta are THIS replica's sums (the gradient all-reduce adds the others); with
+    // synchronised statistics `part` holds the global sums and `lpart` the local ones
+    double lg = sg, lgx = sgx;
+    if (lpart) plane_partials(lpart, c, splits, sm[0], sm[1], lg, lgx);
+    if (threadIdx.x == 0) {
+      if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)lg : (float)lg;
+      if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)lgx : (float)lgx;
+    }
   }
   const float mu = mean[c], is = invstd[c], sc = scale[c], be = beta ? beta[c] : 0.f;
-  const double inv_cnt = 1.0 / ((double)N * HW);
   float mg = 0.f, mgx = 0.f;
   if (use_batch_stats) { mg = (float)(sg * inv_cnt); mgx = (float)(sgx * inv_cnt); }
   const float* gp = dy + ((size_t)n * dy_ctot + dy_coff + c) * HW;
@@ -428,6 +434,11 @@ static void plane_chunks(int planes, int per, bool whole_plane, int& chunks, int
 }
 
 }  // namespace
+
+extern "C" int dlio_chan_stats_splits(int N, int C, int HW) {
+  if (N <= 0 || C <= 0 || HW <= 0) return 0;
+  return pick_splits(N, C, HW);
+}
 
 extern "C" size_t dlio_chan_stats_ws_bytes(int N, int C, int HW) {
   if (N <= 0 || C <= 0 || HW <= 0) return 0;
@@ -584,29 +595,35 @@ extern "C" int dlio_bn_train_apply(const float* x, int N, int x_ctot, int x_coff
                                    float* mean, float* invstd, float* scale, const float* residual,
                                    int r_ctot, int r_coff, float* y, int y_ctot, int y_coff,
                                    float* gap_out, int gap_ctot, int gap_coff, void* ws,
-                                   size_t ws_bytes, dlio_stream_t stream) {
-  if (!x || !y || !mean || !invstd || !scale || N <= 0 || C <= 0 || HW <= 0 || !ws) return DLIO_EINVAL;
+                                   size_t ws_bytes, int phase, double count_scale,
+                                   dlio_stream_t stream) {
+  if (!x || !y || !mean || !invstd || !scale || N <= 0 || C <= 0 || HW <= 0 || !ws || phase < 0 ||
+      phase > 2 || !(count_scale >= 1.0))
+    return DLIO_EINVAL;
   const int splits = pick_splits(N, C, HW);
   if (ws_bytes < (size_t)C * splits * 2 * sizeof(double)) return DLIO_EWS;
   hipStream_t s = as_stream(stream);
   double* part = reinterpret_cast<double*>(ws);
-  hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3((unsigned)(C * splits)), dim3(RB), 0, s, x, x_ctot, x_coff,
-                     (const float*)nullptr, 0, 0, (const float*)nullptr, (const float*)nullptr,
-                     (const float*)nullptr, (const float*)nullptr, N, C, HW, pre_relu, 0, splits, part);
-  int rc = dlio_check_launch();
-  if (rc) return rc;
+  int rc = DLIO_OK;
+  if (phase != 2) {
+    hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3((unsigned)(C * splits)), dim3(RB), 0, s, x, x_ctot, x_coff,
+                       (const float*)nullptr, 0, 0, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, N, C, HW, pre_relu, 0, splits, part);
+    rc = dlio_check_launch();
+    if (rc || phase == 1) return rc;
+  }
   const bool vec = (HW & 3) == 0;
   int chunks, chunk_len;
   plane_chunks(N * C, vec ? HW / 4 : HW, gap_out != nullptr, chunks, chunk_len);
   const dim3 grid((unsigned)(N * C * chunks));
   if (vec)
     hipLaunchKernelGGL(bn_plane_apply_kernel<true>, grid, dim3(256), 0, s, x, x_ctot, x_coff, part, splits,
-                       (double)N * HW, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
+                       (double)N * HW * count_scale, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
                        scale, residual, r_ctot, r_coff, y, y_ctot, y_coff, N, C, HW, pre_relu, post_relu,
                        chunks, chunk_len, gap_out, gap_ctot, gap_coff);
   else
     hipLaunchKernelGGL(bn_plane_apply_kernel<false>, grid, dim3(256), 0, s, x, x_ctot, x_coff, part, splits,
-                       (double)N * HW, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
+                       (double)N * HW * count_scale, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
                        scale, residual, r_ctot, r_coff, y, y_ctot, y_coff, N, C, HW, pre_relu, post_relu,
                        chunks, chunk_len, gap_out, gap_ctot, gap_coff);
   return dlio_check_launch();
@@ -616,30 +633,38 @@ extern "C" int dlio_bn_bwd(const float* dy, int dy_ctot, int dy_coff, const floa
                            int x_coff, const float* mean, const float* invstd, const float* scale,
                            const float* beta, float* dx, int dx_ctot, int dx_coff, float* dgamma,
                            float* dbeta, int accumulate, int N, int C, int HW, int pre_relu,
-                           int post_relu, int use_batch_stats, void* ws, size_t ws_bytes,
-                           dlio_stream_t stream) {
-  if (!dy || !x || !mean || !invstd || !scale || !dx || N <= 0 || C <= 0 || HW <= 0 || !ws)
+                           int post_relu, int use_batch_stats, void* ws, size_t ws_bytes, int phase,
+                           double count_scale, const void* local_ws, dlio_stream_t stream) {
+  if (!dy || !x || !mean || !invstd || !scale || !dx || N <= 0 || C <= 0 || HW <= 0 || !ws ||
+      phase < 0 || phase > 2 || !(count_scale >= 1.0))
     return DLIO_EINVAL;
   const int splits = pick_splits(N, C, HW);
   if (ws_bytes < (size_t)C * splits * 2 * sizeof(double)) return DLIO_EWS;
   hipStream_t s = as_stream(stream);
   double* part = reinterpret_cast<double*>(ws);
-  hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3((unsigned)(C * splits)), dim3(RB), 0, s, dy, dy_ctot,
-                     dy_coff, x, x_ctot, x_coff, mean, invstd, scale, beta, N, C, HW, pre_relu, post_relu,
-                     splits, part);
-  int rc = dlio_check_launch();
-  if (rc) return rc;
+  int rc = DLIO_OK;
+  if (phase != 2) {
+    hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3((unsigned)(C * splits)), dim3(RB), 0, s, dy, dy_ctot,
+                       dy_coff, x, x_ctot, x_coff, mean, invstd, scale, beta, N, C, HW, pre_relu, post_relu,
+                       splits, part);
+    rc = dlio_check_launch();
+    if (rc || phase == 1) return rc;
+  }
   const bool vec = (HW & 3) == 0;
   int chunks, chunk_len;
   plane_chunks(N * C, vec ? HW / 4 : HW, false, chunks, chunk_len);
   const dim3 grid((unsigned)(N * C * chunks));
+  const double inv_cnt = 1.0 / ((double)N * HW * count_scale);
+  const double* lpart = reinterpret_cast<const double*>(local_ws);
   if (vec)
     hipLaunchKernelGGL(bn_plane_bwd_kernel<true>, grid, dim3(256), 0, s, dy, dy_ctot, dy_coff, x, x_ctot,
-                       x_coff, mean, invstd, scale, beta, part, splits, dx, dx_ctot, dx_coff, dgamma, dbeta,
-                       accumulate, N, C, HW, pre_relu, post_relu, use_batch_stats, chunks, chunk_len);
+                       x_coff, mean, invstd, scale, beta, part, lpart, inv_cnt, splits, dx, dx_ctot, dx_coff,
+                       dgamma, dbeta, accumulate, N, C, HW, pre_relu, post_relu, use_batch_stats, chunks,
+                       chunk_len);
   else
     hipLaunchKernelGGL(bn_plane_bwd_kernel<false>, grid, dim3(256), 0, s, dy, dy_ctot, dy_coff, x, x_ctot,
-                       x_coff, mean, invstd, scale, beta, part, splits, dx, dx_ctot, dx_coff, dgamma, dbeta,
-                       accumulate, N, C, HW, pre_relu, post_relu, use_batch_stats, chunks, chunk_len);
+                       x_coff, mean, invstd, scale, beta, part, lpart, inv_cnt, splits, dx, dx_ctot, dx_coff,
+                       dgamma, dbeta, accumulate, N, C, HW, pre_relu, post_relu, use_batch_stats, chunks,
+                       chunk_len);
   return dlio_check_launch();
 }

@@ -9,8 +9,9 @@ started there (asynchronously, from an autograd hook) and runs over xGMI underne
 of encoder backward; only the remaining 22 MB are reduced after backward (~0.3 ms exposed
 instead of ~1.9 ms).
 
-BatchNorm statistics are per replica (the throughput configuration); the averaged gradient is
-exact for everything else.  Works on CPU tensors with the "gloo" backend, which is how the
+BatchNorm statistics are per replica in the throughput configuration; `GradSync.enable_sync_bn()`
+switches to synchronised statistics (exact equivalence with one device at the same global batch,
+tested with two ranks).  The averaged gradient is exact for everything else.  Works on CPU tensors with the "gloo" backend, which is how the
 -m "not gpu" tests cover the world_size > 1 path.
 """
 import os
@@ -57,6 +58,18 @@ class GradSync:
             optimizer.grad_scale = 1.0 / self.world
         self.tail_lo = None          # element offset where the early bucket starts
         self._tail_work = None
+
+    def enable_sync_bn(self, on=True):
+        """synchronised BatchNorm statistics: the per-channel partial sums of every train-mode BN
+        (forward: sum x, sum x^2; backward: sum g, sum g*xhat) are all-reduced between the reduce and
+        the apply kernel, so a global batch split over replicas trains exactly like the same batch on
+        one device (the reference is single-device).  Costs two small collectives per BN layer and
+        step: a parity switch, off for throughput runs."""
+        from . import ops
+        if on and self.world > 1:
+            ops.set_sync_bn(lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM), self.world)
+        else:
+            ops.set_sync_bn(None, 1)
 
     def set_tail(self, lo):
         """gradients [lo:] of the flat buffer are final when `reduce_tail_async` is called"""

@@ -246,28 +246,65 @@ def bn_train_stats(x, N, ctot, coff, C_, HW, pre_relu, gamma, eps, momentum, run
     return prm
 
 
+# SyncBN: (all_reduce callable, world) or None.  The callable sums a float64 tensor over the
+# data-parallel replicas in place (deeplio_amd.dist.GradSync.enable_sync_bn).
+_SYNC_BN = [None]
+
+
+def set_sync_bn(all_reduce, world):
+    _SYNC_BN[0] = (all_reduce, int(world)) if all_reduce is not None and world > 1 else None
+
+
+def _partials_view(ws, N, C_, HW):
+    n = C_ * lib.dlio_chan_stats_splits(N, C_, HW) * 2
+    return ws[:n * 8].view(torch.float64)
+
+
 def bn_train_apply(x, x_ctot, x_coff, gamma, beta, eps, momentum, running_mean, running_var, y, y_ctot,
                    y_coff, N, C_, HW, pre_relu, post_relu, residual=None, r_ctot=0, r_coff=0,
                    gap_out=None, gap_ctot=0, gap_coff=0):
-    """train-mode BN forward (statistics + apply) in two launches -> prm [3][C]"""
+    """train-mode BN forward (statistics + apply) in two launches -> prm [3][C]; with SyncBN the
+    partial sums are all-reduced between the two launches"""
     prm = torch.empty(3, C_, dtype=torch.float32, device=x.device)
     ws = _stats_ws(N, C_, HW, x.device)
-    check(lib.dlio_bn_train_apply(_ptr(x), N, x_ctot, x_coff, C_, HW, int(pre_relu), int(post_relu),
-                                  _ptr(gamma), _ptr(beta), float(eps), float(momentum), _ptr(running_mean),
-                                  _ptr(running_var), _ptr(prm[0]), _ptr(prm[1]), _ptr(prm[2]),
-                                  _ptr(residual), r_ctot, r_coff, _ptr(y), y_ctot, y_coff, _ptr(gap_out),
-                                  gap_ctot, gap_coff, _ptr(ws), ws.numel(), _stream()), "bn_train_apply")
+
+    def call(phase, scale):
+        check(lib.dlio_bn_train_apply(_ptr(x), N, x_ctot, x_coff, C_, HW, int(pre_relu), int(post_relu),
+                                      _ptr(gamma), _ptr(beta), float(eps), float(momentum), _ptr(running_mean),
+                                      _ptr(running_var), _ptr(prm[0]), _ptr(prm[1]), _ptr(prm[2]),
+                                      _ptr(residual), r_ctot, r_coff, _ptr(y), y_ctot, y_coff, _ptr(gap_out),
+                                      gap_ctot, gap_coff, _ptr(ws), ws.numel(), phase, float(scale), _stream()),
+              "bn_train_apply")
+    sync = _SYNC_BN[0]
+    if sync is None:
+        call(0, 1.0)
+    else:
+        call(1, 1.0)
+        sync[0](_partials_view(ws, N, C_, HW))
+        call(2, sync[1])
     return prm
 
 
 def bn_bwd_fused(dy, dy_ctot, dy_coff, x, x_ctot, x_coff, prm, beta, dx, dx_ctot, dx_coff, N, C_, HW,
                  pre_relu, post_relu, use_batch_stats, dgamma=None, dbeta=None, accumulate=False):
-    """BN backward (reductions + dx, dgamma, dbeta) in two launches"""
+    """BN backward (reductions + dx, dgamma, dbeta) in two launches (SyncBN: partials all-reduced in
+    between, dgamma / dbeta from the local copy)"""
     ws = _stats_ws(N, C_, HW, x.device)
-    check(lib.dlio_bn_bwd(_ptr(dy), dy_ctot, dy_coff, _ptr(x), x_ctot, x_coff, _ptr(prm[0]), _ptr(prm[1]),
-                          _ptr(prm[2]), _ptr(beta), _ptr(dx), dx_ctot, dx_coff, _ptr(dgamma), _ptr(dbeta),
-                          int(accumulate), N, C_, HW, int(pre_relu), int(post_relu), int(use_batch_stats),
-                          _ptr(ws), ws.numel(), _stream()), "bn_bwd")
+
+    def call(phase, scale, local):
+        check(lib.dlio_bn_bwd(_ptr(dy), dy_ctot, dy_coff, _ptr(x), x_ctot, x_coff, _ptr(prm[0]), _ptr(prm[1]),
+                              _ptr(prm[2]), _ptr(beta), _ptr(dx), dx_ctot, dx_coff, _ptr(dgamma), _ptr(dbeta),
+                              int(accumulate), N, C_, HW, int(pre_relu), int(post_relu), int(use_batch_stats),
+                              _ptr(ws), ws.numel(), phase, float(scale), _ptr(local), _stream()), "bn_bwd")
+    sync = _SYNC_BN[0]
+    if sync is None or not use_batch_stats:
+        call(0, 1.0, None)
+    else:
+        call(1, 1.0, None)
+        part = _partials_view(ws, N, C_, HW)
+        local = part.clone()
+        sync[0](part)
+        call(2, sync[1], local)
     return dx
 
 

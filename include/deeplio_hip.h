@@ -324,21 +324,30 @@ int dlio_gt_relative(const float* gts, const int32_t* combinations, float* f2f, 
  * n=0) and applies y = post((pre(x)-mean)*scale+beta) + residual like dlio_bn_apply.
  * gap_out (optional, [N][gap_ctot] with channel offset gap_coff): mean over HW of every OUTPUT
  * plane, bit-identical to dlio_gap_fwd(y) -- the SELayer behind a Fire block needs it.
- * ws: dlio_chan_stats_ws_bytes(N, C, HW). */
+ * ws: dlio_chan_stats_ws_bytes(N, C, HW); its first C * dlio_chan_stats_splits(N,C,HW) * 2 doubles
+ * are the (sum, sum of squares) partials.
+ * Synchronised statistics across data-parallel replicas (SyncBN): call with phase = 1 (partials
+ * only), all-reduce(sum) those doubles over the replicas, call again with phase = 2 (apply only)
+ * and count_scale = number of replicas.  phase = 0, count_scale = 1: the whole thing. */
+int dlio_chan_stats_splits(int N, int C, int HW);
 int dlio_bn_train_apply(const float* x, int N, int x_ctot, int x_coff, int C, int HW, int pre_relu,
                         int post_relu, const float* gamma, const float* beta, float eps,
                         float momentum, float* running_mean, float* running_var, float* mean,
                         float* invstd, float* scale, const float* residual, int r_ctot, int r_coff,
                         float* y, int y_ctot, int y_coff, float* gap_out, int gap_ctot, int gap_coff,
-                        void* ws, size_t ws_bytes, dlio_stream_t stream);
+                        void* ws, size_t ws_bytes, int phase, double count_scale,
+                        dlio_stream_t stream);
 /* BatchNorm backward in two launches: dlio_bn_bwd_reduce's reduction + a plane-structured
  * dlio_bn_bwd_apply that sums the partials itself; dgamma / dbeta (optional, += when accumulate)
- * are written by the workgroup of plane n=0. */
+ * are written by the workgroup of plane n=0.  phase / count_scale as above; local_ws (phase 2,
+ * optional): a copy of this replica's partials taken BEFORE the all-reduce -- dgamma / dbeta
+ * stay per-replica sums (the gradient all-reduce adds the others), dx uses the global sums. */
 int dlio_bn_bwd(const float* dy, int dy_ctot, int dy_coff, const float* x, int x_ctot, int x_coff,
                 const float* mean, const float* invstd, const float* scale, const float* beta,
                 float* dx, int dx_ctot, int dx_coff, float* dgamma, float* dbeta, int accumulate,
                 int N, int C, int HW, int pre_relu, int post_relu, int use_batch_stats, void* ws,
-                size_t ws_bytes, dlio_stream_t stream);
+                size_t ws_bytes, int phase, double count_scale, const void* local_ws,
+                dlio_stream_t stream);
 
 /* ---- lidar scan -> range image (the data step in front of the path) --------
  * LaserScan.do_range_projection (deeplio/common/laserscan.py:122-185): per point
