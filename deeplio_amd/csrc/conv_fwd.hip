@@ -645,6 +645,139 @@ int launch_1x1(const float* x, const float* wt, const float* bias, const float* 
   return dlio_check_launch();
 }
 
+// ---- 1x1, float4 pixels, K split over the four waves of a workgroup ---------------------------
+// For squeeze-type layers (many input channels, few output channels, few pixels: blk3-5) the
+// float4 kernel above has only one wave per SIMD in flight and the scalar kernel too few bytes per
+// load.  Here all four waves of a workgroup share the same 128 pixels x 32*MR channels and each
+// takes a quarter of the input channels (4x the waves, 16-byte loads); the partial accumulators
+// are combined through LDS in a fixed order and every wave stores a quarter of the rows.
+template <int MR>
+__global__ __launch_bounds__(256, 2) void conv1x1_v4_splitk_kernel(
+    const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
+    const float* residual, float* y, DlioConvDesc d, int pix_blocks, int co_tiles) {
+  constexpr int U = 4;
+  __shared__ float red[MR * 4 * 16 * 64];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int l31 = lane & 31;
+  const int half = lane >> 5;
+  int bid = blockIdx.x;
+  const int cot = bid % co_tiles; bid /= co_tiles;
+  const int pb = bid % pix_blocks; bid /= pix_blocks;
+  const int n = bid;
+  const int P = d.OH * d.OW;
+  const int co0 = cot * 32 * MR;
+  const int p = pb * 128 + 4 * l31;
+  const bool pvalid = p < P;
+  const size_t pc = pvalid ? p : 0;
+  const int Cin = d.Cin, Cout = d.Cout;
+
+  f32x16 acc[MR][4];
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][e][r] = 0.f;
+
+  const float* xq = x + ((size_t)n * d.in_ctot + d.in_coff) * (size_t)P + pc;
+  const float* wq[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) wq[m] = wt + (size_t)min(co0 + m * 32 + l31, Cout - 1) * 4;
+
+  float a[2][U][MR];
+  float4 b[2][U];
+  auto load_group = [&](int k0, int s) {
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      const float4 v = *reinterpret_cast<const float4*>(wq[m] + wt_index(0, k0 + half, 0, 0, Cout));
+      a[s][0][m] = v.x; a[s][1][m] = v.y; a[s][2][m] = v.z; a[s][3][m] = v.w;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int kk = k0 + 2 * u + half;
+      const bool kv = kk < Cin;
+      float4 v = *reinterpret_cast<const float4*>(xq + (size_t)(kv ? kk : Cin - 1) * P);
+      if (!kv) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      b[s][u] = v;
+    }
+  };
+  auto mfma_group = [&](int s) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int m = 0; m < MR; ++m) {
+        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][u][m], b[s][u].x, acc[m][0], 0, 0, 0);
+        acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][u][m], b[s][u].y, acc[m][1], 0, 0, 0);
+        acc[m][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][u][m], b[s][u].z, acc[m][2], 0, 0, 0);
+        acc[m][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][u][m], b[s][u].w, acc[m][3], 0, 0, 0);
+      }
+  };
+  // this wave's share of the channel groups (8 channels each)
+  const int ngroups = (Cin + 2 * U - 1) / (2 * U);
+  const int per = (ngroups + 3) / 4;
+  const int g0 = wave * per, g1 = min(ngroups, g0 + per);
+  if (g0 < g1) {
+    load_group(g0 * 2 * U, 0);
+    for (int g = g0; g < g1; g += 2) {
+      if (g + 1 < g1) load_group((g + 1) * 2 * U, 1);
+      mfma_group(0);
+      if (g + 2 < g1) load_group((g + 2) * 2 * U, 0);
+      if (g + 1 < g1) mfma_group(1);
+    }
+  }
+  // fixed-order sum of the four partial tiles
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int i = ((m * 4 + e) * 16 + r) * 64 + lane;
+            if (w == 0) red[i] = acc[m][e][r];
+            else red[i] += acc[m][e][r];
+          }
+    }
+    __syncthreads();
+  }
+  if (!pvalid) return;
+  // wave w stores rows r = 4w .. 4w+3 of every 16-row group
+  const size_t plane = (size_t)P;
+  float* yb = y + ((size_t)n * d.out_ctot + d.out_coff) * plane + pc;
+  const float* rb = residual ? residual + ((size_t)n * d.res_ctot + d.res_coff) * plane + pc : nullptr;
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int r = 4 * wave + rr;
+      const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (co >= Cout) continue;
+      const float bv = bias ? bias[co] : 0.f;
+      float4 o = make_float4(red[((m * 4 + 0) * 16 + r) * 64 + lane] + bv, red[((m * 4 + 1) * 16 + r) * 64 + lane] + bv,
+                             red[((m * 4 + 2) * 16 + r) * 64 + lane] + bv, red[((m * 4 + 3) * 16 + r) * 64 + lane] + bv);
+      if (rb) {
+        const float4 rv = *reinterpret_cast<const float4*>(rb + (size_t)co * plane);
+        o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+      }
+      *reinterpret_cast<float4*>(yb + (size_t)co * plane) = o;
+    }
+}
+
+template <int MR>
+int launch_1x1_splitk(const float* x, const float* wt, const float* bias, const float* residual, float* y,
+                      const DlioConvDesc& d, hipStream_t s) {
+  const int P = d.OH * d.OW;
+  const int pix_blocks = cdiv(P, 128);
+  const int co_tiles = cdiv(d.Cout, 32 * MR);
+  const int64_t blocks = (int64_t)pix_blocks * co_tiles * d.N;
+  if (blocks <= 0 || blocks > 0x7fffffff) return DLIO_EINVAL;
+  hipLaunchKernelGGL((conv1x1_v4_splitk_kernel<MR>), dim3((unsigned)blocks), dim3(256), 0, s, x, wt, bias,
+                     residual, y, d, pix_blocks, co_tiles);
+  return dlio_check_launch();
+}
+
 template <int MR>
 int launch_1x1_nr(const float* x, const float* wt, const float* bias, const float* in_mean,
                   const float* in_scale, const float* in_shift, const float* residual, float* y,
@@ -657,6 +790,12 @@ int launch_1x1_nr(const float* x, const float* wt, const float* bias, const floa
   const int64_t waves4 = (int64_t)cdiv(P, 128) * cdiv(d.Cout, 32 * MR) * d.N;
   if (use_v4 && (P & 3) == 0 && (al & 15) == 0 && waves4 >= 2048)
     return launch_1x1_v4<MR>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
+  // under-filled float4 launch with a long K: split K over the workgroup's waves
+  static const int splitk = getenv("DLIO_1X1_SPLITK") ? atoi(getenv("DLIO_1X1_SPLITK")) : 1;   // tuning knob
+  if constexpr (MR <= 2) {
+    if (splitk && use_v4 && !in_scale && (P & 3) == 0 && (al & 15) == 0 && d.Cin >= 256)   // sweep: 192-channel layers lose
+      return launch_1x1_splitk<MR>(x, wt, bias, residual, y, d, s);
+  }
   const int64_t waves2 = (int64_t)cdiv(d.OH * d.OW, 64) * cdiv(d.Cout, 32 * MR) * d.N;
   static const int force_nr = getenv("DLIO_1X1_NR") ? atoi(getenv("DLIO_1X1_NR")) : 0;   // tuning knob
   if (MR < 3 && (force_nr == 2 || (force_nr == 0 && waves2 >= 4096)))
