@@ -898,7 +898,11 @@ extern "C" int dlio_conv2d_fwd(const float* x, const float* wt, const float* bia
   if (d.KH == kh && d.KW == kw && d.SH == sh && d.SW == sw)                                  \
     rc = launch_tw<kh, kw, sh, sw, ck>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
   if (d.KH == 1 && d.KW == 1 && d.SH == 1 && d.SW == 1 && d.PH == 0 && d.PW == 0) {
-    if (d.Cout <= 32) rc = launch_1x1_nr<1>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
+    static const int shortk_mr1 = getenv("DLIO_1X1_SHORTK_MR1") ? atoi(getenv("DLIO_1X1_SHORTK_MR1")) : 80;
+    // short K (squeeze data gradient, expand1x1 forward: <= 80 input channels) is store-bound:
+    // 32-channel tiles (twice the waves, half the registers) are 8-12 % faster there (sweep)
+    if (d.Cout <= 32 || (shortk_mr1 && d.Cin <= shortk_mr1))
+      rc = launch_1x1_nr<1>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
     else if (d.Cout > 64 && d.Cout <= 96)
       rc = launch_1x1_nr<3>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
     else rc = launch_1x1_nr<2>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
