@@ -846,9 +846,10 @@ bool make_plan_1x1(const DlioConvDesc& d, Wg1Plan& p) {
   p.segs = (int)(hw / 32);
   const int64_t total = (int64_t)d.N * p.segs;
   const int64_t pairs = (int64_t)p.co_tiles * p.ci_chunks;
-  // measured (tools/conv_table.py, blocks 128..768): one workgroup per CU is the sweet spot, both
-  // fewer and more (320: a second, mostly empty round) are 15-50 % slower
-  static const int tgt = getenv("DLIO_WGRAD_1X1_BLOCKS") ? atoi(getenv("DLIO_WGRAD_1X1_BLOCKS")) : dlio_num_cus();
+  // measured: in isolation (tools/conv_table.py, blocks 128..768) one workgroup per CU is the
+  // sweet spot and a partial second round (320) costs 15-50 %; inside the training step, where
+  // the other encoder's kernels share the chip, two per CU is 0.2 ms/step better (tools/sweep_env.sh)
+  static const int tgt = getenv("DLIO_WGRAD_1X1_BLOCKS") ? atoi(getenv("DLIO_WGRAD_1X1_BLOCKS")) : 2 * dlio_num_cus();
   int64_t splits = tgt / pairs > 0 ? tgt / pairs : 1;
   // every wave should stream at least MINSEG segments, or prologue + slab reduction dominate
   static const int minseg = getenv("DLIO_WGRAD_1X1_MINSEG") ? atoi(getenv("DLIO_WGRAD_1X1_MINSEG")) : 2;
