@@ -163,9 +163,19 @@ class PSEncoder(BaseNet):
         self.output_shapes = torch.Size([1, 768, hh, ww])
 
     def forward(self, x):
+        for x in self.forward_steps(x):
+            pass
+        return x
+
+    def forward_steps(self, x):
+        """the forward pass as a generator that yields after every module: the two siamese encoders
+        are issued in lockstep on their two streams (BaseLidarFeatNet.forward), so neither stream
+        waits while the host issues the other encoder -- and, because autograd replays nodes in
+        reverse creation order, backward alternates between the two streams as well"""
         tr = self.training
         _bump(self.conv1a[1], tr)
         x = self.pool1(_cbr(x, self.conv1a[0], self.conv1a[1], tr))
+        yield x
         for name, *_ in PS_BLOCKS:
             mods = list(getattr(self, name))
             i = 0
@@ -185,7 +195,7 @@ class PSEncoder(BaseNet):
                 else:
                     x = m(x)
                     i += 1
-        return x
+                yield x
 
     def get_output_shape(self):
         return self.output_shapes
@@ -340,6 +350,7 @@ class BaseLidarFeatNet(BaseNet):
         self.fc1 = nn.Linear(nfeat, 128)
         self.output_shape = torch.Size([1, self.seq_size, 128])
         self.two_streams = os.environ.get("DLIO_TWO_STREAMS", "1") != "0"
+        self.interleave = os.environ.get("DLIO_INTERLEAVE", "1") != "0"
         self._side = None
 
     def forward(self, x):
@@ -354,11 +365,30 @@ class BaseLidarFeatNet(BaseNet):
                 self._side = Fh.aux_stream(xyz.device, "encoder2")
             main = torch.cuda.current_stream()
             self._side.wait_stream(main)
-            with torch.cuda.stream(self._side):
-                fb = self.encoder2(xb)
+            if self.interleave and hasattr(self.encoder1, "forward_steps"):
+                ga, gb = self.encoder1.forward_steps(xa), self.encoder2.forward_steps(xb)
+                fa = fb = None
+                while ga is not None or gb is not None:
+                    if gb is not None:
+                        with torch.cuda.stream(self._side):
+                            try:
+                                fb = next(gb)
+                            except StopIteration:
+                                gb = None
+                    if ga is not None:
+                        try:
+                            fa = next(ga)
+                        except StopIteration:
+                            ga = None
                 if fb.dim() == 4:
-                    fb = Fh.GapFn.apply(fb)
-            fa = self.encoder1(xa)
+                    with torch.cuda.stream(self._side):
+                        fb = Fh.GapFn.apply(fb)
+            else:
+                with torch.cuda.stream(self._side):
+                    fb = self.encoder2(xb)
+                    if fb.dim() == 4:
+                        fb = Fh.GapFn.apply(fb)
+                fa = self.encoder1(xa)
             if fa.dim() == 4:
                 fa = Fh.GapFn.apply(fa)
             main.wait_stream(self._side)
