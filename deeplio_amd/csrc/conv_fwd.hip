@@ -891,7 +891,9 @@ extern "C" int dlio_conv2d_fwd(const float* x, const float* wt, const float* bia
   const double flops = 2.0 * d.N * (double)d.OH * d.OW * d.Cout * (double)d.Cin * d.KH * d.KW;
   const double bytes = 4.0 * d.N * ((double)d.Cin * d.H * d.W + (double)d.Cout * d.OH * d.OW *
                                    (residual ? 2.0 : 1.0));
-  dlio_prof_begin(0, s, flops, bytes);
+  // profiler kinds: 0 = multi-tap convolutions (MFMA-bound), 2 = 1x1 convolutions (HBM-bound)
+  const int pkind = (d.KH == 1 && d.KW == 1) ? 2 : 0;
+  dlio_prof_begin(pkind, s, flops, bytes);
   int rc = DLIO_EUNSUP;
   static const int ck8 = getenv("DLIO_CONV_CK8") ? atoi(getenv("DLIO_CONV_CK8")) : 1;   // tuning knob
 #define CONV_CASE(kh, kw, sh, sw, ck)                                                        \
@@ -920,6 +922,6 @@ extern "C" int dlio_conv2d_fwd(const float* x, const float* wt, const float* bia
   else CONV_CASE(1, 1, 1, 2, 16)
   else CONV_CASE(1, 1, 2, 2, 16)
 #undef CONV_CASE
-  dlio_prof_end(0, s);
+  dlio_prof_end(pkind, s);
   return rc;
 }

@@ -47,7 +47,8 @@ const char* dlio_last_hip_error_string(void);
  * When enabled, the conv launchers bracket each launch with hipEvents on the
  * launch stream.  dlio_prof_collect synchronises those events and returns the
  * summed milliseconds / algorithmic FLOPs / launch count per kernel kind
- * (0 = conv fwd/dgrad MFMA kernel, 1 = conv wgrad MFMA kernel). */
+ * (0 = multi-tap conv forward / data gradient: MFMA-bound; 1 = conv weight gradient;
+ *  2 = 1x1 conv forward / data gradient: HBM-bound). */
 int dlio_prof_enable(int on);
 int dlio_prof_reset(void);
 int dlio_prof_collect(int kind, double* ms, double* flops, double* bytes, int64_t* launches);

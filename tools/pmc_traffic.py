@@ -16,7 +16,8 @@ import sqlite3
 import sys
 
 FAMILIES = {
-    "conv2d_fwd_mfma": ("conv_fwd_kernel", "conv1x1_direct_kernel", "conv1x1_v4_kernel"),
+    "conv2d_fwd_mfma": ("conv_fwd_kernel",),
+    "conv2d_1x1": ("conv1x1_",),
     "conv2d_wgrad_mfma": ("wgrad",),
     "batchnorm": ("chan_reduce", "chan_stats", "bn_apply", "bn_bwd", "bn_plane"),
     "pool_se": ("maxpool", "gap_", "chan_scale", "pool3"),
