@@ -80,8 +80,12 @@ class GradSync:
 
     def reduce_tail_async(self):
         """start the all-reduce of the tail bucket (called from the autograd hook on the odometry
-        net's input: every kernel that wrote these gradients ran on the hook's current stream)"""
+        net's input: every kernel that wrote these gradients ran on the hook's current stream or
+        on its weight-gradient companion)"""
         if self.world > 1 and self.tail_lo is not None and self._tail_work is None:
+            if self.flat_grad.is_cuda:
+                from .functional import join_wgrad_stream
+                join_wgrad_stream()     # the tail's weight gradients are forked onto the companion stream
             self._tail_work = dist.all_reduce(self.flat_grad[self.tail_lo:], op=dist.ReduceOp.SUM, async_op=True)
 
     def broadcast_parameters(self, extra=()):

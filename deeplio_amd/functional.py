@@ -39,7 +39,9 @@ def set_grad_sink(on):
 # to it) and again, explicitly, by FlatOptimizer.step()/GradSync.
 _AUX = {}                   # (device index, name) -> torch.cuda.Stream
 _JOIN_PENDING = [False]
-_WGRAD_FORK = [os.environ.get("DLIO_WGRAD_STREAM", "0") != "0"]   # measured: 43.5 vs 41.9 ms/step -> off
+# weight-gradient fork: slower when first tried (43.5 vs 41.9 ms/step, staged wgrad kernels that filled
+# the chip); with the direct kernels it is 33.2 vs 33.9 ms/step -> on
+_WGRAD_FORK = [os.environ.get("DLIO_WGRAD_STREAM", "1") != "0"]
 
 
 def aux_stream(device, name):
@@ -72,6 +74,45 @@ def _want_join():
             _JOIN_PENDING[0] = False
 
 
+class DeferredBranchFn(Function):
+    """Re-attaches a branch that was computed early on its own stream at the point where its output
+    is consumed.  The autograd engine runs ready nodes newest-first, so a branch issued first in
+    forward (the IMU net: nets.py DeepLIO.forward) has its backward nodes run -- and their kernels
+    enqueued behind an event on the main stream -- after everything issued later, i.e. after the
+    whole encoder backward.  This node is created late, becomes ready as soon as the consumer's
+    backward has produced the branch gradient, and runs the branch's backward right there on the
+    branch's stream, where it overlaps the encoder backward instead of trailing it."""
+
+    _ANCHOR = {}
+
+    @staticmethod
+    def attach(inner, stream):
+        """inner: the branch output (still attached to the branch's own tape)"""
+        key = inner.device
+        a = DeferredBranchFn._ANCHOR.get(key)
+        if a is None:       # the only differentiable input: makes the output require grad
+            a = DeferredBranchFn._ANCHOR[key] = torch.zeros((), device=inner.device, requires_grad=True)
+        return DeferredBranchFn.apply(a, (inner,), stream)
+
+    @staticmethod
+    def forward(ctx, anchor, inner, stream):
+        # `inner` travels in a tuple: as a tensor argument its producer would become a child of
+        # this node and be run a second time by the outer pass
+        ctx.inner, ctx.stream = inner[0], stream
+        return inner[0].detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        inner, s = ctx.inner, ctx.stream
+        ctx.inner = None
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            torch.autograd.backward([inner], [g])
+        g.record_stream(s)
+        _want_join()
+        return None, None, None
+
+
 def set_wgrad_stream(on):
     _WGRAD_FORK[0] = bool(on)
 
@@ -82,6 +123,24 @@ def _wgrad_stream(like):
         return None
     cur = torch.cuda.current_stream()
     return aux_stream(like.device, "wgrad@%x" % cur.cuda_stream)
+
+
+def join_wgrad_stream():
+    """current stream waits for the weight-gradient kernels forked from it so far"""
+    if torch.cuda.is_available():
+        cur = torch.cuda.current_stream()
+        ws = _AUX.get((cur.device.index, "wgrad@%x" % cur.cuda_stream))
+        if ws is not None:
+            cur.wait_stream(ws)
+
+
+def _forked(ws, fn, *tensors):
+    """run fn() (a launch whose only output is a sunk gradient) on the companion stream ws"""
+    ws.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(ws):
+        fn()
+    for t in tensors:
+        t.record_stream(ws)
 
 
 def _sink(param, shape, like):
@@ -167,11 +226,7 @@ class _CBR:
         else:
             # the weight gradient goes straight into the flat gradient buffer and nothing on the
             # tape waits for it: fork it so the data-gradient chain continues immediately
-            ws.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(ws):
-                ops.conv2d_wgrad(x, draw, dw, dd, accumulate=True)
-            draw.record_stream(ws)
-            x.record_stream(ws)
+            _forked(ws, lambda: ops.conv2d_wgrad(x, draw, dw, dd, accumulate=True), draw, x)
         if need_dx:
             conv_dgrad(draw, weight, d, dx, dx_ctot, dx_coff, dx_residual, dxr_ctot, dxr_coff,
                        dx_accumulate)
@@ -625,6 +680,7 @@ class RNNFn(Function):
                 outs[wi], outs[with_bias_slot] = ow, ob
                 grads[wi], grads[with_bias_slot] = rw, rb
                 first[wi] = not aw_        # sunk gradients accumulate from the first call on
+            # (forking these onto the weight-gradient stream was measured: 34.7 vs 33.5 ms/step)
             ops.linear_bwd_weight(dz, xin, rows, N_, K, dw=outs[wi], db=outs[with_bias_slot],
                                   lddz=lddz, ldx=ldx, accumulate=not first[wi])
             first[wi] = False

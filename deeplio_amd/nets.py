@@ -17,6 +17,9 @@ from . import functional as Fh
 from . import ops
 from .misc import get_config_container
 
+# IMU branch backward scheduled at the fusion layer instead of at the end of the backward pass
+_DEFER_IMU = os.environ.get("DLIO_DEFER_IMU_BWD", "1") != "0"
+
 
 def _pair(v):
     return (v, v) if isinstance(v, int) else tuple(v)
@@ -682,6 +685,8 @@ class DeepLIO(BaseNet):
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
             feat_i.record_stream(torch.cuda.current_stream())
+            if _DEFER_IMU and torch.is_grad_enabled() and feat_i.requires_grad:
+                feat_i = Fh.DeferredBranchFn.attach(feat_i, side)
         if feat_i is not None:
             last = feat_i
         if self.fusion_net is not None:
