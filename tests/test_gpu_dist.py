@@ -106,3 +106,59 @@ def test_two_ranks_without_sync_bn_differ_only_through_batchnorm(dev, tmp_path):
     k = next(iter(bufs1))
     assert float((dp["bufs"][k] - bufs1[k]).abs().max()) > 1e-6 * float(bufs1[k].abs().max())
     assert abs(dp["loss"] - loss1) <= 5e-2 * abs(loss1)          # same model, slightly different statistics
+
+
+RCCL_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(gold)r)
+import golden_common as gc
+from deeplio_amd import dist as ddist, ops
+from deeplio_amd.trainer import TrainStep
+sys.path.insert(0, %(here)r)
+from test_gpu_dist import make_cfg, SHAPE, T, GB
+import torch.distributed as dist
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1)
+res = {}
+for mode in ("plain", "rccl"):
+    ts = TrainStep(make_cfg(), SHAPE, dev, GB)
+    gc.fill_state(ts.model, seed=77)
+    if mode == "rccl":
+        sync = ddist.GradSync(ts.optimizer.flat, ts.optimizer.grad, ts.optimizer)
+        sync.world = 2                   # open every world > 1 branch; the group itself has one rank,
+        sync.broadcast_parameters()      # so each collective is the identity and grad_scale stays 1
+        ops.set_sync_bn(lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM), 1)
+        ts.set_grad_sync(sync)
+        assert sync.tail_lo is not None
+    batch = tuple(t.to(dev) for t in gc.make_batch(500, GB, 2, SHAPE[0], SHAPE[1], SHAPE[2], T))
+    losses = [float(ts.step(*batch)) for _ in range(2)]
+    torch.cuda.synchronize()
+    if mode == "rccl":
+        assert sync.max_over_ranks(1.5) == 1.5
+        dist.barrier()
+        ops.set_sync_bn(None, 1)
+    res[mode] = {"loss": losses, "grad": ts.optimizer.grad.cpu().clone(), "flat": ts.optimizer.flat.detach().cpu().clone()}
+torch.save(res, %(out)r)
+dist.destroy_process_group()
+'''
+
+
+def test_collective_call_sites_run_through_rccl(dev, tmp_path):
+    """The N>1 path cannot be launched on a 1-GPU box over RCCL (it refuses two ranks on one device),
+    but every collective call site can: a one-rank RCCL group with the world > 1 branches forced open
+    (parameter broadcast, async tail-bucket all-reduce from the autograd hook, head-bucket all-reduce,
+    SyncBN partial sums, max-over-ranks, barrier).  Each collective is then the identity, so two
+    optimizer steps must be bit-identical to the non-distributed run."""
+    out = str(tmp_path / "rccl.pt")
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER % dict(root=ROOT, gold=os.path.join(HERE, "golden"), here=HERE, out=out))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:]
+    res = torch.load(out, weights_only=False)
+    assert res["plain"]["loss"] == res["rccl"]["loss"]
+    assert torch.equal(res["plain"]["grad"], res["rccl"]["grad"])
+    assert torch.equal(res["plain"]["flat"], res["rccl"]["flat"])
