@@ -198,6 +198,8 @@ def test_stream_overlap_is_bit_exact(dev):
     misc.build_config_container(cfg, types.SimpleNamespace(device=str(dev), batch_size=2))
     batch = tuple(t.to(dev) for t in gc.make_batch(11, 2, 2, 5, 64, 512, 50))
     res = []
+    from deeplio_amd import functional as Fh
+    wgrad_default = Fh._WGRAD_FORK[0]
     for overlap in (True, False, True):
         model = nets.get_model((5, 64, 512), cfg, dev)
         gc.fill_state(model, seed=1000)
@@ -210,7 +212,7 @@ def test_stream_overlap_is_bit_exact(dev):
                 m.side_stream = overlap
         from deeplio_amd import functional as Fh
         Fh.manual_seed(5)
-        Fh.set_wgrad_stream(overlap)     # optional fork of the weight-gradient kernels
+        Fh.set_wgrad_stream(overlap)     # fork of the weight-gradient kernels
         outs = []
         for _ in range(2):
             model.zero_grad()
@@ -220,7 +222,7 @@ def test_stream_overlap_is_bit_exact(dev):
             outs.append([loss.detach().clone(), pt.detach().clone()]
                         + [p.grad.detach().clone() for p in model.parameters() if p.grad is not None])
         res.append(outs)
-    Fh.set_wgrad_stream(False)
+    Fh.set_wgrad_stream(wgrad_default)
     for other in res[1:]:
         for a_step, b_step in zip(res[0], other):
             assert len(a_step) == len(b_step)
