@@ -19,6 +19,17 @@ def main(db_path, out_path, steps, note=""):
             n = re.sub(r"\(anonymous namespace\)::|void ", "", n)
             n = re.sub(r"\(.*", "", n)
             f.write("| `%s` | %d | %.2f | %.1f | %.1f | %.1f | %.1f |\n" % (n[:90], c, s, a, mn, mx, 100 * s / tot))
+        # the bench's kernel families (ops.prof kinds): average launch duration to compare with
+        # roofline.avg_launch_ms / roofline.isolated.avg_launch_ms of the bench JSON
+        fam = {"conv2d_fwd_mfma, multi-tap (forward + data gradient)": ("conv_fwd_kernel",),
+               "conv2d_wgrad_mfma (+ split reduce)": ("wgrad",),
+               "conv2d_1x1 (forward + data gradient)": ("conv1x1_",)}
+        f.write("\n| bench family | kernel launches | total ms | avg us per kernel launch |\n|---|---|---|---|\n")
+        for name, pats in fam.items():
+            sel = [r for r in rows if any(p in r[0] for p in pats)]
+            c, t = sum(r[1] for r in sel), sum(r[2] for r in sel)
+            if c:
+                f.write("| %s | %d | %.2f | %.1f |\n" % (name, c, t, 1e3 * t / c))
     print("wrote", out_path)
 
 
