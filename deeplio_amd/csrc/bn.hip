@@ -13,7 +13,7 @@ constexpr int RB = 256;  // reduction block
 
 // split the (n, hw) domain of one channel over `splits` blocks.
 // mode 0: stats (sum x', sum x'^2)    mode 1: bn backward (sum g, sum g*xh)   mode 2: sum only
-template <int MODE>
+template <int MODE, int UN = 1>
 __global__ __launch_bounds__(RB) void chan_reduce_kernel(
     const float* __restrict__ a, int a_ctot, int a_coff, const float* __restrict__ x, int x_ctot,
     int x_coff, const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -28,17 +28,23 @@ __global__ __launch_bounds__(RB) void chan_reduce_kernel(
   const int64_t total = (int64_t)N * HW;
   const bool vec = (HW & 3) == 0;
   if (vec) {
+    // (n, p) cursor advanced by the block stride (one division up front) and UN independent loads
+    // per operand in flight: beside a resident MFMA kernel only a few wave slots per SIMD are
+    // free, and bytes in flight per wave are what keeps the HBM pipe full then
     const int64_t total4 = total >> 2;
     const int hw4 = HW >> 2;
-    for (int64_t i = (int64_t)sp * RB + threadIdx.x; i < total4; i += (int64_t)splits * RB) {
-      const int n = (int)(i / hw4);
-      const int p = (int)(i - (int64_t)n * hw4) << 2;
-      const float4 av = *reinterpret_cast<const float4*>(a + ((size_t)n * a_ctot + a_coff + c) * HW + p);
-      float ae[4] = {av.x, av.y, av.z, av.w};
+    const int64_t stride = (int64_t)splits * RB;
+    const int q = (int)(stride / hw4), r = (int)(stride - (int64_t)q * hw4);
+    int64_t i = (int64_t)sp * RB + threadIdx.x;
+    int n = (int)(i / hw4), p = (int)(i - (int64_t)n * hw4);
+    const float* ab = a + ((size_t)a_coff + c) * HW;
+    const float* xb = MODE == 1 ? x + ((size_t)x_coff + c) * HW : nullptr;
+    const size_t an = (size_t)a_ctot * HW, xn = (size_t)x_ctot * HW;
+    auto acc = [&](const float4& av, const float4& xv) {
+      const float ae[4] = {av.x, av.y, av.z, av.w};
+      float f0 = 0.f, f1 = 0.f;
       if (MODE == 1) {
-        const float4 xv = *reinterpret_cast<const float4*>(x + ((size_t)n * x_ctot + x_coff + c) * HW + p);
-        float xe[4] = {xv.x, xv.y, xv.z, xv.w};
-        float f0 = 0.f, f1 = 0.f;
+        const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           float xx = pre_relu ? fmaxf(xe[k], 0.f) : xe[k];
@@ -49,7 +55,6 @@ __global__ __launch_bounds__(RB) void chan_reduce_kernel(
         }
         s0 += f0; s1 += f1;
       } else {
-        float f0 = 0.f, f1 = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           float xx = (MODE == 0 && pre_relu) ? fmaxf(ae[k], 0.f) : ae[k];
@@ -57,6 +62,29 @@ __global__ __launch_bounds__(RB) void chan_reduce_kernel(
         }
         s0 += f0; s1 += (MODE == 0) ? (double)f1 : 0.0;
       }
+    };
+    if (UN > 1) {
+      for (; i + (UN - 1) * stride < total4; i += UN * stride) {
+        float4 av[UN], xv[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          av[u] = *reinterpret_cast<const float4*>(ab + (size_t)n * an + ((size_t)p << 2));
+          if (MODE == 1) xv[u] = *reinterpret_cast<const float4*>(xb + (size_t)n * xn + ((size_t)p << 2));
+          else xv[u] = av[u];
+          n += q; p += r;
+          if (p >= hw4) { p -= hw4; ++n; }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) acc(av[u], xv[u]);
+      }
+    }
+    for (; i < total4; i += stride) {
+      const float4 av = *reinterpret_cast<const float4*>(ab + (size_t)n * an + ((size_t)p << 2));
+      float4 xv = av;
+      if (MODE == 1) xv = *reinterpret_cast<const float4*>(xb + (size_t)n * xn + ((size_t)p << 2));
+      acc(av, xv);
+      n += q; p += r;
+      if (p >= hw4) { p -= hw4; ++n; }
     }
   } else {
     for (int64_t i = (int64_t)sp * RB + threadIdx.x; i < total; i += (int64_t)splits * RB) {
@@ -295,7 +323,7 @@ __device__ __forceinline__ void plane_partials(const double* __restrict__ part, 
   a = bc[0]; b = bc[1];
 }
 
-template <bool VEC>
+template <bool VEC, int UN = 1>
 __global__ __launch_bounds__(256) void bn_plane_apply_kernel(
     const float* __restrict__ x, int x_ctot, int x_coff, const double* __restrict__ part, int splits,
     double count, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
@@ -328,7 +356,32 @@ __global__ __launch_bounds__(256) void bn_plane_apply_kernel(
   const int per = VEC ? (HW >> 2) : HW;
   const int i1 = min(per, (chunk + 1) * chunk_len);
   double gs = 0.0;
-  for (int i = chunk * chunk_len + threadIdx.x; i < i1; i += 256) {
+  int i = chunk * chunk_len + threadIdx.x;
+  if (VEC && UN > 1) {
+    for (; i + (UN - 1) * 256 < i1; i += UN * 256) {
+      float4 v[UN], rv[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        v[u] = *reinterpret_cast<const float4*>(xp + ((size_t)(i + u * 256) << 2));
+        rv[u] = rp ? *reinterpret_cast<const float4*>(rp + ((size_t)(i + u * 256) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+        const float re[4] = {rv[u].x, rv[u].y, rv[u].z, rv[u].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float xx = pre_relu ? fmaxf(e[k], 0.f) : e[k];
+          float o = (xx - mu) * sc + be;
+          if (post_relu) o = fmaxf(o, 0.f);
+          e[k] = o + re[k];
+        }
+        *reinterpret_cast<float4*>(yp + ((size_t)(i + u * 256) << 2)) = make_float4(e[0], e[1], e[2], e[3]);
+        gs += (double)((e[0] + e[1]) + (e[2] + e[3]));
+      }
+    }
+  }
+  for (; i < i1; i += 256) {
     if (VEC) {
       const float4 v = *reinterpret_cast<const float4*>(xp + ((size_t)i << 2));
       float e[4] = {v.x, v.y, v.z, v.w};
@@ -360,7 +413,7 @@ __global__ __launch_bounds__(256) void bn_plane_apply_kernel(
   }
 }
 
-template <bool VEC>
+template <bool VEC, int UN = 1>
 __global__ __launch_bounds__(256) void bn_plane_bwd_kernel(
     const float* __restrict__ dy, int dy_ctot, int dy_coff, const float* __restrict__ x, int x_ctot,
     int x_coff, const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -393,7 +446,35 @@ __global__ __launch_bounds__(256) void bn_plane_bwd_kernel(
   const int per = VEC ? (HW >> 2) : HW;
   const int i1 = min(per, (chunk + 1) * chunk_len);
   constexpr int V = VEC ? 4 : 1;
-  for (int i = chunk * chunk_len + threadIdx.x; i < i1; i += 256) {
+  int i = chunk * chunk_len + threadIdx.x;
+  if (VEC && UN > 1) {
+    for (; i + (UN - 1) * 256 < i1; i += UN * 256) {
+      float4 gv[UN], xv[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        gv[u] = *reinterpret_cast<const float4*>(gp + ((size_t)(i + u * 256) << 2));
+        xv[u] = *reinterpret_cast<const float4*>(xp + ((size_t)(i + u * 256) << 2));
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        float ge[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+        const float xe[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float xraw = xe[k];
+          const float xx = pre_relu ? fmaxf(xraw, 0.f) : xraw;
+          float g = ge[k];
+          if (post_relu && !((xx - mu) * sc + be > 0.f)) g = 0.f;
+          const float xh = (xx - mu) * is;
+          float o = sc * (g - mg - xh * mgx);
+          if (pre_relu && !(xraw > 0.f)) o = 0.f;
+          ge[k] = o;
+        }
+        *reinterpret_cast<float4*>(op + ((size_t)(i + u * 256) << 2)) = make_float4(ge[0], ge[1], ge[2], ge[3]);
+      }
+    }
+  }
+  for (; i < i1; i += 256) {
     float ge[4], xe[4];
     if (VEC) {
       const float4 gv = *reinterpret_cast<const float4*>(gp + ((size_t)i << 2));
@@ -434,6 +515,14 @@ static void plane_chunks(int planes, int per, bool whole_plane, int& chunks, int
 }
 
 }  // namespace
+
+// loads in flight per thread in the streaming kernels: 4 (statistics, apply) / 2 per operand (backward);
+// beside a resident MFMA kernel few wave slots are free, so bandwidth has to come from bytes in
+// flight per wave (measured on the full step: 1 -> 33.1 ms, 4 -> 32.8 ms, 8 -> 33.1 ms)
+static int bn_unroll() {
+  static const int v = getenv("DLIO_BN_UNROLL") ? atoi(getenv("DLIO_BN_UNROLL")) : 4;
+  return v;
+}
 
 extern "C" int dlio_chan_stats_splits(int N, int C, int HW) {
   if (N <= 0 || C <= 0 || HW <= 0) return 0;
@@ -606,7 +695,12 @@ extern "C" int dlio_bn_train_apply(const float* x, int N, int x_ctot, int x_coff
   double* part = reinterpret_cast<double*>(ws);
   int rc = DLIO_OK;
   if (phase != 2) {
-    hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3((unsigned)(C * splits)), dim3(RB), 0, s, x, x_ctot, x_coff,
+    if (bn_unroll() > 1)
+      hipLaunchKernelGGL((chan_reduce_kernel<0, 4>), dim3((unsigned)(C * splits)), dim3(RB), 0, s, x, x_ctot, x_coff,
+                       (const float*)nullptr, 0, 0, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, N, C, HW, pre_relu, 0, splits, part);
+    else
+      hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3((unsigned)(C * splits)), dim3(RB), 0, s, x, x_ctot, x_coff,
                        (const float*)nullptr, 0, 0, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, N, C, HW, pre_relu, 0, splits, part);
     rc = dlio_check_launch();
@@ -616,7 +710,12 @@ extern "C" int dlio_bn_train_apply(const float* x, int N, int x_ctot, int x_coff
   int chunks, chunk_len;
   plane_chunks(N * C, vec ? HW / 4 : HW, gap_out != nullptr, chunks, chunk_len);
   const dim3 grid((unsigned)(N * C * chunks));
-  if (vec)
+  if (vec && bn_unroll() > 1)
+    hipLaunchKernelGGL((bn_plane_apply_kernel<true, 4>), grid, dim3(256), 0, s, x, x_ctot, x_coff, part, splits,
+                       (double)N * HW * count_scale, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
+                       scale, residual, r_ctot, r_coff, y, y_ctot, y_coff, N, C, HW, pre_relu, post_relu,
+                       chunks, chunk_len, gap_out, gap_ctot, gap_coff);
+  else if (vec)
     hipLaunchKernelGGL(bn_plane_apply_kernel<true>, grid, dim3(256), 0, s, x, x_ctot, x_coff, part, splits,
                        (double)N * HW * count_scale, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
                        scale, residual, r_ctot, r_coff, y, y_ctot, y_coff, N, C, HW, pre_relu, post_relu,
@@ -644,7 +743,12 @@ extern "C" int dlio_bn_bwd(const float* dy, int dy_ctot, int dy_coff, const floa
   double* part = reinterpret_cast<double*>(ws);
   int rc = DLIO_OK;
   if (phase != 2) {
-    hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3((unsigned)(C * splits)), dim3(RB), 0, s, dy, dy_ctot,
+    if (bn_unroll() > 1)
+      hipLaunchKernelGGL((chan_reduce_kernel<1, 2>), dim3((unsigned)(C * splits)), dim3(RB), 0, s, dy, dy_ctot,
+                       dy_coff, x, x_ctot, x_coff, mean, invstd, scale, beta, N, C, HW, pre_relu, post_relu,
+                       splits, part);
+    else
+      hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3((unsigned)(C * splits)), dim3(RB), 0, s, dy, dy_ctot,
                        dy_coff, x, x_ctot, x_coff, mean, invstd, scale, beta, N, C, HW, pre_relu, post_relu,
                        splits, part);
     rc = dlio_check_launch();
@@ -656,7 +760,12 @@ extern "C" int dlio_bn_bwd(const float* dy, int dy_ctot, int dy_coff, const floa
   const dim3 grid((unsigned)(N * C * chunks));
   const double inv_cnt = 1.0 / ((double)N * HW * count_scale);
   const double* lpart = reinterpret_cast<const double*>(local_ws);
-  if (vec)
+  if (vec && bn_unroll() > 1)
+    hipLaunchKernelGGL((bn_plane_bwd_kernel<true, 2>), grid, dim3(256), 0, s, dy, dy_ctot, dy_coff, x, x_ctot,
+                       x_coff, mean, invstd, scale, beta, part, lpart, inv_cnt, splits, dx, dx_ctot, dx_coff,
+                       dgamma, dbeta, accumulate, N, C, HW, pre_relu, post_relu, use_batch_stats, chunks,
+                       chunk_len);
+  else if (vec)
     hipLaunchKernelGGL(bn_plane_bwd_kernel<true>, grid, dim3(256), 0, s, dy, dy_ctot, dy_coff, x, x_ctot,
                        x_coff, mean, invstd, scale, beta, part, lpart, inv_cnt, splits, dx, dx_ctot, dx_coff,
                        dgamma, dbeta, accumulate, N, C, HW, pre_relu, post_relu, use_batch_stats, chunks,

@@ -157,16 +157,25 @@ __global__ __launch_bounds__(256) void maxpool3_fwd_strip(const float* __restric
     float rb[NIN][2];
     int rk[NIN][2];
     bool rv[NIN];
+    // all row loads first, unconditionally (row index clamped, halo address clamped): a load under
+    // a branch is followed by s_waitcnt vmcnt(0), i.e. one HBM round trip per row
+    float4 v4s[NIN];
+    float hl[NIN];
 #pragma unroll
     for (int j = 0; j < NIN; ++j) {
       const int ih = oh0 * SH - 1 + j;
       rv[j] = ih >= 0 && ih < H;
+      const float* row = xp + (size_t)min(max(ih, 0), H - 1) * W + 4 * b;
+      v4s[j] = *reinterpret_cast<const float4*>(row);
+      hl[j] = row[b > 0 ? -1 : 0];
+    }
+#pragma unroll
+    for (int j = 0; j < NIN; ++j) {
       rb[j][0] = rb[j][1] = 0.f; rk[j][0] = rk[j][1] = 0;
       if (!rv[j]) continue;
-      const float* row = xp + (size_t)ih * W + 4 * b;
-      const float4 v4 = *reinterpret_cast<const float4*>(row);
+      const float4 v4 = v4s[j];
       float v[5];
-      v[0] = b > 0 ? row[-1] : 0.f;
+      v[0] = b > 0 ? hl[j] : 0.f;
       v[1] = v4.x; v[2] = v4.y; v[3] = v4.z; v[4] = v4.w;
       if (xs) {
 #pragma unroll
@@ -279,15 +288,31 @@ __device__ __forceinline__ void pool3_strip(const float* __restrict__ dyp,
   const bool has2 = 2 * b + 2 < OW;
   // output rows whose 3-row window (input rows oh*SH-1 .. oh*SH+1) meets input rows ih0 .. ih0+PR-1
   constexpr int J0 = SH == 1 ? -1 : 0, J1 = SH == 1 ? PR : PR / 2;
+  // loads first and unconditional (row clamped, halo column clamped to a valid address): under a
+  // branch every load is its own HBM round trip
+  constexpr int NJ = J1 - J0 + 1;
+  float2 v01s[NJ];
+  unsigned short k01s[NJ];
+  float v2s[NJ];
+  uint8_t k2s[NJ];
+  const int c2 = has2 ? 2 : 1;
+#pragma unroll
+  for (int j = J0; j <= J1; ++j) {
+    const int oh = min(max(ih0 / SH + j, 0), OH - 1);
+    const size_t ro = (size_t)oh * OW + 2 * b;
+    v01s[j - J0] = *reinterpret_cast<const float2*>(dyp + ro);
+    k01s[j - J0] = *reinterpret_cast<const unsigned short*>(ip + ro);
+    v2s[j - J0] = dyp[ro + c2];
+    k2s[j - J0] = ip[ro + c2];
+  }
 #pragma unroll
   for (int j = J0; j <= J1; ++j) {
     const int oh = ih0 / SH + j;
     if (oh < 0 || oh >= OH) continue;
-    const size_t ro = (size_t)oh * OW + 2 * b;
-    const float2 v01 = *reinterpret_cast<const float2*>(dyp + ro);
-    const unsigned short k01 = *reinterpret_cast<const unsigned short*>(ip + ro);
-    const float v[3] = {v01.x, v01.y, has2 ? dyp[ro + 2] : 0.f};
-    const int k[3] = {k01 & 0xff, k01 >> 8, has2 ? (int)ip[ro + 2] : 4};   // 4 = (ky 1, kx 1): col 2b+2 -> none
+    const float2 v01 = v01s[j - J0];
+    const unsigned short k01 = k01s[j - J0];
+    const float v[3] = {v01.x, v01.y, has2 ? v2s[j - J0] : 0.f};
+    const int k[3] = {k01 & 0xff, k01 >> 8, has2 ? (int)k2s[j - J0] : 4};   // 4 = (ky 1, kx 1): col 2b+2 -> none
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const int ky = k[c] / 3, kx = k[c] - ky * 3;
@@ -348,10 +373,14 @@ __global__ __launch_bounds__(256) void maxpool3_bwd_dot_strip(const float* __res
       const int b = i % W4, ih0 = (i / W4) * PR;
       float G[PR][4];
       pool3_strip<SH>(dy + (size_t)pl * OH * OW, idx + (size_t)pl * OH * OW, ih0, b, OH, OW, G);
+      float4 xvs[PR];
+#pragma unroll
+      for (int r = 0; r < PR; ++r)
+        xvs[r] = *reinterpret_cast<const float4*>(xp + (size_t)min(ih0 + r, H - 1) * W + 4 * b);
 #pragma unroll
       for (int r = 0; r < PR; ++r) {
         if (ih0 + r >= H) continue;
-        const float4 xv = *reinterpret_cast<const float4*>(xp + (size_t)(ih0 + r) * W + 4 * b);
+        const float4 xv = xvs[r];
         acc += (double)((G[r][0] * xv.x + G[r][1] * xv.y) + (G[r][2] * xv.z + G[r][3] * xv.w));
       }
     }
