@@ -12,12 +12,12 @@ struct ProfKind {
   double flops = 0.0, bytes = 0.0;
 };
 ProfKind g_prof[4];
-bool g_prof_on = false;
+int g_prof_mask = 0;        // bit k: kind k is timed
 std::mutex g_mu;
 }  // namespace
 
 void dlio_prof_begin(int kind, hipStream_t s, double flops, double bytes) {
-  if (!g_prof_on || kind < 0 || kind >= 4) return;
+  if (kind < 0 || kind >= 4 || !(g_prof_mask >> kind & 1)) return;
   std::lock_guard<std::mutex> lk(g_mu);
   ProfKind& k = g_prof[kind];
   if (k.used == k.start.size()) {
@@ -33,15 +33,15 @@ void dlio_prof_begin(int kind, hipStream_t s, double flops, double bytes) {
 }
 
 void dlio_prof_end(int kind, hipStream_t s) {
-  if (!g_prof_on || kind < 0 || kind >= 4) return;
+  if (kind < 0 || kind >= 4 || !(g_prof_mask >> kind & 1)) return;
   std::lock_guard<std::mutex> lk(g_mu);
   ProfKind& k = g_prof[kind];
   hipEventRecord(k.stop[k.used], s);
   k.used++;
 }
 
-extern "C" int dlio_prof_enable(int on) {
-  g_prof_on = on != 0;
+extern "C" int dlio_prof_enable(int kinds_mask) {
+  g_prof_mask = kinds_mask & 0xf;
   return DLIO_OK;
 }
 

@@ -723,7 +723,9 @@ def sumsq(g):
 
 # ----------------------------------------------------------------------------- profiling
 def prof_enable(on):
-    lib.dlio_prof_enable(int(bool(on)))
+    """on: False / True (all kinds) or a bit mask of kernel kinds (bit 0 multi-tap conv forward +
+    data gradient, 1 weight gradient, 2 1x1 forward + data gradient)"""
+    lib.dlio_prof_enable(0xf if on is True else int(on))
 
 
 def prof_reset():
