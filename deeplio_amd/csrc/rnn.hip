@@ -289,6 +289,15 @@ __global__ void init_state_kernel(const float* __restrict__ src, float* __restri
     dst[i] = src ? src[i] : 0.f;
 }
 
+// two state vectors (h and c, or dh and dc) in one launch; a null dst is skipped
+__global__ void init_state2_kernel(const float* __restrict__ src_a, float* __restrict__ dst_a,
+                                   const float* __restrict__ src_b, float* __restrict__ dst_b, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (dst_a) dst_a[i] = src_a ? src_a[i] : 0.f;
+    if (dst_b) dst_b[i] = src_b ? src_b[i] : 0.f;
+  }
+}
+
 // ------------------------------------------------------------------ GRU (streamed)
 // gates saved: r, z, n, hn(= W_hn h + b_hn)
 __global__ void gru_cell_fwd_kernel(const float* __restrict__ gx, const float* __restrict__ gh,
@@ -548,8 +557,7 @@ extern "C" int dlio_lstm_seq_fwd(const float* gx, const float* w_hh, const float
   float* ccur = f + (size_t)B * H;
   float* pre = f + (size_t)2 * B * H;  // [B][4H]
   const int n = B * H;
-  hipLaunchKernelGGL(init_state_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, h0, hcur, n);
-  hipLaunchKernelGGL(init_state_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, c0, ccur, n);
+  hipLaunchKernelGGL(init_state2_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, h0, hcur, c0, ccur, n);
   for (int step = 0; step < T; ++step) {
     const int t = reverse ? T - 1 - step : step;
     int rc = dlio_linear_fwd(hcur, H, w_hh, b_hh, gx + (size_t)t * rst * 4 * H, rsb * 4 * H, pre,
@@ -558,8 +566,9 @@ extern "C" int dlio_lstm_seq_fwd(const float* gx, const float* w_hh, const float
     hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, pre, hcur, ccur,
                        hs, ldhs, cs, hp, gates, t, B, H, rst, rsb);
   }
-  if (hT) hipLaunchKernelGGL(init_state_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, hcur, hT, n);
-  if (cT) hipLaunchKernelGGL(init_state_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, ccur, cT, n);
+  if (hT || cT)
+    hipLaunchKernelGGL(init_state2_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, (const float*)hcur, hT,
+                       (const float*)ccur, cT, n);
   return dlio_check_launch();
 }
 
@@ -587,8 +596,7 @@ extern "C" int dlio_lstm_seq_bwd(const float* dhs, int lddhs, const float* dhT, 
   float* dccur = f + (size_t)B * H;
   float* dG = f + (size_t)2 * B * H;  // [B][4H]
   const int n = B * H;
-  hipLaunchKernelGGL(init_state_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, dhT, dhrec, n);
-  hipLaunchKernelGGL(init_state_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, dcT, dccur, n);
+  hipLaunchKernelGGL(init_state2_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, dhT, dhrec, dcT, dccur, n);
   for (int step = 0; step < T; ++step) {
     const int t = reverse ? step : T - 1 - step;
     const int first_fwd = reverse ? (t == T - 1) : (t == 0);
@@ -596,12 +604,14 @@ extern "C" int dlio_lstm_seq_bwd(const float* dhs, int lddhs, const float* dhT, 
     hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, dhs, lddhs,
                        dhrec, dccur, gates, cs, c0, dgates, dG, t, tprev, first_fwd, B, H, rst,
                        rsb);
+    if (step == T - 1 && !dh0) break;      // the last recurrent data gradient is dh0: nobody asked
     int rc = dlio_linear_bwd_data(dG, 4 * H, w_hh, dhrec, H, B, 4 * H, H, 0, f + (size_t)16 * B * H,
                                   ws_bytes - (size_t)16 * B * H * sizeof(float), stream);
     if (rc) return rc;
   }
-  if (dh0) hipLaunchKernelGGL(init_state_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, dhrec, dh0, n);
-  if (dc0) hipLaunchKernelGGL(init_state_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, dccur, dc0, n);
+  if (dh0 || dc0)
+    hipLaunchKernelGGL(init_state2_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, (const float*)dhrec, dh0,
+                       (const float*)dccur, dc0, n);
   return dlio_check_launch();
 }
 
@@ -667,6 +677,7 @@ extern "C" int dlio_gru_seq_bwd(const float* dhs, int lddhs, const float* dhT, c
     const int t = reverse ? step : T - 1 - step;
     hipLaunchKernelGGL(gru_cell_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, dhs, lddhs, dhcur,
                        gates, hp, dgx, dgh, dGh, t, B, H, rst, rsb);
+    if (step == T - 1 && !dh0) break;      // only dh0 is left to compute and nobody asked for it
     int rc = dlio_linear_bwd_data(dGh, 3 * H, w_hh, dhcur, H, B, 3 * H, H, 1, f + (size_t)16 * B * H,
                                   ws_bytes - (size_t)16 * B * H * sizeof(float), stream);
     if (rc) return rc;

@@ -702,10 +702,12 @@ class RNNFn(Function):
                     w_ih, w_hh, b_ih, b_hh = W[l][d]
                     base = (l * D + d) * 4
                     sv = rec["dirs"][d]
-                    dh0 = _new((B, H), dev)
+                    # gradient w.r.t. the state a segment started from: wanted by the segment before
+                    # it; segment 0 started from zeros
+                    dh0 = _new((B, H), dev) if s > 0 else None
                     if mode == "lstm":
                         dg = _new((rows, 4 * H), dev)
-                        dc0 = _new((B, H), dev)
+                        dc0 = _new((B, H), dev) if s > 0 else None
                         ops.lstm_seq_bwd(dout, d * H, D * H, dstate_h[l][d], dstate_c[l][d],
                                          sv["gates"], sv["cs"], sv["c0"], w_hh, dg, dh0, dc0, T, B,
                                          H, 1, T, d == 1)
