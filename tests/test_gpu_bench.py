@@ -1,0 +1,52 @@
+"""The driver's contract with bench.py: one JSON line on stdout with the agreed keys, the roofline
+and (when asked) the CPU-baseline objects; run end to end in a subprocess at the headline shape."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _run(*extra):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", *extra],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_json_contract(dev):
+    d = _run("--no-cpu-baseline", "--iso-steps", "1")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["unit"] == "frame-pairs/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    # value = frame pairs per step / time per step
+    assert abs(d["value"] - d["config"]["frame_pairs_per_step"] / (d["ms_per_step"] * 1e-3)) <= 1e-2 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-3
+    assert 0.0 < r["frac"] < 1.0
+    # live event timing of the dominant family: 50 multi-tap launches per step at the headline shape
+    assert r["launches_per_step"] == 50.0 and r["avg_launch_ms"] > 0
+    iso = r["isolated"]
+    assert iso["frac"] > r["frac"]            # alone, the kernels are faster than beside four other streams
+    assert set(iso["other"]) == {"conv2d_wgrad_mfma", "conv2d_1x1 (forward + data gradient, HBM-bound)"}
+
+
+def test_bench_cpu_baseline_object(dev):
+    d = _run("--no-isolated", "--cpu-steps", "1", "--cpu-batch", "1")
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["unit"] == d["unit"] and c["cores"] >= 1 and c["value"] > 0
