@@ -95,6 +95,10 @@ MODEL_CASES = {
     "resnet_lstm_cat": dict(cfg=dict(lidar="lidar-feat-resnet", imu="imu-feat-rnn", fusion="fusion-layer-cat",
                                      odom="odom-feat-fc", seq=2, overrides=_ov(NO_DROP, SMALL_RNN)),
                             geom=dict(B=2, S=2, C=3, H=16, W=64, T=7)),
+    # BASELINE config 5 shape (full DeepLIO, seq_len 4) at tiny geometry, fp32
+    "pointseg_lstm_cat_s4": dict(cfg=dict(lidar="lidar-feat-pointseg", imu="imu-feat-rnn", fusion="fusion-layer-cat",
+                                          odom="odom-feat-rnn", seq=4, overrides=_ov(NO_DROP, SMALL_RNN)),
+                                 geom=dict(B=3, S=4, C=5, H=16, W=64, T=6)),
     # BASELINE config 1: simple-1 + imu-fc at 64x512, C=2 (soft fusion works with leaky-ReLU features)
     "simple1_fc_soft_cfg1": dict(cfg=dict(lidar="lidar-feat-simple-1", imu="imu-feat-fc", fusion="fusion-layer-soft",
                                           odom="odom-feat-rnn", seq=2,

@@ -120,9 +120,11 @@ def ref_train_forward(model, criterion, batch):
     return pt, pw, pp, pq, loss
 
 
-def golden_models(out):
+def golden_models(out, only=None):
     from deeplio import losses as rlosses
     for name, case in gc.MODEL_CASES.items():
+        if only and "model_" + name not in only:
+            continue
         g = case['geom']
         cfg = gc.case_cfg(name)
         torch.manual_seed(0)
@@ -339,14 +341,17 @@ def main():
     cwd = os.getcwd()
     with tempfile.TemporaryDirectory() as tmp:
         os.chdir(tmp)        # the reference's logger writes ./deeplio.txt
+        only = set(sys.argv[1:])          # e.g. `make_golden.py model_pointseg_lstm_cat_s4`: that file only
         try:
-            golden_spatial(out)
-            golden_se3_loss(out)
-            golden_gt_and_lr(out)
-            golden_projection(out)
-            golden_tester(out)
-            golden_models(out)
-            golden_train_trajectory(out)
+            if not only:
+                golden_spatial(out)
+                golden_se3_loss(out)
+                golden_gt_and_lr(out)
+                golden_projection(out)
+                golden_tester(out)
+            golden_models(out, only)
+            if not only:
+                golden_train_trajectory(out)
         finally:
             os.chdir(cwd)
     for name, d in out.items():
