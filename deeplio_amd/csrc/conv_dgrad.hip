@@ -62,7 +62,45 @@ __global__ void zero_upsample_kernel(const float* __restrict__ src, float* __res
     dst[i] = v;
   }
 }
+// dx[n][c][ih][iw] = phase[(ih % SH) * SW + iw % SW][n][c][ih / SH][iw / SW] (+ residual): the phases
+// of a strided data gradient, each computed as a stride-1 convolution of dY with the taps of
+// that phase (functional.conv_dgrad), woven back into the input grid.  A null phase pointer is
+// a phase without taps (all zeros).  One thread per output element, coalesced along W.
+struct PhasePtrs { const float* p[4]; };
+__global__ __launch_bounds__(256) void phase_interleave_kernel(PhasePtrs ph, const float* __restrict__ residual,
+                                                               float* __restrict__ dx, int N, int C, int H, int W,
+                                                               int SH, int SW, int dx_ctot, int dx_coff,
+                                                               int r_ctot, int r_coff) {
+  const int64_t total = (int64_t)N * C * H * W;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int iw = (int)(i % W);
+    int64_t t = i / W;
+    const int ih = (int)(t % H); t /= H;
+    const int c = (int)(t % C);
+    const int n = (int)(t / C);
+    const int a = ih % SH, b = iw % SW;
+    const float* src = ph.p[a * SW + b];
+    const int Hp = (H - a + SH - 1) / SH, Wp = (W - b + SW - 1) / SW;
+    float v = src ? src[(((size_t)n * C + c) * Hp + ih / SH) * Wp + iw / SW] : 0.f;
+    if (residual) v += residual[(((size_t)n * r_ctot + r_coff + c) * H + ih) * W + iw];
+    dx[(((size_t)n * dx_ctot + dx_coff + c) * H + ih) * W + iw] = v;
+  }
+}
 }  // namespace
+
+extern "C" int dlio_phase_interleave2d(const float* const* phases, int SH, int SW, const float* residual,
+                                       int r_ctot, int r_coff, float* dx, int dx_ctot, int dx_coff, int N,
+                                       int C, int H, int W, dlio_stream_t stream) {
+  if (!phases || !dx || N <= 0 || C <= 0 || H <= 0 || W <= 0 || SH < 1 || SW < 1 || SH * SW > 4 ||
+      dx_ctot < dx_coff + C || (residual && r_ctot < r_coff + C))
+    return DLIO_EINVAL;
+  PhasePtrs ph;
+  for (int i = 0; i < 4; ++i) ph.p[i] = i < SH * SW ? phases[i] : nullptr;
+  hipLaunchKernelGGL(phase_interleave_kernel, dim3(ew_grid((int64_t)N * C * H * W, 256)), dim3(256), 0,
+                     as_stream(stream), ph, residual, dx, N, C, H, W, SH, SW, dx_ctot, dx_coff, r_ctot, r_coff);
+  return dlio_check_launch();
+}
 
 extern "C" int dlio_zero_upsample2d(const float* src, float* dst, int64_t planes, int OH, int OW,
                                     int HU, int WU, int SH, int SW, dlio_stream_t stream) {

@@ -882,10 +882,13 @@ extern "C" int dlio_conv2d_fwd(const float* x, const float* wt, const float* bia
   if (!x || !wt || !y || !dp) return DLIO_EINVAL;
   const DlioConvDesc& d = *dp;
   if (d.N <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.H <= 0 || d.W <= 0) return DLIO_EINVAL;
-  if (d.OH != (d.H + 2 * d.PH - d.KH) / d.SH + 1 && d.OH != (d.H + 2 * d.PH - d.KH + d.SH - 1) / d.SH + 1)
-    return DLIO_EINVAL;
-  if (d.OW != (d.W + 2 * d.PW - d.KW) / d.SW + 1 && d.OW != (d.W + 2 * d.PW - d.KW + d.SW - 1) / d.SW + 1)
-    return DLIO_EINVAL;
+  // output extent: the floor or the ceil form of the usual formula; a stride-1 convolution may also
+  // ask for up to K-1 further rows / columns, which read the zero padding behind the input
+  // (asymmetric padding: the phases of a strided data gradient, functional.conv_dgrad)
+  const int oh_lo = (d.H + 2 * d.PH - d.KH) / d.SH + 1, ow_lo = (d.W + 2 * d.PW - d.KW) / d.SW + 1;
+  const int oh_hi = d.SH == 1 ? oh_lo + d.KH - 1 : (d.H + 2 * d.PH - d.KH + d.SH - 1) / d.SH + 1;
+  const int ow_hi = d.SW == 1 ? ow_lo + d.KW - 1 : (d.W + 2 * d.PW - d.KW + d.SW - 1) / d.SW + 1;
+  if (d.OH < oh_lo || d.OH > oh_hi || d.OW < ow_lo || d.OW > ow_hi || d.OH < 1 || d.OW < 1) return DLIO_EINVAL;
   if (in_scale && (!in_mean || !in_shift)) return DLIO_EINVAL;
   hipStream_t s = as_stream(stream);
   const double flops = 2.0 * d.N * (double)d.OH * d.OW * d.Cout * (double)d.Cin * d.KH * d.KW;
@@ -899,7 +902,7 @@ extern "C" int dlio_conv2d_fwd(const float* x, const float* wt, const float* bia
 #define CONV_CASE(kh, kw, sh, sw, ck)                                                        \
   if (d.KH == kh && d.KW == kw && d.SH == sh && d.SW == sw)                                  \
     rc = launch_tw<kh, kw, sh, sw, ck>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
-  if (d.KH == 1 && d.KW == 1 && d.SH == 1 && d.SW == 1 && d.PH == 0 && d.PW == 0) {
+  if (d.KH == 1 && d.KW == 1 && d.SH == 1 && d.SW == 1 && d.PH == 0 && d.PW == 0 && d.OH == d.H && d.OW == d.W) {
     static const int shortk_mr1 = getenv("DLIO_1X1_SHORTK_MR1") ? atoi(getenv("DLIO_1X1_SHORTK_MR1")) : 80;
     // short K (squeeze data gradient, expand1x1 forward: <= 80 input channels) is store-bound:
     // 32-channel tiles (twice the waves, half the registers) are 8-12 % faster there (sweep)
@@ -919,6 +922,12 @@ extern "C" int dlio_conv2d_fwd(const float* x, const float* wt, const float* bia
   else CONV_CASE(5, 7, 1, 1, 4)
   else CONV_CASE(3, 3, 2, 2, 8)
   else CONV_CASE(3, 3, 1, 2, 8)
+  // tap subsets of the strided layers above (phases of their data gradients)
+  else CONV_CASE(3, 2, 1, 1, 16)
+  else CONV_CASE(3, 1, 1, 1, 16)
+  else CONV_CASE(2, 2, 1, 1, 16)
+  else CONV_CASE(2, 1, 1, 1, 16)
+  else CONV_CASE(1, 2, 1, 1, 16)
   else CONV_CASE(1, 1, 1, 2, 16)
   else CONV_CASE(1, 1, 2, 2, 16)
 #undef CONV_CASE

@@ -173,6 +173,11 @@ class _CBR:
             # data-gradient layout for backward: fetched here, where `weight` is the long-lived
             # Parameter (the cache identifies weights by object; backward only sees unpacked copies)
             d.wt2 = ops.conv2d_prepped(weight, 1)
+            if (d.SH > 1 or d.SW > 1) and x.requires_grad and _DGRAD_PHASES[0]:
+                plan = _phase_plan(d)
+                if plan is not None:           # tap-subset layouts of the phase-decomposed data gradient
+                    d.wt_ph = {(it[0], it[1]): ops.conv2d_prepped_phase(weight, d.SH, d.SW, it[0], it[1])
+                               for it in plan if it is not None}
         ops.conv2d_fwd(x, wt, bias, raw, d)
         OHW = d.OH * d.OW
         if training and _PLANE_BN[0]:
@@ -251,6 +256,8 @@ def conv_dgrad(dy, weight, d, dx, dx_ctot, dx_coff, residual=None, r_ctot=0, r_c
     else:
         # strided conv: insert the stride's zeros into dy and run the stride-1 MFMA kernel on it
         # (SH*SW x the minimal MFMA work, still ~50x faster than a scalar gather)
+        if _DGRAD_PHASES[0] and _dgrad_phases(dy, weight, d, dx, dx_ctot, dx_coff, residual, r_ctot, r_coff):
+            return dx
         HU = (d.OH - 1) * d.SH + 1 + (d.H + 2 * d.PH - d.KH) % d.SH
         WU = (d.OW - 1) * d.SW + 1 + (d.W + 2 * d.PW - d.KW) % d.SW
         up = ops.zero_upsample2d(dy, HU, WU, d.SH, d.SW)
@@ -262,6 +269,75 @@ def conv_dgrad(dy, weight, d, dx, dx_ctot, dx_coff, residual=None, r_ctot=0, r_c
                           res_ctot=r_ctot, res_coff=r_coff)
         ops.conv2d_fwd(up, wt2, None, dx, g, residual=residual)
     return dx
+
+
+_DGRAD_PHASES = [os.environ.get("DLIO_DGRAD_PHASES", "1") != "0"]
+_PHASE_KERNELS = {(3, 3), (3, 2), (3, 1), (2, 2), (2, 1), (1, 2), (1, 1), (3, 5), (5, 7)}   # stride-1 instantiations
+
+
+def set_dgrad_phases(on):
+    _DGRAD_PHASES[0] = bool(on)
+
+
+def _phase_plan(d):
+    """per input phase (a, b) of a strided convolution: (rh, rw, Mh, Mw, pad_top, pad_left, Hp, Wp) of
+    the stride-1 convolution of dy that produces dx[a::SH, b::SW]; None entries are phases without
+    taps; returns None when a phase needs something the stride-1 kernels do not have.
+    Rows ih = SH*i + a only see the taps kh = rh + SH*m with rh = (a + PH) mod SH, and
+    dx[SH*i + a] = sum_m w[rh + SH*m] dy[i + qh - m], qh = (a + PH) div SH -- a correlation with the
+    reversed tap subset under a top padding of Mh-1-qh (the bottom padding is implied by the
+    output extent)."""
+    SH, SW = d.SH, d.SW
+    if SH * SW > 4:
+        return None
+    plan = []
+    for a in range(SH):
+        rh, qh = (a + d.PH) % SH, (a + d.PH) // SH
+        Mh = len(range(rh, d.KH, SH))
+        Hp = len(range(a, d.H, SH))
+        for b in range(SW):
+            rw, qw = (b + d.PW) % SW, (b + d.PW) // SW
+            Mw = len(range(rw, d.KW, SW))
+            Wp = len(range(b, d.W, SW))
+            if Hp == 0 or Wp == 0:
+                return None
+            if Mh == 0 or Mw == 0:
+                plan.append(None)
+                continue
+            pt, pl = Mh - 1 - qh, Mw - 1 - qw
+            lo_h, lo_w = d.OH + 2 * pt - Mh + 1, d.OW + 2 * pl - Mw + 1
+            if (pt < 0 or pl < 0 or (Mh, Mw) not in _PHASE_KERNELS or not (lo_h <= Hp <= lo_h + Mh - 1)
+                    or not (lo_w <= Wp <= lo_w + Mw - 1)):
+                return None
+            plan.append((rh, rw, Mh, Mw, pt, pl, Hp, Wp))
+    return plan
+
+
+def _dgrad_phases(dy, weight, d, dx, dx_ctot, dx_coff, residual, r_ctot, r_coff):
+    """strided data gradient as SH*SW stride-1 convolutions of dy, one per input phase, woven
+    together by dlio_phase_interleave2d: no MFMA work on inserted zeros (the zero-upsample route
+    does SH*SW x the minimum).  Returns False when the plan does not exist."""
+    plan = _phase_plan(d)
+    if plan is None:
+        return False
+    N, Cin, Cout = d.N, d.Cin, d.Cout
+    stash = getattr(d, "wt_ph", None)
+    phases = []
+    for item in plan:
+        if item is None:
+            phases.append(None)
+            continue
+        rh, rw, Mh, Mw, pt, pl, Hp, Wp = item
+        wt = stash.get((rh, rw)) if stash else None
+        if wt is None:                      # direct call (no forward ran on this descriptor)
+            wt = ops.conv2d_prepped_phase(weight, d.SH, d.SW, rh, rw, cache=False)
+        out = _new((N, Cin, Hp, Wp), dy)
+        g = ops.conv_desc(N, Cout, d.OH, d.OW, Cin, Mh, Mw, 1, 1, pt, pl, OH=Hp, OW=Wp, in_ctot=Cout, in_coff=0,
+                          out_ctot=Cin, out_coff=0)
+        ops.conv2d_fwd(dy, wt, None, out, g)
+        phases.append(out)
+    ops.phase_interleave2d(phases, d.SH, d.SW, dx, dx_ctot, dx_coff, N, Cin, d.H, d.W, residual, r_ctot, r_coff)
+    return True
 
 
 class ConvBnAct(Function):

@@ -184,6 +184,48 @@ def conv2d_fwd(x, wt, bias, y, desc, in_aff=None, residual=None):
     return y
 
 
+def phase_interleave2d(phases, SH, SW, dx, dx_ctot, dx_coff, N, C_, H, W, residual=None, r_ctot=0, r_coff=0):
+    """phases: SH*SW tensors [N, C, ceil((H-a)/SH), ceil((W-b)/SW)] (index a*SW+b, None = all zero)"""
+    arr = (C.c_void_p * 4)(*[(None if t is None else t.data_ptr()) for t in list(phases) + [None] * (4 - len(phases))])
+    check(lib.dlio_phase_interleave2d(arr, SH, SW, _ptr(residual), r_ctot, r_coff, _ptr(dx), dx_ctot, dx_coff,
+                                      N, C_, H, W, _stream()), "phase_interleave2d")
+    return dx
+
+
+# data-gradient layouts of the tap subsets of strided convolutions (one per phase).  Cached per
+# weight OBJECT (weakref: a data_ptr can be reused by another tensor) and refreshed when the weight
+# changes; only the long-lived Parameter seen in forward can be cached -- backward sees unpacked
+# copies, so the layouts are fetched in forward and travel on the ConvDesc (like `wt2`).
+_PHASE_W = {}
+
+
+def conv2d_prepped_phase(w, SH, SW, rh, rw, cache=True):
+    """data-gradient (mode 1) layout of w[:, :, rh::SH, rw::SW]"""
+    Cout, Cin, KH, KW = w.shape
+    Mh, Mw = len(range(rh, KH, SH)), len(range(rw, KW, SW))
+    nfl = lib.dlio_conv2d_prep_weight_floats(Cout, Cin, Mh, Mw, 1)
+    e = None
+    if cache:
+        key = (w.data_ptr(), tuple(w.shape), SH, SW, rh, rw)
+        e = _PHASE_W.get(key)
+        if e is None or e["ref"]() is not w:
+            e = _PHASE_W[key] = dict(ref=_weakref.ref(w), epoch=-1, version=-1,
+                                     out=torch.empty(nfl, dtype=torch.float32, device=w.device))
+            for k in [k for k, v in _PHASE_W.items() if v["ref"]() is None]:
+                del _PHASE_W[k]
+        if e["epoch"] == _PREP.epoch and e["version"] == w._version:
+            return e["out"]
+        out = e["out"]
+    else:
+        out = torch.empty(nfl, dtype=torch.float32, device=w.device)
+    sub = w.detach()[:, :, rh::SH, rw::SW].contiguous()
+    check(lib.dlio_conv2d_prep_weight(_ptr(sub), _ptr(out), Cout, Cin, Mh, Mw, 1, _stream()), "conv2d_prep_weight")
+    sub.record_stream(torch.cuda.current_stream())
+    if e is not None:
+        e.update(epoch=_PREP.epoch, version=w._version)
+    return out
+
+
 def zero_upsample2d(src, HU, WU, SH, SW):
     """[N,C,OH,OW] -> [N,C,HU,WU] with the stride's zeros inserted"""
     _chk(src)

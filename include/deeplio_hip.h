@@ -106,6 +106,15 @@ int dlio_conv2d_fwd(const float* x, const float* wt, const float* bias,
  * (HU = (OH-1)*SH+1 + (H+2*PH-KH)%SH, pad KH-1-PH). */
 int dlio_zero_upsample2d(const float* src, float* dst, int64_t planes, int OH, int OW, int HU,
                          int WU, int SH, int SW, dlio_stream_t stream);
+/* Phase decomposition of a strided data gradient (same nn.Conv2d backward lines): input rows
+ * ih = SH*i + a only receive the taps kh = (a+PH) mod SH, +SH, ... -- so dX[a::SH, b::SW] is a
+ * STRIDE-1 convolution of dY with that tap subset (dlio_conv2d_fwd on the subset's data-gradient
+ * layout, no MFMA work on inserted zeros).  This call weaves the SH*SW phase results
+ * ([N][C][ceil((H-a)/SH)][ceil((W-b)/SW)] each, index a*SW+b, NULL = phase without taps) back
+ * into dX (channel slice) and adds the optional residual.  SH*SW <= 4. */
+int dlio_phase_interleave2d(const float* const* phases, int SH, int SW, const float* residual,
+                            int r_ctot, int r_coff, float* dx, int dx_ctot, int dx_coff, int N,
+                            int C, int H, int W, dlio_stream_t stream);
 /* strided data gradient (any stride), scalar reference implementation: dx[n,ci,ih,iw] = sum_{co,dy,dx} dy[...] * w[co][ci][dy][dx]
  * w in the STANDARD [Cout][Cin][KH][KW] layout.  d describes the forward conv. */
 int dlio_conv2d_dgrad_strided(const float* dy, const float* w, float* dx,

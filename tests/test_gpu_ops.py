@@ -520,11 +520,15 @@ def test_adam_sgd_match_torch_optim(dev):
 @pytest.mark.parametrize("case", [((2, 6, 18, 36), 10, 3, 3, 2, 2, 1, 1), ((2, 8, 17, 33), 12, 3, 5, 1, 2, 1, 2),
                                   ((1, 16, 16, 32), 8, 1, 1, 2, 2, 0, 0), ((2, 5, 9, 20), 7, 3, 3, 1, 2, 1, 1),
                                   ((1, 4, 15, 15), 6, 5, 7, 1, 2, 2, 3)])
-def test_strided_dgrad_via_zero_upsample(dev, case):
-    """data gradient of strided convs = stride-1 MFMA conv over the zero-upsampled dy (production
-    route), incl. sizes where (H + 2P - K) % S != 0, a residual operand and a channel-sliced dx;
-    checked against torch and against the scalar reference kernel behind the C-ABI"""
+@pytest.mark.parametrize("phases", [True, False])
+def test_strided_dgrad_via_zero_upsample(dev, case, phases):
+    """data gradient of strided convs, both production routes: phase decomposition (SH*SW stride-1
+    MFMA convs over dy with the taps of each input phase, woven together) and the stride-1 MFMA conv
+    over the zero-upsampled dy it falls back to; incl. sizes where (H + 2P - K) % S != 0, a residual
+    operand and a channel-sliced dx; checked against torch and against the scalar reference kernel
+    behind the C-ABI"""
     from deeplio_amd import functional as Fh, ops
+    Fh.set_dgrad_phases(phases)
     shape, Cout, KH, KW, SH, SW, PH, PW = case
     N, Cin, H, W = shape
     g = _g(21)
@@ -540,6 +544,13 @@ def test_strided_dgrad_via_zero_upsample(dev, case):
     Fh.conv_dgrad(dy.to(dev), w.to(dev), d, dxbuf, Cin + 2, 1, residual=res.to(dev), r_ctot=Cin + 3, r_coff=2)
     assert rel_err(dxbuf[:, 1:1 + Cin], x.grad + res[:, 2:2 + Cin].double()) < TOL
     assert float(dxbuf[:, 0].abs().max()) == 0 and float(dxbuf[:, -1].abs().max()) == 0
+    # accumulate into an existing dx (the second consumer of a tensor adds its gradient)
+    Fh.conv_dgrad(dy.to(dev), w.to(dev), d, dxbuf, Cin + 2, 1, accumulate=True)
+    assert rel_err(dxbuf[:, 1:1 + Cin], 2 * x.grad + res[:, 2:2 + Cin].double()) < TOL
+    if phases:     # the decomposition itself must have run for the layer shapes of FlowNet / ResNet
+        took = Fh._dgrad_phases(dy.to(dev), w.to(dev), d, torch.empty(N, Cin, H, W, device=dev), Cin, 0, None, 0, 0)
+        assert took == ((KH, KW) != (5, 7))
+    Fh.set_dgrad_phases(True)
     ref = torch.empty(N, Cin, H, W, device=dev)
     ops.conv2d_dgrad_strided(dy.to(dev), w.to(dev), ref, d)
     assert rel_err(ref, x.grad) < TOL
