@@ -554,3 +554,27 @@ def test_strided_dgrad_via_zero_upsample(dev, case, phases):
     ref = torch.empty(N, Cin, H, W, device=dev)
     ops.conv2d_dgrad_strided(dy.to(dev), w.to(dev), ref, d)
     assert rel_err(ref, x.grad) < TOL
+
+
+@pytest.mark.parametrize("k,extra", [((3, 3), (2, 1)), ((2, 2), (1, 1)), ((3, 2), (0, 1)), ((1, 2), (0, 1)), ((2, 1), (1, 0))])
+def test_conv_fwd_asymmetric_padding_by_output_extent(dev, k, extra):
+    """stride-1 dlio_conv2d_fwd accepts an output extent up to K-1 rows / columns beyond the
+    symmetric-padding formula: the extra outputs read the zero padding behind the input (bottom /
+    right padding larger than top / left -- what the phases of a strided data gradient need);
+    anything beyond that is rejected"""
+    from deeplio_amd import ops
+    KH, KW = k
+    N, Cin, Cout, H, W, PH, PW = 2, 24, 40, 11, 37, KH - 1, 0 if KW == 1 else 1
+    g = _g(33)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, KH, KW, generator=g) / (Cin * KH * KW) ** 0.5
+    eh, ew = extra
+    ref = F.conv2d(F.pad(x.double(), (PW, PW + ew, PH, PH + eh)), w.double())
+    d = ops.conv_desc(N, Cin, H, W, Cout, KH, KW, 1, 1, PH, PW, OH=ref.shape[2], OW=ref.shape[3])
+    y = torch.empty(N, Cout, ref.shape[2], ref.shape[3], device=dev)
+    ops.conv2d_fwd(x.to(dev), ops.conv2d_prep_weight(w.to(dev), 0), None, y, d)
+    assert rel_err(y, ref) < TOL
+    bad = ops.conv_desc(N, Cin, H, W, Cout, KH, KW, 1, 1, PH, PW, OH=ref.shape[2] - eh + KH, OW=ref.shape[3])
+    with pytest.raises(ValueError):
+        ops.conv2d_fwd(x.to(dev), ops.conv2d_prep_weight(w.to(dev), 0), None,
+                       torch.empty(N, Cout, bad.OH, bad.OW, device=dev), bad)
