@@ -1,0 +1,327 @@
+// 3x3 stride-1 convolution (forward, and data gradient with the tap-reversed layout) with fp32
+// accuracy on the bf16 matrix cores: every fp32 operand is split into three bf16 pieces
+// x = hi + mid + lo (8+8+8 mantissa bits) and a*b is formed from the six products
+// hi*hi, hi*mid, mid*hi, hi*lo, mid*mid, lo*hi -- each a v_mfma_f32_32x32x16_bf16 with exact
+// products and fp32 accumulation (error measured in tools/micro/bf16x3.hip: 4.8e-7 of the tile scale,
+// the fp32 MFMA's own 5.5e-7).  Per 16-channel chunk and tap that is 6 MFMAs of 32 cycles instead of
+// 8 v_mfma_f32_32x32x2_f32 of 64 cycles.
+//
+// Workgroup: 4 waves = 4 output rows x (32*TWN) columns x (32*MR) output channels.  The patch of a
+// 16-channel chunk is split ONCE while it is staged into LDS (three bf16 planes, [plane][pos][16 k]:
+// a lane's B fragment -- 8 consecutive channels of one position -- is one conflict-free
+// ds_read_b128 per plane); weights are pre-split by dlio_conv3x3_bx3_prep into
+// [tap][chunk][plane][n][16 k], a lane's A fragment is one 16-byte load per plane, fetched one tap
+// ahead.  Each wave keeps MR x TWN accumulator tiles, so an A fragment is used for TWN pixel blocks
+// and a B fragment for MR channel tiles.
+//
+// Replaces nn.Conv2d forward / input-gradient for the 3x3 stride-1 layers (pointseg_modules.py:100-106
+// expand3x3, resnet.py BasicBlock, base_net.py:55-71 conv3_1 / conv4_1 / conv5_1).
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+  h = (__bf16)x;
+  const float r = x - (float)h;
+  m = (__bf16)r;
+  l = (__bf16)(r - (float)m);
+}
+
+// w [Cout][Cin][3][3] -> wt [9][KC][3][Nn][16] bf16; mode 0: k = ci, n = co; mode 1: k = co, n = ci, taps reversed
+__global__ void prep_bx3_kernel(const float* __restrict__ w, __bf16* __restrict__ wt, int Cout, int Cin, int mode) {
+  const int K = mode == 0 ? Cin : Cout, Nn = mode == 0 ? Cout : Cin;
+  const int KC = (K + 15) >> 4;
+  const int64_t total = (int64_t)9 * KC * Nn * 16;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int kk = (int)(i & 15);
+    int64_t t = i >> 4;
+    const int n = (int)(t % Nn); t /= Nn;
+    const int kc = (int)(t % KC);
+    const int tap = (int)(t / KC);
+    const int k = kc * 16 + kk;
+    float v = 0.f;
+    if (k < K) {
+      if (mode == 0) v = w[((int64_t)n * Cin + k) * 9 + tap];
+      else v = w[((int64_t)k * Cin + n) * 9 + (8 - tap)];
+    }
+    __bf16 h, m, l;
+    split3(v, h, m, l);
+    const int64_t base = (((int64_t)tap * KC + kc) * 3) * Nn * 16 + (int64_t)n * 16 + kk;
+    wt[base] = h;
+    wt[base + (int64_t)Nn * 16] = m;
+    wt[base + (int64_t)2 * Nn * 16] = l;
+  }
+}
+
+// all split-bf16 weight layouts of a model in ONE launch; item.start / total count the (tap, chunk, n, k)
+// elements of the concatenated index space (one element = three bf16 planes)
+__global__ void prep_bx3_batched_kernel(const DlioPrepItem* __restrict__ items, int n_items, int64_t total) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int lo = 0, hi = n_items - 1;                 // last item with start <= i
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (items[mid].start <= i) lo = mid; else hi = mid - 1;
+    }
+    const DlioPrepItem it = items[lo];
+    const int64_t e = i - it.start;
+    const int K = it.mode == 0 ? it.Cin : it.Cout, Nn = it.mode == 0 ? it.Cout : it.Cin;
+    const int KC = (K + 15) >> 4;
+    const int kk = (int)(e & 15);
+    int64_t t = e >> 4;
+    const int n = (int)(t % Nn); t /= Nn;
+    const int kc = (int)(t % KC);
+    const int tap = (int)(t / KC);
+    const int k = kc * 16 + kk;
+    float v = 0.f;
+    if (k < K) {
+      if (it.mode == 0) v = it.w[((int64_t)n * it.Cin + k) * 9 + tap];
+      else v = it.w[((int64_t)k * it.Cin + n) * 9 + (8 - tap)];
+    }
+    __bf16 h, m, l;
+    split3(v, h, m, l);
+    __bf16* wt = reinterpret_cast<__bf16*>(it.wt);
+    const int64_t base = (((int64_t)tap * KC + kc) * 3) * Nn * 16 + (int64_t)n * 16 + kk;
+    wt[base] = h;
+    wt[base + (int64_t)Nn * 16] = m;
+    wt[base + (int64_t)2 * Nn * 16] = l;
+  }
+}
+
+template <int MR, int TWN>
+__global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
+    const float* __restrict__ x, const __bf16* __restrict__ wt, const float* __restrict__ bias,
+    const float* residual, float* y, DlioConvDesc d, int tiles_w, int tiles_h, int co_tiles) {
+  constexpr int TH = 4, TW = 32 * TWN;
+  constexpr int PR = TH + 2, PC = TW + 2, NPOSP = PR * PC;
+  constexpr int NPOS = (NPOSP + 255) / 256;              // patch positions per thread
+  constexpr int PLANE = NPOSP * 16;                      // bf16 per plane
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);    // [2 buffers][3 planes][NPOSP][16]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  int bid = blockIdx.x;
+  const int cot = bid % co_tiles; bid /= co_tiles;
+  const int tw = bid % tiles_w; bid /= tiles_w;
+  const int th = bid % tiles_h;
+  const int n = bid / tiles_h;
+  const int co0 = cot * 32 * MR, oh0 = th * TH, ow0 = tw * TW;
+  const int Cin = d.Cin, Cout = d.Cout, HW = d.H * d.W;
+  const int KC = (Cin + 15) >> 4;
+
+  // ---- staging: a thread owns NPOS patch positions for all 16 channels of a chunk
+  bool pval[NPOS];
+  int poff[NPOS];
+#pragma unroll
+  for (int j = 0; j < NPOS; ++j) {
+    const int pos = tid + j * 256;
+    const int r = pos / PC, c = pos - r * PC;
+    const int ih = oh0 - d.PH + r, iw = ow0 - d.PW + c;
+    pval[j] = pos < NPOSP && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W;
+    poff[j] = pval[j] ? ih * d.W + iw : 0;
+  }
+  const float* xn = x + ((size_t)n * d.in_ctot + d.in_coff) * HW;
+  float reg[NPOS][16];
+  auto load_chunk = [&](int kc) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int ci = kc * 16 + c;
+      const float* xc = xn + (size_t)min(ci, Cin - 1) * HW;
+#pragma unroll
+      for (int j = 0; j < NPOS; ++j) reg[j][c] = xc[poff[j]];
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const bool cv = kc * 16 + c < Cin;
+#pragma unroll
+      for (int j = 0; j < NPOS; ++j) reg[j][c] = (cv && pval[j]) ? reg[j][c] : 0.f;
+    }
+  };
+  auto store_chunk = [&](__bf16* buf) {
+#pragma unroll
+    for (int j = 0; j < NPOS; ++j) {
+      const int pos = tid + j * 256;
+      if (pos < NPOSP) {
+        bf16x8 ph[2], pm[2], pl[2];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          __bf16 h, m, l;
+          split3(reg[j][c], h, m, l);
+          ph[c >> 3][c & 7] = h; pm[c >> 3][c & 7] = m; pl[c >> 3][c & 7] = l;
+        }
+        bf16x8* dst = reinterpret_cast<bf16x8*>(buf + pos * 16);
+        dst[0] = ph[0]; dst[1] = ph[1];
+        dst = reinterpret_cast<bf16x8*>(buf + PLANE + pos * 16);
+        dst[0] = pm[0]; dst[1] = pm[1];
+        dst = reinterpret_cast<bf16x8*>(buf + 2 * PLANE + pos * 16);
+        dst[0] = pl[0]; dst[1] = pl[1];
+      }
+    }
+  };
+
+  // ---- weight fragments: [tap][kc][plane][Nn][16], lane reads 8 k of row n = co (clamped) per plane
+  int nrow[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) nrow[m] = min(co0 + 32 * m + l31, Cout - 1);
+  const size_t wplane = (size_t)Cout * 16;
+  auto load_a = [&](int tap, int kc, bf16x8 (&a)[MR][3]) {
+    const __bf16* base = wt + (((size_t)tap * KC + kc) * 3) * wplane + 8 * half;
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        a[m][p] = *reinterpret_cast<const bf16x8*>(base + p * wplane + (size_t)nrow[m] * 16);
+  };
+
+  f32x16 acc[MR][TWN];
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+#pragma unroll
+    for (int t = 0; t < TWN; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+
+  auto compute = [&](const __bf16* buf, int kc) {
+    bf16x8 a[2][MR][3];
+    load_a(0, kc, a[0]);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kh = tap / 3, kw = tap - 3 * kh;
+      if (tap + 1 < 9) load_a(tap + 1, kc, a[(tap + 1) & 1]);
+      bf16x8 b[TWN][3];
+#pragma unroll
+      for (int t = 0; t < TWN; ++t) {
+        const int pos = (wave + kh) * PC + 32 * t + l31 + kw;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          b[t][p] = *reinterpret_cast<const bf16x8*>(buf + p * PLANE + pos * 16 + 8 * half);
+      }
+      const auto& aa = a[tap & 1];
+      // six products, smallest first; consecutive MFMAs go to different accumulators
+      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+          for (int t = 0; t < TWN; ++t)
+            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[m][PA[q]], b[t][PB[q]], acc[m][t], 0, 0, 0);
+    }
+  };
+
+  // ---- chunk loop, LDS double buffered, one barrier per chunk
+  load_chunk(0);
+  store_chunk(smem);
+  __syncthreads();
+  for (int kc = 0; kc < KC; ++kc) {
+    const __bf16* cur = smem + (size_t)(kc & 1) * 3 * PLANE;
+    __bf16* nxt = smem + (size_t)((kc + 1) & 1) * 3 * PLANE;
+    if (kc + 1 < KC) load_chunk(kc + 1);
+    compute(cur, kc);
+    if (kc + 1 < KC) store_chunk(nxt);
+    __syncthreads();
+  }
+
+  // ---- epilogue: D tile col = pixel (lane & 31), row = (r & 3) + 8 (r >> 2) + 4 half
+  const int oh = oh0 + wave;
+  if (oh >= d.OH) return;
+  const size_t ohw = (size_t)d.OH * d.OW;
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+#pragma unroll
+    for (int t = 0; t < TWN; ++t) {
+      const int ow = ow0 + 32 * t + l31;
+      if (ow >= d.OW) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (co >= Cout) continue;
+        float v = acc[m][t][r];
+        if (bias) v += bias[co];
+        const size_t pix = (size_t)oh * d.OW + ow;
+        if (residual) v += residual[((size_t)n * d.res_ctot + d.res_coff + co) * ohw + pix];
+        y[((size_t)n * d.out_ctot + d.out_coff + co) * ohw + pix] = v;
+      }
+    }
+}
+
+template <int MR, int TWN>
+int launch_bx3(const float* x, const __bf16* wt, const float* bias, const float* residual, float* y,
+               const DlioConvDesc& d, hipStream_t s) {
+  constexpr int TH = 4, TW = 32 * TWN;
+  const int tiles_w = cdiv(d.OW, TW), tiles_h = cdiv(d.OH, TH), co_tiles = cdiv(d.Cout, 32 * MR);
+  const int64_t blocks = (int64_t)d.N * tiles_h * tiles_w * co_tiles;
+  if (blocks <= 0 || blocks > 0x7fffffff) return DLIO_EINVAL;
+  const size_t lds = (size_t)2 * 3 * (TH + 2) * (TW + 2) * 16 * sizeof(__bf16);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bx3_kernel<MR, TWN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv3x3_bx3_kernel<MR, TWN>), dim3((unsigned)blocks), dim3(256), lds, s, x, wt, bias, residual, y,
+                     d, tiles_w, tiles_h, co_tiles);
+  return dlio_check_launch();
+}
+
+}  // namespace
+
+extern "C" size_t dlio_conv3x3_bx3_prep_floats(int Cout, int Cin, int mode) {
+  if (Cout <= 0 || Cin <= 0 || (mode != 0 && mode != 1)) return 0;
+  const int K = mode == 0 ? Cin : Cout, Nn = mode == 0 ? Cout : Cin;
+  return (size_t)9 * ((K + 15) >> 4) * 3 * Nn * 16 / 2;      // bf16 elements / 2
+}
+
+extern "C" int dlio_conv3x3_bx3_prep(const float* w, void* wt, int Cout, int Cin, int mode, dlio_stream_t stream) {
+  if (!w || !wt || Cout <= 0 || Cin <= 0 || (mode != 0 && mode != 1)) return DLIO_EINVAL;
+  const int K = mode == 0 ? Cin : Cout, Nn = mode == 0 ? Cout : Cin;
+  const int64_t total = (int64_t)9 * ((K + 15) >> 4) * Nn * 16;
+  hipLaunchKernelGGL(prep_bx3_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, as_stream(stream), w,
+                     reinterpret_cast<__bf16*>(wt), Cout, Cin, mode);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_conv3x3_bx3_prep_batched(const DlioPrepItem* items_dev, int n_items, int64_t total,
+                                             dlio_stream_t stream) {
+  if (!items_dev || n_items <= 0 || total <= 0) return DLIO_EINVAL;
+  hipLaunchKernelGGL(prep_bx3_batched_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, as_stream(stream),
+                     items_dev, n_items, total);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_conv3x3_bx3_fwd(const float* x, const void* wt, const float* bias, const float* residual,
+                                    float* y, const DlioConvDesc* dp, dlio_stream_t stream) {
+  if (!x || !wt || !y || !dp) return DLIO_EINVAL;
+  const DlioConvDesc& d = *dp;
+  if (d.KH != 3 || d.KW != 3 || d.SH != 1 || d.SW != 1) return DLIO_EUNSUP;
+  if (d.N <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.H <= 0 || d.W <= 0 || d.PH < 0 || d.PW < 0) return DLIO_EINVAL;
+  const int oh_lo = d.H + 2 * d.PH - 2, ow_lo = d.W + 2 * d.PW - 2;
+  if (d.OH < oh_lo || d.OH > oh_lo + 2 || d.OW < ow_lo || d.OW > ow_lo + 2 || d.OH < 1 || d.OW < 1) return DLIO_EINVAL;
+  hipStream_t s = as_stream(stream);
+  const double flops = 2.0 * d.N * (double)d.OH * d.OW * d.Cout * (double)d.Cin * 9;
+  const double bytes = 4.0 * d.N * ((double)d.Cin * d.H * d.W + (double)d.Cout * d.OH * d.OW * (residual ? 2.0 : 1.0));
+  dlio_prof_begin(0, s, flops, bytes);
+  const __bf16* w = reinterpret_cast<const __bf16*>(wt);
+  // tile: 64 channels x 64 columns per wave when that still gives every CU a few workgroups,
+  // else narrower tiles (small feature maps / few output channels)
+  static const int force_mr = getenv("DLIO_BX3_MR") ? atoi(getenv("DLIO_BX3_MR")) : 0;     // tuning knobs
+  static const int force_twn = getenv("DLIO_BX3_TWN") ? atoi(getenv("DLIO_BX3_TWN")) : 0;
+  auto blocks = [&](int mr, int twn) {
+    return (int64_t)d.N * cdiv(d.OH, 4) * cdiv(d.OW, 32 * twn) * cdiv(d.Cout, 32 * mr);
+  };
+  const int64_t want = 2 * (int64_t)dlio_num_cus();
+  // measured (tools/bench_bx3.py): two pixel blocks per wave pay off from ~192 input channels on
+  // (weight-fragment reuse), one block otherwise (more waves per CU)
+  int mr = d.Cout <= 32 ? 1 : 2, twn = (d.OW > 32 && d.Cin >= 192) ? 2 : 1;
+  if (blocks(mr, twn) < want && twn == 2) twn = 1;
+  if (blocks(mr, twn) < want && mr == 2) mr = 1;
+  if (force_mr) mr = force_mr;
+  if (force_twn) twn = force_twn;
+  int rc;
+  if (mr == 1) rc = twn == 2 ? launch_bx3<1, 2>(x, w, bias, residual, y, d, s) : launch_bx3<1, 1>(x, w, bias, residual, y, d, s);
+  else rc = twn == 2 ? launch_bx3<2, 2>(x, w, bias, residual, y, d, s) : launch_bx3<2, 1>(x, w, bias, residual, y, d, s);
+  dlio_prof_end(0, s);
+  return rc;
+}

@@ -168,7 +168,13 @@ class _CBR:
         Cout, _, KH, KW = weight.shape
         d = ops.conv_desc(N, Cin, H, W, Cout, KH, KW, stride[0], stride[1], pad[0], pad[1],
                           in_ctot=x_ctot, in_coff=x_coff, out_ctot=raw_ctot, out_coff=raw_coff)
-        wt = ops.conv2d_prepped(weight, 0)
+        bx3 = _use_bx3(N, Cin, Cout, KH, KW, stride, d.OH, d.OW)
+        if bx3:
+            wt = ops.conv3x3_bx3_prepped(weight, 0)
+        else:
+            wt = ops.conv2d_prepped(weight, 0)
+        if training and x.requires_grad and _use_bx3(N, Cout, Cin, KH, KW, stride, H, W):
+            d.wbx3_1 = ops.conv3x3_bx3_prepped(weight, 1)       # data-gradient direction: roles swapped
         if training:
             # data-gradient layout for backward: fetched here, where `weight` is the long-lived
             # Parameter (the cache identifies weights by object; backward only sees unpacked copies)
@@ -178,7 +184,10 @@ class _CBR:
                 if plan is not None:           # tap-subset layouts of the phase-decomposed data gradient
                     d.wt_ph = {(it[0], it[1]): ops.conv2d_prepped_phase(weight, d.SH, d.SW, it[0], it[1])
                                for it in plan if it is not None}
-        ops.conv2d_fwd(x, wt, bias, raw, d)
+        if bx3:
+            ops.conv3x3_bx3_fwd(x, wt, bias, raw, d)
+        else:
+            ops.conv2d_fwd(x, wt, bias, raw, d)
         OHW = d.OH * d.OW
         if training and _PLANE_BN[0]:
             # statistics + finalise + apply (+ the plane averages an SELayer wants) in 2 launches
@@ -245,7 +254,12 @@ def conv_dgrad(dy, weight, d, dx, dx_ctot, dx_coff, residual=None, r_ctot=0, r_c
     N, Cin, Cout = d.N, d.Cin, d.Cout
     if accumulate:
         residual, r_ctot, r_coff = dx, dx_ctot, dx_coff
-    if d.SH == 1 and d.SW == 1:
+    wb = getattr(d, "wbx3_1", None) if (d.SH == 1 and d.SW == 1) else None
+    if wb is not None:
+        g = ops.conv_desc(N, Cout, d.OH, d.OW, Cin, 3, 3, 1, 1, 2 - d.PH, 2 - d.PW, OH=d.H, OW=d.W, in_ctot=Cout,
+                          in_coff=0, out_ctot=dx_ctot, out_coff=dx_coff, res_ctot=r_ctot, res_coff=r_coff)
+        ops.conv3x3_bx3_fwd(dy, wb, None, dx, g, residual=residual)
+    elif d.SH == 1 and d.SW == 1:
         wt2 = getattr(d, "wt2", None)
         if wt2 is None:
             wt2 = ops.conv2d_prepped(weight, 1)
@@ -269,6 +283,24 @@ def conv_dgrad(dy, weight, d, dx, dx_ctot, dx_coff, residual=None, r_ctot=0, r_c
                           res_ctot=r_ctot, res_coff=r_coff)
         ops.conv2d_fwd(up, wt2, None, dx, g, residual=residual)
     return dx
+
+
+_CONV_BX3 = [os.environ.get("DLIO_CONV_BX3", "1") != "0"]
+
+
+def set_conv_bx3(on):
+    _CONV_BX3[0] = bool(on)
+
+
+def _use_bx3(N, Cin, Cout, KH, KW, stride, OH, OW):
+    """3x3 stride-1 convolutions go to the split-bf16 kernel (conv_bx3.hip: fp32-accurate products
+    from six bf16 MFMAs, 1.3-1.5x the fp32-MFMA kernel) unless the launch is small AND deep: long
+    channel loops on a handful of workgroups per CU are latency-bound there and the fp32 kernel's
+    deeper weight prefetch wins (blk4 / blk5 data gradients: 0.6-0.85x)"""
+    if not _CONV_BX3[0] or (KH, KW) != (3, 3) or tuple(stride) != (1, 1):
+        return False
+    blocks = N * ((OH + 3) // 4) * ((OW + 31) // 32) * ((Cout + 63) // 64)
+    return not (Cin >= 192 and blocks < 1024)
 
 
 _DGRAD_PHASES = [os.environ.get("DLIO_DGRAD_PHASES", "1") != "0"]

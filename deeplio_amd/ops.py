@@ -96,32 +96,53 @@ class _PrepItemC(_ct.Structure):
 
 
 class _PrepCache:
+    """mode 0 / 1: fp32-MFMA layouts (forward / data gradient) of any conv weight; mode 2 / 3: the
+    split-bf16 layouts (conv_bx3.hip) of 3x3 weights, forward / data gradient"""
+
     def __init__(self):
         self.epoch = 0
         self.entries = {}        # (device index, data_ptr, shape, mode) -> dict
-        self.tables = {}         # device index -> dict(items_dev, n, total, keys)
+        self.tables = {}         # (device index, family) -> dict(items_dev, n, total, keys)
         self.waited = {}         # stream handle -> last refresh event it waited for
         self.batched = os.environ.get("DLIO_BATCHED_PREP", "1") != "0"
+
+    @staticmethod
+    def _floats(w, mode):
+        Cout, Cin, KH, KW = w.shape
+        if mode >= 2:
+            return lib.dlio_conv3x3_bx3_prep_floats(Cout, Cin, mode - 2)
+        return lib.dlio_conv2d_prep_weight_floats(Cout, Cin, KH, KW, mode)
+
+    @staticmethod
+    def _units(w, mode):
+        """index-space size of one item in its family's batched kernel"""
+        Cout, Cin, KH, KW = w.shape
+        if mode >= 2:
+            K, Nn = (Cin, Cout) if mode == 2 else (Cout, Cin)
+            return 9 * ((K + 15) // 16) * Nn * 16
+        return lib.dlio_conv2d_prep_weight_floats(Cout, Cin, KH, KW, mode)
 
     def get(self, w, mode):
         dev = w.device.index if w.device.index is not None else torch.cuda.current_device()
         key = (dev, w.data_ptr(), tuple(w.shape), mode)
         e = self.entries.get(key)
         if e is None or e["ref"]() is None:
-            Cout, Cin, KH, KW = w.shape
             e = dict(ref=_weakref.ref(w), epoch=-1, version=-1, stream=None, event=None,
-                     out=torch.empty(lib.dlio_conv2d_prep_weight_floats(Cout, Cin, KH, KW, mode),
-                                     dtype=torch.float32, device=w.device))
+                     out=torch.empty(self._floats(w, mode), dtype=torch.float32, device=w.device))
             self.entries[key] = e
-            self.tables.pop(dev, None)
+            self.tables.pop((dev, mode >> 1), None)
         cur = torch.cuda.current_stream()
         if e["epoch"] != self.epoch or e["version"] != w._version:
             if self.batched and e["epoch"] >= 0:          # a known weight went stale: refresh them all
                 self._refresh_all(dev, cur)
             if e["epoch"] != self.epoch or e["version"] != w._version:     # newly registered / batching off
                 Cout, Cin, KH, KW = w.shape
-                check(lib.dlio_conv2d_prep_weight(_ptr(w), _ptr(e["out"]), Cout, Cin, KH, KW, mode, _stream()),
-                      "conv2d_prep_weight")
+                if mode >= 2:
+                    check(lib.dlio_conv3x3_bx3_prep(_ptr(w), _ptr(e["out"]), Cout, Cin, mode - 2, _stream()),
+                          "conv3x3_bx3_prep")
+                else:
+                    check(lib.dlio_conv2d_prep_weight(_ptr(w), _ptr(e["out"]), Cout, Cin, KH, KW, mode, _stream()),
+                          "conv2d_prep_weight")
                 e.update(epoch=self.epoch, version=w._version, stream=cur.cuda_stream, event=None)
         elif e["stream"] != cur.cuda_stream and e["event"] is not None:
             # prepped on another stream in this epoch: one wait per (stream, refresh event)
@@ -130,30 +151,42 @@ class _PrepCache:
                 self.waited[cur.cuda_stream] = e["event"]
         return e["out"]
 
-    def _refresh_all(self, dev, cur):
-        t = self.tables.get(dev)
+    def _table(self, dev, family):
+        t = self.tables.get((dev, family))
         if t is None:
-            live = [(k, e) for k, e in self.entries.items() if k[0] == dev and e["ref"]() is not None
-                    and e["epoch"] >= 0]                 # only weights that were used before
-            for k in [k for k, e in self.entries.items() if e["ref"]() is None]:
-                del self.entries[k]
+            live = [(k, e) for k, e in self.entries.items() if k[0] == dev and (k[3] >> 1) == family
+                    and e["ref"]() is not None and e["epoch"] >= 0]       # only weights that were used before
             if not live:
-                return
+                return None
             arr = (_PrepItemC * len(live))()
             start = 0
             for i, (k, e) in enumerate(live):
                 w = e["ref"]()
                 Cout, Cin, KH, KW = w.shape
-                arr[i] = _PrepItemC(w.data_ptr(), e["out"].data_ptr(), Cout, Cin, KH * KW, k[3], start)
-                start += e["out"].numel()
+                arr[i] = _PrepItemC(w.data_ptr(), e["out"].data_ptr(), Cout, Cin, KH * KW, k[3] & 1, start)
+                start += self._units(w, k[3])
             raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
             t = dict(items=raw.to(torch.device("cuda", dev)), n=len(live), total=start, keys=[k for k, _ in live])
-            self.tables[dev] = t
-        check(lib.dlio_conv2d_prep_weights_batched(_ptr(t["items"]), t["n"], t["total"], _stream()),
-              "conv2d_prep_weights_batched")
+            self.tables[(dev, family)] = t
+        return t
+
+    def _refresh_all(self, dev, cur):
+        for k in [k for k, e in self.entries.items() if e["ref"]() is None]:
+            del self.entries[k]
+            self.tables.pop((k[0], k[3] >> 1), None)
+        done = []
+        for family, fn, name in ((0, lib.dlio_conv2d_prep_weights_batched, "conv2d_prep_weights_batched"),
+                                 (1, lib.dlio_conv3x3_bx3_prep_batched, "conv3x3_bx3_prep_batched")):
+            t = self._table(dev, family)
+            if t is None:
+                continue
+            check(fn(_ptr(t["items"]), t["n"], t["total"], _stream()), name)
+            done += t["keys"]
+        if not done:
+            return
         ev = torch.cuda.Event()
         ev.record(cur)
-        for k in t["keys"]:
+        for k in done:
             e = self.entries.get(k)
             w = e["ref"]() if e is not None else None
             if w is not None:
@@ -181,6 +214,33 @@ def conv2d_fwd(x, wt, bias, y, desc, in_aff=None, residual=None):
         m, s, b = in_aff
     check(lib.dlio_conv2d_fwd(_ptr(x), _ptr(wt), _ptr(bias), _ptr(m), _ptr(s), _ptr(b),
                               _ptr(residual), _ptr(y), C.byref(desc), _stream()), "conv2d_fwd")
+    return y
+
+
+def conv3x3_bx3_prep(w, mode, out=None):
+    """split-bf16 weight layout of a [Cout, Cin, 3, 3] tensor (mode 0 forward, 1 data gradient)"""
+    _chk(w)
+    Cout, Cin, KH, KW = w.shape
+    if (KH, KW) != (3, 3):
+        raise ValueError("conv3x3_bx3 needs a 3x3 kernel")
+    if out is None:
+        out = torch.empty(lib.dlio_conv3x3_bx3_prep_floats(Cout, Cin, mode), dtype=torch.float32, device=w.device)
+    check(lib.dlio_conv3x3_bx3_prep(_ptr(w), _ptr(out), Cout, Cin, mode, _stream()), "conv3x3_bx3_prep")
+    return out
+
+
+def conv3x3_bx3_prepped(w, mode):
+    """cached split-bf16 layout (mode 0 forward, 1 data gradient); see _PrepCache.  Call with the
+    long-lived Parameter (forward); backward receives the layouts on the ConvDesc."""
+    _chk(w)
+    if tuple(w.shape[2:]) != (3, 3):
+        raise ValueError("conv3x3_bx3 needs a 3x3 kernel")
+    return _PREP.get(w, mode + 2)
+
+
+def conv3x3_bx3_fwd(x, wt, bias, y, desc, residual=None):
+    check(lib.dlio_conv3x3_bx3_fwd(_ptr(x), _ptr(wt), _ptr(bias), _ptr(residual), _ptr(y), C.byref(desc), _stream()),
+          "conv3x3_bx3_fwd")
     return y
 
 

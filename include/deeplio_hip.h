@@ -100,6 +100,20 @@ int dlio_conv2d_fwd(const float* x, const float* wt, const float* bias,
                     const float* residual, float* y, const DlioConvDesc* d,
                     dlio_stream_t stream);
 
+/* 3x3 stride-1 convolution with fp32 accuracy on the bf16 matrix cores (same nn.Conv2d call sites
+ * as dlio_conv2d_fwd, 3x3 layers): operands are split into three bf16 pieces and each product is
+ * formed from six bf16 MFMAs with fp32 accumulation (csrc/conv_bx3.hip).  Weights are pre-split
+ * by dlio_conv3x3_bx3_prep (mode 0 forward, mode 1 data gradient: taps reversed, channels
+ * transposed) into dlio_conv3x3_bx3_prep_floats floats of storage; desc as for dlio_conv2d_fwd
+ * (KH = KW = 3, SH = SW = 1), bias / residual nullable. */
+size_t dlio_conv3x3_bx3_prep_floats(int Cout, int Cin, int mode);
+int dlio_conv3x3_bx3_prep(const float* w, void* wt, int Cout, int Cin, int mode, dlio_stream_t stream);
+/* every split-bf16 layout of a model in one launch (DlioPrepItem as for dlio_conv2d_prep_weights_batched;
+ * taps is ignored (9); start / total count 9 * ceil(K/16) * N * 16 elements per item) */
+int dlio_conv3x3_bx3_prep_batched(const DlioPrepItem* items_dev, int n_items, int64_t total,
+                                  dlio_stream_t stream);
+int dlio_conv3x3_bx3_fwd(const float* x, const void* wt, const float* bias, const float* residual,
+                         float* y, const DlioConvDesc* desc, dlio_stream_t stream);
 /* dst [planes][HU][WU] = src [planes][OH][OW] with SH-1 / SW-1 zeros inserted between rows /
  * columns (and zero tail rows/columns up to HU, WU): turns the data gradient of a strided
  * convolution into dlio_conv2d_fwd with stride 1 on the data-gradient weight layout
