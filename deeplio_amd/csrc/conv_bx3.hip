@@ -93,7 +93,7 @@ __global__ void prep_bx3_batched_kernel(const DlioPrepItem* __restrict__ items, 
 template <int MR, int TWN>
 __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
     const float* __restrict__ x, const __bf16* __restrict__ wt, const float* __restrict__ bias,
-    const float* residual, float* y, DlioConvDesc d, int tiles_w, int tiles_h, int co_tiles) {
+    const float* residual, float* y, DlioConvDesc d, int tiles_w, int tiles_h, int co_tiles, int patch_at) {
   constexpr int TH = 4, TW = 32 * TWN;
   constexpr int PR = TH + 2, PC = TW + 2, NPOSP = PR * PC;
   constexpr int NPOS = (NPOSP + 255) / 256;              // patch positions per thread
@@ -183,13 +183,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
 
-  auto compute = [&](const __bf16* buf, int kc) {
-    bf16x8 a[2][MR][3];
-    load_a(0, kc, a[0]);
+  // weight fragments run PF taps ahead of their MFMAs (a tap is 6*MR*TWN MFMAs = 0.2-0.6 us of cover
+  // per wave; one tap ahead does not hide an L2 miss when only a few waves share the SIMD)
+  constexpr int PF = 2, RING = PF + 1;
+  auto compute = [&](const __bf16* buf, int kc, bool prefetch) {
+    bf16x8 a[RING][MR][3];
+    if (patch_at < 0 && prefetch) load_chunk(kc + 1);
+#pragma unroll
+    for (int p = 0; p < PF; ++p) load_a(p, kc, a[p]);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int kh = tap / 3, kw = tap - 3 * kh;
-      if (tap + 1 < 9) load_a(tap + 1, kc, a[(tap + 1) & 1]);
+      if (tap + PF < 9) load_a(tap + PF, kc, a[(tap + PF) % RING]);
+      // the next chunk's patch loads go out AFTER the last weight-fragment load of this chunk: loads
+      // return in order, and a weight fragment queued behind 16-32 patch loads stalls its MFMAs for
+      // a full HBM round trip
+      if (tap == patch_at && prefetch) load_chunk(kc + 1);
       bf16x8 b[TWN][3];
 #pragma unroll
       for (int t = 0; t < TWN; ++t) {
@@ -198,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
         for (int p = 0; p < 3; ++p)
           b[t][p] = *reinterpret_cast<const bf16x8*>(buf + p * PLANE + pos * 16 + 8 * half);
       }
-      const auto& aa = a[tap & 1];
+      const auto& aa = a[tap % RING];
       // six products, smallest first; consecutive MFMAs go to different accumulators
       constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
@@ -218,8 +227,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
   for (int kc = 0; kc < KC; ++kc) {
     const __bf16* cur = smem + (size_t)(kc & 1) * 3 * PLANE;
     __bf16* nxt = smem + (size_t)((kc + 1) & 1) * 3 * PLANE;
-    if (kc + 1 < KC) load_chunk(kc + 1);
-    compute(cur, kc);
+    compute(cur, kc, kc + 1 < KC);
     if (kc + 1 < KC) store_chunk(nxt);
     __syncthreads();
   }
@@ -261,8 +269,14 @@ int launch_bx3(const float* x, const __bf16* wt, const float* bias, const float*
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
+  // when the next chunk's patch loads are issued: behind the first three taps' weight fragments for
+  // long channel loops (loads return in order -- fragments queued behind 16-32 patch loads stall
+  // their MFMAs for an HBM round trip: blk4 / blk5 data gradients 100 -> 67 us, 125 -> 60 us), ahead of
+  // everything for short loops (<= 5 chunks: 3-6 % faster there)
+  static const int force_at = getenv("DLIO_BX3_PATCH_AT") ? atoi(getenv("DLIO_BX3_PATCH_AT")) : -2;
+  const int patch_at = force_at >= -1 ? force_at : ((d.Cin + 15) / 16 > 5 ? 0 : -1);
   hipLaunchKernelGGL((conv3x3_bx3_kernel<MR, TWN>), dim3((unsigned)blocks), dim3(256), lds, s, x, wt, bias, residual, y,
-                     d, tiles_w, tiles_h, co_tiles);
+                     d, tiles_w, tiles_h, co_tiles, patch_at);
   return dlio_check_launch();
 }
 

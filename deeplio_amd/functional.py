@@ -294,13 +294,9 @@ def set_conv_bx3(on):
 
 def _use_bx3(N, Cin, Cout, KH, KW, stride, OH, OW):
     """3x3 stride-1 convolutions go to the split-bf16 kernel (conv_bx3.hip: fp32-accurate products
-    from six bf16 MFMAs, 1.3-1.5x the fp32-MFMA kernel) unless the launch is small AND deep: long
-    channel loops on a handful of workgroups per CU are latency-bound there and the fp32 kernel's
-    deeper weight prefetch wins (blk4 / blk5 data gradients: 0.6-0.85x)"""
-    if not _CONV_BX3[0] or (KH, KW) != (3, 3) or tuple(stride) != (1, 1):
-        return False
-    blocks = N * ((OH + 3) // 4) * ((OW + 31) // 32) * ((Cout + 63) // 64)
-    return not (Cin >= 192 and blocks < 1024)
+    from six bf16 MFMAs, 1.3-1.6x the fp32-MFMA kernel on every PointSeg / FlowNet / ResNet shape,
+    tools/bench_bx3.py)"""
+    return _CONV_BX3[0] and (KH, KW) == (3, 3) and tuple(stride) == (1, 1)
 
 
 _DGRAD_PHASES = [os.environ.get("DLIO_DGRAD_PHASES", "1") != "0"]
