@@ -316,7 +316,7 @@ extern "C" int dlio_conv3x3_bx3_fwd(const float* x, const void* wt, const float*
   hipStream_t s = as_stream(stream);
   const double flops = 2.0 * d.N * (double)d.OH * d.OW * d.Cout * (double)d.Cin * 9;
   const double bytes = 4.0 * d.N * ((double)d.Cin * d.H * d.W + (double)d.Cout * d.OH * d.OW * (residual ? 2.0 : 1.0));
-  dlio_prof_begin(0, s, flops, bytes);
+  dlio_prof_begin(3, s, flops, bytes);      // profiler kind 3: split-bf16 3x3 convolutions
   const __bf16* w = reinterpret_cast<const __bf16*>(wt);
   // tile: 64 channels x 64 columns per wave when that still gives every CU a few workgroups,
   // else narrower tiles (small feature maps / few output channels)
@@ -336,6 +336,6 @@ extern "C" int dlio_conv3x3_bx3_fwd(const float* x, const void* wt, const float*
   int rc;
   if (mr == 1) rc = twn == 2 ? launch_bx3<1, 2>(x, w, bias, residual, y, d, s) : launch_bx3<1, 1>(x, w, bias, residual, y, d, s);
   else rc = twn == 2 ? launch_bx3<2, 2>(x, w, bias, residual, y, d, s) : launch_bx3<2, 1>(x, w, bias, residual, y, d, s);
-  dlio_prof_end(0, s);
+  dlio_prof_end(3, s);
   return rc;
 }

@@ -164,7 +164,8 @@ class _CBR:
     @staticmethod
     def forward(x, x_ctot, x_coff, Cin, H, W, weight, bias, gamma, beta, rmean, rvar, stride, pad,
                 training, momentum, eps, pre_relu, post_relu, raw, raw_ctot, raw_coff, out, out_ctot,
-                out_coff, N, residual=None, r_ctot=0, r_coff=0, gap=None, gap_ctot=0, gap_coff=0):
+                out_coff, N, residual=None, r_ctot=0, r_coff=0, gap=None, gap_ctot=0, gap_coff=0,
+                need_dx=True):
         Cout, _, KH, KW = weight.shape
         d = ops.conv_desc(N, Cin, H, W, Cout, KH, KW, stride[0], stride[1], pad[0], pad[1],
                           in_ctot=x_ctot, in_coff=x_coff, out_ctot=raw_ctot, out_coff=raw_coff)
@@ -173,13 +174,13 @@ class _CBR:
             wt = ops.conv3x3_bx3_prepped(weight, 0)
         else:
             wt = ops.conv2d_prepped(weight, 0)
-        if training and x.requires_grad and _use_bx3(N, Cout, Cin, KH, KW, stride, H, W):
+        if training and need_dx and _use_bx3(N, Cout, Cin, KH, KW, stride, H, W):
             d.wbx3_1 = ops.conv3x3_bx3_prepped(weight, 1)       # data-gradient direction: roles swapped
         if training:
             # data-gradient layout for backward: fetched here, where `weight` is the long-lived
             # Parameter (the cache identifies weights by object; backward only sees unpacked copies)
             d.wt2 = ops.conv2d_prepped(weight, 1)
-            if (d.SH > 1 or d.SW > 1) and x.requires_grad and _DGRAD_PHASES[0]:
+            if (d.SH > 1 or d.SW > 1) and need_dx and _DGRAD_PHASES[0]:
                 plan = _phase_plan(d)
                 if plan is not None:           # tap-subset layouts of the phase-decomposed data gradient
                     d.wt_ph = {(it[0], it[1]): ops.conv2d_prepped_phase(weight, d.SH, d.SW, it[0], it[1])
@@ -384,7 +385,7 @@ class ConvBnAct(Function):
         out = _new((N, Cout, OH, OW), x)
         d, prm = _CBR.forward(x, Cin, 0, Cin, H, W, weight, bias, gamma, beta, rmean, rvar, stride,
                               pad, training, momentum, eps, pre_relu, post_relu, raw, Cout, 0, out,
-                              Cout, 0, N)
+                              Cout, 0, N, need_dx=ctx.needs_input_grad[0])
         ctx.save_for_backward(x, weight, beta, raw, prm, gamma, bias)
         ctx.cfg = (d, training, pre_relu, post_relu)
         return out

@@ -578,3 +578,44 @@ def test_conv_fwd_asymmetric_padding_by_output_extent(dev, k, extra):
     with pytest.raises(ValueError):
         ops.conv2d_fwd(x.to(dev), ops.conv2d_prep_weight(w.to(dev), 0), None,
                        torch.empty(N, Cout, bad.OH, bad.OW, device=dev), bad)
+
+
+@pytest.mark.parametrize("case", [(2, 24, 40, 9, 37, 1, 1), (1, 16, 64, 8, 70, 1, 1), (2, 70, 16, 5, 33, 1, 1),
+                                  (1, 3, 5, 4, 4, 1, 1), (2, 200, 48, 12, 40, 1, 1), (1, 20, 33, 7, 66, 0, 2),
+                                  (1, 8, 100, 3, 5, 2, 0)])
+def test_conv3x3_split_bf16_matches_fp64(dev, case):
+    """conv_bx3.hip: 3x3 stride-1 convolution with every product formed from six bf16 MFMAs over
+    three-way operand splits.  Claim: fp32 accuracy -- the error against fp64 must be of the size of
+    the fp32-MFMA kernel's own (a few 1e-7 of the output scale), far inside the 1e-4 bar; forward
+    layout with bias + residual + channel-sliced output, and the data-gradient layout; paddings 0..2,
+    channel counts that are not multiples of 16 / 32, widths that are not multiples of 32"""
+    from deeplio_amd import ops
+    N, Cin, Cout, H, W, PH, PW = case
+    g = _g(41)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref0 = F.conv2d(x.double(), w.double(), b.double(), 1, (PH, PW))
+    OH, OW = ref0.shape[2:]
+    res = torch.randn(N, Cout + 2, OH, OW, generator=g)
+    ref = ref0 + res[:, 1:1 + Cout].double()
+    d = ops.conv_desc(N, Cin, H, W, Cout, 3, 3, 1, 1, PH, PW, out_ctot=Cout + 3, out_coff=2, res_ctot=Cout + 2, res_coff=1)
+    y = torch.zeros(N, Cout + 3, OH, OW, device=dev)
+    ops.conv3x3_bx3_fwd(x.to(dev), ops.conv3x3_bx3_prep(w.to(dev), 0), b.to(dev), y, d, residual=res.to(dev))
+    y32 = torch.zeros(N, Cout + 3, OH, OW, device=dev)
+    ops.conv2d_fwd(x.to(dev), ops.conv2d_prep_weight(w.to(dev), 0), b.to(dev), y32, d, residual=res.to(dev))
+    e_bx3, e_f32 = rel_err(y[:, 2:2 + Cout], ref), rel_err(y32[:, 2:2 + Cout], ref)
+    assert e_bx3 < 3e-6 and e_bx3 < 4 * e_f32 + 2e-7, (e_bx3, e_f32)
+    assert float(y[:, :2].abs().max()) == 0 and float(y[:, 2 + Cout:].abs().max()) == 0
+    # data gradient: dx = conv(dy, w reversed / transposed) with padding 2 - P
+    dy = torch.randn(N, Cout, OH, OW, generator=g)
+    xr = x.double().requires_grad_(True)
+    F.conv2d(xr, w.double(), None, 1, (PH, PW)).backward(dy.double())
+    gd = ops.conv_desc(N, Cout, OH, OW, Cin, 3, 3, 1, 1, 2 - PH, 2 - PW, OH=H, OW=W)
+    dx = torch.empty(N, Cin, H, W, device=dev)
+    ops.conv3x3_bx3_fwd(dy.to(dev), ops.conv3x3_bx3_prep(w.to(dev), 1), None, dx, gd)
+    assert rel_err(dx, xr.grad) < 3e-6
+    # rejected: anything but 3x3 stride 1
+    with pytest.raises((ValueError, RuntimeError)):
+        ops.conv3x3_bx3_fwd(x.to(dev), ops.conv3x3_bx3_prep(w.to(dev), 0), None, y,
+                            ops.conv_desc(N, Cin, H, W, Cout, 3, 3, 1, 2, PH, PW))

@@ -17,6 +17,7 @@ import sys
 
 FAMILIES = {
     "conv2d_fwd_mfma": ("conv_fwd_kernel",),
+    "conv3x3_bx3": ("conv3x3_bx3_kernel",),
     "conv2d_1x1": ("conv1x1_",),
     "conv2d_wgrad_mfma": ("wgrad",),
     "batchnorm": ("chan_reduce", "chan_stats", "bn_apply", "bn_bwd", "bn_plane"),

@@ -21,7 +21,8 @@ def main(db_path, out_path, steps, note=""):
             f.write("| `%s` | %d | %.2f | %.1f | %.1f | %.1f | %.1f |\n" % (n[:90], c, s, a, mn, mx, 100 * s / tot))
         # the bench's kernel families (ops.prof kinds): average launch duration to compare with
         # roofline.avg_launch_ms / roofline.isolated.avg_launch_ms of the bench JSON
-        fam = {"conv2d_fwd_mfma, multi-tap (forward + data gradient)": ("conv_fwd_kernel",),
+        fam = {"conv3x3 split-bf16 MFMA (forward + data gradient)": ("conv3x3_bx3_kernel",),
+               "conv2d_fwd_mfma, multi-tap on the fp32 MFMA (forward + data gradient)": ("conv_fwd_kernel",),
                "conv2d_wgrad_mfma (+ split reduce)": ("wgrad",),
                "conv2d_1x1 (forward + data gradient)": ("conv1x1_",)}
         f.write("\n| bench family | kernel launches | total ms | avg us per kernel launch |\n|---|---|---|---|\n")
