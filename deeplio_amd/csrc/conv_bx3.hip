@@ -198,6 +198,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
       // the next chunk's patch loads go out AFTER the last weight-fragment load of this chunk: loads
       // return in order, and a weight fragment queued behind 16-32 patch loads stalls its MFMAs for
       // a full HBM round trip
+      // (keep the test per tap: the uniform branches also keep each tap's loads and MFMAs together
+      //  -- with one hoisted test, or sched_barrier(0) fences instead, the compiler's own order is
+      //  15-25 % slower on the long-K layers: 64->256 data gradient 193 -> 237-242 us)
       if (tap == patch_at && prefetch) load_chunk(kc + 1);
       bf16x8 b[TWN][3];
 #pragma unroll
