@@ -353,7 +353,24 @@ struct WgACfg {
 
 constexpr int PF_STEP = 2;     // MFMA step of a tile at which the next tile's global loads are issued
 
-template <int KH, int KW, int NT, int MRW>
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+
+// x = hi + mid + lo in bf16 pieces (see conv_bx3.hip): eight values -> three MFMA fragments
+__device__ __forceinline__ void wg_split8(const float (&v)[8], wg_bf16x8& h, wg_bf16x8& m, wg_bf16x8& l) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 hh = (__bf16)v[j];
+    const float r = v[j] - (float)hh;
+    const __bf16 mm = (__bf16)r;
+    h[j] = hh; m[j] = mm; l[j] = (__bf16)(r - (float)mm);
+  }
+}
+
+// BX3: the same GEMM on the bf16 matrix cores with fp32 accuracy -- each fp32 product formed from
+// six bf16 MFMAs over three-way operand splits (conv_bx3.hip).  K = 16 pixels per MFMA: k-block q
+// of a wave's 32 pixels is {16*half + 8q + j}, i.e. the float4 pairs (2q, 2q+1) of the dY
+// registers and 8 consecutive X' values in LDS, split in registers per use.
+template <int KH, int KW, int NT, int MRW, bool BX3 = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_adirect_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ wsp,
     DlioConvDesc d, int co_tiles, int ci_chunks, int splits, int tiles_w, int tiles_h) {
@@ -475,6 +492,55 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_adirect_kernel(
   };
   auto mfma_tile = [&](const float* Xl, const float4 (&a)[C::MR][4], auto&& prefetch) {
     const float* xrow = Xl + wave * C::PC + half * 16;
+    if constexpr (BX3) {
+      // A fragments of both k-blocks, split once per tile
+      wg_bf16x8 ah[C::MR][2], am[C::MR][2], al[C::MR][2];
+#pragma unroll
+      for (int m = 0; m < C::MR; ++m)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const float v[8] = {a[m][2 * q].x, a[m][2 * q].y, a[m][2 * q].z, a[m][2 * q].w,
+                              a[m][2 * q + 1].x, a[m][2 * q + 1].y, a[m][2 * q + 1].z, a[m][2 * q + 1].w};
+          wg_split8(v, ah[m][q], am[m][q], al[m][q]);
+        }
+      // steps: (k-block q, pair of column tiles); B values of the next step are read from LDS while
+      // the MFMAs of this one run; two accumulators alternate inside a step
+      constexpr int NP = (NT + 1) / 2, STEPS = 2 * NP;
+      float bv[2][2][8];
+      auto load_b = [&](int st, float (&dst)[2][8]) {
+        const int q = st / NP, t0 = (st - q * NP) * 2;
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+          if (t0 + g < NT) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dst[g][j] = xrow[off[t0 + g] + 8 * q + j];
+          }
+      };
+      load_b(0, bv[0]);
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) {
+        const int q = st / NP, t0 = (st - q * NP) * 2;
+        if (st + 1 < STEPS) load_b(st + 1, bv[(st + 1) & 1]);
+        if (st == 1) prefetch();
+        wg_bf16x8 bh[2], bm[2], bl[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+          if (t0 + g < NT) wg_split8(bv[st & 1][g], bh[g], bm[g], bl[g]);
+        // six products, smallest first
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+          for (int m = 0; m < C::MR; ++m)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+              if (t0 + g < NT) {
+                const wg_bf16x8& av = term == 0 ? al[m][q] : (term == 1 || term == 3) ? am[m][q] : ah[m][q];
+                const wg_bf16x8& bw = (term == 0 || term == 3 || term == 5) ? bh[g] : (term == 1 || term == 4) ? bm[g] : bl[g];
+                acc[m][t0 + g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bw, acc[m][t0 + g], 0, 0, 0);
+              }
+      }
+      return;
+    }
     float b[2][NT][2];
     auto load_b = [&](int st, float (&bv)[NT][2]) {
 #pragma unroll
@@ -786,7 +852,8 @@ int launch_mr(const float* x, const float* dy, float* dw, const float* in_mean,
                         (size_t)d.N * d.out_ctot * d.OH * d.OW * 4 < 0xffffff00ull;
     if (adirect && vec && !in_scale && fits32) {
       using A = WgACfg<KH, KW, NT, MRW>;
-      auto ka = conv_wgrad_adirect_kernel<KH, KW, NT, MRW>;
+      static const int bx3 = getenv("DLIO_WGRAD_BX3") ? atoi(getenv("DLIO_WGRAD_BX3")) : 1;   // split-bf16 MFMAs (fp32-accurate), 1.25x
+      auto ka = bx3 ? conv_wgrad_adirect_kernel<KH, KW, NT, MRW, true> : conv_wgrad_adirect_kernel<KH, KW, NT, MRW, false>;
       hipFuncSetAttribute(reinterpret_cast<const void*>(ka), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)A::LDS_BYTES);
       const int blocks = p.co_tiles * p.ci_chunks * p.splits;
