@@ -171,8 +171,9 @@ def main():
     for _ in range(args.warmup):
         ts.step(*batch)
     ts.check()
+    KINDS = (0, 1, 2, 3, 4, 5)
     prof_iso = None
-    DOM_KIND = 1                                 # without the isolated pass: the weight gradients
+    DOM_KIND = 4                                 # without the isolated pass: the weight gradients
     if not args.no_isolated:                     # every rank runs it: the steps contain the gradient all-reduce
         set_overlap(ts.model, False)
         ops.prof_enable(True)
@@ -183,7 +184,7 @@ def main():
             ts.step(*batch)
         torch.cuda.synchronize()
         ops.prof_enable(False)
-        prof_iso = {k: ops.prof_collect(k) for k in (0, 1, 2, 3)}
+        prof_iso = {k: ops.prof_collect(k) for k in KINDS}
         set_overlap(ts.model, True)
         DOM_KIND = max(prof_iso, key=lambda k: prof_iso[k]["ms"])
         DOM_KIND = int(sync.max_over_ranks(float(DOM_KIND)))     # one choice for all ranks
@@ -202,14 +203,18 @@ def main():
     ops.prof_enable(False)
     ts.check()
     dt = sync.max_over_ranks(dt)
-    prof_timed = {k: ops.prof_collect(k) for k in (0, 1, 2, 3)}
+    prof_timed = {k: ops.prof_collect(k) for k in KINDS}
     ms_per_step = 1e3 * dt / args.steps
     value = world * B * S / (dt / args.steps)
 
     if rank == 0:
-        kinds = {0: "conv2d_fwd_mfma, multi-tap on the fp32 MFMA (forward + data gradient)", 1: "conv2d_wgrad_mfma",
+        wg_bx3 = os.environ.get("DLIO_WGRAD_BX3", "1") != "0"
+        kinds = {0: "conv2d_fwd_mfma, multi-tap on the fp32 MFMA (forward + data gradient)",
+                 1: "conv2d_wgrad_mfma, stems / strided layers on the fp32 MFMA",
                  2: "conv2d_1x1 (forward + data gradient, HBM-bound)",
-                 3: "conv3x3 split-bf16 MFMA (forward + data gradient)"}
+                 3: "conv3x3 split-bf16 MFMA (forward + data gradient)",
+                 4: "conv3x3 weight gradient" + (" (split-bf16 MFMA)" if wg_bx3 else " (fp32 MFMA)"),
+                 5: "conv1x1 weight gradient (HBM-bound)"}
         prof = prof_timed
         dom = DOM_KIND
         p = prof[dom]
@@ -224,15 +229,16 @@ def main():
         def view(k, v, steps):
             """a kernel family against ITS roofline: MFMA for the multi-tap / weight-gradient kernels
             (algorithmic FLOPs), HBM for the 1x1 kernels (algorithmic bytes = input + output once)"""
-            hbm = k == 2
+            hbm = k in (2, 5)
+            bx3 = k == 3 or (k == 4 and wg_bx3)
             a = gbs(v) if hbm else tfl(v)
-            peak = PEAK_HBM if hbm else (PEAK_BX3_TFLOPS if k == 3 else PEAK_F32_MFMA_TFLOPS)
+            peak = PEAK_HBM if hbm else (PEAK_BX3_TFLOPS if bx3 else PEAK_F32_MFMA_TFLOPS)
             out = {"bound": "hbm" if hbm else "mfma", "achieved": round(a, 2), "peak": peak,
                    "unit": "GB/s" if hbm else "TFLOP/s", "frac": round(a / peak, 4),
                    "launches_per_step": v["launches"] / steps,
                    "avg_launch_ms": round(v["ms"] / max(v["launches"], 1), 5),
                    "ms_per_step_in_kernel": round(v["ms"] / steps, 3)}
-            if k == 3:
+            if bx3:
                 # fp32 products formed from six bf16 MFMAs (three-way operand split, fp32 accumulation):
                 # achieved = ALGORITHMIC fp32 FLOP/s; peak = dense bf16 MFMA peak / 6
                 out["peak_is"] = "bf16 dense MFMA peak 2516.8 TF/s / 6 MFMAs per fp32 product"
@@ -254,7 +260,8 @@ def main():
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
         if os.path.exists(pmc) and B == 8 and S == 2 and headline:
             with open(pmc) as f:
-                t = json.load(f).get({0: "conv2d_fwd_mfma", 1: "conv2d_wgrad_mfma", 2: "conv2d_1x1", 3: "conv3x3_bx3"}[dom])
+                t = json.load(f).get({0: "conv2d_fwd_mfma", 1: "conv2d_wgrad_mfma", 2: "conv2d_1x1", 3: "conv3x3_bx3",
+                                     4: "wgrad3x3", 5: "wgrad1x1"}[dom])
             if t and p["launches"]:
                 roofline["traffic"] = round(t["hbm_bytes_per_step_corrected"] / (p["launches"] / args.steps))
                 roofline["traffic_unit"] = "HBM bytes per launch (avg), from profiles/r01_pmc_traffic.json"
@@ -277,7 +284,7 @@ def main():
             "value": round(value, 3), "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "dtype_note": ("fp32 tensors, accumulation and results throughout; the 3x3 convolutions form each fp32 product "
+            "dtype_note": ("fp32 tensors, accumulation and results throughout; the 3x3 convolutions (forward, data and weight gradient) form each fp32 product "
                            "from six bf16 MFMAs over three-way operand splits (error vs fp64 = the fp32 MFMA's, "
                            "tests/test_gpu_ops.py::test_conv3x3_split_bf16_matches_fp64)"),
             "config": {"workload": ("BASELINE configs[1]: lidar-feat-pointseg(add)+imu-feat-rnn bi-LSTM-128x2"

@@ -972,7 +972,11 @@ extern "C" int dlio_conv2d_wgrad(const float* x, const float* dy, float* dw,
   float* wsp = reinterpret_cast<float*>(ws);
   const double flops = 2.0 * d.N * (double)d.OH * d.OW * d.Cout * (double)d.Cin * d.KH * d.KW;
   const double bytes = 4.0 * d.N * ((double)d.Cin * d.H * d.W + (double)d.Cout * d.OH * d.OW);
-  dlio_prof_begin(1, s, flops, bytes);
+  // profiler kinds: 4 = 3x3 stride-1 (dY-direct kernel, split-bf16 MFMAs), 5 = 1x1 (HBM-bound direct
+  // kernel), 1 = everything else (stems, strided layers: staged fp32-MFMA kernel)
+  const int pkind = (d.KH == 3 && d.KW == 3 && d.SH == 1 && d.SW == 1) ? 4
+                    : (d.KH == 1 && d.KW == 1 && d.SH == 1 && d.SW == 1) ? 5 : 1;
+  dlio_prof_begin(pkind, s, flops, bytes);
   int rc = DLIO_EUNSUP;
   Wg1Plan q;
   if (!in_scale && make_plan_1x1(d, q) && ws_bytes >= q.ws_bytes &&
@@ -981,7 +985,7 @@ extern "C" int dlio_conv2d_wgrad(const float* x, const float* dy, float* dw,
     else if (q.mr == 1) rc = launch_1x1<1, 2>(x, dy, dw, wsp, d, q, accumulate, s);
     else if (q.nt == 1) rc = launch_1x1<2, 1>(x, dy, dw, wsp, d, q, accumulate, s);
     else rc = launch_1x1<2, 2>(x, dy, dw, wsp, d, q, accumulate, s);
-    dlio_prof_end(1, s);
+    dlio_prof_end(pkind, s);
     return rc;
   }
 #define WG_CASE(kh, kw, sh, sw, nt)                                                \
@@ -1000,6 +1004,6 @@ extern "C" int dlio_conv2d_wgrad(const float* x, const float* dy, float* dw,
   else WG_CASE(1, 1, 1, 2, 1)
   else WG_CASE(1, 1, 2, 2, 1)
 #undef WG_CASE
-  dlio_prof_end(1, s);
+  dlio_prof_end(pkind, s);
   return rc;
 }

@@ -47,7 +47,8 @@ const char* dlio_last_hip_error_string(void);
  * When enabled, the conv launchers bracket each launch with hipEvents on the
  * launch stream.  dlio_prof_collect synchronises those events and returns the
  * summed milliseconds / algorithmic FLOPs / launch count per kernel kind
- * (0 = multi-tap conv forward / data gradient: MFMA-bound; 1 = conv weight gradient;
+ * (0 = multi-tap conv forward / data gradient: MFMA-bound; 1 = conv weight gradient other than
+ *  4 = 3x3 stride-1 weight gradient (split-bf16 MFMAs) and 5 = 1x1 weight gradient (HBM-bound);
  *  2 = 1x1 conv forward / data gradient: HBM-bound; 3 = 3x3 stride-1 forward / data gradient on
  *  the split-bf16 kernel, dlio_conv3x3_bx3_fwd).  dlio_prof_enable takes a bit mask
  * of the kinds to time (0 = off): an event pair costs ~1.3 us of stream time, so the
