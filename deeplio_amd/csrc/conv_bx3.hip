@@ -329,9 +329,11 @@ extern "C" int dlio_conv3x3_bx3_fwd(const float* x, const void* wt, const float*
     return (int64_t)d.N * cdiv(d.OH, 4) * cdiv(d.OW, 32 * twn) * cdiv(d.Cout, 32 * mr);
   };
   const int64_t want = 2 * (int64_t)dlio_num_cus();
-  // measured (tools/bench_bx3.py): two pixel blocks per wave pay off from ~192 input channels on
-  // (weight-fragment reuse), one block otherwise (more waves per CU)
-  int mr = d.Cout <= 32 ? 1 : 2, twn = (d.OW > 32 && d.Cin >= 192) ? 2 : 1;
+  // two pixel blocks per wave halve the weight-fragment traffic (the 16-byte fragment loads run at
+  // the L1 bandwidth limit with one block): in isolation that pays from ~192 input channels on
+  // (tools/bench_bx3.py), inside the training step from 48 on (full-step sweep: 29.05 -> 28.8 ms)
+  static const int twn_cin = getenv("DLIO_BX3_TWN_CIN") ? atoi(getenv("DLIO_BX3_TWN_CIN")) : 48;
+  int mr = d.Cout <= 32 ? 1 : 2, twn = (d.OW > 32 && d.Cin >= twn_cin) ? 2 : 1;
   if (blocks(mr, twn) < want && twn == 2) twn = 1;
   if (blocks(mr, twn) < want && mr == 2) mr = 1;
   if (force_mr) mr = force_mr;
