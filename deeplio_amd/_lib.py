@@ -41,6 +41,9 @@ SIGNATURES = {
     "dlio_conv2d_prep_weight": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "dlio_conv2d_prep_weights_batched": (_i, [_p, _i, _i64, _p]),
     "dlio_conv2d_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _cd, _p]),
+    "dlio_conv_bx3_prep_floats": (_sz, [_i, _i, _i, _i]),
+    "dlio_conv_bx3_prep": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "dlio_conv1x1_bx3_fwd": (_i, [_p, _p, _p, _p, _p, _cd, _p]),
     "dlio_conv3x3_bx3_prep_floats": (_sz, [_i, _i, _i]),
     "dlio_conv3x3_bx3_prep": (_i, [_p, _p, _i, _i, _i, _p]),
     "dlio_conv3x3_bx3_prep_batched": (_i, [_p, _i, _i64, _p]),

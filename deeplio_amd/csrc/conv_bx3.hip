@@ -30,11 +30,12 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
   l = (__bf16)(r - (float)m);
 }
 
-// w [Cout][Cin][3][3] -> wt [9][KC][3][Nn][16] bf16; mode 0: k = ci, n = co; mode 1: k = co, n = ci, taps reversed
-__global__ void prep_bx3_kernel(const float* __restrict__ w, __bf16* __restrict__ wt, int Cout, int Cin, int mode) {
+// w [Cout][Cin][taps] -> wt [taps][KC][3][Nn][16] bf16; mode 0: k = ci, n = co; mode 1: k = co, n = ci, taps reversed
+__global__ void prep_bx3_kernel(const float* __restrict__ w, __bf16* __restrict__ wt, int Cout, int Cin, int taps,
+                                int mode) {
   const int K = mode == 0 ? Cin : Cout, Nn = mode == 0 ? Cout : Cin;
   const int KC = (K + 15) >> 4;
-  const int64_t total = (int64_t)9 * KC * Nn * 16;
+  const int64_t total = (int64_t)taps * KC * Nn * 16;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int kk = (int)(i & 15);
     int64_t t = i >> 4;
@@ -44,8 +45,8 @@ __global__ void prep_bx3_kernel(const float* __restrict__ w, __bf16* __restrict_
     const int k = kc * 16 + kk;
     float v = 0.f;
     if (k < K) {
-      if (mode == 0) v = w[((int64_t)n * Cin + k) * 9 + tap];
-      else v = w[((int64_t)k * Cin + n) * 9 + (8 - tap)];
+      if (mode == 0) v = w[((int64_t)n * Cin + k) * taps + tap];
+      else v = w[((int64_t)k * Cin + n) * taps + (taps - 1 - tap)];
     }
     __bf16 h, m, l;
     split3(v, h, m, l);
@@ -77,8 +78,8 @@ __global__ void prep_bx3_batched_kernel(const DlioPrepItem* __restrict__ items, 
     const int k = kc * 16 + kk;
     float v = 0.f;
     if (k < K) {
-      if (it.mode == 0) v = it.w[((int64_t)n * it.Cin + k) * 9 + tap];
-      else v = it.w[((int64_t)k * it.Cin + n) * 9 + (8 - tap)];
+      if (it.mode == 0) v = it.w[((int64_t)n * it.Cin + k) * it.taps + tap];
+      else v = it.w[((int64_t)k * it.Cin + n) * it.taps + (it.taps - 1 - tap)];
     }
     __bf16 h, m, l;
     split3(v, h, m, l);
@@ -258,6 +259,116 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
     }
 }
 
+// ---- 1x1 convolution on the same scheme, no LDS (the float4 structure of conv1x1_v4_kernel in
+// conv_fwd.hip): a wave owns 128 consecutive pixels, lane l the four pixels 4l..4l+3; per 16-channel
+// chunk a lane loads the float4 of 8 channels (8*half + j), component e of those eight is the
+// B fragment of pixel tile e (split in registers), weights come pre-split ([chunk][plane][n][16]).
+// These layers sit at the fp32-MFMA ridge (20-25 FLOP/B); with 2.7x less MFMA time per product they
+// are purely HBM-bound.
+template <int MR>
+__global__ __launch_bounds__(256) void conv1x1_bx3_kernel(
+    const float* __restrict__ x, const __bf16* __restrict__ wt, const float* __restrict__ bias,
+    const float* residual, float* y, DlioConvDesc d, int pix_blocks, int co_tiles) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
+  int bid = blockIdx.x;
+  const int cot = bid % co_tiles; bid /= co_tiles;
+  const int pb = bid % pix_blocks; bid /= pix_blocks;
+  const int n = bid;
+  const int P = d.OH * d.OW;
+  const int co0 = cot * 32 * MR;
+  const int p = (pb * 4 + wave) * 128 + 4 * l31;
+  if ((pb * 4 + wave) * 128 >= P) return;
+  const bool pvalid = p < P;            // P % 4 == 0: a lane's four pixels are all in or all out
+  const size_t pc = pvalid ? p : 0;
+  const int Cin = d.Cin, Cout = d.Cout, KC = (Cin + 15) >> 4;
+
+  f32x16 acc[MR][4];
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][e][r] = 0.f;
+
+  const float* xq = x + ((size_t)n * d.in_ctot + d.in_coff) * (size_t)P + pc;
+  const size_t wplane = (size_t)Cout * 16;
+  const __bf16* wq[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) wq[m] = wt + (size_t)min(co0 + m * 32 + l31, Cout - 1) * 16 + 8 * half;
+
+  float4 v[2][8];
+  bf16x8 a[2][MR][3];
+  auto load_chunk = [&](int kc, int s) {
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        a[s][m][pl] = *reinterpret_cast<const bf16x8*>(wq[m] + ((size_t)kc * 3 + pl) * wplane);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ci = kc * 16 + 8 * half + j;
+      float4 t = *reinterpret_cast<const float4*>(xq + (size_t)min(ci, Cin - 1) * P);
+      if (ci >= Cin) t = make_float4(0.f, 0.f, 0.f, 0.f);
+      v[s][j] = t;
+    }
+  };
+  auto mfma_chunk = [&](int s) {
+    bf16x8 bh[4], bm[4], bl[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float e4[4] = {v[s][j].x, v[s][j].y, v[s][j].z, v[s][j].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        __bf16 h, m, l;
+        split3(e4[e], h, m, l);
+        bh[e][j] = h; bm[e][j] = m; bl[e][j] = l;
+      }
+    }
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bf16x8& bb = PB[q] == 0 ? bh[e] : (PB[q] == 1 ? bm[e] : bl[e]);
+          acc[m][e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][m][PA[q]], bb, acc[m][e], 0, 0, 0);
+        }
+  };
+  load_chunk(0, 0);
+  for (int kc = 0; kc < KC; kc += 2) {
+    if (kc + 1 < KC) load_chunk(kc + 1, 1);
+    mfma_chunk(0);
+    if (kc + 2 < KC) load_chunk(kc + 2, 0);
+    if (kc + 1 < KC) mfma_chunk(1);
+  }
+
+  if (!pvalid) return;
+  const size_t plane = (size_t)P;
+  float* yb = y + ((size_t)n * d.out_ctot + d.out_coff) * plane + pc;
+  const float* rb = residual ? residual + ((size_t)n * d.res_ctot + d.res_coff) * plane + pc : nullptr;
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    float4 rv[16];
+    if (rb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = min(co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, Cout - 1);
+        rv[r] = *reinterpret_cast<const float4*>(rb + (size_t)co * plane);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (co >= Cout) continue;
+      const float bv = bias ? bias[co] : 0.f;
+      float4 o = make_float4(acc[m][0][r] + bv, acc[m][1][r] + bv, acc[m][2][r] + bv, acc[m][3][r] + bv);
+      if (rb) { o.x += rv[r].x; o.y += rv[r].y; o.z += rv[r].z; o.w += rv[r].w; }
+      *reinterpret_cast<float4*>(yb + (size_t)co * plane) = o;
+    }
+  }
+}
+
 template <int MR, int TWN>
 int launch_bx3(const float* x, const __bf16* wt, const float* bias, const float* residual, float* y,
                const DlioConvDesc& d, hipStream_t s) {
@@ -285,19 +396,58 @@ int launch_bx3(const float* x, const __bf16* wt, const float* bias, const float*
 
 }  // namespace
 
-extern "C" size_t dlio_conv3x3_bx3_prep_floats(int Cout, int Cin, int mode) {
-  if (Cout <= 0 || Cin <= 0 || (mode != 0 && mode != 1)) return 0;
+extern "C" size_t dlio_conv_bx3_prep_floats(int Cout, int Cin, int taps, int mode) {
+  if (Cout <= 0 || Cin <= 0 || taps <= 0 || (mode != 0 && mode != 1)) return 0;
   const int K = mode == 0 ? Cin : Cout, Nn = mode == 0 ? Cout : Cin;
-  return (size_t)9 * ((K + 15) >> 4) * 3 * Nn * 16 / 2;      // bf16 elements / 2
+  return (size_t)taps * ((K + 15) >> 4) * 3 * Nn * 16 / 2;      // bf16 elements / 2
+}
+
+extern "C" int dlio_conv_bx3_prep(const float* w, void* wt, int Cout, int Cin, int taps, int mode,
+                                  dlio_stream_t stream) {
+  if (!w || !wt || Cout <= 0 || Cin <= 0 || taps <= 0 || (mode != 0 && mode != 1)) return DLIO_EINVAL;
+  const int K = mode == 0 ? Cin : Cout, Nn = mode == 0 ? Cout : Cin;
+  const int64_t total = (int64_t)taps * ((K + 15) >> 4) * Nn * 16;
+  hipLaunchKernelGGL(prep_bx3_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, as_stream(stream), w,
+                     reinterpret_cast<__bf16*>(wt), Cout, Cin, taps, mode);
+  return dlio_check_launch();
+}
+
+extern "C" size_t dlio_conv3x3_bx3_prep_floats(int Cout, int Cin, int mode) {
+  return dlio_conv_bx3_prep_floats(Cout, Cin, 9, mode);
 }
 
 extern "C" int dlio_conv3x3_bx3_prep(const float* w, void* wt, int Cout, int Cin, int mode, dlio_stream_t stream) {
-  if (!w || !wt || Cout <= 0 || Cin <= 0 || (mode != 0 && mode != 1)) return DLIO_EINVAL;
-  const int K = mode == 0 ? Cin : Cout, Nn = mode == 0 ? Cout : Cin;
-  const int64_t total = (int64_t)9 * ((K + 15) >> 4) * Nn * 16;
-  hipLaunchKernelGGL(prep_bx3_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, as_stream(stream), w,
-                     reinterpret_cast<__bf16*>(wt), Cout, Cin, mode);
-  return dlio_check_launch();
+  return dlio_conv_bx3_prep(w, wt, Cout, Cin, 9, mode, stream);
+}
+
+extern "C" int dlio_conv1x1_bx3_fwd(const float* x, const void* wt, const float* bias, const float* residual,
+                                    float* y, const DlioConvDesc* dp, dlio_stream_t stream) {
+  if (!x || !wt || !y || !dp) return DLIO_EINVAL;
+  const DlioConvDesc& d = *dp;
+  if (d.KH != 1 || d.KW != 1 || d.SH != 1 || d.SW != 1 || d.PH || d.PW) return DLIO_EUNSUP;
+  if (d.N <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.H <= 0 || d.W <= 0 || d.OH != d.H || d.OW != d.W) return DLIO_EINVAL;
+  const int64_t P = (int64_t)d.H * d.W;
+  if (P % 4 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
+                 reinterpret_cast<uintptr_t>(residual)) & 15))
+    return DLIO_EUNSUP;                      // float4 rows: the fp32 kernels of dlio_conv2d_fwd take these
+  hipStream_t s = as_stream(stream);
+  const double flops = 2.0 * d.N * (double)P * d.Cout * (double)d.Cin;
+  const double bytes = 4.0 * d.N * ((double)d.Cin * P + (double)d.Cout * P * (residual ? 2.0 : 1.0));
+  dlio_prof_begin(2, s, flops, bytes);
+  static const int force_mr = getenv("DLIO_BX3_1X1_MR") ? atoi(getenv("DLIO_BX3_1X1_MR")) : 0;
+  const int mr = force_mr ? force_mr : (d.Cout <= 32 ? 1 : 2);
+  const int pix_blocks = (int)((P + 511) / 512), co_tiles = cdiv(d.Cout, 32 * mr);
+  const int64_t blocks = (int64_t)d.N * pix_blocks * co_tiles;
+  const __bf16* w = reinterpret_cast<const __bf16*>(wt);
+  if (mr == 1)
+    hipLaunchKernelGGL((conv1x1_bx3_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, x, w, bias, residual, y, d,
+                       pix_blocks, co_tiles);
+  else
+    hipLaunchKernelGGL((conv1x1_bx3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, x, w, bias, residual, y, d,
+                       pix_blocks, co_tiles);
+  const int rc = dlio_check_launch();
+  dlio_prof_end(2, s);
+  return rc;
 }
 
 extern "C" int dlio_conv3x3_bx3_prep_batched(const DlioPrepItem* items_dev, int n_items, int64_t total,

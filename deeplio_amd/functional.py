@@ -170,12 +170,14 @@ class _CBR:
         d = ops.conv_desc(N, Cin, H, W, Cout, KH, KW, stride[0], stride[1], pad[0], pad[1],
                           in_ctot=x_ctot, in_coff=x_coff, out_ctot=raw_ctot, out_coff=raw_coff)
         bx3 = _use_bx3(N, Cin, Cout, KH, KW, stride, d.OH, d.OW)
+        bx3 = bx3 and (KH == 3 or (pad[0] == 0 and pad[1] == 0))
         if bx3:
-            wt = ops.conv3x3_bx3_prepped(weight, 0)
+            wt = ops.conv_bx3_prepped(weight, 0)
         else:
             wt = ops.conv2d_prepped(weight, 0)
-        if training and need_dx and _use_bx3(N, Cout, Cin, KH, KW, stride, H, W):
-            d.wbx3_1 = ops.conv3x3_bx3_prepped(weight, 1)       # data-gradient direction: roles swapped
+        if (training and need_dx and _use_bx3(N, Cout, Cin, KH, KW, stride, H, W)
+                and (KH == 3 or (pad[0] == 0 and pad[1] == 0))):
+            d.wbx3_1 = ops.conv_bx3_prepped(weight, 1)          # data-gradient direction: roles swapped
         if training:
             # data-gradient layout for backward: fetched here, where `weight` is the long-lived
             # Parameter (the cache identifies weights by object; backward only sees unpacked copies)
@@ -185,7 +187,9 @@ class _CBR:
                 if plan is not None:           # tap-subset layouts of the phase-decomposed data gradient
                     d.wt_ph = {(it[0], it[1]): ops.conv2d_prepped_phase(weight, d.SH, d.SW, it[0], it[1])
                                for it in plan if it is not None}
-        if bx3:
+        if bx3 and KH == 1:
+            ops.conv1x1_bx3_fwd(x, wt, bias, raw, d)
+        elif bx3:
             ops.conv3x3_bx3_fwd(x, wt, bias, raw, d)
         else:
             ops.conv2d_fwd(x, wt, bias, raw, d)
@@ -256,7 +260,11 @@ def conv_dgrad(dy, weight, d, dx, dx_ctot, dx_coff, residual=None, r_ctot=0, r_c
     if accumulate:
         residual, r_ctot, r_coff = dx, dx_ctot, dx_coff
     wb = getattr(d, "wbx3_1", None) if (d.SH == 1 and d.SW == 1) else None
-    if wb is not None:
+    if wb is not None and d.KH == 1:
+        g = ops.conv_desc(N, Cout, d.OH, d.OW, Cin, 1, 1, 1, 1, 0, 0, OH=d.H, OW=d.W, in_ctot=Cout,
+                          in_coff=0, out_ctot=dx_ctot, out_coff=dx_coff, res_ctot=r_ctot, res_coff=r_coff)
+        ops.conv1x1_bx3_fwd(dy, wb, None, dx, g, residual=residual)
+    elif wb is not None:
         g = ops.conv_desc(N, Cout, d.OH, d.OW, Cin, 3, 3, 1, 1, 2 - d.PH, 2 - d.PW, OH=d.H, OW=d.W, in_ctot=Cout,
                           in_coff=0, out_ctot=dx_ctot, out_coff=dx_coff, res_ctot=r_ctot, res_coff=r_coff)
         ops.conv3x3_bx3_fwd(dy, wb, None, dx, g, residual=residual)
@@ -287,6 +295,7 @@ def conv_dgrad(dy, weight, d, dx, dx_ctot, dx_coff, residual=None, r_ctot=0, r_c
 
 
 _CONV_BX3 = [os.environ.get("DLIO_CONV_BX3", "1") != "0"]
+_CONV_BX3_1X1 = [os.environ.get("DLIO_CONV_BX3_1X1", "1") != "0"]
 
 
 def set_conv_bx3(on):
@@ -297,7 +306,15 @@ def _use_bx3(N, Cin, Cout, KH, KW, stride, OH, OW):
     """3x3 stride-1 convolutions go to the split-bf16 kernel (conv_bx3.hip: fp32-accurate products
     from six bf16 MFMAs, 1.3-1.6x the fp32-MFMA kernel on every PointSeg / FlowNet / ResNet shape,
     tools/bench_bx3.py)"""
-    return _CONV_BX3[0] and (KH, KW) == (3, 3) and tuple(stride) == (1, 1)
+    if not _CONV_BX3[0] or tuple(stride) != (1, 1):
+        return False
+    if (KH, KW) == (3, 3):
+        return True
+    # 1x1 (conv1x1_bx3_kernel): the layers that sit at the fp32-MFMA ridge -- at least 48 channels on
+    # both sides and enough pixels to fill the chip (blk3: 1.17-1.36x, tools/bench_bx3_1x1.py); the
+    # narrow and the small ones are HBM- or launch-bound on the fp32 kernels already
+    return ((KH, KW) == (1, 1) and _CONV_BX3_1X1[0] and Cin >= 48 and Cout >= 48 and N * OH * OW >= 65536
+            and (OH * OW) % 4 == 0)
 
 
 _DGRAD_PHASES = [os.environ.get("DLIO_DGRAD_PHASES", "1") != "0"]

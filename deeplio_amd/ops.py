@@ -110,7 +110,7 @@ class _PrepCache:
     def _floats(w, mode):
         Cout, Cin, KH, KW = w.shape
         if mode >= 2:
-            return lib.dlio_conv3x3_bx3_prep_floats(Cout, Cin, mode - 2)
+            return lib.dlio_conv_bx3_prep_floats(Cout, Cin, KH * KW, mode - 2)
         return lib.dlio_conv2d_prep_weight_floats(Cout, Cin, KH, KW, mode)
 
     @staticmethod
@@ -119,7 +119,7 @@ class _PrepCache:
         Cout, Cin, KH, KW = w.shape
         if mode >= 2:
             K, Nn = (Cin, Cout) if mode == 2 else (Cout, Cin)
-            return 9 * ((K + 15) // 16) * Nn * 16
+            return KH * KW * ((K + 15) // 16) * Nn * 16
         return lib.dlio_conv2d_prep_weight_floats(Cout, Cin, KH, KW, mode)
 
     def get(self, w, mode):
@@ -138,8 +138,8 @@ class _PrepCache:
             if e["epoch"] != self.epoch or e["version"] != w._version:     # newly registered / batching off
                 Cout, Cin, KH, KW = w.shape
                 if mode >= 2:
-                    check(lib.dlio_conv3x3_bx3_prep(_ptr(w), _ptr(e["out"]), Cout, Cin, mode - 2, _stream()),
-                          "conv3x3_bx3_prep")
+                    check(lib.dlio_conv_bx3_prep(_ptr(w), _ptr(e["out"]), Cout, Cin, KH * KW, mode - 2, _stream()),
+                          "conv_bx3_prep")
                 else:
                     check(lib.dlio_conv2d_prep_weight(_ptr(w), _ptr(e["out"]), Cout, Cin, KH, KW, mode, _stream()),
                           "conv2d_prep_weight")
@@ -229,13 +229,34 @@ def conv3x3_bx3_prep(w, mode, out=None):
     return out
 
 
-def conv3x3_bx3_prepped(w, mode):
-    """cached split-bf16 layout (mode 0 forward, 1 data gradient); see _PrepCache.  Call with the
-    long-lived Parameter (forward); backward receives the layouts on the ConvDesc."""
+def conv_bx3_prepped(w, mode):
+    """cached split-bf16 layout of a 3x3 or 1x1 weight (mode 0 forward, 1 data gradient); see
+    _PrepCache.  Call with the long-lived Parameter (forward); backward receives the layouts on the
+    ConvDesc."""
     _chk(w)
-    if tuple(w.shape[2:]) != (3, 3):
-        raise ValueError("conv3x3_bx3 needs a 3x3 kernel")
+    if tuple(w.shape[2:]) not in ((3, 3), (1, 1)):
+        raise ValueError("split-bf16 kernels exist for 3x3 and 1x1 weights")
     return _PREP.get(w, mode + 2)
+
+
+conv3x3_bx3_prepped = conv_bx3_prepped
+
+
+def conv1x1_bx3_prep(w, mode, out=None):
+    _chk(w)
+    Cout, Cin, KH, KW = w.shape
+    if (KH, KW) != (1, 1):
+        raise ValueError("conv1x1_bx3 needs a 1x1 kernel")
+    if out is None:
+        out = torch.empty(lib.dlio_conv_bx3_prep_floats(Cout, Cin, 1, mode), dtype=torch.float32, device=w.device)
+    check(lib.dlio_conv_bx3_prep(_ptr(w), _ptr(out), Cout, Cin, 1, mode, _stream()), "conv_bx3_prep")
+    return out
+
+
+def conv1x1_bx3_fwd(x, wt, bias, y, desc, residual=None):
+    check(lib.dlio_conv1x1_bx3_fwd(_ptr(x), _ptr(wt), _ptr(bias), _ptr(residual), _ptr(y), C.byref(desc), _stream()),
+          "conv1x1_bx3_fwd")
+    return y
 
 
 def conv3x3_bx3_fwd(x, wt, bias, y, desc, residual=None):

@@ -108,10 +108,16 @@ int dlio_conv2d_fwd(const float* x, const float* wt, const float* bias,
  * by dlio_conv3x3_bx3_prep (mode 0 forward, mode 1 data gradient: taps reversed, channels
  * transposed) into dlio_conv3x3_bx3_prep_floats floats of storage; desc as for dlio_conv2d_fwd
  * (KH = KW = 3, SH = SW = 1), bias / residual nullable. */
+size_t dlio_conv_bx3_prep_floats(int Cout, int Cin, int taps, int mode);      /* taps = KH*KW: 9 or 1 */
+int dlio_conv_bx3_prep(const float* w, void* wt, int Cout, int Cin, int taps, int mode, dlio_stream_t stream);
+/* 1x1 stride-1 convolution on the same scheme (pixels % 4 == 0 and 16-byte aligned rows, else
+ * DLIO_EUNSUP: use dlio_conv2d_fwd); weights from dlio_conv_bx3_prep(..., taps = 1, mode) */
+int dlio_conv1x1_bx3_fwd(const float* x, const void* wt, const float* bias, const float* residual,
+                         float* y, const DlioConvDesc* desc, dlio_stream_t stream);
 size_t dlio_conv3x3_bx3_prep_floats(int Cout, int Cin, int mode);
 int dlio_conv3x3_bx3_prep(const float* w, void* wt, int Cout, int Cin, int mode, dlio_stream_t stream);
 /* every split-bf16 layout of a model in one launch (DlioPrepItem as for dlio_conv2d_prep_weights_batched;
- * taps is ignored (9); start / total count 9 * ceil(K/16) * N * 16 elements per item) */
+ * taps = 9 or 1; start / total count taps * ceil(K/16) * N * 16 elements per item) */
 int dlio_conv3x3_bx3_prep_batched(const DlioPrepItem* items_dev, int n_items, int64_t total,
                                   dlio_stream_t stream);
 int dlio_conv3x3_bx3_fwd(const float* x, const void* wt, const float* bias, const float* residual,

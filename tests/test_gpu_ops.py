@@ -619,3 +619,36 @@ def test_conv3x3_split_bf16_matches_fp64(dev, case):
     with pytest.raises((ValueError, RuntimeError)):
         ops.conv3x3_bx3_fwd(x.to(dev), ops.conv3x3_bx3_prep(w.to(dev), 0), None, y,
                             ops.conv_desc(N, Cin, H, W, Cout, 3, 3, 1, 2, PH, PW))
+
+
+@pytest.mark.parametrize("case", [(2, 24, 40, 8, 36), (1, 70, 100, 4, 128), (2, 300, 16, 6, 20), (1, 3, 5, 2, 2),
+                                  (3, 48, 192, 16, 32)])
+def test_conv1x1_split_bf16_matches_fp64(dev, case):
+    """conv1x1_bx3_kernel: 1x1 convolution on the split-bf16 scheme (forward with bias + residual +
+    channel-sliced output, and the data-gradient layout); error vs fp64 of the size of the fp32-MFMA
+    kernel's own.  Pixel counts that are not a multiple of 4 are refused (the fp32 kernels take them)."""
+    from deeplio_amd import ops
+    N, Cin, Cout, H, W = case
+    g = _g(43)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(N, Cout + 2, H, W, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double()) + res[:, 1:1 + Cout].double()
+    d = ops.conv_desc(N, Cin, H, W, Cout, 1, 1, 1, 1, 0, 0, out_ctot=Cout + 3, out_coff=2, res_ctot=Cout + 2, res_coff=1)
+    y = torch.zeros(N, Cout + 3, H, W, device=dev)
+    ops.conv1x1_bx3_fwd(x.to(dev), ops.conv1x1_bx3_prep(w.to(dev), 0), b.to(dev), y, d, residual=res.to(dev))
+    y32 = torch.zeros_like(y)
+    ops.conv2d_fwd(x.to(dev), ops.conv2d_prep_weight(w.to(dev), 0), b.to(dev), y32, d, residual=res.to(dev))
+    e_bx3, e_f32 = rel_err(y[:, 2:2 + Cout], ref), rel_err(y32[:, 2:2 + Cout], ref)
+    assert e_bx3 < 3e-6 and e_bx3 < 4 * e_f32 + 2e-7, (e_bx3, e_f32)
+    assert float(y[:, :2].abs().max()) == 0 and float(y[:, 2 + Cout:].abs().max()) == 0
+    dy = torch.randn(N, Cout, H, W, generator=g)
+    xr = x.double().requires_grad_(True)
+    F.conv2d(xr, w.double()).backward(dy.double())
+    dx = torch.empty(N, Cin, H, W, device=dev)
+    ops.conv1x1_bx3_fwd(dy.to(dev), ops.conv1x1_bx3_prep(w.to(dev), 1), None, dx, ops.conv_desc(N, Cout, H, W, Cin, 1, 1, 1, 1, 0, 0))
+    assert rel_err(dx, xr.grad) < 3e-6
+    with pytest.raises((ValueError, RuntimeError)):       # 3 x 5 = 15 pixels: not a multiple of 4
+        ops.conv1x1_bx3_fwd(torch.zeros(1, Cin, 3, 5, device=dev), ops.conv1x1_bx3_prep(w.to(dev), 0), None,
+                            torch.zeros(1, Cout, 3, 5, device=dev), ops.conv_desc(1, Cin, 3, 5, Cout, 1, 1, 1, 1, 0, 0))
