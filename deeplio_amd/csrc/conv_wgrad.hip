@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_adirect_kernel(
 // wave strides over 32-pixel segments on its own with a register double buffer, two workgroups
 // per CU keep ~128 KB of loads in flight (the LDS-staged kernel above manages ~40 KB for these
 // layers, which are HBM-bound).  Partial sums: 4 waves through LDS, then the slab reduction.
-template <int MR, int NT>
+template <int MR, int NT, bool BX3 = false>
 __global__ __launch_bounds__(256, 2) void wgrad1x1_direct_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ wsp,
     DlioConvDesc d, int co_tiles, int ci_chunks, int splits, int segs_per_img) {
@@ -705,6 +705,36 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_direct_kernel(
       }
   };
   auto compute = [&](const float4 (&a)[MR][4], const float4 (&b)[NT][4]) {
+    if constexpr (BX3) {
+      // split-bf16 MFMAs (conv_bx3.hip): k-block q = the lane's pixels 8q..8q+7 of both operands
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        wg_bf16x8 ah[MR], am[MR], al[MR], bh[NT], bm[NT], bl[NT];
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+          const float v[8] = {a[m][2 * q].x, a[m][2 * q].y, a[m][2 * q].z, a[m][2 * q].w,
+                              a[m][2 * q + 1].x, a[m][2 * q + 1].y, a[m][2 * q + 1].z, a[m][2 * q + 1].w};
+          wg_split8(v, ah[m], am[m], al[m]);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float v[8] = {b[t][2 * q].x, b[t][2 * q].y, b[t][2 * q].z, b[t][2 * q].w,
+                              b[t][2 * q + 1].x, b[t][2 * q + 1].y, b[t][2 * q + 1].z, b[t][2 * q + 1].w};
+          wg_split8(v, bh[t], bm[t], bl[t]);
+        }
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+          for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              const wg_bf16x8& av = term == 0 ? al[m] : (term == 1 || term == 3) ? am[m] : ah[m];
+              const wg_bf16x8& bw = (term == 0 || term == 3 || term == 5) ? bh[t] : (term == 1 || term == 4) ? bm[t] : bl[t];
+              acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bw, acc[m][t], 0, 0, 0);
+            }
+      }
+      return;
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e)
 #pragma unroll
@@ -933,8 +963,14 @@ bool make_plan_1x1(const DlioConvDesc& d, Wg1Plan& p) {
 template <int MR, int NT>
 int launch_1x1(const float* x, const float* dy, float* dw, float* wsp, const DlioConvDesc& d,
                const Wg1Plan& p, int accumulate, hipStream_t s) {
-  hipLaunchKernelGGL((wgrad1x1_direct_kernel<MR, NT>), dim3(p.co_tiles * p.ci_chunks * p.splits),
-                     dim3(256), 0, s, x, dy, wsp, d, p.co_tiles, p.ci_chunks, p.splits, p.segs);
+  // split-bf16 MFMAs where the fp32 MFMA time shows (64 x 64-channel tiles); narrow layers are HBM-bound
+  static const int bx3 = getenv("DLIO_WGRAD_1X1_BX3") ? atoi(getenv("DLIO_WGRAD_1X1_BX3")) : 1;
+  if (bx3 && MR == 2 && NT == 2)
+    hipLaunchKernelGGL((wgrad1x1_direct_kernel<MR, NT, true>), dim3(p.co_tiles * p.ci_chunks * p.splits),
+                       dim3(256), 0, s, x, dy, wsp, d, p.co_tiles, p.ci_chunks, p.splits, p.segs);
+  else
+    hipLaunchKernelGGL((wgrad1x1_direct_kernel<MR, NT>), dim3(p.co_tiles * p.ci_chunks * p.splits),
+                       dim3(256), 0, s, x, dy, wsp, d, p.co_tiles, p.ci_chunks, p.splits, p.segs);
   int rc = dlio_check_launch();
   if (rc) return rc;
   const int64_t n = (int64_t)d.Cout * d.Cin;
