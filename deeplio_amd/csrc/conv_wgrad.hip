@@ -965,7 +965,7 @@ int launch_1x1(const float* x, const float* dy, float* dw, float* wsp, const Dli
                const Wg1Plan& p, int accumulate, hipStream_t s) {
   // split-bf16 MFMAs where the fp32 MFMA time shows (64 x 64-channel tiles); narrow layers are HBM-bound
   static const int bx3 = getenv("DLIO_WGRAD_1X1_BX3") ? atoi(getenv("DLIO_WGRAD_1X1_BX3")) : 1;
-  if (bx3 && MR == 2 && NT == 2)
+  if (bx3 == 2 || (bx3 && MR == 2 && NT == 2))
     hipLaunchKernelGGL((wgrad1x1_direct_kernel<MR, NT, true>), dim3(p.co_tiles * p.ci_chunks * p.splits),
                        dim3(256), 0, s, x, dy, wsp, d, p.co_tiles, p.ci_chunks, p.splits, p.segs);
   else
