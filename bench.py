@@ -173,9 +173,12 @@ def main():
     ts.check()
     KINDS = (0, 1, 2, 3, 4, 5)
     prof_iso = None
-    DOM_KIND = 4                                 # without the isolated pass: the weight gradients
-    if not args.no_isolated:                     # every rank runs it: the steps contain the gradient all-reduce
-        set_overlap(ts.model, False)
+    DOM_KIND = 3                                 # without the isolated pass: the 3x3 forward + data gradient family
+    # N > 1: no pre-pass (the timed family is the N = 1 choice; every rank does the same work either way)
+    if not args.no_isolated and world == 1:
+        keep = os.environ.get("DLIO_BENCH_KEEP_OVERLAP", "0") != "0"       # debugging aid
+        if not keep:
+            set_overlap(ts.model, False)
         ops.prof_enable(True)
         ts.step(*batch)                          # creates the event pools
         torch.cuda.synchronize()
@@ -185,9 +188,9 @@ def main():
         torch.cuda.synchronize()
         ops.prof_enable(False)
         prof_iso = {k: ops.prof_collect(k) for k in KINDS}
-        set_overlap(ts.model, True)
+        if not keep:
+            set_overlap(ts.model, True)
         DOM_KIND = max(prof_iso, key=lambda k: prof_iso[k]["ms"])
-        DOM_KIND = int(sync.max_over_ranks(float(DOM_KIND)))     # one choice for all ranks
     prof_on = (1 << DOM_KIND) if os.environ.get("DLIO_BENCH_NOPROF", "0") == "0" else 0
     ops.prof_enable(prof_on)
     for _ in range(2):                           # back to the overlapped step; event pool of the chosen family
