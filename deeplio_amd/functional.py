@@ -296,6 +296,7 @@ def conv_dgrad(dy, weight, d, dx, dx_ctot, dx_coff, residual=None, r_ctot=0, r_c
 
 _CONV_BX3 = [os.environ.get("DLIO_CONV_BX3", "1") != "0"]
 _CONV_BX3_1X1 = [os.environ.get("DLIO_CONV_BX3_1X1", "1") != "0"]
+_BX3_1X1_MIN = [int(v) for v in os.environ.get("DLIO_BX3_1X1_MIN", "48,48,65536").split(",")]   # Cin, Cout, pixels
 
 
 def set_conv_bx3(on):
@@ -313,8 +314,8 @@ def _use_bx3(N, Cin, Cout, KH, KW, stride, OH, OW):
     # 1x1 (conv1x1_bx3_kernel): the layers that sit at the fp32-MFMA ridge -- at least 48 channels on
     # both sides and enough pixels to fill the chip (blk3: 1.17-1.36x, tools/bench_bx3_1x1.py); the
     # narrow and the small ones are HBM- or launch-bound on the fp32 kernels already
-    return ((KH, KW) == (1, 1) and _CONV_BX3_1X1[0] and Cin >= 48 and Cout >= 48 and N * OH * OW >= 65536
-            and (OH * OW) % 4 == 0)
+    return ((KH, KW) == (1, 1) and _CONV_BX3_1X1[0] and Cin >= _BX3_1X1_MIN[0] and Cout >= _BX3_1X1_MIN[1]
+            and N * OH * OW >= _BX3_1X1_MIN[2] and (OH * OW) % 4 == 0)
 
 
 _DGRAD_PHASES = [os.environ.get("DLIO_DGRAD_PHASES", "1") != "0"]
