@@ -31,6 +31,7 @@ _cd = C.POINTER(ConvDesc)
 # name -> (restype, argtypes); mirrors include/deeplio_hip.h one to one
 SIGNATURES = {
     "dlio_version": (_i, []),
+    "dlio_abi_hash": (C.c_uint32, []),
     "dlio_arch": (C.c_char_p, []),
     "dlio_strerror": (C.c_char_p, [_i]),
     "dlio_last_hip_error_string": (C.c_char_p, []),
@@ -95,6 +96,8 @@ SIGNATURES = {
                              _p]),
     "dlio_se3_chain_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "dlio_se3_chain_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "dlio_so3_project": (_i, [_p, _p, _p, _i, _p]),
+    "dlio_so3_project_bwd": (_i, [_p, _p, _p, _i, _p]),
     "dlio_pose_loss_fwd": (_i, [C.POINTER(_p), C.POINTER(_p), C.POINTER(C.c_int32), _p, _p, _f, _i,
                                _p, _p]),
     "dlio_pose_loss_bwd": (_i, [C.POINTER(_p), C.POINTER(_p), C.POINTER(C.c_int32), _p, _p, _f, _i,
@@ -112,6 +115,8 @@ SIGNATURES = {
     "dlio_velo_image": (_i, [_p, _p, _p, _p, _f, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "dlio_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i, _f, _p]),
     "dlio_sgd_step": (_i, [_p, _p, _p, _i64, _f, _f, _f, _i, _f, _p]),
+    "dlio_rmsprop_step": (_i, [_p, _p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p]),
+    "dlio_adadelta_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p]),
     "dlio_sumsq": (_i, [_p, _i64, _p, _p]),
 }
 
@@ -129,6 +134,13 @@ def _load():
             raise ImportError("deeplio_amd: symbol %s missing from %s" % (name, LIB_PATH)) from e
         fn.restype = res
         fn.argtypes = args
+    # a stale library (built from another revision of include/deeplio_hip.h) must not be called
+    # through this table: same symbol names do not mean same signatures
+    from ._header import abi_hash, abi_version
+    if lib.dlio_version() != abi_version() or lib.dlio_abi_hash() != abi_hash():
+        raise ImportError("deeplio_amd: %s was built from a different include/deeplio_hip.h (library ABI %d / "
+                          "%08x, header %d / %08x) -- rebuild with `python -m deeplio_amd.build`"
+                          % (LIB_PATH, lib.dlio_version(), lib.dlio_abi_hash(), abi_version(), abi_hash()))
     return lib
 
 

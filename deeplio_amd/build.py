@@ -38,9 +38,12 @@ def build(force=False, verbose=True):
         if force or _newer(src, obj, hdrs):
             jobs.append((src, obj))
 
+    from ._header import abi_hash
+    crc = "-DDLIO_HEADER_CRC=%du" % abi_hash()
+
     def cc(job):
         src, obj = job
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + [crc, "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))

@@ -7,7 +7,7 @@
 with `torch.save`; `nets/__init__.py:216-223` loads `['state_dict']`.  Module state_dict keys and
 shapes are the reference's already (deeplio_amd/nets.py), so model/criterion entries are
 interchangeable as they are.  The optimizer entry is converted between the flat-buffer optimizer
-and `torch.optim.Adam/SGD.state_dict()` ({'state': {i: {'step','exp_avg','exp_avg_sq'}},
+and `torch.optim.{Adam,SGD,RMSprop,Adadelta}.state_dict()` ({'state': {i: {'step','exp_avg','exp_avg_sq'}},
 'param_groups': [...]}), so a reference run can be resumed here and vice versa."""
 import os
 import shutil
@@ -24,29 +24,42 @@ def save_checkpoint(state, is_best, checkpoint_dir, filename="checkpoint"):
     return file_path
 
 
+def _torch_hyper(opt):
+    """the per-group hyper-parameters torch.optim would list for this optimizer class"""
+    kind = type(opt).__name__
+    if kind == 'Adam':
+        return dict(betas=tuple(opt.betas), eps=opt.eps, amsgrad=False)
+    if kind == 'SGD':
+        return dict(momentum=opt.momentum, dampening=0, nesterov=False)
+    if kind == 'RMSprop':
+        return dict(alpha=opt.alpha, eps=opt.eps, momentum=opt.momentum, centered=opt.centered)
+    if kind == 'Adadelta':
+        return dict(rho=opt.rho, eps=opt.eps)
+    return {}
+
+
 def optimizer_to_torch_state(opt):
-    """FlatOptimizer -> the dict torch.optim.{Adam,SGD}.state_dict() would hold"""
+    """FlatOptimizer -> the dict torch.optim.{Adam,SGD,RMSprop,Adadelta}.state_dict() would hold
+    (the flat state buffers carry torch's own state key names: exp_avg, exp_avg_sq,
+    momentum_buffer, square_avg, grad_avg, acc_delta)"""
     state, groups, idx = {}, [], 0
     index_of = {id(p): i for i, p in enumerate(opt.params)}
+    bufs = opt._state()
+    with_step = type(opt).__name__ != 'SGD'
     for g in opt.param_groups:
         ids = []
         for p in g['params']:
             i = index_of[id(p)]
             o = opt.offsets[i]
-            view = lambda buf: buf[o:o + p.numel()].view(p.shape).detach().clone()
-            if hasattr(opt, 'exp_avg'):
-                if opt.step_count > 0:
-                    state[idx] = {'step': torch.tensor(float(opt.step_count)), 'exp_avg': view(opt.exp_avg),
-                                  'exp_avg_sq': view(opt.exp_avg_sq)}
-            elif opt.step_count > 0:
-                state[idx] = {'momentum_buffer': view(opt.buf)}
+            if opt.step_count > 0:
+                st = {k: b[o:o + p.numel()].view(p.shape).detach().clone() for k, b in bufs.items()}
+                if with_step:
+                    st['step'] = torch.tensor(float(opt.step_count))
+                state[idx] = st
             ids.append(idx)
             idx += 1
         hyper = {k: v for k, v in g.items() if k != 'params'}
-        if hasattr(opt, 'exp_avg'):
-            hyper.update(betas=tuple(opt.betas), eps=opt.eps, amsgrad=False)
-        else:
-            hyper.update(momentum=opt.momentum, dampening=0, nesterov=False)
+        hyper.update(_torch_hyper(opt))
         hyper['params'] = ids
         groups.append(hyper)
     return {'state': state, 'param_groups': groups}
@@ -55,6 +68,7 @@ def optimizer_to_torch_state(opt):
 def optimizer_from_torch_state(opt, sd):
     """load a torch.optim state_dict (or one written by optimizer_to_torch_state)"""
     index_of = {id(p): i for i, p in enumerate(opt.params)}
+    bufs = opt._state()
     step = 0
     with torch.no_grad():
         for g, sg in zip(opt.param_groups, sd['param_groups']):
@@ -67,14 +81,12 @@ def optimizer_from_torch_state(opt, sd):
                     continue
                 i = index_of[id(p)]
                 o = opt.offsets[i]
-                dst = lambda buf: buf[o:o + p.numel()].view(p.shape)
-                if 'exp_avg' in st:
-                    dst(opt.exp_avg).copy_(st['exp_avg'])
-                    dst(opt.exp_avg_sq).copy_(st['exp_avg_sq'])
+                for k, b in bufs.items():
+                    if st.get(k) is not None:
+                        b[o:o + p.numel()].view(p.shape).copy_(st[k])
+                        step = max(step, 1)
+                if 'step' in st:
                     step = max(step, int(st['step']))
-                elif 'momentum_buffer' in st and st['momentum_buffer'] is not None:
-                    dst(opt.buf).copy_(st['momentum_buffer'])
-                    step = max(step, 1)
     if 'step_count' in sd:
         step = sd['step_count']
     opt.step_count = int(step)

@@ -2,8 +2,8 @@
 // of them the odometry LSTM): a single HBM-bound float4 sweep, 28 B per parameter for Adam
 // (read p,g,m,v; write p,m,v), instead of ~600 per-tensor launches.
 //
-// Replaces torch.optim.Adam / SGD as built by create_optimizer (optimizer.py:4-16; weight
-// decay is L2 added to the gradient) and calc_grad_norm (trainer.py:481-486).
+// Replaces torch.optim.Adam / SGD / RMSprop / Adadelta as built by create_optimizer
+// (optimizer.py:4-16; weight decay is L2 added to the gradient) and calc_grad_norm (trainer.py:481-486).
 #include "common.h"
 #include <math.h>
 
@@ -63,6 +63,52 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
   }
 }
 
+// torch.optim.RMSprop (alpha, eps, optional momentum / centered): one sweep, 20-28 B per parameter
+__global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                      float* __restrict__ sq, float* __restrict__ buf,
+                                                      float* __restrict__ gavg, int64_t n, float lr,
+                                                      float alpha, float eps, float wd, float momentum,
+                                                      float gscale) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float gg = g[i] * gscale + wd * p[i];
+    const float s = alpha * sq[i] + (1.f - alpha) * gg * gg;
+    sq[i] = s;
+    float avg;
+    if (gavg) {
+      const float ga = alpha * gavg[i] + (1.f - alpha) * gg;     // lerp as torch: ga + (g - ga)(1 - alpha)
+      gavg[i] = ga;
+      avg = sqrtf(s - ga * ga) + eps;
+    } else {
+      avg = sqrtf(s) + eps;
+    }
+    if (buf) {
+      const float b = momentum * buf[i] + gg / avg;
+      buf[i] = b;
+      p[i] -= lr * b;
+    } else {
+      p[i] -= lr * (gg / avg);
+    }
+  }
+}
+
+// torch.optim.Adadelta (rho, eps): 28 B per parameter
+__global__ __launch_bounds__(256) void adadelta_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ sq, float* __restrict__ acc,
+                                                       int64_t n, float lr, float rho, float eps, float wd,
+                                                       float gscale) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float gg = g[i] * gscale + wd * p[i];
+    const float s = rho * sq[i] + (1.f - rho) * gg * gg;
+    sq[i] = s;
+    const float a = acc[i];
+    const float delta = sqrtf(a + eps) / sqrtf(s + eps) * gg;
+    acc[i] = rho * a + (1.f - rho) * delta * delta;
+    p[i] -= lr * delta;
+  }
+}
+
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n,
                                                     double* out) {
   __shared__ double sm[16];
@@ -96,6 +142,26 @@ extern "C" int dlio_sgd_step(float* p, const float* g, float* buf, int64_t n, fl
   if (!p || !g || n <= 0 || step < 1 || (momentum != 0.f && !buf)) return DLIO_EINVAL;
   hipLaunchKernelGGL(sgd_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, as_stream(stream), p, g, buf,
                      n, lr, momentum, weight_decay, step == 1 ? 1 : 0, grad_scale);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_rmsprop_step(float* p, const float* g, float* square_avg, float* momentum_buf,
+                                 float* grad_avg, int64_t n, float lr, float alpha, float eps,
+                                 float weight_decay, float momentum, float grad_scale,
+                                 dlio_stream_t stream) {
+  if (!p || !g || !square_avg || n <= 0 || (momentum != 0.f && !momentum_buf)) return DLIO_EINVAL;
+  hipLaunchKernelGGL(rmsprop_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, as_stream(stream), p, g,
+                     square_avg, momentum != 0.f ? momentum_buf : nullptr, grad_avg, n, lr, alpha, eps,
+                     weight_decay, momentum, grad_scale);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_adadelta_step(float* p, const float* g, float* square_avg, float* acc_delta,
+                                  int64_t n, float lr, float rho, float eps, float weight_decay,
+                                  float grad_scale, dlio_stream_t stream) {
+  if (!p || !g || !square_avg || !acc_delta || n <= 0) return DLIO_EINVAL;
+  hipLaunchKernelGGL(adadelta_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, as_stream(stream), p, g,
+                     square_avg, acc_delta, n, lr, rho, eps, weight_decay, grad_scale);
   return dlio_check_launch();
 }
 

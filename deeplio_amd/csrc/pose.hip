@@ -132,6 +132,90 @@ __device__ __forceinline__ void rot_to_quat_bwd(const M3& R, const float* g, M3&
   }
 }
 
+// liegroups from_matrix(normalize=True) validity test (SO3.is_valid_matrix, tol 1e-6)
+__device__ __forceinline__ bool rot_is_valid(const M3& P) {
+  float worst = fabsf(det3(P) - 1.f);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float d = P.m[i] * P.m[j] + P.m[3 + i] * P.m[3 + j] + P.m[6 + i] * P.m[6 + j] -
+                      (i == j ? 1.f : 0.f);
+      worst = fmaxf(worst, fabsf(d));
+    }
+  return worst < 1e-6f;
+}
+
+// SO3.normalize (liegroups: U diag(1,1,det U det V) V^T of the SVD) without an SVD: the orthogonal
+// polar factor by Newton's iteration X <- (X + X^-T)/2, quadratically convergent -- from the 1e-6..1e-3
+// defects a product of fp32 rotations can have, four steps reach fp32 round-off.  For det > 0 (always
+// the case for a chain of exponentials) the polar factor IS U V^T.
+__device__ __forceinline__ M3 rot_project(const M3& P) {
+  M3 X = P;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const float c00 = X.m[4] * X.m[8] - X.m[5] * X.m[7], c01 = X.m[5] * X.m[6] - X.m[3] * X.m[8],
+                c02 = X.m[3] * X.m[7] - X.m[4] * X.m[6];
+    const float c10 = X.m[2] * X.m[7] - X.m[1] * X.m[8], c11 = X.m[0] * X.m[8] - X.m[2] * X.m[6],
+                c12 = X.m[1] * X.m[6] - X.m[0] * X.m[7];
+    const float c20 = X.m[1] * X.m[5] - X.m[2] * X.m[4], c21 = X.m[2] * X.m[3] - X.m[0] * X.m[5],
+                c22 = X.m[0] * X.m[4] - X.m[1] * X.m[3];
+    const float inv = 1.f / (X.m[0] * c00 + X.m[1] * c01 + X.m[2] * c02);
+    // X^-T = cofactor(X) / det
+    const float cof[9] = {c00, c01, c02, c10, c11, c12, c20, c21, c22};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) X.m[i] = 0.5f * (X.m[i] + cof[i] * inv);
+  }
+  return X;
+}
+
+// backward of the projection at a (nearly) orthogonal point: dQ = Q skew(Q^T dP), hence
+// dL/dP = Q skew(Q^T G), skew(A) = (A - A^T)/2 (exact on SO(3); the chain's defects are <= 1e-5)
+__device__ __forceinline__ void rot_project_bwd(const M3& Q, const M3& G, M3& dP) {
+  float A[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      A[i * 3 + j] = Q.m[i] * G.m[j] + Q.m[3 + i] * G.m[3 + j] + Q.m[6 + i] * G.m[6 + j];
+  float K[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) K[i * 3 + j] = 0.5f * (A[i * 3 + j] - A[j * 3 + i]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      dP.m[i * 3 + j] += Q.m[i * 3] * K[j] + Q.m[i * 3 + 1] * K[3 + j] + Q.m[i * 3 + 2] * K[6 + j];
+}
+
+__global__ void so3_project_kernel(const float* __restrict__ R, float* __restrict__ Q, int32_t* valid, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  M3 P;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) P.m[k] = R[(size_t)i * 9 + k];
+  const bool ok = rot_is_valid(P);
+  const M3 X = ok ? P : rot_project(P);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Q[(size_t)i * 9 + k] = X.m[k];
+  if (valid) valid[i] = ok ? 1 : 0;
+}
+
+__global__ void so3_project_bwd_kernel(const float* __restrict__ R, const float* __restrict__ G,
+                                       float* __restrict__ dR, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  M3 P, g, d;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { P.m[k] = R[(size_t)i * 9 + k]; g.m[k] = G[(size_t)i * 9 + k]; d.m[k] = 0.f; }
+  if (rot_is_valid(P)) d = g;
+  else rot_project_bwd(rot_project(P), g, d);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) dR[(size_t)i * 9 + k] = d.m[k];
+}
+
 __global__ void se3_chain_fwd_kernel(const float* __restrict__ t, const float* __restrict__ w,
                                      float* __restrict__ p, float* __restrict__ q,
                                      float* __restrict__ R_all, int32_t* status, int B, int S,
@@ -155,21 +239,16 @@ __global__ void se3_chain_fwd_kernel(const float* __restrict__ t, const float* _
     pp[0] = np[0]; pp[1] = np[1]; pp[2] = np[2];
     P = mat_mul(P, R);
     if (!close1(det3(P))) bad |= 1;
-    // liegroups from_matrix(normalize=True) validity test (tol 1e-6): flagged, not repaired
-    {
-      float worst = fabsf(det3(P) - 1.f);
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const float d = P.m[i] * P.m[j] + P.m[3 + i] * P.m[3 + j] + P.m[6 + i] * P.m[6 + j] -
-                          (i == j ? 1.f : 0.f);
-          worst = fmaxf(worst, fabsf(d));
-        }
-      if (!(worst < 1e-6f)) bad |= 2;
-    }
+    // SO3.from_matrix(P, normalize=True) (trainer.py:349): an invalid product is re-orthonormalised
+    // before the quaternion is taken (status bit 1 records that it happened); the chain itself goes
+    // on with the raw product, as in the reference
     float qq[4];
-    rot_to_quat(P, qq);
+    if (rot_is_valid(P)) {
+      rot_to_quat(P, qq);
+    } else {
+      bad |= 2;
+      rot_to_quat(rot_project(P), qq);
+    }
     float* qo = q + ((size_t)b * S + s) * 4;
     if (order == 0) { qo[0] = qq[0]; qo[1] = qq[1]; qo[2] = qq[2]; qo[3] = qq[3]; }
     else { qo[0] = qq[1]; qo[1] = qq[2]; qo[2] = qq[3]; qo[3] = qq[0]; }
@@ -211,7 +290,16 @@ __global__ void se3_chain_bwd_kernel(const float* __restrict__ t, const float* _
       if (order == 0) { g[0] = gq[0]; g[1] = gq[1]; g[2] = gq[2]; g[3] = gq[3]; }
       else { g[1] = gq[0]; g[2] = gq[1]; g[3] = gq[2]; g[0] = gq[3]; }
     }
-    rot_to_quat_bwd(Ps, g, dP);
+    if (rot_is_valid(Ps)) {
+      rot_to_quat_bwd(Ps, g, dP);
+    } else {
+      const M3 Qn = rot_project(Ps);
+      M3 Gq;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Gq.m[i] = 0.f;
+      rot_to_quat_bwd(Qn, g, Gq);
+      rot_project_bwd(Qn, Gq, dP);
+    }
     float gp[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) gp[i] = dpa[i] + (dp ? dp[o * 3 + i] : 0.f);
@@ -238,6 +326,80 @@ __global__ void se3_chain_bwd_kernel(const float* __restrict__ t, const float* _
   }
 }
 
+// ---- geodesic rotation terms (BASELINE configs[4]; no reference counterpart: the reference has
+// MSE on so(3) vectors / quaternion components only, losses/losses.py:71-85) -----------------------
+// theta(a, b) = 2 atan2(|a ^ b|, |<a, b>|) for two 4-vectors: the rotation angle between the
+// rotations two (unit) quaternions stand for, = 2 acos|<a,b>| = |log(Ra^T Rb)|, but conditioned at
+// every angle (acos near 1 loses half the digits), invariant to the sign and the scale of either
+// quaternion and to the component order (wxyz / xyzw).  |a ^ b|^2 = sum_{i<j} (a_i b_j - a_j b_i)^2.
+// Loss term = mean over rows of theta^2 (the squared geodesic distance; MSE's analogue).
+// Returns theta^2; g[i] = d(theta^2)/d a_i when g != nullptr.
+__device__ __forceinline__ float geo_theta2(const float* a, const float* b, float* g) {
+  float d = 0.f, n2 = 0.f, wb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) d += a[i] * b[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j == i) continue;
+      const float w = a[i] * b[j] - a[j] * b[i];
+      if (j > i) n2 += w * w;
+      wb[i] += w * b[j];                 // (a ^ b) . b : gradient of |a ^ b|^2 / 2 w.r.t. a
+    }
+  const float n = sqrtf(n2), c = fabsf(d);
+  const float half = atan2f(n, c);
+  if (g) {
+    const float den = n2 + c * c;
+    if (!(den > 0.f)) {
+      g[0] = g[1] = g[2] = g[3] = 0.f;
+    } else {
+      // d half = (c dn - n dc) / den ; dn = wb / n ; dc = sign(d) b ; half / n -> 1 / c as n -> 0
+      const float hn = n > 1e-6f * c ? half / n : 1.f / c;
+      const float A = 8.f * hn * c / den;
+      const float Bc = 8.f * half * n / den * (d < 0.f ? -1.f : 1.f);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) g[i] = A * wb[i] - Bc * b[i];
+    }
+  }
+  return 4.f * half * half;
+}
+
+// unit quaternion (w, x, y, z) of exp(phi^): (cos(|phi|/2), sin(|phi|/2) phi/|phi|)
+__device__ __forceinline__ void so3_to_quat(const float* phi, float* q) {
+  const float t2 = phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2];
+  const float t = sqrtf(t2);
+  float k;                               // sin(t/2)/t
+  if (t < 1e-3f) k = 0.5f - t2 * (1.f / 48.f);
+  else k = sinf(0.5f * t) / t;
+  q[0] = cosf(0.5f * t); q[1] = k * phi[0]; q[2] = k * phi[1]; q[3] = k * phi[2];
+}
+// g = dL/dq -> dphi
+__device__ __forceinline__ void so3_to_quat_bwd(const float* phi, const float* g, float* dphi) {
+  const float t2 = phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2];
+  const float t = sqrtf(t2);
+  float k, kp;                           // k = sin(t/2)/t ; kp = (dk/dt)/t
+  if (t < 1e-3f) { k = 0.5f - t2 * (1.f / 48.f); kp = -1.f / 24.f + t2 * (1.f / 960.f); }
+  else { const float sh = sinf(0.5f * t), ch = cosf(0.5f * t); k = sh / t; kp = (0.5f * ch * t - sh) / (t2 * t); }
+  const float gv = g[1] * phi[0] + g[2] * phi[1] + g[3] * phi[2];
+  // q_w = cos(t/2): dq_w/dphi = -k/2 phi ; q_v = k phi: dq_v/dphi = k I + kp phi phi^T
+#pragma unroll
+  for (int i = 0; i < 3; ++i) dphi[i] = -0.5f * k * g[0] * phi[i] + k * g[1 + i] + kp * gv * phi[i];
+}
+
+// mean over rows of theta^2; kind 1: rows of 3 (so(3) vectors), kind 3: rows of 4 (quaternions)
+__device__ __forceinline__ float geo_row(int kind, const float* pr, const float* gt, int r, float* grad) {
+  if (kind == 3) return geo_theta2(pr + (size_t)r * 4, gt + (size_t)r * 4, grad);
+  float qa[4], qb[4];
+  so3_to_quat(pr + (size_t)r * 3, qa);
+  so3_to_quat(gt + (size_t)r * 3, qb);
+  if (!grad) return geo_theta2(qa, qb, nullptr);
+  float gq[4];
+  const float v = geo_theta2(qa, qb, gq);
+  so3_to_quat_bwd(pr + (size_t)r * 3, gq, grad);
+  return v;
+}
+
 // ---- pose loss: single block ------------------------------------------------------
 struct LossArgs {
   const float* pred[4];
@@ -251,14 +413,22 @@ __global__ __launch_bounds__(256) void pose_loss_fwd_kernel(LossArgs a, const fl
                                                             float* out) {
   __shared__ double sm[16];
   __shared__ float mse[4];
+  const bool geo = (mode & 2) != 0;
+  mode &= 1;
   for (int i = 0; i < 4; ++i) {
     double s = 0.0;
-    for (int e = threadIdx.x; e < a.n[i]; e += 256) {
-      const float d = a.pred[i][e] - a.gt[i][e];
-      s += (double)d * d;
+    int cnt = a.n[i];
+    if (geo && (i == 1 || i == 3)) {
+      cnt = a.n[i] / (i == 1 ? 3 : 4);
+      for (int r = threadIdx.x; r < cnt; r += 256) s += (double)geo_row(i, a.pred[i], a.gt[i], r, nullptr);
+    } else {
+      for (int e = threadIdx.x; e < a.n[i]; e += 256) {
+        const float d = a.pred[i][e] - a.gt[i][e];
+        s += (double)d * d;
+      }
     }
     const double r = block_sum_d(s, sm);
-    if (threadIdx.x == 0) mse[i] = a.n[i] > 0 ? (float)(r / a.n[i]) : 0.f;
+    if (threadIdx.x == 0) mse[i] = cnt > 0 ? (float)(r / cnt) : 0.f;
     __syncthreads();
   }
   if (threadIdx.x == 0) {
@@ -275,11 +445,23 @@ __global__ __launch_bounds__(256) void pose_loss_bwd_kernel(LossArgs a, const fl
                                                             const float* out, const float* gscale,
                                                             float* dsx, float* dsq) {
   const float gs = gscale ? gscale[0] : 1.f;
+  const bool geo = (mode & 2) != 0;
+  mode &= 1;
   float cx, cq;
   if (mode == 0) { cx = expf(-sx[0]); cq = expf(-sq[0]); }
   else { cx = 1.f; cq = beta; }
   for (int i = 0; i < 4; ++i) {
     if (a.n[i] <= 0 || !a.dpred[i]) continue;
+    if (geo && (i == 1 || i == 3)) {
+      const int w = i == 1 ? 3 : 4, rows = a.n[i] / w;
+      const float coef = gs * cq / (float)rows;
+      for (int r = threadIdx.x; r < rows; r += 256) {
+        float g[4];
+        geo_row(i, a.pred[i], a.gt[i], r, g);
+        for (int k = 0; k < w; ++k) a.dpred[i][(size_t)r * w + k] = coef * g[k];
+      }
+      continue;
+    }
     const float coef = gs * ((i == 0 || i == 2) ? cx : cq) * 2.f / (float)a.n[i];
     for (int e = threadIdx.x; e < a.n[i]; e += 256) a.dpred[i][e] = coef * (a.pred[i][e] - a.gt[i][e]);
   }
@@ -310,6 +492,18 @@ extern "C" int dlio_se3_chain_bwd(const float* t, const float* w, const float* R
   return dlio_check_launch();
 }
 
+extern "C" int dlio_so3_project(const float* R, float* Q, int32_t* valid, int n, dlio_stream_t stream) {
+  if (!R || !Q || n <= 0) return DLIO_EINVAL;
+  hipLaunchKernelGGL(so3_project_kernel, dim3(cdiv(n, 64)), dim3(64), 0, as_stream(stream), R, Q, valid, n);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_so3_project_bwd(const float* R, const float* G, float* dR, int n, dlio_stream_t stream) {
+  if (!R || !G || !dR || n <= 0) return DLIO_EINVAL;
+  hipLaunchKernelGGL(so3_project_bwd_kernel, dim3(cdiv(n, 64)), dim3(64), 0, as_stream(stream), R, G, dR, n);
+  return dlio_check_launch();
+}
+
 static int fill_loss_args(LossArgs& a, const float* const* pred, const float* const* gt,
                           const int32_t* n, float* const* dpred) {
   for (int i = 0; i < 4; ++i) {
@@ -325,8 +519,9 @@ static int fill_loss_args(LossArgs& a, const float* const* pred, const float* co
 extern "C" int dlio_pose_loss_fwd(const float* const* pred, const float* const* gt,
                                   const int32_t* n, const float* sx, const float* sq, float beta,
                                   int mode, float* out, dlio_stream_t stream) {
-  if (!pred || !gt || !n || !out || (mode == 0 && (!sx || !sq)) || (mode != 0 && mode != 1))
+  if (!pred || !gt || !n || !out || ((mode & 1) == 0 && (!sx || !sq)) || mode < 0 || mode > 3)
     return DLIO_EINVAL;
+  if ((mode & 2) && (n[1] % 3 || n[3] % 4)) return DLIO_EINVAL;
   LossArgs a;
   int rc = fill_loss_args(a, pred, gt, n, nullptr);
   if (rc) return rc;
@@ -340,7 +535,9 @@ extern "C" int dlio_pose_loss_bwd(const float* const* pred, const float* const* 
                                   int mode, const float* out, const float* gscale,
                                   float* const* dpred, float* dsx, float* dsq,
                                   dlio_stream_t stream) {
-  if (!pred || !gt || !n || !out || !dpred || (mode == 0 && (!sx || !sq))) return DLIO_EINVAL;
+  if (!pred || !gt || !n || !out || !dpred || ((mode & 1) == 0 && (!sx || !sq)) || mode < 0 || mode > 3)
+    return DLIO_EINVAL;
+  if ((mode & 2) && (n[1] % 3 || n[3] % 4)) return DLIO_EINVAL;
   LossArgs a;
   int rc = fill_loss_args(a, pred, gt, n, dpred);
   if (rc) return rc;

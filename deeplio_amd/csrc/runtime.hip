@@ -73,7 +73,11 @@ extern "C" const char* dlio_last_hip_error_string(void) {
   return hipGetErrorString((hipError_t)dlio_last_hip_error);
 }
 
-extern "C" int dlio_version(void) { return 100; }
+extern "C" int dlio_version(void) { return DLIO_ABI_VERSION; }
+#ifndef DLIO_HEADER_CRC
+#define DLIO_HEADER_CRC 0u
+#endif
+extern "C" uint32_t dlio_abi_hash(void) { return (uint32_t)DLIO_HEADER_CRC; }
 int dlio_num_cus() {
   static int cached = 0;
   if (cached > 0) return cached;

@@ -486,6 +486,43 @@ class FireFn(Function):
                 g3[0], g3[1], g3[2], g3[3], None, None, None, None, None, None, None)
 
 
+class ConvAddFn(Function):
+    """addend + conv1x1(x) + bias: the 'complex' Fire bypass (pointseg_modules.py:110-112,136-138),
+    the sum is the residual operand of the convolution's epilogue"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, addend):
+        x, addend = x.contiguous(), addend.contiguous()
+        N, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        d = ops.conv_desc(N, Cin, H, W, Cout, 1, 1, 1, 1, 0, 0, res_ctot=Cout, res_coff=0)
+        y = _new((N, Cout, H, W), x)
+        ops.conv2d_fwd(x, ops.conv2d_prepped(weight, 0), bias, y, d, residual=addend)
+        d.wt2 = ops.conv2d_prepped(weight, 1)
+        ctx.save_for_backward(x, weight, bias)
+        ctx.d = d
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias = ctx.saved_tensors
+        d = ctx.d
+        dy = dy.contiguous()
+        N, Cout, HW = d.N, d.Cout, d.OH * d.OW
+        ret_b = None
+        if bias is not None:
+            db, acc_b, ret_b = _sink(bias, (Cout,), dy)
+            ops.chan_sum(dy, N, Cout, 0, Cout, HW, out=db, accumulate=acc_b)
+        dw, acc_w, ret_w = _sink(weight, weight.shape, dy)
+        dd = ops.conv_desc(N, d.Cin, d.H, d.W, Cout, 1, 1, 1, 1, 0, 0)
+        ops.conv2d_wgrad(x, dy, dw, dd, accumulate=acc_w)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            conv_dgrad(dy, weight, d, dx, d.Cin, 0)
+        return dx, ret_w, ret_b, dy
+
+
 # =============================================================================== pooling / SE
 class MaxPoolFn(Function):
     @staticmethod

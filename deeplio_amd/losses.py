@@ -9,12 +9,16 @@ from . import functional as Fh
 
 class _PoseLoss(nn.Module):
     mode = 0
+    # 'mse' = the reference's rotation terms (losses.py:71-85); 'geodesic' = squared rotation angle
+    # (BASELINE configs[4]; selected with cfg['losses']['rotation'] = 'geodesic')
+    rotation = 'mse'
 
     def forward(self, pred_f2f_x, pred_f2f_r, pred_f2g_x, pred_f2g_r, gt_f2f_x, gt_f2f_r, gt_f2g_x,
                 gt_f2g_q):
         sx = getattr(self, "sx", None)
         sq = getattr(self, "sq", None)
-        return Fh.PoseLossFn.apply(sx, sq, float(getattr(self, "beta", 0.)), self.mode,
+        mode = self.mode | (2 if self.rotation == 'geodesic' else 0)
+        return Fh.PoseLossFn.apply(sx, sq, float(getattr(self, "beta", 0.)), mode,
                                    bool(self.loss_Types[0]), bool(self.loss_Types[1]), pred_f2f_x,
                                    pred_f2f_r, pred_f2g_x, pred_f2g_r, gt_f2f_x, gt_f2f_r, gt_f2g_x,
                                    gt_f2g_q)
@@ -65,10 +69,16 @@ def get_loss_function(cfg, device):
         loss_types = [True, False]
     else:
         raise ValueError("Wrong loss type selected!")
+    rotation = str(loss_cfg.get('rotation', 'mse')).lower()
+    if rotation not in ('mse', 'geodesic'):
+        raise ValueError("Rotation loss {} is not supported!".format(rotation))
     if loss_name == 'hwsloss':
-        return HWSLoss(sx=params.get('sx', 0.), sq=params.get('sq', -2.5),
+        loss = HWSLoss(sx=params.get('sx', 0.), sq=params.get('sq', -2.5),
                        learn_hyper_params=params.get('learn', False), device=device,
                        loss_Types=loss_types)
-    if loss_name == 'lwsloss':
-        return LWSLoss(beta=params.get('beta', 1125.), loss_Types=loss_types)
-    raise ValueError("Loss {} is not supported!".format(loss_name))
+    elif loss_name == 'lwsloss':
+        loss = LWSLoss(beta=params.get('beta', 1125.), loss_Types=loss_types)
+    else:
+        raise ValueError("Loss {} is not supported!".format(loss_name))
+    loss.rotation = rotation
+    return loss

@@ -92,8 +92,11 @@ class Fire(nn.Module):
         self.expand3x3 = nn.Conv2d(squeeze_planes, expand3x3_planes, 3, padding=1)
         self.expand3x3_bn = nn.BatchNorm2d(expand3x3_planes, momentum=bn_d)
         same = inplanes == expand1x1_planes + expand3x3_planes
+        # pointseg_modules.py:108-112: 'complex' gives blocks whose width changes a 1x1 "upsample"
+        # convolution of the input as residual (and blocks whose width does not change NO residual,
+        # :135-140); 'simple' adds the input where the width allows
         if bypass == "complex" and not same:
-            raise ValueError("Fire bypass 'complex' (1x1 upsample) is not built by PSEncoder")
+            self.upsample = nn.Conv2d(inplanes, expand1x1_planes + expand3x3_planes, 1)
         self.residual = bypass == "simple" and same
 
     def forward(self, x, want_gap=False):
@@ -103,10 +106,15 @@ class Fire(nn.Module):
                                    self.expand3x3, self.expand3x3_bn)
         for b in (sb, e1b, e3b):
             _bump(b, tr)
-        return Fh.FireFn.apply(x, s.weight, s.bias, sb.weight, sb.bias, sb.running_mean, sb.running_var,
-                               e1.weight, e1.bias, e1b.weight, e1b.bias, e1b.running_mean, e1b.running_var,
-                               e3.weight, e3.bias, e3b.weight, e3b.bias, e3b.running_mean, e3b.running_var,
-                               tr, sb.momentum, sb.eps, self.residual, want_gap)
+        up = getattr(self, "upsample", None)
+        out = Fh.FireFn.apply(x, s.weight, s.bias, sb.weight, sb.bias, sb.running_mean, sb.running_var,
+                              e1.weight, e1.bias, e1b.weight, e1b.bias, e1b.running_mean, e1b.running_var,
+                              e3.weight, e3.bias, e3b.weight, e3b.bias, e3b.running_mean, e3b.running_var,
+                              tr, sb.momentum, sb.eps, self.residual, want_gap and up is None)
+        if up is None:
+            return out
+        out = Fh.ConvAddFn.apply(x, up.weight, up.bias, out)      # out + upsample(identity), :136-138
+        return (out, None) if want_gap else out                    # the SELayer takes its own averages
 
 
 class SELayer(nn.Module):

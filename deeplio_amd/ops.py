@@ -694,6 +694,8 @@ def gru_seq_bwd(dhs, dhs_off, lddhs, dhT, gates, hp, w_hh, dgx, dgh, dh0, T, B, 
 
 # ----------------------------------------------------------------------------- pose
 def se3_chain_fwd(t, w, order=0, status=None):
+    _chk(t)
+    _chk(w)
     B, S, _ = t.shape
     p = torch.empty(B, S, 3, dtype=torch.float32, device=t.device)
     q = torch.empty(B, S, 4, dtype=torch.float32, device=t.device)
@@ -710,6 +712,24 @@ def se3_chain_bwd(t, w, R, dp, dq, order=0):
     check(lib.dlio_se3_chain_bwd(_ptr(t), _ptr(w), _ptr(R), _ptr(dp), _ptr(dq), _ptr(dt), _ptr(dw),
                                  B, S, order, _stream()), "se3_chain_bwd")
     return dt, dw
+
+
+def so3_project(R):
+    """R [..., 3, 3] (or [..., 9]) -> (Q, valid): SO3.normalize of liegroups without an SVD"""
+    _chk(R)
+    n = R.numel() // 9
+    Q = torch.empty_like(R)
+    valid = torch.empty(n, dtype=torch.int32, device=R.device)
+    check(lib.dlio_so3_project(_ptr(R), _ptr(Q), _ptr(valid), n, _stream()), "so3_project")
+    return Q, valid
+
+
+def so3_project_bwd(R, G):
+    _chk(R)
+    _chk(G)
+    dR = torch.empty_like(R)
+    check(lib.dlio_so3_project_bwd(_ptr(R), _ptr(G), _ptr(dR), R.numel() // 9, _stream()), "so3_project_bwd")
+    return dR
 
 
 def _ptr_array(ts):
@@ -732,8 +752,8 @@ def pose_loss_bwd(preds, gts, sx, sq, beta, mode, out, gscale):
     n = (C.c_int32 * 4)(*[0 if p is None else p.numel() for p in preds])
     dpreds = [None if p is None else torch.empty_like(p) for p in preds]
     dev = out.device
-    dsx = torch.empty((), dtype=torch.float32, device=dev) if mode == 0 else None
-    dsq = torch.empty((), dtype=torch.float32, device=dev) if mode == 0 else None
+    dsx = torch.empty((), dtype=torch.float32, device=dev) if (mode & 1) == 0 else None
+    dsq = torch.empty((), dtype=torch.float32, device=dev) if (mode & 1) == 0 else None
     check(lib.dlio_pose_loss_bwd(_ptr_array(preds), _ptr_array(gts), n, _ptr(sx), _ptr(sq),
                                  float(beta), mode, _ptr(out), _ptr(gscale), _ptr_array(dpreds),
                                  _ptr(dsx), _ptr(dsq), _stream()), "pose_loss_bwd")
@@ -836,6 +856,20 @@ def sgd_step(p, g, buf, lr, momentum, wd, step, grad_scale=1.0):
     weights_changed()
     check(lib.dlio_sgd_step(_ptr(p), _ptr(g), _ptr(buf), p.numel(), float(lr), float(momentum),
                             float(wd), int(step), float(grad_scale), _stream()), "sgd_step")
+
+
+def rmsprop_step(p, g, square_avg, buf, grad_avg, lr, alpha, eps, wd, momentum, grad_scale=1.0):
+    weights_changed()
+    check(lib.dlio_rmsprop_step(_ptr(p), _ptr(g), _ptr(square_avg), _ptr(buf), _ptr(grad_avg), p.numel(),
+                                float(lr), float(alpha), float(eps), float(wd), float(momentum),
+                                float(grad_scale), _stream()), "rmsprop_step")
+
+
+def adadelta_step(p, g, square_avg, acc_delta, lr, rho, eps, wd, grad_scale=1.0):
+    weights_changed()
+    check(lib.dlio_adadelta_step(_ptr(p), _ptr(g), _ptr(square_avg), _ptr(acc_delta), p.numel(), float(lr),
+                                 float(rho), float(eps), float(wd), float(grad_scale), _stream()),
+          "adadelta_step")
 
 
 def sumsq(g):

@@ -63,6 +63,9 @@ class FlatOptimizer:
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
 
     def _hyper(self):
+        """one (lr, weight decay) for the whole flat buffer: the reference builds every optimizer with
+        a single lr / weight decay for its two groups (trainer.py:56-58); per-group values would need
+        one launch per group and are rejected instead of silently merged"""
         g0 = self.param_groups[0]
         for g in self.param_groups[1:]:
             if g['lr'] != g0['lr'] or g['weight_decay'] != g0['weight_decay']:
@@ -123,13 +126,62 @@ class SGD(FlatOptimizer):
                      self.grad_scale)
 
 
+class RMSprop(FlatOptimizer):
+    """torch.optim.RMSprop (optimizer.py:12-13) over the flat buffers"""
+
+    def __init__(self, params, lr=1e-2, alpha=0.99, eps=1e-8, weight_decay=0., momentum=0., centered=False):
+        super().__init__(params, lr, weight_decay)
+        self.alpha, self.eps, self.momentum, self.centered = alpha, eps, momentum, centered
+        self.square_avg = torch.zeros_like(self.flat)
+        self.buf = torch.zeros_like(self.flat) if momentum != 0. else None
+        self.grad_avg = torch.zeros_like(self.flat) if centered else None
+
+    def _state(self):
+        st = {'square_avg': self.square_avg}
+        if self.buf is not None:
+            st['momentum_buffer'] = self.buf
+        if self.grad_avg is not None:
+            st['grad_avg'] = self.grad_avg
+        return st
+
+    @torch.no_grad()
+    def step(self):
+        _join()
+        lr, wd = self._hyper()
+        self.step_count += 1
+        ops.rmsprop_step(self.flat, self.grad, self.square_avg, self.buf, self.grad_avg, lr, self.alpha,
+                         self.eps, wd, self.momentum, self.grad_scale)
+
+
+class Adadelta(FlatOptimizer):
+    """torch.optim.Adadelta (optimizer.py:14-15) over the flat buffers"""
+
+    def __init__(self, params, lr=1.0, rho=0.9, eps=1e-6, weight_decay=0.):
+        super().__init__(params, lr, weight_decay)
+        self.rho, self.eps = rho, eps
+        self.square_avg = torch.zeros_like(self.flat)
+        self.acc_delta = torch.zeros_like(self.flat)
+
+    def _state(self):
+        return {'square_avg': self.square_avg, 'acc_delta': self.acc_delta}
+
+    @torch.no_grad()
+    def step(self):
+        _join()
+        lr, wd = self._hyper()
+        self.step_count += 1
+        ops.adadelta_step(self.flat, self.grad, self.square_avg, self.acc_delta, lr, self.rho, self.eps, wd,
+                          self.grad_scale)
+
+
 def create_optimizer(params, cfg, args, **kwargs):
     optim_type = cfg['optimizer'].lower()
     if optim_type == 'sgd':
         return SGD(params, lr=args.lr, weight_decay=args.weight_decay, momentum=args.momentum, **kwargs)
     if optim_type == 'adam':
         return Adam(params, lr=args.lr, weight_decay=args.weight_decay, **kwargs)
-    if optim_type in ('rmsprop', 'adadelta'):
-        raise ValueError("Optimizer {} has no HIP kernel in this build (adam and sgd are on the "
-                         "hot path)".format(optim_type))
+    if optim_type == 'rmsprop':
+        return RMSprop(params, lr=args.lr, weight_decay=args.weight_decay, **kwargs)
+    if optim_type == 'adadelta':
+        return Adadelta(params, lr=args.lr, weight_decay=args.weight_decay, **kwargs)
     raise ValueError("Optimizer {} not supported!".format(optim_type))

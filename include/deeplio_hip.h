@@ -36,8 +36,15 @@ extern "C" {
 
 typedef void* dlio_stream_t;
 
-/* ---- library info ---------------------------------------------------- */
+/* ---- library info ----------------------------------------------------
+ * DLIO_ABI_VERSION is bumped whenever a prototype changes; dlio_version() returns the value the
+ * library was built with and dlio_abi_hash() the CRC-32 of the comment-stripped text of THIS header
+ * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
+ * compares both against the header next to it when it loads the library, so a stale .so fails at
+ * import instead of being called with a changed signature. */
+#define DLIO_ABI_VERSION 200
 int dlio_version(void);
+uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);           /* "gfx950" */
 const char* dlio_strerror(int code);
 /* hipGetErrorString of the HIP error behind the last DLIO_ELAUNCH in this thread */
@@ -318,18 +325,29 @@ int dlio_gru_seq_bwd(const float* dhs, int lddhs, const float* dhT, const float*
 /* ---- pose chain + loss --------------------------------------------------
  * Trainer.se3_to_SE3 (trainer.py:324-351): per batch element chain
  * R_s = R_{s-1} exp(w_s), t_s = R_{s-1} t + t_{s-1}; q_s = quat_wxyz(R_s)
- * (tester.py:223-251 variant: order=1 -> xyzw).  status[0] is set to 1 when a
- * determinant check (|det-1| > 1e-5+1e-8) fails, mirroring the ValueError.
+ * (tester.py:223-251 variant: order=1 -> xyzw).  status[0] bit 0 is set when a
+ * determinant check (|det-1| > 1e-5+1e-8) fails, mirroring the ValueError; bit 1 when a
+ * product failed liegroups' validity test (tol 1e-6) and the quaternion was taken from its
+ * re-orthonormalisation, as SO3.from_matrix(normalize=True) does (trainer.py:349).
  * R_all [B][S][9] is saved for backward. */
 int dlio_se3_chain_fwd(const float* t, const float* w, float* p, float* q, float* R_all,
                        int32_t* status, int B, int S, int order, dlio_stream_t stream);
 int dlio_se3_chain_bwd(const float* t, const float* w, const float* R_all, const float* dp,
                        const float* dq, float* dt, float* dw, int B, int S, int order,
                        dlio_stream_t stream);
+/* SO3.normalize of liegroups (the SVD projection behind from_matrix(normalize=True),
+ * trainer.py:349) as an SVD-free Newton polar iteration, for n 3x3 matrices: Q = R when R passes
+ * the validity test (valid[i] = 1, nullable), else its orthogonal polar factor.  _bwd: dR from
+ * G = dL/dQ (first order in the defect of R, which is <= 1e-5 for a chain of exponentials). */
+int dlio_so3_project(const float* R, float* Q, int32_t* valid, int n, dlio_stream_t stream);
+int dlio_so3_project_bwd(const float* R, const float* G, float* dR, int n, dlio_stream_t stream);
 /* HWSLoss / LWSLoss (losses/losses.py:21-39, 68-86).  Eight [B][S*][D] inputs
  * are passed as 4 (pred, gt) pairs with element counts n[4] (0 = term off).
- * mode 0: HWS with sx,sq;  mode 1: LWS with beta.  out: loss[0], mse[1..4].
- * Order of pairs: f2f_t, f2f_w, f2g_p, f2g_q. */
+ * mode bit 0: 0 = HWS with sx,sq; 1 = LWS with beta.  mode bit 1 (BASELINE configs[4], no
+ * reference counterpart): the two rotation terms are geodesic instead of MSE --
+ * L_w = mean_rows theta(exp(w_pred), exp(w_gt))^2, L_q = mean_rows theta(q_pred, q_gt)^2 with
+ * theta = 2 atan2(|a ^ b|, |<a,b>|) (= 2 acos|<a,b>| for unit quaternions = |log(Ra^T Rb)|).
+ * out: loss[0], the four terms [1..4].  Order of pairs: f2f_t, f2f_w, f2g_p, f2g_q. */
 int dlio_pose_loss_fwd(const float* const* pred, const float* const* gt, const int32_t* n,
                        const float* sx, const float* sq, float beta, int mode, float* out,
                        dlio_stream_t stream);
@@ -413,7 +431,7 @@ int dlio_velo_image(const float* proj_xyz, const float* proj_remission, const fl
                     float* out, dlio_stream_t stream);
 
 /* ---- optimizer ----------------------------------------------------------
- * torch.optim.Adam / SGD(momentum) as built by create_optimizer
+ * torch.optim.Adam / SGD(momentum) / RMSprop / Adadelta as built by create_optimizer
  * (optimizer.py:4-16) over ONE flat parameter buffer: weight decay is L2 added
  * to the gradient.  step is the 1-based step count. grad_scale multiplies g
  * first (data-parallel averaging). */
@@ -422,6 +440,18 @@ int dlio_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
                    float grad_scale, dlio_stream_t stream);
 int dlio_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, float momentum,
                   float weight_decay, int step, float grad_scale, dlio_stream_t stream);
+/* torch.optim.RMSprop (optimizer.py:12-13): square_avg = alpha*square_avg + (1-alpha) g^2;
+ * centered (grad_avg != NULL): avg = sqrt(square_avg - grad_avg^2) + eps; momentum != 0
+ * (momentum_buf != NULL): buf = momentum*buf + g/avg, p -= lr*buf; else p -= lr*g/avg. */
+int dlio_rmsprop_step(float* p, const float* g, float* square_avg, float* momentum_buf,
+                      float* grad_avg, int64_t n, float lr, float alpha, float eps,
+                      float weight_decay, float momentum, float grad_scale, dlio_stream_t stream);
+/* torch.optim.Adadelta (optimizer.py:14-15): square_avg = rho*square_avg + (1-rho) g^2;
+ * delta = sqrt(acc_delta+eps)/sqrt(square_avg+eps) * g; acc_delta = rho*acc_delta + (1-rho) delta^2;
+ * p -= lr*delta. */
+int dlio_adadelta_step(float* p, const float* g, float* square_avg, float* acc_delta, int64_t n,
+                       float lr, float rho, float eps, float weight_decay, float grad_scale,
+                       dlio_stream_t stream);
 /* out[0] = sum g^2 (fp64) -- calc_grad_norm, trainer.py:481-486 */
 int dlio_sumsq(const float* g, int64_t n, double* out, dlio_stream_t stream);
 

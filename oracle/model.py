@@ -548,8 +548,44 @@ def get_model(input_shape, cfg, device="cpu"):
 
 
 # ------------------------------------------------------------------------------ losses / optimizer
+def geodesic_theta2(a, b):
+    """Squared rotation angle between the rotations two quaternions [..., 4] stand for:
+    theta = 2 atan2(|a ^ b|, |<a, b>|) (= 2 acos|<a, b>| for unit quaternions = |log(Ra^T Rb)|),
+    invariant to sign, scale and component order.  No reference counterpart (the reference's
+    rotation terms are MSE, losses/losses.py:71-85): this restates the definition in
+    include/deeplio_hip.h (dlio_pose_loss_fwd, mode bit 1) for BASELINE configs[4]."""
+    d = (a * b).sum(-1)
+    n2 = 0.
+    for i in range(4):
+        for j in range(i + 1, 4):
+            n2 = n2 + (a[..., i] * b[..., j] - a[..., j] * b[..., i]) ** 2
+    # sqrt'(0) is infinite: keep autograd finite at identical rotations (the limit gradient is 0)
+    n = torch.sqrt(n2.clamp_min(1e-300 if a.dtype == torch.float64 else 1e-36))
+    return (2. * torch.atan2(n, d.abs())) ** 2
+
+
+def so3_to_quat(phi):
+    """unit quaternion (w, x, y, z) of exp(phi^), phi [..., 3]"""
+    t = phi.norm(dim=-1, keepdim=True)
+    small = t < 1e-3
+    ts = torch.where(small, torch.ones_like(t), t)
+    k = torch.where(small, 0.5 - t * t / 48., torch.sin(0.5 * ts) / ts)
+    return torch.cat([torch.cos(0.5 * t), k * phi], -1)
+
+
+def _rot_terms(rotation, pw, gw, pq, gq, use_local, use_global):
+    if rotation == 'geodesic':
+        Lw = geodesic_theta2(so3_to_quat(pw), so3_to_quat(gw)).mean() if use_local else 0.
+        Lq = geodesic_theta2(pq, gq).mean() if use_global else 0.
+    else:
+        Lw = F.mse_loss(pw, gw) if use_local else 0.
+        Lq = F.mse_loss(pq, gq) if use_global else 0.
+    return Lw, Lq
+
+
 class HWSLoss(nn.Module):
     """losses/losses.py:51-86."""
+    rotation = 'mse'
 
     def __init__(self, sx=0., sq=-2.5, learn=True, loss_Types=(True, True)):
         super().__init__()
@@ -559,14 +595,14 @@ class HWSLoss(nn.Module):
 
     def forward(self, pt, pw, pp, pq, gt, gw, gp, gq):
         Lt = F.mse_loss(pt, gt) if self.loss_Types[0] else 0.
-        Lw = F.mse_loss(pw, gw) if self.loss_Types[0] else 0.
         Lp = F.mse_loss(pp, gp) if self.loss_Types[1] else 0.
-        Lq = F.mse_loss(pq, gq) if self.loss_Types[1] else 0.
+        Lw, Lq = _rot_terms(self.rotation, pw, gw, pq, gq, self.loss_Types[0], self.loss_Types[1])
         return (Lp + Lt) * torch.exp(-self.sx) + self.sx + (Lq + Lw) * torch.exp(-self.sq) + self.sq
 
 
 class LWSLoss(nn.Module):
     """losses/losses.py:11-39."""
+    rotation = 'mse'
 
     def __init__(self, beta=1125., loss_Types=(True, True)):
         super().__init__()
@@ -575,9 +611,8 @@ class LWSLoss(nn.Module):
 
     def forward(self, pt, pw, pp, pq, gt, gw, gp, gq):
         Lt = F.mse_loss(pt, gt) if self.loss_Types[0] else 0.
-        Lw = F.mse_loss(pw, gw) if self.loss_Types[0] else 0.
         Lp = F.mse_loss(pp, gp) if self.loss_Types[1] else 0.
-        Lq = F.mse_loss(pq, gq) if self.loss_Types[1] else 0.
+        Lw, Lq = _rot_terms(self.rotation, pw, gw, pq, gq, self.loss_Types[0], self.loss_Types[1])
         return (Lp + Lt) + self.beta * (Lq + Lw)
 
 
@@ -596,10 +631,13 @@ def get_loss_function(cfg, device="cpu"):
     else:
         raise ValueError("Wrong loss type selected!")
     if name == 'hwsloss':
-        return HWSLoss(params.get('sx', 0.), params.get('sq', -2.5), params.get('learn', False), types).to(device)
-    if name == 'lwsloss':
-        return LWSLoss(params.get('beta', 1125.), types).to(device)
-    raise ValueError("Loss {} is not supported!".format(name))
+        loss = HWSLoss(params.get('sx', 0.), params.get('sq', -2.5), params.get('learn', False), types).to(device)
+    elif name == 'lwsloss':
+        loss = LWSLoss(params.get('beta', 1125.), types).to(device)
+    else:
+        raise ValueError("Loss {} is not supported!".format(name))
+    loss.rotation = str(lc.get('rotation', 'mse')).lower()      # 'geodesic': BASELINE configs[4]
+    return loss
 
 
 def create_optimizer(params, cfg, lr, weight_decay, momentum=0.9):

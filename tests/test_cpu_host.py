@@ -144,14 +144,158 @@ def test_polynomial_lr_decay_matches_reference_table():
     assert np.allclose(lrs, gold['lr_table'], rtol=1e-6)
 
 
-def test_install_as_deeplio_aliases():
-    import deeplio_amd
-    deeplio_amd.install_as_deeplio()
-    from deeplio.models import nets as rn
-    from deeplio import losses as rl
-    assert rn.get_model is deeplio_amd.nets.get_model and rl.get_loss_function is deeplio_amd.losses.get_loss_function
-    for k in [k for k in sys.modules if k == "deeplio" or k.startswith("deeplio.")]:
-        del sys.modules[k]
+def _run_py(code, cwd):
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(HERE, "golden")]))
+    return subprocess.run([sys.executable, "-c", code], cwd=str(cwd), env=env, capture_output=True, text=True,
+                          timeout=600)
+
+
+def test_install_as_deeplio_without_a_reference_checkout(tmp_path):
+    """no `deeplio` on sys.path: the four hot-path names resolve to this package"""
+    code = r"""
+import sys
+import deeplio_amd
+done = deeplio_amd.install_as_deeplio()
+from deeplio.models import nets as rn
+from deeplio import losses as rl
+from deeplio.models.misc import build_config_container, PolynomialLRDecay, DataCombiCreater
+from deeplio.models.optimizer import create_optimizer
+assert rn.get_model is deeplio_amd.nets.get_model and rl.get_loss_function is deeplio_amd.losses.get_loss_function
+assert create_optimizer is deeplio_amd.optimizer.create_optimizer
+print("OK", sorted(done))
+"""
+    r = _run_py(code, tmp_path)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+FAKE_TREE = {       # a stand-in checkout with the reference's import STRUCTURE (train.py:8-13, trainer.py:17-23,
+    # worker.py:12-13, tester.py) -- written for this test, nothing of the reference's code
+    "deeplio/__init__.py": "",
+    "deeplio/common/__init__.py": "LOGGER = 'reference logger'\n",
+    "deeplio/datasets/__init__.py": "class Kitti:\n    origin = 'reference dataset'\n",
+    "deeplio/losses/__init__.py": "def get_loss_function(cfg, device):\n    raise RuntimeError('reference loss')\n"
+                                  "HWSLoss = LWSLoss = object\n",
+    "deeplio/models/__init__.py": "",
+    "deeplio/models/nets/__init__.py": "def get_model(input_shape, cfg, device):\n    raise RuntimeError('reference nets')\n",
+    "deeplio/models/misc.py": "def build_config_container(cfg, args):\n    raise RuntimeError('reference misc')\n"
+                              "DataCombiCreater = PolynomialLRDecay = object\n",
+    "deeplio/models/optimizer.py": "def create_optimizer(params, cfg, args):\n    raise RuntimeError('reference optimizer')\n",
+    "deeplio/models/worker.py": "from deeplio.common import *\nfrom .misc import build_config_container\n"
+                                "class Worker:\n    def __init__(self, args, cfg):\n"
+                                "        self.cc = build_config_container(cfg, args)\n",
+    "deeplio/models/trainer.py": "from deeplio import datasets as ds\nfrom deeplio.common import LOGGER\n"
+                                 "from deeplio.losses import get_loss_function, HWSLoss, LWSLoss\n"
+                                 "from deeplio.models import nets\n"
+                                 "from deeplio.models.misc import DataCombiCreater, PolynomialLRDecay\n"
+                                 "from .optimizer import create_optimizer\nfrom .worker import Worker\n"
+                                 "class Trainer(Worker):\n"
+                                 "    def __init__(self, args, cfg, shape):\n"
+                                 "        super().__init__(args, cfg)\n"
+                                 "        self.model = nets.get_model(input_shape=shape, cfg=cfg, device=self.cc.device)\n"
+                                 "        self.criterion = get_loss_function(cfg, args.device)\n"
+                                 "        self.dataset = ds.Kitti()\n"
+                                 "    def se3_to_SE3(self, x, r):\n        raise RuntimeError('reference se3')\n"
+                                 "class TrainerDeepLIO(Trainer):\n    pass\n",
+    "deeplio/train.py": "import os, sys\n"
+                        "dname = os.path.abspath(os.path.dirname(__file__))\n"
+                        "sys.path.append(dname)\nsys.path.append(os.path.abspath(dname + '/..'))\n"
+                        "from deeplio.models.trainer import TrainerDeepLIO\n"
+                        "if __name__ == '__main__':\n"
+                        "    import types, json\n"
+                        "    sys.path.insert(0, os.environ['GOLDEN_DIR'])\n"
+                        "    import golden_common as gc\n"
+                        "    cfg = gc.case_cfg('pointseg_lstm_cat')\n"
+                        "    args = types.SimpleNamespace(device='cpu', batch_size=2, flags=sys.argv[1:])\n"
+                        "    t = TrainerDeepLIO(args, cfg, (5, 16, 64))\n"
+                        "    print('TRAINER', type(t.model).__module__, type(t.criterion).__module__, t.dataset.origin,\n"
+                        "          'fc_pos.weight' in t.model.state_dict(), args.flags)\n",
+}
+
+
+def _write_tree(root, tree):
+    for rel, text in tree.items():
+        f = root / rel
+        f.parent.mkdir(parents=True, exist_ok=True)
+        f.write_text(text)
+
+
+def test_run_reference_overlays_an_unmodified_entry_point(tmp_path):
+    """python -m deeplio_amd.run_reference <checkout>/deeplio/train.py <flags>: the script's own
+    `from deeplio.models.trainer import TrainerDeepLIO` (train.py:13) resolves to the CHECKOUT's
+    trainer, whose nets / losses / misc / optimizer are this package; datasets / common stay the
+    checkout's.  Uses a stand-in checkout with the reference's import structure (the reference's
+    real worker layer needs KITTI on disk)."""
+    _write_tree(tmp_path, FAKE_TREE)
+    env = dict(os.environ, PYTHONPATH=ROOT, GOLDEN_DIR=os.path.join(HERE, "golden"))
+    r = subprocess.run([sys.executable, "-m", "deeplio_amd.run_reference", str(tmp_path / "deeplio" / "train.py"),
+                        "-b", "8", "--device", "cuda"], cwd=str(tmp_path), env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("TRAINER")][0]
+    assert "deeplio_amd.nets deeplio_amd.losses reference dataset True" in line and "'-b', '8'" in line, line
+    # the order train.py itself would produce when a maintainer adds the two lines at its top:
+    # install AFTER the worker layer was imported rebinds the module-level names as well
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+import deeplio.models.trainer as tr
+import deeplio_amd
+done = deeplio_amd.install_as_deeplio()
+assert tr.nets is deeplio_amd.nets and tr.create_optimizer is deeplio_amd.optimizer.create_optimizer
+assert tr.get_loss_function is deeplio_amd.losses.get_loss_function
+import deeplio.models.worker as wk
+assert wk.build_config_container is deeplio_amd.misc.build_config_container
+import deeplio.datasets as ds
+assert ds.Kitti.origin == 'reference dataset'
+print("OK", done)
+""" % str(tmp_path)
+    r = _run_py(code, tmp_path)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/deeplio"), reason="needs the reference checkout (build container)")
+def test_install_as_deeplio_overlays_the_real_reference(tmp_path):
+    """With the REAL reference on sys.path (third-party imports it lacks here stubbed as in
+    make_golden.install_stubs): after the install the reference's own `deeplio.models.trainer`
+    imports (train.py:13), its `nets` / `get_loss_function` / `create_optimizer` are this package, the
+    model is constructed through the very call of trainer.py:52 (`nets.get_model(input_shape=..., cfg=...,
+    device=...)` after worker.py:41's `build_config_container`), `Trainer.se3_to_SE3` is the HIP chain,
+    and `deeplio.datasets` / `deeplio.common` / `deeplio.models.tester` are still the reference's."""
+    code = r"""
+import os, sys, types
+import make_golden as mg
+mg.install_stubs()
+sys.path.insert(0, mg.REF)
+import deeplio_amd
+done = deeplio_amd.install_as_deeplio()
+from deeplio.models.trainer import TrainerDeepLIO            # train.py:13, unmodified
+import deeplio.models.trainer as tr, deeplio.models.worker as wk, deeplio.models.tester as te
+import deeplio.datasets as ds, deeplio.common.spatial as sp
+for m in (tr, wk, te, ds, sp):
+    assert m.__file__.startswith(mg.REF), m.__file__
+assert tr.nets is deeplio_amd.nets and tr.get_loss_function is deeplio_amd.losses.get_loss_function
+assert tr.create_optimizer is deeplio_amd.optimizer.create_optimizer
+assert tr.PolynomialLRDecay is deeplio_amd.misc.PolynomialLRDecay and tr.DataCombiCreater is deeplio_amd.misc.DataCombiCreater
+assert wk.build_config_container is deeplio_amd.misc.build_config_container
+import golden_common as gc
+cfg = gc.case_cfg('pointseg_lstm_cat')
+args = types.SimpleNamespace(device='cpu', batch_size=2)
+cc = wk.build_config_container(cfg, args)                     # worker.py:41
+model = tr.nets.get_model(input_shape=(5, 16, 64), cfg=cfg, device=cc.device)      # trainer.py:52
+crit = tr.get_loss_function(cfg, args.device)                 # trainer.py:55
+assert type(model).__module__ == 'deeplio_amd.nets' and type(crit).__module__ == 'deeplio_amd.losses'
+assert model.name == 'deeplio' and 'lidar_feat_net.encoder1.fire_blk1.0.squeeze_bn.running_mean' in model.state_dict()
+import torch
+try:
+    tr.Trainer.se3_to_SE3(types.SimpleNamespace(device='cpu'), torch.zeros(1, 2, 3), torch.zeros(1, 2, 3))
+    raise SystemExit("the patched se3_to_SE3 should refuse CPU tensors")
+except RuntimeError as e:
+    assert "no CPU fallback" in str(e), e
+print("OK", done)
+"""
+    r = _run_py(code, tmp_path)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+    assert "deeplio.models.trainer" in r.stdout and "deeplio.models.tester" in r.stdout
 
 
 DP_WORKER = r'''
@@ -198,3 +342,43 @@ def test_data_parallel_exchange_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "rank 0 ok" in outs[0] and "rank 1 ok" in outs[1]
+
+
+def test_stale_library_is_rejected_at_import(tmp_path):
+    """_lib._load() compares the library's ABI version / header CRC with include/deeplio_hip.h: a
+    library built from another revision of the header must fail at import, not at a call"""
+    from deeplio_amd import _header, _lib
+    assert _lib.lib.dlio_version() == _header.abi_version() and _lib.lib.dlio_abi_hash() == _header.abi_hash()
+    hdr = tmp_path / "deeplio_hip.h"
+    hdr.write_text(open(_header.HEADER).read().replace("int dlio_version(void);", "long dlio_version(void);"))
+    assert _header.abi_hash(str(hdr)) != _header.abi_hash()
+    code = ("import deeplio_amd._header as h; h.abi_hash = lambda path=None: 12345\n"
+            "try:\n    import deeplio_amd._lib\nexcept ImportError as e:\n    print('REJECTED', e)\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+    assert "REJECTED" in r.stdout and "different include/deeplio_hip.h" in r.stdout, r.stdout + r.stderr
+
+
+def test_oracle_geodesic_rotation_terms_known_answers():
+    """the geodesic rotation terms (BASELINE configs[4]; definition in include/deeplio_hip.h): angle
+    between rotations about one axis = difference of the angles; invariant to quaternion sign, scale
+    and component order; equals |log(Ra^T Rb)| of the SO(3) restatement"""
+    from oracle import model as om
+    from oracle import se3
+    z = torch.tensor([0., 0., 1.], dtype=torch.float64)
+    for a, b in ((0.3, 0.0), (0.3, -0.5), (3.0, 0.1), (1e-6, 0.)):
+        qa, qb = om.so3_to_quat(a * z), om.so3_to_quat(b * z)
+        assert abs(float(om.geodesic_theta2(qa, qb)) - (a - b) ** 2) < 1e-12
+        assert abs(float(om.geodesic_theta2(-3. * qa, qb)) - (a - b) ** 2) < 1e-12
+        assert abs(float(om.geodesic_theta2(qa[[1, 2, 3, 0]], qb[[1, 2, 3, 0]])) - (a - b) ** 2) < 1e-12
+    g = torch.Generator().manual_seed(0)
+    wa, wb = torch.randn(16, 3, generator=g, dtype=torch.float64), torch.randn(16, 3, generator=g, dtype=torch.float64)
+    th2 = om.geodesic_theta2(om.so3_to_quat(wa), om.so3_to_quat(wb))
+    for i in range(16):
+        rel = se3.so3_exp(wa[i]).t() @ se3.so3_exp(wb[i])
+        assert abs(float(th2[i]) - float(se3.so3_log(rel).norm() ** 2)) < 1e-9
+        assert abs(float(se3.rot_to_quat(se3.so3_exp(wa[i])) @ om.so3_to_quat(wa[i])).__abs__() - 1.) < 1e-12
+    # identical rotations: zero loss and a finite (zero) gradient
+    q = om.so3_to_quat(wa).requires_grad_(True)
+    v = om.geodesic_theta2(q, q.detach()).sum()
+    v.backward()
+    assert float(v) < 1e-20 and torch.isfinite(q.grad).all()

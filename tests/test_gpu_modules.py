@@ -110,7 +110,10 @@ def compare(hip, ora, x, dev, train=True, tol=TOL, fwd=None, ofwd=None, margin=2
 
 
 FIRE_CASES = [(4, 768, 80, 384, 4, 1, None), (4, 512, 80, 384, 4, 1, "simple"), (2, 64, 16, 64, 8, 32, "simple"),
-              (2, 128, 16, 64, 8, 32, "simple"), (3, 256, 48, 192, 5, 9, None), (1, 512, 64, 256, 8, 16, "simple")]
+              (2, 128, 16, 64, 8, 32, "simple"), (3, 256, 48, 192, 5, 9, None), (1, 512, 64, 256, 8, 16, "simple"),
+              # 'complex' bypass (pointseg_modules.py:110-112,136-138): 1x1 upsample residual where the
+              # width changes, no residual where it does not
+              (2, 64, 16, 64, 8, 32, "complex"), (3, 256, 48, 192, 5, 9, "complex"), (2, 128, 16, 64, 8, 32, "complex")]
 
 
 @pytest.mark.parametrize("case", FIRE_CASES)
@@ -179,6 +182,23 @@ def test_basic_block_and_encoders(dev):
     # whole encoder: 40 layers deep with 16-sample batch statistics at the end -> forward only at
     # 3e-4 vs fp64 (torch's own fp32 forward is 1.5e-4 from fp64 here); gradients are covered per layer
     hip, ora = nets.PSEncoder((10, 16, 64), {'bypass': 'simple'}), om.PSEncoder(10, 'simple')
+    gc.fill_state(ora, 77)
+    hip.load_state_dict(ora.state_dict())
+    yh = hip.to(dev).train()(xe.to(dev))
+    yo = ora.double().train()(xe.double())
+    assert rel_err(yh, yo) < 3e-4
+
+
+def test_psencoder_complex_bypass(dev):
+    """cfg['bypass'] = 'complex' through PSEncoder (pointseg_net.py:13,24-55): state_dict keys incl. the
+    upsample convolutions match the oracle's, forward matches the fp64 oracle"""
+    from deeplio_amd import nets
+    from oracle import model as om
+    _ctx(dev)
+    xe = torch.randn(2, 10, 16, 64, generator=torch.Generator().manual_seed(5))
+    hip, ora = nets.PSEncoder((10, 16, 64), {'bypass': 'complex'}), om.PSEncoder(10, 'complex')
+    assert set(hip.state_dict()) == set(ora.state_dict())
+    assert any("upsample" in k for k in hip.state_dict())
     gc.fill_state(ora, 77)
     hip.load_state_dict(ora.state_dict())
     yh = hip.to(dev).train()(xe.to(dev))

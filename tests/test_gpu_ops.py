@@ -489,6 +489,202 @@ def test_pose_loss(dev, mode):
         assert rel_err(dsx, sxr.grad) < 1e-5 and rel_err(dsq, sqr.grad) < 1e-5
 
 
+@pytest.mark.parametrize("mode", [2, 3])
+def test_pose_loss_geodesic(dev, mode):
+    """rotation terms as squared geodesic angles (mode bit 1; BASELINE configs[4]) vs the fp64 oracle,
+    incl. identical rotations (theta = 0), a sign-flipped quaternion (same rotation), tiny and near-pi
+    angles"""
+    from deeplio_amd import ops
+    from oracle import model as om
+    g = _g(12)
+    B, S = 5, 3
+    pw, gw = torch.randn(B, S, 3, generator=g) * 0.4, torch.randn(B, S, 3, generator=g) * 0.4
+    pw[0, 0] = gw[0, 0]                                     # theta = 0
+    pw[1, 0] = torch.tensor([1e-5, -2e-5, 3e-6]); gw[1, 0] = torch.tensor([-2e-5, 1e-5, 1e-6])
+    pw[2, 0] = torch.tensor([3.0, 0.2, 0.1]); gw[2, 0] = torch.tensor([-0.1, 0.05, 0.02])     # large angle
+    pq, gq = torch.randn(B, 2, 4, generator=g), torch.randn(B, 2, 4, generator=g)
+    pq, gq = pq / pq.norm(dim=-1, keepdim=True), gq / gq.norm(dim=-1, keepdim=True)
+    pq[0, 0] = -gq[0, 0]                                    # same rotation, opposite sign
+    pq[1, 0] = gq[1, 0] + 1e-4 * torch.randn(4, generator=g)
+    preds = [torch.randn(B, S, 3, generator=g), pw, torch.randn(B, 2, 3, generator=g), pq]
+    gts = [torch.randn(B, S, 3, generator=g), gw, torch.randn(B, 2, 3, generator=g), gq]
+    sx, sq = torch.tensor(0.3), torch.tensor(-3.0)
+    pr = [p.clone().double().requires_grad_(True) for p in preds]
+    gd64 = [t.double() for t in gts]
+    sxr, sqr = sx.clone().double().requires_grad_(True), sq.clone().double().requires_grad_(True)
+    Lt, Lp = F.mse_loss(pr[0], gd64[0]), F.mse_loss(pr[2], gd64[2])
+    Lw = om.geodesic_theta2(om.so3_to_quat(pr[1]), om.so3_to_quat(gd64[1])).mean()
+    Lq = om.geodesic_theta2(pr[3], gd64[3]).mean()
+    if mode == 2:
+        ref = (Lp + Lt) * torch.exp(-sxr) + sxr + (Lq + Lw) * torch.exp(-sqr) + sqr
+    else:
+        ref = (Lp + Lt) + 1125. * (Lq + Lw)
+    (ref * 0.7).backward()
+    pd, gd = [p.to(dev) for p in preds], [t.to(dev) for t in gts]
+    out = ops.pose_loss_fwd(pd, gd, sx.to(dev), sq.to(dev), 1125., mode)
+    assert rel_err(out[0], ref) < 1e-5
+    assert rel_err(out[2], Lw) < 1e-5 and rel_err(out[4], Lq) < 1e-5
+    gs = torch.tensor(0.7, device=dev)
+    dps, dsx, dsq = ops.pose_loss_bwd(pd, gd, sx.to(dev), sq.to(dev), 1125., mode, out, gs)
+    for a, b in zip(dps, pr):
+        assert rel_err(a, b.grad) < 2e-5
+    if mode == 2:
+        assert rel_err(dsx, sxr.grad) < 1e-5 and rel_err(dsq, sqr.grad) < 1e-5
+
+
+def test_geodesic_loss_module_matches_oracle(dev):
+    """cfg['losses']['rotation'] = 'geodesic' through get_loss_function / the autograd wrapper"""
+    import copy
+    from deeplio_amd import losses
+    from deeplio_amd.config import make_config
+    from oracle import model as om
+    cfg = copy.deepcopy(make_config())
+    cfg['losses']['rotation'] = 'geodesic'
+    hl, ol = losses.get_loss_function(cfg, dev), om.get_loss_function(cfg)
+    assert hl.rotation == ol.rotation == 'geodesic'
+    g = _g(13)
+    shapes = [(4, 2, 3), (4, 2, 3), (4, 2, 3), (4, 2, 4)]
+    preds = [torch.randn(s, generator=g) * 0.5 for s in shapes]
+    gts = [torch.randn(s, generator=g) * 0.5 for s in shapes]
+    ph = [p.clone().to(dev).requires_grad_(True) for p in preds]
+    po = [p.clone().double().requires_grad_(True) for p in preds]
+    lh = hl(*ph, *[t.to(dev) for t in gts])
+    lo = ol.double()(*po, *[t.double() for t in gts])
+    assert rel_err(lh, lo) < 1e-5
+    lh.backward()
+    lo.backward()
+    for a, b in zip(ph, po):
+        assert rel_err(a.grad, b.grad) < 2e-5
+    cfg['losses']['rotation'] = 'chordal'
+    with pytest.raises(ValueError):
+        losses.get_loss_function(cfg, dev)
+
+
+def test_so3_project_matches_svd(dev):
+    """SO3.normalize (the SVD branch of from_matrix(normalize=True), trainer.py:349) as a Newton polar
+    iteration: forward vs the oracle's SVD projection on rotations perturbed by 1e-6..1e-2, the
+    validity decision, and the backward vs autograd through the SVD at chain-sized defects"""
+    from deeplio_amd import ops
+    from oracle import se3
+    g = _g(14)
+    n = 64
+    w = torch.randn(n, 3, generator=g)
+    R = torch.stack([se3.so3_exp(w[i].double()) for i in range(n)])
+    eps = torch.logspace(-8, -2, n).double().view(n, 1, 1)
+    P = (R + eps * torch.randn(n, 3, 3, generator=g).double()).float()
+    Q, valid = ops.so3_project(P.to(dev).contiguous())
+    for i in range(n):
+        ok = se3.is_valid_rotation(P[i])
+        assert bool(valid[i].item()) == ok or abs(float(eps[i]) - 1e-6) < 3e-6      # fp32 ties at the threshold
+        ref = P[i].double() if valid[i].item() else se3.normalize_rotation(P[i].double())
+        assert float((Q[i].cpu().double() - ref).abs().max()) < 3e-7, (i, float(eps[i]))
+    # backward at defects a product of fp32 exponentials can have (<= 1e-5)
+    eps = torch.logspace(-5.5, -5, n).double().view(n, 1, 1)
+    P = (R + eps * torch.randn(n, 3, 3, generator=g).double()).float()
+    G = torch.randn(n, 3, 3, generator=g)
+    Pd = P.double().requires_grad_(True)
+    tot = sum((se3.normalize_rotation(Pd[i]) * G[i].double()).sum() for i in range(n))
+    tot.backward()
+    dR = ops.so3_project_bwd(P.to(dev).contiguous(), G.to(dev).contiguous())
+    assert rel_err(dR, Pd.grad) < 1e-4
+
+
+def test_se3_chain_reorthonormalises_long_chains(dev):
+    """long fp32 chains drift past liegroups' 1e-6 validity tolerance: status bit 1 reports that the
+    quaternions came from the re-orthonormalised product (trainer.py:349), values and gradients
+    still match the fp64 oracle"""
+    from deeplio_amd import ops
+    from oracle import se3
+    g = _g(15)
+    B, S = 4, 48
+    t, w = torch.randn(B, S, 3, generator=g), torch.randn(B, S, 3, generator=g) * 0.5
+    tr, wr = t.clone().double().requires_grad_(True), w.clone().double().requires_grad_(True)
+    p_ref, q_ref = se3.se3_to_SE3(tr, wr)
+    dp, dq = torch.randn(B, S, 3, generator=g), torch.randn(B, S, 4, generator=g)
+    ((p_ref * dp.double()).sum() + (q_ref * dq.double()).sum()).backward()
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    p, q, R = ops.se3_chain_fwd(t.to(dev), w.to(dev), 0, status)
+    assert int(status.item()) & 1 == 0 and int(status.item()) & 2, "the drift should trip the validity test"
+    assert float((q.norm(dim=-1) - 1).abs().max()) < 5e-7          # re-orthonormalised: unit to fp32 round-off
+    assert rel_err(p, p_ref) < TOL and rel_err(q, q_ref) < TOL
+    dt, dw = ops.se3_chain_bwd(t.to(dev), w.to(dev), R, dp.to(dev), dq.to(dev), 0)
+    assert rel_err(dt, tr.grad) < TOL and rel_err(dw, wr.grad) < 2e-4
+
+
+def test_rmsprop_adadelta_match_torch_optim(dev):
+    """optimizer.py:12-15: RMSprop (plain, momentum, centered) and Adadelta vs torch.optim in fp64"""
+    from deeplio_amd import ops
+    g = _g(16)
+    n = 10007
+    p0 = torch.randn(n, generator=g)
+    grads = [torch.randn(n, generator=g) * (10 ** -i) for i in range(5)]
+    for momentum, centered in ((0., False), (0.9, False), (0.9, True), (0., True)):
+        pr = p0.clone().double().requires_grad_(True)
+        opt = torch.optim.RMSprop([pr], lr=1e-3, weight_decay=1e-4, momentum=momentum, centered=centered)
+        p = p0.clone().to(dev)
+        sq = torch.zeros_like(p)
+        buf = torch.zeros_like(p) if momentum else None
+        ga = torch.zeros_like(p) if centered else None
+        for gr in grads:
+            pr.grad = gr.double()
+            opt.step()
+            ops.rmsprop_step(p, gr.to(dev), sq, buf, ga, 1e-3, 0.99, 1e-8, 1e-4, momentum)
+            assert rel_err(p, pr) < 1e-5, (momentum, centered)
+    pr = p0.clone().double().requires_grad_(True)
+    opt = torch.optim.Adadelta([pr], lr=1e-1, weight_decay=1e-4)
+    p = p0.clone().to(dev)
+    sq, acc = torch.zeros_like(p), torch.zeros_like(p)
+    for gr in grads:
+        pr.grad = gr.double()
+        opt.step()
+        ops.adadelta_step(p, gr.to(dev), sq, acc, 1e-1, 0.9, 1e-6, 1e-4)
+        assert rel_err(p, pr) < 1e-5
+
+
+@pytest.mark.parametrize("kind", ["rmsprop", "adadelta"])
+def test_create_optimizer_rmsprop_adadelta(dev, kind):
+    """create_optimizer (optimizer.py:4-16) over model + criterion groups, three steps vs torch.optim on
+    the same parameters; state converts to / from torch.optim's state_dict (checkpoint.py)"""
+    import types
+    from deeplio_amd import checkpoint
+    from deeplio_amd.optimizer import create_optimizer
+    g = _g(17)
+    shapes = [(7, 5), (33,), (4, 3, 3, 3), ()]
+    init = [torch.randn(s, generator=g) for s in shapes]
+    hp = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+    tp = [torch.nn.Parameter(t.clone().double()) for t in init]
+    args = types.SimpleNamespace(lr=1e-2, weight_decay=1e-4, momentum=0.9)
+    opt = create_optimizer([{'params': hp[:3]}, {'params': hp[3:]}], {'optimizer': kind}, args)
+    cls = torch.optim.RMSprop if kind == 'rmsprop' else torch.optim.Adadelta
+    ref = cls([{'params': tp[:3]}, {'params': tp[3:]}], lr=1e-2, weight_decay=1e-4)
+    for it in range(3):
+        opt.zero_grad()
+        ref.zero_grad()
+        for a, b in zip(hp, tp):
+            gr = torch.randn(a.shape, generator=g)
+            a.grad.copy_(gr.to(dev))
+            b.grad = gr.double()
+        opt.step()
+        ref.step()
+        for a, b in zip(hp, tp):
+            assert rel_err(a, b) < 1e-5
+    sd = checkpoint.optimizer_to_torch_state(opt)
+    rsd = ref.state_dict()
+    assert set(sd['state'][0]) == set(rsd['state'][0])
+    for k, v in rsd['state'][0].items():
+        assert rel_err(sd['state'][0][k], v) < 1e-5, k
+    ref2 = cls([{'params': [torch.nn.Parameter(t.clone()) for t in init[:3]]},
+                {'params': [torch.nn.Parameter(t.clone()) for t in init[3:]]}], lr=1e-2, weight_decay=1e-4)
+    ref2.load_state_dict(sd)                                   # torch accepts the converted state
+    opt2 = create_optimizer([{'params': [torch.nn.Parameter(t.clone().to(dev)) for t in init[:3]]},
+                             {'params': [torch.nn.Parameter(t.clone().to(dev)) for t in init[3:]]}],
+                            {'optimizer': kind}, args)
+    checkpoint.optimizer_from_torch_state(opt2, rsd)
+    for k, b in opt2._state().items():
+        assert rel_err(b, opt._state()[k]) < 1e-5, k
+    assert opt2.step_count == 3
+
+
 def test_adam_sgd_match_torch_optim(dev):
     from deeplio_amd import ops
     g = _g(11)
