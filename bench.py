@@ -90,6 +90,46 @@ def cpu_baseline(cfg, C, H, W, T, S, sample_B, steps):
                       % (sample_B, S, C, T, steps, dt)}
 
 
+def self_launch(n, dry_run):
+    """`python bench.py --gpus N` without torchrun: start N ranks of this very command, one per GPU
+    (RANK = LOCAL_RANK = device index, rendezvous on 127.0.0.1), pass rank 0's stdout (the one JSON
+    line) through and fail if any rank fails.  The driver's torchrun form sets WORLD_SIZE itself and
+    never comes through here."""
+    import socket
+    import subprocess
+    gloo = os.environ.get("DLIO_DIST_BACKEND") == "gloo"      # dry run of the N>1 path: ranks may share a device
+    if not dry_run:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < 1 or (have < n and not gloo):
+            raise SystemExit("bench.py --gpus %d: %d HIP device(s) visible (one rank per GPU; set "
+                             "DLIO_DIST_BACKEND=gloo only for a dry run with ranks sharing a device)" % (n, have))
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:                                  # one rank failed: the others would wait forever
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
 _WGRAD_FORK_DEFAULT = True
 
 
@@ -125,7 +165,12 @@ def main():
     ap.add_argument("--channels", type=int, default=5, help="range-image channels per stream (C)")
     ap.add_argument("--no-isolated", action="store_true", help="skip the non-overlapped roofline pass")
     ap.add_argument("--iso-steps", type=int, default=3)
+    ap.add_argument("--spawn", action="store_true", help="start the rank processes from here even for --gpus 1")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous check only: no model, works without a GPU (gloo)")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+        sys.exit(self_launch(args.gpus, args.dry_run))
     if os.environ.get("DLIO_BENCH_WATCHDOG"):
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["DLIO_BENCH_WATCHDOG"]), exit=True)
@@ -137,8 +182,18 @@ def main():
 
     world, rank, local = ddist.init()
     if world != args.gpus:
-        if rank == 0 and world > 1:
-            print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: launch it with --nproc-per-node %d, "
+                         "or without torchrun (it starts its own ranks)" % (args.gpus, world, args.gpus))
+    if args.dry_run:
+        # every rank joins the group, one collective, rank 0 reports: proves launcher + rendezvous
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        if world > 1:
+            torch.distributed.all_reduce(t)
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "rank_sum": float(t.item()), "value": None}))
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     # one GPU per rank; the modulo only matters for the 2-ranks-on-1-GPU gloo dry run of this path

@@ -33,6 +33,9 @@ def init(backend=None):
         if backend is None:
             backend = os.environ.get("DLIO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
+            if local >= torch.cuda.device_count():
+                raise RuntimeError("rank %d (LOCAL_RANK %d) has no GPU: %d HIP device(s) visible -- RCCL needs one "
+                                   "device per rank" % (rank, local, torch.cuda.device_count()))
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return world, rank, local

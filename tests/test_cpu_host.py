@@ -382,3 +382,26 @@ def test_oracle_geodesic_rotation_terms_known_answers():
     v = om.geodesic_theta2(q, q.detach()).sum()
     v.backward()
     assert float(v) < 1e-20 and torch.isfinite(q.grad).all()
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without torchrun spawns two ranks (gloo here: --dry-run skips the
+    model, which needs the GPU), rank 0 prints ONE JSON line with n_gpus = 2; a WORLD_SIZE that
+    contradicts --gpus and a missing GPU both fail loudly"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    bench = os.path.join(ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-run"], env=env, capture_output=True, text=True,
+                       timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_run"] is True and d["rank_sum"] == 3.0
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-run"], env=dict(env, WORLD_SIZE="1", RANK="0"),
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1"], env=env, capture_output=True,
+                           text=True, timeout=600, cwd=ROOT)
+        assert r.returncode != 0 and "HIP device(s) visible" in r.stderr

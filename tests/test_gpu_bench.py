@@ -56,3 +56,30 @@ def test_bench_cpu_baseline_object(dev):
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] == "port" and c["unit"] == d["unit"] and c["cores"] >= 1 and c["value"] > 0
+
+
+def _run_env(env, *extra):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", *extra],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_self_launch_one_rank(dev):
+    """--gpus 1 through the launcher that `python bench.py --gpus N` uses when no torchrun set WORLD_SIZE"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    d = _run_env(env, "--gpus", "1", "--spawn", "--no-cpu-baseline", "--no-isolated")
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "dp1"
+
+
+def test_bench_self_launch_two_ranks_share_the_gpu(dev):
+    """`python bench.py --gpus 2` with no torchrun: two ranks are spawned, the gradient exchange runs
+    (gloo transport: RCCL refuses two ranks on one device, and the test box has one GPU), rank 0
+    prints one line with n_gpus = 2 and the whole-job rate over both ranks"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["DLIO_DIST_BACKEND"] = "gloo"
+    d = _run_env(env, "--gpus", "2", "--batch", "2", "--no-cpu-baseline", "--no-isolated")
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["frame_pairs_per_step"] == 8
+    assert abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) <= 1e-2 * d["value"]
