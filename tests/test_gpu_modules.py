@@ -202,8 +202,12 @@ def test_psencoder_complex_bypass(dev):
     gc.fill_state(ora, 77)
     hip.load_state_dict(ora.state_dict())
     yh = hip.to(dev).train()(xe.to(dev))
+    y32 = ora.train()(xe)                                       # the reference's own arithmetic (torch fp32 CPU)
     yo = ora.double().train()(xe.double())
-    assert rel_err(yh, yo) < 3e-4
+    # 40 layers with 16-sample batch statistics at the end: fp32 itself is ~2e-4 from fp64 here; the HIP
+    # result has to be as close to fp64 as torch's fp32 is (factor 2 + the 1e-4 of north_star)
+    e_hip, e_t32 = rel_err(yh, yo), rel_err(y32, yo)
+    assert e_hip < 1e-4 + 2 * e_t32, (e_hip, e_t32)
 
 
 @pytest.mark.parametrize("mode", ["lstm", "gru"])
