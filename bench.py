@@ -165,6 +165,8 @@ def main():
     ap.add_argument("--channels", type=int, default=5, help="range-image channels per stream (C)")
     ap.add_argument("--no-isolated", action="store_true", help="skip the non-overlapped roofline pass")
     ap.add_argument("--iso-steps", type=int, default=3)
+    ap.add_argument("--serial", action="store_true",
+                    help="diagnosis: whole run with the stream overlap off (one HIP stream; for per-kernel profiles)")
     ap.add_argument("--spawn", action="store_true", help="start the rank processes from here even for --gpus 1")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous check only: no model, works without a GPU (gloo)")
@@ -210,45 +212,84 @@ def main():
     sync.broadcast_parameters()
     ts.set_grad_sync(sync if world > 1 else None)
     batch = synth_batch(1234 + rank, B, S, C, H, W, T, device)
+    if args.serial:
+        set_overlap(ts.model, False)
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    # Which kernel family dominates is MEASURED first: an untimed pass of the same step with the
-    # stream overlap off and hipEvent pairs around every conv launch gives each family's exclusive
-    # ("isolated") chip time.  In the timed region the two siamese encoders, their weight-gradient
-    # companions and the IMU branch run on concurrent HIP streams, so a kernel's event-to-event
-    # duration there includes the share of the chip its neighbours took; both views are reported.
-    # Only the dominant family is timed in the timed region: an event pair costs ~1.3 us of stream
-    # time, and timing all 220 conv launches of a step slows it by 0.6 ms (1.8 %).
+    # Which kernel family dominates is MEASURED first, in two untimed passes of the same step with
+    # hipEvent pairs around every launch of every family (convolutions, BatchNorm, pools):
+    #   isolated   -- stream overlap off: each family's exclusive chip time;
+    #   overlapped -- the real five-stream step: a launch's event-to-event duration includes the share
+    #                 of the chip its neighbours on the other streams took.
+    # The family with the largest OVERLAPPED time is the dominant one; only it is timed in the timed
+    # region (an event pair costs ~1.3 us of stream time; timing all ~400 launches of a step slows it
+    # by ~1 ms).
     for _ in range(args.warmup):
         ts.step(*batch)
     ts.check()
-    KINDS = (0, 1, 2, 3, 4, 5)
-    prof_iso = None
-    DOM_KIND = 3                                 # without the isolated pass: the 3x3 forward + data gradient family
-    # N > 1: no pre-pass (the timed family is the N = 1 choice; every rank does the same work either way)
-    if not args.no_isolated and world == 1:
-        keep = os.environ.get("DLIO_BENCH_KEEP_OVERLAP", "0") != "0"       # debugging aid
-        if not keep:
+    wg_bx3 = os.environ.get("DLIO_WGRAD_BX3", "1") != "0"
+    # family -> (profiler kinds, bound, peak, description)
+    FAMILIES = {
+        "conv3x3_bx3": ((3,), "mfma", PEAK_BX3_TFLOPS, "conv3x3 split-bf16 MFMA (forward + data gradient)"),
+        "conv2d_1x1": ((2,), "hbm", PEAK_HBM_GBS, "conv2d_1x1 (forward + data gradient, HBM-bound)"),
+        "batchnorm": ((6, 7, 8, 9), "hbm", PEAK_HBM_GBS,
+                      "batchnorm (train-mode statistics, apply, backward reductions, backward apply; HBM-bound)"),
+        "wgrad3x3": ((4,), "mfma", PEAK_BX3_TFLOPS if wg_bx3 else PEAK_F32_MFMA_TFLOPS,
+                     "conv3x3 weight gradient" + (" (split-bf16 MFMA)" if wg_bx3 else " (fp32 MFMA)")),
+        "wgrad1x1": ((5,), "hbm", PEAK_HBM_GBS, "conv1x1 weight gradient (HBM-bound)"),
+        "pool_se": ((10,), "hbm", PEAK_HBM_GBS, "max-pool with fused SE scale (forward + backward, HBM-bound)"),
+        "conv2d_fwd_mfma": ((0,), "mfma", PEAK_F32_MFMA_TFLOPS,
+                            "conv2d_fwd_mfma, multi-tap on the fp32 MFMA (forward + data gradient)"),
+        "conv2d_wgrad_mfma": ((1,), "mfma", PEAK_F32_MFMA_TFLOPS, "conv2d_wgrad_mfma, stems / strided layers on the fp32 MFMA"),
+    }
+    SUBKIND = {6: "forward statistics", 7: "forward apply", 8: "backward reductions", 9: "backward apply"}
+    ALL_KINDS = sorted(k for f in FAMILIES.values() for k in f[0])
+
+    def collect():
+        raw = {k: ops.prof_collect(k) for k in ALL_KINDS}
+        fam = {}
+        for name, (kinds, _, _, _) in FAMILIES.items():
+            fam[name] = {key: sum(raw[k][key] for k in kinds) for key in ("ms", "flops", "bytes", "launches")}
+            if len(kinds) > 1:
+                fam[name]["sub"] = {SUBKIND[k]: raw[k] for k in kinds}
+        return fam
+
+    def profiled_pass(steps, overlap):
+        if not overlap:
             set_overlap(ts.model, False)
         ops.prof_enable(True)
         ts.step(*batch)                          # creates the event pools
         torch.cuda.synchronize()
         ops.prof_reset()
-        for _ in range(args.iso_steps):
+        t0 = time.perf_counter()
+        for _ in range(steps):
             ts.step(*batch)
         torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / steps
         ops.prof_enable(False)
-        prof_iso = {k: ops.prof_collect(k) for k in KINDS}
-        if not keep:
+        fam = collect()
+        if not overlap:
             set_overlap(ts.model, True)
-        DOM_KIND = max(prof_iso, key=lambda k: prof_iso[k]["ms"])
-    prof_on = (1 << DOM_KIND) if os.environ.get("DLIO_BENCH_NOPROF", "0") == "0" else 0
+        return fam, ms
+
+    prof_iso = prof_ovl = None
+    ms_iso = ms_ovl = None
+    DOM = "batchnorm"                            # without the pre-passes (N > 1): the N = 1 choice
+    # N > 1: no pre-passes (every rank does the same work either way; the event pools of a pre-pass made
+    # the following timed steps 4-7x slower in the two-ranks-on-one-GPU dry run)
+    if not args.no_isolated and world == 1 and not args.serial:
+        prof_iso, ms_iso = profiled_pass(args.iso_steps, overlap=False)
+        prof_ovl, ms_ovl = profiled_pass(args.iso_steps, overlap=True)
+        DOM = max(prof_ovl, key=lambda f: prof_ovl[f]["ms"])
+    if os.environ.get("DLIO_BENCH_DOM"):
+        DOM = os.environ["DLIO_BENCH_DOM"]
+    prof_on = sum(1 << k for k in FAMILIES[DOM][0]) if os.environ.get("DLIO_BENCH_NOPROF", "0") == "0" else 0
     ops.prof_enable(prof_on)
-    for _ in range(2):                           # back to the overlapped step; event pool of the chosen family
+    for _ in range(2):                           # back to the plain step; event pool of the chosen family
         ts.step(*batch)
     barrier()
     ops.prof_reset()
@@ -261,68 +302,78 @@ def main():
     ops.prof_enable(False)
     ts.check()
     dt = sync.max_over_ranks(dt)
-    prof_timed = {k: ops.prof_collect(k) for k in KINDS}
+    prof_timed = collect()
     ms_per_step = 1e3 * dt / args.steps
     value = world * B * S / (dt / args.steps)
 
     if rank == 0:
-        wg_bx3 = os.environ.get("DLIO_WGRAD_BX3", "1") != "0"
-        kinds = {0: "conv2d_fwd_mfma, multi-tap on the fp32 MFMA (forward + data gradient)",
-                 1: "conv2d_wgrad_mfma, stems / strided layers on the fp32 MFMA",
-                 2: "conv2d_1x1 (forward + data gradient, HBM-bound)",
-                 3: "conv3x3 split-bf16 MFMA (forward + data gradient)",
-                 4: "conv3x3 weight gradient" + (" (split-bf16 MFMA)" if wg_bx3 else " (fp32 MFMA)"),
-                 5: "conv1x1 weight gradient (HBM-bound)"}
-        prof = prof_timed
-        dom = DOM_KIND
-        p = prof[dom]
-        PEAK_HBM = 8000.0                                     # GB/s, MI355X_MICROARCH.md
+        def rate(v, bound):
+            if not v["ms"] > 0:
+                return 0.0
+            return (v["bytes"] / 1e9 if bound == "hbm" else v["flops"] / 1e12) / (v["ms"] * 1e-3)
 
-        def tfl(v):
-            return v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0
-
-        def gbs(v):
-            return v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0
-
-        def view(k, v, steps):
+        def view(name, v, steps):
             """a kernel family against ITS roofline: MFMA for the multi-tap / weight-gradient kernels
-            (algorithmic FLOPs), HBM for the 1x1 kernels (algorithmic bytes = input + output once)"""
-            hbm = k in (2, 5)
-            bx3 = k == 3 or (k == 4 and wg_bx3)
-            a = gbs(v) if hbm else tfl(v)
-            peak = PEAK_HBM if hbm else (PEAK_BX3_TFLOPS if bx3 else PEAK_F32_MFMA_TFLOPS)
-            out = {"bound": "hbm" if hbm else "mfma", "achieved": round(a, 2), "peak": peak,
-                   "unit": "GB/s" if hbm else "TFLOP/s", "frac": round(a / peak, 4),
+            (algorithmic FLOPs), HBM for the 1x1 / BatchNorm / pool kernels (bytes each launch moves by
+            construction: every operand once)"""
+            _, bound, peak, desc = FAMILIES[name]
+            a = rate(v, bound)
+            out = {"kernel": desc, "bound": bound, "achieved": round(a, 2), "peak": peak,
+                   "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": round(a / peak, 4),
                    "launches_per_step": v["launches"] / steps,
                    "avg_launch_ms": round(v["ms"] / max(v["launches"], 1), 5),
                    "ms_per_step_in_kernel": round(v["ms"] / steps, 3)}
-            if bx3:
+            if peak == PEAK_BX3_TFLOPS:
                 # fp32 products formed from six bf16 MFMAs (three-way operand split, fp32 accumulation):
                 # achieved = ALGORITHMIC fp32 FLOP/s; peak = dense bf16 MFMA peak / 6
                 out["peak_is"] = "bf16 dense MFMA peak 2516.8 TF/s / 6 MFMAs per fp32 product"
                 out["frac_of_fp32_mfma_peak"] = round(a / PEAK_F32_MFMA_TFLOPS, 4)
+            if name == "batchnorm":
+                out["bytes_are"] = ("what the four launches move by construction (statistics 1 pass over the conv "
+                                    "output, apply 2-3, backward reductions 2, backward apply 3); SURVEY 8(d)'s fused "
+                                    "minimum counts 0 bytes for BatchNorm, i.e. all of this is overhead relative to it")
+                if "sub" in v:
+                    out["kernels"] = {k: {"GB/s": round(rate(sv, "hbm"), 1), "ms_per_step": round(sv["ms"] / steps, 3),
+                                          "launches_per_step": sv["launches"] / steps} for k, sv in v["sub"].items()}
             return out
-        roofline = {"kernel": kinds[dom]}
-        roofline.update(view(dom, p, args.steps))
-        roofline["traffic"] = None
-        roofline["note"] = ("timed region: kernels of 5 concurrent HIP streams (2 encoders, their weight-gradient "
-                            "companions, IMU branch) share the chip, so per-launch durations include the "
-                            "neighbours' share; only the family with the largest isolated time is timed there (an "
-                            "event pair costs stream time); 'isolated' = all conv families alone, same step, "
-                            "overlap off, measured before the timed region")
-        other = {kinds[k]: view(k, v, args.steps) for k, v in prof.items() if k != dom and v["launches"]}
-        if other:
-            roofline["other"] = other
+
         # PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction of
         # the guide applied): collected by tools/pmc_traffic.py, committed under profiles/
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc) and B == 8 and S == 2 and headline:
-            with open(pmc) as f:
-                t = json.load(f).get({0: "conv2d_fwd_mfma", 1: "conv2d_wgrad_mfma", 2: "conv2d_1x1", 3: "conv3x3_bx3",
-                                     4: "wgrad3x3", 5: "wgrad1x1"}[dom])
-            if t and p["launches"]:
-                roofline["traffic"] = round(t["hbm_bytes_per_step_corrected"] / (p["launches"] / args.steps))
-                roofline["traffic_unit"] = "HBM bytes per launch (avg), from profiles/r01_pmc_traffic.json"
+        pmc = None
+        for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            path = os.path.join(ROOT, "profiles", fn)
+            if os.path.exists(path) and B == 8 and S == 2 and headline:
+                with open(path) as f:
+                    pmc = (fn, json.load(f))
+                break
+
+        def traffic(name, v, steps):
+            t = pmc[1].get(name) if pmc else None
+            if not t or not v["launches"]:
+                return None
+            return round(t["hbm_bytes_per_step_corrected"] / (v["launches"] / steps))
+
+        p = prof_timed[DOM]
+        roofline = view(DOM, p, args.steps)
+        roofline["traffic"] = traffic(DOM, p, args.steps)
+        if roofline["traffic"] is not None:
+            roofline["traffic_unit"] = "HBM bytes per launch (avg), from profiles/%s" % pmc[0]
+        roofline["note"] = ("timed region: kernels of 5 concurrent HIP streams (2 encoders, their weight-gradient "
+                            "companions, IMU branch) share the chip, so per-launch durations include the neighbours' "
+                            "share; only the family with the largest OVERLAPPED time is timed there (an event pair "
+                            "costs stream time).  'other' = every family in an untimed pass of the same overlapped "
+                            "step with all launches timed; 'isolated' = the same with the stream overlap off")
+        if prof_ovl is not None:
+            other = {}
+            for name, v in prof_ovl.items():
+                if name == DOM or not v["launches"]:
+                    continue
+                other[name] = view(name, v, args.iso_steps)
+                other[name]["traffic"] = traffic(name, v, args.iso_steps)
+            roofline["other"] = other
+            roofline["other_pass"] = {"what": "untimed overlapped pass, every family timed (%d steps)" % args.iso_steps,
+                                      "ms_per_step": round(ms_ovl, 3),
+                                      "dominant_there": view(DOM, prof_ovl[DOM], args.iso_steps)}
         # whole-step view on SURVEY 8(d)'s algorithmic figures: 3 x (36.13 GF conv + 0.124 GF RNN) and
         # 3 x 957 MB per frame pair
         pairs_per_s = value
@@ -330,12 +381,20 @@ def main():
             roofline["step"] = {
                 "mfma": {"achieved": round(pairs_per_s * 3 * 36.254e9 / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(pairs_per_s * 3 * 36.254e9 / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
-                "hbm": {"achieved": round(pairs_per_s * 3 * 957e6 / 1e9, 1), "peak": PEAK_HBM, "unit": "GB/s",
-                        "frac": round(pairs_per_s * 3 * 957e6 / 1e9 / PEAK_HBM, 4)}}
+                "hbm": {"achieved": round(pairs_per_s * 3 * 957e6 / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(pairs_per_s * 3 * 957e6 / 1e9 / PEAK_HBM_GBS, 4)}}
+            if pmc and "all" in pmc[1]:
+                tb = pmc[1]["all"]["hbm_bytes_per_step_corrected"]
+                roofline["step"]["hbm_measured"] = {
+                    "bytes_per_step": round(tb), "achieved": round(tb / (ms_per_step * 1e-3) / 1e9, 1),
+                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(tb / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                    "source": "profiles/%s (PMC fabric bytes of one step)" % pmc[0]}
         if prof_iso is not None:
-            iso = {"what": "same kernels, same step, stream overlap off (%d untimed steps)" % args.iso_steps}
-            iso.update(view(dom, prof_iso[dom], args.iso_steps))
-            iso["other"] = {kinds[k]: view(k, v, args.iso_steps) for k, v in prof_iso.items() if k != dom}
+            iso = {"what": "same kernels, same step, stream overlap off (%d untimed steps)" % args.iso_steps,
+                   "ms_per_step": round(ms_iso, 3)}
+            iso.update(view(DOM, prof_iso[DOM], args.iso_steps))
+            iso["other"] = {name: view(name, v, args.iso_steps) for name, v in prof_iso.items()
+                            if name != DOM and v["launches"]}
             roofline["isolated"] = iso
         out = {
             "metric": "frame-pairs/sec training, 64x2048x5 range-img + 50-step IMU, bs=8, 1/2/4/8 GPU",

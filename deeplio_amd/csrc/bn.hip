@@ -694,7 +694,9 @@ extern "C" int dlio_bn_train_apply(const float* x, int N, int x_ctot, int x_coff
   hipStream_t s = as_stream(stream);
   double* part = reinterpret_cast<double*>(ws);
   int rc = DLIO_OK;
+  const double tensor_bytes = 4.0 * N * (double)C * HW;
   if (phase != 2) {
+    DlioProfScope prof(6, s, 0.0, tensor_bytes);
     if (bn_unroll() > 1)
       hipLaunchKernelGGL((chan_reduce_kernel<0, 4>), dim3((unsigned)(C * splits)), dim3(RB), 0, s, x, x_ctot, x_coff,
                        (const float*)nullptr, 0, 0, (const float*)nullptr, (const float*)nullptr,
@@ -710,6 +712,7 @@ extern "C" int dlio_bn_train_apply(const float* x, int N, int x_ctot, int x_coff
   int chunks, chunk_len;
   plane_chunks(N * C, vec ? HW / 4 : HW, gap_out != nullptr, chunks, chunk_len);
   const dim3 grid((unsigned)(N * C * chunks));
+  DlioProfScope prof(7, s, 0.0, tensor_bytes * (residual ? 3.0 : 2.0));
   if (vec && bn_unroll() > 1)
     hipLaunchKernelGGL((bn_plane_apply_kernel<true, 4>), grid, dim3(256), 0, s, x, x_ctot, x_coff, part, splits,
                        (double)N * HW * count_scale, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
@@ -742,7 +745,9 @@ extern "C" int dlio_bn_bwd(const float* dy, int dy_ctot, int dy_coff, const floa
   hipStream_t s = as_stream(stream);
   double* part = reinterpret_cast<double*>(ws);
   int rc = DLIO_OK;
+  const double tensor_bytes = 4.0 * N * (double)C * HW;
   if (phase != 2) {
+    DlioProfScope prof(8, s, 0.0, 2.0 * tensor_bytes);
     if (bn_unroll() > 1)
       hipLaunchKernelGGL((chan_reduce_kernel<1, 2>), dim3((unsigned)(C * splits)), dim3(RB), 0, s, dy, dy_ctot,
                        dy_coff, x, x_ctot, x_coff, mean, invstd, scale, beta, N, C, HW, pre_relu, post_relu,
@@ -760,6 +765,7 @@ extern "C" int dlio_bn_bwd(const float* dy, int dy_ctot, int dy_coff, const floa
   const dim3 grid((unsigned)(N * C * chunks));
   const double inv_cnt = 1.0 / ((double)N * HW * count_scale);
   const double* lpart = reinterpret_cast<const double*>(local_ws);
+  DlioProfScope prof(9, s, 0.0, 3.0 * tensor_bytes);
   if (vec && bn_unroll() > 1)
     hipLaunchKernelGGL((bn_plane_bwd_kernel<true, 2>), grid, dim3(256), 0, s, dy, dy_ctot, dy_coff, x, x_ctot,
                        x_coff, mean, invstd, scale, beta, part, lpart, inv_cnt, splits, dx, dx_ctot, dx_coff,

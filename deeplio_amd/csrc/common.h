@@ -67,6 +67,11 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __ex
 // so that workspace queries work on a build host)
 int dlio_num_cus();
 
-// profiling hooks (prof.hip)
+// profiling hooks (runtime.hip); kinds: include/deeplio_hip.h
 void dlio_prof_begin(int kind, hipStream_t s, double flops, double bytes);
 void dlio_prof_end(int kind, hipStream_t s);
+struct DlioProfScope {          // brackets the launches issued during its lifetime
+  int kind; hipStream_t s;
+  DlioProfScope(int k, hipStream_t st, double flops, double bytes) : kind(k), s(st) { dlio_prof_begin(k, st, flops, bytes); }
+  ~DlioProfScope() { dlio_prof_end(kind, s); }
+};

@@ -489,6 +489,7 @@ extern "C" int dlio_maxpool2d_fwd(const float* x, const float* x_scale, float* y
                                   int SW, int PH, int PW, dlio_stream_t stream) {
   if (!x || !y || N <= 0 || C <= 0 || K <= 0 || K > 15) return DLIO_EINVAL;
   const int64_t total = (int64_t)N * C * OH * OW;
+  DlioProfScope prof(10, as_stream(stream), 0.0, (double)N * C * (4.0 * H * W + (idx ? 5.0 : 4.0) * OH * OW));
   if (K == 3 && SW == 2 && PH == 1 && PW == 1 && (SH == 1 || SH == 2) && (W & 3) == 0 && OW * 2 == W &&
       OH == (H + 2 - 3) / SH + 1) {
     const int64_t work = total / 2;
@@ -522,6 +523,7 @@ extern "C" int dlio_maxpool2d_bwd_dot(const float* dy, const uint8_t* idx, const
                                       int SW, int PH, int PW, dlio_stream_t stream) {
   if (!dy || !idx || !x || !ds || N <= 0 || C <= 0) return DLIO_EINVAL;
   if (!pool_fast(H, W, OH, OW, K, SH, SW, PH, PW)) return DLIO_EUNSUP;
+  DlioProfScope prof(10, as_stream(stream), 0.0, (double)N * C * (4.0 * H * W + 5.0 * OH * OW));
   int grid = N * C;
   if (grid > 65535) grid = 65535;
   static const int strip = getenv("DLIO_POOL_STRIP") ? atoi(getenv("DLIO_POOL_STRIP")) : 1;   // tuning knob
@@ -546,6 +548,7 @@ extern "C" int dlio_maxpool2d_bwd(const float* dy, const uint8_t* idx, const flo
                                   dlio_stream_t stream) {
   if (!dy || !idx || !dx || N <= 0 || C <= 0 || K <= 0) return DLIO_EINVAL;
   const int64_t total = (int64_t)N * C * H * W;
+  DlioProfScope prof(10, as_stream(stream), 0.0, (double)N * C * (4.0 * H * W + 5.0 * OH * OW));
   if (K == 3 && SW == 2 && PH == 1 && PW == 1 && (SH == 1 || SH == 2) && (W & 3) == 0 && OW * 2 == W &&
       OH == (H + 2 - 3) / SH + 1) {
     const int64_t work = total / 4;

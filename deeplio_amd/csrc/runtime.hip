@@ -11,13 +11,13 @@ struct ProfKind {
   size_t used = 0;
   double flops = 0.0, bytes = 0.0;
 };
-ProfKind g_prof[8];
+ProfKind g_prof[DLIO_PROF_KINDS];
 int g_prof_mask = 0;        // bit k: kind k is timed
 std::mutex g_mu;
 }  // namespace
 
 void dlio_prof_begin(int kind, hipStream_t s, double flops, double bytes) {
-  if (kind < 0 || kind >= 8 || !(g_prof_mask >> kind & 1)) return;
+  if (kind < 0 || kind >= DLIO_PROF_KINDS || !(g_prof_mask >> kind & 1)) return;
   std::lock_guard<std::mutex> lk(g_mu);
   ProfKind& k = g_prof[kind];
   if (k.used == k.start.size()) {
@@ -33,7 +33,7 @@ void dlio_prof_begin(int kind, hipStream_t s, double flops, double bytes) {
 }
 
 void dlio_prof_end(int kind, hipStream_t s) {
-  if (kind < 0 || kind >= 8 || !(g_prof_mask >> kind & 1)) return;
+  if (kind < 0 || kind >= DLIO_PROF_KINDS || !(g_prof_mask >> kind & 1)) return;
   std::lock_guard<std::mutex> lk(g_mu);
   ProfKind& k = g_prof[kind];
   hipEventRecord(k.stop[k.used], s);
@@ -41,7 +41,7 @@ void dlio_prof_end(int kind, hipStream_t s) {
 }
 
 extern "C" int dlio_prof_enable(int kinds_mask) {
-  g_prof_mask = kinds_mask & 0xff;
+  g_prof_mask = kinds_mask & ((1 << DLIO_PROF_KINDS) - 1);
   return DLIO_OK;
 }
 
@@ -53,7 +53,7 @@ extern "C" int dlio_prof_reset(void) {
 
 extern "C" int dlio_prof_collect(int kind, double* ms, double* flops, double* bytes,
                                  int64_t* launches) {
-  if (kind < 0 || kind >= 8 || !ms || !flops || !bytes || !launches) return DLIO_EINVAL;
+  if (kind < 0 || kind >= DLIO_PROF_KINDS || !ms || !flops || !bytes || !launches) return DLIO_EINVAL;
   std::lock_guard<std::mutex> lk(g_mu);
   ProfKind& k = g_prof[kind];
   double total = 0.0;

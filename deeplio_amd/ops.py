@@ -882,8 +882,9 @@ def sumsq(g):
 def prof_enable(on):
     """on: False / True (all kinds) or a bit mask of kernel kinds (include/deeplio_hip.h: bit 0 fp32
     multi-tap forward + data gradient, 1 other weight gradients, 2 1x1 forward + data gradient,
-    3 split-bf16 3x3 forward + data gradient, 4 3x3 weight gradient, 5 1x1 weight gradient)"""
-    lib.dlio_prof_enable(0xff if on is True else int(on))
+    3 split-bf16 3x3 forward + data gradient, 4 3x3 weight gradient, 5 1x1 weight gradient,
+    6-9 BatchNorm statistics / apply / backward reductions / backward apply, 10 pools)"""
+    lib.dlio_prof_enable(0xffff if on is True else int(on))
 
 
 def prof_reset():

@@ -51,15 +51,25 @@ const char* dlio_strerror(int code);
 const char* dlio_last_hip_error_string(void);
 
 /* ---- profiling hooks (bench.py roofline leg) ---------------------------
- * When enabled, the conv launchers bracket each launch with hipEvents on the
- * launch stream.  dlio_prof_collect synchronises those events and returns the
- * summed milliseconds / algorithmic FLOPs / launch count per kernel kind
- * (0 = multi-tap conv forward / data gradient: MFMA-bound; 1 = conv weight gradient other than
- *  4 = 3x3 stride-1 weight gradient (split-bf16 MFMAs) and 5 = 1x1 weight gradient (HBM-bound);
- *  2 = 1x1 conv forward / data gradient: HBM-bound; 3 = 3x3 stride-1 forward / data gradient on
- *  the split-bf16 kernel, dlio_conv3x3_bx3_fwd).  dlio_prof_enable takes a bit mask
- * of the kinds to time (0 = off): an event pair costs ~1.3 us of stream time, so the
- * timed region of bench.py times the dominant kind only (all kinds: +0.6 ms per step). */
+ * When enabled, the launchers bracket each launch with hipEvents on the launch stream.
+ * dlio_prof_collect synchronises those events and returns the summed milliseconds / algorithmic
+ * FLOPs / bytes / launch count per kernel kind:
+ *   0  multi-tap conv forward / data gradient on the fp32 MFMA (stems, strided layers)   MFMA-bound
+ *   1  conv weight gradients other than kinds 4 and 5                                      MFMA-bound
+ *   2  1x1 conv forward / data gradient                                                    HBM-bound
+ *   3  3x3 stride-1 forward / data gradient on the split-bf16 kernel (dlio_conv3x3_bx3_fwd) MFMA-bound
+ *   4  3x3 stride-1 weight gradient                                                        MFMA-bound
+ *   5  1x1 weight gradient                                                                 HBM-bound
+ *   6  BatchNorm forward statistics      (bytes: 1 pass over the conv output)              HBM-bound
+ *   7  BatchNorm forward apply           (2 passes, +1 with a residual)                    HBM-bound
+ *   8  BatchNorm backward reductions     (2 passes: dy, x)                                 HBM-bound
+ *   9  BatchNorm backward apply          (3 passes: dy, x, dx)                             HBM-bound
+ *  10  max-pool / SE scale / global average pool, forward and backward                     HBM-bound
+ *  11  native-bf16 convolutions of the mixed-precision path (forward / data / weight gradient)
+ * For the HBM-bound kinds `bytes` are the bytes the launch moves by construction (every operand once).
+ * dlio_prof_enable takes a bit mask of the kinds to time (0 = off): an event pair costs ~1.3 us of
+ * stream time, so the timed region of bench.py times the dominant kind only. */
+#define DLIO_PROF_KINDS 16
 int dlio_prof_enable(int kinds_mask);
 int dlio_prof_reset(void);
 int dlio_prof_collect(int kind, double* ms, double* flops, double* bytes, int64_t* launches);
