@@ -36,6 +36,7 @@ SIGNATURES = {
     "dlio_strerror": (C.c_char_p, [_i]),
     "dlio_last_hip_error_string": (C.c_char_p, []),
     "dlio_prof_enable": (_i, [_i]),
+    "dlio_prof_sample": (_i, [_i]),
     "dlio_prof_reset": (_i, []),
     "dlio_prof_collect": (_i, [_i, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d), C.POINTER(_i64)]),
     "dlio_conv2d_prep_weight_floats": (_sz, [_i, _i, _i, _i, _i]),

@@ -8,9 +8,11 @@
 namespace {
 struct ProfKind {
   std::vector<hipEvent_t> start, stop;
-  size_t used = 0;
+  size_t used = 0, seen = 0;
   double flops = 0.0, bytes = 0.0;
 };
+int g_prof_stride = 1;      // time every stride-th launch of a kind (sampling keeps the timed region unperturbed)
+thread_local bool t_armed[DLIO_PROF_KINDS] = {};
 ProfKind g_prof[DLIO_PROF_KINDS];
 int g_prof_mask = 0;        // bit k: kind k is timed
 std::mutex g_mu;
@@ -20,6 +22,8 @@ void dlio_prof_begin(int kind, hipStream_t s, double flops, double bytes) {
   if (kind < 0 || kind >= DLIO_PROF_KINDS || !(g_prof_mask >> kind & 1)) return;
   std::lock_guard<std::mutex> lk(g_mu);
   ProfKind& k = g_prof[kind];
+  t_armed[kind] = (k.seen++ % (size_t)g_prof_stride) == 0;
+  if (!t_armed[kind]) return;
   if (k.used == k.start.size()) {
     hipEvent_t a, b;
     hipEventCreate(&a);
@@ -34,6 +38,8 @@ void dlio_prof_begin(int kind, hipStream_t s, double flops, double bytes) {
 
 void dlio_prof_end(int kind, hipStream_t s) {
   if (kind < 0 || kind >= DLIO_PROF_KINDS || !(g_prof_mask >> kind & 1)) return;
+  if (!t_armed[kind]) return;
+  t_armed[kind] = false;
   std::lock_guard<std::mutex> lk(g_mu);
   ProfKind& k = g_prof[kind];
   hipEventRecord(k.stop[k.used], s);
@@ -47,7 +53,13 @@ extern "C" int dlio_prof_enable(int kinds_mask) {
 
 extern "C" int dlio_prof_reset(void) {
   std::lock_guard<std::mutex> lk(g_mu);
-  for (auto& k : g_prof) { k.used = 0; k.flops = 0.0; k.bytes = 0.0; }
+  for (auto& k : g_prof) { k.used = 0; k.seen = 0; k.flops = 0.0; k.bytes = 0.0; }
+  return DLIO_OK;
+}
+
+extern "C" int dlio_prof_sample(int stride) {
+  if (stride < 1) return DLIO_EINVAL;
+  g_prof_stride = stride;
   return DLIO_OK;
 }
 

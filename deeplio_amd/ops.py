@@ -887,6 +887,11 @@ def prof_enable(on):
     lib.dlio_prof_enable(0xffff if on is True else int(on))
 
 
+def prof_sample(stride):
+    """time every stride-th launch of each enabled kind only (1 = every launch)"""
+    check(lib.dlio_prof_sample(int(stride)), "prof_sample")
+
+
 def prof_reset():
     lib.dlio_prof_reset()
 

@@ -71,6 +71,10 @@ const char* dlio_last_hip_error_string(void);
  * stream time, so the timed region of bench.py times the dominant kind only. */
 #define DLIO_PROF_KINDS 16
 int dlio_prof_enable(int kinds_mask);
+/* time only every stride-th launch of each enabled kind (1 = all): the per-kind sums then cover the
+ * sampled launches only.  A stride coprime with a kind's launches per step walks through all layers
+ * over consecutive steps. */
+int dlio_prof_sample(int stride);
 int dlio_prof_reset(void);
 int dlio_prof_collect(int kind, double* ms, double* flops, double* bytes, int64_t* launches);
 
