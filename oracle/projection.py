@@ -6,14 +6,23 @@ tests/golden/projection.npz, which was captured from the reference itself."""
 import numpy as np
 
 
-def range_projection(points, remissions, H, W, fov_up, fov_down):
+def range_projection(points, remissions, H, W, fov_up, fov_down, exact_trig=False):
+    """exact_trig=False: numpy's own float32 arctan2 / arcsin, as the reference calls them (their
+    last-ulp results depend on the host's SIMD dispatch); exact_trig=True: correctly rounded float32
+    values (fp64 evaluation rounded once), the host-independent definition the HIP kernel implements
+    (csrc/projection.hip).  The two differ for ~1e-5 of the points of a KITTI-sized cloud;
+    tests/golden/projection_kitti.npz records that set for this container's numpy."""
     fov_up = fov_up / 180.0 * np.pi
     fov_down = fov_down / 180.0 * np.pi
     fov = abs(fov_down) + abs(fov_up)
     depth = np.linalg.norm(points, 2, axis=1)
     scan_x, scan_y, scan_z = points[:, 0], points[:, 1], points[:, 2]
-    yaw = -np.arctan2(scan_y, scan_x)
-    pitch = np.arcsin(scan_z / depth)
+    if exact_trig:
+        yaw = -np.arctan2(scan_y.astype(np.float64), scan_x.astype(np.float64)).astype(np.float32)
+        pitch = np.arcsin((scan_z / depth).astype(np.float64)).astype(np.float32)
+    else:
+        yaw = -np.arctan2(scan_y, scan_x)
+        pitch = np.arcsin(scan_z / depth)
     proj_x = 0.5 * (yaw / np.pi + 1.0)
     proj_y = 1.0 - (pitch + abs(fov_down)) / fov
     proj_x *= W
