@@ -154,7 +154,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)      # >= 20 timed steps
     ap.add_argument("--warmup", type=int, default=5)     # 5 warm-up steps
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (BASELINE: 8)")
-    ap.add_argument("--seq", type=int, default=2, help="frame pairs per sample (S)")
+    ap.add_argument("--seq", type=int, default=None, help="frame pairs per sample (S); default 2 (4 with --dtype bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4, help="samples per CPU-baseline step (bounded sample)")
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -165,6 +165,10 @@ def main():
     ap.add_argument("--channels", type=int, default=5, help="range-image channels per stream (C)")
     ap.add_argument("--no-isolated", action="store_true", help="skip the non-overlapped roofline pass")
     ap.add_argument("--iso-steps", type=int, default=3)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32: the headline (BASELINE configs[1]).  bf16: informational line for BASELINE configs[4] -- "
+                         "mixed precision (bf16 activation storage in the PointSeg encoders, fp32 master weights / "
+                         "statistics / loss), seq_len 4, geodesic rotation loss, per-GPU batch 8")
     ap.add_argument("--serial", action="store_true",
                     help="diagnosis: whole run with the stream overlap off (one HIP stream; for per-kernel profiles)")
     ap.add_argument("--spawn", action="store_true", help="start the rank processes from here even for --gpus 1")
@@ -202,10 +206,19 @@ def main():
     device = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(device)
 
+    bf16 = args.dtype == "bf16"
+    if args.seq is None:
+        args.seq = 4 if bf16 else 2
     C, H, W, T, S, B = args.channels, 64, 2048, 50, args.seq, args.batch
     cfg = make_config(lidar=args.lidar, imu=args.imu, fusion=args.fusion, odom=args.odom, seq=S)
-    headline = (args.lidar, args.imu, args.fusion, args.odom, C) == (
-        "lidar-feat-pointseg", "imu-feat-rnn", "fusion-layer-soft", "odom-feat-rnn", 5)
+    if bf16:
+        if args.lidar != "lidar-feat-pointseg":
+            raise SystemExit("--dtype bf16: the mixed-precision path exists for lidar-feat-pointseg")
+        cfg['lidar-feat-pointseg']['precision'] = 'bf16'
+        cfg['losses']['rotation'] = 'geodesic'
+        args.no_cpu_baseline = True           # the CPU baseline of record belongs to the fp32 headline
+    headline = (args.lidar, args.imu, args.fusion, args.odom, C, args.dtype, S) == (
+        "lidar-feat-pointseg", "imu-feat-rnn", "fusion-layer-soft", "odom-feat-rnn", 5, "f32", 2)
     torch.manual_seed(20260928)                     # same random-init weights on every rank / run
     ts = TrainStep(cfg, (C, H, W), device, B)
     sync = ddist.GradSync(ts.optimizer.flat, ts.optimizer.grad, ts.optimizer)
@@ -245,6 +258,8 @@ def main():
         "conv2d_fwd_mfma": ((0,), "mfma", PEAK_F32_MFMA_TFLOPS,
                             "conv2d_fwd_mfma, multi-tap on the fp32 MFMA (forward + data gradient)"),
         "conv2d_wgrad_mfma": ((1,), "mfma", PEAK_F32_MFMA_TFLOPS, "conv2d_wgrad_mfma, stems / strided layers on the fp32 MFMA"),
+        # mixed precision: 75 FLOP/B fused is far below the bf16 ridge (315) -> priced in bytes
+        "conv_bf16": ((11,), "hbm", PEAK_HBM_GBS, "native-bf16 convolutions (forward, data and weight gradient; HBM-bound)"),
     }
     SUBKIND = {6: "forward statistics", 7: "forward apply", 8: "backward reductions", 9: "backward apply"}
     ALL_KINDS = sorted(k for f in FAMILIES.values() for k in f[0])
@@ -419,13 +434,20 @@ def main():
             "metric": "frame-pairs/sec training, 64x2048x5 range-img + 50-step IMU, bs=8, 1/2/4/8 GPU",
             "value": round(value, 3), "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "dtype_note": ("fp32 tensors, accumulation and results throughout; the 3x3 convolutions (forward, data and weight gradient) form each fp32 product "
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "dtype_note": ("bf16 storage of the PointSeg encoders' activations and activation gradients, one bf16 MFMA per "
+                           "product with fp32 accumulation; fp32 master weights, weight gradients, BatchNorm statistics, stem "
+                           "convolution, RNNs, heads, SE(3) chain, loss and Adam (deeplio_amd/mixed.py; "
+                           "tests/test_gpu_mixed.py)") if bf16 else
+                          ("fp32 tensors, accumulation and results throughout; the 3x3 convolutions (forward, data and weight gradient) form each fp32 product "
                            "from six bf16 MFMAs over three-way operand splits (error vs fp64 = the fp32 MFMA's, "
                            "tests/test_gpu_ops.py::test_conv3x3_split_bf16_matches_fp64)"),
             "config": {"workload": ("BASELINE configs[1]: lidar-feat-pointseg(add)+imu-feat-rnn bi-LSTM-128x2"
                                     "+fusion-layer-soft+odom-feat-rnn bi-LSTM-1024x2, HWS local+global, Adam; "
                                     "64x2048x5, T=50, S=%d, per-GPU batch %d" % (S, B)) if headline else
+                                   ("informational (not the headline): BASELINE configs[4] -- full DeepLIO (PointSeg + bi-LSTM "
+                                    "+ soft fusion + odometry bi-LSTM) bf16 mixed precision, geodesic rotation loss (HWS), Adam; "
+                                    "64x2048x%d, T=50, seq_len %d, per-GPU batch %d (global batch 64 at DP=8)" % (C, S, B)) if bf16 else
                                    ("informational (not the headline config): %s+%s+%s+%s, 64x2048x%d, T=50, S=%d, "
                                     "per-GPU batch %d" % (args.lidar, args.imu, args.fusion, args.odom, C, S, B)),
                        "global_batch": world * B, "frame_pairs_per_step": world * B * S,

@@ -114,6 +114,24 @@ SIGNATURES = {
     "dlio_scan_project": (_i, [_p, _p, _i, _i, _i, _d, _d, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "dlio_scan_normals": (_i, [_p, _p, _p, _i, _i, _p]),
     "dlio_velo_image": (_i, [_p, _p, _p, _p, _f, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "dlio_conv_bf16_prep_elems": (_sz, [_i, _i, _i, _i]),
+    "dlio_conv_bf16_prep": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "dlio_conv_bf16_prep_batched": (_i, [_p, _i, _i64, _p]),
+    "dlio_conv3x3_bf16_fwd": (_i, [_p, _p, _p, _p, _p, _cd, _p]),
+    "dlio_conv1x1_bf16_fwd": (_i, [_p, _p, _p, _p, _p, _cd, _p]),
+    "dlio_conv2d_wgrad_bf16": (_i, [_p, _p, _p, _p, _sz, _i, _cd, _p]),
+    "dlio_bf16_stats_splits": (_i, [_i, _i, _i]),
+    "dlio_bf16_stats_ws_bytes": (_sz, [_i, _i, _i]),
+    "dlio_bn_bf16_apply": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _i, _i, _p, _i, _i,
+                                _p, _i, _i, _i, _p, _sz, _p]),
+    "dlio_bn_bf16_bwd": (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _i,
+                              _p, _sz, _p]),
+    "dlio_maxpool_bf16_fwd": (_i, [_p, _p, _p, _p] + [_i] * 11 + [_p]),
+    "dlio_maxpool_bf16_bwd": (_i, [_p, _p, _p, _p, _p] + [_i] * 11 + [_p]),
+    "dlio_maxpool_bf16_bwd_dot": (_i, [_p, _p, _p, _p] + [_i] * 11 + [_p]),
+    "dlio_gap_bf16_fwd": (_i, [_p, _i, _i, _p, _i, _i, _i, _p]),
+    "dlio_gap_bf16_bwd": (_i, [_p, _p, _i, _i, _i, _p]),
+    "dlio_cast_bf16": (_i, [_p, _p, _i64, _i, _p]),
     "dlio_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i, _f, _p]),
     "dlio_sgd_step": (_i, [_p, _p, _p, _i64, _f, _f, _f, _i, _f, _p]),
     "dlio_rmsprop_step": (_i, [_p, _p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p]),

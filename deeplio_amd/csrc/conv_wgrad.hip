@@ -370,11 +370,16 @@ __device__ __forceinline__ void wg_split8(const float (&v)[8], wg_bf16x8& h, wg_
 // six bf16 MFMAs over three-way operand splits (conv_bx3.hip).  K = 16 pixels per MFMA: k-block q
 // of a wave's 32 pixels is {16*half + 8q + j}, i.e. the float4 pairs (2q, 2q+1) of the dY
 // registers and 8 consecutive X' values in LDS, split in registers per use.
-template <int KH, int KW, int NT, int MRW, bool BX3 = false>
+// NAT (mixed-precision path, BASELINE configs[4]): x and dy are bf16 in memory (the pointers are
+// reinterpreted), the X' patch is widened to fp32 while it is staged (so the LDS layout and the
+// unaligned 8-value fragment reads stay as they are; narrowing back is exact), the dY fragments are
+// the two 16-byte loads of a lane's 16 pixels as they come, and each product is ONE bf16 MFMA.
+template <int KH, int KW, int NT, int MRW, bool BX3 = false, bool NAT = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_adirect_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ wsp,
     DlioConvDesc d, int co_tiles, int ci_chunks, int splits, int tiles_w, int tiles_h) {
   using C = WgACfg<KH, KW, NT, MRW>;
+  constexpr unsigned EB = NAT ? 2u : 4u;          // bytes per element of x / dy
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -432,9 +437,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_adirect_kernel(
   // prefetch with the MFMAs; conditional loads made it wait for every load individually).
   constexpr unsigned OOB = 0xffffff00u;
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(x), 0, (int)((size_t)d.N * d.in_ctot * HW * 4), 0x00020000);
+      const_cast<float*>(x), 0, (int)((size_t)d.N * d.in_ctot * HW * EB), 0x00020000);
   const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(dy), 0, (int)((size_t)d.N * d.out_ctot * ohw * 4), 0x00020000);
+      const_cast<float*>(dy), 0, (int)((size_t)d.N * d.out_ctot * ohw * EB), 0x00020000);
   float rx[C::NCX][C::NPOSX];
   auto load_x = [&](int tile) {
     int tt = tile;
@@ -442,22 +447,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_adirect_kernel(
     const int th = tt % tiles_h; tt /= tiles_h;
     const int n = tt;
     const int ih0 = th * C::TH - d.PH, iw0 = tw * C::TW - d.PW;
-    const unsigned img = (unsigned)(((size_t)n * d.in_ctot + d.in_coff + c0) * HW * 4);   // uniform
+    const unsigned img = (unsigned)(((size_t)n * d.in_ctot + d.in_coff + c0) * HW * EB);   // uniform
     unsigned po[C::NPOSX];
 #pragma unroll
     for (int j = 0; j < C::NPOSX; ++j) {
       const int ih = ih0 + xr[j], iw = iw0 + xc[j];
       const bool pv = (xp + j * C::LPP) < C::PRPC && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W;
-      po[j] = pv ? (unsigned)(ih * d.W + iw) * 4u : OOB;
+      po[j] = pv ? (unsigned)(ih * d.W + iw) * EB : OOB;
     }
 #pragma unroll
     for (int i = 0; i < C::NCX; ++i) {
       const int c = xcph + C::CPAR * i;
-      const unsigned coff = c < ck ? (unsigned)c * (unsigned)HW * 4u : OOB;
+      const unsigned coff = c < ck ? (unsigned)c * (unsigned)HW * EB : OOB;
 #pragma unroll
-      for (int j = 0; j < C::NPOSX; ++j)
-        rx[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-            xrsrc, (po[j] == OOB || coff == OOB) ? OOB : img + po[j] + coff, 0, 0));
+      for (int j = 0; j < C::NPOSX; ++j) {
+        const unsigned vo = (po[j] == OOB || coff == OOB) ? OOB : img + po[j] + coff;
+        if constexpr (NAT)
+          rx[i][j] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(xrsrc, vo, 0, 0) << 16);
+        else
+          rx[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, vo, 0, 0));
+      }
     }
   };
   auto load_a = [&](int tile, float4 (&a)[C::MR][4]) {
@@ -466,14 +475,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_adirect_kernel(
     const int th = tt % tiles_h; tt /= tiles_h;
     const int n = tt;
     const int oh = th * C::TH + wave, ow = tw * C::TW + half * 16;
-    const unsigned img = (unsigned)(((size_t)n * d.out_ctot + d.out_coff + co0) * ohw * 4);   // uniform
-    const unsigned row = (unsigned)(((size_t)l31 * ohw + (size_t)oh * d.OW + ow) * 4);
+    const unsigned img = (unsigned)(((size_t)n * d.out_ctot + d.out_coff + co0) * ohw * EB);   // uniform
+    const unsigned row = (unsigned)(((size_t)l31 * ohw + (size_t)oh * d.OW + ow) * EB);
 #pragma unroll
     for (int m = 0; m < C::MR; ++m)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const bool v = va[m] && oh < d.OH && ow + 4 * q < d.OW;
-        const unsigned vo = v ? img + row + (unsigned)((size_t)m * 32 * ohw * 4) + 16u * q : OOB;
+      for (int q = 0; q < (NAT ? 2 : 4); ++q) {          // NAT: 16 pixels = two 16-byte loads of 8 bf16
+        const bool v = va[m] && oh < d.OH && ow + (NAT ? 8 : 4) * q < d.OW;
+        const unsigned vo = v ? img + row + (unsigned)((size_t)m * 32 * ohw * EB) + 16u * q : OOB;
         a[m][q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, vo, 0, 0));
       }
   };
@@ -492,6 +501,38 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_adirect_kernel(
   };
   auto mfma_tile = [&](const float* Xl, const float4 (&a)[C::MR][4], auto&& prefetch) {
     const float* xrow = Xl + wave * C::PC + half * 16;
+    if constexpr (NAT) {
+      constexpr int NP = (NT + 1) / 2, STEPS = 2 * NP;
+      float bv[2][2][8];
+      auto load_b = [&](int st, float (&dst)[2][8]) {
+        const int q = st / NP, t0 = (st - q * NP) * 2;
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+          if (t0 + g < NT) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dst[g][j] = xrow[off[t0 + g] + 8 * q + j];
+          }
+      };
+      load_b(0, bv[0]);
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) {
+        const int q = st / NP, t0 = (st - q * NP) * 2;
+        if (st + 1 < STEPS) load_b(st + 1, bv[(st + 1) & 1]);
+        if (st == 1) prefetch();
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+          if (t0 + g < NT) {
+            wg_bf16x8 bb;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bb[j] = (__bf16)bv[st & 1][g][j];       // exact: the values came from bf16
+#pragma unroll
+            for (int m = 0; m < C::MR; ++m)
+              acc[m][t0 + g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wg_bf16x8, a[m][q]), bb,
+                                                                      acc[m][t0 + g], 0, 0, 0);
+          }
+      }
+      return;
+    }
     if constexpr (BX3) {
       // A fragments of both k-blocks, split once per tile
       wg_bf16x8 ah[C::MR][2], am[C::MR][2], al[C::MR][2];
@@ -634,10 +675,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_adirect_kernel(
 // wave strides over 32-pixel segments on its own with a register double buffer, two workgroups
 // per CU keep ~128 KB of loads in flight (the LDS-staged kernel above manages ~40 KB for these
 // layers, which are HBM-bound).  Partial sums: 4 waves through LDS, then the slab reduction.
-template <int MR, int NT, bool BX3 = false>
+// NAT: bf16 operands in memory (mixed-precision path): a lane's 16 pixels are two 16-byte loads that
+// ARE the two k-blocks' MFMA fragments -- no conversion, one MFMA per product.
+template <int MR, int NT, bool BX3 = false, bool NAT = false>
 __global__ __launch_bounds__(256, 2) void wgrad1x1_direct_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ wsp,
     DlioConvDesc d, int co_tiles, int ci_chunks, int splits, int segs_per_img) {
+  constexpr int ED = NAT ? 2 : 1;                 // bf16 elements per float slot of the pointer arithmetic
   __shared__ float red[MR * NT * 16 * 64];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -659,15 +703,15 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_direct_kernel(
   for (int m = 0; m < MR; ++m) {
     const int co = co0 + m * 32 + l31;
     va[m] = co < d.Cout;
-    arow[m] = dy + ((size_t)d.out_coff + (va[m] ? co : 0)) * hw + half * 16;
+    arow[m] = dy + (((size_t)d.out_coff + (va[m] ? co : 0)) * hw + half * 16) / ED;
   }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int ci = c0 + t * 32 + l31;
     vb[t] = ci < d.Cin;
-    brow[t] = x + ((size_t)d.in_coff + (vb[t] ? ci : 0)) * hw + half * 16;
+    brow[t] = x + (((size_t)d.in_coff + (vb[t] ? ci : 0)) * hw + half * 16) / ED;
   }
-  const size_t a_img = (size_t)d.out_ctot * hw, b_img = (size_t)d.in_ctot * hw;
+  const size_t a_img = (size_t)d.out_ctot * hw / ED, b_img = (size_t)d.in_ctot * hw / ED;
 
   f32x16 acc[MR][NT];
 #pragma unroll
@@ -688,23 +732,34 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_direct_kernel(
   }
   auto load = [&](float4 (&a)[MR][4], float4 (&b)[NT][4], int g) {
     const int n = g / segs_per_img;
-    const size_t o = (size_t)(g - n * segs_per_img) * 32;
+    const size_t o = (size_t)(g - n * segs_per_img) * 32 / ED;
 #pragma unroll
     for (int m = 0; m < MR; ++m)
       if (va[m]) {
         const float4* p = reinterpret_cast<const float4*>(arow[m] + n * a_img + o);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) a[m][q] = p[q];
+        for (int q = 0; q < (NAT ? 2 : 4); ++q) a[m][q] = p[q];
       }
 #pragma unroll
     for (int t = 0; t < NT; ++t)
       if (vb[t]) {
         const float4* p = reinterpret_cast<const float4*>(brow[t] + n * b_img + o);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) b[t][q] = p[q];
+        for (int q = 0; q < (NAT ? 2 : 4); ++q) b[t][q] = p[q];
       }
   };
   auto compute = [&](const float4 (&a)[MR][4], const float4 (&b)[NT][4]) {
+    if constexpr (NAT) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wg_bf16x8, a[m][q]),
+                                                                __builtin_bit_cast(wg_bf16x8, b[t][q]), acc[m][t], 0, 0, 0);
+      return;
+    }
     if constexpr (BX3) {
       // split-bf16 MFMAs (conv_bx3.hip): k-block q = the lane's pixels 8q..8q+7 of both operands
 #pragma unroll
@@ -980,6 +1035,67 @@ int launch_1x1(const float* x, const float* dy, float* dw, float* wsp, const Dli
 }
 
 }  // namespace
+
+// bf16 x / dy (mixed-precision path): 3x3 stride-1 (dY-direct kernel) and 1x1 stride-1 (direct kernel),
+// fp32 slabs + the fixed-order reduction into dw (fp32, optionally accumulated)
+extern "C" int dlio_conv2d_wgrad_bf16(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes,
+                                      int accumulate, const DlioConvDesc* dp, dlio_stream_t stream) {
+  if (!x || !dy || !dw || !dp || !ws) return DLIO_EINVAL;
+  const DlioConvDesc& d = *dp;
+  if (d.SH != 1 || d.SW != 1) return DLIO_EUNSUP;
+  if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) != 0) return DLIO_EUNSUP;
+  if ((size_t)d.N * d.in_ctot * d.H * d.W * 2 >= 0xffffff00ull || (size_t)d.N * d.out_ctot * d.OH * d.OW * 2 >= 0xffffff00ull)
+    return DLIO_EUNSUP;
+  hipStream_t s = as_stream(stream);
+  float* wsp = reinterpret_cast<float*>(ws);
+  const float* xf = reinterpret_cast<const float*>(x);
+  const float* df = reinterpret_cast<const float*>(dy);
+  const double flops = 2.0 * d.N * (double)d.OH * d.OW * d.Cout * (double)d.Cin * d.KH * d.KW;
+  const double bytes = 2.0 * d.N * ((double)d.Cin * d.H * d.W + (double)d.Cout * d.OH * d.OW);
+  DlioProfScope prof(11, s, flops, bytes);
+  if (d.KH == 1 && d.KW == 1) {
+    Wg1Plan q;
+    if (!make_plan_1x1(d, q)) return DLIO_EUNSUP;
+    if (ws_bytes < q.ws_bytes) return DLIO_EWS;
+    const dim3 grid(q.co_tiles * q.ci_chunks * q.splits);
+#define W1(mr, nt) hipLaunchKernelGGL((wgrad1x1_direct_kernel<mr, nt, false, true>), grid, dim3(256), 0, s, xf, df, wsp, d, \
+                                      q.co_tiles, q.ci_chunks, q.splits, q.segs)
+    if (q.mr == 1 && q.nt == 1) W1(1, 1);
+    else if (q.mr == 1) W1(1, 2);
+    else if (q.nt == 1) W1(2, 1);
+    else W1(2, 2);
+#undef W1
+    int rc = dlio_check_launch();
+    if (rc) return rc;
+    const int64_t n = (int64_t)d.Cout * d.Cin;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(n, 64)), dim3(256), 0, s, wsp, dw, n, q.splits, accumulate);
+    return dlio_check_launch();
+  }
+  if (d.KH != 3 || d.KW != 3 || (d.OW & 7) || (d.W & 7)) return DLIO_EUNSUP;
+  WgPlan p;
+  if (!make_plan(d, p)) return DLIO_EUNSUP;
+  if (ws_bytes < p.ws_bytes) return DLIO_EWS;
+  if (p.mr != 1) return DLIO_EUNSUP;
+  const int blocks = p.co_tiles * p.ci_chunks * p.splits;
+  if (p.nt == 4) {
+    using A = WgACfg<3, 3, 4, 1>;
+    auto ka = conv_wgrad_adirect_kernel<3, 3, 4, 1, false, true>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, (int)A::LDS_BYTES);
+    hipLaunchKernelGGL(ka, dim3(blocks), dim3(256), A::LDS_BYTES, s, xf, df, wsp, d, p.co_tiles, p.ci_chunks, p.splits,
+                       p.tiles_w, p.tiles_h);
+  } else {
+    using A = WgACfg<3, 3, 5, 1>;
+    auto ka = conv_wgrad_adirect_kernel<3, 3, 5, 1, false, true>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, (int)A::LDS_BYTES);
+    hipLaunchKernelGGL(ka, dim3(blocks), dim3(256), A::LDS_BYTES, s, xf, df, wsp, d, p.co_tiles, p.ci_chunks, p.splits,
+                       p.tiles_w, p.tiles_h);
+  }
+  int rc = dlio_check_launch();
+  if (rc) return rc;
+  const int64_t n = (int64_t)d.Cout * d.Cin * 9;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(n, 64)), dim3(256), 0, s, wsp, dw, n, p.splits, accumulate);
+  return dlio_check_launch();
+}
 
 extern "C" size_t dlio_conv2d_wgrad_ws_bytes(const DlioConvDesc* d) {
   WgPlan p;

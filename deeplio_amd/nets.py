@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as Fh
+from . import mixed
 from . import ops
 from .misc import get_config_container
 
@@ -107,7 +108,10 @@ class Fire(nn.Module):
         for b in (sb, e1b, e3b):
             _bump(b, tr)
         up = getattr(self, "upsample", None)
-        out = Fh.FireFn.apply(x, s.weight, s.bias, sb.weight, sb.bias, sb.running_mean, sb.running_var,
+        bf16 = x.dtype == torch.bfloat16          # mixed-precision region (deeplio_amd.mixed): dispatch on the input
+        if bf16 and up is not None:
+            raise ValueError("Fire bypass 'complex' has no bf16 kernel (mixed precision supports None / 'simple')")
+        out = (mixed.FireFn if bf16 else Fh.FireFn).apply(x, s.weight, s.bias, sb.weight, sb.bias, sb.running_mean, sb.running_var,
                               e1.weight, e1.bias, e1b.weight, e1b.bias, e1b.running_mean, e1b.running_var,
                               e3.weight, e3.bias, e3b.weight, e3b.bias, e3b.running_mean, e3b.running_var,
                               tr, sb.momentum, sb.eps, self.residual, want_gap and up is None)
@@ -126,6 +130,10 @@ class SELayer(nn.Module):
                                 nn.Linear(in_features // reduction, in_features, bias=False), nn.Sigmoid())
 
     def forward(self, x, pool=None, gap=None):
+        if x.dtype == torch.bfloat16:
+            if pool is None:
+                raise ValueError("the bf16 SELayer exists fused with the max-pool behind it only (as PSEncoder uses it)")
+            return mixed.SEPoolFn.apply(x, self.fc[0].weight, self.fc[2].weight, pool, gap)
         return Fh.SEPoolFn.apply(x, self.fc[0].weight, self.fc[2].weight, pool, gap)
 
 
@@ -153,6 +161,11 @@ class PSEncoder(BaseNet):
     def __init__(self, input_shape, cfg, bn_d=0.1):
         super().__init__()
         self.bypass = cfg['bypass']
+        # 'bf16': activations / activation gradients of the Fire blocks are stored in bf16 (BASELINE
+        # configs[4], deeplio_amd.mixed); parameters, statistics and the stem stay fp32
+        self.precision = str(cfg.get('precision', 'fp32')).lower()
+        if self.precision not in ('fp32', 'bf16'):
+            raise ValueError("Wrong precision {} (fp32 or bf16)".format(self.precision))
         self.input_shape = input_shape
         c, h, w = input_shape
         self.conv1a = nn.Sequential(nn.Conv2d(c, 64, (3, 5), (1, 2), (1, 2)),
@@ -186,6 +199,8 @@ class PSEncoder(BaseNet):
         tr = self.training
         _bump(self.conv1a[1], tr)
         x = self.pool1(_cbr(x, self.conv1a[0], self.conv1a[1], tr))
+        if self.precision == 'bf16':
+            x = mixed.CastFn.apply(x)
         yield x
         for name, *_ in PS_BLOCKS:
             mods = list(getattr(self, name))
@@ -342,6 +357,11 @@ class FeatureNetSimple1(nn.Module):
 
 
 # ------------------------------------------------------------------------------ lidar feature nets
+def _gap(x):
+    """global average pool -> fp32 [N, C] (leaves the bf16 region of a mixed-precision encoder)"""
+    return (mixed.GapFn if x.dtype == torch.bfloat16 else Fh.GapFn).apply(x)
+
+
 class BaseLidarFeatNet(BaseNet):
     """lidar_feat_nets.py:12-43 + the shared two-stream forward of :73-237."""
     act = ops.ACT_RELU
@@ -393,21 +413,21 @@ class BaseLidarFeatNet(BaseNet):
                             ga = None
                 if fb.dim() == 4:
                     with torch.cuda.stream(self._side):
-                        fb = Fh.GapFn.apply(fb)
+                        fb = _gap(fb)
             else:
                 with torch.cuda.stream(self._side):
                     fb = self.encoder2(xb)
                     if fb.dim() == 4:
-                        fb = Fh.GapFn.apply(fb)
+                        fb = _gap(fb)
                 fa = self.encoder1(xa)
             if fa.dim() == 4:
-                fa = Fh.GapFn.apply(fa)
+                fa = _gap(fa)
             main.wait_stream(self._side)
             fb.record_stream(main)
         else:
             fa, fb = self.encoder1(xa), self.encoder2(xb)
             if fa.dim() == 4:
-                fa, fb = Fh.GapFn.apply(fa), Fh.GapFn.apply(fb)
+                fa, fb = _gap(fa), _gap(fb)
         if self.fusion == 'cat':
             y = Fh.Cat2Fn.apply(fa, fb)
         else:

@@ -97,7 +97,8 @@ class _PrepItemC(_ct.Structure):
 
 class _PrepCache:
     """mode 0 / 1: fp32-MFMA layouts (forward / data gradient) of any conv weight; mode 2 / 3: the
-    split-bf16 layouts (conv_bx3.hip) of 3x3 weights, forward / data gradient"""
+    split-bf16 layouts (conv_bx3.hip) of 3x3 / 1x1 weights, forward / data gradient; mode 4 / 5: the
+    native bf16 layouts of the mixed-precision path (conv_bf16.hip)"""
 
     def __init__(self):
         self.epoch = 0
@@ -109,6 +110,8 @@ class _PrepCache:
     @staticmethod
     def _floats(w, mode):
         Cout, Cin, KH, KW = w.shape
+        if mode >= 4:
+            return (lib.dlio_conv_bf16_prep_elems(Cout, Cin, KH * KW, mode - 4) + 1) // 2     # bf16 in fp32 storage
         if mode >= 2:
             return lib.dlio_conv_bx3_prep_floats(Cout, Cin, KH * KW, mode - 2)
         return lib.dlio_conv2d_prep_weight_floats(Cout, Cin, KH, KW, mode)
@@ -118,7 +121,7 @@ class _PrepCache:
         """index-space size of one item in its family's batched kernel"""
         Cout, Cin, KH, KW = w.shape
         if mode >= 2:
-            K, Nn = (Cin, Cout) if mode == 2 else (Cout, Cin)
+            K, Nn = (Cin, Cout) if mode in (2, 4) else (Cout, Cin)
             return KH * KW * ((K + 15) // 16) * Nn * 16
         return lib.dlio_conv2d_prep_weight_floats(Cout, Cin, KH, KW, mode)
 
@@ -137,7 +140,10 @@ class _PrepCache:
                 self._refresh_all(dev, cur)
             if e["epoch"] != self.epoch or e["version"] != w._version:     # newly registered / batching off
                 Cout, Cin, KH, KW = w.shape
-                if mode >= 2:
+                if mode >= 4:
+                    check(lib.dlio_conv_bf16_prep(_ptr(w), _ptr(e["out"]), Cout, Cin, KH * KW, mode - 4, _stream()),
+                          "conv_bf16_prep")
+                elif mode >= 2:
                     check(lib.dlio_conv_bx3_prep(_ptr(w), _ptr(e["out"]), Cout, Cin, KH * KW, mode - 2, _stream()),
                           "conv_bx3_prep")
                 else:
@@ -176,7 +182,8 @@ class _PrepCache:
             self.tables.pop((k[0], k[3] >> 1), None)
         done = []
         for family, fn, name in ((0, lib.dlio_conv2d_prep_weights_batched, "conv2d_prep_weights_batched"),
-                                 (1, lib.dlio_conv3x3_bx3_prep_batched, "conv3x3_bx3_prep_batched")):
+                                 (1, lib.dlio_conv3x3_bx3_prep_batched, "conv3x3_bx3_prep_batched"),
+                                 (2, lib.dlio_conv_bf16_prep_batched, "conv_bf16_prep_batched")):
             t = self._table(dev, family)
             if t is None:
                 continue

@@ -444,6 +444,58 @@ int dlio_velo_image(const float* proj_xyz, const float* proj_remission, const fl
                     const float* mean, int n_channels, int H, int W, int crop_top, int crop_left,
                     float* out, dlio_stream_t stream);
 
+/* ---- mixed precision (BASELINE configs[4]) ---------------------------------
+ * bf16 storage of the PointSeg encoders' activations and activation gradients (NCHW, channel slices
+ * as above), fp32 master weights, fp32 accumulation, fp32/fp64 BatchNorm statistics, fp32 weight
+ * gradients.  No reference counterpart (the reference is fp32 only); same call sites as the fp32
+ * entry points they mirror.  void* tensors are bf16; H*W must be a multiple of 8 (16-byte accesses).
+ *
+ * Convolutions (csrc/conv_bf16.hip): one v_mfma_f32_32x32x16_bf16 per product.  Weights are re-laid-out
+ * from the fp32 master copy into [tap][ceil(K/16)][N][16] bf16 (mode 0 forward: K = Cin, N = Cout;
+ * mode 1 data gradient: K = Cout, N = Cin, taps reversed); the batched form takes DlioPrepItem as
+ * dlio_conv3x3_bx3_prep_batched does.  bias fp32, residual / y bf16 (residual may alias y). */
+size_t dlio_conv_bf16_prep_elems(int Cout, int Cin, int taps, int mode);
+int dlio_conv_bf16_prep(const float* w, void* wt, int Cout, int Cin, int taps, int mode, dlio_stream_t stream);
+int dlio_conv_bf16_prep_batched(const DlioPrepItem* items_dev, int n_items, int64_t total, dlio_stream_t stream);
+int dlio_conv3x3_bf16_fwd(const void* x, const void* wt, const float* bias, const void* residual, void* y,
+                          const DlioConvDesc* desc, dlio_stream_t stream);
+int dlio_conv1x1_bf16_fwd(const void* x, const void* wt, const float* bias, const void* residual, void* y,
+                          const DlioConvDesc* desc, dlio_stream_t stream);
+/* dW (fp32, accumulated when accumulate != 0) from bf16 x and dy: 3x3 and 1x1 stride-1 layers; ws as
+ * dlio_conv2d_wgrad_ws_bytes(desc) */
+int dlio_conv2d_wgrad_bf16(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, int accumulate,
+                           const DlioConvDesc* desc, dlio_stream_t stream);
+/* train-mode BatchNorm (+ReLU, + residual, + plane averages of the stored output) over bf16:
+ * statistics and apply in two launches; eval_mode != 0: apply only, mean / invstd / scale are inputs
+ * (dlio_bn_eval_params).  ws: dlio_bf16_stats_ws_bytes(N, C, HW). */
+int dlio_bf16_stats_splits(int N, int C, int HW);
+size_t dlio_bf16_stats_ws_bytes(int N, int C, int HW);
+int dlio_bn_bf16_apply(const void* x, int N, int x_ctot, int x_coff, int C, int HW, int post_relu,
+                       const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                       float* running_var, float* mean, float* invstd, float* scale, const void* residual,
+                       int r_ctot, int r_coff, void* y, int y_ctot, int y_coff, float* gap_out, int gap_ctot,
+                       int gap_coff, int eval_mode, void* ws, size_t ws_bytes, dlio_stream_t stream);
+/* backward: reductions + dx (bf16), dgamma / dbeta (fp32, accumulated when accumulate != 0) */
+int dlio_bn_bf16_bwd(const void* dy, int dy_ctot, int dy_coff, const void* x, int x_ctot, int x_coff,
+                     const float* mean, const float* invstd, const float* scale, const float* beta, void* dx,
+                     int dx_ctot, int dx_coff, float* dgamma, float* dbeta, int accumulate, int N, int C, int HW,
+                     int post_relu, int use_batch_stats, void* ws, size_t ws_bytes, dlio_stream_t stream);
+/* 3x3 max-pool, padding 1, stride (1|2, 2), W % 16 == 0, with the fused SELayer scale (x_scale [N*C] fp32,
+ * nullable); idx uint8 = kh*3 + kw of the first maximum.  bwd: dx = x_scale * scatter(dy) + x_add[plane];
+ * bwd_dot: ds[plane] = sum dy * x[arg-max]. */
+int dlio_maxpool_bf16_fwd(const void* x, const float* x_scale, void* y, uint8_t* idx, int N, int C, int H, int W,
+                          int OH, int OW, int K, int SH, int SW, int PH, int PW, dlio_stream_t stream);
+int dlio_maxpool_bf16_bwd(const void* dy, const uint8_t* idx, const float* x_scale, const float* x_add, void* dx,
+                          int N, int C, int H, int W, int OH, int OW, int K, int SH, int SW, int PH, int PW,
+                          dlio_stream_t stream);
+int dlio_maxpool_bf16_bwd_dot(const void* dy, const uint8_t* idx, const void* x, float* ds, int N, int C, int H,
+                              int W, int OH, int OW, int K, int SH, int SW, int PH, int PW, dlio_stream_t stream);
+/* global average pool bf16 -> fp32 [N][C] and its backward fp32 -> bf16 */
+int dlio_gap_bf16_fwd(const void* x, int ctot, int coff, float* out, int N, int C, int HW, dlio_stream_t stream);
+int dlio_gap_bf16_bwd(const float* dout, void* dx, int N, int C, int HW, dlio_stream_t stream);
+/* dir 0: fp32 -> bf16 (round to nearest even); dir 1: bf16 -> fp32; n % 8 == 0 */
+int dlio_cast_bf16(const void* src, void* dst, int64_t n, int dir, dlio_stream_t stream);
+
 /* ---- optimizer ----------------------------------------------------------
  * torch.optim.Adam / SGD(momentum) / RMSprop / Adadelta as built by create_optimizer
  * (optimizer.py:4-16) over ONE flat parameter buffer: weight decay is L2 added
