@@ -9,6 +9,7 @@
 // fusion_nets.py:59-73, odom_feat_nets.py:18-37, deeplio_nets.py:57-90 and the input /
 // recurrent projections of nn.LSTM / nn.GRU (imu_feat_nets.py:63-70, odom_feat_nets.py:61-68).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -357,6 +358,130 @@ __global__ void nonfinite_kernel(const float* __restrict__ x, int64_t n, int32_t
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
+
+// ---- tall-M dense layers on the fp32 MFMA (v_mfma_f32_32x32x2_f32) --------------------------------
+// The IMU branch calls nn.Linear-shaped ops with M = B*T = 400..1600 rows (input projections of the
+// bi-LSTM / GRU over whole windows, the ImuFeatFC MLP): GEMMs of 0.05-0.2 GFLOP that the weight-streaming
+// kernels above (built for M = B*S = 16) execute at ~1 TFLOP/s, 50-90 us per launch, ~170 launches per
+// step.  Same results to fp32 round-off (an fmaf chain in k order per output), fixed summation order.
+//
+// forward: y[M][N] = act(x[M][K] W[N][K]^T + b + addend).  Workgroup = 2 x 2 waves = 64 x 64 outputs; a
+// lane (row l&31, half l>>5) reads FOUR consecutive k of its x row / W row per 16-byte load and feeds
+// four MFMA k-steps (k slot `half` of step e = element 8j + 4*half + e for both operands).
+__global__ __launch_bounds__(256) void linear_fwd_mfma_kernel(
+    const float* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ b,
+    const float* __restrict__ addend, int ldadd, float* __restrict__ y, int ldy, int M, int N, int K, int act,
+    int kvec) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
+  const int m0 = blockIdx.y * 64 + (wave >> 1) * 32, n0 = blockIdx.x * 64 + (wave & 1) * 32;
+  if (m0 >= M || n0 >= N) return;
+  const float* xr = x + (size_t)min(m0 + l31, M - 1) * ldx;
+  const float* wr = w + (size_t)min(n0 + l31, N - 1) * K;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  if (kvec) {
+#pragma unroll 2
+    for (int k0 = 4 * half; k0 < K; k0 += 8) {
+      const float4 a = *reinterpret_cast<const float4*>(xr + k0);
+      const float4 c = *reinterpret_cast<const float4*>(wr + k0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, c.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, c.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, c.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, c.w, acc, 0, 0, 0);
+    }
+  } else {
+    for (int k0 = 0; k0 < K; k0 += 2) {
+      const int k = k0 + half;
+      const float a = k < K ? xr[k] : 0.f, c = k < K ? wr[k] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, c, acc, 0, 0, 0);
+    }
+  }
+  const int n = n0 + l31;
+  if (n >= N) return;
+  const float bv = b ? b[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (m >= M) continue;
+    float v = acc[r] + bv;
+    if (addend) v += addend[(size_t)m * ldadd + n];
+    y[(size_t)m * ldy + n] = act_fwd(v, act);
+  }
+}
+
+// weight gradient: dW[N][K] (+)= dz[M][N]^T x[M][K], db[N] (+)= column sums of dz.  Workgroup = one
+// 32 x 32 tile of dW; its 4 waves take every 4th pair of rows (k slot `half` = row 2s + half), partial
+// tiles summed through LDS in wave order; the k-tile-0 workgroups also produce db.
+__global__ __launch_bounds__(256) void linear_wgrad_mfma_kernel(
+    const float* __restrict__ dz, int lddz, const float* __restrict__ x, int ldx, float* __restrict__ dw,
+    float* __restrict__ db, int M, int N, int K, int accumulate) {
+  __shared__ float red[16 * 64];
+  __shared__ float bred[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
+  const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int n = n0 + l31, k = k0 + l31;
+  const bool vn = n < N, vk = k < K;
+  const float* ap = dz + (vn ? n : 0);
+  const float* bp = x + (vk ? k : 0);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bsum = 0.f;
+  const int steps = (M + 1) >> 1;
+  int s = wave;
+  for (; s + 12 < steps; s += 16) {                 // 4 row pairs per iteration: 8 loads in flight
+    float a[4], c[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int m = 2 * (s + 4 * u) + half;
+      const bool vm = m < M;
+      a[u] = (vm && vn) ? ap[(size_t)m * lddz] : 0.f;
+      c[u] = (vm && vk) ? bp[(size_t)m * ldx] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], c[u], acc, 0, 0, 0);
+      bsum += a[u];
+    }
+  }
+  for (; s < steps; s += 4) {
+    const int m = 2 * s + half;
+    const bool vm = m < M;
+    const float a = (vm && vn) ? ap[(size_t)m * lddz] : 0.f;
+    const float c = (vm && vk) ? bp[(size_t)m * ldx] : 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, c, acc, 0, 0, 0);
+    bsum += a;
+  }
+  bred[wave][lane] = bsum;
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (w == 0) red[r * 64 + lane] = acc[r];
+        else red[r * 64 + lane] += acc[r];
+      }
+    }
+    __syncthreads();
+  }
+  // D tile: row (n) = (r & 3) + 8 (r >> 2) + 4 half, col (k) = lane & 31
+  for (int idx = threadIdx.x; idx < 32 * 32; idx += 256) {
+    const int row = idx >> 5, col = idx & 31;
+    if (n0 + row >= N || k0 + col >= K) continue;
+    const int hf = (row >> 2) & 1, r = (row & 3) + 4 * (row >> 3);
+    const float v = red[r * 64 + hf * 32 + col];
+    float* p = dw + (size_t)(n0 + row) * K + k0 + col;
+    *p = accumulate ? *p + v : v;
+  }
+  if (db && blockIdx.x == 0 && threadIdx.x < 32 && n0 + threadIdx.x < N) {
+    const int j = threadIdx.x;
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) t += bred[w][j] + bred[w][32 + j];
+    db[n0 + j] = accumulate ? db[n0 + j] + t : t;
+  }
+}
+
 }  // namespace
 
 extern "C" int dlio_linear_fwd(const float* x, int ldx, const float* w, const float* b,
@@ -364,6 +489,14 @@ extern "C" int dlio_linear_fwd(const float* x, int ldx, const float* w, const fl
                                int K, int act, dlio_stream_t stream) {
   if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0 || ldx < K || ldy < N || act < 0 || act > 4)
     return DLIO_EINVAL;
+  static const int mfma_from = getenv("DLIO_LINEAR_MFMA_M") ? atoi(getenv("DLIO_LINEAR_MFMA_M")) : 128;
+  if (M >= mfma_from) {                 // tall M (IMU windows): GEMM on the fp32 MFMA
+    const int kvec = (K % 8 == 0) && (ldx % 4 == 0) &&
+                     ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15) == 0;
+    hipLaunchKernelGGL(linear_fwd_mfma_kernel, dim3(cdiv(N, 64), cdiv(M, 64)), dim3(256), 0, as_stream(stream), x, ldx,
+                       w, b, addend, ldadd, y, ldy, M, N, K, act, kvec);
+    return dlio_check_launch();
+  }
   int grid = cdiv(N, 4);
   if (grid > 8192) grid = 8192;
   hipLaunchKernelGGL(linear_fwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, ldx, w, b,
@@ -412,6 +545,12 @@ extern "C" int dlio_linear_bwd_weight(const float* dz, int lddz, const float* x,
                                       dlio_stream_t stream) {
   if (!dz || !x || !dw || M <= 0 || N <= 0 || K <= 0 || lddz < N || ldx < K) return DLIO_EINVAL;
   hipStream_t s = as_stream(stream);
+  static const int mfma_from = getenv("DLIO_LINEAR_MFMA_M") ? atoi(getenv("DLIO_LINEAR_MFMA_M")) : 128;
+  if (M >= mfma_from) {                 // tall M: one launch for dW and db
+    hipLaunchKernelGGL(linear_wgrad_mfma_kernel, dim3(cdiv(K, 32), cdiv(N, 32)), dim3(256), 0, s, dz, lddz, x, ldx, dw,
+                       db, M, N, K, accumulate);
+    return dlio_check_launch();
+  }
   hipLaunchKernelGGL(linear_bwd_weight_kernel, dim3(cdiv(K, 256), cdiv(N, 4)), dim3(256), 0, s, dz,
                      lddz, x, ldx, dw, M, N, K, accumulate);
   int rc = dlio_check_launch();

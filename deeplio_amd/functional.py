@@ -5,6 +5,7 @@ the current HIP stream; torch supplies storage, views and the autograd tape only
 Activations are fp32 NCHW.  Concatenations (Fire's expand1x1 || expand3x3) are never
 materialised by a copy: both convolutions write channel slices of one buffer.
 """
+import contextlib
 import os
 
 import torch
@@ -132,6 +133,19 @@ def join_wgrad_stream():
         ws = _AUX.get((cur.device.index, "wgrad@%x" % cur.cuda_stream))
         if ws is not None:
             cur.wait_stream(ws)
+
+
+_RNN_DIR_FORK = [os.environ.get("DLIO_RNN_DIR_STREAM", "1") != "0"]
+
+
+def _rnn_dir_stream(like):
+    """companion stream for the reverse direction of a bidirectional RNN layer (None = run inline): the
+    two directions are independent, latency-bound chains (a persistent kernel of 2 workgroups per
+    direction), so running them side by side halves the branch's critical path"""
+    if not (_RNN_DIR_FORK[0] and like.is_cuda):
+        return None
+    cur = torch.cuda.current_stream()
+    return aux_stream(like.device, "rnndir@%x" % cur.cuda_stream)
 
 
 def _forked(ws, fn, *tensors):
@@ -773,31 +787,45 @@ class RNNFn(Function):
         state_c = [[None] * D for _ in range(L)]
         saved = []          # per segment: per layer: dict
         tops = _new((B, Sg, T, D * H), x)
+        side = _rnn_dir_stream(x) if D == 2 else None
+        cur = torch.cuda.current_stream() if side is not None else None
         for s in range(Sg):
             inp = x[:, s].contiguous().view(rows, I)
             seg = []
             for l in range(L):
                 out_l = _new((rows, D * H), dev)
                 rec = {"inp": inp, "dirs": []}
+                # every buffer is allocated on the caller's stream; only launches move to the companion
+                bufs = []
+                for d in range(D):
+                    bb = {"gx": _new((rows, G * H), dev), "hp": _new((rows, H), dev), "gates": _new((rows, 4 * H), dev),
+                          "hT": _new((B, H), dev)}
+                    if mode == "lstm":
+                        bb["cs"], bb["cT"] = _new((rows, H), dev), _new((B, H), dev)
+                    bufs.append(bb)
+                if side is not None:
+                    side.wait_stream(cur)
                 for d in range(D):
                     w_ih, w_hh, b_ih, b_hh = W[l][d]
-                    gx = ops.linear_fwd(inp, w_ih, b_ih, M=rows)
-                    hp = _new((rows, H), dev)
-                    gates = _new((rows, 4 * H), dev)
-                    hT = _new((B, H), dev)
+                    bb = bufs[d]
                     h0 = state_h[l][d]
-                    if mode == "lstm":
-                        cs, cT = _new((rows, H), dev), _new((B, H), dev)
-                        c0 = state_c[l][d]
-                        ops.lstm_seq_fwd(gx, w_hh, b_hh, h0, c0, out_l, d * H, D * H, cs, hp, gates,
-                                         hT, cT, T, B, H, 1, T, d == 1)
-                        rec["dirs"].append({"gates": gates, "cs": cs, "hp": hp, "c0": c0})
-                        state_c[l][d] = cT
-                    else:
-                        ops.gru_seq_fwd(gx, w_hh, b_hh, h0, out_l, d * H, D * H, hp, gates, hT, T, B,
-                                        H, 1, T, d == 1)
-                        rec["dirs"].append({"gates": gates, "hp": hp})
-                    state_h[l][d] = hT
+                    with (torch.cuda.stream(side) if (side is not None and d == 1) else contextlib.nullcontext()):
+                        ops.linear_fwd(inp, w_ih, b_ih, M=rows, out=bb["gx"])
+                        if mode == "lstm":
+                            c0 = state_c[l][d]
+                            ops.lstm_seq_fwd(bb["gx"], w_hh, b_hh, h0, c0, out_l, d * H, D * H, bb["cs"], bb["hp"],
+                                             bb["gates"], bb["hT"], bb["cT"], T, B, H, 1, T, d == 1)
+                            rec["dirs"].append({"gates": bb["gates"], "cs": bb["cs"], "hp": bb["hp"], "c0": c0})
+                            state_c[l][d] = bb["cT"]
+                        else:
+                            ops.gru_seq_fwd(bb["gx"], w_hh, b_hh, h0, out_l, d * H, D * H, bb["hp"], bb["gates"],
+                                            bb["hT"], T, B, H, 1, T, d == 1)
+                            rec["dirs"].append({"gates": bb["gates"], "hp": bb["hp"]})
+                    state_h[l][d] = bb["hT"]
+                if side is not None:
+                    cur.wait_stream(side)
+                    for t in list(bufs[1].values()) + [inp, out_l]:
+                        t.record_stream(side)
                 rec["out"] = out_l
                 if l + 1 < L and training and p > 0.:
                     off = _DROPOUT_STATE["offset"]
@@ -828,7 +856,8 @@ class RNNFn(Function):
         outs = [None] * len(weights)       # where the kernels write
         first = [True] * len(weights)
 
-        def acc_w(slot, dz, lddz, xin, ldx, N_, K, with_bias_slot):
+        def ensure_w(slot, N_, K, with_bias_slot):
+            """gradient buffers of one weight / bias pair (allocated on the caller's stream)"""
             wi = slot
             if outs[wi] is None:
                 ow, aw_, rw = _sink(weights[wi], (N_, K), dev)
@@ -840,6 +869,9 @@ class RNNFn(Function):
                 outs[wi], outs[with_bias_slot] = ow, ob
                 grads[wi], grads[with_bias_slot] = rw, rb
                 first[wi] = not aw_        # sunk gradients accumulate from the first call on
+
+        def acc_w(slot, dz, lddz, xin, ldx, N_, K, with_bias_slot):
+            wi = slot
             # (forking these onto the weight-gradient stream was measured: 34.7 vs 33.5 ms/step)
             ops.linear_bwd_weight(dz, xin, rows, N_, K, dw=outs[wi], db=outs[with_bias_slot],
                                   lddz=lddz, ldx=ldx, accumulate=not first[wi])
@@ -848,6 +880,8 @@ class RNNFn(Function):
         dstate_h = [[None] * D for _ in range(L)]
         dstate_c = [[None] * D for _ in range(L)]
         dx = _new((B, Sg, T, I), dev) if ctx.needs_input_grad[0] else None
+        side = _rnn_dir_stream(dtops) if D == 2 else None
+        cur = torch.cuda.current_stream() if side is not None else None
         for s in reversed(range(Sg)):
             seg = saved[s]
             dout = _new((rows, D * H), dev)
@@ -858,30 +892,48 @@ class RNNFn(Function):
                 K_in = rec["inp"].shape[1]
                 need_dinp = l > 0 or dx is not None
                 dinp = _new((rows, K_in), dev) if need_dinp else None
+                bufs = []
+                for d in range(D):
+                    # gradient w.r.t. the state a segment started from: wanted by the segment before
+                    # it; segment 0 started from zeros
+                    bb = {"dh0": _new((B, H), dev) if s > 0 else None}
+                    if mode == "lstm":
+                        bb["dg"] = _new((rows, 4 * H), dev)
+                        bb["dc0"] = _new((B, H), dev) if s > 0 else None
+                    else:
+                        bb["dgx"], bb["dgh"] = _new((rows, 3 * H), dev), _new((rows, 3 * H), dev)
+                    bufs.append(bb)
+                    ensure_w((l * D + d) * 4 + 0, G * H, K_in, (l * D + d) * 4 + 2)
+                    ensure_w((l * D + d) * 4 + 1, G * H, H, (l * D + d) * 4 + 3)
+                if side is not None:
+                    side.wait_stream(cur)
                 for d in range(D):
                     w_ih, w_hh, b_ih, b_hh = W[l][d]
                     base = (l * D + d) * 4
                     sv = rec["dirs"][d]
-                    # gradient w.r.t. the state a segment started from: wanted by the segment before
-                    # it; segment 0 started from zeros
-                    dh0 = _new((B, H), dev) if s > 0 else None
-                    if mode == "lstm":
-                        dg = _new((rows, 4 * H), dev)
-                        dc0 = _new((B, H), dev) if s > 0 else None
-                        ops.lstm_seq_bwd(dout, d * H, D * H, dstate_h[l][d], dstate_c[l][d],
-                                         sv["gates"], sv["cs"], sv["c0"], w_hh, dg, dh0, dc0, T, B,
-                                         H, 1, T, d == 1)
-                        dgx = dgh = dg
-                        dstate_c[l][d] = dc0
-                    else:
-                        dgx, dgh = _new((rows, 3 * H), dev), _new((rows, 3 * H), dev)
-                        ops.gru_seq_bwd(dout, d * H, D * H, dstate_h[l][d], sv["gates"], sv["hp"],
-                                        w_hh, dgx, dgh, dh0, T, B, H, 1, T, d == 1)
-                    dstate_h[l][d] = dh0
-                    acc_w(base + 0, dgx, G * H, rec["inp"], K_in, G * H, K_in, base + 2)
-                    acc_w(base + 1, dgh, G * H, sv["hp"], H, G * H, H, base + 3)
-                    if need_dinp:
-                        ops.linear_bwd_data(dgx, w_ih, rows, out=dinp, accumulate=d > 0)
+                    bb = bufs[d]
+                    # the two directions are independent until their input gradients are summed: the
+                    # reverse direction's recurrence and weight gradients run on a companion stream
+                    with (torch.cuda.stream(side) if (side is not None and d == 1) else contextlib.nullcontext()):
+                        if mode == "lstm":
+                            ops.lstm_seq_bwd(dout, d * H, D * H, dstate_h[l][d], dstate_c[l][d],
+                                             sv["gates"], sv["cs"], sv["c0"], w_hh, bb["dg"], bb["dh0"], bb["dc0"], T, B,
+                                             H, 1, T, d == 1)
+                            bb["dgx"] = bb["dgh"] = bb["dg"]
+                            dstate_c[l][d] = bb["dc0"]
+                        else:
+                            ops.gru_seq_bwd(dout, d * H, D * H, dstate_h[l][d], sv["gates"], sv["hp"],
+                                            w_hh, bb["dgx"], bb["dgh"], bb["dh0"], T, B, H, 1, T, d == 1)
+                        dstate_h[l][d] = bb["dh0"]
+                        acc_w(base + 0, bb["dgx"], G * H, rec["inp"], K_in, G * H, K_in, base + 2)
+                        acc_w(base + 1, bb["dgh"], G * H, sv["hp"], H, G * H, H, base + 3)
+                if side is not None:
+                    cur.wait_stream(side)
+                    for t in [v for v in bufs[1].values() if v is not None] + [dout]:
+                        t.record_stream(side)
+                if need_dinp:
+                    for d in range(D):
+                        ops.linear_bwd_data(bufs[d]["dgx"], W[l][d][0], rows, out=dinp, accumulate=d > 0)
                 if l > 0:
                     prev = seg[l - 1]
                     dout = ops.dropout_bwd(dinp, prev["mask"], p) if "mask" in prev else dinp

@@ -287,7 +287,10 @@ def test_gap_and_channel_scale(dev):
 
 
 @pytest.mark.parametrize("M,N,K", [(16, 128, 768), (16, 4096, 256), (5, 3, 1024), (100, 64, 6),
-                                   (37, 130, 50)])
+                                   (37, 130, 50),
+                                   # tall M (IMU windows: B*T rows): the fp32-MFMA kernels of dense.hip
+                                   (400, 512, 6), (400, 512, 256), (400, 512, 128), (801, 130, 50), (1600, 96, 512),
+                                   (129, 33, 8)])
 @pytest.mark.parametrize("act", [0, 1, 2, 3, 4])
 def test_linear_fwd_bwd(dev, M, N, K, act):
     from deeplio_amd import ops
@@ -308,6 +311,27 @@ def test_linear_fwd_bwd(dev, M, N, K, act):
     assert rel_err(dx, xr.grad) < TOL
     assert rel_err(dw, wr.grad) < TOL
     assert rel_err(db, br.grad) < TOL
+
+
+def test_linear_tall_m_strided_accumulate(dev):
+    """the MFMA kernels with leading dimensions larger than the logical widths (LSTM gate buffers),
+    an addend, and accumulation into existing dW / db"""
+    from deeplio_amd import ops
+    g = _g(21)
+    M, N, K, ldx, lddz = 400, 384, 128, 160, 512
+    xb, wz = torch.randn(M, ldx, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K)
+    b, add = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    x = xb[:, :K]
+    y = ops.linear_fwd(xb.to(dev), wz.to(dev), b.to(dev), ops.ACT_TANH, addend=add.to(dev), M=M, ldx=ldx)
+    ref = torch.tanh(x.double() @ wz.double().t() + b.double() + add.double())
+    assert rel_err(y, ref) < TOL
+    dzb = torch.randn(M, lddz, generator=g)
+    dz = dzb[:, :N]
+    dw0, db0 = torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    dw, db = dw0.clone().to(dev), db0.clone().to(dev)
+    ops.linear_bwd_weight(dzb.to(dev), xb.to(dev), M, N, K, dw=dw, db=db, lddz=lddz, ldx=ldx, accumulate=True)
+    assert rel_err(dw, dw0.double() + dz.double().t() @ x.double()) < TOL
+    assert rel_err(db, db0.double() + dz.double().sum(0)) < TOL
 
 
 def test_elementwise_dropout_nonfinite(dev):

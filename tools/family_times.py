@@ -16,11 +16,11 @@ FAMILIES = [
     ("conv3x3 wgrad", ("conv_wgrad_adirect",)),
     ("conv1x1 wgrad", ("wgrad1x1_",)),
     ("other wgrad + slab reduce", ("conv_wgrad_kernel", "wgrad_reduce_kernel")),
-    ("BN fwd statistics", ("chan_reduce_kernel<0",)),
-    ("BN fwd apply", ("bn_plane_apply_kernel", "bn_apply_kernel")),
-    ("BN bwd reduce", ("chan_reduce_kernel<1", "chan_reduce_kernel<2")),
-    ("BN bwd apply", ("bn_plane_bwd_kernel", "bn_bwd_apply_kernel")),
-    ("max-pool / SE scale", ("maxpool", "chan_scale", "gap_")),
+    ("BN fwd statistics", ("chan_reduce_kernel<0", "bn16_reduce_kernel<0")),
+    ("BN fwd apply", ("bn_plane_apply_kernel", "bn_apply_kernel", "bn16_plane_apply")),
+    ("BN bwd reduce", ("chan_reduce_kernel<1", "chan_reduce_kernel<2", "bn16_reduce_kernel<1")),
+    ("BN bwd apply", ("bn_plane_bwd_kernel", "bn_bwd_apply_kernel", "bn16_plane_bwd")),
+    ("max-pool / SE scale", ("maxpool", "chan_scale", "gap_", "pool16_", "gap16_", "cast_")),
     ("linear (RNN projections, SE fc, heads)", ("linear_", "col_sum_kernel", "act_bwd_kernel")),
     ("LSTM/GRU recurrences", ("lstm_", "gru_", "init_state")),
     ("optimizer + weight re-layout", ("adam_kernel", "sgd_kernel", "rmsprop", "adadelta", "prep_")),
