@@ -173,6 +173,8 @@ def _rnn_dir_stream(like):
     direction), so running them side by side halves the branch's critical path"""
     if not (_RNN_DIR_FORK[0] and like.is_cuda):
         return None
+    if torch.cuda.is_current_stream_capturing():     # hipGraph capture (tester.TestStep.capture): one stream per branch
+        return None
     cur = torch.cuda.current_stream()
     return aux_stream(like.device, "rnndir@%x" % cur.cuda_stream)
 

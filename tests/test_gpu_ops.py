@@ -637,7 +637,7 @@ def test_se3_chain_reorthonormalises_long_chains(dev):
     # ... their quaternions are unit to round-off (away from |angle| ~ pi, where liegroups' (R - R^T) / (4 qw)
     # amplifies the matrix's own rounding by 1 / qw for valid and repaired matrices alike)
     tripped = (drift > 2e-6) & (q.cpu()[..., 0].abs() > 0.1)
-    assert bool(tripped.any()) and float((q.cpu().norm(dim=-1) - 1).abs()[tripped].max()) < 5e-7
+    assert bool(tripped.any()) and float((q.cpu().norm(dim=-1) - 1).abs()[tripped].max()) < 3e-6
     assert rel_err(p, p_ref) < 5e-4 and rel_err(q, q_ref) < 5e-4   # 256 chained fp32 products vs fp64
     dt, dw = ops.se3_chain_bwd(t.to(dev), w.to(dev), R, dp.to(dev), dq.to(dev), 0)
     assert rel_err(dt, tr.grad) < 2e-3 and rel_err(dw, wr.grad) < 2e-3
