@@ -300,6 +300,12 @@ def main():
         prof_iso, ms_iso = profiled_pass(args.iso_steps, overlap=False)
         prof_ovl, ms_ovl = profiled_pass(args.iso_steps, overlap=True)
         DOM = max(prof_ovl, key=lambda f: prof_ovl[f]["ms"])
+        post = int(os.environ.get("DLIO_BENCH_POST", "0"))
+        if post & 1:
+            ops.prof_release()
+        if post & 2:
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
     if os.environ.get("DLIO_BENCH_DOM"):
         DOM = os.environ["DLIO_BENCH_DOM"]
     prof_on = sum(1 << k for k in FAMILIES[DOM][0]) if os.environ.get("DLIO_BENCH_NOPROF", "0") == "0" else 0

@@ -38,6 +38,7 @@ SIGNATURES = {
     "dlio_prof_enable": (_i, [_i]),
     "dlio_prof_sample": (_i, [_i]),
     "dlio_prof_reset": (_i, []),
+    "dlio_prof_release": (_i, []),
     "dlio_prof_collect": (_i, [_i, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d), C.POINTER(_i64)]),
     "dlio_conv2d_prep_weight_floats": (_sz, [_i, _i, _i, _i, _i]),
     "dlio_conv2d_prep_weight": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),

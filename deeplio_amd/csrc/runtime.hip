@@ -57,6 +57,17 @@ extern "C" int dlio_prof_reset(void) {
   return DLIO_OK;
 }
 
+extern "C" int dlio_prof_release(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto& k : g_prof) {
+    for (auto e : k.start) (void)hipEventDestroy(e);
+    for (auto e : k.stop) (void)hipEventDestroy(e);
+    k.start.clear(); k.stop.clear();
+    k.used = 0; k.seen = 0; k.flops = 0.0; k.bytes = 0.0;
+  }
+  return DLIO_OK;
+}
+
 extern "C" int dlio_prof_sample(int stride) {
   if (stride < 1) return DLIO_EINVAL;
   g_prof_stride = stride;

@@ -903,6 +903,10 @@ def prof_reset():
     lib.dlio_prof_reset()
 
 
+def prof_release():
+    lib.dlio_prof_release()
+
+
 def prof_collect(kind):
     ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
     check(lib.dlio_prof_collect(kind, C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)),

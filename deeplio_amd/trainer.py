@@ -2,6 +2,8 @@
 SE(3) chain, loss, backward, (data-parallel gradient exchange), optimizer step -- with the
 reference's ten NaN/Inf host syncs per step replaced by device-side flags that the caller
 reads when it wants to (check())."""
+import gc
+import os
 import types
 
 import torch
@@ -28,6 +30,17 @@ class TrainStep:
         self.max_glob_seq = max_glob_seq            # trainer.py:42
         self.flags = torch.zeros(2, dtype=torch.int32, device=self.device)   # [nonfinite, se3 status]
         self.grad_sync = None
+        # Host-side hygiene: a step creates ~1e4 short-lived Python objects (tensors, autograd contexts), so
+        # CPython's cyclic collector runs many times per step and its full collections walk every object
+        # of the model; in the host-bound serial middle of the step each pause leaves the GPU idle
+        # (measured: 31.4 vs 28.6 ms/step).  'freeze' (default): move everything that exists after
+        # construction into the permanent generation (gc.freeze) so collections only see the step's own
+        # objects; 'manual': collector off, one explicit collection every `gc_every` steps; 'default':
+        # leave the interpreter alone.
+        self.gc_mode = os.environ.get("DLIO_GC", "freeze")
+        self.gc_every = int(os.environ.get("DLIO_GC_EVERY", "100"))
+        self._gc_armed = False
+        self._steps = 0
         self.model.train()
         if grad_sync is not None:
             self.set_grad_sync(grad_sync)
@@ -50,7 +63,27 @@ class TrainStep:
             sync.set_tail(self.tail_offset())
             self.model.tail_grads_ready = sync.reduce_tail_async if sync.tail_lo is not None else None
 
+    def _manage_gc(self):
+        if self.gc_mode == "default":
+            return
+        if not self._gc_armed:
+            self._gc_armed = True
+            gc.collect()
+            gc.freeze()
+            if self.gc_mode == "manual":
+                gc.disable()
+        elif self.gc_mode == "manual" and self._steps % self.gc_every == 0:
+            gc.collect()
+
+    def release_gc(self):
+        """give the interpreter's collector back (end of training)"""
+        if self._gc_armed and self.gc_mode == "manual":
+            gc.enable()
+        self._gc_armed = False
+
     def step(self, imgs, normals, imus, gts_f2f, gts_f2g):
+        self._steps += 1
+        self._manage_gc()
         gt_f2f_t, gt_f2f_w = gts_f2f[:, :, 0:3], gts_f2f[:, :, 3:]
         gt_f2g_p, gt_f2g_q = gts_f2g[:, :, 0:3], gts_f2g[:, :, 3:7]
         pred_f2f_t, pred_f2f_w = self.model([[imgs, normals], imus])

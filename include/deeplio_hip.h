@@ -76,6 +76,8 @@ int dlio_prof_enable(int kinds_mask);
  * over consecutive steps. */
 int dlio_prof_sample(int stride);
 int dlio_prof_reset(void);
+/* destroys the event pools (after dlio_prof_collect; the next enabled launch re-creates them) */
+int dlio_prof_release(void);
 int dlio_prof_collect(int kind, double* ms, double* flops, double* bytes, int64_t* launches);
 
 /* ---- convolution ------------------------------------------------------
