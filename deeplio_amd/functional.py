@@ -45,6 +45,35 @@ _JOIN_PENDING = [False]
 _WGRAD_FORK = [os.environ.get("DLIO_WGRAD_STREAM", "1") != "0"]
 
 
+class on_stream:
+    """`with torch.cuda.stream(s)` without its Python layers (current_stream() + two Stream objects +
+    device guards: ~25 us per use, ~120 uses per step): set torch's current stream through the C entry
+    points and restore the previous one"""
+    __slots__ = ("s", "prev")
+
+    def __init__(self, s):
+        self.s = s
+
+    def __enter__(self):
+        self.prev = torch._C._cuda_getCurrentStream(self.s.device_index)
+        torch._C._cuda_setStream(stream_id=self.s.stream_id, device_index=self.s.device_index,
+                                 device_type=self.s.device_type)
+        return self.s
+
+    def __exit__(self, *exc):
+        p = self.prev
+        torch._C._cuda_setStream(stream_id=p[0], device_index=p[1], device_type=p[2])
+        return False
+
+
+def current_stream_obj(device_index=None):
+    """torch.cuda.current_stream() through the C getter"""
+    if device_index is None:
+        device_index = torch._C._cuda_getDevice()
+    p = torch._C._cuda_getCurrentStream(device_index)
+    return torch.cuda.Stream(stream_id=p[0], device_index=p[1], device_type=p[2])
+
+
 def aux_stream(device, name):
     key = (device.index if device.index is not None else torch.cuda.current_device(), name)
     s = _AUX.get(key)
@@ -151,8 +180,7 @@ def _wgrad_stream(like):
     """companion stream of the current one for weight-gradient kernels (None = run inline)"""
     if not (_WGRAD_FORK[0] and like.is_cuda):
         return None
-    cur = torch.cuda.current_stream()
-    return aux_stream(like.device, "wgrad@%x" % cur.cuda_stream)
+    return aux_stream(like.device, "wgrad@%x" % ops.raw_stream())
 
 
 def join_wgrad_stream():
@@ -175,14 +203,13 @@ def _rnn_dir_stream(like):
         return None
     if torch.cuda.is_current_stream_capturing():     # hipGraph capture (tester.TestStep.capture): one stream per branch
         return None
-    cur = torch.cuda.current_stream()
-    return aux_stream(like.device, "rnndir@%x" % cur.cuda_stream)
+    return aux_stream(like.device, "rnndir@%x" % ops.raw_stream())
 
 
 def _forked(ws, fn, *tensors):
     """run fn() (a launch whose only output is a sunk gradient) on the companion stream ws"""
-    ws.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(ws):
+    ws.wait_stream(current_stream_obj(ws.device_index))
+    with on_stream(ws):
         fn()
     for t in tensors:
         t.record_stream(ws)
@@ -819,7 +846,7 @@ class RNNFn(Function):
         saved = []          # per segment: per layer: dict
         tops = _new((B, Sg, T, D * H), x)
         side = _rnn_dir_stream(x) if D == 2 else None
-        cur = torch.cuda.current_stream() if side is not None else None
+        cur = current_stream_obj() if side is not None else None
         for s in range(Sg):
             inp = x[:, s].contiguous().view(rows, I)
             seg = []
@@ -840,7 +867,7 @@ class RNNFn(Function):
                     w_ih, w_hh, b_ih, b_hh = W[l][d]
                     bb = bufs[d]
                     h0 = state_h[l][d]
-                    with (torch.cuda.stream(side) if (side is not None and d == 1) else contextlib.nullcontext()):
+                    with (on_stream(side) if (side is not None and d == 1) else contextlib.nullcontext()):
                         ops.linear_fwd(inp, w_ih, b_ih, M=rows, out=bb["gx"])
                         if mode == "lstm":
                             c0 = state_c[l][d]
@@ -912,7 +939,7 @@ class RNNFn(Function):
         dstate_c = [[None] * D for _ in range(L)]
         dx = _new((B, Sg, T, I), dev) if ctx.needs_input_grad[0] else None
         side = _rnn_dir_stream(dtops) if D == 2 else None
-        cur = torch.cuda.current_stream() if side is not None else None
+        cur = current_stream_obj() if side is not None else None
         for s in reversed(range(Sg)):
             seg = saved[s]
             dout = _new((rows, D * H), dev)
@@ -945,7 +972,7 @@ class RNNFn(Function):
                     bb = bufs[d]
                     # the two directions are independent until their input gradients are summed: the
                     # reverse direction's recurrence and weight gradients run on a companion stream
-                    with (torch.cuda.stream(side) if (side is not None and d == 1) else contextlib.nullcontext()):
+                    with (on_stream(side) if (side is not None and d == 1) else contextlib.nullcontext()):
                         if mode == "lstm":
                             ops.lstm_seq_bwd(dout, d * H, D * H, dstate_h[l][d], dstate_c[l][d],
                                              sv["gates"], sv["cs"], sv["c0"], w_hh, bb["dg"], bb["dh0"], bb["dc0"], T, B,

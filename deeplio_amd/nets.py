@@ -401,7 +401,7 @@ class BaseLidarFeatNet(BaseNet):
                 fa = fb = None
                 while ga is not None or gb is not None:
                     if gb is not None:
-                        with torch.cuda.stream(self._side):
+                        with Fh.on_stream(self._side):
                             try:
                                 fb = next(gb)
                             except StopIteration:
@@ -412,10 +412,10 @@ class BaseLidarFeatNet(BaseNet):
                         except StopIteration:
                             ga = None
                 if fb.dim() == 4:
-                    with torch.cuda.stream(self._side):
+                    with Fh.on_stream(self._side):
                         fb = _gap(fb)
             else:
-                with torch.cuda.stream(self._side):
+                with Fh.on_stream(self._side):
                     fb = self.encoder2(xb)
                     if fb.dim() == 4:
                         fb = _gap(fb)
@@ -704,7 +704,7 @@ class DeepLIO(BaseNet):
             side = self._side
             main = torch.cuda.current_stream()
             side.wait_stream(main)
-            with torch.cuda.stream(side):
+            with Fh.on_stream(side):
                 feat_i = self.imu_feat_net(imu_meas)
         elif self.imu_feat_net is not None:     # same issue order (dropout counter) as the overlapped path
             feat_i = self.imu_feat_net(imu_meas)

@@ -20,8 +20,16 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+def raw_stream():
+    """handle (int) of torch's current HIP stream on the current device.  torch.cuda.current_stream()
+    builds a Python Stream object through four layers of device-index helpers (~9 us; at ~1100 launches
+    per step that was 5 ms of host time on a step whose host side is nearly critical) -- this is the
+    C-level getter the same call ends in"""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(raw_stream())
 
 
 def _chk(t, dtype=torch.float32):
@@ -41,8 +49,7 @@ _WS = {}
 def workspace(nbytes, device, slot=0):
     """Caller-owned scratch handed to the library (grown geometrically, reused).  One slot
     per (device, stream, slot) so concurrent streams never share scratch."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream().cuda_stream, slot)
+    key = (device.index if device.index is not None else torch._C._cuda_getDevice(), raw_stream(), slot)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         size = max(int(nbytes * 1.25), 1 << 20)
@@ -134,8 +141,10 @@ class _PrepCache:
                      out=torch.empty(self._floats(w, mode), dtype=torch.float32, device=w.device))
             self.entries[key] = e
             self.tables.pop((dev, mode >> 1), None)
-        cur = torch.cuda.current_stream()
+        cur = None
+        cur_raw = raw_stream()
         if e["epoch"] != self.epoch or e["version"] != w._version:
+            cur = torch.cuda.current_stream()
             if self.batched and e["epoch"] >= 0:          # a known weight went stale: refresh them all
                 self._refresh_all(dev, cur)
             if e["epoch"] != self.epoch or e["version"] != w._version:     # newly registered / batching off
@@ -149,12 +158,12 @@ class _PrepCache:
                 else:
                     check(lib.dlio_conv2d_prep_weight(_ptr(w), _ptr(e["out"]), Cout, Cin, KH, KW, mode, _stream()),
                           "conv2d_prep_weight")
-                e.update(epoch=self.epoch, version=w._version, stream=cur.cuda_stream, event=None)
-        elif e["stream"] != cur.cuda_stream and e["event"] is not None:
+                e.update(epoch=self.epoch, version=w._version, stream=cur_raw, event=None)
+        elif e["stream"] != cur_raw and e["event"] is not None:
             # prepped on another stream in this epoch: one wait per (stream, refresh event)
-            if self.waited.get(cur.cuda_stream) is not e["event"]:
-                cur.wait_event(e["event"])
-                self.waited[cur.cuda_stream] = e["event"]
+            if self.waited.get(cur_raw) is not e["event"]:
+                torch.cuda.current_stream().wait_event(e["event"])
+                self.waited[cur_raw] = e["event"]
         return e["out"]
 
     def _table(self, dev, family):
