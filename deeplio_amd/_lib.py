@@ -108,7 +108,7 @@ SIGNATURES = {
     "dlio_gt_relative": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "dlio_chan_stats_splits": (_i, [_i, _i, _i]),
     "dlio_bn_train_apply": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _i, _i,
-                                 _p, _i, _i, _p, _i, _i, _p, _sz, _i, _d, _p]),
+                                 _p, _i, _i, _p, _i, _i, _p, _sz, _i, _d, _p, _p, _p, _p]),
     "dlio_bn_bwd": (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i,
                          _p, _sz, _i, _d, _p, _p]),
     "dlio_scan_project_ws_bytes": (_sz, [_i, _i]),

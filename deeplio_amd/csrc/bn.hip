@@ -330,7 +330,8 @@ __global__ __launch_bounds__(256) void bn_plane_apply_kernel(
     float momentum, float* running_mean, float* running_var, float* mean_o, float* invstd_o,
     float* scale_o, const float* residual, int r_ctot, int r_coff, float* y, int y_ctot, int y_coff,
     int N, int C, int HW, int pre_relu, int post_relu, int chunks, int chunk_len,
-    float* __restrict__ gap_out, int gap_ctot, int gap_coff) {
+    float* __restrict__ gap_out, int gap_ctot, int gap_coff, const float* __restrict__ r_mean = nullptr,
+    const float* __restrict__ r_scale = nullptr, const float* __restrict__ r_shift = nullptr) {
   __shared__ double sm[2][16];
   const int chunk = blockIdx.x % chunks;
   const int pl = blockIdx.x / chunks;
@@ -353,6 +354,10 @@ __global__ __launch_bounds__(256) void bn_plane_apply_kernel(
   const float* xp = x + ((size_t)n * x_ctot + x_coff + c) * HW;
   float* yp = y + ((size_t)n * y_ctot + y_coff + c) * HW;
   const float* rp = residual ? residual + ((size_t)n * r_ctot + r_coff + c) * HW : nullptr;
+  // residual stored before ITS BatchNorm + ReLU (apply-on-load): r' = max(0, (r - r_mean) * r_scale + r_shift)
+  const bool raff = rp && r_scale;
+  const float rmu = raff ? r_mean[r_coff + c] : 0.f, rsc = raff ? r_scale[r_coff + c] : 1.f,
+              rsh = raff ? r_shift[r_coff + c] : 0.f;
   const int per = VEC ? (HW >> 2) : HW;
   const int i1 = min(per, (chunk + 1) * chunk_len);
   double gs = 0.0;
@@ -368,12 +373,13 @@ __global__ __launch_bounds__(256) void bn_plane_apply_kernel(
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
         float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-        const float re[4] = {rv[u].x, rv[u].y, rv[u].z, rv[u].w};
+        float re[4] = {rv[u].x, rv[u].y, rv[u].z, rv[u].w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const float xx = pre_relu ? fmaxf(e[k], 0.f) : e[k];
           float o = (xx - mu) * sc + be;
           if (post_relu) o = fmaxf(o, 0.f);
+          if (raff) re[k] = fmaxf((re[k] - rmu) * rsc + rsh, 0.f);
           e[k] = o + re[k];
         }
         *reinterpret_cast<float4*>(yp + ((size_t)(i + u * 256) << 2)) = make_float4(e[0], e[1], e[2], e[3]);
@@ -387,12 +393,13 @@ __global__ __launch_bounds__(256) void bn_plane_apply_kernel(
       float e[4] = {v.x, v.y, v.z, v.w};
       float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
       if (rp) rv = *reinterpret_cast<const float4*>(rp + ((size_t)i << 2));
-      const float re[4] = {rv.x, rv.y, rv.z, rv.w};
+      float re[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float xx = pre_relu ? fmaxf(e[k], 0.f) : e[k];
         float o = (xx - mu) * sc + be;
         if (post_relu) o = fmaxf(o, 0.f);
+        if (raff) re[k] = fmaxf((re[k] - rmu) * rsc + rsh, 0.f);
         e[k] = o + re[k];
       }
       *reinterpret_cast<float4*>(yp + ((size_t)i << 2)) = make_float4(e[0], e[1], e[2], e[3]);
@@ -402,7 +409,7 @@ __global__ __launch_bounds__(256) void bn_plane_apply_kernel(
       if (pre_relu) xx = fmaxf(xx, 0.f);
       float o = (xx - mu) * sc + be;
       if (post_relu) o = fmaxf(o, 0.f);
-      if (rp) o += rp[i];
+      if (rp) o += raff ? fmaxf((rp[i] - rmu) * rsc + rsh, 0.f) : rp[i];
       yp[i] = o;
       gs += o;
     }
@@ -685,6 +692,7 @@ extern "C" int dlio_bn_train_apply(const float* x, int N, int x_ctot, int x_coff
                                    int r_ctot, int r_coff, float* y, int y_ctot, int y_coff,
                                    float* gap_out, int gap_ctot, int gap_coff, void* ws,
                                    size_t ws_bytes, int phase, double count_scale,
+                                   const float* r_mean, const float* r_scale, const float* r_shift,
                                    dlio_stream_t stream) {
   if (!x || !y || !mean || !invstd || !scale || N <= 0 || C <= 0 || HW <= 0 || !ws || phase < 0 ||
       phase > 2 || !(count_scale >= 1.0))
@@ -717,17 +725,17 @@ extern "C" int dlio_bn_train_apply(const float* x, int N, int x_ctot, int x_coff
     hipLaunchKernelGGL((bn_plane_apply_kernel<true, 4>), grid, dim3(256), 0, s, x, x_ctot, x_coff, part, splits,
                        (double)N * HW * count_scale, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
                        scale, residual, r_ctot, r_coff, y, y_ctot, y_coff, N, C, HW, pre_relu, post_relu,
-                       chunks, chunk_len, gap_out, gap_ctot, gap_coff);
+                       chunks, chunk_len, gap_out, gap_ctot, gap_coff, r_mean, r_scale, r_shift);
   else if (vec)
     hipLaunchKernelGGL(bn_plane_apply_kernel<true>, grid, dim3(256), 0, s, x, x_ctot, x_coff, part, splits,
                        (double)N * HW * count_scale, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
                        scale, residual, r_ctot, r_coff, y, y_ctot, y_coff, N, C, HW, pre_relu, post_relu,
-                       chunks, chunk_len, gap_out, gap_ctot, gap_coff);
+                       chunks, chunk_len, gap_out, gap_ctot, gap_coff, r_mean, r_scale, r_shift);
   else
     hipLaunchKernelGGL(bn_plane_apply_kernel<false>, grid, dim3(256), 0, s, x, x_ctot, x_coff, part, splits,
                        (double)N * HW * count_scale, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
                        scale, residual, r_ctot, r_coff, y, y_ctot, y_coff, N, C, HW, pre_relu, post_relu,
-                       chunks, chunk_len, gap_out, gap_ctot, gap_coff);
+                       chunks, chunk_len, gap_out, gap_ctot, gap_coff, r_mean, r_scale, r_shift);
   return dlio_check_launch();
 }
 

@@ -677,10 +677,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_adirect_kernel(
 // layers, which are HBM-bound).  Partial sums: 4 waves through LDS, then the slab reduction.
 // NAT: bf16 operands in memory (mixed-precision path): a lane's 16 pixels are two 16-byte loads that
 // ARE the two k-blocks' MFMA fragments -- no conversion, one MFMA per product.
-template <int MR, int NT, bool BX3 = false, bool NAT = false>
+// AFF: the X operand is the BatchNorm+ReLU of what is stored, x' = max(0, (x - mean[ci]) * scale[ci] + shift[ci])
+// (apply-on-load: the producer's activated output is never materialised); a lane owns one channel, so
+// the three constants are per-lane registers and the transform is 2 VALU per loaded value.
+template <int MR, int NT, bool BX3 = false, bool NAT = false, bool AFF = false>
 __global__ __launch_bounds__(256, 2) void wgrad1x1_direct_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ wsp,
-    DlioConvDesc d, int co_tiles, int ci_chunks, int splits, int segs_per_img) {
+    DlioConvDesc d, int co_tiles, int ci_chunks, int splits, int segs_per_img,
+    const float* __restrict__ in_mean = nullptr, const float* __restrict__ in_scale = nullptr,
+    const float* __restrict__ in_shift = nullptr) {
   constexpr int ED = NAT ? 2 : 1;                 // bf16 elements per float slot of the pointer arithmetic
   __shared__ float red[MR * NT * 16 * 64];
   const int tid = threadIdx.x;
@@ -710,6 +715,14 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_direct_kernel(
     const int ci = c0 + t * 32 + l31;
     vb[t] = ci < d.Cin;
     brow[t] = x + (((size_t)d.in_coff + (vb[t] ? ci : 0)) * hw + half * 16) / ED;
+  }
+  float amu[NT], asc[NT], ash[NT];
+  if constexpr (AFF) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int ci = min(c0 + t * 32 + l31, d.Cin - 1);
+      amu[t] = in_mean[ci]; asc[t] = in_scale[ci]; ash[t] = in_shift[ci];
+    }
   }
   const size_t a_img = (size_t)d.out_ctot * hw / ED, b_img = (size_t)d.in_ctot * hw / ED;
 
@@ -746,6 +759,16 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_direct_kernel(
         const float4* p = reinterpret_cast<const float4*>(brow[t] + n * b_img + o);
 #pragma unroll
         for (int q = 0; q < (NAT ? 2 : 4); ++q) b[t][q] = p[q];
+        if constexpr (AFF) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float4 v = b[t][q];
+            v.x = (v.x - amu[t]) * asc[t] + ash[t]; v.y = (v.y - amu[t]) * asc[t] + ash[t];
+            v.z = (v.z - amu[t]) * asc[t] + ash[t]; v.w = (v.w - amu[t]) * asc[t] + ash[t];
+            if (d.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            b[t][q] = v;
+          }
+        }
       }
   };
   auto compute = [&](const float4 (&a)[MR][4], const float4 (&b)[NT][4]) {
@@ -1017,10 +1040,19 @@ bool make_plan_1x1(const DlioConvDesc& d, Wg1Plan& p) {
 
 template <int MR, int NT>
 int launch_1x1(const float* x, const float* dy, float* dw, float* wsp, const DlioConvDesc& d,
-               const Wg1Plan& p, int accumulate, hipStream_t s) {
+               const Wg1Plan& p, int accumulate, hipStream_t s, const float* in_mean = nullptr,
+               const float* in_scale = nullptr, const float* in_shift = nullptr) {
   // split-bf16 MFMAs where the fp32 MFMA time shows (64 x 64-channel tiles); narrow layers are HBM-bound
   static const int bx3 = getenv("DLIO_WGRAD_1X1_BX3") ? atoi(getenv("DLIO_WGRAD_1X1_BX3")) : 1;
-  if (bx3 == 2 || (bx3 && MR == 2 && NT == 2))
+  if (in_scale && (bx3 == 2 || (bx3 && MR == 2 && NT == 2)))
+    hipLaunchKernelGGL((wgrad1x1_direct_kernel<MR, NT, true, false, true>), dim3(p.co_tiles * p.ci_chunks * p.splits),
+                       dim3(256), 0, s, x, dy, wsp, d, p.co_tiles, p.ci_chunks, p.splits, p.segs, in_mean, in_scale,
+                       in_shift);
+  else if (in_scale)
+    hipLaunchKernelGGL((wgrad1x1_direct_kernel<MR, NT, false, false, true>), dim3(p.co_tiles * p.ci_chunks * p.splits),
+                       dim3(256), 0, s, x, dy, wsp, d, p.co_tiles, p.ci_chunks, p.splits, p.segs, in_mean, in_scale,
+                       in_shift);
+  else if (bx3 == 2 || (bx3 && MR == 2 && NT == 2))
     hipLaunchKernelGGL((wgrad1x1_direct_kernel<MR, NT, true>), dim3(p.co_tiles * p.ci_chunks * p.splits),
                        dim3(256), 0, s, x, dy, wsp, d, p.co_tiles, p.ci_chunks, p.splits, p.segs);
   else
@@ -1131,12 +1163,12 @@ extern "C" int dlio_conv2d_wgrad(const float* x, const float* dy, float* dw,
   dlio_prof_begin(pkind, s, flops, bytes);
   int rc = DLIO_EUNSUP;
   Wg1Plan q;
-  if (!in_scale && make_plan_1x1(d, q) && ws_bytes >= q.ws_bytes &&
+  if (make_plan_1x1(d, q) && ws_bytes >= q.ws_bytes &&
       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0) {
-    if (q.mr == 1 && q.nt == 1) rc = launch_1x1<1, 1>(x, dy, dw, wsp, d, q, accumulate, s);
-    else if (q.mr == 1) rc = launch_1x1<1, 2>(x, dy, dw, wsp, d, q, accumulate, s);
-    else if (q.nt == 1) rc = launch_1x1<2, 1>(x, dy, dw, wsp, d, q, accumulate, s);
-    else rc = launch_1x1<2, 2>(x, dy, dw, wsp, d, q, accumulate, s);
+    if (q.mr == 1 && q.nt == 1) rc = launch_1x1<1, 1>(x, dy, dw, wsp, d, q, accumulate, s, in_mean, in_scale, in_shift);
+    else if (q.mr == 1) rc = launch_1x1<1, 2>(x, dy, dw, wsp, d, q, accumulate, s, in_mean, in_scale, in_shift);
+    else if (q.nt == 1) rc = launch_1x1<2, 1>(x, dy, dw, wsp, d, q, accumulate, s, in_mean, in_scale, in_shift);
+    else rc = launch_1x1<2, 2>(x, dy, dw, wsp, d, q, accumulate, s, in_mean, in_scale, in_shift);
     dlio_prof_end(pkind, s);
     return rc;
   }

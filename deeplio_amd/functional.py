@@ -237,11 +237,16 @@ class _CBR:
     def forward(x, x_ctot, x_coff, Cin, H, W, weight, bias, gamma, beta, rmean, rvar, stride, pad,
                 training, momentum, eps, pre_relu, post_relu, raw, raw_ctot, raw_coff, out, out_ctot,
                 out_coff, N, residual=None, r_ctot=0, r_coff=0, gap=None, gap_ctot=0, gap_coff=0,
-                need_dx=True):
+                need_dx=True, in_aff=None, r_aff=None, stats_into=None):
+        """in_aff (mean, scale, shift rows over the x_ctot input channels): x is stored BEFORE its producer's
+        BatchNorm + ReLU and activated while the convolution loads it; r_aff: the same for the residual;
+        stats_into (three [Cout] tensors): train-mode statistics only -- the activated output is not
+        written, the consumers apply (mean, scale, beta) on load (apply-on-load)."""
         Cout, _, KH, KW = weight.shape
         d = ops.conv_desc(N, Cin, H, W, Cout, KH, KW, stride[0], stride[1], pad[0], pad[1],
-                          in_ctot=x_ctot, in_coff=x_coff, out_ctot=raw_ctot, out_coff=raw_coff)
-        bx3 = _use_bx3(N, Cin, Cout, KH, KW, stride, d.OH, d.OW)
+                          in_ctot=x_ctot, in_coff=x_coff, out_ctot=raw_ctot, out_coff=raw_coff,
+                          in_relu=1 if in_aff is not None else 0)
+        bx3 = _use_bx3(N, Cin, Cout, KH, KW, stride, d.OH, d.OW) and in_aff is None
         bx3 = bx3 and (KH == 3 or (pad[0] == 0 and pad[1] == 0))
         if bx3:
             wt = ops.conv_bx3_prepped(weight, 0)
@@ -264,13 +269,17 @@ class _CBR:
         elif bx3:
             ops.conv3x3_bx3_fwd(x, wt, bias, raw, d)
         else:
-            ops.conv2d_fwd(x, wt, bias, raw, d)
+            ops.conv2d_fwd(x, wt, bias, raw, d, in_aff=in_aff)
         OHW = d.OH * d.OW
+        if stats_into is not None:
+            prm = ops.bn_train_stats(raw, N, raw_ctot, raw_coff, Cout, OHW, pre_relu, gamma, eps, momentum, rmean, rvar,
+                                     prm=stats_into)
+            return d, prm
         if training and _PLANE_BN[0]:
             # statistics + finalise + apply (+ the plane averages an SELayer wants) in 2 launches
             prm = ops.bn_train_apply(raw, raw_ctot, raw_coff, gamma, beta, eps, momentum, rmean, rvar, out,
                                      out_ctot, out_coff, N, Cout, OHW, pre_relu, post_relu, residual, r_ctot,
-                                     r_coff, gap, gap_ctot, gap_coff)
+                                     r_coff, gap, gap_ctot, gap_coff, r_aff=r_aff)
             return d, prm
         if training:
             prm = ops.bn_train_stats(raw, N, raw_ctot, raw_coff, Cout, OHW, pre_relu, gamma, eps,
@@ -284,7 +293,7 @@ class _CBR:
     @staticmethod
     def backward(dy, dy_ctot, dy_coff, x, d, weight, bias, gamma, prm, beta, raw, training, pre_relu,
                  post_relu, draw, need_dx, dx=None, dx_ctot=0, dx_coff=0, dx_residual=None,
-                 dxr_ctot=0, dxr_coff=0, dx_accumulate=False):
+                 dxr_ctot=0, dxr_coff=0, dx_accumulate=False, in_aff=None):
         """dy: grad wrt the activated output (slice).  draw: scratch [N,Cout,OH,OW] (contiguous).
         Returns (dweight, dbias, dgamma, dbeta); writes dx (slice) if need_dx:
         dx = dgrad (+ dx_residual) (+ previous dx when dx_accumulate)."""
@@ -310,14 +319,15 @@ class _CBR:
                 ops.chan_sum(draw, N, Cout, 0, Cout, OHW, out=dbias, accumulate=acc)
         dw, acc_w, ret_w = _sink(weight, weight.shape, dy)
         dd = ops.conv_desc(N, d.Cin, d.H, d.W, Cout, d.KH, d.KW, d.SH, d.SW, d.PH, d.PW, OH=d.OH,
-                           OW=d.OW, in_ctot=d.in_ctot, in_coff=d.in_coff, out_ctot=Cout, out_coff=0)
+                           OW=d.OW, in_ctot=d.in_ctot, in_coff=d.in_coff, out_ctot=Cout, out_coff=0,
+                           in_relu=1 if in_aff is not None else 0)
         ws = _wgrad_stream(dy) if acc_w else None
         if ws is None:
-            ops.conv2d_wgrad(x, draw, dw, dd, accumulate=acc_w)
+            ops.conv2d_wgrad(x, draw, dw, dd, in_aff=in_aff, accumulate=acc_w)
         else:
             # the weight gradient goes straight into the flat gradient buffer and nothing on the
             # tape waits for it: fork it so the data-gradient chain continues immediately
-            _forked(ws, lambda: ops.conv2d_wgrad(x, draw, dw, dd, accumulate=True), draw, x)
+            _forked(ws, lambda: ops.conv2d_wgrad(x, draw, dw, dd, in_aff=in_aff, accumulate=True), draw, x)
         if need_dx:
             conv_dgrad(draw, weight, d, dx, dx_ctot, dx_coff, dx_residual, dxr_ctot, dxr_coff,
                        dx_accumulate)
@@ -497,33 +507,58 @@ class ConvBnAct(Function):
 class FireFn(Function):
     """Fire block (pointseg_modules.py:116-142) as ONE tape node: squeeze CBR, then the two
     expand convolutions write the halves of the concatenated output; 'simple' bypass is the
-    residual operand of the BN-apply kernels."""
+    residual operand of the BN-apply kernels.
+
+    Apply-on-load (training, blocks without bypass whose only consumer is the next Fire block):
+    `defer` -- the expand BatchNorms only take their statistics; the block returns its RAW expand
+    output and an [3, CE] table (mean, scale, beta) instead of the activated tensor, which is never
+    written.  `x_aff` -- the input is such a pair: the squeeze convolution, the bypass residual and (in
+    backward) the squeeze weight gradient apply max(0, (x - mean) * scale + beta) while they load.  The raw
+    tensor stands in for the activated one on the tape: its gradient IS d loss / d activated output."""
 
     @staticmethod
     def forward(ctx, x, sw, sb, sg, sbe, srm, srv, e1w, e1b, e1g, e1be, e1rm, e1rv, e3w, e3b, e3g,
-                e3be, e3rm, e3rv, training, momentum, eps, bypass, want_gap=False):
+                e3be, e3rm, e3rv, training, momentum, eps, bypass, want_gap=False, x_aff=None, defer=False):
         x = x.contiguous()
         N, Cin, H, W = x.shape
         S_, E1, E3 = sw.shape[0], e1w.shape[0], e3w.shape[0]
         CE = E1 + E3
         raw_s, act_s = _new((N, S_, H, W), x), _new((N, S_, H, W), x)
         d_s, prm_s = _CBR.forward(x, Cin, 0, Cin, H, W, sw, sb, sg, sbe, srm, srv, (1, 1), (0, 0),
-                                  training, momentum, eps, False, True, raw_s, S_, 0, act_s, S_, 0, N)
-        raw_e, out = _new((N, CE, H, W), x), _new((N, CE, H, W), x)
+                                  training, momentum, eps, False, True, raw_s, S_, 0, act_s, S_, 0, N,
+                                  in_aff=x_aff)
+        raw_e = _new((N, CE, H, W), x)
         res = x if bypass else None
+        if defer:
+            aff = _new((3, CE), x)
+            inv1, inv3 = _new((E1,), x), _new((E3,), x)
+            d_1, _ = _CBR.forward(act_s, S_, 0, S_, H, W, e1w, e1b, e1g, e1be, e1rm, e1rv, (1, 1), (0, 0), training,
+                                  momentum, eps, False, True, raw_e, CE, 0, None, CE, 0, N,
+                                  stats_into=(aff[0, :E1], inv1, aff[1, :E1]))
+            d_3, _ = _CBR.forward(act_s, S_, 0, S_, H, W, e3w, e3b, e3g, e3be, e3rm, e3rv, (1, 1), (1, 1), training,
+                                  momentum, eps, False, True, raw_e, CE, E1, None, CE, E1, N,
+                                  stats_into=(aff[0, E1:], inv3, aff[1, E1:]))
+            ops.copy2d(e1be, E1, aff[2], CE, 1, E1)
+            ops.copy2d(e3be, E3, aff[2], CE, 1, E3, dst_off=E1)
+            ctx.save_for_backward(x, sw, sbe, e1w, e1be, e3w, e3be, raw_s, act_s, raw_e, prm_s, aff, inv1, inv3,
+                                  sb, sg, e1b, e1g, e3b, e3g, x_aff)
+            ctx.cfg = (d_s, d_1, d_3, training, bypass, True)
+            ctx.mark_non_differentiable(aff)
+            return raw_e, aff
+        out = _new((N, CE, H, W), x)
         # plane averages of the block output for the SELayer behind it: a by-product of the BN
         # apply kernels in training, one extra pass otherwise
         fused_gap = want_gap and training and _PLANE_BN[0]
         gap = _new((N, CE), x) if fused_gap else None
         d_1, prm_1 = _CBR.forward(act_s, S_, 0, S_, H, W, e1w, e1b, e1g, e1be, e1rm, e1rv, (1, 1),
                                   (0, 0), training, momentum, eps, False, True, raw_e, CE, 0, out,
-                                  CE, 0, N, res, Cin, 0, gap, CE, 0)
+                                  CE, 0, N, res, Cin, 0, gap, CE, 0, r_aff=x_aff if bypass else None)
         d_3, prm_3 = _CBR.forward(act_s, S_, 0, S_, H, W, e3w, e3b, e3g, e3be, e3rm, e3rv, (1, 1),
                                   (1, 1), training, momentum, eps, False, True, raw_e, CE, E1, out,
-                                  CE, E1, N, res, Cin, E1, gap, CE, E1)
+                                  CE, E1, N, res, Cin, E1, gap, CE, E1, r_aff=x_aff if bypass else None)
         ctx.save_for_backward(x, sw, sbe, e1w, e1be, e3w, e3be, raw_s, act_s, raw_e, prm_s, prm_1,
-                              prm_3, sb, sg, e1b, e1g, e3b, e3g)
-        ctx.cfg = (d_s, d_1, d_3, training, bypass)
+                              prm_3, sb, sg, e1b, e1g, e3b, e3g, x_aff)
+        ctx.cfg = (d_s, d_1, d_3, training, bypass, False)
         if not want_gap:
             return out
         if gap is None:
@@ -533,9 +568,16 @@ class FireFn(Function):
 
     @staticmethod
     def backward(ctx, dout, *_unused_dgap):
-        (x, sw, sbe, e1w, e1be, e3w, e3be, raw_s, act_s, raw_e, prm_s, prm_1, prm_3, sb, sg, e1b, e1g,
-         e3b, e3g) = ctx.saved_tensors
-        d_s, d_1, d_3, training, bypass = ctx.cfg
+        d_s, d_1, d_3, training, bypass, deferred = ctx.cfg
+        if deferred:
+            (x, sw, sbe, e1w, e1be, e3w, e3be, raw_s, act_s, raw_e, prm_s, aff, inv1, inv3, sb, sg, e1b, e1g,
+             e3b, e3g, x_aff) = ctx.saved_tensors
+            E1 = e1w.shape[0]
+            prm_1 = (aff[0, :E1], inv1, aff[1, :E1])
+            prm_3 = (aff[0, E1:], inv3, aff[1, E1:])
+        else:
+            (x, sw, sbe, e1w, e1be, e3w, e3be, raw_s, act_s, raw_e, prm_s, prm_1, prm_3, sb, sg, e1b, e1g,
+             e3b, e3g, x_aff) = ctx.saved_tensors
         dout = dout.contiguous()
         N, Cin, H, W = x.shape
         S_, E1, E3 = sw.shape[0], e1w.shape[0], e3w.shape[0]
@@ -553,9 +595,9 @@ class FireFn(Function):
         dx = torch.empty_like(x) if need_dx else None
         draw_s = _new((N, S_, H, W), x)
         gs = _CBR.backward(dact_s, S_, 0, x, d_s, sw, sb, sg, prm_s, sbe, raw_s, training, False, True,
-                           draw_s, need_dx, dx, Cin, 0, dout if bypass else None, CE, 0)
+                           draw_s, need_dx, dx, Cin, 0, dout if bypass else None, CE, 0, in_aff=x_aff)
         return (dx, gs[0], gs[1], gs[2], gs[3], None, None, g1[0], g1[1], g1[2], g1[3], None, None,
-                g3[0], g3[1], g3[2], g3[3], None, None, None, None, None, None, None)
+                g3[0], g3[1], g3[2], g3[3], None, None, None, None, None, None, None, None, None)
 
 
 class ConvAddFn(Function):

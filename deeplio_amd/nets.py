@@ -20,6 +20,8 @@ from .misc import get_config_container
 
 # IMU branch backward scheduled at the fusion layer instead of at the end of the backward pass
 _DEFER_IMU = os.environ.get("DLIO_DEFER_IMU_BWD", "1") != "0"
+# BatchNorm + ReLU of bypass-free Fire blocks applied by their consumer instead of being written
+_APPLY_ON_LOAD = os.environ.get("DLIO_APPLY_ON_LOAD", "1") != "0"
 
 
 def _pair(v):
@@ -100,25 +102,38 @@ class Fire(nn.Module):
             self.upsample = nn.Conv2d(inplanes, expand1x1_planes + expand3x3_planes, 1)
         self.residual = bypass == "simple" and same
 
-    def forward(self, x, want_gap=False):
-        """want_gap: also return the [N, C] plane averages of the output (for a following SELayer)"""
+    def forward(self, x, want_gap=False, defer=False):
+        """want_gap: also return the [N, C] plane averages of the output (for a following SELayer).
+        x may be a (raw, aff) pair from a deferring block (functional.FireFn); defer: return such a pair."""
         tr = self.training
         s, sb, e1, e1b, e3, e3b = (self.squeeze, self.squeeze_bn, self.expand1x1, self.expand1x1_bn,
                                    self.expand3x3, self.expand3x3_bn)
         for b in (sb, e1b, e3b):
             _bump(b, tr)
+        x_aff = None
+        if isinstance(x, tuple):
+            x, x_aff = x
         up = getattr(self, "upsample", None)
         bf16 = x.dtype == torch.bfloat16          # mixed-precision region (deeplio_amd.mixed): dispatch on the input
         if bf16 and up is not None:
             raise ValueError("Fire bypass 'complex' has no bf16 kernel (mixed precision supports None / 'simple')")
-        out = (mixed.FireFn if bf16 else Fh.FireFn).apply(x, s.weight, s.bias, sb.weight, sb.bias, sb.running_mean, sb.running_var,
-                              e1.weight, e1.bias, e1b.weight, e1b.bias, e1b.running_mean, e1b.running_var,
-                              e3.weight, e3.bias, e3b.weight, e3b.bias, e3b.running_mean, e3b.running_var,
-                              tr, sb.momentum, sb.eps, self.residual, want_gap and up is None)
+        args = (x, s.weight, s.bias, sb.weight, sb.bias, sb.running_mean, sb.running_var,
+                e1.weight, e1.bias, e1b.weight, e1b.bias, e1b.running_mean, e1b.running_var,
+                e3.weight, e3.bias, e3b.weight, e3b.bias, e3b.running_mean, e3b.running_var,
+                tr, sb.momentum, sb.eps, self.residual, want_gap and up is None)
+        if bf16:
+            out = mixed.FireFn.apply(*args)
+        else:
+            out = Fh.FireFn.apply(*args, x_aff, defer)
         if up is None:
             return out
         out = Fh.ConvAddFn.apply(x, up.weight, up.bias, out)      # out + upsample(identity), :136-138
         return (out, None) if want_gap else out                    # the SELayer takes its own averages
+
+    def can_defer(self):
+        """this block's activated output may stay unwritten (apply-on-load in the next Fire block): training,
+        no bypass / upsample on THIS block's output path"""
+        return self.training and not self.residual and getattr(self, "upsample", None) is None
 
 
 class SELayer(nn.Module):
@@ -217,6 +232,13 @@ class PSEncoder(BaseNet):
                     i += 1
                 elif isinstance(m, Fire) and i + 1 < len(mods) and isinstance(mods[i + 1], SELayer):
                     x, gap = m(x, want_gap=True)       # the SELayer's squeeze comes out of the BN apply
+                    i += 1
+                elif (isinstance(m, Fire) and i + 1 < len(mods) and isinstance(mods[i + 1], Fire) and _APPLY_ON_LOAD
+                      and m.can_defer() and getattr(mods[i + 1], "upsample", None) is None
+                      and self.precision == 'fp32' and ops._SYNC_BN[0] is None):
+                    # the only consumer is the next Fire block: it applies this block's BatchNorm + ReLU
+                    # while it loads (squeeze convolution, bypass residual, squeeze weight gradient)
+                    x = m(x, defer=True)
                     i += 1
                 else:
                     x = m(x)

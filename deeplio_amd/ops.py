@@ -374,9 +374,11 @@ def bn_finalize(stats, count, gamma, eps, momentum, running_mean, running_var):
     return prm
 
 
-def bn_train_stats(x, N, ctot, coff, C_, HW, pre_relu, gamma, eps, momentum, running_mean, running_var):
-    """batch statistics + finalize (+ running-stat update) -> params [3][C]: mean, invstd, scale"""
-    prm = torch.empty(3, C_, dtype=torch.float32, device=x.device)
+def bn_train_stats(x, N, ctot, coff, C_, HW, pre_relu, gamma, eps, momentum, running_mean, running_var, prm=None):
+    """batch statistics + finalize (+ running-stat update) -> params [3][C]: mean, invstd, scale (prm: three
+    caller-provided [C] tensors to write them into)"""
+    if prm is None:
+        prm = torch.empty(3, C_, dtype=torch.float32, device=x.device)
     ws = _stats_ws(N, C_, HW, x.device)
     check(lib.dlio_bn_train_stats(_ptr(x), N, ctot, coff, C_, HW, int(pre_relu), _ptr(gamma), float(eps),
                                   float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(prm[0]),
@@ -401,7 +403,7 @@ def _partials_view(ws, N, C_, HW):
 
 def bn_train_apply(x, x_ctot, x_coff, gamma, beta, eps, momentum, running_mean, running_var, y, y_ctot,
                    y_coff, N, C_, HW, pre_relu, post_relu, residual=None, r_ctot=0, r_coff=0,
-                   gap_out=None, gap_ctot=0, gap_coff=0):
+                   gap_out=None, gap_ctot=0, gap_coff=0, r_aff=None):
     """train-mode BN forward (statistics + apply) in two launches -> prm [3][C]; with SyncBN the
     partial sums are all-reduced between the two launches"""
     prm = torch.empty(3, C_, dtype=torch.float32, device=x.device)
@@ -412,7 +414,10 @@ def bn_train_apply(x, x_ctot, x_coff, gamma, beta, eps, momentum, running_mean, 
                                       _ptr(gamma), _ptr(beta), float(eps), float(momentum), _ptr(running_mean),
                                       _ptr(running_var), _ptr(prm[0]), _ptr(prm[1]), _ptr(prm[2]),
                                       _ptr(residual), r_ctot, r_coff, _ptr(y), y_ctot, y_coff, _ptr(gap_out),
-                                      gap_ctot, gap_coff, _ptr(ws), ws.numel(), phase, float(scale), _stream()),
+                                      gap_ctot, gap_coff, _ptr(ws), ws.numel(), phase, float(scale),
+                                      _ptr(r_aff[0]) if r_aff is not None else None,
+                                      _ptr(r_aff[1]) if r_aff is not None else None,
+                                      _ptr(r_aff[2]) if r_aff is not None else None, _stream()),
               "bn_train_apply")
     sync = _SYNC_BN[0]
     if sync is None:

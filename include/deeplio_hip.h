@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 200
+#define DLIO_ABI_VERSION 201
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);           /* "gfx950" */
@@ -396,7 +396,10 @@ int dlio_gt_relative(const float* gts, const int32_t* combinations, float* f2f, 
  * are the (sum, sum of squares) partials.
  * Synchronised statistics across data-parallel replicas (SyncBN): call with phase = 1 (partials
  * only), all-reduce(sum) those doubles over the replicas, call again with phase = 2 (apply only)
- * and count_scale = number of replicas.  phase = 0, count_scale = 1: the whole thing. */
+ * and count_scale = number of replicas.  phase = 0, count_scale = 1: the whole thing.
+ * r_mean / r_scale / r_shift (nullable, [r_ctot] each): the residual buffer holds the producer's RAW
+ * convolution output and is activated on load, residual' = max(0, (r - r_mean) * r_scale + r_shift)
+ * (apply-on-load: the producing Fire block's BatchNorm+ReLU output is never written). */
 int dlio_chan_stats_splits(int N, int C, int HW);
 int dlio_bn_train_apply(const float* x, int N, int x_ctot, int x_coff, int C, int HW, int pre_relu,
                         int post_relu, const float* gamma, const float* beta, float eps,
@@ -404,6 +407,7 @@ int dlio_bn_train_apply(const float* x, int N, int x_ctot, int x_coff, int C, in
                         float* invstd, float* scale, const float* residual, int r_ctot, int r_coff,
                         float* y, int y_ctot, int y_coff, float* gap_out, int gap_ctot, int gap_coff,
                         void* ws, size_t ws_bytes, int phase, double count_scale,
+                        const float* r_mean, const float* r_scale, const float* r_shift,
                         dlio_stream_t stream);
 /* BatchNorm backward in two launches: dlio_bn_bwd_reduce's reduction + a plane-structured
  * dlio_bn_bwd_apply that sums the partials itself; dgamma / dbeta (optional, += when accumulate)

@@ -126,6 +126,37 @@ def test_fire(dev, case, train):
     compare(nets.Fire(cin, sq, e, e, bypass=byp), om.Fire(cin, sq, e, e, 0.1, byp), x, dev, train)
 
 
+class _FirePair(nn.Module):
+    def __init__(self, mk, a, b, defer):
+        super().__init__()
+        self.a, self.b, self.defer = mk(*a), mk(*b), defer
+
+    def forward(self, x):
+        return self.b(self.a(x, defer=True)) if self.defer else self.b(self.a(x))
+
+
+PAIR_CASES = [  # N, H, W, first block (bypass-free), second block: the PSEncoder pairs blk1.0->1.1, blk3.2->3.3, blk5.0->5.1
+    (2, 8, 32, (64, 16, 64, 64, None), (128, 16, 64, 64, "simple")),
+    (2, 8, 64, (384, 64, 256, 256, "simple"), (512, 64, 256, 256, "simple")),
+    (3, 4, 32, (512, 80, 384, 384, "simple"), (768, 80, 384, 384, None)),
+    (1, 16, 128, (256, 48, 192, 192, "simple"), (384, 48, 192, 192, "simple"))]
+
+
+@pytest.mark.parametrize("case", PAIR_CASES)
+def test_fire_pair_apply_on_load(dev, case):
+    """apply-on-load: the first block returns its RAW expand output + (mean, scale, beta); the second
+    block's squeeze convolution, bypass residual and squeeze weight gradient activate it while loading.
+    Same oracle (two plain Fire blocks), same 1e-4 bars as test_fire; and bit-for-bit the same forward
+    values as the materialising path wherever both run the same kernels."""
+    from deeplio_amd import nets
+    from oracle import model as om
+    N, H, W, a, b = case
+    x = torch.randn(N, a[0], H, W, generator=torch.Generator().manual_seed(1))
+    hmk = lambda ci, sq, e1, e3, byp: nets.Fire(ci, sq, e1, e3, bypass=byp)
+    omk = lambda ci, sq, e1, e3, byp: om.Fire(ci, sq, e1, e3, 0.1, byp)
+    compare(_FirePair(hmk, a, b, True), _FirePair(omk, a, b, False), x, dev, True)
+
+
 CBR_CASES = [  # N, cin, cout, k, stride, pad, H, W, pre_relu, bias
     (1, 40, 72, 3, 1, 1, 33, 33, True, True), (2, 72, 64, 3, 1, 1, 17, 17, True, True),
     (2, 10, 64, (3, 5), (1, 2), (1, 2), 16, 64, False, True), (2, 6, 64, (5, 7), (1, 2), (2, 3), 16, 64, False, False),
