@@ -61,7 +61,8 @@ SIGNATURES = {
     "dlio_bn_finalize": (_i, [_p, _p, _i, _d, _p, _f, _f, _p, _p, _p, _p, _p, _p]),
     "dlio_bn_eval_params": (_i, [_p, _p, _p, _f, _i, _p, _p, _p, _p]),
     "dlio_bn_apply": (_i, [_p, _i, _i, _p, _p, _p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
-    "dlio_bn_train_stats": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _f, _f, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "dlio_bn_train_stats": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _f, _f, _p, _p, _p, _p, _p, _p, _sz, _p, _p, _i, _d,
+                                 _p]),
     "dlio_bn_bwd_reduce": (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p,
                                _p, _p, _i, _p, _sz, _p]),
     "dlio_bn_bwd_apply": (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p,

@@ -133,9 +133,11 @@ __global__ void chan_reduce_final(const double* __restrict__ part, int C, int sp
 __global__ void chan_stats_finalize_kernel(const double* __restrict__ part, int C, int splits,
                                            double count, const float* __restrict__ gamma, float eps,
                                            float momentum, float* running_mean, float* running_var,
-                                           float* mean, float* invstd, float* scale) {
+                                           float* mean, float* invstd, float* scale,
+                                           const float* __restrict__ beta = nullptr, float* shift_out = nullptr) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
+  if (shift_out) shift_out[c] = beta ? beta[c] : 0.f;     // third row of an apply-on-load table (mean, scale, beta)
   double a = 0.0, b = 0.0;
   for (int s = 0; s < splits; ++s) {
     a += part[((size_t)c * splits + s) * 2 + 0];
@@ -579,20 +581,26 @@ extern "C" int dlio_bn_train_stats(const float* x, int N, int ctot, int coff, in
                                    int pre_relu, const float* gamma, float eps, float momentum,
                                    float* running_mean, float* running_var, float* mean,
                                    float* invstd, float* scale, void* ws, size_t ws_bytes,
+                                   const float* beta, float* shift_out, int phase, double count_scale,
                                    dlio_stream_t stream) {
-  if (!x || !mean || !invstd || !scale || N <= 0 || C <= 0 || HW <= 0 || !ws) return DLIO_EINVAL;
+  if (!x || !mean || !invstd || !scale || N <= 0 || C <= 0 || HW <= 0 || !ws || phase < 0 || phase > 2 ||
+      !(count_scale >= 1.0))
+    return DLIO_EINVAL;
   const int splits = pick_splits(N, C, HW);
   if (ws_bytes < (size_t)C * splits * 2 * sizeof(double)) return DLIO_EWS;
   hipStream_t s = as_stream(stream);
   double* part = reinterpret_cast<double*>(ws);
-  hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3((unsigned)(C * splits)), dim3(RB), 0, s, x, ctot, coff,
-                     (const float*)nullptr, 0, 0, (const float*)nullptr, (const float*)nullptr,
-                     (const float*)nullptr, (const float*)nullptr, N, C, HW, pre_relu, 0, splits, part);
-  int rc = dlio_check_launch();
-  if (rc) return rc;
+  if (phase != 2) {
+    DlioProfScope prof(6, s, 0.0, 4.0 * N * (double)C * HW);
+    hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3((unsigned)(C * splits)), dim3(RB), 0, s, x, ctot, coff,
+                       (const float*)nullptr, 0, 0, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, N, C, HW, pre_relu, 0, splits, part);
+    const int rc = dlio_check_launch();
+    if (rc || phase == 1) return rc;
+  }
   hipLaunchKernelGGL(chan_stats_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, s, part, C, splits,
-                     (double)N * HW, gamma, eps, momentum, running_mean, running_var, mean, invstd,
-                     scale);
+                     (double)N * HW * count_scale, gamma, eps, momentum, running_mean, running_var, mean, invstd,
+                     scale, beta, shift_out);
   return dlio_check_launch();
 }
 

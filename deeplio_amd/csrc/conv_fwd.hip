@@ -533,6 +533,8 @@ __global__ __launch_bounds__(256) void conv1x1_v4_kernel(
 
   float a[2][U][MR];
   float4 b[2][U];
+  float af[2][U][3];
+  const bool relu_in = d.in_relu != 0;
   auto load_group = [&](int k0, int s) {
     // the U k-steps of a group are contiguous in the prepped layout: one 16-byte (U = 4) or
     // 8-byte (U = 2) load per output-channel tile; rows behind Cin are zero (k0 + 2U <= KP)
@@ -554,16 +556,26 @@ __global__ __launch_bounds__(256) void conv1x1_v4_kernel(
       const int kc = kv ? kk : Cin - 1;
       float4 v = *reinterpret_cast<const float4*>(xq + (size_t)kc * P);
       if (AFF) {
-        const float mu = in_mean[kc], sc = in_scale[kc], sh = in_shift[kc];
-        v.x = (v.x - mu) * sc + sh; v.y = (v.y - mu) * sc + sh;
-        v.z = (v.z - mu) * sc + sh; v.w = (v.w - mu) * sc + sh;
-        if (d.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        // the constants travel with the operand and are applied when it is USED (mfma_group): applying
+        // them here would wait for the load and serialise the two-deep prefetch
+        af[s][u][0] = kv ? in_mean[kc] : 0.f; af[s][u][1] = kv ? in_scale[kc] : 0.f; af[s][u][2] = kv ? in_shift[kc] : 0.f;
       }
       if (!kv) v = make_float4(0.f, 0.f, 0.f, 0.f);
       b[s][u] = v;
     }
   };
   auto mfma_group = [&](int s) {
+    if (AFF) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float mu = af[s][u][0], sc = af[s][u][1], sh = af[s][u][2];
+        float4 v = b[s][u];
+        v.x = (v.x - mu) * sc + sh; v.y = (v.y - mu) * sc + sh;
+        v.z = (v.z - mu) * sc + sh; v.w = (v.w - mu) * sc + sh;
+        if (relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        b[s][u] = v;
+      }
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll

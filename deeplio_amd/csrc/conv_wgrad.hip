@@ -759,17 +759,19 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_direct_kernel(
         const float4* p = reinterpret_cast<const float4*>(brow[t] + n * b_img + o);
 #pragma unroll
         for (int q = 0; q < (NAT ? 2 : 4); ++q) b[t][q] = p[q];
-        if constexpr (AFF) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float4 v = b[t][q];
-            v.x = (v.x - amu[t]) * asc[t] + ash[t]; v.y = (v.y - amu[t]) * asc[t] + ash[t];
-            v.z = (v.z - amu[t]) * asc[t] + ash[t]; v.w = (v.w - amu[t]) * asc[t] + ash[t];
-            if (d.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            b[t][q] = v;
-          }
-        }
       }
+  };
+  const bool relu_in = d.in_relu != 0;
+  // AFF: the X operand is activated when it is used (not when it is loaded: that would wait for the
+  // prefetch the MFMAs of the previous segment are supposed to cover); invalid channels stay 0
+  auto xf = [&](float4 v, int t) {
+    if constexpr (AFF) {
+      v.x = (v.x - amu[t]) * asc[t] + ash[t]; v.y = (v.y - amu[t]) * asc[t] + ash[t];
+      v.z = (v.z - amu[t]) * asc[t] + ash[t]; v.w = (v.w - amu[t]) * asc[t] + ash[t];
+      if (relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (!vb[t]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return v;
   };
   auto compute = [&](const float4 (&a)[MR][4], const float4 (&b)[NT][4]) {
     if constexpr (NAT) {
@@ -796,8 +798,8 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_direct_kernel(
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          const float v[8] = {b[t][2 * q].x, b[t][2 * q].y, b[t][2 * q].z, b[t][2 * q].w,
-                              b[t][2 * q + 1].x, b[t][2 * q + 1].y, b[t][2 * q + 1].z, b[t][2 * q + 1].w};
+          const float4 b0 = xf(b[t][2 * q], t), b1 = xf(b[t][2 * q + 1], t);
+          const float v[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
           wg_split8(v, bh[t], bm[t], bl[t]);
         }
 #pragma unroll
@@ -814,13 +816,18 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_direct_kernel(
       return;
     }
 #pragma unroll
-    for (int e = 0; e < 16; ++e)
+    for (int q = 0; q < 4; ++q) {
+      float4 bq[NT];
 #pragma unroll
-      for (int m = 0; m < MR; ++m)
+      for (int t = 0; t < NT; ++t) bq[t] = xf(b[t][q], t);
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-          acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a[m][e >> 2], e & 3),
-                                                           f4e(b[t][e >> 2], e & 3), acc[m][t], 0, 0, 0);
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a[m][q], e), f4e(bq[t], e), acc[m][t], 0, 0, 0);
+    }
   };
 
   const int total = d.N * segs_per_img;
@@ -1044,7 +1051,9 @@ int launch_1x1(const float* x, const float* dy, float* dw, float* wsp, const Dli
                const float* in_scale = nullptr, const float* in_shift = nullptr) {
   // split-bf16 MFMAs where the fp32 MFMA time shows (64 x 64-channel tiles); narrow layers are HBM-bound
   static const int bx3 = getenv("DLIO_WGRAD_1X1_BX3") ? atoi(getenv("DLIO_WGRAD_1X1_BX3")) : 1;
-  if (in_scale && (bx3 == 2 || (bx3 && MR == 2 && NT == 2)))
+  static const int aff_bx3 = getenv("DLIO_WGRAD_1X1_AFF_BX3") ? atoi(getenv("DLIO_WGRAD_1X1_AFF_BX3")) : 0;
+  // in-affine + split-bf16 on the 64 x 64 tile needs 26 registers more than there are (scratch spills): fp32 MFMAs there
+  if (in_scale && aff_bx3 && (bx3 == 2 || (bx3 && MR == 2 && NT == 2)))
     hipLaunchKernelGGL((wgrad1x1_direct_kernel<MR, NT, true, false, true>), dim3(p.co_tiles * p.ci_chunks * p.splits),
                        dim3(256), 0, s, x, dy, wsp, d, p.co_tiles, p.ci_chunks, p.splits, p.segs, in_mean, in_scale,
                        in_shift);

@@ -237,7 +237,7 @@ class _CBR:
     def forward(x, x_ctot, x_coff, Cin, H, W, weight, bias, gamma, beta, rmean, rvar, stride, pad,
                 training, momentum, eps, pre_relu, post_relu, raw, raw_ctot, raw_coff, out, out_ctot,
                 out_coff, N, residual=None, r_ctot=0, r_coff=0, gap=None, gap_ctot=0, gap_coff=0,
-                need_dx=True, in_aff=None, r_aff=None, stats_into=None):
+                need_dx=True, in_aff=None, r_aff=None, stats_into=None, shift_into=None):
         """in_aff (mean, scale, shift rows over the x_ctot input channels): x is stored BEFORE its producer's
         BatchNorm + ReLU and activated while the convolution loads it; r_aff: the same for the residual;
         stats_into (three [Cout] tensors): train-mode statistics only -- the activated output is not
@@ -273,7 +273,7 @@ class _CBR:
         OHW = d.OH * d.OW
         if stats_into is not None:
             prm = ops.bn_train_stats(raw, N, raw_ctot, raw_coff, Cout, OHW, pre_relu, gamma, eps, momentum, rmean, rvar,
-                                     prm=stats_into)
+                                     prm=stats_into, beta=beta, shift_out=shift_into)
             return d, prm
         if training and _PLANE_BN[0]:
             # statistics + finalise + apply (+ the plane averages an SELayer wants) in 2 launches
@@ -534,12 +534,10 @@ class FireFn(Function):
             inv1, inv3 = _new((E1,), x), _new((E3,), x)
             d_1, _ = _CBR.forward(act_s, S_, 0, S_, H, W, e1w, e1b, e1g, e1be, e1rm, e1rv, (1, 1), (0, 0), training,
                                   momentum, eps, False, True, raw_e, CE, 0, None, CE, 0, N,
-                                  stats_into=(aff[0, :E1], inv1, aff[1, :E1]))
+                                  stats_into=(aff[0, :E1], inv1, aff[1, :E1]), shift_into=aff[2, :E1])
             d_3, _ = _CBR.forward(act_s, S_, 0, S_, H, W, e3w, e3b, e3g, e3be, e3rm, e3rv, (1, 1), (1, 1), training,
                                   momentum, eps, False, True, raw_e, CE, E1, None, CE, E1, N,
-                                  stats_into=(aff[0, E1:], inv3, aff[1, E1:]))
-            ops.copy2d(e1be, E1, aff[2], CE, 1, E1)
-            ops.copy2d(e3be, E3, aff[2], CE, 1, E3, dst_off=E1)
+                                  stats_into=(aff[0, E1:], inv3, aff[1, E1:]), shift_into=aff[2, E1:])
             ctx.save_for_backward(x, sw, sbe, e1w, e1be, e3w, e3be, raw_s, act_s, raw_e, prm_s, aff, inv1, inv3,
                                   sb, sg, e1b, e1g, e3b, e3g, x_aff)
             ctx.cfg = (d_s, d_1, d_3, training, bypass, True)

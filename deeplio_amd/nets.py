@@ -235,7 +235,7 @@ class PSEncoder(BaseNet):
                     i += 1
                 elif (isinstance(m, Fire) and i + 1 < len(mods) and isinstance(mods[i + 1], Fire) and _APPLY_ON_LOAD
                       and m.can_defer() and getattr(mods[i + 1], "upsample", None) is None
-                      and self.precision == 'fp32' and ops._SYNC_BN[0] is None):
+                      and self.precision == 'fp32'):
                     # the only consumer is the next Fire block: it applies this block's BatchNorm + ReLU
                     # while it loads (squeeze convolution, bypass residual, squeeze weight gradient)
                     x = m(x, defer=True)

@@ -374,16 +374,26 @@ def bn_finalize(stats, count, gamma, eps, momentum, running_mean, running_var):
     return prm
 
 
-def bn_train_stats(x, N, ctot, coff, C_, HW, pre_relu, gamma, eps, momentum, running_mean, running_var, prm=None):
+def bn_train_stats(x, N, ctot, coff, C_, HW, pre_relu, gamma, eps, momentum, running_mean, running_var, prm=None,
+                   beta=None, shift_out=None):
     """batch statistics + finalize (+ running-stat update) -> params [3][C]: mean, invstd, scale (prm: three
     caller-provided [C] tensors to write them into)"""
     if prm is None:
         prm = torch.empty(3, C_, dtype=torch.float32, device=x.device)
     ws = _stats_ws(N, C_, HW, x.device)
-    check(lib.dlio_bn_train_stats(_ptr(x), N, ctot, coff, C_, HW, int(pre_relu), _ptr(gamma), float(eps),
-                                  float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(prm[0]),
-                                  _ptr(prm[1]), _ptr(prm[2]), _ptr(ws), ws.numel(), _stream()),
-          "bn_train_stats")
+
+    def call(phase, scale):
+        check(lib.dlio_bn_train_stats(_ptr(x), N, ctot, coff, C_, HW, int(pre_relu), _ptr(gamma), float(eps),
+                                      float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(prm[0]),
+                                      _ptr(prm[1]), _ptr(prm[2]), _ptr(ws), ws.numel(), _ptr(beta), _ptr(shift_out),
+                                      phase, float(scale), _stream()), "bn_train_stats")
+    sync = _SYNC_BN[0]
+    if sync is None:
+        call(0, 1.0)
+    else:                       # synchronised statistics: partials all-reduced between the two launches
+        call(1, 1.0)
+        sync[0](_partials_view(ws, N, C_, HW))
+        call(2, sync[1])
     return prm
 
 

@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 201
+#define DLIO_ABI_VERSION 203
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);           /* "gfx950" */
@@ -189,11 +189,14 @@ int dlio_bn_finalize(const double* sum, const double* sumsq, int C, double count
                      const float* gamma, float eps, float momentum,
                      float* running_mean, float* running_var,
                      float* mean, float* invstd, float* scale, dlio_stream_t stream);
-/* dlio_chan_stats + dlio_bn_finalize in two launches instead of three (count = N*HW) */
+/* dlio_chan_stats + dlio_bn_finalize in two launches instead of three (count = N*HW).
+ * shift_out (nullable, [C]): receives beta -- with mean and scale the (mean, scale, shift) table the
+ * in_mean / in_scale / in_shift operands of the consumers take when this BatchNorm is applied on load. */
 int dlio_bn_train_stats(const float* x, int N, int ctot, int coff, int C, int HW, int pre_relu,
                         const float* gamma, float eps, float momentum, float* running_mean,
                         float* running_var, float* mean, float* invstd, float* scale, void* ws,
-                        size_t ws_bytes, dlio_stream_t stream);
+                        size_t ws_bytes, const float* beta, float* shift_out, int phase, double count_scale,
+                        dlio_stream_t stream);       /* phase / count_scale: SyncBN split as for dlio_bn_train_apply */
 /* eval mode: mean=running_mean, invstd=rsqrt(running_var+eps), scale=gamma*invstd */
 int dlio_bn_eval_params(const float* running_mean, const float* running_var, const float* gamma,
                         float eps, int C, float* mean, float* invstd, float* scale,

@@ -137,9 +137,9 @@ class _FirePair(nn.Module):
 
 PAIR_CASES = [  # N, H, W, first block (bypass-free), second block: the PSEncoder pairs blk1.0->1.1, blk3.2->3.3, blk5.0->5.1
     (2, 8, 32, (64, 16, 64, 64, None), (128, 16, 64, 64, "simple")),
-    (2, 8, 64, (384, 64, 256, 256, "simple"), (512, 64, 256, 256, "simple")),
-    (3, 4, 32, (512, 80, 384, 384, "simple"), (768, 80, 384, 384, None)),
-    (1, 16, 128, (256, 48, 192, 192, "simple"), (384, 48, 192, 192, "simple"))]
+    (1, 4, 32, (384, 64, 256, 256, "simple"), (512, 64, 256, 256, "simple")),
+    (2, 4, 8, (512, 80, 384, 384, "simple"), (768, 80, 384, 384, None)),
+    (1, 8, 32, (256, 48, 192, 192, "simple"), (384, 48, 192, 192, "simple"))]
 
 
 @pytest.mark.parametrize("case", PAIR_CASES)
