@@ -663,10 +663,12 @@ int launch_1x1(const float* x, const float* wt, const float* bias, const float* 
 // load.  Here all four waves of a workgroup share the same 128 pixels x 32*MR channels and each
 // takes a quarter of the input channels (4x the waves, 16-byte loads); the partial accumulators
 // are combined through LDS in a fixed order and every wave stores a quarter of the rows.
-template <int MR>
+template <int MR, bool AFF>
 __global__ __launch_bounds__(256, 2) void conv1x1_v4_splitk_kernel(
     const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
-    const float* residual, float* y, DlioConvDesc d, int pix_blocks, int co_tiles) {
+    const float* __restrict__ in_mean, const float* __restrict__ in_scale,
+    const float* __restrict__ in_shift, const float* residual, float* y, DlioConvDesc d,
+    int pix_blocks, int co_tiles) {
   constexpr int U = 4;
   __shared__ float red[MR * 4 * 16 * 64];
   const int lane = threadIdx.x & 63;
@@ -699,6 +701,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_v4_splitk_kernel(
 
   float a[2][U][MR];
   float4 b[2][U];
+  float af[2][U][3];
+  const bool relu_in = d.in_relu != 0;
   auto load_group = [&](int k0, int s) {
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
@@ -709,12 +713,27 @@ __global__ __launch_bounds__(256, 2) void conv1x1_v4_splitk_kernel(
     for (int u = 0; u < U; ++u) {
       const int kk = k0 + 2 * u + half;
       const bool kv = kk < Cin;
-      float4 v = *reinterpret_cast<const float4*>(xq + (size_t)(kv ? kk : Cin - 1) * P);
+      const int kc = kv ? kk : Cin - 1;
+      float4 v = *reinterpret_cast<const float4*>(xq + (size_t)kc * P);
+      if (AFF) {   // applied at use time, see conv1x1_v4_kernel
+        af[s][u][0] = kv ? in_mean[kc] : 0.f; af[s][u][1] = kv ? in_scale[kc] : 0.f; af[s][u][2] = kv ? in_shift[kc] : 0.f;
+      }
       if (!kv) v = make_float4(0.f, 0.f, 0.f, 0.f);
       b[s][u] = v;
     }
   };
   auto mfma_group = [&](int s) {
+    if (AFF) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float mu = af[s][u][0], sc = af[s][u][1], sh = af[s][u][2];
+        float4 v = b[s][u];
+        v.x = (v.x - mu) * sc + sh; v.y = (v.y - mu) * sc + sh;
+        v.z = (v.z - mu) * sc + sh; v.w = (v.w - mu) * sc + sh;
+        if (relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        b[s][u] = v;
+      }
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -778,15 +797,20 @@ __global__ __launch_bounds__(256, 2) void conv1x1_v4_splitk_kernel(
 }
 
 template <int MR>
-int launch_1x1_splitk(const float* x, const float* wt, const float* bias, const float* residual, float* y,
+int launch_1x1_splitk(const float* x, const float* wt, const float* bias, const float* in_mean,
+                      const float* in_scale, const float* in_shift, const float* residual, float* y,
                       const DlioConvDesc& d, hipStream_t s) {
   const int P = d.OH * d.OW;
   const int pix_blocks = cdiv(P, 128);
   const int co_tiles = cdiv(d.Cout, 32 * MR);
   const int64_t blocks = (int64_t)pix_blocks * co_tiles * d.N;
   if (blocks <= 0 || blocks > 0x7fffffff) return DLIO_EINVAL;
-  hipLaunchKernelGGL((conv1x1_v4_splitk_kernel<MR>), dim3((unsigned)blocks), dim3(256), 0, s, x, wt, bias,
-                     residual, y, d, pix_blocks, co_tiles);
+  if (in_scale)
+    hipLaunchKernelGGL((conv1x1_v4_splitk_kernel<MR, true>), dim3((unsigned)blocks), dim3(256), 0, s, x, wt,
+                       bias, in_mean, in_scale, in_shift, residual, y, d, pix_blocks, co_tiles);
+  else
+    hipLaunchKernelGGL((conv1x1_v4_splitk_kernel<MR, false>), dim3((unsigned)blocks), dim3(256), 0, s, x, wt,
+                       bias, in_mean, in_scale, in_shift, residual, y, d, pix_blocks, co_tiles);
   return dlio_check_launch();
 }
 
@@ -805,8 +829,11 @@ int launch_1x1_nr(const float* x, const float* wt, const float* bias, const floa
   // under-filled float4 launch with a long K: split K over the workgroup's waves
   static const int splitk = getenv("DLIO_1X1_SPLITK") ? atoi(getenv("DLIO_1X1_SPLITK")) : 1;   // tuning knob
   if constexpr (MR <= 2) {
-    if (splitk && use_v4 && !in_scale && (P & 3) == 0 && (al & 15) == 0 && d.Cin >= 256)   // sweep: 192-channel layers lose
-      return launch_1x1_splitk<MR>(x, wt, bias, residual, y, d, s);
+    if (splitk && use_v4 && (P & 3) == 0 && (al & 15) == 0 && d.Cin >= 256)   // sweep: 192-channel layers lose
+      return launch_1x1_splitk<MR>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
+    // an in-affine layer would otherwise fall to the dword kernel: the under-filled float4 launch is faster
+    if (use_v4 && in_scale && (P & 3) == 0 && (al & 15) == 0 && waves4 >= 512)
+      return launch_1x1_v4<MR>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
   }
   const int64_t waves2 = (int64_t)cdiv(d.OH * d.OW, 64) * cdiv(d.Cout, 32 * MR) * d.N;
   static const int force_nr = getenv("DLIO_1X1_NR") ? atoi(getenv("DLIO_1X1_NR")) : 0;   // tuning knob
