@@ -86,6 +86,7 @@ SIGNATURES = {
     "dlio_ew_scale": (_i, [_p, _f, _p, _i64, _p]),
     "dlio_copy2d": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
     "dlio_dropout_fwd": (_i, [_p, _p, _p, _i64, _f, _u64, _u64, _p]),
+    "dlio_dropout_fwd_at": (_i, [_p, _p, _p, _i64, _f, _u64, _u64, _p, _p]),
     "dlio_dropout_bwd": (_i, [_p, _p, _p, _i64, _f, _p]),
     "dlio_nonfinite_flag": (_i, [_p, _i64, _p, _p]),
     "dlio_rnn_ws_bytes": (_sz, [_i, _i, _i]),

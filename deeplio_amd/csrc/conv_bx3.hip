@@ -23,6 +23,14 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// timing ablations of the 3x3 kernel (tools/bx3_ablate.py builds variant libraries; results are WRONG with any
+// bit set): 1 no split + LDS store, 2 no patch loads, 4 no weight-fragment loads, 8 no LDS fragment reads
+#ifndef BX3_ABLATE
+#define BX3_ABLATE 0
+#endif
+template <class T>
+__device__ __forceinline__ void opaque(T& v) { asm volatile("" : "=v"(v)); }
+
 __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
   h = (__bf16)x;
   const float r = x - (float)h;
@@ -126,6 +134,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
   const float* xn = x + ((size_t)n * d.in_ctot + d.in_coff) * HW;
   float reg[NPOS][16];
   auto load_chunk = [&](int kc) {
+    if constexpr (BX3_ABLATE & 2) { if (kc > 0) return; }
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
       const int ci = kc * 16 + c;
@@ -172,8 +181,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
 #pragma unroll
     for (int m = 0; m < MR; ++m)
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
-        a[m][p] = *reinterpret_cast<const bf16x8*>(base + p * wplane + (size_t)nrow[m] * 16);
+      for (int p = 0; p < 3; ++p) {
+        if constexpr (BX3_ABLATE & 4) opaque(a[m][p]);
+        else a[m][p] = *reinterpret_cast<const bf16x8*>(base + p * wplane + (size_t)nrow[m] * 16);
+      }
   };
 
   f32x16 acc[MR][TWN];
@@ -208,8 +219,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
       for (int t = 0; t < TWN; ++t) {
         const int pos = (wave + kh) * PC + 32 * t + l31 + kw;
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-          b[t][p] = *reinterpret_cast<const bf16x8*>(buf + p * PLANE + pos * 16 + 8 * half);
+        for (int p = 0; p < 3; ++p) {
+          if constexpr (BX3_ABLATE & 8) opaque(b[t][p]);
+          else b[t][p] = *reinterpret_cast<const bf16x8*>(buf + p * PLANE + pos * 16 + 8 * half);
+        }
       }
       const auto& aa = a[tap % RING];
       // six products, smallest first; consecutive MFMAs go to different accumulators
@@ -232,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
     const __bf16* cur = smem + (size_t)(kc & 1) * 3 * PLANE;
     __bf16* nxt = smem + (size_t)((kc + 1) & 1) * 3 * PLANE;
     compute(cur, kc, kc + 1 < KC);
-    if (kc + 1 < KC) store_chunk(nxt);
+    if constexpr (!(BX3_ABLATE & 1)) { if (kc + 1 < KC) store_chunk(nxt); }
     __syncthreads();
   }
 

@@ -93,10 +93,13 @@ def join_aux_streams():
             cur.wait_stream(s)
 
 
+_NO_JOIN = [False]      # set while a hipGraph records a backward pass (a captured stream must not wait for outside work)
+
+
 def _want_join():
     """called from backward nodes: join the auxiliary streams once when this backward pass ends
     (engine final callbacks run on the stream that called backward())"""
-    if _AUX and not _JOIN_PENDING[0]:
+    if _AUX and not _JOIN_PENDING[0] and not _NO_JOIN[0]:
         _JOIN_PENDING[0] = True
         try:
             torch.autograd.Variable._execution_engine.queue_callback(join_aux_streams)
@@ -327,7 +330,11 @@ class _CBR:
         else:
             # the weight gradient goes straight into the flat gradient buffer and nothing on the
             # tape waits for it: fork it so the data-gradient chain continues immediately
-            _forked(ws, lambda: ops.conv2d_wgrad(x, draw, dw, dd, in_aff=in_aff, accumulate=True), draw, x)
+            # (every operand is marked as in use on the companion stream: the apply-on-load constants too -- they are
+            #  the last thing a deferred Fire block frees, and a reused block under a queued kernel gave wrong
+            #  gradients for the first layers of backward, state-dependently)
+            _forked(ws, lambda: ops.conv2d_wgrad(x, draw, dw, dd, in_aff=in_aff, accumulate=True), draw, x,
+                    *(in_aff if in_aff is not None else ()))
         if need_dx:
             conv_dgrad(draw, weight, d, dx, dx_ctot, dx_coff, dx_residual, dxr_ctot, dxr_coff,
                        dx_accumulate)
@@ -831,7 +838,7 @@ class SegSumFn(Function):
         return ops.seg_sum_bwd(dy.contiguous(), *ctx.shape)
 
 
-_DROPOUT_STATE = {"seed": 0x5EED, "offset": 0}
+_DROPOUT_STATE = {"seed": 0x5EED, "offset": 0, "base": None}
 
 
 def manual_seed(seed):
@@ -841,13 +848,46 @@ def manual_seed(seed):
     _DROPOUT_STATE["offset"] = 0
 
 
+def dropout_offset():
+    return _DROPOUT_STATE["offset"]
+
+
+def advance_dropout(groups):
+    """skip `groups` counter values (a replayed hipGraph consumed them on the device)"""
+    _DROPOUT_STATE["offset"] += int(groups)
+
+
+class dropout_base:
+    """While active, dropout launches take their Philox offset as (local offset + *base) with `base` an int64
+    device scalar: recorded into a hipGraph they draw a new mask at every replay.  `consumed` = the counter
+    values one pass through the block uses; the caller writes the process-wide offset into `base` before a
+    replay and advances it by `consumed` afterwards (the masks are then the ones the eager step would draw)."""
+
+    def __init__(self, base):
+        self.base, self.consumed = base, 0
+
+    def __enter__(self):
+        self.saved = (_DROPOUT_STATE["offset"], _DROPOUT_STATE["base"])
+        _DROPOUT_STATE["offset"], _DROPOUT_STATE["base"] = 0, self.base
+        return self
+
+    def __exit__(self, *exc):
+        self.consumed = _DROPOUT_STATE["offset"]
+        _DROPOUT_STATE["offset"], _DROPOUT_STATE["base"] = self.saved
+        return False
+
+
+def _dropout_launch(x, p):
+    off = _DROPOUT_STATE["offset"]
+    _DROPOUT_STATE["offset"] = off + (x.numel() + 3) // 4
+    return ops.dropout_fwd(x, p, _DROPOUT_STATE["seed"], off, base=_DROPOUT_STATE["base"])
+
+
 class DropoutFn(Function):
     @staticmethod
     def forward(ctx, x, p):
         x = x.contiguous()
-        off = _DROPOUT_STATE["offset"]
-        _DROPOUT_STATE["offset"] = off + (x.numel() + 3) // 4
-        y, mask = ops.dropout_fwd(x, p, _DROPOUT_STATE["seed"], off)
+        y, mask = _dropout_launch(x, p)
         ctx.save_for_backward(mask)
         ctx.p = p
         return y
@@ -926,9 +966,7 @@ class RNNFn(Function):
                         t.record_stream(side)
                 rec["out"] = out_l
                 if l + 1 < L and training and p > 0.:
-                    off = _DROPOUT_STATE["offset"]
-                    _DROPOUT_STATE["offset"] = off + (out_l.numel() + 3) // 4
-                    inp, mask = ops.dropout_fwd(out_l, p, _DROPOUT_STATE["seed"], off)
+                    inp, mask = _dropout_launch(out_l, p)
                     rec["mask"] = mask
                 else:
                     inp = out_l

@@ -407,6 +407,10 @@ class BaseLidarFeatNet(BaseNet):
         self._side = None
 
     def forward(self, x):
+        return self.head(*self.encode(x))
+
+    def encode(self, x):
+        """the two siamese encoders -> (feature a, feature b, (batch, sequence))"""
         xyz, nrm = x[0], x[1]
         b, s, t, c, h, w = xyz.shape
         xa, xb = xyz.reshape(b * s, t * c, h, w), nrm.reshape(b * s, t * c, h, w)
@@ -450,6 +454,11 @@ class BaseLidarFeatNet(BaseNet):
             fa, fb = self.encoder1(xa), self.encoder2(xb)
             if fa.dim() == 4:
                 fa, fb = _gap(fa), _gap(fb)
+        return fa, fb, (b, s)
+
+    def head(self, fa, fb, bs):
+        """fusion of the two encoder features, fc1, dropout (the part behind the encoders: small, serial)"""
+        b, s = bs
         if self.fusion == 'cat':
             y = Fh.Cat2Fn.apply(fa, fb)
         else:
@@ -711,8 +720,16 @@ class DeepLIO(BaseNet):
         self.fc_ori = nn.Linear(in_shape, 3)
 
     def forward(self, x):
+        return self.forward_tail(self.forward_features(x))
+
+    def forward_features(self, x, defer_imu=True):
+        """The wide part of the step: IMU net and the two lidar encoders, on their own streams.
+        -> dict(lidar=(fa, fb, (b, s)) | None, imu=feature | None, imu_stream=stream | None); with defer_imu
+        the IMU feature is re-attached through DeferredBranchFn (its backward then runs where autograd
+        reaches it), else it is returned on its own tape and the caller runs its backward
+        (tail_graph.TailGraph)."""
         lidar_imgs, imu_meas = x[0], x[1]
-        last = feat_l = feat_i = None
+        enc = feat_i = None
         if self.training and getattr(self, "_bn_counters", None) is not None:
             self._bn_counters += 1
         # The IMU branch (latency-bound persistent RNN kernels, 2 workgroups) is independent of the
@@ -731,17 +748,26 @@ class DeepLIO(BaseNet):
         elif self.imu_feat_net is not None:     # same issue order (dropout counter) as the overlapped path
             feat_i = self.imu_feat_net(imu_meas)
         if self.lidar_feat_net is not None:
-            last = feat_l = self.lidar_feat_net(lidar_imgs)
+            enc = self.lidar_feat_net.encode(lidar_imgs)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
             feat_i.record_stream(torch.cuda.current_stream())
-            if _DEFER_IMU and torch.is_grad_enabled() and feat_i.requires_grad:
+            if defer_imu and _DEFER_IMU and torch.is_grad_enabled() and feat_i.requires_grad:
                 feat_i = Fh.DeferredBranchFn.attach(feat_i, side)
+        return {"lidar": enc, "imu": feat_i, "imu_stream": side}
+
+    def forward_tail(self, feats, grads_ready_hook=True):
+        """Everything behind the feature extractors: lidar fusion + fc1, fusion net, odometry net, heads --
+        ~100 small dependent launches."""
+        last = feat_l = None
+        feat_i = feats["imu"]
+        if feats["lidar"] is not None:
+            last = feat_l = self.lidar_feat_net.head(*feats["lidar"])
         if feat_i is not None:
             last = feat_i
         if self.fusion_net is not None:
             last = self.fusion_net([feat_l, feat_i])
-        if (self.tail_grads_ready is not None and self.training and torch.is_tensor(last)
+        if (grads_ready_hook and self.tail_grads_ready is not None and self.training and torch.is_tensor(last)
                 and last.requires_grad):
             cb = self.tail_grads_ready
             last.register_hook(lambda g: cb())

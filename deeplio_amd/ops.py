@@ -661,11 +661,14 @@ def copy2d(src, lds, dst, ldd, rows, cols, accumulate=False, src_off=0, dst_off=
     return dst
 
 
-def dropout_fwd(x, p, seed, offset):
+def dropout_fwd(x, p, seed, offset, base=None):
+    """base: int64 device scalar added to the Philox offset on the device (replayed launches)"""
     y = torch.empty_like(x)
     mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
-    check(lib.dlio_dropout_fwd(_ptr(x), _ptr(y), _ptr(mask), x.numel(), float(p), int(seed),
-                               int(offset), _stream()), "dropout_fwd")
+    if base is not None and (base.dtype != torch.int64 or base.device != x.device):
+        raise ValueError("dropout offset base must be an int64 tensor on the input's device")
+    check(lib.dlio_dropout_fwd_at(_ptr(x), _ptr(y), _ptr(mask), x.numel(), float(p), int(seed),
+                                  int(offset), _ptr(base), _stream()), "dropout_fwd")
     return y, mask
 
 

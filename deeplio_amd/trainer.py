@@ -8,12 +8,14 @@ import types
 
 import torch
 
+from . import functional as Fh
 from . import ops
 from .losses import get_loss_function
 from .misc import build_config_container
 from .nets import get_model
 from .optimizer import create_optimizer
 from .se3 import se3_to_SE3
+from .tail_graph import TailGraph
 
 
 class TrainStep:
@@ -41,6 +43,14 @@ class TrainStep:
         self.gc_every = int(os.environ.get("DLIO_GC_EVERY", "100"))
         self._gc_armed = False
         self._steps = 0
+        # DLIO_TAIL_GRAPH=1: from step `tail_after`+1 on the serial middle of the step (everything between the
+        # encoders' last layer and their first backward kernel) is one hipGraph launch.  Off by default: without a
+        # profiler attached the host is ~4.5 ms ahead of the GPU when it reaches that part, the ~230 launches
+        # take 1.27 ms of GPU time eager and 1.42 ms replayed (a graph node costs >= 4.5 us); it pays when the
+        # host is the slower side (under rocprofv3: 34.8 -> 31.0 ms/step), tools/step_sections.py
+        self.tail_mode = os.environ.get("DLIO_TAIL_GRAPH", "0") != "0"
+        self.tail_after = int(os.environ.get("DLIO_TAIL_GRAPH_AFTER", "2"))     # eager warm-up steps: workspaces, caches
+        self._tails = {}
         self.model.train()
         if grad_sync is not None:
             self.set_grad_sync(grad_sync)
@@ -81,12 +91,11 @@ class TrainStep:
             gc.enable()
         self._gc_armed = False
 
-    def step(self, imgs, normals, imus, gts_f2f, gts_f2g):
-        self._steps += 1
-        self._manage_gc()
+    def _tail(self, feats, gts_f2f, gts_f2g, hook=True):
+        """features -> loss: the model's last layers, NaN/Inf flags, SE(3) chain, criterion"""
         gt_f2f_t, gt_f2f_w = gts_f2f[:, :, 0:3], gts_f2f[:, :, 3:]
         gt_f2g_p, gt_f2g_q = gts_f2g[:, :, 0:3], gts_f2g[:, :, 3:7]
-        pred_f2f_t, pred_f2f_w = self.model([[imgs, normals], imus])
+        pred_f2f_t, pred_f2f_w = self.model.forward_tail(feats, grads_ready_hook=hook)
         ops.nonfinite_flag(pred_f2f_t, self.flags[0:1])        # trainer.py:240-243, no host sync
         ops.nonfinite_flag(pred_f2f_w, self.flags[0:1])
         pred_f2g_p, pred_f2g_q = se3_to_SE3(pred_f2f_t, pred_f2f_w, status=self.flags[1:2])
@@ -96,14 +105,54 @@ class TrainStep:
         elif lt[1] and not lt[0]:
             pred_f2f_t, pred_f2f_w = pred_f2f_t.detach(), pred_f2f_w.detach()
         sl = slice(1, self.max_glob_seq + 1)
-        loss = self.criterion(pred_f2f_t, pred_f2f_w, pred_f2g_p[:, sl, :], pred_f2g_q[:, sl, :],
+        return self.criterion(pred_f2f_t, pred_f2f_w, pred_f2g_p[:, sl, :], pred_f2g_q[:, sl, :],
                               gt_f2f_t, gt_f2f_w, gt_f2g_p[:, sl, :], gt_f2g_q[:, sl, :])
+
+    def step(self, imgs, normals, imus, gts_f2f, gts_f2g):
+        self._steps += 1
+        self._manage_gc()
+        if self.tail_mode and imgs.is_cuda and self.model.training and self._steps > self.tail_after:
+            return self._step_tail_graph(imgs, normals, imus, gts_f2f, gts_f2g)
+        loss = self._tail(self.model.forward_features([[imgs, normals], imus]), gts_f2f, gts_f2g)
         self.optimizer.zero_grad()
         loss.backward()
         if self.grad_sync is not None:
             self.grad_sync.all_reduce_grads()
         self.optimizer.step()
         return loss.detach()
+
+    def _step_tail_graph(self, imgs, normals, imus, gts_f2f, gts_f2g):
+        """the same step with its serial middle replayed as one hipGraph (tail_graph.py)"""
+        self.optimizer.zero_grad()          # the recorded tail accumulates into the flat gradient buffer
+        feats = self.model.forward_features([[imgs, normals], imus], defer_imu=False)
+        sig = TailGraph.signature_of(feats, gts_f2f, gts_f2g)
+        tg = self._tails.get(sig)
+        if tg is None:
+            if len(self._tails) >= 4:       # ragged last batches etc.: a few shapes, not a leak
+                self._tails.pop(next(iter(self._tails)))
+            tg = self._tails[sig] = TailGraph(self).capture(feats, gts_f2f, gts_f2g)
+        loss, (d_fa, d_fb, d_fi) = tg.replay(feats, gts_f2f, gts_f2g)
+        if self.model.tail_grads_ready is not None:
+            self.model.tail_grads_ready()
+        # The branches' own tapes, eager and multi-stream.  The IMU net first: its latency-bound backward then
+        # runs beside the whole encoder backward, and the host issues it while the GPU replays the tail.
+        fi, side = feats["imu"], feats["imu_stream"]
+        if d_fi is not None:
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream())
+                with Fh.on_stream(side):
+                    torch.autograd.backward([fi], [d_fi])
+            else:
+                torch.autograd.backward([fi], [d_fi])
+        if feats["lidar"] is not None:
+            roots = [(f, g) for f, g in zip(feats["lidar"][:2], (d_fa, d_fb)) if g is not None]
+            if roots:
+                torch.autograd.backward([r[0] for r in roots], [r[1] for r in roots])
+        Fh.join_aux_streams()
+        if self.grad_sync is not None:
+            self.grad_sync.all_reduce_grads()
+        self.optimizer.step()
+        return loss.clone()
 
     def check(self):
         """raise like trainer.py:240-243 / :341-348 if any step since the last check went bad"""

@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 203
+#define DLIO_ABI_VERSION 204
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);           /* "gfx950" */
@@ -298,6 +298,11 @@ int dlio_copy2d(const float* src, int lds, float* dst, int ldd, int rows, int co
 /* nn.Dropout: mask from Philox4x32-10(seed, offset); y = x*mask/(1-p); mask saved as u8 */
 int dlio_dropout_fwd(const float* x, float* y, uint8_t* mask, int64_t n, float p,
                      uint64_t seed, uint64_t offset, dlio_stream_t stream);
+/* the same with the Philox offset = offset + *offset_base read ON THE DEVICE (offset_base may be NULL):
+ * a launch recorded into a hipGraph draws a new mask at every replay (tail_graph.py) */
+int dlio_dropout_fwd_at(const float* x, float* y, uint8_t* mask, int64_t n, float p,
+                        uint64_t seed, uint64_t offset, const uint64_t* offset_base,
+                        dlio_stream_t stream);
 int dlio_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, int64_t n, float p,
                      dlio_stream_t stream);
 /* trainer.py:221-243 NaN/Inf guards: flag[0] |= 1 if any non-finite */

@@ -418,3 +418,55 @@ def test_lidar_fusion_cat_resnet_vs_oracle(dev):
     assert "lidar_feat_net.fc1.weight" in g64
     assert np.median(e_hip) <= max(1e-3, 3.0 * np.median(e_ref)), (np.median(e_hip), np.median(e_ref))
     assert max(e_hip) <= max(2e-2, 10.0 * max(e_ref)), (max(e_hip), max(e_ref))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["headline", "fc-cat"])
+def test_tail_graph_matches_eager(dev, variant):
+    """TrainStep replays the serial middle of the step (fusion, odometry net, heads, SE(3) chain, loss and their
+    backward) as one hipGraph (tail_graph.py).  Same kernels, same order, same Philox offsets (read on the device):
+    losses, flags and every parameter after six steps on changing batches are bit-identical to the eager step."""
+    from deeplio_amd import functional as Fh
+    from deeplio_amd.config import make_config
+    from deeplio_amd.trainer import TrainStep
+    if variant == "headline":
+        cfg = make_config(seq=2)
+    else:
+        cfg = make_config(lidar="lidar-feat-simple-1", imu="imu-feat-fc", fusion="fusion-layer-cat", odom="odom-feat-fc",
+                          seq=3, overrides={"deeplio/dropout": 0.2})
+    S = cfg['datasets']['sequence-size']
+    batches = [tuple(t.to(dev) for t in gc.make_batch(20 + i, 2, S, 5, 64, 256, 50)) for i in range(3)]
+    runs = []
+    for graph in (False, True):
+        torch.manual_seed(3)
+        ts = TrainStep(cfg, (5, 64, 256), dev, 2)
+        ts.tail_mode, ts.tail_after = graph, 2
+        Fh.manual_seed(9)
+        losses = [ts.step(*batches[i % 3]).clone() for i in range(6)]
+        torch.cuda.synchronize()
+        runs.append((losses, ts.optimizer.flat.clone(), ts.flags.clone(), Fh.dropout_offset()))
+        if graph:
+            assert len(ts._tails) == 1 and next(iter(ts._tails.values())).consumed > 0
+        ts.release_gc()
+    (la, pa, fa, oa), (lb, pb, fb, ob) = runs
+    assert oa == ob                                    # the same number of Philox counters consumed
+    assert float(la[0]) != float(la[-1]) and all(bool(torch.isfinite(v)) for v in la)
+    for a, b in zip(la, lb):
+        assert torch.equal(a, b)
+    assert torch.equal(pa, pb) and torch.equal(fa, fb)
+
+
+@pytest.mark.gpu
+def test_tail_graph_recaptures_on_a_new_batch_shape(dev):
+    """a ragged last batch (other B) gets its own recorded tail; the first shape's graph is kept"""
+    from deeplio_amd.config import make_config
+    from deeplio_amd.trainer import TrainStep
+    cfg = make_config(seq=2)
+    ts = TrainStep(cfg, (5, 64, 256), dev, 2)
+    ts.tail_mode, ts.tail_after = True, 1
+    b2 = tuple(t.to(dev) for t in gc.make_batch(5, 2, 2, 5, 64, 256, 50))
+    b1 = tuple(t.to(dev) for t in gc.make_batch(6, 1, 2, 5, 64, 256, 50))
+    vals = [float(ts.step(*b).item()) for b in (b2, b2, b2, b1, b2, b1)]
+    assert len(ts._tails) == 2 and all(np.isfinite(vals))
+    ts.check()
+    ts.release_gc()

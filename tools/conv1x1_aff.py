@@ -19,8 +19,8 @@ def timeit(fn, iters=20):
 
 
 # (name, Cin, squeeze, H, W): the Fire blocks whose input arrives as (raw, aff)
-layers = [("b1.1", 128, 16, 64, 512), ("b2.1", 256, 32, 64, 256), ("b3.1", 384, 48, 32, 128), ("b3.2", 384, 64, 32, 128),
-          ("b3.3", 512, 64, 32, 128), ("b4.1", 512, 64, 16, 64), ("b5.1", 768, 80, 8, 32)]
+layers = [("b1.1", 128, 16, 64, 512), ("b2.1", 256, 32, 64, 256), ("b3.1", 384, 48, 64, 128), ("b3.2", 384, 64, 64, 128),
+          ("b3.3", 512, 64, 64, 128), ("b4.1", 512, 64, 32, 64), ("b5.1", 768, 80, 16, 32)]
 print("%-6s %5s %5s %8s %9s %9s %7s" % ("layer", "cin", "cout", "pixels", "plain us", "aff us", "TB/s"))
 for nm, cin, cout, H, W in layers:
     x = torch.randn(N, cin, H, W, device=dev)
