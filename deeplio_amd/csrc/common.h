@@ -35,6 +35,21 @@ static inline int ew_grid(int64_t work_items, int block) {
   return (int)g;
 }
 
+// XCD-aware workgroup order.  The dispatcher deals workgroups round-robin over the 8 XCDs (workgroup b runs on XCD
+// b % 8), each with its own L2: neighbours in blockIdx -- which the kernels make neighbours in the tensor (the
+// output-channel tiles of one pixel tile, adjacent halo tiles) so that they share input -- land on eight different
+// L2s and every one of them fetches the shared input from HBM again.  With v = (b % 8) * (n / 8) + b / 8 an XCD
+// works through a contiguous range of virtual indices, in order.
+#ifndef DLIO_XCD_SWIZZLE
+#define DLIO_XCD_SWIZZLE 1
+#endif
+__device__ __forceinline__ int xcd_block_index() {
+  const int b = blockIdx.x;
+  if constexpr (!DLIO_XCD_SWIZZLE) return b;
+  const int per = gridDim.x >> 3;
+  return b < (per << 3) ? (b & 7) * per + (b >> 3) : b;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(
   __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);    // [2 buffers][NPOSP][16]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
-  int bid = blockIdx.x;
+  int bid = xcd_block_index();
   const int cot = bid % co_tiles; bid /= co_tiles;
   const int tw = bid % tiles_w; bid /= tiles_w;
   const int th = bid % tiles_h;
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void conv1x1_bf16_kernel(
     const __bf16* __restrict__ x, const __bf16* __restrict__ wt, const float* __restrict__ bias,
     const __bf16* residual, __bf16* y, DlioConvDesc d, int pix_blocks, int co_tiles) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
-  int bid = blockIdx.x;
+  int bid = xcd_block_index();
   const int cot = bid % co_tiles; bid /= co_tiles;
   const int pb = bid % pix_blocks; bid /= pix_blocks;
   const int n = bid;

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
   __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);    // [2 buffers][3 planes][NPOSP][16]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
-  int bid = blockIdx.x;
+  int bid = xcd_block_index();
   const int cot = bid % co_tiles; bid /= co_tiles;
   const int tw = bid % tiles_w; bid /= tiles_w;
   const int th = bid % tiles_h;
@@ -278,22 +278,36 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
 // B fragment of pixel tile e (split in registers), weights come pre-split ([chunk][plane][n][16]).
 // These layers sit at the fp32-MFMA ridge (20-25 FLOP/B); with 2.7x less MFMA time per product they
 // are purely HBM-bound.
-template <int MR>
-__global__ __launch_bounds__(256) void conv1x1_bx3_kernel(
+// AFF (apply-on-load): the stored input is the producer's RAW output; x' = (x - mean[ci]) * scale[ci] + shift[ci]
+// (+ ReLU when d.in_relu) is formed right before the split.  The three constants per input channel sit in LDS
+// ([ci][4] floats, zero rows behind Cin so that padded channels stay 0); a lane reads the row of each of its eight
+// channels with one ds_read_b128.
+template <int MR, bool AFF>
+__global__ __launch_bounds__(256, 2) void conv1x1_bx3_kernel(
     const float* __restrict__ x, const __bf16* __restrict__ wt, const float* __restrict__ bias,
+    const float* __restrict__ in_mean, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
     const float* residual, float* y, DlioConvDesc d, int pix_blocks, int co_tiles) {
+  extern __shared__ __attribute__((aligned(16))) float aff_tab[];      // AFF: [KC * 16][4]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
-  int bid = blockIdx.x;
+  int bid = xcd_block_index();
   const int cot = bid % co_tiles; bid /= co_tiles;
   const int pb = bid % pix_blocks; bid /= pix_blocks;
   const int n = bid;
   const int P = d.OH * d.OW;
   const int co0 = cot * 32 * MR;
   const int p = (pb * 4 + wave) * 128 + 4 * l31;
+  const int Cin = d.Cin, Cout = d.Cout, KC = (Cin + 15) >> 4;
+  if constexpr (AFF) {
+    for (int c = threadIdx.x; c < KC * 16; c += 256) {
+      const bool cv = c < Cin;
+      *reinterpret_cast<float4*>(aff_tab + 4 * c) = make_float4(cv ? in_mean[c] : 0.f, cv ? in_scale[c] : 0.f,
+                                                                cv ? in_shift[c] : 0.f, 0.f);
+    }
+    __syncthreads();
+  }
   if ((pb * 4 + wave) * 128 >= P) return;
   const bool pvalid = p < P;            // P % 4 == 0: a lane's four pixels are all in or all out
   const size_t pc = pvalid ? p : 0;
-  const int Cin = d.Cin, Cout = d.Cout, KC = (Cin + 15) >> 4;
 
   f32x16 acc[MR][4];
 #pragma unroll
@@ -303,57 +317,84 @@ __global__ __launch_bounds__(256) void conv1x1_bx3_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][e][r] = 0.f;
 
-  const float* xq = x + ((size_t)n * d.in_ctot + d.in_coff) * (size_t)P + pc;
+  const float* xn = x + ((size_t)n * d.in_ctot + d.in_coff) * (size_t)P;      // wave-uniform
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xn), 0, (int)((size_t)Cin * P * 4),
+                                                                         0x00020000);
+  const unsigned rowb = (unsigned)P * 4u;                                   // bytes per channel plane
+  const unsigned voff = ((unsigned)pc + 8u * (unsigned)half * (unsigned)P) * 4u;   // (lanes past P read pixel 0 and store nothing)
   const size_t wplane = (size_t)Cout * 16;
-  const __bf16* wq[MR];
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(wt), 0,
+                                                                         (int)((size_t)KC * 3 * wplane * 2), 0x00020000);
+  unsigned woff[MR];
 #pragma unroll
-  for (int m = 0; m < MR; ++m) wq[m] = wt + (size_t)min(co0 + m * 32 + l31, Cout - 1) * 16 + 8 * half;
+  for (int m = 0; m < MR; ++m) woff[m] = ((unsigned)min(co0 + m * 32 + l31, Cout - 1) * 16u + 8u * (unsigned)half) * 2u;
 
+  // the activation loads are double buffered; the weight fragments (L1 / L2 hits) have one buffer for two output-channel
+  // tiles -- refilled right behind the MFMAs that used them -- so that the kernel fits two waves per SIMD
+  constexpr int AB = MR == 2 ? 1 : 2;
   float4 v[2][8];
-  bf16x8 a[2][MR][3];
-  auto load_chunk = [&](int kc, int s) {
+  bf16x8 a[AB][MR][3];
+  auto load_a = [&](int kc, int s) {
 #pragma unroll
     for (int m = 0; m < MR; ++m)
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl)
-        a[s][m][pl] = *reinterpret_cast<const bf16x8*>(wq[m] + ((size_t)kc * 3 + pl) * wplane);
+        a[s % AB][m][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+            wrsrc, woff[m], (unsigned)(kc * 3 + pl) * (unsigned)wplane * 2u, 0));
+  };
+  auto load_chunk = [&](int kc, int s) {
+    if (AB == 2) load_a(kc, s);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int ci = kc * 16 + 8 * half + j;
-      float4 t = *reinterpret_cast<const float4*>(xq + (size_t)min(ci, Cin - 1) * P);
-      if (ci >= Cin) t = make_float4(0.f, 0.f, 0.f, 0.f);
-      v[s][j] = t;
-    }
+    for (int j = 0; j < 8; ++j)
+      // buffer descriptor over this image's Cin planes + ONE per-lane 32-bit offset + a scalar offset per row (eight
+      // 64-bit row pointers were what spilled at two waves per SIMD); rows behind Cin are out of range: they read 0
+      v[s][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, (unsigned)(kc * 16 + j) * rowb, 0));
   };
   auto mfma_chunk = [&](int s) {
-    bf16x8 bh[4], bm[4], bl[4];
+    // one pixel tile (float4 component e) at a time: its eight channels are split into three bf16x8 fragments and
+    // used at once -- 12 fragment registers live instead of 48 (with two output-channel tiles the kernel then
+    // fits two waves per SIMD: the load / MFMA / store phases of a wave are serial, a second wave fills them)
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+    if constexpr (AFF) {
+      const bool relu_in = d.in_relu != 0;
+      const int kc = s >> 1;                 // (the chunk index travels in the upper bits of s)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float e4[4] = {v[s][j].x, v[s][j].y, v[s][j].z, v[s][j].w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        __bf16 h, m, l;
-        split3(e4[e], h, m, l);
-        bh[e][j] = h; bm[e][j] = m; bl[e][j] = l;
+      for (int j = 0; j < 8; ++j) {
+        const float4 t = *reinterpret_cast<const float4*>(aff_tab + 4 * (kc * 16 + 8 * half + j));
+        float4 w = v[s & 1][j];
+        w.x = (w.x - t.x) * t.y + t.z; w.y = (w.y - t.x) * t.y + t.z;
+        w.z = (w.z - t.x) * t.y + t.z; w.w = (w.w - t.x) * t.y + t.z;
+        if (relu_in) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
+        v[s & 1][j] = w;
       }
     }
-    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+    s &= 1;
 #pragma unroll
-    for (int q = 0; q < 6; ++q)
+    for (int e = 0; e < 4; ++e) {
+      bf16x8 bb[3];
 #pragma unroll
-      for (int m = 0; m < MR; ++m)
+      for (int j = 0; j < 8; ++j) {
+        const float xv = e == 0 ? v[s][j].x : (e == 1 ? v[s][j].y : (e == 2 ? v[s][j].z : v[s][j].w));
+        __bf16 h, m, l;
+        split3(xv, h, m, l);
+        bb[0][j] = h; bb[1][j] = m; bb[2][j] = l;
+      }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const bf16x8& bb = PB[q] == 0 ? bh[e] : (PB[q] == 1 ? bm[e] : bl[e]);
-          acc[m][e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][m][PA[q]], bb, acc[m][e], 0, 0, 0);
-        }
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+          acc[m][e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s % AB][m][PA[q]], bb[PB[q]], acc[m][e], 0, 0, 0);
+    }
   };
+  if (AB == 1) load_a(0, 0);
   load_chunk(0, 0);
   for (int kc = 0; kc < KC; kc += 2) {
     if (kc + 1 < KC) load_chunk(kc + 1, 1);
-    mfma_chunk(0);
+    mfma_chunk(2 * kc);
+    if (AB == 1 && kc + 1 < KC) load_a(kc + 1, 0);
     if (kc + 2 < KC) load_chunk(kc + 2, 0);
-    if (kc + 1 < KC) mfma_chunk(1);
+    if (kc + 1 < KC) mfma_chunk(2 * (kc + 1) + 1);
+    if (AB == 1 && kc + 2 < KC) load_a(kc + 2, 0);
   }
 
   if (!pvalid) return;
@@ -433,16 +474,22 @@ extern "C" int dlio_conv3x3_bx3_prep(const float* w, void* wt, int Cout, int Cin
   return dlio_conv_bx3_prep(w, wt, Cout, Cin, 9, mode, stream);
 }
 
-extern "C" int dlio_conv1x1_bx3_fwd(const float* x, const void* wt, const float* bias, const float* residual,
-                                    float* y, const DlioConvDesc* dp, dlio_stream_t stream) {
+extern "C" int dlio_conv1x1_bx3_fwd_aff(const float* x, const void* wt, const float* bias, const float* in_mean,
+                                        const float* in_scale, const float* in_shift, const float* residual,
+                                        float* y, const DlioConvDesc* dp, dlio_stream_t stream) {
   if (!x || !wt || !y || !dp) return DLIO_EINVAL;
+  if (in_scale && (!in_mean || !in_shift)) return DLIO_EINVAL;
   const DlioConvDesc& d = *dp;
   if (d.KH != 1 || d.KW != 1 || d.SH != 1 || d.SW != 1 || d.PH || d.PW) return DLIO_EUNSUP;
   if (d.N <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.H <= 0 || d.W <= 0 || d.OH != d.H || d.OW != d.W) return DLIO_EINVAL;
   const int64_t P = (int64_t)d.H * d.W;
+  if ((size_t)d.Cin * P * 4 >= 0x7fffffffull || (size_t)((d.Cin + 15) / 16) * 3 * d.Cout * 32 >= 0x7fffffffull)
+    return DLIO_EUNSUP;                      // 32-bit buffer offsets
   if (P % 4 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
                  reinterpret_cast<uintptr_t>(residual)) & 15))
     return DLIO_EUNSUP;                      // float4 rows: the fp32 kernels of dlio_conv2d_fwd take these
+  const size_t lds = in_scale ? (size_t)((d.Cin + 15) / 16) * 16 * 4 * sizeof(float) : 0;
+  if (lds > 48 * 1024) return DLIO_EUNSUP;
   hipStream_t s = as_stream(stream);
   const double flops = 2.0 * d.N * (double)P * d.Cout * (double)d.Cin;
   const double bytes = 4.0 * d.N * ((double)d.Cin * P + (double)d.Cout * P * (residual ? 2.0 : 1.0));
@@ -452,15 +499,19 @@ extern "C" int dlio_conv1x1_bx3_fwd(const float* x, const void* wt, const float*
   const int pix_blocks = (int)((P + 511) / 512), co_tiles = cdiv(d.Cout, 32 * mr);
   const int64_t blocks = (int64_t)d.N * pix_blocks * co_tiles;
   const __bf16* w = reinterpret_cast<const __bf16*>(wt);
-  if (mr == 1)
-    hipLaunchKernelGGL((conv1x1_bx3_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, x, w, bias, residual, y, d,
-                       pix_blocks, co_tiles);
-  else
-    hipLaunchKernelGGL((conv1x1_bx3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, x, w, bias, residual, y, d,
-                       pix_blocks, co_tiles);
+#define BX1(MRV, AFFV) hipLaunchKernelGGL((conv1x1_bx3_kernel<MRV, AFFV>), dim3((unsigned)blocks), dim3(256), lds, s, x, w, bias, \
+                                          in_mean, in_scale, in_shift, residual, y, d, pix_blocks, co_tiles)
+  if (mr == 1) { if (in_scale) BX1(1, true); else BX1(1, false); }
+  else { if (in_scale) BX1(2, true); else BX1(2, false); }
+#undef BX1
   const int rc = dlio_check_launch();
   dlio_prof_end(2, s);
   return rc;
+}
+
+extern "C" int dlio_conv1x1_bx3_fwd(const float* x, const void* wt, const float* bias, const float* residual,
+                                    float* y, const DlioConvDesc* dp, dlio_stream_t stream) {
+  return dlio_conv1x1_bx3_fwd_aff(x, wt, bias, nullptr, nullptr, nullptr, residual, y, dp, stream);
 }
 
 extern "C" int dlio_conv3x3_bx3_prep_batched(const DlioPrepItem* items_dev, int n_items, int64_t total,

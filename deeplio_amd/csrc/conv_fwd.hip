@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(
   const int l31 = lane & 31;
   const int half = lane >> 5;
 
-  int bid = blockIdx.x;
+  int bid = xcd_block_index();
   const int cot = bid % co_tiles; bid /= co_tiles;
   const int tw = bid % tiles_w;   bid /= tiles_w;
   const int th = bid % tiles_h;   bid /= tiles_h;
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void conv1x1_direct_kernel(
   const int wave = threadIdx.x >> 6;
   const int l31 = lane & 31;
   const int half = lane >> 5;
-  int bid = blockIdx.x;
+  int bid = xcd_block_index();
   const int cot = bid % co_tiles; bid /= co_tiles;
   const int pb = bid % pix_blocks; bid /= pix_blocks;
   const int n = bid;
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void conv1x1_direct_kernel(
 // again one float4 -> 512 contiguous bytes per half-wave, a quarter of the load/store
 // instructions of the dword kernel.
 template <int MR, bool AFF>
-__global__ __launch_bounds__(256) void conv1x1_v4_kernel(
+__global__ __launch_bounds__(256, MR == 2 ? 2 : 1) void conv1x1_v4_kernel(
     const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
     const float* __restrict__ in_mean, const float* __restrict__ in_scale,
     const float* __restrict__ in_shift, const float* residual, float* y, DlioConvDesc d,
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void conv1x1_v4_kernel(
   const int wave = threadIdx.x >> 6;
   const int l31 = lane & 31;
   const int half = lane >> 5;
-  int bid = blockIdx.x;
+  int bid = xcd_block_index();
   const int cot = bid % co_tiles; bid /= co_tiles;
   const int pb = bid % pix_blocks; bid /= pix_blocks;
   const int n = bid;
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_v4_splitk_kernel(
   const int wave = threadIdx.x >> 6;
   const int l31 = lane & 31;
   const int half = lane >> 5;
-  int bid = blockIdx.x;
+  int bid = xcd_block_index();
   const int cot = bid % co_tiles; bid /= co_tiles;
   const int pb = bid % pix_blocks; bid /= pix_blocks;
   const int n = bid;

@@ -249,7 +249,7 @@ class _CBR:
         d = ops.conv_desc(N, Cin, H, W, Cout, KH, KW, stride[0], stride[1], pad[0], pad[1],
                           in_ctot=x_ctot, in_coff=x_coff, out_ctot=raw_ctot, out_coff=raw_coff,
                           in_relu=1 if in_aff is not None else 0)
-        bx3 = _use_bx3(N, Cin, Cout, KH, KW, stride, d.OH, d.OW) and in_aff is None
+        bx3 = _use_bx3(N, Cin, Cout, KH, KW, stride, d.OH, d.OW) and (in_aff is None or (KH, KW) == (1, 1))
         bx3 = bx3 and (KH == 3 or (pad[0] == 0 and pad[1] == 0))
         if bx3:
             wt = ops.conv_bx3_prepped(weight, 0)
@@ -268,7 +268,7 @@ class _CBR:
                     d.wt_ph = {(it[0], it[1]): ops.conv2d_prepped_phase(weight, d.SH, d.SW, it[0], it[1])
                                for it in plan if it is not None}
         if bx3 and KH == 1:
-            ops.conv1x1_bx3_fwd(x, wt, bias, raw, d)
+            ops.conv1x1_bx3_fwd(x, wt, bias, raw, d, in_aff=in_aff)
         elif bx3:
             ops.conv3x3_bx3_fwd(x, wt, bias, raw, d)
         else:
@@ -385,7 +385,7 @@ def conv_dgrad(dy, weight, d, dx, dx_ctot, dx_coff, residual=None, r_ctot=0, r_c
 
 _CONV_BX3 = [os.environ.get("DLIO_CONV_BX3", "1") != "0"]
 _CONV_BX3_1X1 = [os.environ.get("DLIO_CONV_BX3_1X1", "1") != "0"]
-_BX3_1X1_MIN = [int(v) for v in os.environ.get("DLIO_BX3_1X1_MIN", "48,48,65536").split(",")]   # Cin, Cout, pixels
+_BX3_1X1_MIN = [int(v) for v in os.environ.get("DLIO_BX3_1X1_MIN", "16,16,65536,8192").split(",")]   # Cin, Cout, pixels, pixels (widening layers)
 
 
 def set_conv_bx3(on):
@@ -400,11 +400,14 @@ def _use_bx3(N, Cin, Cout, KH, KW, stride, OH, OW):
         return False
     if (KH, KW) == (3, 3):
         return True
-    # 1x1 (conv1x1_bx3_kernel): the layers that sit at the fp32-MFMA ridge -- at least 48 channels on
-    # both sides and enough pixels to fill the chip (blk3: 1.17-1.36x, tools/bench_bx3_1x1.py); the
-    # narrow and the small ones are HBM- or launch-bound on the fp32 kernels already
-    return ((KH, KW) == (1, 1) and _CONV_BX3_1X1[0] and Cin >= _BX3_1X1_MIN[0] and Cout >= _BX3_1X1_MIN[1]
-            and N * OH * OW >= _BX3_1X1_MIN[2] and (OH * OW) % 4 == 0)
+    # 1x1 (conv1x1_bx3_kernel, two waves per SIMD): every layer with enough pixels to fill the chip (blk1-3:
+    # 28-90 us = 4.1-6 TB/s against 35-135 us on the fp32-MFMA float4 kernel, tools/conv1x1_table.py); of the small
+    # ones (blk4/5) the widening layers (few input channels, >= 4x as many output channels: their time is the
+    # store) -- the narrowing ones have a long K loop and few waves, the fp32 split-K kernel is faster there
+    if (KH, KW) != (1, 1) or not _CONV_BX3_1X1[0] or (OH * OW) % 4 or Cin < _BX3_1X1_MIN[0] or Cout < _BX3_1X1_MIN[1]:
+        return False
+    pix = N * OH * OW
+    return pix >= _BX3_1X1_MIN[2] or (pix >= _BX3_1X1_MIN[3] and Cin <= 128 and Cout >= 4 * Cin)
 
 
 _DGRAD_PHASES = [os.environ.get("DLIO_DGRAD_PHASES", "1") != "0"]

@@ -269,9 +269,13 @@ def conv1x1_bx3_prep(w, mode, out=None):
     return out
 
 
-def conv1x1_bx3_fwd(x, wt, bias, y, desc, residual=None):
-    check(lib.dlio_conv1x1_bx3_fwd(_ptr(x), _ptr(wt), _ptr(bias), _ptr(residual), _ptr(y), C.byref(desc), _stream()),
-          "conv1x1_bx3_fwd")
+def conv1x1_bx3_fwd(x, wt, bias, y, desc, residual=None, in_aff=None):
+    """in_aff = (mean, scale, shift) per input channel or None (apply-on-load, see conv2d_fwd)"""
+    m = s = b = None
+    if in_aff is not None:
+        m, s, b = in_aff
+    check(lib.dlio_conv1x1_bx3_fwd_aff(_ptr(x), _ptr(wt), _ptr(bias), _ptr(m), _ptr(s), _ptr(b), _ptr(residual), _ptr(y),
+                                       C.byref(desc), _stream()), "conv1x1_bx3_fwd")
     return y
 
 

@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 204
+#define DLIO_ABI_VERSION 205
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);           /* "gfx950" */
@@ -137,6 +137,12 @@ int dlio_conv_bx3_prep(const float* w, void* wt, int Cout, int Cin, int taps, in
  * DLIO_EUNSUP: use dlio_conv2d_fwd); weights from dlio_conv_bx3_prep(..., taps = 1, mode) */
 int dlio_conv1x1_bx3_fwd(const float* x, const void* wt, const float* bias, const float* residual,
                          float* y, const DlioConvDesc* desc, dlio_stream_t stream);
+/* the same with the apply-on-load transform of dlio_conv2d_fwd on the input (in_scale NULL = none): the stored
+ * input is the producer's raw output, (x - in_mean[ci]) * in_scale[ci] + in_shift[ci] (+ ReLU when desc->in_relu)
+ * is formed while the operand is split */
+int dlio_conv1x1_bx3_fwd_aff(const float* x, const void* wt, const float* bias, const float* in_mean,
+                             const float* in_scale, const float* in_shift, const float* residual,
+                             float* y, const DlioConvDesc* desc, dlio_stream_t stream);
 size_t dlio_conv3x3_bx3_prep_floats(int Cout, int Cin, int mode);
 int dlio_conv3x3_bx3_prep(const float* w, void* wt, int Cout, int Cin, int mode, dlio_stream_t stream);
 /* every split-bf16 layout of a model in one launch (DlioPrepItem as for dlio_conv2d_prep_weights_batched;

@@ -43,7 +43,10 @@ def test_bench_json_contract(dev):
     per_step = {"conv3x3 split-bf16": 48.0, "conv3x3 weight gradient": 24.0, "conv1x1 weight gradient": 48.0,
                 "conv2d_wgrad": 2.0, "conv2d_1x1": 96.0, "conv2d_fwd_mfma": 2.0, "batchnorm": 296.0, "max-pool": 32.0}
     fam = next(k for k in per_step if r["kernel"].startswith(k))
-    assert r["launches_per_step"] == per_step[fam] and r["avg_launch_ms"] > 0
+    # (BatchNorm: 296 with every apply written; apply-on-load skips the 2 expand applies of the 5 bypass-free Fire
+    #  blocks of each encoder: 276)
+    want = (per_step[fam], 276.0) if fam == "batchnorm" else (per_step[fam],)
+    assert r["launches_per_step"] in want and r["avg_launch_ms"] > 0
     # every family, BatchNorm and the pools included, is a candidate: measured in the overlapped pre-pass
     other = r["other"]
     names = set(other) | {next(n for n in ("conv3x3_bx3", "conv2d_1x1", "batchnorm", "wgrad3x3", "wgrad1x1", "pool_se",
@@ -58,7 +61,7 @@ def test_bench_json_contract(dev):
                                                            "backward apply"}
     assert "traffic" in bn
     iso = r["isolated"]
-    assert iso["launches_per_step"] == per_step[fam]
+    assert iso["launches_per_step"] in want
     assert iso["ms_per_step_in_kernel"] < r["other_pass"]["dominant_there"]["ms_per_step_in_kernel"]   # alone: faster
     assert len(iso["other"]) == 7             # the other seven families
 

@@ -59,7 +59,7 @@ def _run_two_ranks(tmp_path, sync_bn, port):
     script = tmp_path / ("worker_%d.py" % sync_bn)
     script.write_text(WORKER % dict(root=ROOT, gold=os.path.join(HERE, "golden"), here=HERE, out=out,
                                     sync_bn="True" if sync_bn else "False"))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", DLIO_BX3_1X1_MIN=SAME_KERNELS)
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=600)[0] for p in procs]
@@ -67,14 +67,27 @@ def _run_two_ranks(tmp_path, sync_bn, port):
     return torch.load(out, weights_only=False)
 
 
+# The 1x1 routing looks at the pixel count of the launch (functional._use_bx3), which halves per rank: a layer may
+# run on the split-bf16 kernel in one process and on the fp32-MFMA kernel in two.  Both are fp32-accurate, but their
+# roundings differ and the encoder gradients amplify 1e-7 in an activation to 1e-3 (ReLU flips) -- the
+# comparisons below are about the data-parallel machinery, so both sides are given the same kernels.
+SAME_KERNELS = "16,16,1,1"
+
+
 def _single_process(dev):
     import golden_common as gc
+    from deeplio_amd import functional as Fh
     from deeplio_amd.trainer import TrainStep
-    ts = TrainStep(make_cfg(), SHAPE, dev, GB)
-    gc.fill_state(ts.model, seed=77)
-    batch = tuple(t.to(dev) for t in gc.make_batch(500, GB, 2, SHAPE[0], SHAPE[1], SHAPE[2], T))
-    loss = ts.step(*batch)
-    torch.cuda.synchronize()
+    saved = list(Fh._BX3_1X1_MIN)
+    Fh._BX3_1X1_MIN[:] = [int(v) for v in SAME_KERNELS.split(",")]
+    try:
+        ts = TrainStep(make_cfg(), SHAPE, dev, GB)
+        gc.fill_state(ts.model, seed=77)
+        batch = tuple(t.to(dev) for t in gc.make_batch(500, GB, 2, SHAPE[0], SHAPE[1], SHAPE[2], T))
+        loss = ts.step(*batch)
+        torch.cuda.synchronize()
+    finally:
+        Fh._BX3_1X1_MIN[:] = saved
     bufs = {k: v.detach().cpu() for k, v in ts.model.named_buffers() if k.endswith("running_mean") or k.endswith("running_var")}
     return float(loss), ts.optimizer.grad.cpu().clone(), bufs, ts
 

@@ -642,8 +642,9 @@ def test_se3_chain_reorthonormalises_long_chains(dev):
     # near qw = 0 liegroups' branches may pick the other sign in fp64)
     assert rel_err(p, p_ref) < 1e-3
     dots = (q.cpu().double() * q_ref.detach()).sum(-1).abs()
-    well = q_ref.detach()[..., 0].abs() > 0.1      # (R - R^T) / (4 qw): the fp32 matrix's rounding is amplified by 1 / qw
-    assert float((1 - dots)[well].abs().max()) < 1e-5 and float((1 - dots).abs().max()) < 5e-2
+    well = q_ref.detach()[..., 0].abs() > 0.3      # (R - R^T) / (4 qw): the fp32 matrix's rounding is amplified by 1 / qw
+    assert float((1 - dots).abs().median()) < 1e-7 and float((1 - dots)[well].abs().max()) < 1e-4 \
+        and float((1 - dots).abs().max()) < 5e-2
     dt, dw = ops.se3_chain_bwd(t.to(dev), w.to(dev), R, dp.to(dev), dq.to(dev), 0)
     assert bool(torch.isfinite(dt).all()) and bool(torch.isfinite(dw).all())
     assert rel_err(dt, tr.grad) < 5e-2        # gradients through 256 products, sign-branch cases included: same scale
@@ -886,3 +887,15 @@ def test_conv1x1_split_bf16_matches_fp64(dev, case):
     with pytest.raises((ValueError, RuntimeError)):       # 3 x 5 = 15 pixels: not a multiple of 4
         ops.conv1x1_bx3_fwd(torch.zeros(1, Cin, 3, 5, device=dev), ops.conv1x1_bx3_prep(w.to(dev), 0), None,
                             torch.zeros(1, Cout, 3, 5, device=dev), ops.conv_desc(1, Cin, 3, 5, Cout, 1, 1, 1, 1, 0, 0))
+    # apply-on-load: the input is stored raw, max(0, (x - mean) * scale + shift) is formed while it is split; the
+    # input is a channel slice of a wider tensor (the constants are indexed by the slice's own channels)
+    aff = torch.randn(3, Cin, generator=g)
+    xw = torch.randn(N, Cin + 3, H, W, generator=g)
+    act = torch.relu((xw[:, 2:2 + Cin].double() - aff[0].double().view(1, -1, 1, 1)) * aff[1].double().view(1, -1, 1, 1)
+                     + aff[2].double().view(1, -1, 1, 1))
+    ref_a = F.conv2d(act, w.double(), b.double())
+    da = ops.conv_desc(N, Cin, H, W, Cout, 1, 1, 1, 1, 0, 0, in_ctot=Cin + 3, in_coff=2, in_relu=1)
+    ya = torch.empty(N, Cout, H, W, device=dev)
+    affd = aff.to(dev)
+    ops.conv1x1_bx3_fwd(xw.to(dev), ops.conv1x1_bx3_prep(w.to(dev), 0), b.to(dev), ya, da, in_aff=(affd[0], affd[1], affd[2]))
+    assert rel_err(ya, ref_a) < 3e-6

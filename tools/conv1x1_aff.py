@@ -33,7 +33,13 @@ for nm, cin, cout, H, W in layers:
     d1 = ops.conv_desc(N, cin, H, W, cout, 1, 1, 1, 1, 0, 0, in_relu=1)
     t0 = timeit(lambda: ops.conv2d_fwd(x, wt, None, y, d0))
     t1 = timeit(lambda: ops.conv2d_fwd(x, wt, None, y2, d1, in_aff=(aff[0], aff[1], aff[2])))
+    wb = ops.conv1x1_bx3_prep(w, 0)
+    y3 = torch.empty_like(y)
+    t2 = timeit(lambda: ops.conv1x1_bx3_fwd(x, wb, None, y3, d0))
+    t3 = timeit(lambda: ops.conv1x1_bx3_fwd(x, wb, None, y3, d1, in_aff=(aff[0], aff[1], aff[2])))
     ref = torch.nn.functional.conv2d(torch.relu((x - aff[0].view(1, -1, 1, 1)) * aff[1].view(1, -1, 1, 1) + aff[2].view(1, -1, 1, 1)), w)
     err = ((y2 - ref).abs().max() / ref.abs().max()).item()
     byt = 4.0 * N * H * W * (cin + cout)
-    print("%-6s %5d %5d %8d %9.1f %9.1f %7.2f  err %.1e" % (nm, cin, cout, N * H * W, t0, t1, byt / t1 / 1e6, err))
+    err3 = ((y3 - ref).abs().max() / ref.abs().max()).item()
+    print("%-6s %5d %5d %8d %9.1f %9.1f %7.2f  err %.1e | bx3 %7.1f aff %7.1f %5.2f TB/s err %.1e" % (
+        nm, cin, cout, N * H * W, t0, t1, byt / t1 / 1e6, err, t2, t3, byt / t3 / 1e6, err3))
