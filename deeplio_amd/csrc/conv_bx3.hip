@@ -99,10 +99,14 @@ __global__ void prep_bx3_batched_kernel(const DlioPrepItem* __restrict__ items, 
   }
 }
 
+// stats (optional): per-channel (sum, sum of squares) of what this workgroup stores, [Cout][slots][2] floats with
+// slot = the workgroup's (image, tile) index -- the train-mode BatchNorm behind the convolution takes its statistics
+// from these partials (dlio_chan_partials_reduce) instead of reading the output again.
 template <int MR, int TWN>
 __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
     const float* __restrict__ x, const __bf16* __restrict__ wt, const float* __restrict__ bias,
-    const float* residual, float* y, DlioConvDesc d, int tiles_w, int tiles_h, int co_tiles, int patch_at) {
+    const float* residual, float* y, DlioConvDesc d, int tiles_w, int tiles_h, int co_tiles, int patch_at,
+    float* __restrict__ stats) {
   constexpr int TH = 4, TW = 32 * TWN;
   constexpr int PR = TH + 2, PC = TW + 2, NPOSP = PR * PC;
   constexpr int NPOS = (NPOSP + 255) / 256;              // patch positions per thread
@@ -251,14 +255,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
 
   // ---- epilogue: D tile col = pixel (lane & 31), row = (r & 3) + 8 (r >> 2) + 4 half
   const int oh = oh0 + wave;
-  if (oh >= d.OH) return;
+  const bool row_ok = oh < d.OH;
+  if (!row_ok && !stats) return;
   const size_t ohw = (size_t)d.OH * d.OW;
+  float* red = reinterpret_cast<float*>(smem_raw);        // statistics: [4 waves][32 * MR channels][2] (the patch buffers are free)
 #pragma unroll
-  for (int m = 0; m < MR; ++m)
+  for (int m = 0; m < MR; ++m) {
+    float ssum[16], ssq[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ssum[r] = ssq[r] = 0.f;
 #pragma unroll
     for (int t = 0; t < TWN; ++t) {
       const int ow = ow0 + 32 * t + l31;
-      if (ow >= d.OW) continue;
+      if (ow >= d.OW || !row_ok) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -268,8 +277,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
         const size_t pix = (size_t)oh * d.OW + ow;
         if (residual) v += residual[((size_t)n * d.res_ctot + d.res_coff + co) * ohw + pix];
         y[((size_t)n * d.out_ctot + d.out_coff + co) * ohw + pix] = v;
+        ssum[r] += v; ssq[r] += v * v;
       }
     }
+    if (stats) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float a = ssum[r], b = ssq[r];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }   // the 32 pixels of a half
+        if (l31 == 0) {
+          const int cl = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;
+          red[(wave * 32 * MR + cl) * 2 + 0] = a;
+          red[(wave * 32 * MR + cl) * 2 + 1] = b;
+        }
+      }
+    }
+  }
+  if (stats) {
+    __syncthreads();
+    if (tid < 64 * MR) {
+      const int cl = tid >> 1, j = tid & 1, co = co0 + cl;
+      if (co < Cout) {
+        const float v = ((red[(0 * 32 * MR + cl) * 2 + j] + red[(1 * 32 * MR + cl) * 2 + j]) + red[(2 * 32 * MR + cl) * 2 + j]) +
+                        red[(3 * 32 * MR + cl) * 2 + j];
+        const int slots = d.N * tiles_h * tiles_w, slot = (n * tiles_h + th) * tiles_w + tw;
+        stats[((size_t)co * slots + slot) * 2 + j] = v;
+      }
+    }
+  }
 }
 
 // ---- 1x1 convolution on the same scheme, no LDS (the float4 structure of conv1x1_v4_kernel in
@@ -286,8 +322,9 @@ template <int MR, bool AFF>
 __global__ __launch_bounds__(256, 2) void conv1x1_bx3_kernel(
     const float* __restrict__ x, const __bf16* __restrict__ wt, const float* __restrict__ bias,
     const float* __restrict__ in_mean, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
-    const float* residual, float* y, DlioConvDesc d, int pix_blocks, int co_tiles) {
+    const float* residual, float* y, DlioConvDesc d, int pix_blocks, int co_tiles, float* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) float aff_tab[];      // AFF: [KC * 16][4]
+  __shared__ float red[4 * 32 * MR * 2];                               // statistics partials of the four waves
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
   int bid = xcd_block_index();
   const int cot = bid % co_tiles; bid /= co_tiles;
@@ -305,7 +342,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bx3_kernel(
     }
     __syncthreads();
   }
-  if ((pb * 4 + wave) * 128 >= P) return;
+  const bool wave_ok = (pb * 4 + wave) * 128 < P;
+  if (!wave_ok && !stats) return;
   const bool pvalid = p < P;            // P % 4 == 0: a lane's four pixels are all in or all out
   const size_t pc = pvalid ? p : 0;
 
@@ -386,9 +424,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bx3_kernel(
           acc[m][e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s % AB][m][PA[q]], bb[PB[q]], acc[m][e], 0, 0, 0);
     }
   };
-  if (AB == 1) load_a(0, 0);
-  load_chunk(0, 0);
-  for (int kc = 0; kc < KC; kc += 2) {
+  if (AB == 1 && wave_ok) load_a(0, 0);
+  if (wave_ok) load_chunk(0, 0);
+  for (int kc = 0; wave_ok && kc < KC; kc += 2) {
     if (kc + 1 < KC) load_chunk(kc + 1, 1);
     mfma_chunk(2 * kc);
     if (AB == 1 && kc + 1 < KC) load_a(kc + 1, 0);
@@ -397,14 +435,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bx3_kernel(
     if (AB == 1 && kc + 2 < KC) load_a(kc + 2, 0);
   }
 
-  if (!pvalid) return;
+  if (!pvalid && !stats) return;
   const size_t plane = (size_t)P;
   float* yb = y + ((size_t)n * d.out_ctot + d.out_coff) * plane + pc;
   const float* rb = residual ? residual + ((size_t)n * d.res_ctot + d.res_coff) * plane + pc : nullptr;
 #pragma unroll
   for (int m = 0; m < MR; ++m) {
     float4 rv[16];
-    if (rb) {
+    if (rb && pvalid) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = min(co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, Cout - 1);
@@ -414,18 +452,44 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bx3_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (co >= Cout) continue;
-      const float bv = bias ? bias[co] : 0.f;
-      float4 o = make_float4(acc[m][0][r] + bv, acc[m][1][r] + bv, acc[m][2][r] + bv, acc[m][3][r] + bv);
-      if (rb) { o.x += rv[r].x; o.y += rv[r].y; o.z += rv[r].z; o.w += rv[r].w; }
-      *reinterpret_cast<float4*>(yb + (size_t)co * plane) = o;
+      float a = 0.f, b = 0.f;
+      if (co < Cout && pvalid) {
+        const float bv = bias ? bias[co] : 0.f;
+        float4 o = make_float4(acc[m][0][r] + bv, acc[m][1][r] + bv, acc[m][2][r] + bv, acc[m][3][r] + bv);
+        if (rb) { o.x += rv[r].x; o.y += rv[r].y; o.z += rv[r].z; o.w += rv[r].w; }
+        *reinterpret_cast<float4*>(yb + (size_t)co * plane) = o;
+        a = (o.x + o.y) + (o.z + o.w);
+        b = (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+      }
+      if (stats) {
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }   // the 128 pixels of the wave
+        if (l31 == 0) {
+          const int cl = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;
+          red[(wave * 32 * MR + cl) * 2 + 0] = a;
+          red[(wave * 32 * MR + cl) * 2 + 1] = b;
+        }
+      }
+    }
+  }
+  if (stats) {
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if (tid < 64 * MR) {
+      const int cl = tid >> 1, j = tid & 1, co = co0 + cl;
+      if (co < Cout) {
+        const float v = ((red[(0 * 32 * MR + cl) * 2 + j] + red[(1 * 32 * MR + cl) * 2 + j]) + red[(2 * 32 * MR + cl) * 2 + j]) +
+                        red[(3 * 32 * MR + cl) * 2 + j];
+        const int slots = d.N * pix_blocks;
+        stats[((size_t)co * slots + (n * pix_blocks + pb)) * 2 + j] = v;
+      }
     }
   }
 }
 
 template <int MR, int TWN>
 int launch_bx3(const float* x, const __bf16* wt, const float* bias, const float* residual, float* y,
-               const DlioConvDesc& d, hipStream_t s) {
+               const DlioConvDesc& d, hipStream_t s, float* stats) {
   constexpr int TH = 4, TW = 32 * TWN;
   const int tiles_w = cdiv(d.OW, TW), tiles_h = cdiv(d.OH, TH), co_tiles = cdiv(d.Cout, 32 * MR);
   const int64_t blocks = (int64_t)d.N * tiles_h * tiles_w * co_tiles;
@@ -444,7 +508,7 @@ int launch_bx3(const float* x, const __bf16* wt, const float* bias, const float*
   static const int force_at = getenv("DLIO_BX3_PATCH_AT") ? atoi(getenv("DLIO_BX3_PATCH_AT")) : -2;
   const int patch_at = force_at >= -1 ? force_at : ((d.Cin + 15) / 16 > 5 ? 0 : -1);
   hipLaunchKernelGGL((conv3x3_bx3_kernel<MR, TWN>), dim3((unsigned)blocks), dim3(256), lds, s, x, wt, bias, residual, y,
-                     d, tiles_w, tiles_h, co_tiles, patch_at);
+                     d, tiles_w, tiles_h, co_tiles, patch_at, stats);
   return dlio_check_launch();
 }
 
@@ -474,9 +538,52 @@ extern "C" int dlio_conv3x3_bx3_prep(const float* w, void* wt, int Cout, int Cin
   return dlio_conv_bx3_prep(w, wt, Cout, Cin, 9, mode, stream);
 }
 
-extern "C" int dlio_conv1x1_bx3_fwd_aff(const float* x, const void* wt, const float* bias, const float* in_mean,
-                                        const float* in_scale, const float* in_shift, const float* residual,
-                                        float* y, const DlioConvDesc* dp, dlio_stream_t stream) {
+// which tile shape a launch gets (shared by the launchers and dlio_conv_bx3_stats_slots)
+static void bx3_1x1_shape(const DlioConvDesc& d, int& mr, int& pix_blocks) {
+  static const int force_mr = getenv("DLIO_BX3_1X1_MR") ? atoi(getenv("DLIO_BX3_1X1_MR")) : 0;
+  mr = force_mr ? force_mr : (d.Cout <= 32 ? 1 : 2);
+  pix_blocks = (int)(((int64_t)d.H * d.W + 511) / 512);
+}
+
+static void bx3_3x3_shape(const DlioConvDesc& d, int& mr, int& twn) {
+  // tile: 64 channels x 64 columns per wave when that still gives every CU a few workgroups,
+  // else narrower tiles (small feature maps / few output channels)
+  static const int force_mr = getenv("DLIO_BX3_MR") ? atoi(getenv("DLIO_BX3_MR")) : 0;     // tuning knobs
+  static const int force_twn = getenv("DLIO_BX3_TWN") ? atoi(getenv("DLIO_BX3_TWN")) : 0;
+  auto blocks = [&](int m, int t) {
+    return (int64_t)d.N * cdiv(d.OH, 4) * cdiv(d.OW, 32 * t) * cdiv(d.Cout, 32 * m);
+  };
+  const int64_t want = 2 * (int64_t)dlio_num_cus();
+  // two pixel blocks per wave halve the weight-fragment traffic (the 16-byte fragment loads run at
+  // the L1 bandwidth limit with one block): in isolation that pays from ~192 input channels on
+  // (tools/bench_bx3.py), inside the training step from 48 on (full-step sweep: 29.05 -> 28.8 ms)
+  static const int twn_cin = getenv("DLIO_BX3_TWN_CIN") ? atoi(getenv("DLIO_BX3_TWN_CIN")) : 48;
+  mr = d.Cout <= 32 ? 1 : 2; twn = (d.OW > 32 && d.Cin >= twn_cin) ? 2 : 1;
+  if (blocks(mr, twn) < want && twn == 2) twn = 1;
+  if (blocks(mr, twn) < want && mr == 2) mr = 1;
+  if (force_mr) mr = force_mr;
+  if (force_twn) twn = force_twn;
+}
+
+extern "C" int dlio_conv_bx3_stats_slots(const DlioConvDesc* dp) {
+  if (!dp) return 0;
+  const DlioConvDesc& d = *dp;
+  if (d.KH == 1 && d.KW == 1) {
+    int mr, pb;
+    bx3_1x1_shape(d, mr, pb);
+    return d.N * pb;
+  }
+  if (d.KH == 3 && d.KW == 3) {
+    int mr, twn;
+    bx3_3x3_shape(d, mr, twn);
+    return d.N * cdiv(d.OH, 4) * cdiv(d.OW, 32 * twn);
+  }
+  return 0;
+}
+
+extern "C" int dlio_conv1x1_bx3_fwd_stats(const float* x, const void* wt, const float* bias, const float* in_mean,
+                                          const float* in_scale, const float* in_shift, const float* residual,
+                                          float* y, float* stats, const DlioConvDesc* dp, dlio_stream_t stream) {
   if (!x || !wt || !y || !dp) return DLIO_EINVAL;
   if (in_scale && (!in_mean || !in_shift)) return DLIO_EINVAL;
   const DlioConvDesc& d = *dp;
@@ -494,13 +601,13 @@ extern "C" int dlio_conv1x1_bx3_fwd_aff(const float* x, const void* wt, const fl
   const double flops = 2.0 * d.N * (double)P * d.Cout * (double)d.Cin;
   const double bytes = 4.0 * d.N * ((double)d.Cin * P + (double)d.Cout * P * (residual ? 2.0 : 1.0));
   dlio_prof_begin(2, s, flops, bytes);
-  static const int force_mr = getenv("DLIO_BX3_1X1_MR") ? atoi(getenv("DLIO_BX3_1X1_MR")) : 0;
-  const int mr = force_mr ? force_mr : (d.Cout <= 32 ? 1 : 2);
-  const int pix_blocks = (int)((P + 511) / 512), co_tiles = cdiv(d.Cout, 32 * mr);
+  int mr, pix_blocks;
+  bx3_1x1_shape(d, mr, pix_blocks);
+  const int co_tiles = cdiv(d.Cout, 32 * mr);
   const int64_t blocks = (int64_t)d.N * pix_blocks * co_tiles;
   const __bf16* w = reinterpret_cast<const __bf16*>(wt);
 #define BX1(MRV, AFFV) hipLaunchKernelGGL((conv1x1_bx3_kernel<MRV, AFFV>), dim3((unsigned)blocks), dim3(256), lds, s, x, w, bias, \
-                                          in_mean, in_scale, in_shift, residual, y, d, pix_blocks, co_tiles)
+                                          in_mean, in_scale, in_shift, residual, y, d, pix_blocks, co_tiles, stats)
   if (mr == 1) { if (in_scale) BX1(1, true); else BX1(1, false); }
   else { if (in_scale) BX1(2, true); else BX1(2, false); }
 #undef BX1
@@ -509,9 +616,15 @@ extern "C" int dlio_conv1x1_bx3_fwd_aff(const float* x, const void* wt, const fl
   return rc;
 }
 
+extern "C" int dlio_conv1x1_bx3_fwd_aff(const float* x, const void* wt, const float* bias, const float* in_mean,
+                                        const float* in_scale, const float* in_shift, const float* residual,
+                                        float* y, const DlioConvDesc* dp, dlio_stream_t stream) {
+  return dlio_conv1x1_bx3_fwd_stats(x, wt, bias, in_mean, in_scale, in_shift, residual, y, nullptr, dp, stream);
+}
+
 extern "C" int dlio_conv1x1_bx3_fwd(const float* x, const void* wt, const float* bias, const float* residual,
                                     float* y, const DlioConvDesc* dp, dlio_stream_t stream) {
-  return dlio_conv1x1_bx3_fwd_aff(x, wt, bias, nullptr, nullptr, nullptr, residual, y, dp, stream);
+  return dlio_conv1x1_bx3_fwd_stats(x, wt, bias, nullptr, nullptr, nullptr, residual, y, nullptr, dp, stream);
 }
 
 extern "C" int dlio_conv3x3_bx3_prep_batched(const DlioPrepItem* items_dev, int n_items, int64_t total,
@@ -522,8 +635,8 @@ extern "C" int dlio_conv3x3_bx3_prep_batched(const DlioPrepItem* items_dev, int 
   return dlio_check_launch();
 }
 
-extern "C" int dlio_conv3x3_bx3_fwd(const float* x, const void* wt, const float* bias, const float* residual,
-                                    float* y, const DlioConvDesc* dp, dlio_stream_t stream) {
+extern "C" int dlio_conv3x3_bx3_fwd_stats(const float* x, const void* wt, const float* bias, const float* residual,
+                                          float* y, float* stats, const DlioConvDesc* dp, dlio_stream_t stream) {
   if (!x || !wt || !y || !dp) return DLIO_EINVAL;
   const DlioConvDesc& d = *dp;
   if (d.KH != 3 || d.KW != 3 || d.SH != 1 || d.SW != 1) return DLIO_EUNSUP;
@@ -535,26 +648,16 @@ extern "C" int dlio_conv3x3_bx3_fwd(const float* x, const void* wt, const float*
   const double bytes = 4.0 * d.N * ((double)d.Cin * d.H * d.W + (double)d.Cout * d.OH * d.OW * (residual ? 2.0 : 1.0));
   dlio_prof_begin(3, s, flops, bytes);      // profiler kind 3: split-bf16 3x3 convolutions
   const __bf16* w = reinterpret_cast<const __bf16*>(wt);
-  // tile: 64 channels x 64 columns per wave when that still gives every CU a few workgroups,
-  // else narrower tiles (small feature maps / few output channels)
-  static const int force_mr = getenv("DLIO_BX3_MR") ? atoi(getenv("DLIO_BX3_MR")) : 0;     // tuning knobs
-  static const int force_twn = getenv("DLIO_BX3_TWN") ? atoi(getenv("DLIO_BX3_TWN")) : 0;
-  auto blocks = [&](int mr, int twn) {
-    return (int64_t)d.N * cdiv(d.OH, 4) * cdiv(d.OW, 32 * twn) * cdiv(d.Cout, 32 * mr);
-  };
-  const int64_t want = 2 * (int64_t)dlio_num_cus();
-  // two pixel blocks per wave halve the weight-fragment traffic (the 16-byte fragment loads run at
-  // the L1 bandwidth limit with one block): in isolation that pays from ~192 input channels on
-  // (tools/bench_bx3.py), inside the training step from 48 on (full-step sweep: 29.05 -> 28.8 ms)
-  static const int twn_cin = getenv("DLIO_BX3_TWN_CIN") ? atoi(getenv("DLIO_BX3_TWN_CIN")) : 48;
-  int mr = d.Cout <= 32 ? 1 : 2, twn = (d.OW > 32 && d.Cin >= twn_cin) ? 2 : 1;
-  if (blocks(mr, twn) < want && twn == 2) twn = 1;
-  if (blocks(mr, twn) < want && mr == 2) mr = 1;
-  if (force_mr) mr = force_mr;
-  if (force_twn) twn = force_twn;
+  int mr, twn;
+  bx3_3x3_shape(d, mr, twn);
   int rc;
-  if (mr == 1) rc = twn == 2 ? launch_bx3<1, 2>(x, w, bias, residual, y, d, s) : launch_bx3<1, 1>(x, w, bias, residual, y, d, s);
-  else rc = twn == 2 ? launch_bx3<2, 2>(x, w, bias, residual, y, d, s) : launch_bx3<2, 1>(x, w, bias, residual, y, d, s);
+  if (mr == 1) rc = twn == 2 ? launch_bx3<1, 2>(x, w, bias, residual, y, d, s, stats) : launch_bx3<1, 1>(x, w, bias, residual, y, d, s, stats);
+  else rc = twn == 2 ? launch_bx3<2, 2>(x, w, bias, residual, y, d, s, stats) : launch_bx3<2, 1>(x, w, bias, residual, y, d, s, stats);
   dlio_prof_end(3, s);
   return rc;
+}
+
+extern "C" int dlio_conv3x3_bx3_fwd(const float* x, const void* wt, const float* bias, const float* residual,
+                                    float* y, const DlioConvDesc* dp, dlio_stream_t stream) {
+  return dlio_conv3x3_bx3_fwd_stats(x, wt, bias, residual, y, nullptr, dp, stream);
 }

@@ -22,6 +22,11 @@ def _new(shape, like):
 
 _SINK = [True]
 _PLANE_BN = [os.environ.get("DLIO_PLANE_BN", "1") != "0"]
+# BatchNorm statistics from the split-bf16 convolutions' epilogue instead of a pass over their output.  Off: measured
+# SLOWER (27.07 vs 26.99 ms/step overlapped, 34.68 vs 34.36 serial) -- the statistics pass runs right behind the
+# convolution and reads its output from L2 / Infinity Cache (13 us average), the epilogue reductions (320 cross-lane
+# steps + a barrier per workgroup) cost the HBM-bound 1x1 kernels more than that
+_FUSED_STATS = [os.environ.get("DLIO_FUSED_BN_STATS", "0") != "0"]
 
 
 def set_grad_sink(on):
@@ -267,26 +272,30 @@ class _CBR:
                 if plan is not None:           # tap-subset layouts of the phase-decomposed data gradient
                     d.wt_ph = {(it[0], it[1]): ops.conv2d_prepped_phase(weight, d.SH, d.SW, it[0], it[1])
                                for it in plan if it is not None}
+        # train-mode statistics from the convolution's own epilogue (split-bf16 kernels): the raw output is not
+        # read a second time for them
+        fused = ops.conv_bx3_stats_buffer(d, x.device) if (bx3 and training and not pre_relu and _FUSED_STATS[0]) else None
+        st = fused[0] if fused is not None else None
         if bx3 and KH == 1:
-            ops.conv1x1_bx3_fwd(x, wt, bias, raw, d, in_aff=in_aff)
+            ops.conv1x1_bx3_fwd(x, wt, bias, raw, d, in_aff=in_aff, stats=st)
         elif bx3:
-            ops.conv3x3_bx3_fwd(x, wt, bias, raw, d)
+            ops.conv3x3_bx3_fwd(x, wt, bias, raw, d, stats=st)
         else:
             ops.conv2d_fwd(x, wt, bias, raw, d, in_aff=in_aff)
         OHW = d.OH * d.OW
         if stats_into is not None:
             prm = ops.bn_train_stats(raw, N, raw_ctot, raw_coff, Cout, OHW, pre_relu, gamma, eps, momentum, rmean, rvar,
-                                     prm=stats_into, beta=beta, shift_out=shift_into)
+                                     prm=stats_into, beta=beta, shift_out=shift_into, fused=fused)
             return d, prm
         if training and _PLANE_BN[0]:
             # statistics + finalise + apply (+ the plane averages an SELayer wants) in 2 launches
             prm = ops.bn_train_apply(raw, raw_ctot, raw_coff, gamma, beta, eps, momentum, rmean, rvar, out,
                                      out_ctot, out_coff, N, Cout, OHW, pre_relu, post_relu, residual, r_ctot,
-                                     r_coff, gap, gap_ctot, gap_coff, r_aff=r_aff)
+                                     r_coff, gap, gap_ctot, gap_coff, r_aff=r_aff, fused=fused)
             return d, prm
         if training:
             prm = ops.bn_train_stats(raw, N, raw_ctot, raw_coff, Cout, OHW, pre_relu, gamma, eps,
-                                     momentum, rmean, rvar)
+                                     momentum, rmean, rvar, fused=fused)
         else:
             prm = ops.bn_eval_params(rmean, rvar, gamma, eps)
         ops.bn_apply(raw, raw_ctot, raw_coff, prm, beta, out, out_ctot, out_coff, N, Cout, OHW,

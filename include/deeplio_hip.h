@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 205
+#define DLIO_ABI_VERSION 206
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);           /* "gfx950" */
@@ -143,6 +143,19 @@ int dlio_conv1x1_bx3_fwd(const float* x, const void* wt, const float* bias, cons
 int dlio_conv1x1_bx3_fwd_aff(const float* x, const void* wt, const float* bias, const float* in_mean,
                              const float* in_scale, const float* in_shift, const float* residual,
                              float* y, const DlioConvDesc* desc, dlio_stream_t stream);
+/* Statistics of the train-mode BatchNorm behind a split-bf16 convolution taken in the convolution's epilogue
+ * (the output is not read again): with stats != NULL every workgroup also writes the per-channel (sum, sum of
+ * squares) of what it stored to stats[Cout][slots][2] floats, slots = dlio_conv_bx3_stats_slots(desc).
+ * dlio_chan_partials_reduce sums them (fixed order, double) into the workspace layout of the phase-2 calls of
+ * dlio_bn_train_stats / dlio_bn_train_apply (N, HW as passed there; ws_bytes >= dlio_chan_stats_ws_bytes). */
+int dlio_conv_bx3_stats_slots(const DlioConvDesc* desc);
+int dlio_conv1x1_bx3_fwd_stats(const float* x, const void* wt, const float* bias, const float* in_mean,
+                               const float* in_scale, const float* in_shift, const float* residual,
+                               float* y, float* stats, const DlioConvDesc* desc, dlio_stream_t stream);
+int dlio_conv3x3_bx3_fwd_stats(const float* x, const void* wt, const float* bias, const float* residual,
+                               float* y, float* stats, const DlioConvDesc* desc, dlio_stream_t stream);
+int dlio_chan_partials_reduce(const float* stats, int C, int slots, int N, int HW, void* ws,
+                              size_t ws_bytes, dlio_stream_t stream);
 size_t dlio_conv3x3_bx3_prep_floats(int Cout, int Cin, int mode);
 int dlio_conv3x3_bx3_prep(const float* w, void* wt, int Cout, int Cin, int mode, dlio_stream_t stream);
 /* every split-bf16 layout of a model in one launch (DlioPrepItem as for dlio_conv2d_prep_weights_batched;
