@@ -198,8 +198,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(
 // ---- 1x1: a wave owns 128 consecutive pixels, lane l the four pixels 4l..4l+3 (one 8-byte load per
 // channel), half selects channels 8*half..8*half+7 of the 16-channel chunk; component e of the eight
 // loads is the B fragment of pixel tile e.  No LDS.
+// Two waves per SIMD (the load / MFMA / store phases of a wave are serial; a second wave fills them): buffer-descriptor
+// loads -- one 32-bit lane offset + scalar row offsets instead of eight 64-bit row pointers, rows behind Cin out of
+// range = 0 -- keep the kernel under 256 registers (conv1x1_bx3_kernel, conv_bx3.hip).
 template <int MR>
-__global__ __launch_bounds__(256) void conv1x1_bf16_kernel(
+__global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(
     const __bf16* __restrict__ x, const __bf16* __restrict__ wt, const float* __restrict__ bias,
     const __bf16* residual, __bf16* y, DlioConvDesc d, int pix_blocks, int co_tiles) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
@@ -223,24 +226,27 @@ __global__ __launch_bounds__(256) void conv1x1_bf16_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][e][r] = 0.f;
 
-  const __bf16* xq = x + ((size_t)n * d.in_ctot + d.in_coff) * (size_t)P + pc;
+  const __bf16* xn = x + ((size_t)n * d.in_ctot + d.in_coff) * (size_t)P;       // wave-uniform
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(xn), 0, (int)((size_t)Cin * P * 2),
+                                                                         0x00020000);
+  const unsigned rowb = (unsigned)P * 2u;                                      // bytes per channel plane
+  const unsigned voff = ((unsigned)pc + 8u * (unsigned)half * (unsigned)P) * 2u;
   const size_t wplane = (size_t)Cout * 16;
-  const __bf16* wq[MR];
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(wt), 0, (int)((size_t)KC * wplane * 2),
+                                                                         0x00020000);
+  unsigned woff[MR];
 #pragma unroll
-  for (int m = 0; m < MR; ++m) wq[m] = wt + (size_t)min(co0 + m * 32 + l31, Cout - 1) * 16 + 8 * half;
+  for (int m = 0; m < MR; ++m) woff[m] = ((unsigned)min(co0 + m * 32 + l31, Cout - 1) * 16u + 8u * (unsigned)half) * 2u;
 
   bf16x4 v[2][8];
   bf16x8 a[2][MR];
   auto load_chunk = [&](int kc, int s) {
 #pragma unroll
-    for (int m = 0; m < MR; ++m) a[s][m] = *reinterpret_cast<const bf16x8*>(wq[m] + (size_t)kc * wplane);
+    for (int m = 0; m < MR; ++m)
+      a[s][m] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, woff[m], (unsigned)kc * (unsigned)wplane * 2u, 0));
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int ci = kc * 16 + 8 * half + j;
-      bf16x4 t = *reinterpret_cast<const bf16x4*>(xq + (size_t)min(ci, Cin - 1) * P);
-      if (ci >= Cin) { t[0] = t[1] = t[2] = t[3] = (__bf16)0.f; }
-      v[s][j] = t;
-    }
+    for (int j = 0; j < 8; ++j)
+      v[s][j] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, voff, (unsigned)(kc * 16 + j) * rowb, 0));
   };
   auto mfma_chunk = [&](int s) {
     bf16x8 b[4];
@@ -371,6 +377,8 @@ extern "C" int dlio_conv1x1_bf16_fwd(const void* x, const void* wt, const float*
   const int64_t P = (int64_t)d.H * d.W;
   if (P % 4 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 7))
     return DLIO_EUNSUP;
+  if ((size_t)d.Cin * P * 2 >= 0x7fffffffull || (size_t)((d.Cin + 15) / 16) * d.Cout * 32 >= 0x7fffffffull)
+    return DLIO_EUNSUP;                      // 32-bit buffer offsets
   hipStream_t s = as_stream(stream);
   const double flops = 2.0 * d.N * (double)P * d.Cout * (double)d.Cin;
   const double bytes = 2.0 * d.N * ((double)d.Cin * P + (double)d.Cout * P * (residual ? 2.0 : 1.0));
