@@ -322,11 +322,16 @@ template <int MR, bool AFF>
 __global__ __launch_bounds__(256, 2) void conv1x1_bx3_kernel(
     const float* __restrict__ x, const __bf16* __restrict__ wt, const float* __restrict__ bias,
     const float* __restrict__ in_mean, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
-    const float* residual, float* y, DlioConvDesc d, int pix_blocks, int co_tiles, float* __restrict__ stats) {
+    const float* residual, float* y, DlioConvDesc d, int pix_blocks, int co_tiles, float* __restrict__ stats,
+    int ksplit, float* __restrict__ slab) {
   extern __shared__ __attribute__((aligned(16))) float aff_tab[];      // AFF: [KC * 16][4]
   __shared__ float red[4 * 32 * MR * 2];                               // statistics partials of the four waves
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
   int bid = xcd_block_index();
+  // K split over workgroups (slab != nullptr; narrowing layers on few pixels: a long channel loop and too few
+  // waves to hide it): this workgroup takes chunks [kc_lo, kc_hi) and writes its partial tile to slab[ks]
+  const int ks = slab ? bid % ksplit : 0;
+  if (slab) bid /= ksplit;
   const int cot = bid % co_tiles; bid /= co_tiles;
   const int pb = bid % pix_blocks; bid /= pix_blocks;
   const int n = bid;
@@ -424,15 +429,30 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bx3_kernel(
           acc[m][e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s % AB][m][PA[q]], bb[PB[q]], acc[m][e], 0, 0, 0);
     }
   };
-  if (AB == 1 && wave_ok) load_a(0, 0);
-  if (wave_ok) load_chunk(0, 0);
-  for (int kc = 0; wave_ok && kc < KC; kc += 2) {
-    if (kc + 1 < KC) load_chunk(kc + 1, 1);
+  const int kper = slab ? (KC + ksplit - 1) / ksplit : KC;
+  const int kc_lo = ks * kper, kc_hi = min(KC, kc_lo + kper);
+  if (AB == 1 && wave_ok && kc_lo < kc_hi) load_a(kc_lo, 0);
+  if (wave_ok && kc_lo < kc_hi) load_chunk(kc_lo, 0);
+  for (int kc = kc_lo; wave_ok && kc < kc_hi; kc += 2) {
+    if (kc + 1 < kc_hi) load_chunk(kc + 1, 1);
     mfma_chunk(2 * kc);
-    if (AB == 1 && kc + 1 < KC) load_a(kc + 1, 0);
-    if (kc + 2 < KC) load_chunk(kc + 2, 0);
-    if (kc + 1 < KC) mfma_chunk(2 * (kc + 1) + 1);
-    if (AB == 1 && kc + 2 < KC) load_a(kc + 2, 0);
+    if (AB == 1 && kc + 1 < kc_hi) load_a(kc + 1, 0);
+    if (kc + 2 < kc_hi) load_chunk(kc + 2, 0);
+    if (kc + 1 < kc_hi) mfma_chunk(2 * (kc + 1) + 1);
+    if (AB == 1 && kc + 2 < kc_hi) load_a(kc + 2, 0);
+  }
+  if (slab) {           // partial tile, [ks][n][co][p] fp32; bias / residual are added by slab_sum_kernel
+    if (!pvalid) return;
+    float* sb = slab + (((size_t)ks * d.N + n) * Cout) * (size_t)P + pc;
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (co < Cout)
+          *reinterpret_cast<float4*>(sb + (size_t)co * P) = make_float4(acc[m][0][r], acc[m][1][r], acc[m][2][r], acc[m][3][r]);
+      }
+    return;
   }
 
   if (!pvalid && !stats) return;
@@ -484,6 +504,31 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bx3_kernel(
         stats[((size_t)co * slots + (n * pix_blocks + pb)) * 2 + j] = v;
       }
     }
+  }
+}
+
+// sum of the K-split partial tiles (fixed order) + bias + residual -> the output slice
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slab, int ksplit, int N, int Cout, int P4,
+                                                       const float* __restrict__ bias, const float* residual, int res_ctot,
+                                                       int res_coff, float* y, int out_ctot, int out_coff) {
+  const int64_t total = (int64_t)N * Cout * P4, stride = total;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int p4 = (int)(i % P4);
+    const int64_t t = i / P4;
+    const int co = (int)(t % Cout), n = (int)(t / Cout);
+    const float4* sp = reinterpret_cast<const float4*>(slab) + i;
+    float4 a = sp[0];
+    for (int k = 1; k < ksplit; ++k) {
+      const float4 b = sp[(int64_t)k * stride];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    const float bv = bias ? bias[co] : 0.f;
+    a.x += bv; a.y += bv; a.z += bv; a.w += bv;
+    if (residual) {
+      const float4 r = reinterpret_cast<const float4*>(residual + ((size_t)n * res_ctot + res_coff + co) * (size_t)P4 * 4)[p4];
+      a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+    }
+    reinterpret_cast<float4*>(y + ((size_t)n * out_ctot + out_coff + co) * (size_t)P4 * 4)[p4] = a;
   }
 }
 
@@ -581,9 +626,31 @@ extern "C" int dlio_conv_bx3_stats_slots(const DlioConvDesc* dp) {
   return 0;
 }
 
-extern "C" int dlio_conv1x1_bx3_fwd_stats(const float* x, const void* wt, const float* bias, const float* in_mean,
-                                          const float* in_scale, const float* in_shift, const float* residual,
-                                          float* y, float* stats, const DlioConvDesc* dp, dlio_stream_t stream) {
+// K split over workgroups for narrowing layers on few pixels: how many slices (1 = none)
+static int bx3_1x1_ksplit(const DlioConvDesc& d) {
+  static const int on = getenv("DLIO_BX3_1X1_KSPLIT") ? atoi(getenv("DLIO_BX3_1X1_KSPLIT")) : 1;
+  if (!on) return 1;
+  int mr, pb;
+  bx3_1x1_shape(d, mr, pb);
+  const int KC = (d.Cin + 15) / 16;
+  const int64_t blocks = (int64_t)d.N * pb * cdiv(d.Cout, 32 * mr);
+  if ((int64_t)d.N * d.H * d.W >= 65536 || KC < 12 || blocks >= 1024) return 1;
+  int ks = (int)((1024 + blocks - 1) / blocks);
+  if (ks > KC / 3) ks = KC / 3;                 // at least three chunks per slice
+  if (ks > 16) ks = 16;
+  return ks < 2 ? 1 : ks;
+}
+
+extern "C" size_t dlio_conv1x1_bx3_ws_bytes(const DlioConvDesc* dp) {
+  if (!dp || dp->KH != 1 || dp->KW != 1) return 0;
+  const int ks = bx3_1x1_ksplit(*dp);
+  return ks < 2 ? 0 : (size_t)ks * dp->N * dp->Cout * dp->H * dp->W * sizeof(float);
+}
+
+extern "C" int dlio_conv1x1_bx3_fwd_ws(const float* x, const void* wt, const float* bias, const float* in_mean,
+                                       const float* in_scale, const float* in_shift, const float* residual,
+                                       float* y, float* stats, void* ws, size_t ws_bytes, const DlioConvDesc* dp,
+                                       dlio_stream_t stream) {
   if (!x || !wt || !y || !dp) return DLIO_EINVAL;
   if (in_scale && (!in_mean || !in_shift)) return DLIO_EINVAL;
   const DlioConvDesc& d = *dp;
@@ -604,16 +671,31 @@ extern "C" int dlio_conv1x1_bx3_fwd_stats(const float* x, const void* wt, const 
   int mr, pix_blocks;
   bx3_1x1_shape(d, mr, pix_blocks);
   const int co_tiles = cdiv(d.Cout, 32 * mr);
-  const int64_t blocks = (int64_t)d.N * pix_blocks * co_tiles;
+  int ksplit = stats ? 1 : bx3_1x1_ksplit(d);
+  if (ksplit > 1 && (!ws || ws_bytes < (size_t)ksplit * d.N * d.Cout * P * sizeof(float))) ksplit = 1;
+  float* slab = ksplit > 1 ? reinterpret_cast<float*>(ws) : nullptr;
+  const int64_t blocks = (int64_t)d.N * pix_blocks * co_tiles * ksplit;
   const __bf16* w = reinterpret_cast<const __bf16*>(wt);
 #define BX1(MRV, AFFV) hipLaunchKernelGGL((conv1x1_bx3_kernel<MRV, AFFV>), dim3((unsigned)blocks), dim3(256), lds, s, x, w, bias, \
-                                          in_mean, in_scale, in_shift, residual, y, d, pix_blocks, co_tiles, stats)
+                                          in_mean, in_scale, in_shift, residual, y, d, pix_blocks, co_tiles, stats, ksplit, slab)
   if (mr == 1) { if (in_scale) BX1(1, true); else BX1(1, false); }
   else { if (in_scale) BX1(2, true); else BX1(2, false); }
 #undef BX1
-  const int rc = dlio_check_launch();
+  int rc = dlio_check_launch();
+  if (!rc && slab) {
+    const int64_t total = (int64_t)d.N * d.Cout * (P / 4);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, s, slab, ksplit, d.N, d.Cout, (int)(P / 4), bias,
+                       residual, d.res_ctot, d.res_coff, y, d.out_ctot, d.out_coff);
+    rc = dlio_check_launch();
+  }
   dlio_prof_end(2, s);
   return rc;
+}
+
+extern "C" int dlio_conv1x1_bx3_fwd_stats(const float* x, const void* wt, const float* bias, const float* in_mean,
+                                          const float* in_scale, const float* in_shift, const float* residual,
+                                          float* y, float* stats, const DlioConvDesc* dp, dlio_stream_t stream) {
+  return dlio_conv1x1_bx3_fwd_ws(x, wt, bias, in_mean, in_scale, in_shift, residual, y, stats, nullptr, 0, dp, stream);
 }
 
 extern "C" int dlio_conv1x1_bx3_fwd_aff(const float* x, const void* wt, const float* bias, const float* in_mean,

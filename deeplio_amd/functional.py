@@ -394,6 +394,7 @@ def conv_dgrad(dy, weight, d, dx, dx_ctot, dx_coff, residual=None, r_ctot=0, r_c
 
 _CONV_BX3 = [os.environ.get("DLIO_CONV_BX3", "1") != "0"]
 _CONV_BX3_1X1 = [os.environ.get("DLIO_CONV_BX3_1X1", "1") != "0"]
+_BX3_1X1_KSPLIT = [os.environ.get("DLIO_BX3_1X1_KSPLIT", "1") != "0"]
 _BX3_1X1_MIN = [int(v) for v in os.environ.get("DLIO_BX3_1X1_MIN", "16,16,65536,8192").split(",")]   # Cin, Cout, pixels, pixels (widening layers)
 
 
@@ -416,7 +417,13 @@ def _use_bx3(N, Cin, Cout, KH, KW, stride, OH, OW):
     if (KH, KW) != (1, 1) or not _CONV_BX3_1X1[0] or (OH * OW) % 4 or Cin < _BX3_1X1_MIN[0] or Cout < _BX3_1X1_MIN[1]:
         return False
     pix = N * OH * OW
-    return pix >= _BX3_1X1_MIN[2] or (pix >= _BX3_1X1_MIN[3] and Cin <= 128 and Cout >= 4 * Cin)
+    if pix >= _BX3_1X1_MIN[2]:
+        return True
+    # small layers: the widening ones, and on the smallest maps (blk5: <= 16 k pixels) the narrowing ones with >= 192
+    # input channels, whose channel loop the kernel splits over workgroups (dlio_conv1x1_bx3_fwd_ws: 39-55 -> 22-25 us;
+    # at 32 k pixels the slabs cost more than the fp32 split-K kernel's 30 us)
+    return pix >= _BX3_1X1_MIN[3] and ((Cin <= 128 and Cout >= 4 * Cin) or
+                                       (_BX3_1X1_KSPLIT[0] and Cin >= 192 and pix <= 16384))
 
 
 _DGRAD_PHASES = [os.environ.get("DLIO_DGRAD_PHASES", "1") != "0"]

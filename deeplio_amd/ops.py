@@ -275,8 +275,11 @@ def conv1x1_bx3_fwd(x, wt, bias, y, desc, residual=None, in_aff=None, stats=None
     m = s = b = None
     if in_aff is not None:
         m, s, b = in_aff
-    check(lib.dlio_conv1x1_bx3_fwd_stats(_ptr(x), _ptr(wt), _ptr(bias), _ptr(m), _ptr(s), _ptr(b), _ptr(residual), _ptr(y),
-                                         _ptr(stats), C.byref(desc), _stream()), "conv1x1_bx3_fwd")
+    nbytes = lib.dlio_conv1x1_bx3_ws_bytes(C.byref(desc)) if stats is None else 0
+    ws = workspace(nbytes, x.device, slot=4) if nbytes else None       # K split over workgroups (narrowing small layers)
+    check(lib.dlio_conv1x1_bx3_fwd_ws(_ptr(x), _ptr(wt), _ptr(bias), _ptr(m), _ptr(s), _ptr(b), _ptr(residual), _ptr(y),
+                                      _ptr(stats), _ptr(ws), ws.numel() if ws is not None else 0, C.byref(desc), _stream()),
+          "conv1x1_bx3_fwd")
     return y
 
 

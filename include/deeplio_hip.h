@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 206
+#define DLIO_ABI_VERSION 207
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);           /* "gfx950" */
@@ -156,6 +156,15 @@ int dlio_conv3x3_bx3_fwd_stats(const float* x, const void* wt, const float* bias
                                float* y, float* stats, const DlioConvDesc* desc, dlio_stream_t stream);
 int dlio_chan_partials_reduce(const float* stats, int C, int slots, int N, int HW, void* ws,
                               size_t ws_bytes, dlio_stream_t stream);
+/* dlio_conv1x1_bx3_fwd_stats with scratch: narrowing layers on few pixels (>= 192 input channels, < 65536 pixels, too
+ * few workgroups to fill the chip) split their channel loop over workgroups, write fp32 partial tiles to ws and sum
+ * them (fixed order, + bias + residual) in a second launch.  dlio_conv1x1_bx3_ws_bytes(desc) = bytes that split
+ * wants (0: the layer runs unsplit); with less (or ws NULL) the call runs unsplit. */
+size_t dlio_conv1x1_bx3_ws_bytes(const DlioConvDesc* desc);
+int dlio_conv1x1_bx3_fwd_ws(const float* x, const void* wt, const float* bias, const float* in_mean,
+                            const float* in_scale, const float* in_shift, const float* residual,
+                            float* y, float* stats, void* ws, size_t ws_bytes, const DlioConvDesc* desc,
+                            dlio_stream_t stream);
 size_t dlio_conv3x3_bx3_prep_floats(int Cout, int Cin, int mode);
 int dlio_conv3x3_bx3_prep(const float* w, void* wt, int Cout, int Cin, int mode, dlio_stream_t stream);
 /* every split-bf16 layout of a model in one launch (DlioPrepItem as for dlio_conv2d_prep_weights_batched;

@@ -935,3 +935,26 @@ def test_bn_statistics_from_the_convolution_epilogue(dev, case):
     for a, c in zip(fused, plain):
         assert rel_err(a, c.double()) < 2e-6
     assert rel_err(rm_a, rm_b.double()) < 2e-6 and rel_err(rv_a, rv_b.double()) < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(16, 512, 80, 16, 32), (4, 768, 80, 8, 64), (2, 384, 48, 16, 16), (1, 200, 24, 4, 32)])
+def test_conv1x1_split_bf16_k_split_over_workgroups(dev, case):
+    """narrowing 1x1 layers on few pixels: the channel loop is split over workgroups, fp32 partial tiles summed in a
+    second launch with bias + residual into a channel slice; same result as the unsplit kernel's to rounding, fp64
+    error as everywhere"""
+    from deeplio_amd import _lib, ops
+    import ctypes as C
+    N, Cin, Cout, H, W = case
+    g = _g(91)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(N, Cout + 2, H, W, generator=g)
+    d = ops.conv_desc(N, Cin, H, W, Cout, 1, 1, 1, 1, 0, 0, out_ctot=Cout + 3, out_coff=2, res_ctot=Cout + 2, res_coff=1)
+    assert _lib.lib.dlio_conv1x1_bx3_ws_bytes(C.byref(d)) > 0            # these shapes do take the split
+    ref = F.conv2d(x.double(), w.double(), b.double()) + res[:, 1:1 + Cout].double()
+    y = torch.zeros(N, Cout + 3, H, W, device=dev)
+    ops.conv1x1_bx3_fwd(x.to(dev), ops.conv1x1_bx3_prep(w.to(dev), 0), b.to(dev), y, d, residual=res.to(dev))
+    assert rel_err(y[:, 2:2 + Cout], ref) < 3e-6
+    assert float(y[:, :2].abs().max()) == 0 and float(y[:, 2 + Cout:].abs().max()) == 0
