@@ -638,6 +638,8 @@ static int bx3_1x1_ksplit(const DlioConvDesc& d) {
   int ks = (int)((1024 + blocks - 1) / blocks);
   if (ks > KC / 3) ks = KC / 3;                 // at least three chunks per slice
   if (ks > 16) ks = 16;
+  static const int force = getenv("DLIO_BX3_1X1_KS_FORCE") ? atoi(getenv("DLIO_BX3_1X1_KS_FORCE")) : 0;   // tuning knob
+  if (force && (int64_t)d.N * d.H * d.W > 16384) ks = force;
   return ks < 2 ? 1 : ks;
 }
 

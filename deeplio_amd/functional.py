@@ -395,6 +395,7 @@ def conv_dgrad(dy, weight, d, dx, dx_ctot, dx_coff, residual=None, r_ctot=0, r_c
 _CONV_BX3 = [os.environ.get("DLIO_CONV_BX3", "1") != "0"]
 _CONV_BX3_1X1 = [os.environ.get("DLIO_CONV_BX3_1X1", "1") != "0"]
 _BX3_1X1_KSPLIT = [os.environ.get("DLIO_BX3_1X1_KSPLIT", "1") != "0"]
+_BX3_1X1_KSPLIT_PIX = [int(os.environ.get("DLIO_BX3_1X1_KSPLIT_PIX", "16384"))]
 _BX3_1X1_MIN = [int(v) for v in os.environ.get("DLIO_BX3_1X1_MIN", "16,16,65536,8192").split(",")]   # Cin, Cout, pixels, pixels (widening layers)
 
 
@@ -423,7 +424,7 @@ def _use_bx3(N, Cin, Cout, KH, KW, stride, OH, OW):
     # input channels, whose channel loop the kernel splits over workgroups (dlio_conv1x1_bx3_fwd_ws: 39-55 -> 22-25 us;
     # at 32 k pixels the slabs cost more than the fp32 split-K kernel's 30 us)
     return pix >= _BX3_1X1_MIN[3] and ((Cin <= 128 and Cout >= 4 * Cin) or
-                                       (_BX3_1X1_KSPLIT[0] and Cin >= 192 and pix <= 16384))
+                                       (_BX3_1X1_KSPLIT[0] and Cin >= 192 and pix <= _BX3_1X1_KSPLIT_PIX[0]))
 
 
 _DGRAD_PHASES = [os.environ.get("DLIO_DGRAD_PHASES", "1") != "0"]
