@@ -214,6 +214,40 @@ def _rnn_dir_stream(like):
     return aux_stream(like.device, "rnndir@%x" % ops.raw_stream())
 
 
+_EXPAND_FORK = [os.environ.get("DLIO_EXPAND_STREAM", "0") != "0"]
+
+
+class _ExpandFork:
+    """Fire forward: the expand1x1 branch (HBM-bound 1x1 convolution + its BatchNorm) on a companion stream beside the
+    expand3x3 branch (MFMA-bound) -- both only read the squeeze output and write disjoint channel slices.
+    `with _ExpandFork(like, *tensors) as f: f.run(lambda: ...)`; leaving the block joins the companion."""
+
+    def __init__(self, like, *tensors):
+        self.on = _EXPAND_FORK[0] and like.is_cuda and not torch.cuda.is_current_stream_capturing()
+        self.tensors = tensors
+        self.s = aux_stream(like.device, "expand@%x" % ops.raw_stream()) if self.on else None
+
+    def __enter__(self):
+        if self.on:
+            self.cur = current_stream_obj(self.s.device_index)
+            self.s.wait_stream(self.cur)
+        return self
+
+    def run(self, fn):
+        if not self.on:
+            return fn()
+        with on_stream(self.s):
+            return fn()
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.cur.wait_stream(self.s)
+            for t in self.tensors:
+                if t is not None:
+                    t.record_stream(self.s)
+        return False
+
+
 def _forked(ws, fn, *tensors):
     """run fn() (a launch whose only output is a sunk gradient) on the companion stream ws"""
     ws.wait_stream(current_stream_obj(ws.device_index))
@@ -559,10 +593,12 @@ class FireFn(Function):
         if defer:
             aff = _new((3, CE), x)
             inv1, inv3 = _new((E1,), x), _new((E3,), x)
-            d_1, _ = _CBR.forward(act_s, S_, 0, S_, H, W, e1w, e1b, e1g, e1be, e1rm, e1rv, (1, 1), (0, 0), training,
-                                  momentum, eps, False, True, raw_e, CE, 0, None, CE, 0, N,
-                                  stats_into=(aff[0, :E1], inv1, aff[1, :E1]), shift_into=aff[2, :E1])
-            d_3, _ = _CBR.forward(act_s, S_, 0, S_, H, W, e3w, e3b, e3g, e3be, e3rm, e3rv, (1, 1), (1, 1), training,
+            with _ExpandFork(x, act_s, raw_e, aff, inv1) as fk:
+                d_1, _ = fk.run(lambda: _CBR.forward(
+                    act_s, S_, 0, S_, H, W, e1w, e1b, e1g, e1be, e1rm, e1rv, (1, 1), (0, 0), training,
+                    momentum, eps, False, True, raw_e, CE, 0, None, CE, 0, N,
+                    stats_into=(aff[0, :E1], inv1, aff[1, :E1]), shift_into=aff[2, :E1]))
+                d_3, _ = _CBR.forward(act_s, S_, 0, S_, H, W, e3w, e3b, e3g, e3be, e3rm, e3rv, (1, 1), (1, 1), training,
                                   momentum, eps, False, True, raw_e, CE, E1, None, CE, E1, N,
                                   stats_into=(aff[0, E1:], inv3, aff[1, E1:]), shift_into=aff[2, E1:])
             ctx.save_for_backward(x, sw, sbe, e1w, e1be, e3w, e3be, raw_s, act_s, raw_e, prm_s, aff, inv1, inv3,
@@ -575,12 +611,15 @@ class FireFn(Function):
         # apply kernels in training, one extra pass otherwise
         fused_gap = want_gap and training and _PLANE_BN[0]
         gap = _new((N, CE), x) if fused_gap else None
-        d_1, prm_1 = _CBR.forward(act_s, S_, 0, S_, H, W, e1w, e1b, e1g, e1be, e1rm, e1rv, (1, 1),
-                                  (0, 0), training, momentum, eps, False, True, raw_e, CE, 0, out,
-                                  CE, 0, N, res, Cin, 0, gap, CE, 0, r_aff=x_aff if bypass else None)
-        d_3, prm_3 = _CBR.forward(act_s, S_, 0, S_, H, W, e3w, e3b, e3g, e3be, e3rm, e3rv, (1, 1),
-                                  (1, 1), training, momentum, eps, False, True, raw_e, CE, E1, out,
-                                  CE, E1, N, res, Cin, E1, gap, CE, E1, r_aff=x_aff if bypass else None)
+        with _ExpandFork(x, act_s, raw_e, out, gap, res, x_aff) as fk:
+            d_1, prm_1 = fk.run(lambda: _CBR.forward(
+                act_s, S_, 0, S_, H, W, e1w, e1b, e1g, e1be, e1rm, e1rv, (1, 1), (0, 0), training, momentum, eps, False, True,
+                raw_e, CE, 0, out, CE, 0, N, res, Cin, 0, gap, CE, 0, r_aff=x_aff if bypass else None))
+            d_3, prm_3 = _CBR.forward(act_s, S_, 0, S_, H, W, e3w, e3b, e3g, e3be, e3rm, e3rv, (1, 1),
+                                      (1, 1), training, momentum, eps, False, True, raw_e, CE, E1, out,
+                                      CE, E1, N, res, Cin, E1, gap, CE, E1, r_aff=x_aff if bypass else None)
+        if fk.on and torch.is_tensor(prm_1):
+            prm_1.record_stream(fk.cur)          # allocated under the companion stream, lives on the caller's
         ctx.save_for_backward(x, sw, sbe, e1w, e1be, e3w, e3be, raw_s, act_s, raw_e, prm_s, prm_1,
                               prm_3, sb, sg, e1b, e1g, e3b, e3g, x_aff)
         ctx.cfg = (d_s, d_1, d_3, training, bypass, False)
