@@ -58,7 +58,7 @@ __global__ void prep_bf16_batched_kernel(const DlioPrepItem* __restrict__ items,
 template <int MR, int TWN>
 __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(
     const __bf16* __restrict__ x, const __bf16* __restrict__ wt, const float* __restrict__ bias,
-    const __bf16* residual, __bf16* y, DlioConvDesc d, int tiles_w, int tiles_h, int co_tiles, int patch_at) {
+    const __bf16* residual, __bf16* y, DlioConvDesc d, int tiles_w, int tiles_h, int co_tiles, int patch_at, int vec_out) {
   constexpr int TH = 4, TW = 32 * TWN;
   constexpr int PR = TH + 2, PC = TW + 2, NPOSP = PR * PC;
   constexpr int NPOS = (NPOSP + 255) / 256;              // patch positions per thread
@@ -176,6 +176,42 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(
   const int oh = oh0 + wave;
   if (oh >= d.OH) return;
   const size_t ohw = (size_t)d.OH * d.OW;
+  if (vec_out) {
+    // Straight from the accumulators a store instruction writes 2-byte elements: two 64-byte pieces.  Transposed through
+    // the wave's own LDS region (fp32, 32 channels at a time, [channel][TW + 8]: one rounding, after bias + residual) a
+    // lane stores 8 pixels = 16 bytes and an instruction covers 8 / TWN channel rows of TW contiguous pixels
+    // (conv3x3_bx3_kernel's epilogue, conv_bx3.hip).
+    constexpr int TWP = TWN == 1 ? TW + 4 : TW + 8;
+    constexpr int Q = TW / 8;                           // 8-pixel groups per channel row
+    float* wbuf = reinterpret_cast<float*>(smem_raw) + wave * (32 * TWP);
+    __bf16* yrow = y + ((size_t)n * d.out_ctot + d.out_coff) * ohw + (size_t)oh * d.OW + ow0;
+    const __bf16* rrow = residual ? residual + ((size_t)n * d.res_ctot + d.res_coff) * ohw + (size_t)oh * d.OW + ow0 : nullptr;
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+#pragma unroll
+      for (int t = 0; t < TWN; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          wbuf[((r & 3) + 8 * (r >> 2) + 4 * half) * TWP + 32 * t + l31] = acc[m][t][r];
+#pragma unroll
+      for (int i = 0; i < (32 * Q) / 64; ++i) {
+        const int idx = i * 64 + lane, cl = idx / Q, q = idx - cl * Q;
+        const int co = co0 + 32 * m + cl;
+        if (co >= Cout || ow0 + 8 * q >= d.OW) continue;
+        const float4 v0 = *reinterpret_cast<const float4*>(wbuf + cl * TWP + 8 * q);
+        const float4 v1 = *reinterpret_cast<const float4*>(wbuf + cl * TWP + 8 * q + 4);
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        const float bv = bias ? bias[co] : 0.f;
+        bf16x8 rv;
+        if (rrow) rv = *reinterpret_cast<const bf16x8*>(rrow + (size_t)co * ohw + 8 * q);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)(v[e] + bv + (rrow ? (float)rv[e] : 0.f));
+        *reinterpret_cast<bf16x8*>(yrow + (size_t)co * ohw + 8 * q) = o;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int m = 0; m < MR; ++m)
 #pragma unroll
@@ -302,10 +338,25 @@ int launch_3x3(const __bf16* x, const __bf16* wt, const float* bias, const __bf1
   const int tiles_w = cdiv(d.OW, TW), tiles_h = cdiv(d.OH, TH), co_tiles = cdiv(d.Cout, 32 * MR);
   const int64_t blocks = (int64_t)d.N * tiles_h * tiles_w * co_tiles;
   if (blocks <= 0 || blocks > 0x7fffffff) return DLIO_EINVAL;
-  const size_t lds = (size_t)2 * (TH + 2) * (TW + 2) * 16 * sizeof(__bf16);
+  size_t lds = (size_t)2 * (TH + 2) * (TW + 2) * 16 * sizeof(__bf16);
   const int patch_at = (d.Cin + 15) / 16 > 5 ? 0 : -1;
+  // 16-byte stores through LDS: rows of 8-pixel groups, 16-byte aligned planes; the fp32 transposed tiles of the four
+  // waves (32 channels at a time) need more LDS than the bf16 patch buffers
+  static const int vec_on = getenv("DLIO_BF16_VEC_OUT") ? atoi(getenv("DLIO_BF16_VEC_OUT")) : 1;
+  const int vec_out = vec_on && (d.OW & 7) == 0 && (((size_t)d.OH * d.OW) & 7) == 0 &&
+                      ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0;
+  if (vec_out) {
+    const size_t need = (size_t)4 * 32 * (TWN == 1 ? TW + 4 : TW + 8) * sizeof(float);
+    if (need > lds) lds = need;
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<MR, TWN>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      attr_done = true;
+    }
+  }
   hipLaunchKernelGGL((conv3x3_bf16_kernel<MR, TWN>), dim3((unsigned)blocks), dim3(256), lds, s, x, wt, bias, residual,
-                     y, d, tiles_w, tiles_h, co_tiles, patch_at);
+                     y, d, tiles_w, tiles_h, co_tiles, patch_at, vec_out);
   return dlio_check_launch();
 }
 

@@ -28,6 +28,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef BX3_ABLATE
 #define BX3_ABLATE 0
 #endif
+#ifndef BX3_STEM_PF
+#define BX3_STEM_PF 4      // weight-fragment prefetch distance (taps) of the 15-tap stem: 12 MFMAs per tap cover less latency
+#endif
 template <class T>
 __device__ __forceinline__ void opaque(T& v) { asm volatile("" : "=v"(v)); }
 
@@ -102,13 +105,15 @@ __global__ void prep_bx3_batched_kernel(const DlioPrepItem* __restrict__ items, 
 // stats (optional): per-channel (sum, sum of squares) of what this workgroup stores, [Cout][slots][2] floats with
 // slot = the workgroup's (image, tile) index -- the train-mode BatchNorm behind the convolution takes its statistics
 // from these partials (dlio_chan_partials_reduce) instead of reading the output again.
-template <int MR, int TWN>
+// KH x KW taps, row stride 1, column stride SW (3x3 / 1: Fire expand3x3 & co; 3x5 / 2: the PointSeg stem,
+// pointseg_net.py:18-20): output column c of a tile reads patch columns SW * c + kw.
+template <int MR, int TWN, int KH = 3, int KW = 3, int SW = 1>
 __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
     const float* __restrict__ x, const __bf16* __restrict__ wt, const float* __restrict__ bias,
     const float* residual, float* y, DlioConvDesc d, int tiles_w, int tiles_h, int co_tiles, int patch_at,
-    float* __restrict__ stats) {
-  constexpr int TH = 4, TW = 32 * TWN;
-  constexpr int PR = TH + 2, PC = TW + 2, NPOSP = PR * PC;
+    float* __restrict__ stats, int vec_out) {
+  constexpr int TH = 4, TW = 32 * TWN, NT = KH * KW;
+  constexpr int PR = TH + KH - 1, PC = SW * (TW - 1) + KW, NPOSP = PR * PC;
   constexpr int NPOS = (NPOSP + 255) / 256;              // patch positions per thread
   constexpr int PLANE = NPOSP * 16;                      // bf16 per plane
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
   for (int j = 0; j < NPOS; ++j) {
     const int pos = tid + j * 256;
     const int r = pos / PC, c = pos - r * PC;
-    const int ih = oh0 - d.PH + r, iw = ow0 - d.PW + c;
+    const int ih = oh0 - d.PH + r, iw = ow0 * SW - d.PW + c;
     pval[j] = pos < NPOSP && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W;
     poff[j] = pval[j] ? ih * d.W + iw : 0;
   }
@@ -153,11 +158,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
       for (int j = 0; j < NPOS; ++j) reg[j][c] = (cv && pval[j]) ? reg[j][c] : 0.f;
     }
   };
+  // column stride 2: the even and the odd patch columns of a row are stored apart, so that the 32 lanes of a B-fragment
+  // read (columns 2 * lane + kw) are 32 consecutive positions again -- conflict-free like the stride-1 layout
+  constexpr int PCH = (PC + 1) / 2;
   auto store_chunk = [&](__bf16* buf) {
 #pragma unroll
     for (int j = 0; j < NPOS; ++j) {
-      const int pos = tid + j * 256;
+      int pos = tid + j * 256;
       if (pos < NPOSP) {
+        if constexpr (SW == 2) {
+          const int r = pos / PC, c = pos - r * PC;
+          pos = r * PC + (c & 1) * PCH + (c >> 1);
+        }
         bf16x8 ph[2], pm[2], pl[2];
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
@@ -201,16 +213,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
 
   // weight fragments run PF taps ahead of their MFMAs (a tap is 6*MR*TWN MFMAs = 0.2-0.6 us of cover
   // per wave; one tap ahead does not hide an L2 miss when only a few waves share the SIMD)
-  constexpr int PF = 2, RING = PF + 1;
+  constexpr int PF = (KW == 5 ? BX3_STEM_PF : 2), RING = PF + 1;
   auto compute = [&](const __bf16* buf, int kc, bool prefetch) {
     bf16x8 a[RING][MR][3];
     if (patch_at < 0 && prefetch) load_chunk(kc + 1);
 #pragma unroll
     for (int p = 0; p < PF; ++p) load_a(p, kc, a[p]);
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int kh = tap / 3, kw = tap - 3 * kh;
-      if (tap + PF < 9) load_a(tap + PF, kc, a[(tap + PF) % RING]);
+    for (int tap = 0; tap < NT; ++tap) {
+      const int kh = tap / KW, kw = tap - KW * kh;
+      if (tap + PF < NT) load_a(tap + PF, kc, a[(tap + PF) % RING]);
       // the next chunk's patch loads go out AFTER the last weight-fragment load of this chunk: loads
       // return in order, and a weight fragment queued behind 16-32 patch loads stalls its MFMAs for
       // a full HBM round trip
@@ -221,7 +233,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
       bf16x8 b[TWN][3];
 #pragma unroll
       for (int t = 0; t < TWN; ++t) {
-        const int pos = (wave + kh) * PC + 32 * t + l31 + kw;
+        const int pos = SW == 2 ? (wave + kh) * PC + (kw & 1) * PCH + (32 * t + l31) + (kw >> 1)
+                                : (wave + kh) * PC + 32 * t + l31 + kw;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
           if constexpr (BX3_ABLATE & 8) opaque(b[t][p]);
@@ -258,6 +271,41 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
   const bool row_ok = oh < d.OH;
   if (!row_ok && !stats) return;
   const size_t ohw = (size_t)d.OH * d.OW;
+  // Stores through LDS (vec_out): straight from the accumulators a store instruction writes two 128-byte pieces (32
+  // pixels of channel c and of channel c + 4) as dwords; transposed through the wave's own LDS region ([channel][TW + 8
+  // floats]: the patch buffers are free, and the row stride puts the two halves on different banks) a lane stores one
+  // float4 and an instruction covers 4 / TWN channel rows of TW contiguous pixels -- a quarter of the store instructions,
+  // 16-byte accesses, bias and residual applied on the way out.
+  if (vec_out && !stats) {
+    constexpr int TWP = TWN == 1 ? TW + 4 : TW + 8;      // (TW + 4: the 64-channel x 32-pixel tile has to fit its 39 KB of patch buffers)
+    float* wbuf = reinterpret_cast<float*>(smem_raw) + wave * (32 * MR * TWP);
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+      for (int t = 0; t < TWN; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          wbuf[(32 * m + (r & 3) + 8 * (r >> 2) + 4 * half) * TWP + 32 * t + l31] = acc[m][t][r];
+    // (each wave reads back only what it wrote itself: no barrier)
+    constexpr int Q = TW / 4;                   // float4 per channel row
+    float* yrow = y + ((size_t)n * d.out_ctot + d.out_coff) * ohw + (size_t)oh * d.OW + ow0;
+    const float* rrow = residual ? residual + ((size_t)n * d.res_ctot + d.res_coff) * ohw + (size_t)oh * d.OW + ow0 : nullptr;
+#pragma unroll
+    for (int i = 0; i < (32 * MR * Q) / 64; ++i) {
+      const int idx = i * 64 + lane, cl = idx / Q, q = idx - cl * Q;
+      const int co = co0 + cl;
+      if (co >= Cout || ow0 + 4 * q >= d.OW) continue;
+      float4 v = *reinterpret_cast<const float4*>(wbuf + cl * TWP + 4 * q);
+      const float bv = bias ? bias[co] : 0.f;
+      v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+      if (rrow) {
+        const float4 rv = *reinterpret_cast<const float4*>(rrow + (size_t)co * ohw + 4 * q);
+        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+      }
+      *reinterpret_cast<float4*>(yrow + (size_t)co * ohw + 4 * q) = v;
+    }
+    return;
+  }
   float* red = reinterpret_cast<float*>(smem_raw);        // statistics: [4 waves][32 * MR channels][2] (the patch buffers are free)
 #pragma unroll
   for (int m = 0; m < MR; ++m) {
@@ -532,18 +580,20 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
   }
 }
 
-template <int MR, int TWN>
+template <int MR, int TWN, int KH = 3, int KW = 3, int SW = 1>
 int launch_bx3(const float* x, const __bf16* wt, const float* bias, const float* residual, float* y,
                const DlioConvDesc& d, hipStream_t s, float* stats) {
   constexpr int TH = 4, TW = 32 * TWN;
   const int tiles_w = cdiv(d.OW, TW), tiles_h = cdiv(d.OH, TH), co_tiles = cdiv(d.Cout, 32 * MR);
   const int64_t blocks = (int64_t)d.N * tiles_h * tiles_w * co_tiles;
   if (blocks <= 0 || blocks > 0x7fffffff) return DLIO_EINVAL;
-  const size_t lds = (size_t)2 * 3 * (TH + 2) * (TW + 2) * 16 * sizeof(__bf16);
+  // one patch buffer is enough for a single-chunk layer (<= 16 input channels: the stem) -- twice the workgroups per CU
+  const size_t lds = (size_t)(d.Cin <= 16 ? 1 : 2) * 3 * (TH + KH - 1) * (SW * (TW - 1) + KW) * 16 * sizeof(__bf16);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bx3_kernel<MR, TWN>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bx3_kernel<MR, TWN, KH, KW, SW>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((size_t)2 * 3 * (TH + KH - 1) * (SW * (TW - 1) + KW) * 16 * sizeof(__bf16)));
     attr_done = true;
   }
   // when the next chunk's patch loads are issued: behind the first three taps' weight fragments for
@@ -552,8 +602,14 @@ int launch_bx3(const float* x, const __bf16* wt, const float* bias, const float*
   // everything for short loops (<= 5 chunks: 3-6 % faster there)
   static const int force_at = getenv("DLIO_BX3_PATCH_AT") ? atoi(getenv("DLIO_BX3_PATCH_AT")) : -2;
   const int patch_at = force_at >= -1 ? force_at : ((d.Cin + 15) / 16 > 5 ? 0 : -1);
-  hipLaunchKernelGGL((conv3x3_bx3_kernel<MR, TWN>), dim3((unsigned)blocks), dim3(256), lds, s, x, wt, bias, residual, y,
-                     d, tiles_w, tiles_h, co_tiles, patch_at, stats);
+  // float4 stores through LDS: rows of 4-pixel groups (OW % 4 == 0, 16-byte aligned planes), the transposed tile fits the
+  // (possibly single) patch buffer
+  static const int vec_on = getenv("DLIO_BX3_VEC_OUT") ? atoi(getenv("DLIO_BX3_VEC_OUT")) : 1;
+  const int vec_out = vec_on && (d.OW & 3) == 0 && (((size_t)d.OH * d.OW) & 3) == 0 &&
+                      ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0 &&
+                      (size_t)4 * 32 * MR * (TWN == 1 ? TW + 4 : TW + 8) * sizeof(float) <= lds;
+  hipLaunchKernelGGL((conv3x3_bx3_kernel<MR, TWN, KH, KW, SW>), dim3((unsigned)blocks), dim3(256), lds, s, x, wt, bias, residual, y,
+                     d, tiles_w, tiles_h, co_tiles, patch_at, stats, vec_out);
   return dlio_check_launch();
 }
 
@@ -744,4 +800,26 @@ extern "C" int dlio_conv3x3_bx3_fwd_stats(const float* x, const void* wt, const 
 extern "C" int dlio_conv3x3_bx3_fwd(const float* x, const void* wt, const float* bias, const float* residual,
                                     float* y, const DlioConvDesc* dp, dlio_stream_t stream) {
   return dlio_conv3x3_bx3_fwd_stats(x, wt, bias, residual, y, nullptr, dp, stream);
+}
+
+// 3x5 taps, stride (1, 2) (the PointSeg stem, pointseg_net.py:18-20: 2C -> 64 channels at 64 x 2048 -> 64 x 1024) on the
+// same kernel; weights from dlio_conv_bx3_prep(taps = 15, mode 0).  Forward only (the stem's input needs no gradient).
+extern "C" int dlio_conv3x5s2_bx3_fwd(const float* x, const void* wt, const float* bias, const float* residual, float* y,
+                                      const DlioConvDesc* dp, dlio_stream_t stream) {
+  if (!x || !wt || !y || !dp) return DLIO_EINVAL;
+  const DlioConvDesc& d = *dp;
+  if (d.KH != 3 || d.KW != 5 || d.SH != 1 || d.SW != 2) return DLIO_EUNSUP;
+  if (d.N <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.H <= 0 || d.W <= 0 || d.PH < 0 || d.PW < 0) return DLIO_EINVAL;
+  if (d.OH != d.H + 2 * d.PH - 2 || d.OW != (d.W + 2 * d.PW - 5) / 2 + 1 || d.OH < 1 || d.OW < 1) return DLIO_EINVAL;
+  hipStream_t s = as_stream(stream);
+  const double flops = 2.0 * d.N * (double)d.OH * d.OW * d.Cout * (double)d.Cin * 15;
+  const double bytes = 4.0 * d.N * ((double)d.Cin * d.H * d.W + (double)d.Cout * d.OH * d.OW * (residual ? 2.0 : 1.0));
+  dlio_prof_begin(3, s, flops, bytes);
+  const __bf16* w = reinterpret_cast<const __bf16*>(wt);
+  static const int force_mr = getenv("DLIO_BX3_STEM_MR") ? atoi(getenv("DLIO_BX3_STEM_MR")) : 0;   // tuning knob
+  const int mr = force_mr ? force_mr : (d.Cout <= 32 ? 1 : 2);
+  const int rc = mr == 1 ? launch_bx3<1, 1, 3, 5, 2>(x, w, bias, residual, y, d, s, nullptr)
+                         : launch_bx3<2, 1, 3, 5, 2>(x, w, bias, residual, y, d, s, nullptr);
+  dlio_prof_end(3, s);
+  return rc;
 }

@@ -290,6 +290,11 @@ class _CBR:
                           in_relu=1 if in_aff is not None else 0)
         bx3 = _use_bx3(N, Cin, Cout, KH, KW, stride, d.OH, d.OW) and (in_aff is None or (KH, KW) == (1, 1))
         bx3 = bx3 and (KH == 3 or (pad[0] == 0 and pad[1] == 0))
+        # the PointSeg stem (3x5, stride (1, 2), pointseg_net.py:18-20), forward only: MFMA-bound on the fp32 matrix
+        # cores (61 % busy), half the MFMA time on the split-bf16 kernel
+        stem = (not bx3 and _CONV_BX3[0] and _CONV_BX3_STEM[0] and (KH, KW) == (3, 5) and tuple(stride) == (1, 2)
+                and in_aff is None and not need_dx)
+        bx3 = bx3 or stem
         if bx3:
             wt = ops.conv_bx3_prepped(weight, 0)
         else:
@@ -308,9 +313,11 @@ class _CBR:
                                for it in plan if it is not None}
         # train-mode statistics from the convolution's own epilogue (split-bf16 kernels): the raw output is not
         # read a second time for them
-        fused = ops.conv_bx3_stats_buffer(d, x.device) if (bx3 and training and not pre_relu and _FUSED_STATS[0]) else None
+        fused = ops.conv_bx3_stats_buffer(d, x.device) if (bx3 and not stem and training and not pre_relu and _FUSED_STATS[0]) else None
         st = fused[0] if fused is not None else None
-        if bx3 and KH == 1:
+        if stem:
+            ops.conv3x5s2_bx3_fwd(x, wt, bias, raw, d)
+        elif bx3 and KH == 1:
             ops.conv1x1_bx3_fwd(x, wt, bias, raw, d, in_aff=in_aff, stats=st)
         elif bx3:
             ops.conv3x3_bx3_fwd(x, wt, bias, raw, d, stats=st)
@@ -428,6 +435,7 @@ def conv_dgrad(dy, weight, d, dx, dx_ctot, dx_coff, residual=None, r_ctot=0, r_c
 
 _CONV_BX3 = [os.environ.get("DLIO_CONV_BX3", "1") != "0"]
 _CONV_BX3_1X1 = [os.environ.get("DLIO_CONV_BX3_1X1", "1") != "0"]
+_CONV_BX3_STEM = [os.environ.get("DLIO_CONV_BX3_STEM", "1") != "0"]
 _BX3_1X1_KSPLIT = [os.environ.get("DLIO_BX3_1X1_KSPLIT", "1") != "0"]
 _BX3_1X1_KSPLIT_PIX = [int(os.environ.get("DLIO_BX3_1X1_KSPLIT_PIX", "16384"))]
 _BX3_1X1_MIN = [int(v) for v in os.environ.get("DLIO_BX3_1X1_MIN", "16,16,65536,8192").split(",")]   # Cin, Cout, pixels, pixels (widening layers)

@@ -250,8 +250,8 @@ def conv_bx3_prepped(w, mode):
     _PrepCache.  Call with the long-lived Parameter (forward); backward receives the layouts on the
     ConvDesc."""
     _chk(w)
-    if tuple(w.shape[2:]) not in ((3, 3), (1, 1)):
-        raise ValueError("split-bf16 kernels exist for 3x3 and 1x1 weights")
+    if tuple(w.shape[2:]) not in ((3, 3), (1, 1), (3, 5)):
+        raise ValueError("split-bf16 kernels exist for 3x3, 1x1 and (forward, stride (1, 2)) 3x5 weights")
     return _PREP.get(w, mode + 2)
 
 
@@ -286,6 +286,13 @@ def conv1x1_bx3_fwd(x, wt, bias, y, desc, residual=None, in_aff=None, stats=None
 def conv3x3_bx3_fwd(x, wt, bias, y, desc, residual=None, stats=None):
     check(lib.dlio_conv3x3_bx3_fwd_stats(_ptr(x), _ptr(wt), _ptr(bias), _ptr(residual), _ptr(y), _ptr(stats), C.byref(desc),
                                          _stream()), "conv3x3_bx3_fwd")
+    return y
+
+
+def conv3x5s2_bx3_fwd(x, wt, bias, y, desc, residual=None):
+    """the PointSeg stem (3x5 taps, stride (1, 2)) on the split-bf16 kernel; wt = conv_bx3_prepped(w, 0)"""
+    check(lib.dlio_conv3x5s2_bx3_fwd(_ptr(x), _ptr(wt), _ptr(bias), _ptr(residual), _ptr(y), C.byref(desc), _stream()),
+          "conv3x5s2_bx3_fwd")
     return y
 
 

@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 207
+#define DLIO_ABI_VERSION 208
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);           /* "gfx950" */
@@ -154,6 +154,10 @@ int dlio_conv1x1_bx3_fwd_stats(const float* x, const void* wt, const float* bias
                                float* y, float* stats, const DlioConvDesc* desc, dlio_stream_t stream);
 int dlio_conv3x3_bx3_fwd_stats(const float* x, const void* wt, const float* bias, const float* residual,
                                float* y, float* stats, const DlioConvDesc* desc, dlio_stream_t stream);
+/* the split-bf16 kernel with 3x5 taps and stride (1, 2): the PointSeg stem (pointseg_net.py:18-20), forward only;
+ * weights from dlio_conv_bx3_prep(taps = 15, mode 0) */
+int dlio_conv3x5s2_bx3_fwd(const float* x, const void* wt, const float* bias, const float* residual, float* y,
+                           const DlioConvDesc* desc, dlio_stream_t stream);
 int dlio_chan_partials_reduce(const float* stats, int C, int slots, int N, int HW, void* ws,
                               size_t ws_bytes, dlio_stream_t stream);
 /* dlio_conv1x1_bx3_fwd_stats with scratch: narrowing layers on few pixels (>= 192 input channels, < 65536 pixels, too

@@ -38,9 +38,9 @@ def test_bench_json_contract(dev):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-3
     assert 0.0 < r["frac"] < 1.0
     # live event timing of the family with the largest OVERLAPPED time (launches per step at the headline
-    # shape: 48 split-bf16 3x3, 24 + 48 + 2 weight gradients, 96 1x1, 2 fp32 multi-tap stems, 4 x 74 BatchNorm
+    # shape: 48 split-bf16 3x3 + the 2 stems, 24 + 48 + 2 weight gradients, 96 1x1, 4 x 74 BatchNorm
     # launches, 32 pool launches)
-    per_step = {"conv3x3 split-bf16": 48.0, "conv3x3 weight gradient": 24.0, "conv1x1 weight gradient": 48.0,
+    per_step = {"conv3x3 split-bf16": 50.0, "conv3x3 weight gradient": 24.0, "conv1x1 weight gradient": 48.0,
                 "conv2d_wgrad": 2.0, "conv2d_1x1": 96.0, "conv2d_fwd_mfma": 2.0, "batchnorm": 296.0, "max-pool": 32.0}
     fam = next(k for k in per_step if r["kernel"].startswith(k))
     # (BatchNorm: 296 with every apply written; apply-on-load skips the 2 expand applies of the 5 bypass-free Fire
@@ -52,8 +52,9 @@ def test_bench_json_contract(dev):
     names = set(other) | {next(n for n in ("conv3x3_bx3", "conv2d_1x1", "batchnorm", "wgrad3x3", "wgrad1x1", "pool_se",
                                            "conv2d_fwd_mfma", "conv2d_wgrad_mfma")
                                if n not in other)}
-    assert names == {"conv3x3_bx3", "conv2d_1x1", "batchnorm", "wgrad3x3", "wgrad1x1", "pool_se", "conv2d_fwd_mfma",
-                     "conv2d_wgrad_mfma"}
+    # (the fp32 multi-tap family is empty at the headline shape since the PointSeg stem runs on the split-bf16 kernel)
+    assert names - {"conv2d_fwd_mfma"} == {"conv3x3_bx3", "conv2d_1x1", "batchnorm", "wgrad3x3", "wgrad1x1", "pool_se",
+                                           "conv2d_wgrad_mfma"}
     dom_ovl = r["other_pass"]["dominant_there"]["ms_per_step_in_kernel"]
     assert all(dom_ovl >= v["ms_per_step_in_kernel"] for v in other.values())     # dominant on OVERLAPPED time
     bn = other.get("batchnorm") or r
@@ -63,7 +64,7 @@ def test_bench_json_contract(dev):
     iso = r["isolated"]
     assert iso["launches_per_step"] in want
     assert iso["ms_per_step_in_kernel"] < r["other_pass"]["dominant_there"]["ms_per_step_in_kernel"]   # alone: faster
-    assert len(iso["other"]) == 7             # the other seven families
+    assert len(iso["other"]) in (6, 7)        # the other families (the fp32 multi-tap one is empty at the headline shape)
 
 
 def test_bench_cpu_baseline_object(dev):

@@ -958,3 +958,25 @@ def test_conv1x1_split_bf16_k_split_over_workgroups(dev, case):
     ops.conv1x1_bx3_fwd(x.to(dev), ops.conv1x1_bx3_prep(w.to(dev), 0), b.to(dev), y, d, residual=res.to(dev))
     assert rel_err(y[:, 2:2 + Cout], ref) < 3e-6
     assert float(y[:, :2].abs().max()) == 0 and float(y[:, 2 + Cout:].abs().max()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 10, 64, 8, 70), (1, 10, 64, 64, 256), (3, 4, 24, 5, 33), (1, 16, 40, 9, 130)])
+def test_stem_conv3x5_stride2_split_bf16_matches_fp64(dev, case):
+    """the PointSeg stem (3x5 taps, stride (1, 2), padding (1, 2), pointseg_net.py:18-20) on the split-bf16 kernel:
+    error vs fp64 of the size of the fp32-MFMA kernel's own, ragged widths / channel counts included"""
+    from deeplio_amd import ops
+    N, Cin, Cout, H, W = case
+    g = _g(55)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 5, generator=g) / (Cin * 15) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), (1, 2), (1, 2))
+    d = ops.conv_desc(N, Cin, H, W, Cout, 3, 5, 1, 2, 1, 2)
+    assert (d.OH, d.OW) == tuple(ref.shape[2:])
+    y = torch.empty(N, Cout, d.OH, d.OW, device=dev)
+    ops.conv3x5s2_bx3_fwd(x.to(dev), ops.conv_bx3_prepped(torch.nn.Parameter(w.to(dev)), 0), b.to(dev), y, d)
+    y32 = torch.empty_like(y)
+    ops.conv2d_fwd(x.to(dev), ops.conv2d_prep_weight(w.to(dev), 0), b.to(dev), y32, d)
+    e_bx3, e_f32 = rel_err(y, ref), rel_err(y32, ref)
+    assert e_bx3 < 3e-6 and e_bx3 < 4 * e_f32 + 2e-7, (e_bx3, e_f32)
