@@ -61,8 +61,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   const int l31 = lane & 31;
   const int half = lane >> 5;
 
-  int bid = blockIdx.x;
-  const int split = bid % splits; bid /= splits;
+  // XCD-aware order (common.h): the (output-channel tile, input-channel chunk) pairs of one pixel split are
+  // neighbours -- they read the same dY / X pixels -- and an XCD works through whole splits
+  int bid = xcd_block_index();
+  const int npairs = co_tiles * ci_chunks;
+  const int split = bid / npairs; bid -= split * npairs;
   const int cic = bid % ci_chunks; bid /= ci_chunks;
   const int cot = bid;
   const int co0 = cot * C::CO_T;
@@ -387,8 +390,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_adirect_kernel(
   const int l31 = lane & 31;
   const int half = lane >> 5;
 
-  int bid = blockIdx.x;
-  const int split = bid % splits; bid /= splits;
+  int bid = xcd_block_index();           // XCD-aware: the pairs of one pixel split are neighbours (see conv_wgrad_kernel)
+  const int npairs = co_tiles * ci_chunks;
+  const int split = bid / npairs; bid -= split * npairs;
   const int cic = bid % ci_chunks; bid /= ci_chunks;
   const int co0 = bid * C::CO_T;
   const int c0 = cic * C::CKMAX;
@@ -694,8 +698,9 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_direct_kernel(
   const int l31 = lane & 31;
   const int half = lane >> 5;
 
-  int bid = blockIdx.x;
-  const int split = bid % splits; bid /= splits;
+  int bid = xcd_block_index();           // XCD-aware: the pairs of one pixel split are neighbours (see conv_wgrad_kernel)
+  const int npairs = co_tiles * ci_chunks;
+  const int split = bid / npairs; bid -= split * npairs;
   const int cic = bid % ci_chunks; bid /= ci_chunks;
   const int co0 = bid * 32 * MR;
   const int c0 = cic * 32 * NT;
