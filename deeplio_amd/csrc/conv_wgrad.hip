@@ -944,8 +944,11 @@ bool make_plan(const DlioConvDesc& d, WgPlan& p) {
   p.tiles_h = cdiv(d.OH, 4);
   const int64_t total_tiles = (int64_t)d.N * p.tiles_w * p.tiles_h;
   int64_t pairs = (int64_t)p.co_tiles * p.ci_chunks;
-  static const int tgt = getenv("DLIO_WGRAD_BLOCKS") ? atoi(getenv("DLIO_WGRAD_BLOCKS")) : 512;
-  // floor, not ceil: 2 workgroups per CU = 512 slots, a 513th block costs a whole extra round
+  // one workgroup per CU: the weight-gradient kernels run on companion streams beside the data-gradient chain, and with
+  // the XCD-aware order half the workgroups leave the chain more of the chip than they lose (sweep: 256 / 192 -> 26.75,
+  // 512 -> 27.0, 128 -> 26.96 ms/step)
+  static const int tgt = getenv("DLIO_WGRAD_BLOCKS") ? atoi(getenv("DLIO_WGRAD_BLOCKS")) : 256;
+  // floor, not ceil: a block more than the slots costs a whole extra round
   int64_t splits = tgt / pairs > 0 ? tgt / pairs : 1;
   if (splits > total_tiles) splits = total_tiles;
   const size_t slab = (size_t)d.Cout * d.Cin * taps * 4;
