@@ -706,20 +706,26 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_direct_kernel(
   const int c0 = cic * 32 * NT;
   const size_t hw = (size_t)d.H * d.W;
 
-  const float* arow[MR];
-  const float* brow[NT];
+  // buffer descriptors over the two tensors + a 32-bit lane offset per row (the 64-bit row pointers of the 64 x 64 tile
+  // spilled); the launcher has checked that both tensors are < 4 GB
+  constexpr unsigned ES = 4 / ED;                 // bytes per element
+  const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(dy), 0, (int)(unsigned)min((size_t)d.N * d.out_ctot * hw * ES, (size_t)0xffffff00u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(x), 0, (int)(unsigned)min((size_t)d.N * d.in_ctot * hw * ES, (size_t)0xffffff00u), 0x00020000);
+  unsigned aoff[MR], boff[NT];
   bool va[MR], vb[NT];
 #pragma unroll
   for (int m = 0; m < MR; ++m) {
     const int co = co0 + m * 32 + l31;
     va[m] = co < d.Cout;
-    arow[m] = dy + (((size_t)d.out_coff + (va[m] ? co : 0)) * hw + half * 16) / ED;
+    aoff[m] = (unsigned)((((size_t)d.out_coff + (va[m] ? co : 0)) * hw + half * 16) * ES);
   }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int ci = c0 + t * 32 + l31;
     vb[t] = ci < d.Cin;
-    brow[t] = x + (((size_t)d.in_coff + (vb[t] ? ci : 0)) * hw + half * 16) / ED;
+    boff[t] = (unsigned)((((size_t)d.in_coff + (vb[t] ? ci : 0)) * hw + half * 16) * ES);
   }
   float amu[NT], asc[NT], ash[NT];
   if constexpr (AFF) {
@@ -729,7 +735,7 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_direct_kernel(
       amu[t] = in_mean[ci]; asc[t] = in_scale[ci]; ash[t] = in_shift[ci];
     }
   }
-  const size_t a_img = (size_t)d.out_ctot * hw / ED, b_img = (size_t)d.in_ctot * hw / ED;
+  const unsigned a_img = (unsigned)((size_t)d.out_ctot * hw * ES), b_img = (unsigned)((size_t)d.in_ctot * hw * ES);   // bytes per image
 
   f32x16 acc[MR][NT];
 #pragma unroll
@@ -750,20 +756,20 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_direct_kernel(
   }
   auto load = [&](float4 (&a)[MR][4], float4 (&b)[NT][4], int g) {
     const int n = g / segs_per_img;
-    const size_t o = (size_t)(g - n * segs_per_img) * 32 / ED;
+    const unsigned o = (unsigned)(g - n * segs_per_img) * 32u * ES;
 #pragma unroll
     for (int m = 0; m < MR; ++m)
       if (va[m]) {
-        const float4* p = reinterpret_cast<const float4*>(arow[m] + n * a_img + o);
 #pragma unroll
-        for (int q = 0; q < (NAT ? 2 : 4); ++q) a[m][q] = p[q];
+        for (int q = 0; q < (NAT ? 2 : 4); ++q)
+          a[m][q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff[m], (unsigned)n * a_img + o + 16u * q, 0));
       }
 #pragma unroll
     for (int t = 0; t < NT; ++t)
       if (vb[t]) {
-        const float4* p = reinterpret_cast<const float4*>(brow[t] + n * b_img + o);
 #pragma unroll
-        for (int q = 0; q < (NAT ? 2 : 4); ++q) b[t][q] = p[q];
+        for (int q = 0; q < (NAT ? 2 : 4); ++q)
+          b[t][q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(brsrc, boff[t], (unsigned)n * b_img + o + 16u * q, 0));
       }
   };
   const bool relu_in = d.in_relu != 0;
