@@ -52,6 +52,7 @@ SIGNATURES = {
     "dlio_conv1x1_bx3_fwd_stats": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _cd, _p]),
     "dlio_conv3x3_bx3_fwd_stats": (_i, [_p, _p, _p, _p, _p, _p, _cd, _p]),
     "dlio_conv3x5s2_bx3_fwd": (_i, [_p, _p, _p, _p, _p, _cd, _p]),
+    "dlio_conv3x3_bx3_fwd_aff": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _cd, _p]),
     "dlio_chan_partials_reduce": (_i, [_p, _i, _i, _i, _i, _p, _sz, _p]),
     "dlio_conv1x1_bx3_ws_bytes": (_sz, [_cd]),
     "dlio_conv1x1_bx3_fwd_ws": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _cd, _p]),

@@ -107,11 +107,14 @@ __global__ void prep_bx3_batched_kernel(const DlioPrepItem* __restrict__ items, 
 // from these partials (dlio_chan_partials_reduce) instead of reading the output again.
 // KH x KW taps, row stride 1, column stride SW (3x3 / 1: Fire expand3x3 & co; 3x5 / 2: the PointSeg stem,
 // pointseg_net.py:18-20): output column c of a tile reads patch columns SW * c + kw.
-template <int MR, int TWN, int KH = 3, int KW = 3, int SW = 1>
+// AFF (apply-on-load): the stored input is the producer's RAW output; max(0, (x - mean[ci]) * scale[ci] + shift[ci]) (the
+// ReLU when d.in_relu) is formed when a chunk is split into LDS -- padding positions stay 0 (they pad the ACTIVATED tensor).
+template <int MR, int TWN, int KH = 3, int KW = 3, int SW = 1, bool AFF = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
     const float* __restrict__ x, const __bf16* __restrict__ wt, const float* __restrict__ bias,
     const float* residual, float* y, DlioConvDesc d, int tiles_w, int tiles_h, int co_tiles, int patch_at,
-    float* __restrict__ stats, int vec_out) {
+    float* __restrict__ stats, int vec_out, const float* __restrict__ in_mean, const float* __restrict__ in_scale,
+    const float* __restrict__ in_shift) {
   constexpr int TH = 4, TW = 32 * TWN, NT = KH * KW;
   constexpr int PR = TH + KH - 1, PC = SW * (TW - 1) + KW, NPOSP = PR * PC;
   constexpr int NPOS = (NPOSP + 255) / 256;              // patch positions per thread
@@ -161,7 +164,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
   // column stride 2: the even and the odd patch columns of a row are stored apart, so that the 32 lanes of a B-fragment
   // read (columns 2 * lane + kw) are 32 consecutive positions again -- conflict-free like the stride-1 layout
   constexpr int PCH = (PC + 1) / 2;
-  auto store_chunk = [&](__bf16* buf) {
+  auto store_chunk = [&](__bf16* buf, int kcs) {
+    if constexpr (AFF) {
+      const bool relu_in = d.in_relu != 0;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const int ci = min(kcs * 16 + c, Cin - 1);                  // uniform: scalar loads
+        const float mu = in_mean[ci], sc = in_scale[ci], sh = in_shift[ci];
+        const bool cv = kcs * 16 + c < Cin;
+#pragma unroll
+        for (int j = 0; j < NPOS; ++j) {
+          float v = (reg[j][c] - mu) * sc + sh;
+          if (relu_in) v = fmaxf(v, 0.f);
+          reg[j][c] = (cv && pval[j]) ? v : 0.f;
+        }
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NPOS; ++j) {
       int pos = tid + j * 256;
@@ -256,13 +274,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
 
   // ---- chunk loop, LDS double buffered, one barrier per chunk
   load_chunk(0);
-  store_chunk(smem);
+  store_chunk(smem, 0);
   __syncthreads();
   for (int kc = 0; kc < KC; ++kc) {
     const __bf16* cur = smem + (size_t)(kc & 1) * 3 * PLANE;
     __bf16* nxt = smem + (size_t)((kc + 1) & 1) * 3 * PLANE;
     compute(cur, kc, kc + 1 < KC);
-    if constexpr (!(BX3_ABLATE & 1)) { if (kc + 1 < KC) store_chunk(nxt); }
+    if constexpr (!(BX3_ABLATE & 1)) { if (kc + 1 < KC) store_chunk(nxt, kc + 1); }
     __syncthreads();
   }
 
@@ -580,9 +598,13 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
   }
 }
 
-template <int MR, int TWN, int KH = 3, int KW = 3, int SW = 1>
+template <int MR, int TWN, int KH = 3, int KW = 3, int SW = 1, bool AFF = false>
 int launch_bx3(const float* x, const __bf16* wt, const float* bias, const float* residual, float* y,
-               const DlioConvDesc& d, hipStream_t s, float* stats) {
+               const DlioConvDesc& d, hipStream_t s, float* stats, const float* in_mean = nullptr,
+               const float* in_scale = nullptr, const float* in_shift = nullptr) {
+  if constexpr (!AFF && KH == 3 && KW == 3 && SW == 1) {
+    if (in_scale) return launch_bx3<MR, TWN, KH, KW, SW, true>(x, wt, bias, residual, y, d, s, stats, in_mean, in_scale, in_shift);
+  }
   constexpr int TH = 4, TW = 32 * TWN;
   const int tiles_w = cdiv(d.OW, TW), tiles_h = cdiv(d.OH, TH), co_tiles = cdiv(d.Cout, 32 * MR);
   const int64_t blocks = (int64_t)d.N * tiles_h * tiles_w * co_tiles;
@@ -591,7 +613,7 @@ int launch_bx3(const float* x, const __bf16* wt, const float* bias, const float*
   const size_t lds = (size_t)(d.Cin <= 16 ? 1 : 2) * 3 * (TH + KH - 1) * (SW * (TW - 1) + KW) * 16 * sizeof(__bf16);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bx3_kernel<MR, TWN, KH, KW, SW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bx3_kernel<MR, TWN, KH, KW, SW, AFF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)((size_t)2 * 3 * (TH + KH - 1) * (SW * (TW - 1) + KW) * 16 * sizeof(__bf16)));
     attr_done = true;
@@ -608,8 +630,8 @@ int launch_bx3(const float* x, const __bf16* wt, const float* bias, const float*
   const int vec_out = vec_on && (d.OW & 3) == 0 && (((size_t)d.OH * d.OW) & 3) == 0 &&
                       ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0 &&
                       (size_t)4 * 32 * MR * (TWN == 1 ? TW + 4 : TW + 8) * sizeof(float) <= lds;
-  hipLaunchKernelGGL((conv3x3_bx3_kernel<MR, TWN, KH, KW, SW>), dim3((unsigned)blocks), dim3(256), lds, s, x, wt, bias, residual, y,
-                     d, tiles_w, tiles_h, co_tiles, patch_at, stats, vec_out);
+  hipLaunchKernelGGL((conv3x3_bx3_kernel<MR, TWN, KH, KW, SW, AFF>), dim3((unsigned)blocks), dim3(256), lds, s, x, wt, bias, residual, y,
+                     d, tiles_w, tiles_h, co_tiles, patch_at, stats, vec_out, in_mean, in_scale, in_shift);
   return dlio_check_launch();
 }
 
@@ -775,9 +797,11 @@ extern "C" int dlio_conv3x3_bx3_prep_batched(const DlioPrepItem* items_dev, int 
   return dlio_check_launch();
 }
 
-extern "C" int dlio_conv3x3_bx3_fwd_stats(const float* x, const void* wt, const float* bias, const float* residual,
-                                          float* y, float* stats, const DlioConvDesc* dp, dlio_stream_t stream) {
+extern "C" int dlio_conv3x3_bx3_fwd_aff(const float* x, const void* wt, const float* bias, const float* in_mean,
+                                        const float* in_scale, const float* in_shift, const float* residual,
+                                        float* y, float* stats, const DlioConvDesc* dp, dlio_stream_t stream) {
   if (!x || !wt || !y || !dp) return DLIO_EINVAL;
+  if (in_scale && (!in_mean || !in_shift)) return DLIO_EINVAL;
   const DlioConvDesc& d = *dp;
   if (d.KH != 3 || d.KW != 3 || d.SH != 1 || d.SW != 1) return DLIO_EUNSUP;
   if (d.N <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.H <= 0 || d.W <= 0 || d.PH < 0 || d.PW < 0) return DLIO_EINVAL;
@@ -791,15 +815,22 @@ extern "C" int dlio_conv3x3_bx3_fwd_stats(const float* x, const void* wt, const 
   int mr, twn;
   bx3_3x3_shape(d, mr, twn);
   int rc;
-  if (mr == 1) rc = twn == 2 ? launch_bx3<1, 2>(x, w, bias, residual, y, d, s, stats) : launch_bx3<1, 1>(x, w, bias, residual, y, d, s, stats);
-  else rc = twn == 2 ? launch_bx3<2, 2>(x, w, bias, residual, y, d, s, stats) : launch_bx3<2, 1>(x, w, bias, residual, y, d, s, stats);
+#define L3(MRV, TWV) launch_bx3<MRV, TWV>(x, w, bias, residual, y, d, s, stats, in_mean, in_scale, in_shift)
+  if (mr == 1) rc = twn == 2 ? L3(1, 2) : L3(1, 1);
+  else rc = twn == 2 ? L3(2, 2) : L3(2, 1);
+#undef L3
   dlio_prof_end(3, s);
   return rc;
 }
 
+extern "C" int dlio_conv3x3_bx3_fwd_stats(const float* x, const void* wt, const float* bias, const float* residual,
+                                          float* y, float* stats, const DlioConvDesc* dp, dlio_stream_t stream) {
+  return dlio_conv3x3_bx3_fwd_aff(x, wt, bias, nullptr, nullptr, nullptr, residual, y, stats, dp, stream);
+}
+
 extern "C" int dlio_conv3x3_bx3_fwd(const float* x, const void* wt, const float* bias, const float* residual,
                                     float* y, const DlioConvDesc* dp, dlio_stream_t stream) {
-  return dlio_conv3x3_bx3_fwd_stats(x, wt, bias, residual, y, nullptr, dp, stream);
+  return dlio_conv3x3_bx3_fwd_aff(x, wt, bias, nullptr, nullptr, nullptr, residual, y, nullptr, dp, stream);
 }
 
 // 3x5 taps, stride (1, 2) (the PointSeg stem, pointseg_net.py:18-20: 2C -> 64 channels at 64 x 2048 -> 64 x 1024) on the

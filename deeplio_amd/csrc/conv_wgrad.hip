@@ -377,10 +377,14 @@ __device__ __forceinline__ void wg_split8(const float (&v)[8], wg_bf16x8& h, wg_
 // reinterpreted), the X' patch is widened to fp32 while it is staged (so the LDS layout and the
 // unaligned 8-value fragment reads stay as they are; narrowing back is exact), the dY fragments are
 // the two 16-byte loads of a lane's 16 pixels as they come, and each product is ONE bf16 MFMA.
-template <int KH, int KW, int NT, int MRW, bool BX3 = false, bool NAT = false>
+// AFF (apply-on-load): X is stored before its producer's BatchNorm + ReLU; x' = max(0, (x - mean[ci]) * scale[ci] + shift[ci])
+// (the ReLU when d.in_relu) is formed while the patch is stored to LDS, padding positions stay 0.
+template <int KH, int KW, int NT, int MRW, bool BX3 = false, bool NAT = false, bool AFF = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_adirect_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ wsp,
-    DlioConvDesc d, int co_tiles, int ci_chunks, int splits, int tiles_w, int tiles_h) {
+    DlioConvDesc d, int co_tiles, int ci_chunks, int splits, int tiles_w, int tiles_h,
+    const float* __restrict__ in_mean = nullptr, const float* __restrict__ in_scale = nullptr,
+    const float* __restrict__ in_shift = nullptr) {
   using C = WgACfg<KH, KW, NT, MRW>;
   constexpr unsigned EB = NAT ? 2u : 4u;          // bytes per element of x / dy
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -445,6 +449,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_adirect_kernel(
   const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(dy), 0, (int)((size_t)d.N * d.out_ctot * ohw * EB), 0x00020000);
   float rx[C::NCX][C::NPOSX];
+  bool xval[C::NPOSX];                       // AFF: which of this thread's positions of the tile in `rx` are inside the image
   auto load_x = [&](int tile) {
     int tt = tile;
     const int tw = tt % tiles_w; tt /= tiles_w;
@@ -458,6 +463,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_adirect_kernel(
       const int ih = ih0 + xr[j], iw = iw0 + xc[j];
       const bool pv = (xp + j * C::LPP) < C::PRPC && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W;
       po[j] = pv ? (unsigned)(ih * d.W + iw) * EB : OOB;
+      if constexpr (AFF) xval[j] = pv;
     }
 #pragma unroll
     for (int i = 0; i < C::NCX; ++i) {
@@ -493,12 +499,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_adirect_kernel(
   auto store_x = [&](float* Xl) {
 #pragma unroll
     for (int i = 0; i < C::NCX; ++i) {
-      const int c = xcph + C::CPAR * i;
+      // (one position lane group per workgroup: the channel is the loop index -- the AFF constants are scalar loads)
+      const int c = C::CPAR == 1 ? i : xcph + C::CPAR * i;
       if (c < C::CKMAX) {
+        float mu = 0.f, sc = 0.f, sh = 0.f;
+        if constexpr (AFF) {
+          const int ci = min(c0 + c, d.Cin - 1);
+          mu = in_mean[ci]; sc = in_scale[ci]; sh = in_shift[ci];
+        }
 #pragma unroll
         for (int j = 0; j < C::NPOSX; ++j) {
           const int pos = xp + j * C::LPP;
-          if (pos < C::PRPC) Xl[c * C::PLANE + pos] = rx[i][j];
+          if (pos < C::PRPC) {
+            float v = rx[i][j];
+            if constexpr (AFF) {
+              v = (v - mu) * sc + sh;
+              if (d.in_relu) v = fmaxf(v, 0.f);
+              if (!(xval[j] && c < ck)) v = 0.f;
+            }
+            Xl[c * C::PLANE + pos] = v;
+          }
         }
       }
     }
@@ -979,15 +999,17 @@ int launch_mr(const float* x, const float* dy, float* dw, const float* in_mean,
     static const int adirect = getenv("DLIO_WGRAD_ADIRECT") ? atoi(getenv("DLIO_WGRAD_ADIRECT")) : 1;
     const bool fits32 = (size_t)d.N * d.in_ctot * d.H * d.W * 4 < 0xffffff00ull &&
                         (size_t)d.N * d.out_ctot * d.OH * d.OW * 4 < 0xffffff00ull;
-    if (adirect && vec && !in_scale && fits32) {
+    if (adirect && vec && fits32) {
       using A = WgACfg<KH, KW, NT, MRW>;
       static const int bx3 = getenv("DLIO_WGRAD_BX3") ? atoi(getenv("DLIO_WGRAD_BX3")) : 1;   // split-bf16 MFMAs (fp32-accurate), 1.25x
-      auto ka = bx3 ? conv_wgrad_adirect_kernel<KH, KW, NT, MRW, true> : conv_wgrad_adirect_kernel<KH, KW, NT, MRW, false>;
+      auto ka = in_scale ? (bx3 ? conv_wgrad_adirect_kernel<KH, KW, NT, MRW, true, false, true>
+                                : conv_wgrad_adirect_kernel<KH, KW, NT, MRW, false, false, true>)
+                         : (bx3 ? conv_wgrad_adirect_kernel<KH, KW, NT, MRW, true> : conv_wgrad_adirect_kernel<KH, KW, NT, MRW, false>);
       hipFuncSetAttribute(reinterpret_cast<const void*>(ka), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)A::LDS_BYTES);
       const int blocks = p.co_tiles * p.ci_chunks * p.splits;
       hipLaunchKernelGGL(ka, dim3(blocks), dim3(256), A::LDS_BYTES, s, x, dy, wsp, d, p.co_tiles,
-                         p.ci_chunks, p.splits, p.tiles_w, p.tiles_h);
+                         p.ci_chunks, p.splits, p.tiles_w, p.tiles_h, in_mean, in_scale, in_shift);
       int rc = dlio_check_launch();
       if (rc) return rc;
       const int64_t n = (int64_t)d.Cout * d.Cin * KH * KW;
@@ -1137,13 +1159,13 @@ extern "C" int dlio_conv2d_wgrad_bf16(const void* x, const void* dy, float* dw, 
     auto ka = conv_wgrad_adirect_kernel<3, 3, 4, 1, false, true>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, (int)A::LDS_BYTES);
     hipLaunchKernelGGL(ka, dim3(blocks), dim3(256), A::LDS_BYTES, s, xf, df, wsp, d, p.co_tiles, p.ci_chunks, p.splits,
-                       p.tiles_w, p.tiles_h);
+                       p.tiles_w, p.tiles_h, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
   } else {
     using A = WgACfg<3, 3, 5, 1>;
     auto ka = conv_wgrad_adirect_kernel<3, 3, 5, 1, false, true>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, (int)A::LDS_BYTES);
     hipLaunchKernelGGL(ka, dim3(blocks), dim3(256), A::LDS_BYTES, s, xf, df, wsp, d, p.co_tiles, p.ci_chunks, p.splits,
-                       p.tiles_w, p.tiles_h);
+                       p.tiles_w, p.tiles_h, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
   }
   int rc = dlio_check_launch();
   if (rc) return rc;

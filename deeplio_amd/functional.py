@@ -27,6 +27,8 @@ _PLANE_BN = [os.environ.get("DLIO_PLANE_BN", "1") != "0"]
 # convolution and reads its output from L2 / Infinity Cache (13 us average), the epilogue reductions (320 cross-lane
 # steps + a barrier per workgroup) cost the HBM-bound 1x1 kernels more than that
 _FUSED_STATS = [os.environ.get("DLIO_FUSED_BN_STATS", "0") != "0"]
+# Fire squeeze output activated on load by the expand convolutions / weight gradients instead of written
+_SQUEEZE_AOL = [os.environ.get("DLIO_SQUEEZE_AOL", "0") != "0"]
 
 
 def set_grad_sink(on):
@@ -288,7 +290,7 @@ class _CBR:
         d = ops.conv_desc(N, Cin, H, W, Cout, KH, KW, stride[0], stride[1], pad[0], pad[1],
                           in_ctot=x_ctot, in_coff=x_coff, out_ctot=raw_ctot, out_coff=raw_coff,
                           in_relu=1 if in_aff is not None else 0)
-        bx3 = _use_bx3(N, Cin, Cout, KH, KW, stride, d.OH, d.OW) and (in_aff is None or (KH, KW) == (1, 1))
+        bx3 = _use_bx3(N, Cin, Cout, KH, KW, stride, d.OH, d.OW)
         bx3 = bx3 and (KH == 3 or (pad[0] == 0 and pad[1] == 0))
         # the PointSeg stem (3x5, stride (1, 2), pointseg_net.py:18-20), forward only: MFMA-bound on the fp32 matrix
         # cores (61 % busy), half the MFMA time on the split-bf16 kernel
@@ -320,7 +322,7 @@ class _CBR:
         elif bx3 and KH == 1:
             ops.conv1x1_bx3_fwd(x, wt, bias, raw, d, in_aff=in_aff, stats=st)
         elif bx3:
-            ops.conv3x3_bx3_fwd(x, wt, bias, raw, d, stats=st)
+            ops.conv3x3_bx3_fwd(x, wt, bias, raw, d, stats=st, in_aff=in_aff)
         else:
             ops.conv2d_fwd(x, wt, bias, raw, d, in_aff=in_aff)
         OHW = d.OH * d.OW
@@ -592,10 +594,23 @@ class FireFn(Function):
         N, Cin, H, W = x.shape
         S_, E1, E3 = sw.shape[0], e1w.shape[0], e3w.shape[0]
         CE = E1 + E3
-        raw_s, act_s = _new((N, S_, H, W), x), _new((N, S_, H, W), x)
-        d_s, prm_s = _CBR.forward(x, Cin, 0, Cin, H, W, sw, sb, sg, sbe, srm, srv, (1, 1), (0, 0),
-                                  training, momentum, eps, False, True, raw_s, S_, 0, act_s, S_, 0, N,
-                                  in_aff=x_aff)
+        raw_s = _new((N, S_, H, W), x)
+        # the squeeze output the same way (training): statistics only, both expand convolutions and their weight gradients
+        # activate it while they stage it -- its BatchNorm-apply launch and the activated copy go
+        sq_aol = bool(training and _SQUEEZE_AOL[0] and x.is_cuda)
+        if sq_aol:
+            act_s = _new((3, S_), x)          # (mean, scale, beta): travels in the slots of the activated tensor / its parameters
+            prm_s = _new((S_,), x)            # invstd
+            d_s, _ = _CBR.forward(x, Cin, 0, Cin, H, W, sw, sb, sg, sbe, srm, srv, (1, 1), (0, 0), training, momentum, eps,
+                                  False, True, raw_s, S_, 0, None, S_, 0, N, in_aff=x_aff,
+                                  stats_into=(act_s[0], prm_s, act_s[1]), shift_into=act_s[2])
+            s_in, s_aff = raw_s, (act_s[0], act_s[1], act_s[2])
+        else:
+            act_s = _new((N, S_, H, W), x)
+            d_s, prm_s = _CBR.forward(x, Cin, 0, Cin, H, W, sw, sb, sg, sbe, srm, srv, (1, 1), (0, 0),
+                                      training, momentum, eps, False, True, raw_s, S_, 0, act_s, S_, 0, N,
+                                      in_aff=x_aff)
+            s_in, s_aff = act_s, None
         raw_e = _new((N, CE, H, W), x)
         res = x if bypass else None
         if defer:
@@ -603,15 +618,15 @@ class FireFn(Function):
             inv1, inv3 = _new((E1,), x), _new((E3,), x)
             with _ExpandFork(x, act_s, raw_e, aff, inv1) as fk:
                 d_1, _ = fk.run(lambda: _CBR.forward(
-                    act_s, S_, 0, S_, H, W, e1w, e1b, e1g, e1be, e1rm, e1rv, (1, 1), (0, 0), training,
-                    momentum, eps, False, True, raw_e, CE, 0, None, CE, 0, N,
+                    s_in, S_, 0, S_, H, W, e1w, e1b, e1g, e1be, e1rm, e1rv, (1, 1), (0, 0), training,
+                    momentum, eps, False, True, raw_e, CE, 0, None, CE, 0, N, in_aff=s_aff,
                     stats_into=(aff[0, :E1], inv1, aff[1, :E1]), shift_into=aff[2, :E1]))
-                d_3, _ = _CBR.forward(act_s, S_, 0, S_, H, W, e3w, e3b, e3g, e3be, e3rm, e3rv, (1, 1), (1, 1), training,
-                                  momentum, eps, False, True, raw_e, CE, E1, None, CE, E1, N,
+                d_3, _ = _CBR.forward(s_in, S_, 0, S_, H, W, e3w, e3b, e3g, e3be, e3rm, e3rv, (1, 1), (1, 1), training,
+                                  momentum, eps, False, True, raw_e, CE, E1, None, CE, E1, N, in_aff=s_aff,
                                   stats_into=(aff[0, E1:], inv3, aff[1, E1:]), shift_into=aff[2, E1:])
             ctx.save_for_backward(x, sw, sbe, e1w, e1be, e3w, e3be, raw_s, act_s, raw_e, prm_s, aff, inv1, inv3,
                                   sb, sg, e1b, e1g, e3b, e3g, x_aff)
-            ctx.cfg = (d_s, d_1, d_3, training, bypass, True)
+            ctx.cfg = (d_s, d_1, d_3, training, bypass, True, sq_aol)
             ctx.mark_non_differentiable(aff)
             return raw_e, aff
         out = _new((N, CE, H, W), x)
@@ -621,16 +636,16 @@ class FireFn(Function):
         gap = _new((N, CE), x) if fused_gap else None
         with _ExpandFork(x, act_s, raw_e, out, gap, res, x_aff) as fk:
             d_1, prm_1 = fk.run(lambda: _CBR.forward(
-                act_s, S_, 0, S_, H, W, e1w, e1b, e1g, e1be, e1rm, e1rv, (1, 1), (0, 0), training, momentum, eps, False, True,
-                raw_e, CE, 0, out, CE, 0, N, res, Cin, 0, gap, CE, 0, r_aff=x_aff if bypass else None))
-            d_3, prm_3 = _CBR.forward(act_s, S_, 0, S_, H, W, e3w, e3b, e3g, e3be, e3rm, e3rv, (1, 1),
+                s_in, S_, 0, S_, H, W, e1w, e1b, e1g, e1be, e1rm, e1rv, (1, 1), (0, 0), training, momentum, eps, False, True,
+                raw_e, CE, 0, out, CE, 0, N, res, Cin, 0, gap, CE, 0, in_aff=s_aff, r_aff=x_aff if bypass else None))
+            d_3, prm_3 = _CBR.forward(s_in, S_, 0, S_, H, W, e3w, e3b, e3g, e3be, e3rm, e3rv, (1, 1),
                                       (1, 1), training, momentum, eps, False, True, raw_e, CE, E1, out,
-                                      CE, E1, N, res, Cin, E1, gap, CE, E1, r_aff=x_aff if bypass else None)
+                                      CE, E1, N, res, Cin, E1, gap, CE, E1, in_aff=s_aff, r_aff=x_aff if bypass else None)
         if fk.on and torch.is_tensor(prm_1):
             prm_1.record_stream(fk.cur)          # allocated under the companion stream, lives on the caller's
         ctx.save_for_backward(x, sw, sbe, e1w, e1be, e3w, e3be, raw_s, act_s, raw_e, prm_s, prm_1,
                               prm_3, sb, sg, e1b, e1g, e3b, e3g, x_aff)
-        ctx.cfg = (d_s, d_1, d_3, training, bypass, False)
+        ctx.cfg = (d_s, d_1, d_3, training, bypass, False, sq_aol)
         if not want_gap:
             return out
         if gap is None:
@@ -640,7 +655,7 @@ class FireFn(Function):
 
     @staticmethod
     def backward(ctx, dout, *_unused_dgap):
-        d_s, d_1, d_3, training, bypass, deferred = ctx.cfg
+        d_s, d_1, d_3, training, bypass, deferred, sq_aol = ctx.cfg
         if deferred:
             (x, sw, sbe, e1w, e1be, e3w, e3be, raw_s, act_s, raw_e, prm_s, aff, inv1, inv3, sb, sg, e1b, e1g,
              e3b, e3g, x_aff) = ctx.saved_tensors
@@ -654,14 +669,18 @@ class FireFn(Function):
         N, Cin, H, W = x.shape
         S_, E1, E3 = sw.shape[0], e1w.shape[0], e3w.shape[0]
         CE = E1 + E3
+        s_aff = None
+        if sq_aol:                # the slots hold (mean, scale, beta) and invstd; the expand weight gradients activate raw_s on load
+            aff_s, inv_s = act_s, prm_s
+            act_s, s_aff, prm_s = raw_s, (aff_s[0], aff_s[1], aff_s[2]), (aff_s[0], inv_s, aff_s[1])
         dact_s = _new((N, S_, H, W), x)
         draw1 = _new((N, E1, H, W), x)
         g1 = _CBR.backward(dout, CE, 0, act_s, d_1, e1w, e1b, e1g, prm_1, e1be, raw_e, training, False,
-                           True, draw1, True, dact_s, S_, 0)
+                           True, draw1, True, dact_s, S_, 0, in_aff=s_aff)
         del draw1
         draw3 = _new((N, E3, H, W), x)
         g3 = _CBR.backward(dout, CE, E1, act_s, d_3, e3w, e3b, e3g, prm_3, e3be, raw_e, training, False,
-                           True, draw3, True, dact_s, S_, 0, dx_accumulate=True)
+                           True, draw3, True, dact_s, S_, 0, dx_accumulate=True, in_aff=s_aff)
         del draw3
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty_like(x) if need_dx else None

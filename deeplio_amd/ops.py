@@ -283,9 +283,12 @@ def conv1x1_bx3_fwd(x, wt, bias, y, desc, residual=None, in_aff=None, stats=None
     return y
 
 
-def conv3x3_bx3_fwd(x, wt, bias, y, desc, residual=None, stats=None):
-    check(lib.dlio_conv3x3_bx3_fwd_stats(_ptr(x), _ptr(wt), _ptr(bias), _ptr(residual), _ptr(y), _ptr(stats), C.byref(desc),
-                                         _stream()), "conv3x3_bx3_fwd")
+def conv3x3_bx3_fwd(x, wt, bias, y, desc, residual=None, stats=None, in_aff=None):
+    m = s = b = None
+    if in_aff is not None:
+        m, s, b = in_aff
+    check(lib.dlio_conv3x3_bx3_fwd_aff(_ptr(x), _ptr(wt), _ptr(bias), _ptr(m), _ptr(s), _ptr(b), _ptr(residual), _ptr(y),
+                                       _ptr(stats), C.byref(desc), _stream()), "conv3x3_bx3_fwd")
     return y
 
 

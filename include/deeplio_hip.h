@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 208
+#define DLIO_ABI_VERSION 209
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);           /* "gfx950" */
@@ -154,6 +154,11 @@ int dlio_conv1x1_bx3_fwd_stats(const float* x, const void* wt, const float* bias
                                float* y, float* stats, const DlioConvDesc* desc, dlio_stream_t stream);
 int dlio_conv3x3_bx3_fwd_stats(const float* x, const void* wt, const float* bias, const float* residual,
                                float* y, float* stats, const DlioConvDesc* desc, dlio_stream_t stream);
+/* dlio_conv3x3_bx3_fwd_stats with the apply-on-load transform of dlio_conv2d_fwd on the input (in_scale NULL = none):
+ * the stored input is the producer's raw output; padding positions stay 0 (they pad the ACTIVATED tensor) */
+int dlio_conv3x3_bx3_fwd_aff(const float* x, const void* wt, const float* bias, const float* in_mean,
+                             const float* in_scale, const float* in_shift, const float* residual,
+                             float* y, float* stats, const DlioConvDesc* desc, dlio_stream_t stream);
 /* the split-bf16 kernel with 3x5 taps and stride (1, 2): the PointSeg stem (pointseg_net.py:18-20), forward only;
  * weights from dlio_conv_bx3_prep(taps = 15, mode 0) */
 int dlio_conv3x5s2_bx3_fwd(const float* x, const void* wt, const float* bias, const float* residual, float* y,
