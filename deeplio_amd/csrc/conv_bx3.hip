@@ -374,6 +374,233 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
   }
 }
 
+// ---- 3x3 stride 1, weight fragments through LDS --------------------------------------------------
+// conv3x3_bx3_kernel's four waves own four rows of the SAME 32*MR output channels: each of them fetched the same
+// 16-byte weight fragments from global memory (6 per tap and wave for MR = 2), and with five streams sharing the chip
+// those loads were what the step waited for (timing ablation with the fragment loads removed: 26.2 -> 23.3 ms per
+// training step).  Here a workgroup fetches the fragments of three taps ONCE (18 KB, 4-5 sixteen-byte loads per
+// thread), stores them into a two-slot LDS ring and every wave reads them with ds_read_b128 -- a quarter of the
+// global weight-fragment traffic.  The ring takes the place of the second patch buffer (LDS stays at 75 KB per
+// workgroup = two per CU): the patch is single-buffered, its global loads still run under the MFMAs of the
+// previous chunk, only the split + LDS store wait for the end-of-chunk barrier.  4 barriers per chunk.
+// Forward / data gradient of "same" 3x3 layers without input transform or statistics epilogue.
+template <int MR, int TWN>
+__global__ __launch_bounds__(256, 2) void conv3x3_bx3_alds_kernel(
+    const float* __restrict__ x, const __bf16* __restrict__ wt, const float* __restrict__ bias,
+    const float* residual, float* y, DlioConvDesc d, int tiles_w, int tiles_h, int co_tiles, int vec_out) {
+  constexpr int TH = 4, TW = 32 * TWN, PR = TH + 2, PC = TW + 2, NPOSP = PR * PC;
+  constexpr int NPOS = (NPOSP + 255) / 256;
+  constexpr int PLANE = NPOSP * 16;                      // bf16 per patch plane
+  constexpr int TG = 3;                                  // taps per weight group
+  constexpr int AROWS = 32 * MR;
+  constexpr int AGRP = TG * 3 * AROWS * 16;              // bf16 per ring slot: [tap][plane][row][16 k]
+  constexpr int APIECES = AGRP / 8;                      // 16-byte pieces per group
+  constexpr int ALD = (APIECES + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* patch = reinterpret_cast<__bf16*>(smem_raw);   // [3 planes][NPOSP][16]
+  __bf16* ring = patch + 3 * PLANE;                      // [2 slots][AGRP]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  int bid = xcd_block_index();
+  const int cot = bid % co_tiles; bid /= co_tiles;
+  const int tw = bid % tiles_w; bid /= tiles_w;
+  const int th = bid % tiles_h;
+  const int n = bid / tiles_h;
+  const int co0 = cot * 32 * MR, oh0 = th * TH, ow0 = tw * TW;
+  const int Cin = d.Cin, Cout = d.Cout, HW = d.H * d.W;
+  const int KC = (Cin + 15) >> 4;
+
+  // ---- patch staging (as conv3x3_bx3_kernel)
+  bool pval[NPOS];
+  int poff[NPOS];
+#pragma unroll
+  for (int j = 0; j < NPOS; ++j) {
+    const int pos = tid + j * 256;
+    const int r = pos / PC, c = pos - r * PC;
+    const int ih = oh0 - d.PH + r, iw = ow0 - d.PW + c;
+    pval[j] = pos < NPOSP && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W;
+    poff[j] = pval[j] ? ih * d.W + iw : 0;
+  }
+  const float* xn = x + ((size_t)n * d.in_ctot + d.in_coff) * HW;
+  float reg[NPOS][16];
+  auto load_patch = [&](int kc) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const float* xc = xn + (size_t)min(kc * 16 + c, Cin - 1) * HW;
+#pragma unroll
+      for (int j = 0; j < NPOS; ++j) reg[j][c] = xc[poff[j]];
+    }
+  };
+  auto store_patch = [&](int kc) {
+#pragma unroll
+    for (int j = 0; j < NPOS; ++j) {
+      const int pos = tid + j * 256;
+      if (pos < NPOSP) {
+        bf16x8 ph[2], pm[2], pl[2];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const float v = (kc * 16 + c < Cin && pval[j]) ? reg[j][c] : 0.f;
+          __bf16 h, m, l;
+          split3(v, h, m, l);
+          ph[c >> 3][c & 7] = h; pm[c >> 3][c & 7] = m; pl[c >> 3][c & 7] = l;
+        }
+        bf16x8* dst = reinterpret_cast<bf16x8*>(patch + pos * 16);
+        dst[0] = ph[0]; dst[1] = ph[1];
+        dst = reinterpret_cast<bf16x8*>(patch + PLANE + pos * 16);
+        dst[0] = pm[0]; dst[1] = pm[1];
+        dst = reinterpret_cast<bf16x8*>(patch + 2 * PLANE + pos * 16);
+        dst[0] = pl[0]; dst[1] = pl[1];
+      }
+    }
+  };
+
+  // ---- weight groups: piece q = ((tap_l * 3 + plane) * AROWS + row) * 2 + k-half, the same order in LDS
+  const size_t wplane = (size_t)Cout * 16;
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__bf16*>(wt), 0, (int)((size_t)9 * KC * 3 * wplane * 2), 0x00020000);
+  unsigned aoffv[ALD];           // per-lane byte offset inside a (tap, chunk, plane) block; plane / tap part added per group
+  int atp[ALD];                  // tap_l * 3 + plane of the piece
+#pragma unroll
+  for (int i = 0; i < ALD; ++i) {
+    const int q = tid + i * 256;
+    const int hk = q & 1, row = (q >> 1) % AROWS, tp = (q >> 1) / AROWS;
+    atp[i] = q < APIECES ? tp : -1;
+    aoffv[i] = (unsigned)(min(co0 + row, Cout - 1) * 16 + hk * 8) * 2u;
+  }
+  u32x4 areg[ALD];
+  auto load_agroup = [&](int kc, int g) {
+#pragma unroll
+    for (int i = 0; i < ALD; ++i)
+      if (atp[i] >= 0) {
+        const int tap = g * TG + atp[i] / 3, pl = atp[i] - 3 * (atp[i] / 3);
+        const unsigned so = (unsigned)((((size_t)tap * KC + kc) * 3 + pl) * wplane * 2);
+        areg[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, aoffv[i] + so, 0, 0);
+      }
+  };
+  auto store_agroup = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < ALD; ++i)
+      if (atp[i] >= 0) *reinterpret_cast<u32x4*>(ring + (size_t)slot * AGRP + (size_t)(tid + i * 256) * 8) = areg[i];
+  };
+
+  f32x16 acc[MR][TWN];
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+#pragma unroll
+    for (int t = 0; t < TWN; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+
+  auto read_a = [&](const __bf16* slot, int tl, bf16x8 (&a)[MR][3]) {
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        a[m][p] = *reinterpret_cast<const bf16x8*>(slot + ((tl * 3 + p) * AROWS + m * 32 + l31) * 16 + 8 * half);
+  };
+  auto compute_group = [&](const __bf16* slot, int g) {
+    bf16x8 a[2][MR][3];
+    read_a(slot, 0, a[0]);
+#pragma unroll
+    for (int tl = 0; tl < TG; ++tl) {
+      const int tap = g * TG + tl, kh = tap / 3, kw = tap - 3 * kh;
+      if (tl + 1 < TG) read_a(slot, tl + 1, a[(tl + 1) & 1]);
+      bf16x8 b[TWN][3];
+#pragma unroll
+      for (int t = 0; t < TWN; ++t) {
+        const int pos = (wave + kh) * PC + 32 * t + l31 + kw;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          b[t][p] = *reinterpret_cast<const bf16x8*>(patch + p * PLANE + pos * 16 + 8 * half);
+      }
+      const auto& aa = a[tl & 1];
+      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+          for (int t = 0; t < TWN; ++t)
+            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[m][PA[q]], b[t][PB[q]], acc[m][t], 0, 0, 0);
+    }
+  };
+
+  // ---- pipeline: weight groups double-slotted, patch single-buffered
+  load_patch(0);
+  load_agroup(0, 0);
+  store_patch(0);
+  store_agroup(0);
+  __syncthreads();
+  int gi = 0;                                            // running group index -> ring slot
+  for (int kc = 0; kc < KC; ++kc) {
+    const bool more = kc + 1 < KC;
+#pragma unroll
+    for (int g = 0; g < 3; ++g, ++gi) {
+      const bool anext = g < 2 || more;
+      if (anext) load_agroup(g < 2 ? kc : kc + 1, g < 2 ? g + 1 : 0);
+      if (g == 0 && more) load_patch(kc + 1);
+      compute_group(ring + (size_t)(gi & 1) * AGRP, g);
+      if (anext) store_agroup((gi + 1) & 1);              // read last during group gi - 1: every wave is past that barrier
+      __syncthreads();
+    }
+    if (more) {
+      store_patch(kc + 1);                               // every wave is past the last group's barrier: the patch is free
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue (conv3x3_bx3_kernel's)
+  const int oh = oh0 + wave;
+  if (oh >= d.OH) return;
+  const size_t ohw = (size_t)d.OH * d.OW;
+  if (vec_out) {
+    constexpr int TWP = TWN == 1 ? TW + 4 : TW + 8;
+    float* wbuf = reinterpret_cast<float*>(smem_raw) + wave * (32 * MR * TWP);
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+      for (int t = 0; t < TWN; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          wbuf[(32 * m + (r & 3) + 8 * (r >> 2) + 4 * half) * TWP + 32 * t + l31] = acc[m][t][r];
+    constexpr int Q = TW / 4;
+    float* yrow = y + ((size_t)n * d.out_ctot + d.out_coff) * ohw + (size_t)oh * d.OW + ow0;
+    const float* rrow = residual ? residual + ((size_t)n * d.res_ctot + d.res_coff) * ohw + (size_t)oh * d.OW + ow0 : nullptr;
+#pragma unroll
+    for (int i = 0; i < (32 * MR * Q) / 64; ++i) {
+      const int idx = i * 64 + lane, cl = idx / Q, q = idx - cl * Q;
+      const int co = co0 + cl;
+      if (co >= Cout || ow0 + 4 * q >= d.OW) continue;
+      float4 v = *reinterpret_cast<const float4*>(wbuf + cl * TWP + 4 * q);
+      const float bv = bias ? bias[co] : 0.f;
+      v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+      if (rrow) {
+        const float4 rv = *reinterpret_cast<const float4*>(rrow + (size_t)co * ohw + 4 * q);
+        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+      }
+      *reinterpret_cast<float4*>(yrow + (size_t)co * ohw + 4 * q) = v;
+    }
+    return;
+  }
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+#pragma unroll
+    for (int t = 0; t < TWN; ++t) {
+      const int ow = ow0 + 32 * t + l31;
+      if (ow >= d.OW) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (co >= Cout) continue;
+        float v = acc[m][t][r];
+        if (bias) v += bias[co];
+        const size_t pix = (size_t)oh * d.OW + ow;
+        if (residual) v += residual[((size_t)n * d.res_ctot + d.res_coff + co) * ohw + pix];
+        y[((size_t)n * d.out_ctot + d.out_coff + co) * ohw + pix] = v;
+      }
+    }
+}
+
 // ---- 1x1 convolution on the same scheme, no LDS (the float4 structure of conv1x1_v4_kernel in
 // conv_fwd.hip): a wave owns 128 consecutive pixels, lane l the four pixels 4l..4l+3; per 16-channel
 // chunk a lane loads the float4 of 8 channels (8*half + j), component e of those eight is the
@@ -598,6 +825,31 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
   }
 }
 
+template <int MR, int TWN>
+int launch_bx3_alds(const float* x, const __bf16* wt, const float* bias, const float* residual, float* y,
+                    const DlioConvDesc& d, hipStream_t s) {
+  constexpr int TH = 4, TW = 32 * TWN;
+  const int tiles_w = cdiv(d.OW, TW), tiles_h = cdiv(d.OH, TH), co_tiles = cdiv(d.Cout, 32 * MR);
+  const int64_t blocks = (int64_t)d.N * tiles_h * tiles_w * co_tiles;
+  if (blocks <= 0 || blocks > 0x7fffffff) return DLIO_EINVAL;
+  const size_t patch_b = (size_t)3 * (TH + 2) * (TW + 2) * 16 * sizeof(__bf16);
+  const size_t ring_b = (size_t)2 * 3 * 3 * 32 * MR * 16 * sizeof(__bf16);
+  const size_t epi_b = (size_t)4 * 32 * MR * (TWN == 1 ? TW + 4 : TW + 8) * sizeof(float);
+  const size_t lds = patch_b + ring_b;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bx3_alds_kernel<MR, TWN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  static const int vec_on = getenv("DLIO_BX3_VEC_OUT") ? atoi(getenv("DLIO_BX3_VEC_OUT")) : 1;
+  const int vec_out = vec_on && (d.OW & 3) == 0 && (((size_t)d.OH * d.OW) & 3) == 0 &&
+                      ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0 && epi_b <= lds;
+  hipLaunchKernelGGL((conv3x3_bx3_alds_kernel<MR, TWN>), dim3((unsigned)blocks), dim3(256), lds, s, x, wt, bias, residual, y,
+                     d, tiles_w, tiles_h, co_tiles, vec_out);
+  return dlio_check_launch();
+}
+
 template <int MR, int TWN, int KH = 3, int KW = 3, int SW = 1, bool AFF = false>
 int launch_bx3(const float* x, const __bf16* wt, const float* bias, const float* residual, float* y,
                const DlioConvDesc& d, hipStream_t s, float* stats, const float* in_mean = nullptr,
@@ -815,7 +1067,13 @@ extern "C" int dlio_conv3x3_bx3_fwd_aff(const float* x, const void* wt, const fl
   int mr, twn;
   bx3_3x3_shape(d, mr, twn);
   int rc;
-#define L3(MRV, TWV) launch_bx3<MRV, TWV>(x, w, bias, residual, y, d, s, stats, in_mean, in_scale, in_shift)
+  // weight fragments through LDS (conv3x3_bx3_alds_kernel) for the plain layers; the variants with an input transform or
+  // a statistics epilogue stay on the global-fragment kernel
+  static const int alds = getenv("DLIO_BX3_ALDS") ? atoi(getenv("DLIO_BX3_ALDS")) : 1;
+  const bool use_alds = alds && !stats && !in_scale && (size_t)9 * ((d.Cin + 15) / 16) * 3 * d.Cout * 32 < 0x7fffffffull &&
+                        (alds == 2 || mr == 2);
+#define L3(MRV, TWV) (use_alds ? launch_bx3_alds<MRV, TWV>(x, w, bias, residual, y, d, s) \
+                               : launch_bx3<MRV, TWV>(x, w, bias, residual, y, d, s, stats, in_mean, in_scale, in_shift))
   if (mr == 1) rc = twn == 2 ? L3(1, 2) : L3(1, 1);
   else rc = twn == 2 ? L3(2, 2) : L3(2, 1);
 #undef L3
