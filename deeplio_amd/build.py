@@ -60,6 +60,13 @@ def build(force=False, verbose=True):
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
         if verbose:
             print("[build] linked", LIB, flush=True)
+        # a kernel template the host pass could not instantiate links fine and only fails at dlopen (undefined
+        # __device_stub__ symbol): load the library once here, where the build can still fail
+        import ctypes
+        try:
+            ctypes.CDLL(LIB)
+        except OSError as e:
+            raise RuntimeError("libdeeplio_hip.so does not load: %s" % e)
     return LIB
 
 

@@ -24,7 +24,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // timing ablations of the 3x3 kernel (tools/bx3_ablate.py builds variant libraries; results are WRONG with any
-// bit set): 1 no split + LDS store, 2 no patch loads, 4 no weight-fragment loads, 8 no LDS fragment reads
+// bit set): 1 no split + LDS store, 2 no patch loads, 4 no weight-fragment loads, 8 no LDS fragment reads (3x3 global-
+// fragment kernel); 16 no weight-fragment loads in the 1x1 kernel
 #ifndef BX3_ABLATE
 #define BX3_ABLATE 0
 #endif
@@ -675,7 +676,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bx3_kernel(
     for (int m = 0; m < MR; ++m)
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl)
-        a[s % AB][m][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+        if constexpr (BX3_ABLATE & 16) opaque(a[s % AB][m][pl]);
+        else a[s % AB][m][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
             wrsrc, woff[m], (unsigned)(kc * 3 + pl) * (unsigned)wplane * 2u, 0));
   };
   auto load_chunk = [&](int kc, int s) {
