@@ -10,7 +10,7 @@ import sqlite3
 import sys
 
 FAMILIES = [
-    ("conv3x3 fwd+dgrad (split-bf16 MFMA)", ("conv3x3_bx3_kernel", "conv3x3_bf16")),
+    ("conv3x3 fwd+dgrad (split-bf16 MFMA)", ("conv3x3_bx3_kernel", "conv3x3_bx3_alds_kernel", "conv3x3_bf16")),
     ("stem conv fwd (fp32 MFMA)", ("conv_fwd_kernel",)),
     ("conv1x1 fwd+dgrad", ("conv1x1_",)),
     ("conv3x3 wgrad", ("conv_wgrad_adirect",)),
