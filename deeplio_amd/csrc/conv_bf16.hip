@@ -64,7 +64,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(
   constexpr int NPOS = (NPOSP + 255) / 256;              // patch positions per thread
   constexpr int PLANE = NPOSP * 16;                      // bf16 per buffer
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);    // [2 buffers][NPOSP][16]
+  __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);    // [2 buffers][NPOSP][16], then the weight chunks [2][9 taps][32 MR rows][16]
+  // Weight fragments through LDS (conv3x3_bx3_alds_kernel, conv_bx3.hip): the four waves own four rows of the SAME output
+  // channels and each fetched the same fragments from global memory.  One plane of bf16 weights is small enough to keep
+  // both the patch and the weights of a chunk double-buffered (61 KB for the 64 x 64 tile): the workgroup fetches the 9
+  // taps of the next chunk straight into LDS (buffer_load_dwordx4 ... lds, 4-5 instructions per wave) while it computes.
+  constexpr int ACH = 9 * 32 * MR * 16;                  // bf16 per weight chunk
+  constexpr int AINS = 9 * MR;                           // wave instructions per chunk (64 sixteen-byte pieces each)
+  __bf16* abuf = smem + 2 * PLANE;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
   int bid = xcd_block_index();
@@ -117,14 +124,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(
     }
   };
 
-  int nrow[MR];
-#pragma unroll
-  for (int m = 0; m < MR; ++m) nrow[m] = min(co0 + 32 * m + l31, Cout - 1);
   const size_t wplane = (size_t)Cout * 16;
-  auto load_a = [&](int tap, int kc, bf16x8 (&a)[MR]) {
-    const __bf16* base = wt + ((size_t)tap * KC + kc) * wplane + 8 * half;
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(wt), 0,
+                                                                         (int)((size_t)9 * KC * wplane * 2), 0x00020000);
+  unsigned awoff[MR];            // piece of this lane inside a (tap, chunk) block: row lane / 2 of tile m, k-half lane & 1
 #pragma unroll
-    for (int m = 0; m < MR; ++m) a[m] = *reinterpret_cast<const bf16x8*>(base + (size_t)nrow[m] * 16);
+  for (int m = 0; m < MR; ++m) awoff[m] = ((unsigned)min(co0 + m * 32 + (lane >> 1), Cout - 1) * 16u + 8u * (unsigned)(lane & 1)) * 2u;
+  auto load_achunk = [&](int kc, int slot) {              // instruction t = tap * MR + m, dealt round-robin to the waves
+#pragma unroll
+    for (int i = 0; i < (AINS + 3) / 4; ++i) {
+      const int t = i * 4 + wave;
+      if (t < AINS) {
+        const int tap = t / MR, m = t - tap * MR;
+        __bf16* dst = abuf + (size_t)slot * ACH + (size_t)t * 64 * 8;
+#if defined(__HIP_DEVICE_COMPILE__)     // (the host pass cannot instantiate the address-space cast)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, awoff[m],
+                                                 (unsigned)(((size_t)tap * KC + kc) * wplane * 2), 0, 0);
+#else
+        (void)dst; (void)m;
+#endif
+      }
+    }
+  };
+  // LDS order of a chunk: piece (t, lane) -> row lane / 2, k-half lane & 1 of (tap, m): fragment of lane (l31, half) =
+  // row l31, k-half `half` -> piece 2 * l31 + half
+  auto read_a = [&](const __bf16* ab, int tap, bf16x8 (&a)[MR]) {
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+      a[m] = *reinterpret_cast<const bf16x8*>(ab + ((size_t)(tap * MR + m) * 64 + 2 * l31 + half) * 8);
   };
 
   f32x16 acc[MR][TWN];
@@ -135,16 +162,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
 
-  constexpr int PF = 3, RING = PF + 1;       // weight fragments run PF taps ahead of their MFMAs
-  auto compute = [&](const __bf16* buf, int kc, bool prefetch) {
-    bf16x8 a[RING][MR];
+  auto compute = [&](const __bf16* buf, const __bf16* ab, int kc, bool prefetch) {
+    bf16x8 a[2][MR];
     if (patch_at < 0 && prefetch) load_chunk(kc + 1);
-#pragma unroll
-    for (int p = 0; p < PF; ++p) load_a(p, kc, a[p]);
+    read_a(ab, 0, a[0]);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int kh = tap / 3, kw = tap - 3 * kh;
-      if (tap + PF < 9) load_a(tap + PF, kc, a[(tap + PF) % RING]);
+      if (tap + 1 < 9) read_a(ab, tap + 1, a[(tap + 1) & 1]);
       if (tap == patch_at && prefetch) load_chunk(kc + 1);
       bf16x8 b[TWN];
 #pragma unroll
@@ -152,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(
         const int pos = (wave + kh) * PC + 32 * t + l31 + kw;
         b[t] = *reinterpret_cast<const bf16x8*>(buf + pos * 16 + 8 * half);
       }
-      const auto& aa = a[tap % RING];
+      const auto& aa = a[tap & 1];
 #pragma unroll
       for (int m = 0; m < MR; ++m)
 #pragma unroll
@@ -161,14 +186,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(
     }
   };
 
+  load_achunk(0, 0);
   load_chunk(0);
   store_chunk(smem);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int kc = 0; kc < KC; ++kc) {
     const __bf16* cur = smem + (size_t)(kc & 1) * PLANE;
     __bf16* nxt = smem + (size_t)((kc + 1) & 1) * PLANE;
-    compute(cur, kc, kc + 1 < KC);
-    if (kc + 1 < KC) store_chunk(nxt);
+    const bool more = kc + 1 < KC;
+    if (more) load_achunk(kc + 1, (kc + 1) & 1);          // that slot was read during chunk kc - 1: every wave is past its barrier
+    compute(cur, abuf + (size_t)(kc & 1) * ACH, kc, more);
+    if (more) store_chunk(nxt);                         // (waits for the patch loads, which are younger than the weight pieces)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
@@ -338,7 +368,7 @@ int launch_3x3(const __bf16* x, const __bf16* wt, const float* bias, const __bf1
   const int tiles_w = cdiv(d.OW, TW), tiles_h = cdiv(d.OH, TH), co_tiles = cdiv(d.Cout, 32 * MR);
   const int64_t blocks = (int64_t)d.N * tiles_h * tiles_w * co_tiles;
   if (blocks <= 0 || blocks > 0x7fffffff) return DLIO_EINVAL;
-  size_t lds = (size_t)2 * (TH + 2) * (TW + 2) * 16 * sizeof(__bf16);
+  size_t lds = (size_t)2 * (TH + 2) * (TW + 2) * 16 * sizeof(__bf16) + (size_t)2 * 9 * 32 * MR * 16 * sizeof(__bf16);   // patch + weight chunks
   const int patch_at = (d.Cin + 15) / 16 > 5 ? 0 : -1;
   // 16-byte stores through LDS: rows of 8-pixel groups, 16-byte aligned planes; the fp32 transposed tiles of the four
   // waves (32 channels at a time) need more LDS than the bf16 patch buffers
@@ -348,6 +378,8 @@ int launch_3x3(const __bf16* x, const __bf16* wt, const float* bias, const __bf1
   if (vec_out) {
     const size_t need = (size_t)4 * 32 * (TWN == 1 ? TW + 4 : TW + 8) * sizeof(float);
     if (need > lds) lds = need;
+  }
+  {
     static bool attr_done = false;
     if (!attr_done) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<MR, TWN>),
