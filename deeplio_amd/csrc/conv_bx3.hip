@@ -459,29 +459,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_alds_kernel(
   const size_t wplane = (size_t)Cout * 16;
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<__bf16*>(wt), 0, (int)((size_t)9 * KC * 3 * wplane * 2), 0x00020000);
-  unsigned aoffv[ALD];           // per-lane byte offset inside a (tap, chunk, plane) block; plane / tap part added per group
-  int atp[ALD];                  // tap_l * 3 + plane of the piece
+  // straight into LDS (buffer_load_dwordx4 ... lds: the 64 pieces of a wave instruction land at consecutive 16-byte
+  // slots): instruction t = (tap_l * 3 + plane) * MR + m covers the 32 rows x 2 k-halves of one (tap, plane, tile), the
+  // instructions of a group are dealt round-robin to the four waves
+  constexpr int AINS = TG * 3 * MR;
+  unsigned awoff[MR];
 #pragma unroll
-  for (int i = 0; i < ALD; ++i) {
-    const int q = tid + i * 256;
-    const int hk = q & 1, row = (q >> 1) % AROWS, tp = (q >> 1) / AROWS;
-    atp[i] = q < APIECES ? tp : -1;
-    aoffv[i] = (unsigned)(min(co0 + row, Cout - 1) * 16 + hk * 8) * 2u;
-  }
-  u32x4 areg[ALD];
-  auto load_agroup = [&](int kc, int g) {
+  for (int m = 0; m < MR; ++m) awoff[m] = ((unsigned)min(co0 + m * 32 + (lane >> 1), Cout - 1) * 16u + 8u * (unsigned)(lane & 1)) * 2u;
+  auto load_agroup = [&](int kc, int g, int slot) {
 #pragma unroll
-    for (int i = 0; i < ALD; ++i)
-      if (atp[i] >= 0) {
-        const int tap = g * TG + atp[i] / 3, pl = atp[i] - 3 * (atp[i] / 3);
-        const unsigned so = (unsigned)((((size_t)tap * KC + kc) * 3 + pl) * wplane * 2);
-        areg[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, aoffv[i] + so, 0, 0);
+    for (int i = 0; i < (AINS + 3) / 4; ++i) {
+      const int t = i * 4 + wave;
+      if (t < AINS) {
+        const int m = t % MR, tp = t / MR, tap = g * TG + tp / 3, pl = tp - 3 * (tp / 3);
+        __bf16* dst = ring + (size_t)slot * AGRP + (size_t)t * 64 * 8;
+#if defined(__HIP_DEVICE_COMPILE__)     // (the host pass cannot instantiate the address-space cast)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, awoff[m],
+                                                 (unsigned)((((size_t)tap * KC + kc) * 3 + pl) * wplane * 2), 0, 0);
+#else
+        (void)dst; (void)m; (void)tap; (void)pl;
+#endif
       }
-  };
-  auto store_agroup = [&](int slot) {
-#pragma unroll
-    for (int i = 0; i < ALD; ++i)
-      if (atp[i] >= 0) *reinterpret_cast<u32x4*>(ring + (size_t)slot * AGRP + (size_t)(tid + i * 256) * 8) = areg[i];
+    }
   };
 
   f32x16 acc[MR][TWN];
@@ -527,10 +526,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_alds_kernel(
   };
 
   // ---- pipeline: weight groups double-slotted, patch single-buffered
+  load_agroup(0, 0, 0);
   load_patch(0);
-  load_agroup(0, 0);
   store_patch(0);
-  store_agroup(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int gi = 0;                                            // running group index -> ring slot
   for (int kc = 0; kc < KC; ++kc) {
@@ -538,10 +537,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_alds_kernel(
 #pragma unroll
     for (int g = 0; g < 3; ++g, ++gi) {
       const bool anext = g < 2 || more;
-      if (anext) load_agroup(g < 2 ? kc : kc + 1, g < 2 ? g + 1 : 0);
+      // the other slot was read last during group gi - 1: every wave is past that barrier
+      if (anext) load_agroup(g < 2 ? kc : kc + 1, g < 2 ? g + 1 : 0, (gi + 1) & 1);
       if (g == 0 && more) load_patch(kc + 1);
       compute_group(ring + (size_t)(gi & 1) * AGRP, g);
-      if (anext) store_agroup((gi + 1) & 1);              // read last during group gi - 1: every wave is past that barrier
+      // the group's pieces have landed; the patch loads issued behind them (group 0) stay in flight
+      if (g == 0 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPOS * 16) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
     if (more) {
