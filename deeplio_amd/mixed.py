@@ -72,6 +72,9 @@ def _stats_ws(N, C_, HW, device):
 def bn_apply(x, x_ctot, x_coff, gamma, beta, eps, momentum, rmean, rvar, y, y_ctot, y_coff, N, C_, HW, post_relu,
              residual=None, r_ctot=0, r_coff=0, gap_out=None, gap_ctot=0, gap_coff=0, eval_prm=None):
     """train: statistics + apply -> prm [3][C] (mean, invstd, scale); eval: apply with eval_prm"""
+    if eval_prm is None and ops._SYNC_BN[0] is not None:
+        raise NotImplementedError("synchronised BatchNorm statistics (GradSync.enable_sync_bn) exist on the fp32 path only; "
+                                  "the bf16 path takes per-replica statistics")
     prm = eval_prm if eval_prm is not None else torch.empty(3, C_, dtype=torch.float32, device=x.device)
     ws = _stats_ws(N, C_, HW, x.device)
     check(lib.dlio_bn_bf16_apply(_ptr(x), N, x_ctot, x_coff, C_, HW, int(post_relu), _ptr(gamma), _ptr(beta),

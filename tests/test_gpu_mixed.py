@@ -409,3 +409,21 @@ def test_model_bf16_training_tracks_fp32(dev):
     for a16, a32 in zip(l16, l32):
         assert abs(a16 - a32) <= 0.1 * abs(a32), (l16, l32)
     assert set(g16) == set(g32)
+
+
+@pytest.mark.gpu
+def test_bf16_path_refuses_synchronised_batchnorm(dev):
+    """SyncBN (partials all-reduced between the statistics and the apply launch) exists on the fp32 path only: the bf16
+    kernels take per-replica statistics, so a training-mode bf16 BatchNorm with SyncBN switched on fails loudly"""
+    from deeplio_amd import mixed, ops
+    x = torch.randn(2, 8, 4, 8, device=dev).to(torch.bfloat16)
+    y = torch.empty_like(x)
+    g, b = torch.ones(8, device=dev), torch.zeros(8, device=dev)
+    rm, rv = torch.zeros(8, device=dev), torch.ones(8, device=dev)
+    ops.set_sync_bn(lambda t: t, 2)
+    try:
+        with pytest.raises(NotImplementedError):
+            mixed.bn_apply(x, 8, 0, g, b, 1e-5, 0.1, rm, rv, y, 8, 0, 2, 8, 32, True)
+    finally:
+        ops.set_sync_bn(None, 1)
+    mixed.bn_apply(x, 8, 0, g, b, 1e-5, 0.1, rm, rv, y, 8, 0, 2, 8, 32, True)      # per-replica statistics: fine
