@@ -1073,7 +1073,8 @@ extern "C" int dlio_conv3x3_bx3_fwd_aff(const float* x, const void* wt, const fl
   int rc;
   // weight fragments through LDS (conv3x3_bx3_alds_kernel) for the plain layers; the variants with an input transform or
   // a statistics epilogue stay on the global-fragment kernel
-  static const int alds = getenv("DLIO_BX3_ALDS") ? atoi(getenv("DLIO_BX3_ALDS")) : 1;
+  // (DLIO_BX3_ALDS: 0 off, 1 the 64-channel tiles only, 2 = default all tiles: 25.39 / 25.61 / 26.3 ms for 2 / 1 / 0)
+  static const int alds = getenv("DLIO_BX3_ALDS") ? atoi(getenv("DLIO_BX3_ALDS")) : 2;
   const bool use_alds = alds && !stats && !in_scale && (size_t)9 * ((d.Cin + 15) / 16) * 3 * d.Cout * 32 < 0x7fffffffull &&
                         (alds == 2 || mr == 2);
 #define L3(MRV, TWV) (use_alds ? launch_bx3_alds<MRV, TWV>(x, w, bias, residual, y, d, s) \

@@ -1067,7 +1067,8 @@ bool make_plan_1x1(const DlioConvDesc& d, Wg1Plan& p) {
   // measured: in isolation (tools/conv_table.py, blocks 128..768) one workgroup per CU is the
   // sweet spot and a partial second round (320) costs 15-50 %; inside the training step, where
   // the other encoder's kernels share the chip, two per CU is 0.2 ms/step better (tools/sweep_env.sh)
-  static const int tgt = getenv("DLIO_WGRAD_1X1_BLOCKS") ? atoi(getenv("DLIO_WGRAD_1X1_BLOCKS")) : 2 * dlio_num_cus();
+  // (re-measured with the XCD-aware order: one per CU 25.51, 1.5 per CU 25.61, two per CU 25.62 ms/step)
+  static const int tgt = getenv("DLIO_WGRAD_1X1_BLOCKS") ? atoi(getenv("DLIO_WGRAD_1X1_BLOCKS")) : dlio_num_cus();
   int64_t splits = tgt / pairs > 0 ? tgt / pairs : 1;
   // every wave should stream at least MINSEG segments, or prologue + slab reduction dominate
   static const int minseg = getenv("DLIO_WGRAD_1X1_MINSEG") ? atoi(getenv("DLIO_WGRAD_1X1_MINSEG")) : 2;
