@@ -141,7 +141,10 @@ __global__ __launch_bounds__(256) void maxpool3_fwd_strip(const float* __restric
                                                           const float* __restrict__ xs,
                                                           float* __restrict__ y,
                                                           uint8_t* __restrict__ idx, int64_t planes,
-                                                          int H, int W, int OH, int OW) {
+                                                          int H, int W, int OH, int OW,
+                                                          const float* __restrict__ aff = nullptr, int C = 1) {
+  // aff (apply-on-load, [3][C] = mean, scale, shift): x is a convolution's raw output, the pool takes the maximum of
+  // max(0, (x - mean[c]) * scale[c] + shift[c]) -- the BatchNorm + ReLU in front of the pool is never written
   constexpr int FR = SH == 1 ? 8 : 4;              // output rows per thread
   constexpr int NIN = (FR - 1) * SH + 3;           // input rows they touch
   const int OW2 = OW >> 1, strips = (OH + FR - 1) / FR;
@@ -154,6 +157,8 @@ __global__ __launch_bounds__(256) void maxpool3_fwd_strip(const float* __restric
     const int64_t pl = t / strips;
     const float* xp = x + (size_t)pl * H * W;
     const float s = xs ? xs[pl] : 1.f;
+    float amu = 0.f, asc = 1.f, ash = 0.f;
+    if (aff) { const int c = (int)(pl % C); amu = aff[c]; asc = aff[C + c]; ash = aff[2 * C + c]; }
     float rb[NIN][2];
     int rk[NIN][2];
     bool rv[NIN];
@@ -177,6 +182,10 @@ __global__ __launch_bounds__(256) void maxpool3_fwd_strip(const float* __restric
       float v[5];
       v[0] = b > 0 ? hl[j] : 0.f;
       v[1] = v4.x; v[2] = v4.y; v[3] = v4.z; v[4] = v4.w;
+      if (aff) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] = fmaxf((v[k] - amu) * asc + ash, 0.f);
+      }
       if (xs) {
 #pragma unroll
         for (int k = 0; k < 5; ++k) v[k] *= s;
@@ -484,6 +493,24 @@ __global__ __launch_bounds__(256) void chan_scale_bwd_kernel(const float* __rest
 
 }  // namespace
 
+extern "C" int dlio_maxpool2d_fwd_aff(const float* x, const float* aff, float* y, uint8_t* idx, int N, int C, int H,
+                                      int W, int OH, int OW, int K, int SH, int SW, int PH, int PW,
+                                      dlio_stream_t stream) {
+  if (!x || !aff || !y || N <= 0 || C <= 0) return DLIO_EINVAL;
+  if (!(K == 3 && SW == 2 && PH == 1 && PW == 1 && (SH == 1 || SH == 2) && (W & 3) == 0 && OW * 2 == W &&
+        OH == (H + 2 - 3) / SH + 1))
+    return DLIO_EUNSUP;
+  const int64_t work = (int64_t)N * C * OH * OW / 2;
+  DlioProfScope prof(10, as_stream(stream), 0.0, (double)N * C * (4.0 * H * W + (idx ? 5.0 : 4.0) * OH * OW));
+  if (SH == 1)
+    hipLaunchKernelGGL(maxpool3_fwd_strip<1>, dim3(ew_grid(cdiv64(work, 8), 256)), dim3(256), 0, as_stream(stream), x,
+                       (const float*)nullptr, y, idx, (int64_t)N * C, H, W, OH, OW, aff, C);
+  else
+    hipLaunchKernelGGL(maxpool3_fwd_strip<2>, dim3(ew_grid(cdiv64(work, 4), 256)), dim3(256), 0, as_stream(stream), x,
+                       (const float*)nullptr, y, idx, (int64_t)N * C, H, W, OH, OW, aff, C);
+  return dlio_check_launch();
+}
+
 extern "C" int dlio_maxpool2d_fwd(const float* x, const float* x_scale, float* y, uint8_t* idx,
                                   int N, int C, int H, int W, int OH, int OW, int K, int SH,
                                   int SW, int PH, int PW, dlio_stream_t stream) {
@@ -496,10 +523,10 @@ extern "C" int dlio_maxpool2d_fwd(const float* x, const float* x_scale, float* y
     static const int strip = getenv("DLIO_POOL_STRIP") ? atoi(getenv("DLIO_POOL_STRIP")) : 1;   // tuning knob
     if (strip && SH == 1)
       hipLaunchKernelGGL(maxpool3_fwd_strip<1>, dim3(ew_grid(cdiv64(work, 8), 256)), dim3(256), 0,
-                         as_stream(stream), x, x_scale, y, idx, (int64_t)N * C, H, W, OH, OW);
+                         as_stream(stream), x, x_scale, y, idx, (int64_t)N * C, H, W, OH, OW, (const float*)nullptr, 1);
     else if (strip)
       hipLaunchKernelGGL(maxpool3_fwd_strip<2>, dim3(ew_grid(cdiv64(work, 4), 256)), dim3(256), 0,
-                         as_stream(stream), x, x_scale, y, idx, (int64_t)N * C, H, W, OH, OW);
+                         as_stream(stream), x, x_scale, y, idx, (int64_t)N * C, H, W, OH, OW, (const float*)nullptr, 1);
     else if (SH == 1)
       hipLaunchKernelGGL(maxpool3_fwd_sw2<1>, dim3(ew_grid(work, 256)), dim3(256), 0, as_stream(stream),
                          x, x_scale, y, idx, (int64_t)N * C, H, W, OH, OW);

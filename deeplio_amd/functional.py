@@ -574,6 +574,41 @@ class ConvBnAct(Function):
         return (dx, dw, db, dg, dbt) + (None,) * 9
 
 
+class ConvBnActPoolFn(Function):
+    """conv -> BatchNorm -> ReLU -> MaxPool2d(3, pad 1, stride (1|2, 2)) as one tape node with the BatchNorm + ReLU applied
+    by the pool while it loads (training): the activated tensor is never written.  The PointSeg stem + pool1
+    (pointseg_net.py:18-21: 268 MB per encoder at the headline shape)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, rmean, rvar, stride, pad, momentum, eps, pk, pstride, ppad):
+        x = x.contiguous()
+        N, Cin, H, W = x.shape
+        Cout, _, KH, KW = weight.shape
+        OH = (H + 2 * pad[0] - KH) // stride[0] + 1
+        OW = (W + 2 * pad[1] - KW) // stride[1] + 1
+        raw = _new((N, Cout, OH, OW), x)
+        aff, inv = _new((3, Cout), x), _new((Cout,), x)
+        d, _ = _CBR.forward(x, Cin, 0, Cin, H, W, weight, bias, gamma, beta, rmean, rvar, stride, pad, True, momentum, eps,
+                            False, True, raw, Cout, 0, None, Cout, 0, N, need_dx=ctx.needs_input_grad[0],
+                            stats_into=(aff[0], inv, aff[1]), shift_into=aff[2])
+        y, idx = ops.maxpool2d_fwd_aff(raw, aff, pk, pstride[0], pstride[1], ppad[0], ppad[1])
+        ctx.save_for_backward(x, weight, beta, raw, aff, inv, gamma, bias, idx)
+        ctx.cfg = (d, pk, pstride, ppad)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, beta, raw, aff, inv, gamma, bias, idx = ctx.saved_tensors
+        d, pk, pstride, ppad = ctx.cfg
+        dact = ops.maxpool2d_bwd(dy.contiguous(), idx, tuple(raw.shape), pk, pstride[0], pstride[1], ppad[0], ppad[1])
+        draw = torch.empty_like(raw)
+        need_dx = ctx.needs_input_grad[0]
+        dx = torch.empty_like(x) if need_dx else None
+        dw, db, dg, dbt = _CBR.backward(dact, d.Cout, 0, x, d, weight, bias, gamma, (aff[0], inv, aff[1]), beta, raw,
+                                        True, False, True, draw, need_dx, dx, d.Cin, 0)
+        return (dx, dw, db, dg, dbt) + (None,) * 9
+
+
 # =============================================================================== Fire
 class FireFn(Function):
     """Fire block (pointseg_modules.py:116-142) as ONE tape node: squeeze CBR, then the two

@@ -22,6 +22,7 @@ from .misc import get_config_container
 _DEFER_IMU = os.environ.get("DLIO_DEFER_IMU_BWD", "1") != "0"
 # BatchNorm + ReLU of bypass-free Fire blocks applied by their consumer instead of being written
 _APPLY_ON_LOAD = os.environ.get("DLIO_APPLY_ON_LOAD", "1") != "0"
+_STEM_AOL = os.environ.get("DLIO_STEM_AOL", "1") != "0"      # ... and of the stem by pool1
 
 
 def _pair(v):
@@ -58,6 +59,16 @@ def _cbr(x, conv, bn, training, pre_relu=False, post_relu=True):
     return Fh.ConvBnAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
                               bn.running_var, _pair(conv.stride), _pair(conv.padding),
                               training, bn.momentum, bn.eps, pre_relu, post_relu)
+
+
+def _pool_fast_behind(x, conv, pool):
+    """does the pool behind `conv` applied to x take the 3x3 / pad 1 / stride (1|2, 2) kernels (ops.pool_fast_path)?"""
+    kh, kw = _pair(conv.kernel_size); sh, sw = _pair(conv.stride); ph, pw = _pair(conv.padding)
+    H = (x.shape[2] + 2 * ph - kh) // sh + 1
+    W = (x.shape[3] + 2 * pw - kw) // sw + 1
+    OH = ops.pool_out(H, pool.k, pool.stride[0], pool.pad[0], False)
+    OW = ops.pool_out(W, pool.k, pool.stride[1], pool.pad[1], False)
+    return ops.pool_fast_path(H, W, OH, OW, pool.k, pool.stride[0], pool.stride[1], pool.pad[0], pool.pad[1])
 
 
 def _bump(bn, training):
@@ -213,7 +224,13 @@ class PSEncoder(BaseNet):
         reverse creation order, backward alternates between the two streams as well"""
         tr = self.training
         _bump(self.conv1a[1], tr)
-        x = self.pool1(_cbr(x, self.conv1a[0], self.conv1a[1], tr))
+        p1, c1, b1 = self.pool1, self.conv1a[0], self.conv1a[1]
+        if tr and _APPLY_ON_LOAD and _STEM_AOL and x.is_cuda and not p1.ceil_mode and _pool_fast_behind(x, c1, p1):
+            # the stem's BatchNorm + ReLU is applied by pool1 while it loads (apply-on-load)
+            x = Fh.ConvBnActPoolFn.apply(x, c1.weight, c1.bias, b1.weight, b1.bias, b1.running_mean, b1.running_var,
+                                         _pair(c1.stride), _pair(c1.padding), b1.momentum, b1.eps, p1.k, p1.stride, p1.pad)
+        else:
+            x = p1(_cbr(x, c1, b1, tr))
         if self.precision == 'bf16':
             x = mixed.CastFn.apply(x)
         yield x

@@ -569,6 +569,19 @@ def maxpool2d_fwd(x, k, sh, sw, ph, pw, ceil_mode=False, x_scale=None, want_idx=
     return y, idx
 
 
+def maxpool2d_fwd_aff(x, aff, k, sh, sw, ph, pw):
+    """the fast-path pool over max(0, (x - aff[0]) * aff[1] + aff[2]) per channel (apply-on-load; aff [3, C] contiguous)"""
+    N, C_, H, W = x.shape
+    OH, OW = pool_out(H, k, sh, ph, False), pool_out(W, k, sw, pw, False)
+    if tuple(aff.shape) != (3, C_) or not aff.is_contiguous():
+        raise ValueError("aff must be a contiguous [3, C] tensor")
+    y = torch.empty(N, C_, OH, OW, dtype=torch.float32, device=x.device)
+    idx = torch.empty(N, C_, OH, OW, dtype=torch.uint8, device=x.device)
+    check(lib.dlio_maxpool2d_fwd_aff(_ptr(x), _ptr(aff), _ptr(y), _ptr(idx), N, C_, H, W, OH, OW, k, sh, sw, ph, pw,
+                                     _stream()), "maxpool2d_fwd_aff")
+    return y, idx
+
+
 def maxpool2d_bwd(dy, idx, in_shape, k, sh, sw, ph, pw, x_scale=None, x_add=None):
     N, C_, H, W = in_shape
     OH, OW = dy.shape[2], dy.shape[3]

@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 209
+#define DLIO_ABI_VERSION 210
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);           /* "gfx950" */
@@ -273,6 +273,11 @@ int dlio_chan_sum(const float* x, int N, int ctot, int coff, int C, int HW, floa
 int dlio_maxpool2d_fwd(const float* x, const float* x_scale, float* y, uint8_t* idx,
                        int N, int C, int H, int W, int OH, int OW, int K, int SH, int SW,
                        int PH, int PW, dlio_stream_t stream);
+/* the 3x3, pad 1, stride (1|2, 2) pool over max(0, (x - aff[0][c]) * aff[1][c] + aff[2][c]) (apply-on-load: x is the
+ * raw output of the convolution in front of the pool, aff = [3][C] mean / scale / shift; PointSeg stem -> pool1,
+ * pointseg_net.py:18-21); DLIO_EUNSUP for other pool shapes */
+int dlio_maxpool2d_fwd_aff(const float* x, const float* aff, float* y, uint8_t* idx, int N, int C, int H, int W,
+                           int OH, int OW, int K, int SH, int SW, int PH, int PW, dlio_stream_t stream);
 /* dx = scatter(dy) * x_scale[n][c] + x_add[n][c]; x_scale / x_add nullable (x_add only on the
  * 3x3, pad 1, stride (1|2, 2) fast path: SELayer + pool backward in one pass) */
 int dlio_maxpool2d_bwd(const float* dy, const uint8_t* idx, const float* x_scale,

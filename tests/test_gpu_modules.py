@@ -289,3 +289,27 @@ def test_odom_rnn_fc_softfusion_imufc(dev):
     fc = {'input-size': 6, 'hidden-size': [16, 32, 8], 'dropout': 0.}
     xi = torch.rand(3, 3, 7, 6, generator=torch.Generator().manual_seed(8))
     compare(nets.ImuFeatFC(fc), om.ImuFeatFC(fc, ctx), xi, dev)
+
+
+def test_stem_pool_apply_on_load(dev):
+    """PSEncoder stem + pool1 as one node: pool1 takes the maximum over max(0, BN(raw)) while it loads the stem's raw
+    output (dlio_maxpool2d_fwd_aff).  Forward, input-free backward (weight / BatchNorm gradients) and the running
+    statistics against the materialising path, which is tested against the oracle elsewhere."""
+    from deeplio_amd import nets
+    torch.manual_seed(4)
+    cfg = {'bypass': 'simple', 'dropout': 0.0, 'classes': ['a', 'b'], 'part': 'encoder'}
+    res = []
+    for fused in (True, False):
+        torch.manual_seed(4)
+        enc = nets.PSEncoder((10, 16, 128), cfg).to(dev).train()
+        nets._STEM_AOL = fused
+        x = torch.randn(2, 10, 16, 128, generator=torch.Generator().manual_seed(5)).to(dev)
+        try:
+            y = next(enc.forward_steps(x))
+        finally:
+            nets._STEM_AOL = True
+        y.square().sum().backward()
+        c, b = enc.conv1a[0], enc.conv1a[1]
+        res.append([y.detach(), c.weight.grad, b.weight.grad, b.bias.grad, b.running_mean.clone(), b.running_var.clone()])
+    for a, r in zip(*res):
+        assert rel_err(a, r.double()) < 2e-5
