@@ -79,6 +79,7 @@ SIGNATURES = {
     "dlio_chan_sum": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _p, _sz, _p]),
     "dlio_maxpool2d_fwd": (_i, [_p, _p, _p, _p] + [_i] * 11 + [_p]),
     "dlio_maxpool2d_fwd_aff": (_i, [_p, _p, _p, _p] + [_i] * 11 + [_p]),
+    "dlio_bn_bwd_pool": (_i, [_p] * 10 + [_i] * 8 + [_p, _sz, _p]),
     "dlio_maxpool2d_bwd": (_i, [_p, _p, _p, _p, _p] + [_i] * 11 + [_p]),
     "dlio_maxpool2d_bwd_dot": (_i, [_p, _p, _p, _p] + [_i] * 11 + [_p]),
     "dlio_gap_fwd": (_i, [_p, _i, _i, _p, _i, _i, _i, _p]),

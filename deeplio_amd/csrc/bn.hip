@@ -511,6 +511,115 @@ __global__ __launch_bounds__(256) void bn_plane_bwd_kernel(
 
 // chunks per plane: one when planes alone fill the chip (or the plane average is wanted), else
 // enough for ~2048 workgroups; chunk_len is a multiple of 256 work items
+// ---- BatchNorm backward behind a 3x3 / pad 1 / stride (SH, 2) max-pool: the gradient of the activated tensor is never
+// materialised -- both passes gather it from the pooled gradient and the arg-max map (dx[h][w] = sum over the <= 3 x 2
+// windows whose arg-max is (h, w): maxpool3_bwd's rule) for the four columns of a float4 while they stream x.
+// Columns w0 .. w0+3 (w0 % 4 == 0) see the outputs ow0 = w0 / 2 .. ow0 + 2: k = 0 -> (ow0, kx 1); 1 -> (ow0, 2), (ow0+1, 0);
+// 2 -> (ow0+1, 1); 3 -> (ow0+1, 2), (ow0+2, 0).
+template <int SH>
+__device__ __forceinline__ void pool_grad4(const float* __restrict__ gp, const uint8_t* __restrict__ ip, int h, int w0,
+                                           int OH, int OW, float (&g)[4]) {
+  g[0] = g[1] = g[2] = g[3] = 0.f;
+  const int ow0 = w0 >> 1;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int num = h + 1 - ky;                 // = oh * SH
+    if (num < 0 || (SH == 2 && (num & 1))) continue;
+    const int oh = SH == 2 ? num >> 1 : num;
+    if (oh >= OH) continue;
+    const size_t ro = (size_t)oh * OW + ow0;
+    const float2 d01 = *reinterpret_cast<const float2*>(gp + ro);
+    const unsigned short i01 = *reinterpret_cast<const unsigned short*>(ip + ro);
+    const bool v2 = ow0 + 2 < OW;
+    const float d2 = v2 ? gp[ro + 2] : 0.f;
+    const int i0 = i01 & 255, i1 = i01 >> 8, i2 = v2 ? (int)ip[ro + 2] : -1;
+    const int b = ky * 3;
+    if (i0 == b + 1) g[0] += d01.x;
+    if (i0 == b + 2) g[1] += d01.x;
+    if (i1 == b + 0) g[1] += d01.y;
+    if (i1 == b + 1) g[2] += d01.y;
+    if (i1 == b + 2) g[3] += d01.y;
+    if (i2 == b + 0) g[3] += d2;
+  }
+}
+
+template <int SH>
+__global__ __launch_bounds__(RB) void bn_pool_bwd_reduce_kernel(
+    const float* __restrict__ dyp, const uint8_t* __restrict__ idx, const float* __restrict__ x,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ scale,
+    const float* __restrict__ beta, int N, int C, int H, int W, int OH, int OW, int splits, double* __restrict__ part) {
+  __shared__ double sm[2][16];
+  const int c = blockIdx.x / splits, sp = blockIdx.x % splits;
+  const float mu = mean[c], is = invstd[c], sc = scale[c], be = beta ? beta[c] : 0.f;
+  const int w4 = W >> 2;
+  const int64_t per = (int64_t)H * w4, total = (int64_t)N * per;
+  double s0 = 0.0, s1 = 0.0;
+  for (int64_t i = (int64_t)sp * RB + threadIdx.x; i < total; i += (int64_t)splits * RB) {
+    const int n = (int)(i / per);
+    const int r = (int)(i - (int64_t)n * per);
+    const int h = r / w4, w0 = (r - h * w4) << 2;
+    const size_t pl = (size_t)n * C + c;
+    const float4 xv = *reinterpret_cast<const float4*>(x + (pl * H + h) * W + w0);
+    float g[4];
+    pool_grad4<SH>(dyp + pl * OH * OW, idx + pl * OH * OW, h, w0, OH, OW, g);
+    const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
+    float f0 = 0.f, f1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float xh = (xe[k] - mu) * is;
+      const float gg = ((xe[k] - mu) * sc + be > 0.f) ? g[k] : 0.f;
+      f0 += gg; f1 += gg * xh;
+    }
+    s0 += f0; s1 += f1;
+  }
+  const double r0 = block_sum_d(s0, sm[0]);
+  const double r1 = block_sum_d(s1, sm[1]);
+  if (threadIdx.x == 0) {
+    part[((size_t)c * splits + sp) * 2 + 0] = r0;
+    part[((size_t)c * splits + sp) * 2 + 1] = r1;
+  }
+}
+
+template <int SH>
+__global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(
+    const float* __restrict__ dyp, const uint8_t* __restrict__ idx, const float* __restrict__ x,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ scale,
+    const float* __restrict__ beta, const double* __restrict__ part, double inv_cnt, int splits, float* __restrict__ dx,
+    float* dgamma, float* dbeta, int accumulate, int N, int C, int H, int W, int OH, int OW, int chunks, int chunk_len) {
+  __shared__ double sm[2][16];
+  const int chunk = blockIdx.x % chunks;
+  const int pl = blockIdx.x / chunks;
+  const int n = pl / C, c = pl - n * C;
+  double sg, sgx;
+  plane_partials(part, c, splits, sm[0], sm[1], sg, sgx);
+  if (n == 0 && chunk == 0 && threadIdx.x == 0) {
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)sg : (float)sg;
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)sgx : (float)sgx;
+  }
+  const float mu = mean[c], is = invstd[c], sc = scale[c], be = beta ? beta[c] : 0.f;
+  const float mg = (float)(sg * inv_cnt), mgx = (float)(sgx * inv_cnt);
+  const int w4 = W >> 2, per = H * w4;
+  const int i1 = min(per, (chunk + 1) * chunk_len);
+  const float* gp = dyp + (size_t)pl * OH * OW;
+  const uint8_t* ip = idx + (size_t)pl * OH * OW;
+  for (int i = chunk * chunk_len + threadIdx.x; i < i1; i += 256) {
+    const int h = i / w4, w0 = (i - h * w4) << 2;
+    const size_t o = ((size_t)pl * H + h) * W + w0;
+    const float4 xv = *reinterpret_cast<const float4*>(x + o);
+    float g[4];
+    pool_grad4<SH>(gp, ip, h, w0, OH, OW, g);
+    const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
+    float oe[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float xh = (xe[k] - mu) * is;
+      const float gg = ((xe[k] - mu) * sc + be > 0.f) ? g[k] : 0.f;
+      oe[k] = sc * (gg - mg - xh * mgx);
+    }
+    *reinterpret_cast<float4*>(dx + o) = make_float4(oe[0], oe[1], oe[2], oe[3]);
+  }
+}
+
 static void plane_chunks(int planes, int per, bool whole_plane, int& chunks, int& chunk_len) {
   chunks = 1;
   if (!whole_plane && planes < 2048) {
@@ -636,6 +745,45 @@ extern "C" int dlio_chan_partials_reduce(const float* stats, int C, int slots, i
   DlioProfScope prof(6, s, 0.0, 8.0 * C * (double)slots);
   hipLaunchKernelGGL(chan_partials_reduce_kernel, dim3((unsigned)C), dim3(256), 0, s, stats, slots, splits,
                      reinterpret_cast<double*>(ws));
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_bn_bwd_pool(const float* dy_pool, const uint8_t* idx, const float* x, const float* mean,
+                                const float* invstd, const float* scale, const float* beta, float* dx,
+                                float* dgamma, float* dbeta, int accumulate, int N, int C, int H, int W, int OH,
+                                int OW, int SH, void* ws, size_t ws_bytes, dlio_stream_t stream) {
+  if (!dy_pool || !idx || !x || !mean || !invstd || !scale || !dx || !ws || N <= 0 || C <= 0) return DLIO_EINVAL;
+  if (!((SH == 1 || SH == 2) && (W & 3) == 0 && OW * 2 == W && OH == (H + 2 - 3) / SH + 1)) return DLIO_EUNSUP;
+  if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(dy_pool)) & 15) != 0)
+    return DLIO_EUNSUP;
+  const int HW = H * W;
+  const int splits = pick_splits(N, C, HW);
+  if (ws_bytes < (size_t)C * splits * 2 * sizeof(double)) return DLIO_EWS;
+  hipStream_t s = as_stream(stream);
+  double* part = reinterpret_cast<double*>(ws);
+  const double tensor_bytes = 4.0 * N * (double)C * HW;
+  {
+    DlioProfScope prof(8, s, 0.0, tensor_bytes * 1.6);
+    if (SH == 1)
+      hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel<1>, dim3((unsigned)(C * splits)), dim3(RB), 0, s, dy_pool, idx, x, mean,
+                         invstd, scale, beta, N, C, H, W, OH, OW, splits, part);
+    else
+      hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel<2>, dim3((unsigned)(C * splits)), dim3(RB), 0, s, dy_pool, idx, x, mean,
+                         invstd, scale, beta, N, C, H, W, OH, OW, splits, part);
+    const int rc = dlio_check_launch();
+    if (rc) return rc;
+  }
+  int chunks, chunk_len;
+  plane_chunks(N * C, HW / 4, false, chunks, chunk_len);
+  const dim3 grid((unsigned)(N * C * chunks));
+  const double inv_cnt = 1.0 / ((double)N * HW);
+  DlioProfScope prof(9, s, 0.0, tensor_bytes * 2.6);
+  if (SH == 1)
+    hipLaunchKernelGGL(bn_pool_bwd_apply_kernel<1>, grid, dim3(256), 0, s, dy_pool, idx, x, mean, invstd, scale, beta, part,
+                       inv_cnt, splits, dx, dgamma, dbeta, accumulate, N, C, H, W, OH, OW, chunks, chunk_len);
+  else
+    hipLaunchKernelGGL(bn_pool_bwd_apply_kernel<2>, grid, dim3(256), 0, s, dy_pool, idx, x, mean, invstd, scale, beta, part,
+                       inv_cnt, splits, dx, dgamma, dbeta, accumulate, N, C, H, W, OH, OW, chunks, chunk_len);
   return dlio_check_launch();
 }
 

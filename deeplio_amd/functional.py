@@ -29,6 +29,8 @@ _PLANE_BN = [os.environ.get("DLIO_PLANE_BN", "1") != "0"]
 _FUSED_STATS = [os.environ.get("DLIO_FUSED_BN_STATS", "0") != "0"]
 # Fire squeeze output activated on load by the expand convolutions / weight gradients instead of written
 _SQUEEZE_AOL = [os.environ.get("DLIO_SQUEEZE_AOL", "0") != "0"]
+# stem: pool1's backward folded into the stem's BatchNorm backward (ConvBnActPoolFn)
+_POOL_BN_BWD = [os.environ.get("DLIO_POOL_BN_BWD", "1") != "0"]
 
 
 def set_grad_sink(on):
@@ -348,7 +350,7 @@ class _CBR:
     @staticmethod
     def backward(dy, dy_ctot, dy_coff, x, d, weight, bias, gamma, prm, beta, raw, training, pre_relu,
                  post_relu, draw, need_dx, dx=None, dx_ctot=0, dx_coff=0, dx_residual=None,
-                 dxr_ctot=0, dxr_coff=0, dx_accumulate=False, in_aff=None):
+                 dxr_ctot=0, dxr_coff=0, dx_accumulate=False, in_aff=None, pooled=None):
         """dy: grad wrt the activated output (slice).  draw: scratch [N,Cout,OH,OW] (contiguous).
         Returns (dweight, dbias, dgamma, dbeta); writes dx (slice) if need_dx:
         dx = dgrad (+ dx_residual) (+ previous dx when dx_accumulate)."""
@@ -359,9 +361,14 @@ class _CBR:
             dgamma, acc_g, ret_g = _new((Cout,), dy), False, None
             dbeta, acc_b, ret_b = _new((Cout,), dy), False, None
             ret_g, ret_b = dgamma, dbeta
-        (ops.bn_bwd_fused if _PLANE_BN[0] else ops.bn_bwd)(
-            dy, dy_ctot, dy_coff, raw, d.out_ctot, d.out_coff, prm, beta, draw, Cout, 0, N,
-            Cout, OHW, pre_relu, post_relu, training, dgamma, dbeta, accumulate=acc_g)
+        if pooled is not None:
+            # dy is the POOLED gradient: (arg-max map, pool row stride) -- the BatchNorm passes gather the gradient of the
+            # activated tensor themselves (dlio_bn_bwd_pool), the pool's backward pass is not run
+            ops.bn_bwd_pool(dy, pooled[0], raw, prm, beta, draw, pooled[1], dgamma, dbeta, accumulate=acc_g)
+        else:
+            (ops.bn_bwd_fused if _PLANE_BN[0] else ops.bn_bwd)(
+                dy, dy_ctot, dy_coff, raw, d.out_ctot, d.out_coff, prm, beta, draw, Cout, 0, N,
+                Cout, OHW, pre_relu, post_relu, training, dgamma, dbeta, accumulate=acc_g)
         ret_bias = None
         if bias is not None:
             dbias, acc, ret_bias = _sink(bias, (Cout,), dy)
@@ -600,12 +607,17 @@ class ConvBnActPoolFn(Function):
     def backward(ctx, dy):
         x, weight, beta, raw, aff, inv, gamma, bias, idx = ctx.saved_tensors
         d, pk, pstride, ppad = ctx.cfg
-        dact = ops.maxpool2d_bwd(dy.contiguous(), idx, tuple(raw.shape), pk, pstride[0], pstride[1], ppad[0], ppad[1])
+        dy = dy.contiguous()
         draw = torch.empty_like(raw)
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty_like(x) if need_dx else None
+        # the pool's backward folded into the BatchNorm backward (not with synchronised statistics: that path needs the
+        # partials all-reduced between the two launches)
+        fold = _POOL_BN_BWD[0] and ops._SYNC_BN[0] is None
+        dact = dy if fold else ops.maxpool2d_bwd(dy, idx, tuple(raw.shape), pk, pstride[0], pstride[1], ppad[0], ppad[1])
         dw, db, dg, dbt = _CBR.backward(dact, d.Cout, 0, x, d, weight, bias, gamma, (aff[0], inv, aff[1]), beta, raw,
-                                        True, False, True, draw, need_dx, dx, d.Cin, 0)
+                                        True, False, True, draw, need_dx, dx, d.Cin, 0,
+                                        pooled=(idx, pstride[0]) if fold else None)
         return (dx, dw, db, dg, dbt) + (None,) * 9
 
 

@@ -507,6 +507,18 @@ def bn_bwd_fused(dy, dy_ctot, dy_coff, x, x_ctot, x_coff, prm, beta, dx, dx_ctot
     return dx
 
 
+def bn_bwd_pool(dy_pool, idx, x, prm, beta, dx, sh, dgamma=None, dbeta=None, accumulate=False):
+    """BatchNorm + ReLU backward with the gradient gathered from the pooled gradient / arg-max map of the fast-path pool
+    behind it (dlio_bn_bwd_pool); x, dx contiguous [N, C, H, W]"""
+    N, C_, H, W = x.shape
+    OH, OW = dy_pool.shape[2], dy_pool.shape[3]
+    ws = _stats_ws(N, C_, H * W, x.device)
+    check(lib.dlio_bn_bwd_pool(_ptr(dy_pool), _ptr(idx), _ptr(x), _ptr(prm[0]), _ptr(prm[1]), _ptr(prm[2]), _ptr(beta),
+                               _ptr(dx), _ptr(dgamma), _ptr(dbeta), int(accumulate), N, C_, H, W, OH, OW, int(sh),
+                               _ptr(ws), ws.numel(), _stream()), "bn_bwd_pool")
+    return dx
+
+
 def bn_eval_params(running_mean, running_var, gamma, eps):
     C_ = running_mean.numel()
     prm = torch.empty(3, C_, dtype=torch.float32, device=running_mean.device)

@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 210
+#define DLIO_ABI_VERSION 211
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);           /* "gfx950" */
@@ -459,6 +459,14 @@ int dlio_bn_train_apply(const float* x, int N, int x_ctot, int x_coff, int C, in
                         void* ws, size_t ws_bytes, int phase, double count_scale,
                         const float* r_mean, const float* r_scale, const float* r_shift,
                         dlio_stream_t stream);
+/* Train-mode BatchNorm (+ ReLU) backward behind a 3x3 / pad 1 / stride (SH, 2) max-pool (dlio_maxpool2d_fwd_aff): both
+ * launches gather the gradient of the activated tensor from the pooled gradient dy_pool [N,C,OH,OW] and the arg-max map
+ * while they stream x [N,C,H,W] -- the pool's own backward pass and its output are not needed.  dx contiguous;
+ * ws as dlio_chan_stats_ws_bytes(N, C, H * W); DLIO_EUNSUP for other pool shapes / unaligned tensors. */
+int dlio_bn_bwd_pool(const float* dy_pool, const uint8_t* idx, const float* x, const float* mean,
+                     const float* invstd, const float* scale, const float* beta, float* dx, float* dgamma,
+                     float* dbeta, int accumulate, int N, int C, int H, int W, int OH, int OW, int SH, void* ws,
+                     size_t ws_bytes, dlio_stream_t stream);
 /* BatchNorm backward in two launches: dlio_bn_bwd_reduce's reduction + a plane-structured
  * dlio_bn_bwd_apply that sums the partials itself; dgamma / dbeta (optional, += when accumulate)
  * are written by the workgroup of plane n=0.  phase / count_scale as above; local_ws (phase 2,

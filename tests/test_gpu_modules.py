@@ -298,18 +298,22 @@ def test_stem_pool_apply_on_load(dev):
     from deeplio_amd import nets
     torch.manual_seed(4)
     cfg = {'bypass': 'simple', 'dropout': 0.0, 'classes': ['a', 'b'], 'part': 'encoder'}
+    from deeplio_amd import functional as Fh
     res = []
-    for fused in (True, False):
+    # fused forward + pool backward folded into the BatchNorm backward (dlio_bn_bwd_pool) | fused forward, separate pool
+    # backward | the materialising path
+    for fused, fold in ((True, True), (True, False), (False, False)):
         torch.manual_seed(4)
         enc = nets.PSEncoder((10, 16, 128), cfg).to(dev).train()
-        nets._STEM_AOL = fused
+        nets._STEM_AOL, Fh._POOL_BN_BWD[0] = fused, fold
         x = torch.randn(2, 10, 16, 128, generator=torch.Generator().manual_seed(5)).to(dev)
         try:
             y = next(enc.forward_steps(x))
+            y.square().sum().backward()
         finally:
-            nets._STEM_AOL = True
-        y.square().sum().backward()
+            nets._STEM_AOL, Fh._POOL_BN_BWD[0] = True, True
         c, b = enc.conv1a[0], enc.conv1a[1]
         res.append([y.detach(), c.weight.grad, b.weight.grad, b.bias.grad, b.running_mean.clone(), b.running_var.clone()])
-    for a, r in zip(*res):
-        assert rel_err(a, r.double()) < 2e-5
+    for other in res[:2]:
+        for a, r in zip(other, res[2]):
+            assert rel_err(a, r.double()) < 2e-5
