@@ -470,3 +470,83 @@ def test_tail_graph_recaptures_on_a_new_batch_shape(dev):
     assert len(ts._tails) == 2 and all(np.isfinite(vals))
     ts.check()
     ts.release_gc()
+
+
+def _headline_oracle_grads(cfg, batch, dtype):
+    from oracle import model as om
+    from oracle import se3 as ose3
+    m = om.get_model((5, 64, 2048), cfg)
+    gc.fill_state(m, seed=1000)
+    m, c = m.to(dtype).train(), om.get_loss_function(cfg).to(dtype)
+    xyz, nrm, imu, f2f, f2g = (t.to(dtype) for t in batch)
+    a, b = m([[xyz, nrm], imu])
+    p2, q2 = ose3.se3_to_SE3(a, b)
+    lo = c(a, b, p2[:, 1:3], q2[:, 1:3], f2f[:, :, 0:3], f2f[:, :, 3:], f2g[:, 1:3, 0:3], f2g[:, 1:3, 3:7])
+    lo.backward()
+    g = {k: p.grad.double() for k, p in m.named_parameters() if p.grad is not None}
+    g["criterion.sx"], g["criterion.sq"] = c.sx.grad.double(), c.sq.grad.double()
+    return lo.detach().double(), g
+
+
+def test_headline_shape_gradients_vs_oracle(dev):
+    """BASELINE configs[1] at its real geometry (64x2048x5, bi-LSTM 128x2, odometry bi-LSTM 1024x2, soft fusion),
+    B=1, S=2, train mode, dropout 0, fill_state weights: `loss.backward()` of the HIP path (trainer.py:238-266
+    of the reference) against the CPU oracle in fp64, with the oracle's own fp32 run beside it.
+
+    Measured (tools/grad_noise_probe.py, CPU oracle only): the envelope does NOT collapse at this size.  The
+    gradient that reaches the output of the last Fire block is accurate in fp32 (1e-6 against fp64); one block
+    further back torch's own fp32 gradient is 4e-3 (B = 8) ... 1.3e-2 (B = 1) away from fp64, and every encoder
+    parameter inherits that.  Cause: ReLU / max-pool decisions.  The forward activations of the deepest blocks
+    carry ~1e-5 relative fp32 error, so a fraction f ~ 1e-5 of the masks differs between ANY two fp32
+    evaluations (or fp32 and fp64), and a masked gradient with a fraction f of its elements flipped is
+    sqrt(f) ~ 3e-3 away in relative L2 -- per block, adding in quadrature on the way back (an upstream gradient
+    without the average pool in front gives the same 1.3e-2).  No fp32 implementation can agree with another to
+    1e-4 here, the reference with itself at another thread count included.  So: everything behind the encoders
+    (IMU net, fusion, odometry net, heads, loss weights) is held to 1e-4; the encoder gradients must be samples
+    of the same error distribution as torch-fp32's (median and maximum within 1.5x, every parameter within 5x
+    of torch's own error for it); the 1e-4 claim for the encoder KERNELS at this geometry is carried per
+    launch, on identical operands, by test_gpu_ops.py::test_conv_headline_launch_sizes_vs_fp64 and the
+    decision-stable layer tests of test_gpu_modules.py."""
+    from deeplio_amd import losses, misc, nets
+    from deeplio_amd.config import make_config
+    cfg = make_config(seq=2, overrides=gc.NO_DROP)
+    misc.build_config_container(cfg, types.SimpleNamespace(device=str(dev), batch_size=1))
+    model = nets.get_model((5, 64, 2048), cfg, dev)
+    gc.fill_state(model, seed=1000)
+    model.train()
+    crit = losses.get_loss_function(cfg, dev)
+    batch = gc.make_batch(7, 1, 2, 5, 64, 2048, 50)
+    *_, loss = hip_step_forward(model, crit, tuple(t.to(dev) for t in batch))
+    loss.backward()
+    torch.cuda.synchronize()
+    l64, g64 = _headline_oracle_grads(cfg, batch, torch.float64)
+    l32, g32 = _headline_oracle_grads(cfg, batch, torch.float32)
+    assert abs(float(loss.detach()) - float(l64)) <= TOL * abs(float(l64))
+    named = dict(model.named_parameters())
+    named["criterion.sx"], named["criterion.sq"] = crit.sx, crit.sq
+    gmax = max(float(v.abs().max()) for v in g64.values())
+    rows = []
+    for k, ref in g64.items():
+        assert named[k].grad is not None, k
+        mine = named[k].grad.detach().double().cpu()
+        if float(ref.abs().max()) < 1e-5 * gmax:       # analytically-zero gradients (conv bias in front of a BN, Q3 weights)
+            assert float(mine.abs().max()) < 1e-4 * gmax, k
+            continue
+        rows.append((k, _l2(mine, ref), _l2(g32[k], ref)))
+    e_hip = np.asarray([r[1] for r in rows])
+    e_ref = np.asarray([r[2] for r in rows])
+    worst = sorted(rows, key=lambda r: -r[1] / max(r[2], 1e-4 / 3))[:6]
+    print("headline gradients, rel-L2 vs fp64 over %d parameters: hip median %.2e max %.2e | torch-fp32 median %.2e "
+          "max %.2e" % (len(rows), np.median(e_hip), e_hip.max(), np.median(e_ref), e_ref.max()))
+    for k, a, b in worst:
+        print("   %-60s hip %.2e  torch-fp32 %.2e" % (k, a, b))
+    # everything behind the encoders (IMU net, fusion, odometry net, heads, loss weights) is well conditioned: 1e-4
+    tail = [(k, a, b) for k, a, b in rows if not k.startswith("lidar_feat_net.encoder")]
+    assert tail and all(a <= max(TOL, 3.0 * b) for _, a, b in tail), [r for r in tail if r[1] > max(TOL, 3.0 * r[2])][:8]
+    assert np.median(e_hip) <= max(TOL, 1.5 * np.median(e_ref)), (np.median(e_hip), np.median(e_ref))
+    assert e_hip.max() <= max(TOL, 1.5 * e_ref.max()), (e_hip.max(), e_ref.max())
+    bad = [(k, a, b) for k, a, b in rows if a > max(TOL, 5.0 * b)]
+    assert not bad, bad[:8]
+    for k, p in model.named_parameters():
+        if k not in g64:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k

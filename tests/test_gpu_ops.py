@@ -980,3 +980,63 @@ def test_stem_conv3x5_stride2_split_bf16_matches_fp64(dev, case):
     ops.conv2d_fwd(x.to(dev), ops.conv2d_prep_weight(w.to(dev), 0), b.to(dev), y32, d)
     e_bx3, e_f32 = rel_err(y, ref), rel_err(y32, ref)
     assert e_bx3 < 3e-6 and e_bx3 < 4 * e_f32 + 2e-7, (e_bx3, e_f32)
+
+
+# Fire layers of the PointSeg encoders at the LAUNCH sizes bench.py times (N = B*S = 16 frame pairs of BASELINE
+# configs[1]): the XCD-ordered / one-workgroup-per-CU weight gradients, the split-K and k-split 1x1 kernels and the
+# TWN = 2 data gradients only take these branches at full size.
+HEADLINE_LAYERS = [
+    # N, Cin, Cout, H, W, k
+    (16, 16, 64, 64, 512, 3),      # blk1 expand3x3
+    (16, 64, 256, 64, 128, 3),     # blk3 expand3x3
+    (16, 80, 384, 16, 32, 3),      # blk5 expand3x3
+    (16, 512, 64, 32, 64, 1),      # blk4 squeeze
+    (16, 128, 16, 64, 512, 1),     # blk1 squeeze (second Fire)
+    (16, 64, 256, 64, 128, 1),     # blk3 expand1x1
+    (16, 768, 80, 16, 32, 1),      # blk5 squeeze (k-split over workgroups)
+]
+
+
+@pytest.mark.parametrize("case", HEADLINE_LAYERS)
+def test_conv_headline_launch_sizes_vs_fp64(dev, case):
+    """forward, data gradient and weight gradient through the kernels functional._CBR routes these layers to
+    (split-bf16 / fp32-MFMA by functional._use_bx3, dlio_conv2d_wgrad's own dispatch), against F.conv2d in fp64
+    on the host: <= 1e-4 of each tensor's scale (north_star), measured ~1e-6."""
+    from deeplio_amd import functional as Fh
+    from deeplio_amd import ops
+    N, Cin, Cout, H, W, k = case
+    p = k // 2
+    g = _g(77)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    dy = torch.randn(N, Cout, H, W, generator=g)
+    xr = x.double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, None, 1, p)
+    y_ref.backward(dy.double())
+    xd, wd, dyd = x.to(dev), w.to(dev), dy.to(dev)
+    d = ops.conv_desc(N, Cin, H, W, Cout, k, k, 1, 1, p, p)
+    y = torch.full((N, Cout, H, W), float("nan"), device=dev)
+    if Fh._use_bx3(N, Cin, Cout, k, k, (1, 1), H, W):
+        if k == 3:
+            ops.conv3x3_bx3_fwd(xd, ops.conv3x3_bx3_prep(wd, 0), None, y, d)
+        else:
+            ops.conv1x1_bx3_fwd(xd, ops.conv1x1_bx3_prep(wd, 0), None, y, d)
+    else:
+        ops.conv2d_fwd(xd, ops.conv2d_prep_weight(wd, 0), None, y, d)
+    e_f = rel_err(y, y_ref)
+    if Fh._use_bx3(N, Cout, Cin, k, k, (1, 1), H, W):
+        d.wbx3_1 = (ops.conv3x3_bx3_prep if k == 3 else ops.conv1x1_bx3_prep)(wd, 1)
+    d.wt2 = ops.conv2d_prep_weight(wd, 1)
+    dx = torch.full((N, Cin, H, W), float("nan"), device=dev)
+    Fh.conv_dgrad(dyd, wd, d, dx, Cin, 0)
+    e_d = rel_err(dx, xr.grad)
+    dw = torch.full_like(wd, float("nan"))
+    ops.conv2d_wgrad(xd, dyd, dw, d)
+    e_w = rel_err(dw, wr.grad)
+    # accumulate=True adds onto what is there (the flat gradient buffer of the training step)
+    dw2 = torch.ones_like(wd)
+    ops.conv2d_wgrad(xd, dyd, dw2, d, accumulate=True)
+    e_w2 = rel_err(dw2 - 1.0, wr.grad)
+    print("%s: fwd %.1e dgrad %.1e wgrad %.1e (accumulated %.1e)" % (case, e_f, e_d, e_w, e_w2))
+    assert e_f < TOL and e_d < TOL and e_w < TOL and e_w2 < TOL, (e_f, e_d, e_w, e_w2)
