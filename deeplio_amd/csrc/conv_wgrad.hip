@@ -12,6 +12,7 @@
 // Replaces the weight-gradient half of nn.Conv2d backward for every conv on the path
 // (same reference sites as conv_fwd.hip).
 #include "common.h"
+#include "wgrad3.h"
 #include <stdlib.h>
 
 namespace {
@@ -1150,6 +1151,14 @@ extern "C" int dlio_conv2d_wgrad_bf16(const void* x, const void* dy, float* dw, 
     return dlio_check_launch();
   }
   if (d.KH != 3 || d.KW != 3 || (d.OW & 7) || (d.W & 7)) return DLIO_EUNSUP;
+  DlioWgrad3Plan p3;
+  if (dlio_wgrad3_plan(d, 2, p3) && ws_bytes >= p3.ws_bytes) {
+    int rc = dlio_wgrad3_launch(x, dy, wsp, d, p3, 2, s);
+    if (rc) return rc;
+    const int64_t n = (int64_t)d.Cout * d.Cin * 9;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(n, 64)), dim3(256), 0, s, wsp, dw, n, p3.splits, accumulate);
+    return dlio_check_launch();
+  }
   WgPlan p;
   if (!make_plan(d, p)) return DLIO_EUNSUP;
   if (ws_bytes < p.ws_bytes) return DLIO_EWS;
@@ -1178,9 +1187,12 @@ extern "C" int dlio_conv2d_wgrad_bf16(const void* x, const void* dy, float* dw, 
 extern "C" size_t dlio_conv2d_wgrad_ws_bytes(const DlioConvDesc* d) {
   WgPlan p;
   if (!d || !make_plan(*d, p)) return 0;
+  size_t need = p.ws_bytes;
   Wg1Plan q;
-  if (make_plan_1x1(*d, q) && q.ws_bytes > p.ws_bytes) return q.ws_bytes;
-  return p.ws_bytes;
+  if (make_plan_1x1(*d, q) && q.ws_bytes > need) need = q.ws_bytes;
+  DlioWgrad3Plan p3;
+  if (dlio_wgrad3_plan(*d, 4, p3) && p3.ws_bytes > need) need = p3.ws_bytes;
+  return need;
 }
 
 extern "C" int dlio_conv2d_wgrad(const float* x, const float* dy, float* dw,
@@ -1208,6 +1220,19 @@ extern "C" int dlio_conv2d_wgrad(const float* x, const float* dy, float* dw,
                     : (d.KH == 1 && d.KW == 1 && d.SH == 1 && d.SW == 1) ? 5 : 1;
   dlio_prof_begin(pkind, s, flops, bytes);
   int rc = DLIO_EUNSUP;
+  DlioWgrad3Plan p3;
+  if (!in_scale && dlio_wgrad3_plan(d, 4, p3) && ws_bytes >= p3.ws_bytes &&
+      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0) {
+    rc = dlio_wgrad3_launch(x, dy, wsp, d, p3, 4, s);
+    if (!rc) {
+      const int64_t n = (int64_t)d.Cout * d.Cin * 9;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(n, 64)), dim3(256), 0, s, wsp, dw, n, p3.splits,
+                         accumulate);
+      rc = dlio_check_launch();
+    }
+    dlio_prof_end(pkind, s);
+    return rc;
+  }
   Wg1Plan q;
   if (make_plan_1x1(d, q) && ws_bytes >= q.ws_bytes &&
       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0) {
