@@ -70,7 +70,7 @@ struct W3Cfg {
   static constexpr int PS = (TH + 2) * RS;               // plane stride
   static constexpr int BUF = NP * PS;                    // dwords of one patch buffer
   static constexpr int RED = MR * NTB * 3 * 16 * 64;     // accumulator exchange at the end
-  static constexpr int SM_DWORDS = 2 * BUF > RED ? 2 * BUF : RED;
+  static constexpr int SM_DWORDS = 2 * BUF > 4 * RED ? 2 * BUF : 4 * RED;   // epilogue: one region per wave
   static constexpr size_t LDS_BYTES = (size_t)SM_DWORDS * 4;
   static constexpr int PPR = NAT ? 4 : 8;                // 16-byte pieces per (row, channel): 4 fp32 / 8 bf16 columns each
   static constexpr int XITEMS = (TH + 2) * CKC * PPR;
@@ -117,221 +117,231 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const float* __restrict_
         for (int r = 0; r < 16; ++r) acc[m][t][k][r] = 0.f;
 
   const int total_tiles = d.N * tiles_h * tiles_w;
-  const size_t ohw = (size_t)d.OH * d.OW, HW = (size_t)d.H * d.W;
+  const unsigned ohw = (unsigned)(d.OH * d.OW), HW = (unsigned)(d.H * d.W);     // byte sizes < 4 GB (dlio_wgrad3_plan)
   constexpr unsigned OOB = 0xffffff00u;
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(x), 0, (int)((size_t)d.N * d.in_ctot * HW * EB), 0x00020000);
   const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(dy), 0, (int)((size_t)d.N * d.out_ctot * ohw * EB), 0x00020000);
 
-  // ---- X patch: rows oh0 - 1 .. oh0 + 4, columns iw0 .. iw0 + 31 (no column halo), CKC channels.
-  // fp32: piece = 4 columns; thread -> (c4 = tid & 7, then channel, then row).  NAT: piece = 8 columns (c4 < 4).
+  // ---- X patch: rows oh0 - 1 .. oh0 + 4, columns iw0 .. iw0 + 31 (no column halo), CKC channels, as 16-byte pieces
+  // (fp32: 4 columns, 8 per row; bf16: 8 columns, 4 per row).  Everything that does not depend on the tile is computed
+  // once; per tile a piece costs one scalar base + a select (unconditional loads: an invalid piece reads beyond
+  // num_records and gets zeros, no branches).
   constexpr int PPR = C::PPR, NXI = C::NXI;
-  u32x4 rx[NXI];
-  auto load_x = [&](int tile) {
+  constexpr int RPI = 256 / (PPR * C::CKC);              // patch rows covered by one piece index (256 threads)
+  static_assert(RPI * PPR * C::CKC == 256, "a piece index must cover whole patch rows");
+  const int xc4 = tid % PPR, xch = (tid / PPR) % C::CKC, xr0 = tid / (PPR * C::CKC);
+  const int xcol = xc4 * (32 / PPR);
+  const bool xok = c0 + xch < d.Cin;
+  const unsigned xoff0 = ((unsigned)xch * HW + (unsigned)(xr0 * d.W + xcol)) * EB;
+  const unsigned xlds0 = (unsigned)(xr0 * C::RS + xch * C::CS + (NAT ? 4 : 2) * xc4);
+  struct XRaw { u32x4 v[NXI]; };
+  auto load_x = [&](int tile, XRaw& rx) {
     int tt = tile;
     const int tw = tt % tiles_w; tt /= tiles_w;
     const int th = tt % tiles_h; tt /= tiles_h;
     const int n = tt;
-    const unsigned img = (unsigned)(((size_t)n * d.in_ctot + d.in_coff + c0) * HW * EB);     // uniform
+    // (row -1 of the first tile row wraps below the image base: such pieces are invalid and never use it)
+    const unsigned base = ((unsigned)(n * d.in_ctot + d.in_coff + c0) * HW + (unsigned)((th * C::TH - 1) * d.W + tw * C::TW)) * EB;
+    const bool tv = (tile < total_tiles) & xok & (tw * C::TW + xcol < d.W);
 #pragma unroll
     for (int i = 0; i < NXI; ++i) {
-      const int it = tid + 256 * i;
-      const int c4 = it % PPR, ch = (it / PPR) % C::CKC, r = it / (PPR * C::CKC);
-      const int ih = th * C::TH - 1 + r, iw = tw * C::TW + c4 * (32 / PPR);
-      const bool v = it < C::XITEMS && c0 + ch < d.Cin && ih >= 0 && ih < d.H && iw < d.W;
-      const unsigned vo = v ? img + (unsigned)(((size_t)ch * HW + (size_t)ih * d.W + iw) * EB) : OOB;
-      rx[i] = load_b128(xrsrc, vo);
+      const int r = RPI * i + xr0;
+      const int ih = th * C::TH - 1 + r;
+      const bool v = tv & (r < C::TH + 2) & (ih >= 0) & (ih < d.H);
+      rx.v[i] = load_b128(xrsrc, v ? base + xoff0 + (unsigned)(RPI * i * d.W) * EB : OOB);
     }
   };
-  auto store_x = [&](unsigned* buf) {
-#pragma unroll
-    for (int i = 0; i < NXI; ++i) {
-      const int it = tid + 256 * i;
-      const int c4 = it % PPR, ch = (it / PPR) % C::CKC, r = it / (PPR * C::CKC);
-      if (C::XITEMS % 256 != 0 && it >= C::XITEMS) continue;
-      if constexpr (NAT) {
-        *reinterpret_cast<u32x4*>(buf + r * C::RS + ch * C::CS + 4 * c4) = rx[i];
-      } else {
-        const float v0 = as_f(rx[i][0]), v1 = as_f(rx[i][1]);
-        const float v2 = as_f(rx[i][2]), v3 = as_f(rx[i][3]);
-        unsigned h0, m0, l0, h1, m1, l1;
-        split_pair(v0, v1, h0, m0, l0);
-        split_pair(v2, v3, h1, m1, l1);
-        const u32x2 h = {h0, h1}, m = {m0, m1}, l = {l0, l1};
-        unsigned* p = buf + r * C::RS + ch * C::CS + 2 * c4;
-        *reinterpret_cast<u32x2*>(p) = h;
-        *reinterpret_cast<u32x2*>(p + C::PS) = m;
-        *reinterpret_cast<u32x2*>(p + 2 * C::PS) = l;
-      }
+  auto store_piece = [&](const XRaw& rx, int i, unsigned* buf) {
+    if (C::XITEMS % 256 != 0 && RPI * i + xr0 >= C::TH + 2) return;
+    unsigned* p = buf + xlds0 + RPI * i * C::RS;
+    if constexpr (NAT) {
+      *reinterpret_cast<u32x4*>(p) = rx.v[i];
+    } else {
+      const float v0 = as_f(rx.v[i][0]), v1 = as_f(rx.v[i][1]), v2 = as_f(rx.v[i][2]), v3 = as_f(rx.v[i][3]);
+      unsigned h0, m0, l0, h1, m1, l1;
+      split_pair(v0, v1, h0, m0, l0);
+      split_pair(v2, v3, h1, m1, l1);
+      *reinterpret_cast<u32x2*>(p) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(p + C::PS) = u32x2{m0, m1};
+      *reinterpret_cast<u32x2*>(p + 2 * C::PS) = u32x2{l0, l1};
     }
   };
 
   // ---- dY: lane (co, half) of wave w: row oh0 + w, columns iw0 + 16 half - 1 .. + 16
   constexpr int NAL = NAT ? 2 : 4;                       // aligned 16-byte loads of the 16 columns
   struct ARaw { u32x4 v[MR][NAL]; unsigned hl[MR], hr[MR]; };
+  unsigned aoff[MR];
+  bool aok[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    aok[m] = co0 + 32 * m + l31 < d.Cout;
+    aoff[m] = ((unsigned)(32 * m + l31) * ohw + (unsigned)(wave * d.OW + 16 * half)) * EB;
+  }
   auto load_a = [&](int tile, ARaw& a) {
     int tt = tile;
     const int tw = tt % tiles_w; tt /= tiles_w;
     const int th = tt % tiles_h; tt /= tiles_h;
     const int n = tt;
     const int oh = th * C::TH + wave, ow = tw * C::TW + half * 16;
-    const unsigned img = (unsigned)(((size_t)n * d.out_ctot + d.out_coff + co0) * ohw * EB);   // uniform
-    const unsigned row = (unsigned)(((size_t)l31 * ohw + (size_t)oh * d.OW + ow) * EB);
+    const unsigned base = ((unsigned)(n * d.out_ctot + d.out_coff + co0) * ohw + (unsigned)(th * C::TH * d.OW + tw * C::TW)) * EB;
+    const bool rv = (tile < total_tiles) & (oh < d.OH);
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
-      const bool vm = co0 + m * 32 + l31 < d.Cout && oh < d.OH;
-      const unsigned base = img + row + (unsigned)((size_t)m * 32 * ohw * EB);
+      const bool vm = rv & aok[m];
+      const unsigned b = base + aoff[m];
 #pragma unroll
       for (int q = 0; q < NAL; ++q) {
-        const bool v = vm && ow + (16 / NAL) * q < d.OW;
-        a.v[m][q] = load_b128(arsrc, v ? base + 16u * q : OOB);
+        const bool v = vm & (ow + (16 / NAL) * q < d.OW);
+        a.v[m][q] = load_b128(arsrc, v ? b + 16u * q : OOB);
       }
-      const bool vl = vm && ow - 1 >= 0 && ow - 1 < d.OW, vr = vm && ow + 16 < d.OW;
+      const bool vl = vm & (ow >= 1) & (ow - 1 < d.OW), vr = vm & (ow + 16 < d.OW);
       if constexpr (NAT) {
-        a.hl[m] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(arsrc, vl ? base - 2u : OOB, 0, 0);
-        a.hr[m] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(arsrc, vr ? base + 32u : OOB, 0, 0);
+        a.hl[m] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(arsrc, vl ? b - 2u : OOB, 0, 0);
+        a.hr[m] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(arsrc, vr ? b + 32u : OOB, 0, 0);
       } else {
-        a.hl[m] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(arsrc, vl ? base - 4u : OOB, 0, 0);
-        a.hr[m] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(arsrc, vr ? base + 64u : OOB, 0, 0);
+        a.hl[m] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(arsrc, vl ? b - 4u : OOB, 0, 0);
+        a.hr[m] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(arsrc, vr ? b + 64u : OOB, 0, 0);
       }
     }
   };
-  // packed fragments: E[p][m][0..8] (pairs (v0,v1) .. (v16,v17)), O[p][m][0..7] (pairs (v1,v2) .. (v15,v16))
-  struct AFrag { unsigned E[NP][MR][9], O[NP][MR][8]; };
-  auto prep_a = [&](const ARaw& a, AFrag& f) {
+  // packed fragments: E[p][m][0..8] = pairs (v0,v1) .. (v16,v17); the odd-aligned pairs O (kx = 1) are one funnel shift
+  // per dword away and are formed when a k-block's MFMAs start (fp32), or are simply what was loaded (bf16)
+  struct AFrag { unsigned E[NP][MR][9], O[NAT ? 1 : 0 + 1][MR][8]; };
+  auto prep_pair = [&](const ARaw& a, int j, AFrag& f) {
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
       if constexpr (NAT) {
         // the loaded dwords are the aligned pairs (v1,v2) ... (v15,v16) = O; E is the funnel shift
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f.O[0][m][j] = a.v[m][j >> 2][j & 3];
-        f.E[0][m][0] = (a.hl[m] & 0xffffu) | (f.O[0][m][0] << 16);
-#pragma unroll
-        for (int j = 1; j < 8; ++j) f.E[0][m][j] = __builtin_amdgcn_alignbit(f.O[0][m][j], f.O[0][m][j - 1], 16);
-        f.E[0][m][8] = (f.O[0][m][7] >> 16) | (a.hr[m] << 16);
+        if (j < 8) f.O[0][m][j] = a.v[m][j >> 2][j & 3];
+        if (j == 0) f.E[0][m][0] = (a.hl[m] & 0xffffu) | (a.v[m][0][0] << 16);
+        else if (j < 8) f.E[0][m][j] = __builtin_amdgcn_alignbit(a.v[m][j >> 2][j & 3], a.v[m][(j - 1) >> 2][(j - 1) & 3], 16);
+        else f.E[0][m][8] = (a.v[m][1][3] >> 16) | (a.hr[m] << 16);
       } else {
-        float v[18];
-        v[0] = as_f(a.hl[m]);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[1 + j] = as_f(a.v[m][j >> 2][j & 3]);
-        v[17] = as_f(a.hr[m]);
-#pragma unroll
-        for (int j = 0; j < 9; ++j) split_pair(v[2 * j], v[2 * j + 1], f.E[0][m][j], f.E[1][m][j], f.E[2][m][j]);
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) f.O[p][m][j] = __builtin_amdgcn_alignbit(f.E[p][m][j + 1], f.E[p][m][j], 16);
+        const float lo = j == 0 ? as_f(a.hl[m]) : as_f(a.v[m][(2 * j - 1) >> 2][(2 * j - 1) & 3]);
+        const float hi = j == 8 ? as_f(a.hr[m]) : as_f(a.v[m][(2 * j) >> 2][(2 * j) & 3]);
+        split_pair(lo, hi, f.E[0][m][j], f.E[1][m][j], f.E[2][m][j]);
       }
     }
-  };
-  auto a_op = [&](const AFrag& f, int p, int m, int kx, int q) -> bf16x8 {
-    u32x4 r;
-    if (kx == 1) r = u32x4{f.O[p][m][4 * q], f.O[p][m][4 * q + 1], f.O[p][m][4 * q + 2], f.O[p][m][4 * q + 3]};
-    else {
-      const int b = 4 * q + (kx == 0 ? 1 : 0);
-      r = u32x4{f.E[p][m][b], f.E[p][m][b + 1], f.E[p][m][b + 2], f.E[p][m][b + 3]};
-    }
-    return __builtin_bit_cast(bf16x8, r);
   };
 
   // six products, smallest first: (lo,hi) (mid,mid) (hi,lo) (mid,hi) (hi,mid) (hi,hi)   [A plane, B plane]
   constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
   constexpr int NTERM = NAT ? 1 : 6;
+  constexpr int NS = 2 * NTB;                            // steps of a tile: (k-block q, B tile t)
+  constexpr int NM = NTERM * 3 * MR;                     // MFMAs of a step
 
-  auto mfma_half = [&](const unsigned* buf, const AFrag& f, int q) {
+  struct BFrag { bf16x8 v[NP]; };
+  auto read_b = [&](const unsigned* buf, int step, BFrag& b) {
+    const int q = step / NTB, t = step - q * NTB;
     const char* bp = reinterpret_cast<const char*>(buf) + 16 * q;
-    bf16x8 b[NTB][NP];
 #pragma unroll
-    for (int t = 0; t < NTB; ++t)
+    for (int p = 0; p < NP; ++p)
+      b.v[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bp + boff[t] + (size_t)p * C::PS * 4));
+  };
+
+  // ---- pipeline.  One straight-line body per tile, no branches (a tile behind the last one loads zeros).  Tile n is
+  // multiplied out of (bufc, fc) in NS steps; between the MFMAs sits tile n+1's staging: its dY pairs are split and
+  // packed in the first steps (from registers loaded a whole tile earlier; step 0 sends out the dY loads of tile n+2),
+  // its patch is loaded in step 0 and split into the other LDS buffer in the last two steps.
+  XRaw xa;
+  ARaw ra, rb;
+  AFrag fa, fb;
+  unsigned* buf0 = smem;
+  unsigned* buf1 = smem + C::BUF;
+  const int ntiles = split < total_tiles ? (total_tiles - split + splits - 1) / splits : 0;
+  load_x(split, xa);
+  load_a(split, ra);
 #pragma unroll
-      for (int p = 0; p < NP; ++p)
-        b[t][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bp + boff[t] + (size_t)p * C::PS * 4));
-#ifdef W3_DEBUG
-    if (blockIdx.x == 0 && wave == 0 && (lane == W3_DEBUG || lane == 20) && !NAT) {
-      for (int t = 0; t < NTB; ++t)
-        for (int p = 0; p < NP; ++p) {
-          const u32x4 v = __builtin_bit_cast(u32x4, b[t][p]);
-          printf("lane %d q %d B[t=%d][p=%d] = %08x %08x %08x %08x (boff %u)\n", lane, q, t, p, v[0], v[1], v[2], v[3], boff[t]);
-        }
-      for (int p = 0; p < NP; ++p) {
-        printf("lane %d q %d E[p=%d] =", lane, q, p);
-        for (int j = 0; j < 9; ++j) printf(" %08x", f.E[p][0][j]);
-        printf(" | O =");
-        for (int j = 0; j < 8; ++j) printf(" %08x", f.O[p][0][j]);
-        printf("\n");
+  for (int i = 0; i < NXI; ++i) store_piece(xa, i, buf0);
+#pragma unroll
+  for (int j = 0; j < 9; ++j) prep_pair(ra, j, fa);
+  load_a(split + splits, ra);
+  __syncthreads();
+
+  constexpr int XS0 = NS - 2;                            // first step that stores patch pieces
+  constexpr int PS_N = NS - 2;                           // steps that prepare dY pairs
+  auto body = [&](const unsigned* bufc, const AFrag& fc, unsigned* bufn, AFrag& fn, const ARaw& ac, ARaw& an, int tile1,
+                  int tile2) {
+    BFrag bq[2];
+    read_b(bufc, 0, bq[0]);
+    unsigned O[NP][MR][4];                               // kx = 1 operand of the current k-block
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      const int q = st / NTB, t = st - q * NTB;
+      if (st + 1 < NS) read_b(bufc, st + 1, bq[(st + 1) & 1]);
+      if (st == 0) { load_x(tile1, xa); load_a(tile2, an); }
+      if (t == 0) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+          for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              O[p][m][j] = NAT ? fc.O[0][m][4 * q + j]
+                               : __builtin_amdgcn_alignbit(fc.E[p][m][4 * q + j + 1], fc.E[p][m][4 * q + j], 16);
       }
-    }
-#endif
+      // this step's share of the next tile's staging
 #pragma unroll
-    for (int t = 0; t < NTB; ++t)
+      for (int j = 0; j < 9; ++j)
+        if (st < PS_N && j % PS_N == st) prep_pair(ac, j, fn);
+#pragma unroll
+      for (int i = 0; i < NXI; ++i)
+        if (st >= XS0 && i % 2 == st - XS0) store_piece(xa, i, bufn);
+      const BFrag& b = bq[st & 1];
 #pragma unroll
       for (int term = 0; term < NTERM; ++term)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-          for (int m = 0; m < MR; ++m)
-            acc[m][t][kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_op(f, NAT ? 0 : TA[term], m, kx, q),
-                                                                  b[t][NAT ? 0 : TB[term]], acc[m][t][kx], 0, 0, 0);
-  };
-
-  // ---- pipeline
-  ARaw ra;
-  AFrag fa, fb;
-  unsigned* buf0 = smem;
-  unsigned* buf1 = smem + C::BUF;
-  int tile = split;
-  if (tile < total_tiles) {
-    load_x(tile);
-    load_a(tile, ra);
-    store_x(buf0);
-    prep_a(ra, fa);
-    if (tile + splits < total_tiles) { load_x(tile + splits); load_a(tile + splits, ra); }
-  }
-  __syncthreads();
-  // two tiles per trip: (buf0, fa) then (buf1, fb)
-  while (tile < total_tiles) {
-    {
-      const bool more = tile + splits < total_tiles;
-      mfma_half(buf0, fa, 0);
-      if (more) { store_x(buf1); prep_a(ra, fb); }
-      if (tile + 2 * splits < total_tiles) { load_x(tile + 2 * splits); load_a(tile + 2 * splits, ra); }
-      mfma_half(buf0, fa, 1);
-      __syncthreads();
-      if (!more) break;
-      tile += splits;
-    }
-    {
-      const bool more = tile + splits < total_tiles;
-      mfma_half(buf1, fb, 0);
-      if (more) { store_x(buf0); prep_a(ra, fa); }
-      if (tile + 2 * splits < total_tiles) { load_x(tile + 2 * splits); load_a(tile + 2 * splits, ra); }
-      mfma_half(buf1, fb, 1);
-      __syncthreads();
-      if (!more) break;
-      tile += splits;
-    }
-  }
-
-  // ---- sum the four waves' accumulators through LDS (fixed order), write the slab
-  float* red = reinterpret_cast<float*>(smem);
-  for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
-#pragma unroll
-      for (int m = 0; m < MR; ++m)
-#pragma unroll
-        for (int t = 0; t < NTB; ++t)
-#pragma unroll
-          for (int k = 0; k < 3; ++k)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int i = (((m * NTB + t) * 3 + k) * 16 + r) * 64 + lane;
-              if (w == 0) red[i] = acc[m][t][k][r];
-              else red[i] += acc[m][t][k][r];
+          for (int m = 0; m < MR; ++m) {
+            const int pa = NAT ? 0 : TA[term];
+            u32x4 av;
+            if (kx == 1) av = u32x4{O[pa][m][0], O[pa][m][1], O[pa][m][2], O[pa][m][3]};
+            else {
+              const int e = 4 * q + (kx == 0 ? 1 : 0);
+              av = u32x4{fc.E[pa][m][e], fc.E[pa][m][e + 1], fc.E[pa][m][e + 2], fc.E[pa][m][e + 3]};
             }
+            acc[m][t][kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), b.v[NAT ? 0 : TB[term]],
+                                                                  acc[m][t][kx], 0, 0, 0);
+          }
+      // schedule of the step: the next step's fragment reads first, then MFMAs with the staging work dealt between them
+      __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, NAT ? 8 : 5, 0);
+        if (st == 0 && i < 6) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+        if (st >= XS0 && i % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
     }
     __syncthreads();
+  };
+  for (int it = 0; it < ntiles; it += 2) {
+    body(buf0, fa, buf1, fb, ra, rb, split + (it + 1) * splits, split + (it + 2) * splits);
+    if (it + 1 >= ntiles) break;
+    body(buf1, fb, buf0, fa, rb, ra, split + (it + 2) * splits, split + (it + 3) * splits);
   }
+
+  // ---- the four waves' accumulators meet in LDS (one region per wave, 16-byte stores, one barrier) and every thread sums
+  // its output elements over the waves in a fixed order while it writes the slab
+  float* red = reinterpret_cast<float*>(smem);
+  {
+    float* mine = red + wave * C::RED;
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+      for (int t = 0; t < NTB; ++t)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const f32x4 v = {acc[m][t][k][4 * r4], acc[m][t][k][4 * r4 + 1], acc[m][t][k][4 * r4 + 2], acc[m][t][k][4 * r4 + 3]};
+            *reinterpret_cast<f32x4*>(mine + ((((m * NTB + t) * 3 + k) * 4 + r4) * 64 + lane) * 4) = v;
+          }
+  }
+  __syncthreads();
   const size_t row_len = (size_t)d.Cin * 9;
   float* out = wsp + (size_t)split * d.Cout * row_len;
   const int nch = min(C::CKC, d.Cin - c0);
@@ -345,8 +355,9 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const float* __restrict_
     const int bl = 16 * (s & 1) + (ch & 15);             // B lane
     const int m = col >> 5, row = col & 31;
     const int hf = (row >> 2) & 1, r = (row & 3) + 4 * (row >> 3);
+    const int i = ((((m * NTB + t) * 3 + kx) * 4 + (r >> 2)) * 64 + hf * 32 + bl) * 4 + (r & 3);
     out[(size_t)(co0 + col) * row_len + (size_t)(c0 + ch) * 9 + tap] =
-        red[(((m * NTB + t) * 3 + kx) * 16 + r) * 64 + hf * 32 + bl];
+        ((red[i] + red[C::RED + i]) + red[2 * C::RED + i]) + red[3 * C::RED + i];
   }
 }
 
