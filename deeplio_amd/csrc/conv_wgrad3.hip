@@ -41,6 +41,17 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned pk(bf16x2 v) { return __builtin_bit_cast(unsigned, v); }
 
+// compile-time loop: f(integral_constant<int, i>) for i in [B, E) -- the instruction stream below is laid out by index
+// arithmetic that must fold (a `#pragma unroll` the optimiser declines leaves register arrays indexed at run time = scratch)
+template <int I> struct IC { static constexpr int value = I; };
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(IC<B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
 __device__ __forceinline__ u32x4 load_b128(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset) {
   return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, 0, 0));
 }
@@ -58,6 +69,9 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsign
   const bf16x2 ll = {(__bf16)sa, (__bf16)sb};
   h = pk(hh); m = pk(mm); l = pk(ll);
 }
+
+// six products, smallest first: (lo,hi) (mid,mid) (hi,lo) (mid,hi) (hi,mid) (hi,hi)   [A plane, B plane]
+__device__ constexpr int TA_[6] = {2, 1, 0, 1, 0, 0}, TB_[6] = {0, 1, 2, 0, 1, 0};
 
 template <int MR, int NTB, bool NAT>
 struct W3Cfg {
@@ -137,7 +151,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const float* __restrict_
   const unsigned xoff0 = ((unsigned)xch * HW + (unsigned)(xr0 * d.W + xcol)) * EB;
   const unsigned xlds0 = (unsigned)(xr0 * C::RS + xch * C::CS + (NAT ? 4 : 2) * xc4);
   struct XRaw { u32x4 v[NXI]; };
-  auto load_x = [&](int tile, XRaw& rx) {
+  auto load_x = [&](int tile, XRaw& rx, int i0, int i1) {
     int tt = tile;
     const int tw = tt % tiles_w; tt /= tiles_w;
     const int th = tt % tiles_h; tt /= tiles_h;
@@ -147,10 +161,30 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const float* __restrict_
     const bool tv = (tile < total_tiles) & xok & (tw * C::TW + xcol < d.W);
 #pragma unroll
     for (int i = 0; i < NXI; ++i) {
+      if (i < i0 || i >= i1) continue;
       const int r = RPI * i + xr0;
       const int ih = th * C::TH - 1 + r;
       const bool v = tv & (r < C::TH + 2) & (ih >= 0) & (ih < d.H);
       rx.v[i] = load_b128(xrsrc, v ? base + xoff0 + (unsigned)(RPI * i * d.W) * EB : OOB);
+    }
+  };
+  // one half of a piece (fp32: a pair of columns -> one dword per plane, kept in `xt` until the piece's second half
+  // completes the 8-byte stores); bf16: the whole piece at hp == 0
+  unsigned xt[3];
+  auto store_half = [&](const XRaw& rx, int i, int hp, unsigned* buf) {
+    unsigned* p = buf + xlds0 + RPI * i * C::RS;
+    const bool ok = !(C::XITEMS % 256 != 0 && RPI * i + xr0 >= C::TH + 2);
+    if constexpr (NAT) {
+      if (hp == 0 && ok) *reinterpret_cast<u32x4*>(p) = rx.v[i];
+    } else {
+      unsigned h, m, l;
+      split_pair(as_f(rx.v[i][2 * hp]), as_f(rx.v[i][2 * hp + 1]), h, m, l);
+      if (hp == 0) { xt[0] = h; xt[1] = m; xt[2] = l; }
+      else if (ok) {
+        *reinterpret_cast<u32x2*>(p) = u32x2{xt[0], h};
+        *reinterpret_cast<u32x2*>(p + C::PS) = u32x2{xt[1], m};
+        *reinterpret_cast<u32x2*>(p + 2 * C::PS) = u32x2{xt[2], l};
+      }
     }
   };
   auto store_piece = [&](const XRaw& rx, int i, unsigned* buf) {
@@ -206,31 +240,43 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const float* __restrict_
       }
     }
   };
-  // packed fragments: E[p][m][0..8] = pairs (v0,v1) .. (v16,v17); the odd-aligned pairs O (kx = 1) are one funnel shift
-  // per dword away and are formed when a k-block's MFMAs start (fp32), or are simply what was loaded (bf16)
-  struct AFrag { unsigned E[NP][MR][9], O[NAT ? 1 : 0 + 1][MR][8]; };
-  auto prep_pair = [&](const ARaw& a, int j, AFrag& f) {
+  // ---- A operands of one k-block q (8 columns per lane): from the ten values v[8q .. 8q+9] (v[0] = left halo,
+  // v[1..16] = the lane's columns, v[17] = right halo) the even pairs e[j] = (v[8q+2j], v[8q+2j+1]), j = 0..4; then
+  // kx = 2 reads e[0..3], kx = 0 reads c[0..3] = e[1..4] (a copy: MFMA operands are aligned register tuples), kx = 1
+  // reads o[j] = funnel shift of (e[j+1], e[j]) by 16 bits.  bf16 operands: the loaded dwords are the odd pairs, e is the shift.
+  struct AQ { unsigned e[NP][MR][5], c[NP][MR][4], o[NP][MR][4]; };
+  auto a_pair = [&](const ARaw& a, int q, int j, AQ& f) {
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
+      const int k = 8 * q + 2 * j;                       // v index of the pair's low half, 0 .. 16
       if constexpr (NAT) {
-        // the loaded dwords are the aligned pairs (v1,v2) ... (v15,v16) = O; E is the funnel shift
-        if (j < 8) f.O[0][m][j] = a.v[m][j >> 2][j & 3];
-        if (j == 0) f.E[0][m][0] = (a.hl[m] & 0xffffu) | (a.v[m][0][0] << 16);
-        else if (j < 8) f.E[0][m][j] = __builtin_amdgcn_alignbit(a.v[m][j >> 2][j & 3], a.v[m][(j - 1) >> 2][(j - 1) & 3], 16);
-        else f.E[0][m][8] = (a.v[m][1][3] >> 16) | (a.hr[m] << 16);
+        // raw dword i = (v[2i+1], v[2i+2]);  (v[k], v[k+1]) with k even = (raw[k/2 - 1].hi, raw[k/2].lo)
+        const int i = k / 2;
+        if (i == 0) f.e[0][m][j] = (a.hl[m] & 0xffffu) | (a.v[m][0][0] << 16);
+        else if (i == 8) f.e[0][m][j] = (a.v[m][1][3] >> 16) | (a.hr[m] << 16);
+        else f.e[0][m][j] = __builtin_amdgcn_alignbit(a.v[m][i >> 2][i & 3], a.v[m][(i - 1) >> 2][(i - 1) & 3], 16);
+        if (j < 4) f.o[0][m][j] = a.v[m][(4 * q + j) >> 2][(4 * q + j) & 3];
       } else {
-        const float lo = j == 0 ? as_f(a.hl[m]) : as_f(a.v[m][(2 * j - 1) >> 2][(2 * j - 1) & 3]);
-        const float hi = j == 8 ? as_f(a.hr[m]) : as_f(a.v[m][(2 * j) >> 2][(2 * j) & 3]);
-        split_pair(lo, hi, f.E[0][m][j], f.E[1][m][j], f.E[2][m][j]);
+        const float lo = k == 0 ? as_f(a.hl[m]) : as_f(a.v[m][(k - 1) >> 2][(k - 1) & 3]);
+        const float hi = k == 16 ? as_f(a.hr[m]) : as_f(a.v[m][k >> 2][k & 3]);
+        split_pair(lo, hi, f.e[0][m][j], f.e[1][m][j], f.e[2][m][j]);
       }
     }
   };
+  auto a_finish = [&](int p, AQ& f) {
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f.c[p][m][j] = f.e[p][m][j + 1];
+        if constexpr (!NAT) f.o[p][m][j] = __builtin_amdgcn_alignbit(f.e[p][m][j + 1], f.e[p][m][j], 16);
+      }
+  };
 
   // six products, smallest first: (lo,hi) (mid,mid) (hi,lo) (mid,hi) (hi,mid) (hi,hi)   [A plane, B plane]
-  constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
   constexpr int NTERM = NAT ? 1 : 6;
   constexpr int NS = 2 * NTB;                            // steps of a tile: (k-block q, B tile t)
-  constexpr int NM = NTERM * 3 * MR;                     // MFMAs of a step
+  constexpr int UH = NTB * NTERM;                        // work units (= groups of 3 MR MFMAs) per k-block half
 
   struct BFrag { bf16x8 v[NP]; };
   auto read_b = [&](const unsigned* buf, int step, BFrag& b) {
@@ -241,87 +287,92 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const float* __restrict_
       b.v[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bp + boff[t] + (size_t)p * C::PS * 4));
   };
 
-  // ---- pipeline.  One straight-line body per tile, no branches (a tile behind the last one loads zeros).  Tile n is
-  // multiplied out of (bufc, fc) in NS steps; between the MFMAs sits tile n+1's staging: its dY pairs are split and
-  // packed in the first steps (from registers loaded a whole tile earlier; step 0 sends out the dY loads of tile n+2),
-  // its patch is loaded in step 0 and split into the other LDS buffer in the last two steps.
+  // ---- pipeline.  One wave per SIMD issues everything in order, so the kernel is a hand-laid instruction stream: a tile
+  // is 2 NTB steps of NTERM groups of 3 MR MFMAs, and behind every group sits ONE item of the staging work, in this order:
+  //   first half  (MFMAs of k-block 0): the k-block-1 operands of THIS tile (5 pair splits, NP finishes), the dY loads
+  //                of tile n+2 into the registers that just became free, the first half of tile n+1's patch pieces
+  //                (split + LDS store into the other buffer), the loads of those pieces for tile n+2;
+  //   second half (MFMAs of k-block 1): the k-block-0 operands of tile n+1, the second half of tile n+1's patch, its reload.
+  // Every load has at least half a tile of MFMAs between issue and first use; no branches (a tile behind the last one
+  // loads zeros).
+  constexpr int NLO = NXI / 2;                           // patch pieces staged in the first half
+  constexpr int XH = NAT ? 1 : 2;                        // items per piece
+  constexpr int L0 = 5 + NP + 1 + XH * NLO + 1;          // items of the first half
+  constexpr int L1 = 5 + NP + XH * (NXI - NLO) + 1;      // items of the second half
   XRaw xa;
   ARaw ra, rb;
-  AFrag fa, fb;
+  AQ a0, a1;
   unsigned* buf0 = smem;
   unsigned* buf1 = smem + C::BUF;
   const int ntiles = split < total_tiles ? (total_tiles - split + splits - 1) / splits : 0;
-  load_x(split, xa);
+  load_x(split, xa, 0, NXI);
   load_a(split, ra);
 #pragma unroll
-  for (int i = 0; i < NXI; ++i) store_piece(xa, i, buf0);
+  for (int i = 0; i < NXI; ++i)
 #pragma unroll
-  for (int j = 0; j < 9; ++j) prep_pair(ra, j, fa);
-  load_a(split + splits, ra);
+    for (int hp = 0; hp < XH; ++hp) store_half(xa, i, hp, buf0);
+#pragma unroll
+  for (int j = 0; j < 5; ++j) a_pair(ra, 0, j, a0);
+#pragma unroll
+  for (int p = 0; p < NP; ++p) a_finish(p, a0);
+  load_x(split + splits, xa, 0, NXI);
+  load_a(split + splits, rb);
   __syncthreads();
 
-  constexpr int XS0 = NS - 2;                            // first step that stores patch pieces
-  constexpr int PS_N = NS - 2;                           // steps that prepare dY pairs
-  auto body = [&](const unsigned* bufc, const AFrag& fc, unsigned* bufn, AFrag& fn, const ARaw& ac, ARaw& an, int tile1,
-                  int tile2) {
+  auto body = [&](const unsigned* bufc, unsigned* bufn, ARaw& rc, const ARaw& rn, int tile2) {
+    // item `it` of half `h`
+    auto item = [&](auto h_, auto it_) {
+      constexpr int h = decltype(h_)::value, it = decltype(it_)::value;
+      if constexpr (h == 0) {
+        if constexpr (it < 5) a_pair(rc, 1, it, a1);
+        else if constexpr (it < 5 + NP) a_finish(it - 5, a1);
+        else if constexpr (it == 5 + NP) load_a(tile2, rc);
+        else if constexpr (it < L0 - 1) store_half(xa, (it - 6 - NP) / XH, (it - 6 - NP) % XH, bufn);
+        else load_x(tile2, xa, 0, NLO);
+      } else {
+        if constexpr (it < 5) a_pair(rn, 0, it, a0);
+        else if constexpr (it < 5 + NP) a_finish(it - 5, a0);
+        else if constexpr (it < L1 - 1) store_half(xa, NLO + (it - 5 - NP) / XH, (it - 5 - NP) % XH, bufn);
+        else load_x(tile2, xa, NLO, NXI);
+      }
+    };
     BFrag bq[2];
     read_b(bufc, 0, bq[0]);
-    unsigned O[NP][MR][4];                               // kx = 1 operand of the current k-block
-#pragma unroll
-    for (int st = 0; st < NS; ++st) {
-      const int q = st / NTB, t = st - q * NTB;
-      if (st + 1 < NS) read_b(bufc, st + 1, bq[(st + 1) & 1]);
-      if (st == 0) { load_x(tile1, xa); load_a(tile2, an); }
-      if (t == 0) {
-#pragma unroll
-        for (int p = 0; p < NP; ++p)
-#pragma unroll
-          for (int m = 0; m < MR; ++m)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              O[p][m][j] = NAT ? fc.O[0][m][4 * q + j]
-                               : __builtin_amdgcn_alignbit(fc.E[p][m][4 * q + j + 1], fc.E[p][m][4 * q + j], 16);
-      }
-      // this step's share of the next tile's staging
-#pragma unroll
-      for (int j = 0; j < 9; ++j)
-        if (st < PS_N && j % PS_N == st) prep_pair(ac, j, fn);
-#pragma unroll
-      for (int i = 0; i < NXI; ++i)
-        if (st >= XS0 && i % 2 == st - XS0) store_piece(xa, i, bufn);
+    static_for<0, NS>([&](auto st_) {
+      constexpr int st = decltype(st_)::value;
+      constexpr int q = st / NTB, t = st - q * NTB;
+      if constexpr (st + 1 < NS) read_b(bufc, st + 1, bq[(st + 1) & 1]);
       const BFrag& b = bq[st & 1];
-#pragma unroll
-      for (int term = 0; term < NTERM; ++term)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
+      static_for<0, NTERM>([&](auto term_) {
+        constexpr int term = decltype(term_)::value;
+        const AQ& f = q == 0 ? a0 : a1;
+        constexpr int pa = NAT ? 0 : TA_[term];
+        static_for<0, 3>([&](auto kx_) {
+          constexpr int kx = decltype(kx_)::value;
 #pragma unroll
           for (int m = 0; m < MR; ++m) {
-            const int pa = NAT ? 0 : TA[term];
-            u32x4 av;
-            if (kx == 1) av = u32x4{O[pa][m][0], O[pa][m][1], O[pa][m][2], O[pa][m][3]};
-            else {
-              const int e = 4 * q + (kx == 0 ? 1 : 0);
-              av = u32x4{fc.E[pa][m][e], fc.E[pa][m][e + 1], fc.E[pa][m][e + 2], fc.E[pa][m][e + 3]};
-            }
-            acc[m][t][kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), b.v[NAT ? 0 : TB[term]],
+            const unsigned* src = kx == 2 ? f.e[pa][m] : kx == 0 ? f.c[pa][m] : f.o[pa][m];
+            const u32x4 av = {src[0], src[1], src[2], src[3]};
+            acc[m][t][kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), b.v[NAT ? 0 : TB_[term]],
                                                                   acc[m][t][kx], 0, 0, 0);
           }
-      // schedule of the step: the next step's fragment reads first, then MFMAs with the staging work dealt between them
-      __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);
-#pragma unroll
-      for (int i = 0; i < NM; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, NAT ? 8 : 5, 0);
-        if (st == 0 && i < 6) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-        if (st >= XS0 && i % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-      }
-    }
+        });
+        // the items of this unit (normally one; the bf16 variant has fewer units than items)
+        constexpr int u = t * NTERM + term;              // unit inside the half
+        constexpr int L = q == 0 ? L0 : L1;
+        static_for<0, L>([&](auto it_) {
+          constexpr int it = decltype(it_)::value;
+          if constexpr ((L <= UH ? it : it * UH / L) == u) item(IC<q>{}, it_);
+        });
+      });
+    });
     __syncthreads();
   };
+  // two tiles per trip and no exit in the middle (with an exit between the bodies the accumulators get different registers
+  // on the two paths and 144 v_accvgpr_mov per trip): an odd tile count runs one all-zero tile
   for (int it = 0; it < ntiles; it += 2) {
-    body(buf0, fa, buf1, fb, ra, rb, split + (it + 1) * splits, split + (it + 2) * splits);
-    if (it + 1 >= ntiles) break;
-    body(buf1, fb, buf0, fa, rb, ra, split + (it + 2) * splits, split + (it + 3) * splits);
+    body(buf0, buf1, ra, rb, split + (it + 2) * splits);
+    body(buf1, buf0, rb, ra, split + (it + 3) * splits);
   }
 
   // ---- the four waves' accumulators meet in LDS (one region per wave, 16-byte stores, one barrier) and every thread sums
