@@ -43,6 +43,14 @@ __device__ __forceinline__ unsigned pk(bf16x2 v) { return __builtin_bit_cast(uns
 
 // compile-time loop: f(integral_constant<int, i>) for i in [B, E) -- the instruction stream below is laid out by index
 // arithmetic that must fold (a `#pragma unroll` the optimiser declines leaves register arrays indexed at run time = scratch)
+// timing ablations (tools/w3_ablate.sh builds variant libraries; results are WRONG with any bit set): 1 no patch split / LDS
+// store, 2 no dY operand preparation, 4 no global loads, 8 no MFMAs, 16 no LDS fragment reads, 32 no barrier -- all in the loop
+#ifndef W3_ABL
+#define W3_ABL 0
+#endif
+#ifndef W3_SGB
+#define W3_SGB 5
+#endif
 template <int I> struct IC { static constexpr int value = I; };
 template <int B, int E, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -52,22 +60,28 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-__device__ __forceinline__ u32x4 load_b128(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset) {
-  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, 0, 0));
+// voffset: per-lane, range-checked against num_records (an invalid lane passes an offset beyond it and reads zeros).
+// The scalar tile base is added to it on the VALU (32-bit, wraps): the hardware adds soffset zero-extended and
+// unchecked, so a base that is "negative" before the lane's row offset is added (row -1 of the first tile row, the
+// left halo of column 0) cannot travel in it.
+__device__ __forceinline__ u32x4 load_b128(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned soffset) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0));
 }
 // NEVER write __builtin_bit_cast(float, vec[i]): hipcc 7.2 miscompiles a bit_cast whose operand is a vector-element
 // lvalue -- it reads element 0 whatever i is (a 16-byte load then shrinks to one dword, replicated).  Passing the
 // element by value first is what works.
 __device__ __forceinline__ float as_f(unsigned u) { return __builtin_bit_cast(float, u); }
 
-// (a, b) -> packed bf16 pairs (low half = a) of the three pieces a = h + m + l
+// (a, b) -> packed bf16 pairs (low half = a) of the three pieces a = h + m + l: 11 VALU (v_cvt_pk_bf16_f32 rounds to
+// nearest even; a bf16 widens to fp32 by a shift / a mask of the packed dword)
+__device__ __forceinline__ unsigned cvt_pk(float a, float b) {
+  return pk(bf16x2{(__bf16)a, (__bf16)b});
+}
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
-  const bf16x2 hh = {(__bf16)a, (__bf16)b};
-  const float ra = a - (float)hh[0], rb = b - (float)hh[1];
-  const bf16x2 mm = {(__bf16)ra, (__bf16)rb};
-  const float sa = ra - (float)mm[0], sb = rb - (float)mm[1];
-  const bf16x2 ll = {(__bf16)sa, (__bf16)sb};
-  h = pk(hh); m = pk(mm); l = pk(ll);
+  h = cvt_pk(a, b);
+  const float ra = a - as_f(h << 16), rb = b - as_f(h & 0xffff0000u);
+  m = cvt_pk(ra, rb);
+  l = cvt_pk(ra - as_f(m << 16), rb - as_f(m & 0xffff0000u));
 }
 
 // six products, smallest first: (lo,hi) (mid,mid) (hi,lo) (mid,hi) (hi,mid) (hi,hi)   [A plane, B plane]
@@ -145,27 +159,38 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const float* __restrict_
   constexpr int PPR = C::PPR, NXI = C::NXI;
   constexpr int RPI = 256 / (PPR * C::CKC);              // patch rows covered by one piece index (256 threads)
   static_assert(RPI * PPR * C::CKC == 256, "a piece index must cover whole patch rows");
-  const int xc4 = tid % PPR, xch = (tid / PPR) % C::CKC, xr0 = tid / (PPR * C::CKC);
+  const int xc4 = tid % PPR, xch = (tid / PPR) % C::CKC, xr0 = RPI == 1 ? 0 : tid / (PPR * C::CKC);
   const int xcol = xc4 * (32 / PPR);
-  const bool xok = c0 + xch < d.Cin;
+  // per-thread constants: byte offset inside (image, tile) and the largest tile column base for which the piece is inside
+  // the image (-1: never -- channel beyond Cin)
   const unsigned xoff0 = ((unsigned)xch * HW + (unsigned)(xr0 * d.W + xcol)) * EB;
+  const int xlim = c0 + xch < d.Cin ? d.W - xcol : -1;
   const unsigned xlds0 = (unsigned)(xr0 * C::RS + xch * C::CS + (NAT ? 4 : 2) * xc4);
   struct XRaw { u32x4 v[NXI]; };
-  auto load_x = [&](int tile, XRaw& rx, int i0, int i1) {
+  // tile coordinates: decoded once per tile (scalar unit), shared by its three load groups
+  struct Tile { int n, th, tw; bool ok; };
+  auto decode = [&](int tile) {
+    Tile t;
     int tt = tile;
-    const int tw = tt % tiles_w; tt /= tiles_w;
-    const int th = tt % tiles_h; tt /= tiles_h;
-    const int n = tt;
+    t.tw = tt % tiles_w; tt /= tiles_w;
+    t.th = tt % tiles_h; tt /= tiles_h;
+    t.n = tt;
+    t.ok = tile < total_tiles;
+    return t;
+  };
+  auto load_x = [&](const Tile& t, XRaw& rx, int i0, int i1) {
     // (row -1 of the first tile row wraps below the image base: such pieces are invalid and never use it)
-    const unsigned base = ((unsigned)(n * d.in_ctot + d.in_coff + c0) * HW + (unsigned)((th * C::TH - 1) * d.W + tw * C::TW)) * EB;
-    const bool tv = (tile < total_tiles) & xok & (tw * C::TW + xcol < d.W);
+    const unsigned base = ((unsigned)(t.n * d.in_ctot + d.in_coff + c0) * HW + (unsigned)((t.th * C::TH - 1) * d.W + t.tw * C::TW)) * EB;
+    const int col0 = t.ok ? t.tw * C::TW : 0x7fffffff;
 #pragma unroll
     for (int i = 0; i < NXI; ++i) {
       if (i < i0 || i >= i1) continue;
       const int r = RPI * i + xr0;
-      const int ih = th * C::TH - 1 + r;
-      const bool v = tv & (r < C::TH + 2) & (ih >= 0) & (ih < d.H);
-      rx.v[i] = load_b128(xrsrc, v ? base + xoff0 + (unsigned)(RPI * i * d.W) * EB : OOB);
+      const int ih = t.th * C::TH - 1 + r;
+      bool v;
+      if constexpr (RPI == 1) v = (((unsigned)ih < (unsigned)d.H) ? col0 : 0x7fffffff) < xlim;      // row test on the scalar unit
+      else v = (col0 < xlim) & (r < C::TH + 2) & ((unsigned)ih < (unsigned)d.H);
+      rx.v[i] = load_b128(xrsrc, v ? base + (unsigned)(RPI * i * d.W) * EB + xoff0 : OOB, 0);
     }
   };
   // one half of a piece (fp32: a pair of columns -> one dword per plane, kept in `xt` until the piece's second half
@@ -207,36 +232,29 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const float* __restrict_
   constexpr int NAL = NAT ? 2 : 4;                       // aligned 16-byte loads of the 16 columns
   struct ARaw { u32x4 v[MR][NAL]; unsigned hl[MR], hr[MR]; };
   unsigned aoff[MR];
-  bool aok[MR];
+  int alim[MR];                                          // largest tile column base for which the lane's first 4 columns exist
 #pragma unroll
   for (int m = 0; m < MR; ++m) {
-    aok[m] = co0 + 32 * m + l31 < d.Cout;
     aoff[m] = ((unsigned)(32 * m + l31) * ohw + (unsigned)(wave * d.OW + 16 * half)) * EB;
+    alim[m] = co0 + 32 * m + l31 < d.Cout ? d.OW - 16 * half : -1;
   }
-  auto load_a = [&](int tile, ARaw& a) {
-    int tt = tile;
-    const int tw = tt % tiles_w; tt /= tiles_w;
-    const int th = tt % tiles_h; tt /= tiles_h;
-    const int n = tt;
-    const int oh = th * C::TH + wave, ow = tw * C::TW + half * 16;
-    const unsigned base = ((unsigned)(n * d.out_ctot + d.out_coff + co0) * ohw + (unsigned)(th * C::TH * d.OW + tw * C::TW)) * EB;
-    const bool rv = (tile < total_tiles) & (oh < d.OH);
+  auto load_a = [&](const Tile& t, ARaw& a) {
+    const int oh = t.th * C::TH + wave;
+    const unsigned base = ((unsigned)(t.n * d.out_ctot + d.out_coff + co0) * ohw + (unsigned)(t.th * C::TH * d.OW + t.tw * C::TW)) * EB;
+    const int col0 = (t.ok & (oh < d.OH)) ? t.tw * C::TW : 0x7fffffff;          // wave-uniform
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
-      const bool vm = rv & aok[m];
-      const unsigned b = base + aoff[m];
 #pragma unroll
-      for (int q = 0; q < NAL; ++q) {
-        const bool v = vm & (ow + (16 / NAL) * q < d.OW);
-        a.v[m][q] = load_b128(arsrc, v ? b + 16u * q : OOB);
-      }
-      const bool vl = vm & (ow >= 1) & (ow - 1 < d.OW), vr = vm & (ow + 16 < d.OW);
+      for (int q = 0; q < NAL; ++q)
+        a.v[m][q] = load_b128(arsrc, (col0 < alim[m] - (16 / NAL) * q) ? base + aoff[m] + 16u * q : OOB, 0);
+      // halos: column 16 half - 1 (not for the image's first column) and 16 half + 16
+      const bool vl = (col0 < alim[m] + 1) & !((col0 == 0) & (half == 0)), vr = col0 < alim[m] - 16;
       if constexpr (NAT) {
-        a.hl[m] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(arsrc, vl ? b - 2u : OOB, 0, 0);
-        a.hr[m] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(arsrc, vr ? b + 32u : OOB, 0, 0);
+        a.hl[m] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(arsrc, vl ? base + aoff[m] - 2u : OOB, 0, 0);
+        a.hr[m] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(arsrc, vr ? base + aoff[m] + 32u : OOB, 0, 0);
       } else {
-        a.hl[m] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(arsrc, vl ? b - 4u : OOB, 0, 0);
-        a.hr[m] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(arsrc, vr ? b + 64u : OOB, 0, 0);
+        a.hl[m] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(arsrc, vl ? base + aoff[m] - 4u : OOB, 0, 0);
+        a.hr[m] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(arsrc, vr ? base + aoff[m] + 64u : OOB, 0, 0);
       }
     }
   };
@@ -305,8 +323,11 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const float* __restrict_
   unsigned* buf0 = smem;
   unsigned* buf1 = smem + C::BUF;
   const int ntiles = split < total_tiles ? (total_tiles - split + splits - 1) / splits : 0;
-  load_x(split, xa, 0, NXI);
-  load_a(split, ra);
+  {
+    const Tile t0 = decode(split);
+    load_x(t0, xa, 0, NXI);
+    load_a(t0, ra);
+  }
 #pragma unroll
   for (int i = 0; i < NXI; ++i)
 #pragma unroll
@@ -315,25 +336,44 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const float* __restrict_
   for (int j = 0; j < 5; ++j) a_pair(ra, 0, j, a0);
 #pragma unroll
   for (int p = 0; p < NP; ++p) a_finish(p, a0);
-  load_x(split + splits, xa, 0, NXI);
-  load_a(split + splits, rb);
+  {
+    const Tile t1 = decode(split + splits);
+    load_x(t1, xa, 0, NXI);
+    load_a(t1, rb);
+  }
   __syncthreads();
 
-  auto body = [&](const unsigned* bufc, unsigned* bufn, ARaw& rc, const ARaw& rn, int tile2) {
+  // coordinates of the tile two ahead, advanced by `splits` tiles per body with carries (a division-free update on the
+  // scalar unit)
+  Tile tq = decode(split + 2 * splits);
+  const int adv_w = splits % tiles_w, adv_h = (splits / tiles_w) % tiles_h, adv_n = splits / tiles_w / tiles_h;
+  auto advance = [&](Tile& t) {
+    t.tw += adv_w;
+    const int cw = t.tw >= tiles_w;
+    t.tw -= cw ? tiles_w : 0;
+    t.th += adv_h + cw;
+    const int ch = t.th >= tiles_h;
+    t.th -= ch ? tiles_h : 0;
+    t.n += adv_n + ch;
+    t.ok = t.n < d.N;
+  };
+  auto body = [&](const unsigned* bufc, unsigned* bufn, ARaw& rc, const ARaw& rn) {
+    const Tile tile2 = tq;
+    advance(tq);
     // item `it` of half `h`
     auto item = [&](auto h_, auto it_) {
       constexpr int h = decltype(h_)::value, it = decltype(it_)::value;
       if constexpr (h == 0) {
-        if constexpr (it < 5) a_pair(rc, 1, it, a1);
-        else if constexpr (it < 5 + NP) a_finish(it - 5, a1);
-        else if constexpr (it == 5 + NP) load_a(tile2, rc);
-        else if constexpr (it < L0 - 1) store_half(xa, (it - 6 - NP) / XH, (it - 6 - NP) % XH, bufn);
-        else load_x(tile2, xa, 0, NLO);
+        if constexpr (it < 5) { if constexpr (!(W3_ABL & 2)) a_pair(rc, 1, it, a1); }
+        else if constexpr (it < 5 + NP) { if constexpr (!(W3_ABL & 2)) a_finish(it - 5, a1); }
+        else if constexpr (it == 5 + NP) { if constexpr (!(W3_ABL & 4)) load_a(tile2, rc); }
+        else if constexpr (it < L0 - 1) { if constexpr (!(W3_ABL & 1)) store_half(xa, (it - 6 - NP) / XH, (it - 6 - NP) % XH, bufn); }
+        else { if constexpr (!(W3_ABL & 4)) load_x(tile2, xa, 0, NLO); }
       } else {
-        if constexpr (it < 5) a_pair(rn, 0, it, a0);
-        else if constexpr (it < 5 + NP) a_finish(it - 5, a0);
-        else if constexpr (it < L1 - 1) store_half(xa, NLO + (it - 5 - NP) / XH, (it - 5 - NP) % XH, bufn);
-        else load_x(tile2, xa, NLO, NXI);
+        if constexpr (it < 5) { if constexpr (!(W3_ABL & 2)) a_pair(rn, 0, it, a0); }
+        else if constexpr (it < 5 + NP) { if constexpr (!(W3_ABL & 2)) a_finish(it - 5, a0); }
+        else if constexpr (it < L1 - 1) { if constexpr (!(W3_ABL & 1)) store_half(xa, NLO + (it - 5 - NP) / XH, (it - 5 - NP) % XH, bufn); }
+        else { if constexpr (!(W3_ABL & 4)) load_x(tile2, xa, NLO, NXI); }
       }
     };
     BFrag bq[2];
@@ -341,7 +381,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const float* __restrict_
     static_for<0, NS>([&](auto st_) {
       constexpr int st = decltype(st_)::value;
       constexpr int q = st / NTB, t = st - q * NTB;
-      if constexpr (st + 1 < NS) read_b(bufc, st + 1, bq[(st + 1) & 1]);
+      if constexpr (st + 1 < NS && !(W3_ABL & 16)) read_b(bufc, st + 1, bq[(st + 1) & 1]);
       const BFrag& b = bq[st & 1];
       static_for<0, NTERM>([&](auto term_) {
         constexpr int term = decltype(term_)::value;
@@ -353,8 +393,9 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const float* __restrict_
           for (int m = 0; m < MR; ++m) {
             const unsigned* src = kx == 2 ? f.e[pa][m] : kx == 0 ? f.c[pa][m] : f.o[pa][m];
             const u32x4 av = {src[0], src[1], src[2], src[3]};
-            acc[m][t][kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), b.v[NAT ? 0 : TB_[term]],
-                                                                  acc[m][t][kx], 0, 0, 0);
+            if constexpr (!(W3_ABL & 8))
+              acc[m][t][kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), b.v[NAT ? 0 : TB_[term]],
+                                                                    acc[m][t][kx], 0, 0, 0);
           }
         });
         // the items of this unit (normally one; the bf16 variant has fewer units than items)
@@ -364,15 +405,28 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const float* __restrict_
           constexpr int it = decltype(it_)::value;
           if constexpr ((L <= UH ? it : it * UH / L) == u) item(IC<q>{}, it_);
         });
+        // an MFMA occupies its pipe for 32 cycles = 8 issue slots: deal the item's instructions evenly behind the
+        // unit's MFMAs (three in a row followed by 15 VALU leave the pipe idle for half the time)
+#if W3_SGB
+#pragma unroll
+        for (int k = 0; k < 3 * MR; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, W3_SGB, 0);
+          __builtin_amdgcn_sched_group_barrier(0x320, 1, 0);
+        }
+        // nothing crosses a unit: the groups above would otherwise pull later items' instructions forward -- and with them
+        // the s_waitcnt on loads that were meant to have half a tile of MFMAs to land
+        __builtin_amdgcn_sched_barrier(0);
+#endif
       });
     });
-    __syncthreads();
+    if constexpr (!(W3_ABL & 32)) __syncthreads();
   };
   // two tiles per trip and no exit in the middle (with an exit between the bodies the accumulators get different registers
   // on the two paths and 144 v_accvgpr_mov per trip): an odd tile count runs one all-zero tile
   for (int it = 0; it < ntiles; it += 2) {
-    body(buf0, buf1, ra, rb, split + (it + 2) * splits);
-    body(buf1, buf0, rb, ra, split + (it + 3) * splits);
+    body(buf0, buf1, ra, rb);
+    body(buf1, buf0, rb, ra);
   }
 
   // ---- the four waves' accumulators meet in LDS (one region per wave, 16-byte stores, one barrier) and every thread sums
