@@ -68,11 +68,14 @@ class GradSync:
         the apply kernel, so a global batch split over replicas trains exactly like the same batch on
         one device (the reference is single-device).  Costs two small collectives per BN layer and
         step: a parity switch, off for throughput runs."""
+        from . import functional as Fh
         from . import ops
         if on and self.world > 1:
             ops.set_sync_bn(lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM), self.world)
+            Fh._ROUTE_WORLD[0] = self.world       # kernel routing by the global launch size: same kernels as one process
         else:
             ops.set_sync_bn(None, 1)
+            Fh._ROUTE_WORLD[0] = 1
 
     def set_tail(self, lo):
         """gradients [lo:] of the flat buffer are final when `reduce_tail_async` is called"""

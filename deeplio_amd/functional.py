@@ -338,6 +338,9 @@ class _CBR:
                                      out_ctot, out_coff, N, Cout, OHW, pre_relu, post_relu, residual, r_ctot,
                                      r_coff, gap, gap_ctot, gap_coff, r_aff=r_aff, fused=fused)
             return d, prm
+        if r_aff is not None:
+            raise RuntimeError("a residual that is stored before its BatchNorm + ReLU (apply-on-load) needs the plane-"
+                               "structured BatchNorm path (training with DLIO_PLANE_BN=1)")
         if training:
             prm = ops.bn_train_stats(raw, N, raw_ctot, raw_coff, Cout, OHW, pre_relu, gamma, eps,
                                      momentum, rmean, rvar, fused=fused)
@@ -454,6 +457,12 @@ def set_conv_bx3(on):
     _CONV_BX3[0] = bool(on)
 
 
+# Data-parallel PARITY runs (synchronised BatchNorm: a global batch split over ranks must train exactly like the same batch
+# in one process) route the 1x1 layers by the GLOBAL launch size, so that every world size picks the same kernels; throughput
+# runs (per-replica statistics) route by what each GPU actually launches.  Set by dist.GradSync.enable_sync_bn.
+_ROUTE_WORLD = [1]
+
+
 def _use_bx3(N, Cin, Cout, KH, KW, stride, OH, OW):
     """3x3 stride-1 convolutions go to the split-bf16 kernel (conv_bx3.hip: fp32-accurate products
     from six bf16 MFMAs, 1.3-1.6x the fp32-MFMA kernel on every PointSeg / FlowNet / ResNet shape,
@@ -468,7 +477,7 @@ def _use_bx3(N, Cin, Cout, KH, KW, stride, OH, OW):
     # store) -- the narrowing ones have a long K loop and few waves, the fp32 split-K kernel is faster there
     if (KH, KW) != (1, 1) or not _CONV_BX3_1X1[0] or (OH * OW) % 4 or Cin < _BX3_1X1_MIN[0] or Cout < _BX3_1X1_MIN[1]:
         return False
-    pix = N * OH * OW
+    pix = N * OH * OW * _ROUTE_WORLD[0]
     if pix >= _BX3_1X1_MIN[2]:
         return True
     # small layers: the widening ones, and on the smallest maps (blk5: <= 16 k pixels) the narrowing ones with >= 192

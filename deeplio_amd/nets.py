@@ -143,8 +143,9 @@ class Fire(nn.Module):
 
     def can_defer(self):
         """this block's activated output may stay unwritten (apply-on-load in the next Fire block): training,
-        no bypass / upsample on THIS block's output path"""
-        return self.training and not self.residual and getattr(self, "upsample", None) is None
+        no bypass / upsample on THIS block's output path -- and the plane-structured BatchNorm kernels in use: only
+        they take the residual's (mean, scale, beta) (with DLIO_PLANE_BN=0 the consumer would add the RAW tensor)"""
+        return (self.training and Fh._PLANE_BN[0] and not self.residual and getattr(self, "upsample", None) is None)
 
 
 class SELayer(nn.Module):

@@ -78,15 +78,24 @@ class FlatOptimizer:
         return float(ops.sumsq(self.grad).sqrt().item())
 
     def state_dict(self):
-        return {'step': self.step_count, 'state': {k: v for k, v in self._state().items()},
-                'param_groups': [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups]}
+        """the layout torch.optim.<same class>.state_dict() has ({'state': {i: {...}}, 'param_groups': [...]}): the
+        reference's Trainer saves this entry (trainer.py:161) and loads it back (trainer.py:108), so a checkpoint
+        written through the overlay resumes under the reference's own torch.optim optimizer and vice versa"""
+        from .checkpoint import optimizer_to_torch_state
+        return optimizer_to_torch_state(self)
 
     def load_state_dict(self, sd):
-        self.step_count = sd['step']
-        for k, v in sd['state'].items():
-            self._state()[k].copy_(v)
-        for g, s in zip(self.param_groups, sd['param_groups']):
-            g.update(s)
+        """torch.optim layout (what the reference writes), or the flat layout this class wrote before round 3
+        ({'step', 'state': {buffer name: flat tensor}, 'param_groups'})"""
+        if 'step' in sd and all(isinstance(k, str) for k in sd.get('state', {})):
+            self.step_count = int(sd['step'])
+            for k, v in sd['state'].items():
+                self._state()[k].copy_(v)
+            for g, s in zip(self.param_groups, sd['param_groups']):
+                g.update({k: v for k, v in s.items() if k != 'params'})
+            return
+        from .checkpoint import optimizer_from_torch_state
+        optimizer_from_torch_state(self, sd)
 
 
 class Adam(FlatOptimizer):

@@ -86,10 +86,21 @@ class TrainStep:
             gc.collect()
 
     def release_gc(self):
-        """give the interpreter's collector back (end of training)"""
-        if self._gc_armed and self.gc_mode == "manual":
-            gc.enable()
+        """give the interpreter's collector back (end of training): the objects frozen by the first step return to the
+        collector's generations (gc.freeze() is process-global -- an embedding program, e.g. the reference's Trainer
+        building several steps, must not keep them exempt for good)"""
+        if self._gc_armed:
+            gc.unfreeze()
+            if self.gc_mode == "manual":
+                gc.enable()
         self._gc_armed = False
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.release_gc()
+        return False
 
     def _tail(self, feats, gts_f2f, gts_f2g, hook=True):
         """features -> loss: the model's last layers, NaN/Inf flags, SE(3) chain, criterion"""

@@ -462,7 +462,9 @@ int dlio_bn_train_apply(const float* x, int N, int x_ctot, int x_coff, int C, in
 /* Train-mode BatchNorm (+ ReLU) backward behind a 3x3 / pad 1 / stride (SH, 2) max-pool (dlio_maxpool2d_fwd_aff): both
  * launches gather the gradient of the activated tensor from the pooled gradient dy_pool [N,C,OH,OW] and the arg-max map
  * while they stream x [N,C,H,W] -- the pool's own backward pass and its output are not needed.  dx contiguous;
- * ws as dlio_chan_stats_ws_bytes(N, C, H * W); DLIO_EUNSUP for other pool shapes / unaligned tensors. */
+ * ws as dlio_chan_stats_ws_bytes(N, C, H * W); DLIO_EUNSUP for other pool shapes / unaligned tensors.
+ * Per-replica statistics only: there is no phase / count_scale pair here, so a caller that synchronises BatchNorm
+ * statistics over ranks must take dlio_maxpool2d_bwd + dlio_bn_bwd (phases 1 / 2) instead. */
 int dlio_bn_bwd_pool(const float* dy_pool, const uint8_t* idx, const float* x, const float* mean,
                      const float* invstd, const float* scale, const float* beta, float* dx, float* dgamma,
                      float* dbeta, int accumulate, int N, int C, int H, int W, int OH, int OW, int SH, void* ws,

@@ -1040,3 +1040,36 @@ def test_conv_headline_launch_sizes_vs_fp64(dev, case):
     e_w2 = rel_err(dw2 - 1.0, wr.grad)
     print("%s: fwd %.1e dgrad %.1e wgrad %.1e (accumulated %.1e)" % (case, e_f, e_d, e_w, e_w2))
     assert e_f < TOL and e_d < TOL and e_w < TOL and e_w2 < TOL, (e_f, e_d, e_w, e_w2)
+
+
+@pytest.mark.parametrize("sh,H", [(1, 8), (2, 8), (2, 9), (1, 5)])
+def test_bn_bwd_pool_matches_pool_backward_then_bn_backward(dev, sh, H):
+    """dlio_bn_bwd_pool (BatchNorm + ReLU backward that gathers its gradient from the pooled gradient and the arg-max map
+    of the 3x3 / stride-(sh, 2) max-pool behind it) against the two-launch route it replaces -- dlio_maxpool2d_bwd, then
+    dlio_bn_bwd -- for both row strides the entry point dispatches (PSEncoder only uses sh = 1: pointseg_net.py:21)
+    and an odd height.  Per-replica statistics only: the entry point has no SyncBN phases (include/deeplio_hip.h)."""
+    from deeplio_amd import ops
+    N, C_, W = 3, 6, 64
+    g = _g(91)
+    raw = torch.randn(N, C_, H, W, generator=g).to(dev)
+    gamma = (1.0 + 0.2 * torch.randn(C_, generator=g)).to(dev)
+    beta = (0.2 * torch.randn(C_, generator=g)).to(dev)
+    rm, rv = torch.zeros(C_, device=dev), torch.ones(C_, device=dev)
+    act = torch.empty_like(raw)
+    prm = ops.bn_train_apply(raw, C_, 0, gamma, beta, 1e-5, 0.1, rm, rv, act, C_, 0, N, C_, H * W, False, True)
+    y, idx = ops.maxpool2d_fwd(act, 3, sh, 2, 1, 1)
+    assert ops.pool_fast_path(H, W, y.shape[2], y.shape[3], 3, sh, 2, 1, 1)
+    dyp = torch.randn(y.shape, generator=g).to(dev)
+    # reference route
+    dact = ops.maxpool2d_bwd(dyp, idx, raw.shape, 3, sh, 2, 1, 1)
+    dx_ref = torch.empty_like(raw)
+    dg_ref, db_ref = torch.empty(C_, device=dev), torch.empty(C_, device=dev)
+    ops.bn_bwd_fused(dact, C_, 0, raw, C_, 0, prm, beta, dx_ref, C_, 0, N, C_, H * W, False, True, True, dg_ref, db_ref)
+    # folded route, written over NaNs and accumulated onto ones
+    dx = torch.full_like(raw, float("nan"))
+    dg, db = torch.full((C_,), float("nan"), device=dev), torch.full((C_,), float("nan"), device=dev)
+    ops.bn_bwd_pool(dyp, idx, raw, prm, beta, dx, sh, dg, db)
+    assert rel_err(dx, dx_ref) < 1e-6 and rel_err(dg, dg_ref) < 1e-6 and rel_err(db, db_ref) < 1e-6
+    dg2, db2 = torch.ones(C_, device=dev), torch.ones(C_, device=dev)
+    ops.bn_bwd_pool(dyp, idx, raw, prm, beta, dx, sh, dg2, db2, accumulate=True)
+    assert rel_err(dg2 - 1.0, dg_ref) < 1e-5 and rel_err(db2 - 1.0, db_ref) < 1e-5

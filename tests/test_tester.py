@@ -103,6 +103,64 @@ def test_optimizer_state_is_torch_optim_layout(dev):
         assert float((a.detach().cpu() - b.detach()).abs().max()) < 1e-6
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["adam", "sgd", "rmsprop", "adadelta"])
+def test_overlay_optimizer_resumes_from_a_torch_optim_checkpoint(dev, tmp_path, kind):
+    """the reference's Trainer calls `self.optimizer.state_dict()` when it saves (trainer.py:161) and
+    `self.optimizer.load_state_dict(checkpoint['optimizer'])` when it resumes (trainer.py:108).  Through the overlay
+    that object is a FlatOptimizer: a checkpoint written by torch.optim (the reference alone) must load into it, what
+    it writes must load into torch.optim, and the legacy flat layout of earlier builds still loads."""
+    import types
+    from deeplio_amd.optimizer import create_optimizer
+    mk = {"adam": lambda ps: torch.optim.Adam(ps, lr=2e-3, weight_decay=1e-4),
+          "sgd": lambda ps: torch.optim.SGD(ps, lr=2e-3, weight_decay=1e-4, momentum=0.9),
+          "rmsprop": lambda ps: torch.optim.RMSprop(ps, lr=2e-3, weight_decay=1e-4),
+          "adadelta": lambda ps: torch.optim.Adadelta(ps, lr=2e-3, weight_decay=1e-4)}[kind]
+    ref = _mlp()
+    topt = mk([{'params': ref.parameters()}])
+    for _ in range(3):
+        topt.zero_grad()
+        ref(torch.ones(4, 5)).square().sum().backward()
+        topt.step()
+    path = str(tmp_path / "cpkt.tar")
+    torch.save({'state_dict': ref.state_dict(), 'optimizer': topt.state_dict()}, path)     # a reference-written file
+
+    mine = _mlp().to(dev)
+    args = types.SimpleNamespace(lr=2e-3, weight_decay=1e-4, momentum=0.9)
+    fopt = create_optimizer([{'params': mine.parameters()}], {'optimizer': kind}, args)
+    ck = torch.load(path, map_location=dev, weights_only=False)
+    mine.load_state_dict(ck['state_dict'])
+    fopt.load_state_dict(ck['optimizer'])                                                   # trainer.py:108
+    for opt, net, x in ((topt, ref, torch.ones(4, 5)), (fopt, mine, torch.ones(4, 5, device=dev))):
+        opt.zero_grad()
+        net(x).square().sum().backward()
+        opt.step()
+    for a, b in zip(mine.parameters(), ref.parameters()):
+        assert float((a.detach().cpu() - b.detach()).abs().max()) < 2e-6
+    # and back: what the overlay writes (trainer.py:161) resumes under torch.optim
+    sd = fopt.state_dict()
+    assert set(sd) == {'state', 'param_groups'} and all(isinstance(k, int) for k in sd['state'])
+    t2 = mk([{'params': _mlp().parameters()}])
+    t2.load_state_dict({'state': {i: {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in st.items()}
+                                  for i, st in sd['state'].items()}, 'param_groups': sd['param_groups']})
+    ref2 = t2.param_groups[0]['params']
+    with torch.no_grad():
+        for p, q in zip(ref2, ref.parameters()):
+            p.copy_(q)
+    for opt, ps in ((t2, ref2), (topt, list(ref.parameters()))):
+        opt.zero_grad()
+        for p in ps:
+            p.grad = torch.full_like(p, 0.25)
+        opt.step()
+    for a, b in zip(ref2, ref.parameters()):
+        assert float((a.detach() - b.detach()).abs().max()) < 2e-6
+    # the flat layout written before round 3
+    legacy = {'step': fopt.step_count, 'state': {k: v.clone() for k, v in fopt._state().items()},
+              'param_groups': [{'lr': 5e-4, 'weight_decay': 1e-4}]}
+    fopt.load_state_dict(legacy)
+    assert fopt.param_groups[0]['lr'] == 5e-4
+
+
 # ------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 def test_teststep_matches_eval_model_and_tester_quaternions(dev):
