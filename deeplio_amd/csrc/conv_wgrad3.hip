@@ -98,7 +98,7 @@ struct W3Cfg {
   static constexpr int PS = (TH + 2) * RS;               // plane stride
   static constexpr int BUF = NP * PS;                    // dwords of one patch buffer
   static constexpr int RED = MR * NTB * 3 * 16 * 64;     // accumulator exchange at the end
-  static constexpr int SM_DWORDS = 2 * BUF > 4 * RED ? 2 * BUF : 4 * RED;   // epilogue: one region per wave
+  static constexpr int SM_DWORDS = 2 * BUF > 2 * RED ? 2 * BUF : 2 * RED;   // epilogue: two accumulator regions
   static constexpr size_t LDS_BYTES = (size_t)SM_DWORDS * 4;
   static constexpr int PPR = NAT ? 4 : 8;                // 16-byte pieces per (row, channel): 4 fp32 / 8 bf16 columns each
   static constexpr int XITEMS = (TH + 2) * CKC * PPR;
@@ -429,22 +429,41 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const float* __restrict_
     body(buf1, buf0, rb, ra);
   }
 
-  // ---- the four waves' accumulators meet in LDS (one region per wave, 16-byte stores, one barrier) and every thread sums
-  // its output elements over the waves in a fixed order while it writes the slab
+  // ---- the four waves' accumulators meet in LDS: waves 2, 3 park theirs in two regions (16-byte stores), waves 0, 1 add
+  // them to their own and write the sums back, every thread then adds the two regions while it writes the slab --
+  // a fixed order ((w0 + w2) + (w1 + w3)), two barriers, and no more LDS than the pipeline's two patch buffers
   float* red = reinterpret_cast<float*>(smem);
   {
-    float* mine = red + wave * C::RED;
+    float* mine = red + (wave & 1) * C::RED;
+    auto slot = [&](int m, int t, int k, int r4) { return mine + ((((m * NTB + t) * 3 + k) * 4 + r4) * 64 + lane) * 4; };
+    if (wave >= 2) {
 #pragma unroll
-    for (int m = 0; m < MR; ++m)
+      for (int m = 0; m < MR; ++m)
 #pragma unroll
-      for (int t = 0; t < NTB; ++t)
+        for (int t = 0; t < NTB; ++t)
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
+          for (int k = 0; k < 3; ++k)
 #pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) {
-            const f32x4 v = {acc[m][t][k][4 * r4], acc[m][t][k][4 * r4 + 1], acc[m][t][k][4 * r4 + 2], acc[m][t][k][4 * r4 + 3]};
-            *reinterpret_cast<f32x4*>(mine + ((((m * NTB + t) * 3 + k) * 4 + r4) * 64 + lane) * 4) = v;
-          }
+            for (int r4 = 0; r4 < 4; ++r4)
+              *reinterpret_cast<f32x4*>(slot(m, t, k, r4)) =
+                  f32x4{acc[m][t][k][4 * r4], acc[m][t][k][4 * r4 + 1], acc[m][t][k][4 * r4 + 2], acc[m][t][k][4 * r4 + 3]};
+    }
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int t = 0; t < NTB; ++t)
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+              f32x4* p = reinterpret_cast<f32x4*>(slot(m, t, k, r4));
+              const f32x4 o = *p;
+              *p = f32x4{acc[m][t][k][4 * r4] + o[0], acc[m][t][k][4 * r4 + 1] + o[1], acc[m][t][k][4 * r4 + 2] + o[2],
+                         acc[m][t][k][4 * r4 + 3] + o[3]};
+            }
+    }
   }
   __syncthreads();
   const size_t row_len = (size_t)d.Cin * 9;
@@ -462,7 +481,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const float* __restrict_
     const int hf = (row >> 2) & 1, r = (row & 3) + 4 * (row >> 3);
     const int i = ((((m * NTB + t) * 3 + kx) * 4 + (r >> 2)) * 64 + hf * 32 + bl) * 4 + (r & 3);
     out[(size_t)(co0 + col) * row_len + (size_t)(c0 + ch) * 9 + tap] =
-        ((red[i] + red[C::RED + i]) + red[2 * C::RED + i]) + red[3 * C::RED + i];
+        red[i] + red[C::RED + i];
   }
 }
 
