@@ -95,6 +95,12 @@ MODEL_CASES = {
     "resnet_lstm_cat": dict(cfg=dict(lidar="lidar-feat-resnet", imu="imu-feat-rnn", fusion="fusion-layer-cat",
                                      odom="odom-feat-fc", seq=2, overrides=_ov(NO_DROP, SMALL_RNN)),
                             geom=dict(B=2, S=2, C=3, H=16, W=64, T=7)),
+    # PointSeg with bypass: "complex" (pointseg_modules.py:110-112,136-138: a 1x1 `upsample` residual where a Fire block
+    # changes the width, none where it keeps it) -- pins the oracle's complex branch to the reference's own numbers
+    "pointseg_complex_lstm_cat": dict(cfg=dict(lidar="lidar-feat-pointseg", imu="imu-feat-rnn", fusion="fusion-layer-cat",
+                                               odom="odom-feat-rnn", seq=2,
+                                               overrides=_ov(NO_DROP, SMALL_RNN, {'lidar-feat-pointseg/bypass': 'complex'})),
+                                      geom=dict(B=2, S=2, C=3, H=16, W=64, T=5)),
     # BASELINE config 5 shape (full DeepLIO, seq_len 4) at tiny geometry, fp32
     "pointseg_lstm_cat_s4": dict(cfg=dict(lidar="lidar-feat-pointseg", imu="imu-feat-rnn", fusion="fusion-layer-cat",
                                           odom="odom-feat-rnn", seq=4, overrides=_ov(NO_DROP, SMALL_RNN)),
