@@ -48,14 +48,9 @@ SIGNATURES = {
     "dlio_conv_bx3_prep": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "dlio_conv1x1_bx3_fwd": (_i, [_p, _p, _p, _p, _p, _cd, _p]),
     "dlio_conv1x1_bx3_fwd_aff": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _cd, _p]),
-    "dlio_conv_bx3_stats_slots": (_i, [_cd]),
-    "dlio_conv1x1_bx3_fwd_stats": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _cd, _p]),
-    "dlio_conv3x3_bx3_fwd_stats": (_i, [_p, _p, _p, _p, _p, _p, _cd, _p]),
     "dlio_conv3x5s2_bx3_fwd": (_i, [_p, _p, _p, _p, _p, _cd, _p]),
-    "dlio_conv3x3_bx3_fwd_aff": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _cd, _p]),
-    "dlio_chan_partials_reduce": (_i, [_p, _i, _i, _i, _i, _p, _sz, _p]),
     "dlio_conv1x1_bx3_ws_bytes": (_sz, [_cd]),
-    "dlio_conv1x1_bx3_fwd_ws": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _cd, _p]),
+    "dlio_conv1x1_bx3_fwd_ws": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _cd, _p]),
     "dlio_conv3x3_bx3_prep_floats": (_sz, [_i, _i, _i]),
     "dlio_conv3x3_bx3_prep": (_i, [_p, _p, _i, _i, _i, _p]),
     "dlio_conv3x3_bx3_prep_batched": (_i, [_p, _i, _i64, _p]),
@@ -97,7 +92,6 @@ SIGNATURES = {
     "dlio_ew_scale": (_i, [_p, _f, _p, _i64, _p]),
     "dlio_copy2d": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
     "dlio_dropout_fwd": (_i, [_p, _p, _p, _i64, _f, _u64, _u64, _p]),
-    "dlio_dropout_fwd_at": (_i, [_p, _p, _p, _i64, _f, _u64, _u64, _p, _p]),
     "dlio_dropout_bwd": (_i, [_p, _p, _p, _i64, _f, _p]),
     "dlio_nonfinite_flag": (_i, [_p, _i64, _p, _p]),
     "dlio_rnn_ws_bytes": (_sz, [_i, _i, _i]),

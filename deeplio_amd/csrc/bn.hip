@@ -713,41 +713,6 @@ extern "C" int dlio_bn_train_stats(const float* x, int N, int ctot, int coff, in
   return dlio_check_launch();
 }
 
-// The convolution kernels' per-workgroup statistics partials ([C][slots][2] floats: sum, sum of squares) summed
-// into the layout the phase-2 launches above read ([C][splits][2] doubles: the total in split 0, zeros behind it).
-// One workgroup per channel, fixed-order strided sums in double + tree.
-__global__ __launch_bounds__(256) void chan_partials_reduce_kernel(const float* __restrict__ st, int slots, int splits,
-                                                                   double* __restrict__ part) {
-  __shared__ double sm[2][256];
-  const int c = blockIdx.x, t = threadIdx.x;
-  const float2* p = reinterpret_cast<const float2*>(st) + (size_t)c * slots;
-  double a = 0.0, b = 0.0;
-  for (int i = t; i < slots; i += 256) {
-    const float2 v = p[i];
-    a += v.x; b += v.y;
-  }
-  sm[0][t] = a; sm[1][t] = b;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (t < o) { sm[0][t] += sm[0][t + o]; sm[1][t] += sm[1][t + o]; }
-    __syncthreads();
-  }
-  for (int i = t; i < splits * 2; i += 256)
-    part[(size_t)c * splits * 2 + i] = i < 2 ? sm[i][0] : 0.0;
-}
-
-extern "C" int dlio_chan_partials_reduce(const float* stats, int C, int slots, int N, int HW, void* ws,
-                                         size_t ws_bytes, dlio_stream_t stream) {
-  if (!stats || !ws || C <= 0 || slots <= 0 || N <= 0 || HW <= 0) return DLIO_EINVAL;
-  const int splits = pick_splits(N, C, HW);
-  if (ws_bytes < (size_t)C * splits * 2 * sizeof(double)) return DLIO_EWS;
-  hipStream_t s = as_stream(stream);
-  DlioProfScope prof(6, s, 0.0, 8.0 * C * (double)slots);
-  hipLaunchKernelGGL(chan_partials_reduce_kernel, dim3((unsigned)C), dim3(256), 0, s, stats, slots, splits,
-                     reinterpret_cast<double*>(ws));
-  return dlio_check_launch();
-}
-
 extern "C" int dlio_bn_bwd_pool(const float* dy_pool, const uint8_t* idx, const float* x, const float* mean,
                                 const float* invstd, const float* scale, const float* beta, float* dx,
                                 float* dgamma, float* dbeta, int accumulate, int N, int C, int H, int W, int OH,

@@ -103,19 +103,13 @@ __global__ void prep_bx3_batched_kernel(const DlioPrepItem* __restrict__ items, 
   }
 }
 
-// stats (optional): per-channel (sum, sum of squares) of what this workgroup stores, [Cout][slots][2] floats with
-// slot = the workgroup's (image, tile) index -- the train-mode BatchNorm behind the convolution takes its statistics
-// from these partials (dlio_chan_partials_reduce) instead of reading the output again.
 // KH x KW taps, row stride 1, column stride SW (3x3 / 1: Fire expand3x3 & co; 3x5 / 2: the PointSeg stem,
 // pointseg_net.py:18-20): output column c of a tile reads patch columns SW * c + kw.
-// AFF (apply-on-load): the stored input is the producer's RAW output; max(0, (x - mean[ci]) * scale[ci] + shift[ci]) (the
-// ReLU when d.in_relu) is formed when a chunk is split into LDS -- padding positions stay 0 (they pad the ACTIVATED tensor).
-template <int MR, int TWN, int KH = 3, int KW = 3, int SW = 1, bool AFF = false>
+template <int MR, int TWN, int KH = 3, int KW = 3, int SW = 1>
 __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
     const float* __restrict__ x, const __bf16* __restrict__ wt, const float* __restrict__ bias,
     const float* residual, float* y, DlioConvDesc d, int tiles_w, int tiles_h, int co_tiles, int patch_at,
-    float* __restrict__ stats, int vec_out, const float* __restrict__ in_mean, const float* __restrict__ in_scale,
-    const float* __restrict__ in_shift) {
+    int vec_out) {
   constexpr int TH = 4, TW = 32 * TWN, NT = KH * KW;
   constexpr int PR = TH + KH - 1, PC = SW * (TW - 1) + KW, NPOSP = PR * PC;
   constexpr int NPOS = (NPOSP + 255) / 256;              // patch positions per thread
@@ -166,21 +160,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
   // read (columns 2 * lane + kw) are 32 consecutive positions again -- conflict-free like the stride-1 layout
   constexpr int PCH = (PC + 1) / 2;
   auto store_chunk = [&](__bf16* buf, int kcs) {
-    if constexpr (AFF) {
-      const bool relu_in = d.in_relu != 0;
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const int ci = min(kcs * 16 + c, Cin - 1);                  // uniform: scalar loads
-        const float mu = in_mean[ci], sc = in_scale[ci], sh = in_shift[ci];
-        const bool cv = kcs * 16 + c < Cin;
-#pragma unroll
-        for (int j = 0; j < NPOS; ++j) {
-          float v = (reg[j][c] - mu) * sc + sh;
-          if (relu_in) v = fmaxf(v, 0.f);
-          reg[j][c] = (cv && pval[j]) ? v : 0.f;
-        }
-      }
-    }
 #pragma unroll
     for (int j = 0; j < NPOS; ++j) {
       int pos = tid + j * 256;
@@ -288,14 +267,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
   // ---- epilogue: D tile col = pixel (lane & 31), row = (r & 3) + 8 (r >> 2) + 4 half
   const int oh = oh0 + wave;
   const bool row_ok = oh < d.OH;
-  if (!row_ok && !stats) return;
+  if (!row_ok) return;
   const size_t ohw = (size_t)d.OH * d.OW;
   // Stores through LDS (vec_out): straight from the accumulators a store instruction writes two 128-byte pieces (32
   // pixels of channel c and of channel c + 4) as dwords; transposed through the wave's own LDS region ([channel][TW + 8
   // floats]: the patch buffers are free, and the row stride puts the two halves on different banks) a lane stores one
   // float4 and an instruction covers 4 / TWN channel rows of TW contiguous pixels -- a quarter of the store instructions,
   // 16-byte accesses, bias and residual applied on the way out.
-  if (vec_out && !stats) {
+  if (vec_out) {
     constexpr int TWP = TWN == 1 ? TW + 4 : TW + 8;      // (TW + 4: the 64-channel x 32-pixel tile has to fit its 39 KB of patch buffers)
     float* wbuf = reinterpret_cast<float*>(smem_raw) + wave * (32 * MR * TWP);
 #pragma unroll
@@ -325,16 +304,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
     }
     return;
   }
-  float* red = reinterpret_cast<float*>(smem_raw);        // statistics: [4 waves][32 * MR channels][2] (the patch buffers are free)
 #pragma unroll
-  for (int m = 0; m < MR; ++m) {
-    float ssum[16], ssq[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ssum[r] = ssq[r] = 0.f;
+  for (int m = 0; m < MR; ++m)
 #pragma unroll
     for (int t = 0; t < TWN; ++t) {
       const int ow = ow0 + 32 * t + l31;
-      if (ow >= d.OW || !row_ok) continue;
+      if (ow >= d.OW) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -344,35 +319,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
         const size_t pix = (size_t)oh * d.OW + ow;
         if (residual) v += residual[((size_t)n * d.res_ctot + d.res_coff + co) * ohw + pix];
         y[((size_t)n * d.out_ctot + d.out_coff + co) * ohw + pix] = v;
-        ssum[r] += v; ssq[r] += v * v;
       }
     }
-    if (stats) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float a = ssum[r], b = ssq[r];
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }   // the 32 pixels of a half
-        if (l31 == 0) {
-          const int cl = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;
-          red[(wave * 32 * MR + cl) * 2 + 0] = a;
-          red[(wave * 32 * MR + cl) * 2 + 1] = b;
-        }
-      }
-    }
-  }
-  if (stats) {
-    __syncthreads();
-    if (tid < 64 * MR) {
-      const int cl = tid >> 1, j = tid & 1, co = co0 + cl;
-      if (co < Cout) {
-        const float v = ((red[(0 * 32 * MR + cl) * 2 + j] + red[(1 * 32 * MR + cl) * 2 + j]) + red[(2 * 32 * MR + cl) * 2 + j]) +
-                        red[(3 * 32 * MR + cl) * 2 + j];
-        const int slots = d.N * tiles_h * tiles_w, slot = (n * tiles_h + th) * tiles_w + tw;
-        stats[((size_t)co * slots + slot) * 2 + j] = v;
-      }
-    }
-  }
 }
 
 // ---- 3x3 stride 1, weight fragments through LDS --------------------------------------------------
@@ -618,10 +566,8 @@ template <int MR, bool AFF>
 __global__ __launch_bounds__(256, 2) void conv1x1_bx3_kernel(
     const float* __restrict__ x, const __bf16* __restrict__ wt, const float* __restrict__ bias,
     const float* __restrict__ in_mean, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
-    const float* residual, float* y, DlioConvDesc d, int pix_blocks, int co_tiles, float* __restrict__ stats,
-    int ksplit, float* __restrict__ slab) {
+    const float* residual, float* y, DlioConvDesc d, int pix_blocks, int co_tiles, int ksplit, float* __restrict__ slab) {
   extern __shared__ __attribute__((aligned(16))) float aff_tab[];      // AFF: [KC * 16][4]
-  __shared__ float red[4 * 32 * MR * 2];                               // statistics partials of the four waves
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
   int bid = xcd_block_index();
   // K split over workgroups (slab != nullptr; narrowing layers on few pixels: a long channel loop and too few
@@ -644,7 +590,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bx3_kernel(
     __syncthreads();
   }
   const bool wave_ok = (pb * 4 + wave) * 128 < P;
-  if (!wave_ok && !stats) return;
+  if (!wave_ok) return;
   const bool pvalid = p < P;            // P % 4 == 0: a lane's four pixels are all in or all out
   const size_t pc = pvalid ? p : 0;
 
@@ -752,14 +698,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bx3_kernel(
     return;
   }
 
-  if (!pvalid && !stats) return;
+  if (!pvalid) return;
   const size_t plane = (size_t)P;
   float* yb = y + ((size_t)n * d.out_ctot + d.out_coff) * plane + pc;
   const float* rb = residual ? residual + ((size_t)n * d.res_ctot + d.res_coff) * plane + pc : nullptr;
 #pragma unroll
   for (int m = 0; m < MR; ++m) {
     float4 rv[16];
-    if (rb && pvalid) {
+    if (rb) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = min(co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, Cout - 1);
@@ -769,36 +715,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bx3_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      float a = 0.f, b = 0.f;
-      if (co < Cout && pvalid) {
+      if (co < Cout) {
         const float bv = bias ? bias[co] : 0.f;
         float4 o = make_float4(acc[m][0][r] + bv, acc[m][1][r] + bv, acc[m][2][r] + bv, acc[m][3][r] + bv);
         if (rb) { o.x += rv[r].x; o.y += rv[r].y; o.z += rv[r].z; o.w += rv[r].w; }
         *reinterpret_cast<float4*>(yb + (size_t)co * plane) = o;
-        a = (o.x + o.y) + (o.z + o.w);
-        b = (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
-      }
-      if (stats) {
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }   // the 128 pixels of the wave
-        if (l31 == 0) {
-          const int cl = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;
-          red[(wave * 32 * MR + cl) * 2 + 0] = a;
-          red[(wave * 32 * MR + cl) * 2 + 1] = b;
-        }
-      }
-    }
-  }
-  if (stats) {
-    __syncthreads();
-    const int tid = threadIdx.x;
-    if (tid < 64 * MR) {
-      const int cl = tid >> 1, j = tid & 1, co = co0 + cl;
-      if (co < Cout) {
-        const float v = ((red[(0 * 32 * MR + cl) * 2 + j] + red[(1 * 32 * MR + cl) * 2 + j]) + red[(2 * 32 * MR + cl) * 2 + j]) +
-                        red[(3 * 32 * MR + cl) * 2 + j];
-        const int slots = d.N * pix_blocks;
-        stats[((size_t)co * slots + (n * pix_blocks + pb)) * 2 + j] = v;
       }
     }
   }
@@ -854,13 +775,9 @@ int launch_bx3_alds(const float* x, const __bf16* wt, const float* bias, const f
   return dlio_check_launch();
 }
 
-template <int MR, int TWN, int KH = 3, int KW = 3, int SW = 1, bool AFF = false>
+template <int MR, int TWN, int KH = 3, int KW = 3, int SW = 1>
 int launch_bx3(const float* x, const __bf16* wt, const float* bias, const float* residual, float* y,
-               const DlioConvDesc& d, hipStream_t s, float* stats, const float* in_mean = nullptr,
-               const float* in_scale = nullptr, const float* in_shift = nullptr) {
-  if constexpr (!AFF && KH == 3 && KW == 3 && SW == 1) {
-    if (in_scale) return launch_bx3<MR, TWN, KH, KW, SW, true>(x, wt, bias, residual, y, d, s, stats, in_mean, in_scale, in_shift);
-  }
+               const DlioConvDesc& d, hipStream_t s) {
   constexpr int TH = 4, TW = 32 * TWN;
   const int tiles_w = cdiv(d.OW, TW), tiles_h = cdiv(d.OH, TH), co_tiles = cdiv(d.Cout, 32 * MR);
   const int64_t blocks = (int64_t)d.N * tiles_h * tiles_w * co_tiles;
@@ -869,7 +786,7 @@ int launch_bx3(const float* x, const __bf16* wt, const float* bias, const float*
   const size_t lds = (size_t)(d.Cin <= 16 ? 1 : 2) * 3 * (TH + KH - 1) * (SW * (TW - 1) + KW) * 16 * sizeof(__bf16);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bx3_kernel<MR, TWN, KH, KW, SW, AFF>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bx3_kernel<MR, TWN, KH, KW, SW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)((size_t)2 * 3 * (TH + KH - 1) * (SW * (TW - 1) + KW) * 16 * sizeof(__bf16)));
     attr_done = true;
@@ -886,8 +803,8 @@ int launch_bx3(const float* x, const __bf16* wt, const float* bias, const float*
   const int vec_out = vec_on && (d.OW & 3) == 0 && (((size_t)d.OH * d.OW) & 3) == 0 &&
                       ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0 &&
                       (size_t)4 * 32 * MR * (TWN == 1 ? TW + 4 : TW + 8) * sizeof(float) <= lds;
-  hipLaunchKernelGGL((conv3x3_bx3_kernel<MR, TWN, KH, KW, SW, AFF>), dim3((unsigned)blocks), dim3(256), lds, s, x, wt, bias, residual, y,
-                     d, tiles_w, tiles_h, co_tiles, patch_at, stats, vec_out, in_mean, in_scale, in_shift);
+  hipLaunchKernelGGL((conv3x3_bx3_kernel<MR, TWN, KH, KW, SW>), dim3((unsigned)blocks), dim3(256), lds, s, x, wt, bias, residual, y,
+                     d, tiles_w, tiles_h, co_tiles, patch_at, vec_out);
   return dlio_check_launch();
 }
 
@@ -917,7 +834,7 @@ extern "C" int dlio_conv3x3_bx3_prep(const float* w, void* wt, int Cout, int Cin
   return dlio_conv_bx3_prep(w, wt, Cout, Cin, 9, mode, stream);
 }
 
-// which tile shape a launch gets (shared by the launchers and dlio_conv_bx3_stats_slots)
+// which tile shape a launch gets
 static void bx3_1x1_shape(const DlioConvDesc& d, int& mr, int& pix_blocks) {
   static const int force_mr = getenv("DLIO_BX3_1X1_MR") ? atoi(getenv("DLIO_BX3_1X1_MR")) : 0;
   mr = force_mr ? force_mr : (d.Cout <= 32 ? 1 : 2);
@@ -942,22 +859,6 @@ static void bx3_3x3_shape(const DlioConvDesc& d, int& mr, int& twn) {
   if (blocks(mr, twn) < want && mr == 2) mr = 1;
   if (force_mr) mr = force_mr;
   if (force_twn) twn = force_twn;
-}
-
-extern "C" int dlio_conv_bx3_stats_slots(const DlioConvDesc* dp) {
-  if (!dp) return 0;
-  const DlioConvDesc& d = *dp;
-  if (d.KH == 1 && d.KW == 1) {
-    int mr, pb;
-    bx3_1x1_shape(d, mr, pb);
-    return d.N * pb;
-  }
-  if (d.KH == 3 && d.KW == 3) {
-    int mr, twn;
-    bx3_3x3_shape(d, mr, twn);
-    return d.N * cdiv(d.OH, 4) * cdiv(d.OW, 32 * twn);
-  }
-  return 0;
 }
 
 // K split over workgroups for narrowing layers on few pixels: how many slices (1 = none)
@@ -985,7 +886,7 @@ extern "C" size_t dlio_conv1x1_bx3_ws_bytes(const DlioConvDesc* dp) {
 
 extern "C" int dlio_conv1x1_bx3_fwd_ws(const float* x, const void* wt, const float* bias, const float* in_mean,
                                        const float* in_scale, const float* in_shift, const float* residual,
-                                       float* y, float* stats, void* ws, size_t ws_bytes, const DlioConvDesc* dp,
+                                       float* y, void* ws, size_t ws_bytes, const DlioConvDesc* dp,
                                        dlio_stream_t stream) {
   if (!x || !wt || !y || !dp) return DLIO_EINVAL;
   if (in_scale && (!in_mean || !in_shift)) return DLIO_EINVAL;
@@ -1007,13 +908,13 @@ extern "C" int dlio_conv1x1_bx3_fwd_ws(const float* x, const void* wt, const flo
   int mr, pix_blocks;
   bx3_1x1_shape(d, mr, pix_blocks);
   const int co_tiles = cdiv(d.Cout, 32 * mr);
-  int ksplit = stats ? 1 : bx3_1x1_ksplit(d);
+  int ksplit = bx3_1x1_ksplit(d);
   if (ksplit > 1 && (!ws || ws_bytes < (size_t)ksplit * d.N * d.Cout * P * sizeof(float))) ksplit = 1;
   float* slab = ksplit > 1 ? reinterpret_cast<float*>(ws) : nullptr;
   const int64_t blocks = (int64_t)d.N * pix_blocks * co_tiles * ksplit;
   const __bf16* w = reinterpret_cast<const __bf16*>(wt);
 #define BX1(MRV, AFFV) hipLaunchKernelGGL((conv1x1_bx3_kernel<MRV, AFFV>), dim3((unsigned)blocks), dim3(256), lds, s, x, w, bias, \
-                                          in_mean, in_scale, in_shift, residual, y, d, pix_blocks, co_tiles, stats, ksplit, slab)
+                                          in_mean, in_scale, in_shift, residual, y, d, pix_blocks, co_tiles, ksplit, slab)
   if (mr == 1) { if (in_scale) BX1(1, true); else BX1(1, false); }
   else { if (in_scale) BX1(2, true); else BX1(2, false); }
 #undef BX1
@@ -1028,21 +929,15 @@ extern "C" int dlio_conv1x1_bx3_fwd_ws(const float* x, const void* wt, const flo
   return rc;
 }
 
-extern "C" int dlio_conv1x1_bx3_fwd_stats(const float* x, const void* wt, const float* bias, const float* in_mean,
-                                          const float* in_scale, const float* in_shift, const float* residual,
-                                          float* y, float* stats, const DlioConvDesc* dp, dlio_stream_t stream) {
-  return dlio_conv1x1_bx3_fwd_ws(x, wt, bias, in_mean, in_scale, in_shift, residual, y, stats, nullptr, 0, dp, stream);
-}
-
 extern "C" int dlio_conv1x1_bx3_fwd_aff(const float* x, const void* wt, const float* bias, const float* in_mean,
                                         const float* in_scale, const float* in_shift, const float* residual,
                                         float* y, const DlioConvDesc* dp, dlio_stream_t stream) {
-  return dlio_conv1x1_bx3_fwd_stats(x, wt, bias, in_mean, in_scale, in_shift, residual, y, nullptr, dp, stream);
+  return dlio_conv1x1_bx3_fwd_ws(x, wt, bias, in_mean, in_scale, in_shift, residual, y, nullptr, 0, dp, stream);
 }
 
 extern "C" int dlio_conv1x1_bx3_fwd(const float* x, const void* wt, const float* bias, const float* residual,
                                     float* y, const DlioConvDesc* dp, dlio_stream_t stream) {
-  return dlio_conv1x1_bx3_fwd_stats(x, wt, bias, nullptr, nullptr, nullptr, residual, y, nullptr, dp, stream);
+  return dlio_conv1x1_bx3_fwd_ws(x, wt, bias, nullptr, nullptr, nullptr, residual, y, nullptr, 0, dp, stream);
 }
 
 extern "C" int dlio_conv3x3_bx3_prep_batched(const DlioPrepItem* items_dev, int n_items, int64_t total,
@@ -1053,11 +948,9 @@ extern "C" int dlio_conv3x3_bx3_prep_batched(const DlioPrepItem* items_dev, int 
   return dlio_check_launch();
 }
 
-extern "C" int dlio_conv3x3_bx3_fwd_aff(const float* x, const void* wt, const float* bias, const float* in_mean,
-                                        const float* in_scale, const float* in_shift, const float* residual,
-                                        float* y, float* stats, const DlioConvDesc* dp, dlio_stream_t stream) {
+extern "C" int dlio_conv3x3_bx3_fwd(const float* x, const void* wt, const float* bias, const float* residual,
+                                    float* y, const DlioConvDesc* dp, dlio_stream_t stream) {
   if (!x || !wt || !y || !dp) return DLIO_EINVAL;
-  if (in_scale && (!in_mean || !in_shift)) return DLIO_EINVAL;
   const DlioConvDesc& d = *dp;
   if (d.KH != 3 || d.KW != 3 || d.SH != 1 || d.SW != 1) return DLIO_EUNSUP;
   if (d.N <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.H <= 0 || d.W <= 0 || d.PH < 0 || d.PW < 0) return DLIO_EINVAL;
@@ -1071,29 +964,18 @@ extern "C" int dlio_conv3x3_bx3_fwd_aff(const float* x, const void* wt, const fl
   int mr, twn;
   bx3_3x3_shape(d, mr, twn);
   int rc;
-  // weight fragments through LDS (conv3x3_bx3_alds_kernel) for the plain layers; the variants with an input transform or
-  // a statistics epilogue stay on the global-fragment kernel
+  // weight fragments through LDS (conv3x3_bx3_alds_kernel)
   // (DLIO_BX3_ALDS: 0 off, 1 the 64-channel tiles only, 2 = default all tiles: 25.39 / 25.61 / 26.3 ms for 2 / 1 / 0)
   static const int alds = getenv("DLIO_BX3_ALDS") ? atoi(getenv("DLIO_BX3_ALDS")) : 2;
-  const bool use_alds = alds && !stats && !in_scale && (size_t)9 * ((d.Cin + 15) / 16) * 3 * d.Cout * 32 < 0x7fffffffull &&
+  const bool use_alds = alds && (size_t)9 * ((d.Cin + 15) / 16) * 3 * d.Cout * 32 < 0x7fffffffull &&
                         (alds == 2 || mr == 2);
 #define L3(MRV, TWV) (use_alds ? launch_bx3_alds<MRV, TWV>(x, w, bias, residual, y, d, s) \
-                               : launch_bx3<MRV, TWV>(x, w, bias, residual, y, d, s, stats, in_mean, in_scale, in_shift))
+                               : launch_bx3<MRV, TWV>(x, w, bias, residual, y, d, s))
   if (mr == 1) rc = twn == 2 ? L3(1, 2) : L3(1, 1);
   else rc = twn == 2 ? L3(2, 2) : L3(2, 1);
 #undef L3
   dlio_prof_end(3, s);
   return rc;
-}
-
-extern "C" int dlio_conv3x3_bx3_fwd_stats(const float* x, const void* wt, const float* bias, const float* residual,
-                                          float* y, float* stats, const DlioConvDesc* dp, dlio_stream_t stream) {
-  return dlio_conv3x3_bx3_fwd_aff(x, wt, bias, nullptr, nullptr, nullptr, residual, y, stats, dp, stream);
-}
-
-extern "C" int dlio_conv3x3_bx3_fwd(const float* x, const void* wt, const float* bias, const float* residual,
-                                    float* y, const DlioConvDesc* dp, dlio_stream_t stream) {
-  return dlio_conv3x3_bx3_fwd_aff(x, wt, bias, nullptr, nullptr, nullptr, residual, y, nullptr, dp, stream);
 }
 
 // 3x5 taps, stride (1, 2) (the PointSeg stem, pointseg_net.py:18-20: 2C -> 64 channels at 64 x 2048 -> 64 x 1024) on the
@@ -1112,8 +994,8 @@ extern "C" int dlio_conv3x5s2_bx3_fwd(const float* x, const void* wt, const floa
   const __bf16* w = reinterpret_cast<const __bf16*>(wt);
   static const int force_mr = getenv("DLIO_BX3_STEM_MR") ? atoi(getenv("DLIO_BX3_STEM_MR")) : 0;   // tuning knob
   const int mr = force_mr ? force_mr : (d.Cout <= 32 ? 1 : 2);
-  const int rc = mr == 1 ? launch_bx3<1, 1, 3, 5, 2>(x, w, bias, residual, y, d, s, nullptr)
-                         : launch_bx3<2, 1, 3, 5, 2>(x, w, bias, residual, y, d, s, nullptr);
+  const int rc = mr == 1 ? launch_bx3<1, 1, 3, 5, 2>(x, w, bias, residual, y, d, s)
+                         : launch_bx3<2, 1, 3, 5, 2>(x, w, bias, residual, y, d, s);
   dlio_prof_end(3, s);
   return rc;
 }

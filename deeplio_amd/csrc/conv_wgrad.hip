@@ -328,34 +328,6 @@ __device__ __forceinline__ float f4e(const float4& v, int i) {
 }
 
 // ---- stride-1 multi-tap weight gradient with the dY operand straight from global memory ----
-// Same GEMM and the same LDS patch for X' as conv_wgrad_kernel, but the A operand is not staged:
-// wave w owns output row oh0+w of the tile and lane (co = l&31, half = l>>5) reads the 16
-// consecutive pixels ow0 + 16*half .. +15 of its dY row as 4 float4 (one 128-B segment per
-// channel row and wave), which feed the 16 MFMA k-steps of the tile (k slot `half` of step e is
-// pixel 16*half + e for both operands).  Per tile this removes 16*MR LDS writes and 16*MR LDS
-// reads per lane and halves the LDS footprint (more resident workgroups); the next tile's dY
-// and X' are prefetched into registers while the current tile's MFMAs run.
-template <int KH, int KW, int NT, int MRW>
-struct WgACfg {
-  static constexpr int TH = 4, TW = 32;
-  static constexpr int MR = MRW, CO_T = 32 * MRW;
-  static constexpr int TAPS = KH * KW;
-  static constexpr int CKMAX = (NT * 32) / TAPS;
-  static constexpr int PR = TH - 1 + KH;
-  static constexpr int PC = TW - 1 + KW;
-  static constexpr int PRPC = PR * PC;
-  static constexpr int PLANE = PRPC | 1;
-  static constexpr int XL = CKMAX * PLANE;          // one pipeline stage (X' patch only)
-  static constexpr int RED = MR * NT * 16 * 64;
-  static constexpr int SM_FLOATS = 2 * XL > RED ? 2 * XL : RED;
-  static constexpr size_t LDS_BYTES = (size_t)SM_FLOATS * 4;
-  static constexpr int LPP = PRPC <= 128 ? 128 : 256;
-  static constexpr int CPAR = 256 / LPP;
-  static constexpr int NPOSX = (PRPC + LPP - 1) / LPP;
-  static constexpr int NCX = (CKMAX + CPAR - 1) / CPAR;
-};
-
-constexpr int PF_STEP = 2;     // MFMA step of a tile at which the next tile's global loads are issued
 
 typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -367,328 +339,6 @@ __device__ __forceinline__ void wg_split8(const float (&v)[8], wg_bf16x8& h, wg_
     const float r = v[j] - (float)hh;
     const __bf16 mm = (__bf16)r;
     h[j] = hh; m[j] = mm; l[j] = (__bf16)(r - (float)mm);
-  }
-}
-
-// BX3: the same GEMM on the bf16 matrix cores with fp32 accuracy -- each fp32 product formed from
-// six bf16 MFMAs over three-way operand splits (conv_bx3.hip).  K = 16 pixels per MFMA: k-block q
-// of a wave's 32 pixels is {16*half + 8q + j}, i.e. the float4 pairs (2q, 2q+1) of the dY
-// registers and 8 consecutive X' values in LDS, split in registers per use.
-// NAT (mixed-precision path, BASELINE configs[4]): x and dy are bf16 in memory (the pointers are
-// reinterpreted), the X' patch is widened to fp32 while it is staged (so the LDS layout and the
-// unaligned 8-value fragment reads stay as they are; narrowing back is exact), the dY fragments are
-// the two 16-byte loads of a lane's 16 pixels as they come, and each product is ONE bf16 MFMA.
-// AFF (apply-on-load): X is stored before its producer's BatchNorm + ReLU; x' = max(0, (x - mean[ci]) * scale[ci] + shift[ci])
-// (the ReLU when d.in_relu) is formed while the patch is stored to LDS, padding positions stay 0.
-template <int KH, int KW, int NT, int MRW, bool BX3 = false, bool NAT = false, bool AFF = false>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_adirect_kernel(
-    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ wsp,
-    DlioConvDesc d, int co_tiles, int ci_chunks, int splits, int tiles_w, int tiles_h,
-    const float* __restrict__ in_mean = nullptr, const float* __restrict__ in_scale = nullptr,
-    const float* __restrict__ in_shift = nullptr) {
-  using C = WgACfg<KH, KW, NT, MRW>;
-  constexpr unsigned EB = NAT ? 2u : 4u;          // bytes per element of x / dy
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int l31 = lane & 31;
-  const int half = lane >> 5;
-
-  int bid = xcd_block_index();           // XCD-aware: the pairs of one pixel split are neighbours (see conv_wgrad_kernel)
-  const int npairs = co_tiles * ci_chunks;
-  const int split = bid / npairs; bid -= split * npairs;
-  const int cic = bid % ci_chunks; bid /= ci_chunks;
-  const int co0 = bid * C::CO_T;
-  const int c0 = cic * C::CKMAX;
-  const int ck = min(C::CKMAX, d.Cin - c0);
-  const int nj = ck * C::TAPS;
-
-  int off[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int j = t * 32 + l31;
-    int o = 0;
-    if (j < nj) {
-      const int cl = j / C::TAPS;
-      const int tap = j - cl * C::TAPS;
-      const int ky = tap / KW, kx = tap - ky * KW;
-      o = cl * C::PLANE + ky * C::PC + kx;
-    }
-    off[t] = o;
-  }
-
-  f32x16 acc[C::MR][NT];
-#pragma unroll
-  for (int m = 0; m < C::MR; ++m)
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
-
-  const int total_tiles = d.N * tiles_h * tiles_w;
-  const size_t ohw = (size_t)d.OH * d.OW;
-  const size_t HW = (size_t)d.H * d.W;
-  const int xp = tid % C::LPP, xcph = tid / C::LPP;
-  int xr[C::NPOSX], xc[C::NPOSX];
-#pragma unroll
-  for (int j = 0; j < C::NPOSX; ++j) {
-    const int pos = xp + j * C::LPP;
-    xr[j] = pos / C::PC;
-    xc[j] = pos - xr[j] * C::PC;
-  }
-  bool va[C::MR];
-#pragma unroll
-  for (int m = 0; m < C::MR; ++m) va[m] = co0 + m * 32 + l31 < d.Cout;
-
-  // Unconditional buffer loads: an invalid element gets a voffset beyond num_records and the
-  // hardware returns 0 (no branches, so the compiler can count vmcnt and really overlap the
-  // prefetch with the MFMAs; conditional loads made it wait for every load individually).
-  constexpr unsigned OOB = 0xffffff00u;
-  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(x), 0, (int)((size_t)d.N * d.in_ctot * HW * EB), 0x00020000);
-  const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(dy), 0, (int)((size_t)d.N * d.out_ctot * ohw * EB), 0x00020000);
-  float rx[C::NCX][C::NPOSX];
-  bool xval[C::NPOSX];                       // AFF: which of this thread's positions of the tile in `rx` are inside the image
-  auto load_x = [&](int tile) {
-    int tt = tile;
-    const int tw = tt % tiles_w; tt /= tiles_w;
-    const int th = tt % tiles_h; tt /= tiles_h;
-    const int n = tt;
-    const int ih0 = th * C::TH - d.PH, iw0 = tw * C::TW - d.PW;
-    const unsigned img = (unsigned)(((size_t)n * d.in_ctot + d.in_coff + c0) * HW * EB);   // uniform
-    unsigned po[C::NPOSX];
-#pragma unroll
-    for (int j = 0; j < C::NPOSX; ++j) {
-      const int ih = ih0 + xr[j], iw = iw0 + xc[j];
-      const bool pv = (xp + j * C::LPP) < C::PRPC && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W;
-      po[j] = pv ? (unsigned)(ih * d.W + iw) * EB : OOB;
-      if constexpr (AFF) xval[j] = pv;
-    }
-#pragma unroll
-    for (int i = 0; i < C::NCX; ++i) {
-      const int c = xcph + C::CPAR * i;
-      const unsigned coff = c < ck ? (unsigned)c * (unsigned)HW * EB : OOB;
-#pragma unroll
-      for (int j = 0; j < C::NPOSX; ++j) {
-        const unsigned vo = (po[j] == OOB || coff == OOB) ? OOB : img + po[j] + coff;
-        if constexpr (NAT)
-          rx[i][j] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(xrsrc, vo, 0, 0) << 16);
-        else
-          rx[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, vo, 0, 0));
-      }
-    }
-  };
-  auto load_a = [&](int tile, float4 (&a)[C::MR][4]) {
-    int tt = tile;
-    const int tw = tt % tiles_w; tt /= tiles_w;
-    const int th = tt % tiles_h; tt /= tiles_h;
-    const int n = tt;
-    const int oh = th * C::TH + wave, ow = tw * C::TW + half * 16;
-    const unsigned img = (unsigned)(((size_t)n * d.out_ctot + d.out_coff + co0) * ohw * EB);   // uniform
-    const unsigned row = (unsigned)(((size_t)l31 * ohw + (size_t)oh * d.OW + ow) * EB);
-#pragma unroll
-    for (int m = 0; m < C::MR; ++m)
-#pragma unroll
-      for (int q = 0; q < (NAT ? 2 : 4); ++q) {          // NAT: 16 pixels = two 16-byte loads of 8 bf16
-        const bool v = va[m] && oh < d.OH && ow + (NAT ? 8 : 4) * q < d.OW;
-        const unsigned vo = v ? img + row + (unsigned)((size_t)m * 32 * ohw * EB) + 16u * q : OOB;
-        a[m][q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, vo, 0, 0));
-      }
-  };
-  auto store_x = [&](float* Xl) {
-#pragma unroll
-    for (int i = 0; i < C::NCX; ++i) {
-      // (one position lane group per workgroup: the channel is the loop index -- the AFF constants are scalar loads)
-      const int c = C::CPAR == 1 ? i : xcph + C::CPAR * i;
-      if (c < C::CKMAX) {
-        float mu = 0.f, sc = 0.f, sh = 0.f;
-        if constexpr (AFF) {
-          const int ci = min(c0 + c, d.Cin - 1);
-          mu = in_mean[ci]; sc = in_scale[ci]; sh = in_shift[ci];
-        }
-#pragma unroll
-        for (int j = 0; j < C::NPOSX; ++j) {
-          const int pos = xp + j * C::LPP;
-          if (pos < C::PRPC) {
-            float v = rx[i][j];
-            if constexpr (AFF) {
-              v = (v - mu) * sc + sh;
-              if (d.in_relu) v = fmaxf(v, 0.f);
-              if (!(xval[j] && c < ck)) v = 0.f;
-            }
-            Xl[c * C::PLANE + pos] = v;
-          }
-        }
-      }
-    }
-  };
-  auto mfma_tile = [&](const float* Xl, const float4 (&a)[C::MR][4], auto&& prefetch) {
-    const float* xrow = Xl + wave * C::PC + half * 16;
-    if constexpr (NAT) {
-      constexpr int NP = (NT + 1) / 2, STEPS = 2 * NP;
-      float bv[2][2][8];
-      auto load_b = [&](int st, float (&dst)[2][8]) {
-        const int q = st / NP, t0 = (st - q * NP) * 2;
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-          if (t0 + g < NT) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) dst[g][j] = xrow[off[t0 + g] + 8 * q + j];
-          }
-      };
-      load_b(0, bv[0]);
-#pragma unroll
-      for (int st = 0; st < STEPS; ++st) {
-        const int q = st / NP, t0 = (st - q * NP) * 2;
-        if (st + 1 < STEPS) load_b(st + 1, bv[(st + 1) & 1]);
-        if (st == 1) prefetch();
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-          if (t0 + g < NT) {
-            wg_bf16x8 bb;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) bb[j] = (__bf16)bv[st & 1][g][j];       // exact: the values came from bf16
-#pragma unroll
-            for (int m = 0; m < C::MR; ++m)
-              acc[m][t0 + g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wg_bf16x8, a[m][q]), bb,
-                                                                      acc[m][t0 + g], 0, 0, 0);
-          }
-      }
-      return;
-    }
-    if constexpr (BX3) {
-      // A fragments of both k-blocks, split once per tile
-      wg_bf16x8 ah[C::MR][2], am[C::MR][2], al[C::MR][2];
-#pragma unroll
-      for (int m = 0; m < C::MR; ++m)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const float v[8] = {a[m][2 * q].x, a[m][2 * q].y, a[m][2 * q].z, a[m][2 * q].w,
-                              a[m][2 * q + 1].x, a[m][2 * q + 1].y, a[m][2 * q + 1].z, a[m][2 * q + 1].w};
-          wg_split8(v, ah[m][q], am[m][q], al[m][q]);
-        }
-      // steps: (k-block q, pair of column tiles); B values of the next step are read from LDS while
-      // the MFMAs of this one run; two accumulators alternate inside a step
-      constexpr int NP = (NT + 1) / 2, STEPS = 2 * NP;
-      float bv[2][2][8];
-      auto load_b = [&](int st, float (&dst)[2][8]) {
-        const int q = st / NP, t0 = (st - q * NP) * 2;
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-          if (t0 + g < NT) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) dst[g][j] = xrow[off[t0 + g] + 8 * q + j];
-          }
-      };
-      load_b(0, bv[0]);
-#pragma unroll
-      for (int st = 0; st < STEPS; ++st) {
-        const int q = st / NP, t0 = (st - q * NP) * 2;
-        if (st + 1 < STEPS) load_b(st + 1, bv[(st + 1) & 1]);
-        if (st == 1) prefetch();
-        wg_bf16x8 bh[2], bm[2], bl[2];
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-          if (t0 + g < NT) wg_split8(bv[st & 1][g], bh[g], bm[g], bl[g]);
-        // six products, smallest first
-#pragma unroll
-        for (int term = 0; term < 6; ++term)
-#pragma unroll
-          for (int m = 0; m < C::MR; ++m)
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-              if (t0 + g < NT) {
-                const wg_bf16x8& av = term == 0 ? al[m][q] : (term == 1 || term == 3) ? am[m][q] : ah[m][q];
-                const wg_bf16x8& bw = (term == 0 || term == 3 || term == 5) ? bh[g] : (term == 1 || term == 4) ? bm[g] : bl[g];
-                acc[m][t0 + g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bw, acc[m][t0 + g], 0, 0, 0);
-              }
-      }
-      return;
-    }
-    float b[2][NT][2];
-    auto load_b = [&](int st, float (&bv)[NT][2]) {
-#pragma unroll
-      for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) bv[t][e] = xrow[off[t] + st * 2 + e];
-    };
-    load_b(0, b[0]);
-#pragma unroll
-    for (int st = 0; st < 8; ++st) {
-      if (st + 1 < 8) load_b(st + 1, b[(st + 1) & 1]);
-      if (st == PF_STEP) prefetch();
-#pragma unroll
-      for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int m = 0; m < C::MR; ++m)
-#pragma unroll
-          for (int t = 0; t < NT; ++t)
-            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a[m][(st * 2 + e) >> 2], (st * 2 + e) & 3),
-                                                             b[st & 1][t][e], acc[m][t], 0, 0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 2 * C::MR * NT, 0);
-    }
-  };
-
-  float4 a0[C::MR][4], a1[C::MR][4];
-  if (split < total_tiles) {
-    load_x(split);
-    load_a(split, a0);
-    store_x(smem);
-  }
-  __syncthreads();
-  int tile = split;
-  while (tile < total_tiles) {
-    {
-      const int nt_ = tile + splits;
-      const bool more = nt_ < total_tiles;
-      mfma_tile(smem, a0, [&]() { if (more) { load_x(nt_); load_a(nt_, a1); } });
-      if (more) store_x(smem + C::XL);
-      __syncthreads();
-      if (!more) break;
-      tile = nt_;
-    }
-    {
-      const int nt_ = tile + splits;
-      const bool more = nt_ < total_tiles;
-      mfma_tile(smem + C::XL, a1, [&]() { if (more) { load_x(nt_); load_a(nt_, a0); } });
-      if (more) store_x(smem);
-      __syncthreads();
-      if (!more) break;
-      tile = nt_;
-    }
-  }
-
-  float* red = smem;
-  for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
-#pragma unroll
-      for (int m = 0; m < C::MR; ++m)
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int i = ((m * NT + t) * 16 + r) * 64 + lane;
-            if (w == 0) red[i] = acc[m][t][r];
-            else red[i] += acc[m][t][r];
-          }
-    }
-    __syncthreads();
-  }
-  const size_t row_len = (size_t)d.Cin * C::TAPS;
-  float* out = wsp + (size_t)split * d.Cout * row_len;
-  for (int idx = tid; idx < C::CO_T * NT * 32; idx += 256) {
-    const int j = idx % (NT * 32);
-    const int col = idx / (NT * 32);
-    if (j >= nj || co0 + col >= d.Cout) continue;
-    const int m = col >> 5, row = col & 31;
-    const int hf = (row >> 2) & 1;
-    const int r = (row & 3) + 4 * (row >> 3);
-    const int t = j >> 5, lj = j & 31;
-    out[(size_t)(co0 + col) * row_len + (size_t)c0 * C::TAPS + j] =
-        red[((m * NT + t) * 16 + r) * 64 + hf * 32 + lj];
   }
 }
 
@@ -996,29 +646,6 @@ int launch_mr(const float* x, const float* dy, float* dw, const float* in_mean,
   constexpr bool CAN_VEC = SH == 1 && SW == 1 && ((KH == 1 && KW == 1) || (KH == 3 && KW == 3));
   const bool vec = CAN_VEC && (d.OW & 3) == 0 && (d.W & 3) == 0 &&
                    ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
-  if constexpr (KH == 3 && KW == 3 && SH == 1 && SW == 1 && MRW == 1) {
-    static const int adirect = getenv("DLIO_WGRAD_ADIRECT") ? atoi(getenv("DLIO_WGRAD_ADIRECT")) : 1;
-    const bool fits32 = (size_t)d.N * d.in_ctot * d.H * d.W * 4 < 0xffffff00ull &&
-                        (size_t)d.N * d.out_ctot * d.OH * d.OW * 4 < 0xffffff00ull;
-    if (adirect && vec && fits32) {
-      using A = WgACfg<KH, KW, NT, MRW>;
-      static const int bx3 = getenv("DLIO_WGRAD_BX3") ? atoi(getenv("DLIO_WGRAD_BX3")) : 1;   // split-bf16 MFMAs (fp32-accurate), 1.25x
-      auto ka = in_scale ? (bx3 ? conv_wgrad_adirect_kernel<KH, KW, NT, MRW, true, false, true>
-                                : conv_wgrad_adirect_kernel<KH, KW, NT, MRW, false, false, true>)
-                         : (bx3 ? conv_wgrad_adirect_kernel<KH, KW, NT, MRW, true> : conv_wgrad_adirect_kernel<KH, KW, NT, MRW, false>);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(ka), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)A::LDS_BYTES);
-      const int blocks = p.co_tiles * p.ci_chunks * p.splits;
-      hipLaunchKernelGGL(ka, dim3(blocks), dim3(256), A::LDS_BYTES, s, x, dy, wsp, d, p.co_tiles,
-                         p.ci_chunks, p.splits, p.tiles_w, p.tiles_h, in_mean, in_scale, in_shift);
-      int rc = dlio_check_launch();
-      if (rc) return rc;
-      const int64_t n = (int64_t)d.Cout * d.Cin * KH * KW;
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(n, 64)), dim3(256), 0, s, wsp, dw, n,
-                         p.splits, p.accumulate);
-      return dlio_check_launch();
-    }
-  }
   auto kern = (CAN_VEC && vec) ? conv_wgrad_kernel<KH, KW, SH, SW, NT, MRW, CAN_VEC>
                                : conv_wgrad_kernel<KH, KW, SH, SW, NT, MRW, false>;
   hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1159,29 +786,7 @@ extern "C" int dlio_conv2d_wgrad_bf16(const void* x, const void* dy, float* dw, 
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(n, 64)), dim3(256), 0, s, wsp, dw, n, p3.splits, accumulate);
     return dlio_check_launch();
   }
-  WgPlan p;
-  if (!make_plan(d, p)) return DLIO_EUNSUP;
-  if (ws_bytes < p.ws_bytes) return DLIO_EWS;
-  if (p.mr != 1) return DLIO_EUNSUP;
-  const int blocks = p.co_tiles * p.ci_chunks * p.splits;
-  if (p.nt == 4) {
-    using A = WgACfg<3, 3, 4, 1>;
-    auto ka = conv_wgrad_adirect_kernel<3, 3, 4, 1, false, true>;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, (int)A::LDS_BYTES);
-    hipLaunchKernelGGL(ka, dim3(blocks), dim3(256), A::LDS_BYTES, s, xf, df, wsp, d, p.co_tiles, p.ci_chunks, p.splits,
-                       p.tiles_w, p.tiles_h, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
-  } else {
-    using A = WgACfg<3, 3, 5, 1>;
-    auto ka = conv_wgrad_adirect_kernel<3, 3, 5, 1, false, true>;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, (int)A::LDS_BYTES);
-    hipLaunchKernelGGL(ka, dim3(blocks), dim3(256), A::LDS_BYTES, s, xf, df, wsp, d, p.co_tiles, p.ci_chunks, p.splits,
-                       p.tiles_w, p.tiles_h, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
-  }
-  int rc = dlio_check_launch();
-  if (rc) return rc;
-  const int64_t n = (int64_t)d.Cout * d.Cin * 9;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(n, 64)), dim3(256), 0, s, wsp, dw, n, p.splits, accumulate);
-  return dlio_check_launch();
+  return DLIO_EUNSUP;
 }
 
 extern "C" size_t dlio_conv2d_wgrad_ws_bytes(const DlioConvDesc* d) {

@@ -319,10 +319,9 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
 
 __global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                    uint8_t* __restrict__ mask, int64_t n, float p, uint64_t seed,
-                                   uint64_t offset, const uint64_t* __restrict__ offset_base) {
+                                   uint64_t offset) {
   const float inv = 1.0f / (1.0f - p);
   const int64_t groups = (n + 3) >> 2;
-  if (offset_base) offset += *offset_base;     // replayed launches (hipGraph): the counter lives on the device
   for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < groups;
        g += (int64_t)gridDim.x * blockDim.x) {
     const uint64_t ctr = offset + (uint64_t)g;
@@ -604,18 +603,12 @@ extern "C" int dlio_copy2d(const float* src, int lds, float* dst, int ldd, int r
   return dlio_check_launch();
 }
 
-extern "C" int dlio_dropout_fwd_at(const float* x, float* y, uint8_t* mask, int64_t n, float p,
-                                   uint64_t seed, uint64_t offset, const uint64_t* offset_base,
-                                   dlio_stream_t stream) {
-  if (!x || !y || !mask || n <= 0 || !(p >= 0.f && p < 1.f)) return DLIO_EINVAL;
-  hipLaunchKernelGGL(dropout_fwd_kernel, dim3(ew_grid((n + 3) / 4, 256)), dim3(256), 0,
-                     as_stream(stream), x, y, mask, n, p, seed, offset, offset_base);
-  return dlio_check_launch();
-}
-
 extern "C" int dlio_dropout_fwd(const float* x, float* y, uint8_t* mask, int64_t n, float p,
                                 uint64_t seed, uint64_t offset, dlio_stream_t stream) {
-  return dlio_dropout_fwd_at(x, y, mask, n, p, seed, offset, nullptr, stream);
+  if (!x || !y || !mask || n <= 0 || !(p >= 0.f && p < 1.f)) return DLIO_EINVAL;
+  hipLaunchKernelGGL(dropout_fwd_kernel, dim3(ew_grid((n + 3) / 4, 256)), dim3(256), 0,
+                     as_stream(stream), x, y, mask, n, p, seed, offset);
+  return dlio_check_launch();
 }
 
 extern "C" int dlio_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, int64_t n,

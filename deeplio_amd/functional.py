@@ -22,13 +22,6 @@ def _new(shape, like):
 
 _SINK = [True]
 _PLANE_BN = [os.environ.get("DLIO_PLANE_BN", "1") != "0"]
-# BatchNorm statistics from the split-bf16 convolutions' epilogue instead of a pass over their output.  Off: measured
-# SLOWER (27.07 vs 26.99 ms/step overlapped, 34.68 vs 34.36 serial) -- the statistics pass runs right behind the
-# convolution and reads its output from L2 / Infinity Cache (13 us average), the epilogue reductions (320 cross-lane
-# steps + a barrier per workgroup) cost the HBM-bound 1x1 kernels more than that
-_FUSED_STATS = [os.environ.get("DLIO_FUSED_BN_STATS", "0") != "0"]
-# Fire squeeze output activated on load by the expand convolutions / weight gradients instead of written
-_SQUEEZE_AOL = [os.environ.get("DLIO_SQUEEZE_AOL", "0") != "0"]
 # stem: pool1's backward folded into the stem's BatchNorm backward (ConvBnActPoolFn)
 _POOL_BN_BWD = [os.environ.get("DLIO_POOL_BN_BWD", "1") != "0"]
 
@@ -218,40 +211,6 @@ def _rnn_dir_stream(like):
     return aux_stream(like.device, "rnndir@%x" % ops.raw_stream())
 
 
-_EXPAND_FORK = [os.environ.get("DLIO_EXPAND_STREAM", "0") != "0"]
-
-
-class _ExpandFork:
-    """Fire forward: the expand1x1 branch (HBM-bound 1x1 convolution + its BatchNorm) on a companion stream beside the
-    expand3x3 branch (MFMA-bound) -- both only read the squeeze output and write disjoint channel slices.
-    `with _ExpandFork(like, *tensors) as f: f.run(lambda: ...)`; leaving the block joins the companion."""
-
-    def __init__(self, like, *tensors):
-        self.on = _EXPAND_FORK[0] and like.is_cuda and not torch.cuda.is_current_stream_capturing()
-        self.tensors = tensors
-        self.s = aux_stream(like.device, "expand@%x" % ops.raw_stream()) if self.on else None
-
-    def __enter__(self):
-        if self.on:
-            self.cur = current_stream_obj(self.s.device_index)
-            self.s.wait_stream(self.cur)
-        return self
-
-    def run(self, fn):
-        if not self.on:
-            return fn()
-        with on_stream(self.s):
-            return fn()
-
-    def __exit__(self, *exc):
-        if self.on:
-            self.cur.wait_stream(self.s)
-            for t in self.tensors:
-                if t is not None:
-                    t.record_stream(self.s)
-        return False
-
-
 def _forked(ws, fn, *tensors):
     """run fn() (a launch whose only output is a sunk gradient) on the companion stream ws"""
     ws.wait_stream(current_stream_obj(ws.device_index))
@@ -315,35 +274,31 @@ class _CBR:
                 if plan is not None:           # tap-subset layouts of the phase-decomposed data gradient
                     d.wt_ph = {(it[0], it[1]): ops.conv2d_prepped_phase(weight, d.SH, d.SW, it[0], it[1])
                                for it in plan if it is not None}
-        # train-mode statistics from the convolution's own epilogue (split-bf16 kernels): the raw output is not
-        # read a second time for them
-        fused = ops.conv_bx3_stats_buffer(d, x.device) if (bx3 and not stem and training and not pre_relu and _FUSED_STATS[0]) else None
-        st = fused[0] if fused is not None else None
         if stem:
             ops.conv3x5s2_bx3_fwd(x, wt, bias, raw, d)
         elif bx3 and KH == 1:
-            ops.conv1x1_bx3_fwd(x, wt, bias, raw, d, in_aff=in_aff, stats=st)
+            ops.conv1x1_bx3_fwd(x, wt, bias, raw, d, in_aff=in_aff)
         elif bx3:
-            ops.conv3x3_bx3_fwd(x, wt, bias, raw, d, stats=st, in_aff=in_aff)
+            ops.conv3x3_bx3_fwd(x, wt, bias, raw, d)
         else:
             ops.conv2d_fwd(x, wt, bias, raw, d, in_aff=in_aff)
         OHW = d.OH * d.OW
         if stats_into is not None:
             prm = ops.bn_train_stats(raw, N, raw_ctot, raw_coff, Cout, OHW, pre_relu, gamma, eps, momentum, rmean, rvar,
-                                     prm=stats_into, beta=beta, shift_out=shift_into, fused=fused)
+                                     prm=stats_into, beta=beta, shift_out=shift_into)
             return d, prm
         if training and _PLANE_BN[0]:
             # statistics + finalise + apply (+ the plane averages an SELayer wants) in 2 launches
             prm = ops.bn_train_apply(raw, raw_ctot, raw_coff, gamma, beta, eps, momentum, rmean, rvar, out,
                                      out_ctot, out_coff, N, Cout, OHW, pre_relu, post_relu, residual, r_ctot,
-                                     r_coff, gap, gap_ctot, gap_coff, r_aff=r_aff, fused=fused)
+                                     r_coff, gap, gap_ctot, gap_coff, r_aff=r_aff)
             return d, prm
         if r_aff is not None:
             raise RuntimeError("a residual that is stored before its BatchNorm + ReLU (apply-on-load) needs the plane-"
                                "structured BatchNorm path (training with DLIO_PLANE_BN=1)")
         if training:
             prm = ops.bn_train_stats(raw, N, raw_ctot, raw_coff, Cout, OHW, pre_relu, gamma, eps,
-                                     momentum, rmean, rvar, fused=fused)
+                                     momentum, rmean, rvar)
         else:
             prm = ops.bn_eval_params(rmean, rvar, gamma, eps)
         ops.bn_apply(raw, raw_ctot, raw_coff, prm, beta, out, out_ctot, out_coff, N, Cout, OHW,
@@ -651,38 +606,24 @@ class FireFn(Function):
         S_, E1, E3 = sw.shape[0], e1w.shape[0], e3w.shape[0]
         CE = E1 + E3
         raw_s = _new((N, S_, H, W), x)
-        # the squeeze output the same way (training): statistics only, both expand convolutions and their weight gradients
-        # activate it while they stage it -- its BatchNorm-apply launch and the activated copy go
-        sq_aol = bool(training and _SQUEEZE_AOL[0] and x.is_cuda)
-        if sq_aol:
-            act_s = _new((3, S_), x)          # (mean, scale, beta): travels in the slots of the activated tensor / its parameters
-            prm_s = _new((S_,), x)            # invstd
-            d_s, _ = _CBR.forward(x, Cin, 0, Cin, H, W, sw, sb, sg, sbe, srm, srv, (1, 1), (0, 0), training, momentum, eps,
-                                  False, True, raw_s, S_, 0, None, S_, 0, N, in_aff=x_aff,
-                                  stats_into=(act_s[0], prm_s, act_s[1]), shift_into=act_s[2])
-            s_in, s_aff = raw_s, (act_s[0], act_s[1], act_s[2])
-        else:
-            act_s = _new((N, S_, H, W), x)
-            d_s, prm_s = _CBR.forward(x, Cin, 0, Cin, H, W, sw, sb, sg, sbe, srm, srv, (1, 1), (0, 0),
-                                      training, momentum, eps, False, True, raw_s, S_, 0, act_s, S_, 0, N,
-                                      in_aff=x_aff)
-            s_in, s_aff = act_s, None
+        act_s = _new((N, S_, H, W), x)
+        d_s, prm_s = _CBR.forward(x, Cin, 0, Cin, H, W, sw, sb, sg, sbe, srm, srv, (1, 1), (0, 0),
+                                  training, momentum, eps, False, True, raw_s, S_, 0, act_s, S_, 0, N,
+                                  in_aff=x_aff)
         raw_e = _new((N, CE, H, W), x)
         res = x if bypass else None
         if defer:
             aff = _new((3, CE), x)
             inv1, inv3 = _new((E1,), x), _new((E3,), x)
-            with _ExpandFork(x, act_s, raw_e, aff, inv1) as fk:
-                d_1, _ = fk.run(lambda: _CBR.forward(
-                    s_in, S_, 0, S_, H, W, e1w, e1b, e1g, e1be, e1rm, e1rv, (1, 1), (0, 0), training,
-                    momentum, eps, False, True, raw_e, CE, 0, None, CE, 0, N, in_aff=s_aff,
-                    stats_into=(aff[0, :E1], inv1, aff[1, :E1]), shift_into=aff[2, :E1]))
-                d_3, _ = _CBR.forward(s_in, S_, 0, S_, H, W, e3w, e3b, e3g, e3be, e3rm, e3rv, (1, 1), (1, 1), training,
-                                  momentum, eps, False, True, raw_e, CE, E1, None, CE, E1, N, in_aff=s_aff,
+            d_1, _ = _CBR.forward(act_s, S_, 0, S_, H, W, e1w, e1b, e1g, e1be, e1rm, e1rv, (1, 1), (0, 0), training,
+                                  momentum, eps, False, True, raw_e, CE, 0, None, CE, 0, N,
+                                  stats_into=(aff[0, :E1], inv1, aff[1, :E1]), shift_into=aff[2, :E1])
+            d_3, _ = _CBR.forward(act_s, S_, 0, S_, H, W, e3w, e3b, e3g, e3be, e3rm, e3rv, (1, 1), (1, 1), training,
+                                  momentum, eps, False, True, raw_e, CE, E1, None, CE, E1, N,
                                   stats_into=(aff[0, E1:], inv3, aff[1, E1:]), shift_into=aff[2, E1:])
             ctx.save_for_backward(x, sw, sbe, e1w, e1be, e3w, e3be, raw_s, act_s, raw_e, prm_s, aff, inv1, inv3,
                                   sb, sg, e1b, e1g, e3b, e3g, x_aff)
-            ctx.cfg = (d_s, d_1, d_3, training, bypass, True, sq_aol)
+            ctx.cfg = (d_s, d_1, d_3, training, bypass, True)
             ctx.mark_non_differentiable(aff)
             return raw_e, aff
         out = _new((N, CE, H, W), x)
@@ -690,18 +631,15 @@ class FireFn(Function):
         # apply kernels in training, one extra pass otherwise
         fused_gap = want_gap and training and _PLANE_BN[0]
         gap = _new((N, CE), x) if fused_gap else None
-        with _ExpandFork(x, act_s, raw_e, out, gap, res, x_aff) as fk:
-            d_1, prm_1 = fk.run(lambda: _CBR.forward(
-                s_in, S_, 0, S_, H, W, e1w, e1b, e1g, e1be, e1rm, e1rv, (1, 1), (0, 0), training, momentum, eps, False, True,
-                raw_e, CE, 0, out, CE, 0, N, res, Cin, 0, gap, CE, 0, in_aff=s_aff, r_aff=x_aff if bypass else None))
-            d_3, prm_3 = _CBR.forward(s_in, S_, 0, S_, H, W, e3w, e3b, e3g, e3be, e3rm, e3rv, (1, 1),
-                                      (1, 1), training, momentum, eps, False, True, raw_e, CE, E1, out,
-                                      CE, E1, N, res, Cin, E1, gap, CE, E1, in_aff=s_aff, r_aff=x_aff if bypass else None)
-        if fk.on and torch.is_tensor(prm_1):
-            prm_1.record_stream(fk.cur)          # allocated under the companion stream, lives on the caller's
+        d_1, prm_1 = _CBR.forward(act_s, S_, 0, S_, H, W, e1w, e1b, e1g, e1be, e1rm, e1rv, (1, 1), (0, 0), training,
+                                  momentum, eps, False, True, raw_e, CE, 0, out, CE, 0, N, res, Cin, 0, gap, CE, 0,
+                                  r_aff=x_aff if bypass else None)
+        d_3, prm_3 = _CBR.forward(act_s, S_, 0, S_, H, W, e3w, e3b, e3g, e3be, e3rm, e3rv, (1, 1),
+                                  (1, 1), training, momentum, eps, False, True, raw_e, CE, E1, out,
+                                  CE, E1, N, res, Cin, E1, gap, CE, E1, r_aff=x_aff if bypass else None)
         ctx.save_for_backward(x, sw, sbe, e1w, e1be, e3w, e3be, raw_s, act_s, raw_e, prm_s, prm_1,
                               prm_3, sb, sg, e1b, e1g, e3b, e3g, x_aff)
-        ctx.cfg = (d_s, d_1, d_3, training, bypass, False, sq_aol)
+        ctx.cfg = (d_s, d_1, d_3, training, bypass, False)
         if not want_gap:
             return out
         if gap is None:
@@ -711,7 +649,7 @@ class FireFn(Function):
 
     @staticmethod
     def backward(ctx, dout, *_unused_dgap):
-        d_s, d_1, d_3, training, bypass, deferred, sq_aol = ctx.cfg
+        d_s, d_1, d_3, training, bypass, deferred = ctx.cfg
         if deferred:
             (x, sw, sbe, e1w, e1be, e3w, e3be, raw_s, act_s, raw_e, prm_s, aff, inv1, inv3, sb, sg, e1b, e1g,
              e3b, e3g, x_aff) = ctx.saved_tensors
@@ -725,18 +663,14 @@ class FireFn(Function):
         N, Cin, H, W = x.shape
         S_, E1, E3 = sw.shape[0], e1w.shape[0], e3w.shape[0]
         CE = E1 + E3
-        s_aff = None
-        if sq_aol:                # the slots hold (mean, scale, beta) and invstd; the expand weight gradients activate raw_s on load
-            aff_s, inv_s = act_s, prm_s
-            act_s, s_aff, prm_s = raw_s, (aff_s[0], aff_s[1], aff_s[2]), (aff_s[0], inv_s, aff_s[1])
         dact_s = _new((N, S_, H, W), x)
         draw1 = _new((N, E1, H, W), x)
         g1 = _CBR.backward(dout, CE, 0, act_s, d_1, e1w, e1b, e1g, prm_1, e1be, raw_e, training, False,
-                           True, draw1, True, dact_s, S_, 0, in_aff=s_aff)
+                           True, draw1, True, dact_s, S_, 0)
         del draw1
         draw3 = _new((N, E3, H, W), x)
         g3 = _CBR.backward(dout, CE, E1, act_s, d_3, e3w, e3b, e3g, prm_3, e3be, raw_e, training, False,
-                           True, draw3, True, dact_s, S_, 0, dx_accumulate=True, in_aff=s_aff)
+                           True, draw3, True, dact_s, S_, 0, dx_accumulate=True)
         del draw3
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty_like(x) if need_dx else None
@@ -980,7 +914,7 @@ class SegSumFn(Function):
         return ops.seg_sum_bwd(dy.contiguous(), *ctx.shape)
 
 
-_DROPOUT_STATE = {"seed": 0x5EED, "offset": 0, "base": None}
+_DROPOUT_STATE = {"seed": 0x5EED, "offset": 0}
 
 
 def manual_seed(seed):
@@ -994,35 +928,10 @@ def dropout_offset():
     return _DROPOUT_STATE["offset"]
 
 
-def advance_dropout(groups):
-    """skip `groups` counter values (a replayed hipGraph consumed them on the device)"""
-    _DROPOUT_STATE["offset"] += int(groups)
-
-
-class dropout_base:
-    """While active, dropout launches take their Philox offset as (local offset + *base) with `base` an int64
-    device scalar: recorded into a hipGraph they draw a new mask at every replay.  `consumed` = the counter
-    values one pass through the block uses; the caller writes the process-wide offset into `base` before a
-    replay and advances it by `consumed` afterwards (the masks are then the ones the eager step would draw)."""
-
-    def __init__(self, base):
-        self.base, self.consumed = base, 0
-
-    def __enter__(self):
-        self.saved = (_DROPOUT_STATE["offset"], _DROPOUT_STATE["base"])
-        _DROPOUT_STATE["offset"], _DROPOUT_STATE["base"] = 0, self.base
-        return self
-
-    def __exit__(self, *exc):
-        self.consumed = _DROPOUT_STATE["offset"]
-        _DROPOUT_STATE["offset"], _DROPOUT_STATE["base"] = self.saved
-        return False
-
-
 def _dropout_launch(x, p):
     off = _DROPOUT_STATE["offset"]
     _DROPOUT_STATE["offset"] = off + (x.numel() + 3) // 4
-    return ops.dropout_fwd(x, p, _DROPOUT_STATE["seed"], off, base=_DROPOUT_STATE["base"])
+    return ops.dropout_fwd(x, p, _DROPOUT_STATE["seed"], off)
 
 
 class DropoutFn(Function):

@@ -744,8 +744,7 @@ class DeepLIO(BaseNet):
         """The wide part of the step: IMU net and the two lidar encoders, on their own streams.
         -> dict(lidar=(fa, fb, (b, s)) | None, imu=feature | None, imu_stream=stream | None); with defer_imu
         the IMU feature is re-attached through DeferredBranchFn (its backward then runs where autograd
-        reaches it), else it is returned on its own tape and the caller runs its backward
-        (tail_graph.TailGraph)."""
+        reaches it), else it is returned on its own tape and the caller runs its backward."""
         lidar_imgs, imu_meas = x[0], x[1]
         enc = feat_i = None
         if self.training and getattr(self, "_bn_counters", None) is not None:

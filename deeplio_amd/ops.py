@@ -269,26 +269,22 @@ def conv1x1_bx3_prep(w, mode, out=None):
     return out
 
 
-def conv1x1_bx3_fwd(x, wt, bias, y, desc, residual=None, in_aff=None, stats=None):
-    """in_aff = (mean, scale, shift) per input channel or None (apply-on-load, see conv2d_fwd); stats: see
-    conv_bx3_stats_buffer"""
+def conv1x1_bx3_fwd(x, wt, bias, y, desc, residual=None, in_aff=None):
+    """in_aff = (mean, scale, shift) per input channel or None (apply-on-load, see conv2d_fwd)"""
     m = s = b = None
     if in_aff is not None:
         m, s, b = in_aff
-    nbytes = lib.dlio_conv1x1_bx3_ws_bytes(C.byref(desc)) if stats is None else 0
+    nbytes = lib.dlio_conv1x1_bx3_ws_bytes(C.byref(desc))
     ws = workspace(nbytes, x.device, slot=4) if nbytes else None       # K split over workgroups (narrowing small layers)
     check(lib.dlio_conv1x1_bx3_fwd_ws(_ptr(x), _ptr(wt), _ptr(bias), _ptr(m), _ptr(s), _ptr(b), _ptr(residual), _ptr(y),
-                                      _ptr(stats), _ptr(ws), ws.numel() if ws is not None else 0, C.byref(desc), _stream()),
+                                      _ptr(ws), ws.numel() if ws is not None else 0, C.byref(desc), _stream()),
           "conv1x1_bx3_fwd")
     return y
 
 
-def conv3x3_bx3_fwd(x, wt, bias, y, desc, residual=None, stats=None, in_aff=None):
-    m = s = b = None
-    if in_aff is not None:
-        m, s, b = in_aff
-    check(lib.dlio_conv3x3_bx3_fwd_aff(_ptr(x), _ptr(wt), _ptr(bias), _ptr(m), _ptr(s), _ptr(b), _ptr(residual), _ptr(y),
-                                       _ptr(stats), C.byref(desc), _stream()), "conv3x3_bx3_fwd")
+def conv3x3_bx3_fwd(x, wt, bias, y, desc, residual=None):
+    check(lib.dlio_conv3x3_bx3_fwd(_ptr(x), _ptr(wt), _ptr(bias), _ptr(residual), _ptr(y), C.byref(desc), _stream()),
+          "conv3x3_bx3_fwd")
     return y
 
 
@@ -297,22 +293,6 @@ def conv3x5s2_bx3_fwd(x, wt, bias, y, desc, residual=None):
     check(lib.dlio_conv3x5s2_bx3_fwd(_ptr(x), _ptr(wt), _ptr(bias), _ptr(residual), _ptr(y), C.byref(desc), _stream()),
           "conv3x5s2_bx3_fwd")
     return y
-
-
-def conv_bx3_stats_buffer(desc, device):
-    """-> (stats, slots): scratch for the per-workgroup BatchNorm statistics a split-bf16 convolution of this
-    shape writes when asked to (stats=...); consumed by bn_train_stats / bn_train_apply(fused=...) on the same stream"""
-    slots = lib.dlio_conv_bx3_stats_slots(C.byref(desc))
-    if slots <= 0:
-        raise ValueError("no split-bf16 kernel for this convolution")
-    buf = workspace(desc.Cout * slots * 8, device, slot=3)
-    return buf[:desc.Cout * slots * 8].view(torch.float32), slots
-
-
-def _partials_from_conv(fused, C_, N, HW, ws):
-    stats, slots = fused
-    check(lib.dlio_chan_partials_reduce(_ptr(stats), C_, slots, N, HW, _ptr(ws), ws.numel(), _stream()),
-          "chan_partials_reduce")
 
 
 def phase_interleave2d(phases, SH, SW, dx, dx_ctot, dx_coff, N, C_, H, W, residual=None, r_ctot=0, r_coff=0):
@@ -409,10 +389,9 @@ def bn_finalize(stats, count, gamma, eps, momentum, running_mean, running_var):
 
 
 def bn_train_stats(x, N, ctot, coff, C_, HW, pre_relu, gamma, eps, momentum, running_mean, running_var, prm=None,
-                   beta=None, shift_out=None, fused=None):
+                   beta=None, shift_out=None):
     """batch statistics + finalize (+ running-stat update) -> params [3][C]: mean, invstd, scale (prm: three
-    caller-provided [C] tensors to write them into).  fused = (stats, slots) from the producing convolution's
-    epilogue (conv_bx3_stats_buffer): x is not read."""
+    caller-provided [C] tensors to write them into)"""
     if prm is None:
         prm = torch.empty(3, C_, dtype=torch.float32, device=x.device)
     ws = _stats_ws(N, C_, HW, x.device)
@@ -423,12 +402,7 @@ def bn_train_stats(x, N, ctot, coff, C_, HW, pre_relu, gamma, eps, momentum, run
                                       _ptr(prm[1]), _ptr(prm[2]), _ptr(ws), ws.numel(), _ptr(beta), _ptr(shift_out),
                                       phase, float(scale), _stream()), "bn_train_stats")
     sync = _SYNC_BN[0]
-    if fused is not None:
-        _partials_from_conv(fused, C_, N, HW, ws)
-        if sync is not None:
-            sync[0](_partials_view(ws, N, C_, HW))
-        call(2, sync[1] if sync is not None else 1.0)
-    elif sync is None:
+    if sync is None:
         call(0, 1.0)
     else:                       # synchronised statistics: partials all-reduced between the two launches
         call(1, 1.0)
@@ -453,9 +427,9 @@ def _partials_view(ws, N, C_, HW):
 
 def bn_train_apply(x, x_ctot, x_coff, gamma, beta, eps, momentum, running_mean, running_var, y, y_ctot,
                    y_coff, N, C_, HW, pre_relu, post_relu, residual=None, r_ctot=0, r_coff=0,
-                   gap_out=None, gap_ctot=0, gap_coff=0, r_aff=None, fused=None):
+                   gap_out=None, gap_ctot=0, gap_coff=0, r_aff=None):
     """train-mode BN forward (statistics + apply) in two launches -> prm [3][C]; with SyncBN the
-    partial sums are all-reduced between the two launches; fused: as in bn_train_stats"""
+    partial sums are all-reduced between the two launches"""
     prm = torch.empty(3, C_, dtype=torch.float32, device=x.device)
     ws = _stats_ws(N, C_, HW, x.device)
 
@@ -470,12 +444,7 @@ def bn_train_apply(x, x_ctot, x_coff, gamma, beta, eps, momentum, running_mean, 
                                       _ptr(r_aff[2]) if r_aff is not None else None, _stream()),
               "bn_train_apply")
     sync = _SYNC_BN[0]
-    if fused is not None:
-        _partials_from_conv(fused, C_, N, HW, ws)
-        if sync is not None:
-            sync[0](_partials_view(ws, N, C_, HW))
-        call(2, sync[1] if sync is not None else 1.0)
-    elif sync is None:
+    if sync is None:
         call(0, 1.0)
     else:
         call(1, 1.0)
@@ -731,14 +700,11 @@ def copy2d(src, lds, dst, ldd, rows, cols, accumulate=False, src_off=0, dst_off=
     return dst
 
 
-def dropout_fwd(x, p, seed, offset, base=None):
-    """base: int64 device scalar added to the Philox offset on the device (replayed launches)"""
+def dropout_fwd(x, p, seed, offset):
     y = torch.empty_like(x)
     mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
-    if base is not None and (base.dtype != torch.int64 or base.device != x.device):
-        raise ValueError("dropout offset base must be an int64 tensor on the input's device")
-    check(lib.dlio_dropout_fwd_at(_ptr(x), _ptr(y), _ptr(mask), x.numel(), float(p), int(seed),
-                                  int(offset), _ptr(base), _stream()), "dropout_fwd")
+    check(lib.dlio_dropout_fwd(_ptr(x), _ptr(y), _ptr(mask), x.numel(), float(p), int(seed), int(offset), _stream()),
+          "dropout_fwd")
     return y, mask
 
 

@@ -15,7 +15,6 @@ from .misc import build_config_container
 from .nets import get_model
 from .optimizer import create_optimizer
 from .se3 import se3_to_SE3
-from .tail_graph import TailGraph
 
 
 class TrainStep:
@@ -43,14 +42,6 @@ class TrainStep:
         self.gc_every = int(os.environ.get("DLIO_GC_EVERY", "100"))
         self._gc_armed = False
         self._steps = 0
-        # DLIO_TAIL_GRAPH=1: from step `tail_after`+1 on the serial middle of the step (everything between the
-        # encoders' last layer and their first backward kernel) is one hipGraph launch.  Off by default: without a
-        # profiler attached the host is ~4.5 ms ahead of the GPU when it reaches that part, the ~230 launches
-        # take 1.27 ms of GPU time eager and 1.42 ms replayed (a graph node costs >= 4.5 us); it pays when the
-        # host is the slower side (under rocprofv3: 34.8 -> 31.0 ms/step), tools/step_sections.py
-        self.tail_mode = os.environ.get("DLIO_TAIL_GRAPH", "0") != "0"
-        self.tail_after = int(os.environ.get("DLIO_TAIL_GRAPH_AFTER", "2"))     # eager warm-up steps: workspaces, caches
-        self._tails = {}
         self.model.train()
         if grad_sync is not None:
             self.set_grad_sync(grad_sync)
@@ -122,8 +113,6 @@ class TrainStep:
     def step(self, imgs, normals, imus, gts_f2f, gts_f2g):
         self._steps += 1
         self._manage_gc()
-        if self.tail_mode and imgs.is_cuda and self.model.training and self._steps > self.tail_after:
-            return self._step_tail_graph(imgs, normals, imus, gts_f2f, gts_f2g)
         loss = self._tail(self.model.forward_features([[imgs, normals], imus]), gts_f2f, gts_f2g)
         self.optimizer.zero_grad()
         loss.backward()
@@ -131,39 +120,6 @@ class TrainStep:
             self.grad_sync.all_reduce_grads()
         self.optimizer.step()
         return loss.detach()
-
-    def _step_tail_graph(self, imgs, normals, imus, gts_f2f, gts_f2g):
-        """the same step with its serial middle replayed as one hipGraph (tail_graph.py)"""
-        self.optimizer.zero_grad()          # the recorded tail accumulates into the flat gradient buffer
-        feats = self.model.forward_features([[imgs, normals], imus], defer_imu=False)
-        sig = TailGraph.signature_of(feats, gts_f2f, gts_f2g)
-        tg = self._tails.get(sig)
-        if tg is None:
-            if len(self._tails) >= 4:       # ragged last batches etc.: a few shapes, not a leak
-                self._tails.pop(next(iter(self._tails)))
-            tg = self._tails[sig] = TailGraph(self).capture(feats, gts_f2f, gts_f2g)
-        loss, (d_fa, d_fb, d_fi) = tg.replay(feats, gts_f2f, gts_f2g)
-        if self.model.tail_grads_ready is not None:
-            self.model.tail_grads_ready()
-        # The branches' own tapes, eager and multi-stream.  The IMU net first: its latency-bound backward then
-        # runs beside the whole encoder backward, and the host issues it while the GPU replays the tail.
-        fi, side = feats["imu"], feats["imu_stream"]
-        if d_fi is not None:
-            if side is not None:
-                side.wait_stream(torch.cuda.current_stream())
-                with Fh.on_stream(side):
-                    torch.autograd.backward([fi], [d_fi])
-            else:
-                torch.autograd.backward([fi], [d_fi])
-        if feats["lidar"] is not None:
-            roots = [(f, g) for f, g in zip(feats["lidar"][:2], (d_fa, d_fb)) if g is not None]
-            if roots:
-                torch.autograd.backward([r[0] for r in roots], [r[1] for r in roots])
-        Fh.join_aux_streams()
-        if self.grad_sync is not None:
-            self.grad_sync.all_reduce_grads()
-        self.optimizer.step()
-        return loss.clone()
 
     def check(self):
         """raise like trainer.py:240-243 / :341-348 if any step since the last check went bad"""

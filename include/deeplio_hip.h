@@ -143,36 +143,18 @@ int dlio_conv1x1_bx3_fwd(const float* x, const void* wt, const float* bias, cons
 int dlio_conv1x1_bx3_fwd_aff(const float* x, const void* wt, const float* bias, const float* in_mean,
                              const float* in_scale, const float* in_shift, const float* residual,
                              float* y, const DlioConvDesc* desc, dlio_stream_t stream);
-/* Statistics of the train-mode BatchNorm behind a split-bf16 convolution taken in the convolution's epilogue
- * (the output is not read again): with stats != NULL every workgroup also writes the per-channel (sum, sum of
- * squares) of what it stored to stats[Cout][slots][2] floats, slots = dlio_conv_bx3_stats_slots(desc).
- * dlio_chan_partials_reduce sums them (fixed order, double) into the workspace layout of the phase-2 calls of
- * dlio_bn_train_stats / dlio_bn_train_apply (N, HW as passed there; ws_bytes >= dlio_chan_stats_ws_bytes). */
-int dlio_conv_bx3_stats_slots(const DlioConvDesc* desc);
-int dlio_conv1x1_bx3_fwd_stats(const float* x, const void* wt, const float* bias, const float* in_mean,
-                               const float* in_scale, const float* in_shift, const float* residual,
-                               float* y, float* stats, const DlioConvDesc* desc, dlio_stream_t stream);
-int dlio_conv3x3_bx3_fwd_stats(const float* x, const void* wt, const float* bias, const float* residual,
-                               float* y, float* stats, const DlioConvDesc* desc, dlio_stream_t stream);
-/* dlio_conv3x3_bx3_fwd_stats with the apply-on-load transform of dlio_conv2d_fwd on the input (in_scale NULL = none):
- * the stored input is the producer's raw output; padding positions stay 0 (they pad the ACTIVATED tensor) */
-int dlio_conv3x3_bx3_fwd_aff(const float* x, const void* wt, const float* bias, const float* in_mean,
-                             const float* in_scale, const float* in_shift, const float* residual,
-                             float* y, float* stats, const DlioConvDesc* desc, dlio_stream_t stream);
 /* the split-bf16 kernel with 3x5 taps and stride (1, 2): the PointSeg stem (pointseg_net.py:18-20), forward only;
  * weights from dlio_conv_bx3_prep(taps = 15, mode 0) */
 int dlio_conv3x5s2_bx3_fwd(const float* x, const void* wt, const float* bias, const float* residual, float* y,
                            const DlioConvDesc* desc, dlio_stream_t stream);
-int dlio_chan_partials_reduce(const float* stats, int C, int slots, int N, int HW, void* ws,
-                              size_t ws_bytes, dlio_stream_t stream);
-/* dlio_conv1x1_bx3_fwd_stats with scratch: narrowing layers on few pixels (>= 192 input channels, < 65536 pixels, too
+/* dlio_conv1x1_bx3_fwd_aff with scratch: narrowing layers on few pixels (>= 192 input channels, < 65536 pixels, too
  * few workgroups to fill the chip) split their channel loop over workgroups, write fp32 partial tiles to ws and sum
  * them (fixed order, + bias + residual) in a second launch.  dlio_conv1x1_bx3_ws_bytes(desc) = bytes that split
  * wants (0: the layer runs unsplit); with less (or ws NULL) the call runs unsplit. */
 size_t dlio_conv1x1_bx3_ws_bytes(const DlioConvDesc* desc);
 int dlio_conv1x1_bx3_fwd_ws(const float* x, const void* wt, const float* bias, const float* in_mean,
                             const float* in_scale, const float* in_shift, const float* residual,
-                            float* y, float* stats, void* ws, size_t ws_bytes, const DlioConvDesc* desc,
+                            float* y, void* ws, size_t ws_bytes, const DlioConvDesc* desc,
                             dlio_stream_t stream);
 size_t dlio_conv3x3_bx3_prep_floats(int Cout, int Cin, int mode);
 int dlio_conv3x3_bx3_prep(const float* w, void* wt, int Cout, int Cin, int mode, dlio_stream_t stream);
@@ -340,11 +322,6 @@ int dlio_copy2d(const float* src, int lds, float* dst, int ldd, int rows, int co
 /* nn.Dropout: mask from Philox4x32-10(seed, offset); y = x*mask/(1-p); mask saved as u8 */
 int dlio_dropout_fwd(const float* x, float* y, uint8_t* mask, int64_t n, float p,
                      uint64_t seed, uint64_t offset, dlio_stream_t stream);
-/* the same with the Philox offset = offset + *offset_base read ON THE DEVICE (offset_base may be NULL):
- * a launch recorded into a hipGraph draws a new mask at every replay (tail_graph.py) */
-int dlio_dropout_fwd_at(const float* x, float* y, uint8_t* mask, int64_t n, float p,
-                        uint64_t seed, uint64_t offset, const uint64_t* offset_base,
-                        dlio_stream_t stream);
 int dlio_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, int64_t n, float p,
                      dlio_stream_t stream);
 /* trainer.py:221-243 NaN/Inf guards: flag[0] |= 1 if any non-finite */

@@ -207,7 +207,7 @@ def test_fire_bf16_vs_fp64_oracle(dev, case, train):
     2e-2 of the output scale.  Gradients: rounding the activations to bf16 moves ~0.3 % of the ReLU inputs
     across zero, and each such element changes its gradient contribution by 100 % -- a relative L2 error of
     sqrt(0.003) ~ 5 % per block that ANY bf16 execution has (measured: the fp32 kernels on an input
-    perturbed by 2^-9 relative noise deviate by 4-6 %, tools/debug_mixed2.py); asserted: relative L2 <= 0.12
+    perturbed by 2^-9 relative noise deviate by 4-6 %, tools/bf16_flip_probe.py); asserted: relative L2 <= 0.12
     and the direction (cosine) >= 0.99 for the input gradient and every weight gradient."""
     from deeplio_amd import nets
     from oracle import model as om

@@ -420,58 +420,6 @@ def test_lidar_fusion_cat_resnet_vs_oracle(dev):
     assert max(e_hip) <= max(2e-2, 10.0 * max(e_ref)), (max(e_hip), max(e_ref))
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["headline", "fc-cat"])
-def test_tail_graph_matches_eager(dev, variant):
-    """TrainStep replays the serial middle of the step (fusion, odometry net, heads, SE(3) chain, loss and their
-    backward) as one hipGraph (tail_graph.py).  Same kernels, same order, same Philox offsets (read on the device):
-    losses, flags and every parameter after six steps on changing batches are bit-identical to the eager step."""
-    from deeplio_amd import functional as Fh
-    from deeplio_amd.config import make_config
-    from deeplio_amd.trainer import TrainStep
-    if variant == "headline":
-        cfg = make_config(seq=2)
-    else:
-        cfg = make_config(lidar="lidar-feat-simple-1", imu="imu-feat-fc", fusion="fusion-layer-cat", odom="odom-feat-fc",
-                          seq=3, overrides={"deeplio/dropout": 0.2})
-    S = cfg['datasets']['sequence-size']
-    batches = [tuple(t.to(dev) for t in gc.make_batch(20 + i, 2, S, 5, 64, 256, 50)) for i in range(3)]
-    runs = []
-    for graph in (False, True):
-        torch.manual_seed(3)
-        ts = TrainStep(cfg, (5, 64, 256), dev, 2)
-        ts.tail_mode, ts.tail_after = graph, 2
-        Fh.manual_seed(9)
-        losses = [ts.step(*batches[i % 3]).clone() for i in range(6)]
-        torch.cuda.synchronize()
-        runs.append((losses, ts.optimizer.flat.clone(), ts.flags.clone(), Fh.dropout_offset()))
-        if graph:
-            assert len(ts._tails) == 1 and next(iter(ts._tails.values())).consumed > 0
-        ts.release_gc()
-    (la, pa, fa, oa), (lb, pb, fb, ob) = runs
-    assert oa == ob                                    # the same number of Philox counters consumed
-    assert float(la[0]) != float(la[-1]) and all(bool(torch.isfinite(v)) for v in la)
-    for a, b in zip(la, lb):
-        assert torch.equal(a, b)
-    assert torch.equal(pa, pb) and torch.equal(fa, fb)
-
-
-@pytest.mark.gpu
-def test_tail_graph_recaptures_on_a_new_batch_shape(dev):
-    """a ragged last batch (other B) gets its own recorded tail; the first shape's graph is kept"""
-    from deeplio_amd.config import make_config
-    from deeplio_amd.trainer import TrainStep
-    cfg = make_config(seq=2)
-    ts = TrainStep(cfg, (5, 64, 256), dev, 2)
-    ts.tail_mode, ts.tail_after = True, 1
-    b2 = tuple(t.to(dev) for t in gc.make_batch(5, 2, 2, 5, 64, 256, 50))
-    b1 = tuple(t.to(dev) for t in gc.make_batch(6, 1, 2, 5, 64, 256, 50))
-    vals = [float(ts.step(*b).item()) for b in (b2, b2, b2, b1, b2, b1)]
-    assert len(ts._tails) == 2 and all(np.isfinite(vals))
-    ts.check()
-    ts.release_gc()
-
-
 def _headline_oracle_grads(cfg, batch, dtype):
     from oracle import model as om
     from oracle import se3 as ose3
@@ -550,3 +498,100 @@ def test_headline_shape_gradients_vs_oracle(dev):
     for k, p in model.named_parameters():
         if k not in g64:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+
+
+@pytest.mark.parametrize("loss_type", ["local+global", "local", "global"])
+def test_reference_iteration_protocol_on_hip_objects(dev, tmp_path, loss_type):
+    """The call sequence of the reference's training iteration and epoch end (trainer.py:197-317 and :150-170),
+    restated here, issued against deeplio_amd objects on the GPU and against the oracle's on the CPU: host-side
+    NaN / Inf guards on the batch and the predictions, the detach-by-loss-type rule (:246-256), the criterion on the
+    global window [1 : max_glob_seq + 1], `loss.detach().item()`, zero_grad / backward / step, calc_grad_norm over
+    `model.parameters()` (:481-486), criterion.sx / sq reads, then `state_dict()` of model, optimizer and criterion
+    into a checkpoint and PolynomialLRDecay.step().  Three iterations: losses and gradient norms agree with the
+    oracle (1e-4 first iteration, the fp32 envelope afterwards), the checkpoint has the reference's layout and
+    torch.optim loads its optimizer entry."""
+    from deeplio_amd import losses, misc, nets
+    from deeplio_amd.optimizer import create_optimizer
+    from deeplio_amd.se3 import se3_to_SE3
+    from oracle import model as om
+    from oracle import se3 as ose3
+    name = "pointseg_lstm_cat"
+    g = gc.MODEL_CASES[name]['geom']
+    kw = dict(gc.MODEL_CASES[name]['cfg'])
+    kw['overrides'] = dict(kw['overrides'], **{'losses/loss-type': loss_type})
+    from deeplio_amd.config import make_config
+    cfg = make_config(**kw)
+    args = types.SimpleNamespace(device=str(dev), batch_size=g['B'], lr=1e-3, weight_decay=1e-4, momentum=0.9)
+    misc.build_config_container(cfg, args)
+    max_glob_seq = 2                                                       # trainer.py:42
+
+    def calc_grad_norm(parameters):                                        # trainer.py:481-486
+        ps = [p for p in parameters if p.grad is not None]
+        return torch.norm(torch.stack([torch.norm(p.grad.detach(), 2) for p in ps]), 2)
+
+    def guard(t, what):                                                    # trainer.py:221-243
+        if torch.isnan(t).any() or torch.isinf(t).any():
+            raise ValueError("%s:\n%s" % (what, t))
+
+    def iteration(model, crit, opt, chain, batch):
+        imgs, normals, imus, gts_f2f, gts_f2g = batch
+        for t, what in ((gts_f2f, "gt-f2f"), (gts_f2g, "gt-f2g"), (normals, "normals"), (imgs, "imgs")):
+            guard(t, what)
+        gt_f2f_t, gt_f2f_w, gt_f2g_p, gt_f2g_q = gts_f2f[:, :, 0:3], gts_f2f[:, :, 3:], gts_f2g[:, :, 0:3], gts_f2g[:, :, 3:7]
+        pred_f2f_t, pred_f2f_w = model([[imgs, normals], imus])
+        guard(pred_f2f_t, "pred_f2f_x")
+        guard(pred_f2f_w, "pred_f2f_r")
+        pred_f2g_p, pred_f2g_q = chain(pred_f2f_t, pred_f2f_w)
+        if crit.loss_Types[0] and not crit.loss_Types[1]:
+            pred_f2g_p, pred_f2g_q = pred_f2g_p.detach(), pred_f2g_q.detach()
+        elif not crit.loss_Types[0] and crit.loss_Types[1]:
+            pred_f2f_t, pred_f2f_w = pred_f2f_t.detach(), pred_f2f_w.detach()
+        sl = slice(1, max_glob_seq + 1)
+        loss = crit(pred_f2f_t, pred_f2f_w, pred_f2g_p[:, sl, :], pred_f2g_q[:, sl, :], gt_f2f_t, gt_f2f_w,
+                    gt_f2g_p[:, sl, :], gt_f2g_q[:, sl, :])
+        val = loss.detach().item()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return val, float(calc_grad_norm(model.parameters())), float(crit.sx.data), float(crit.sq.data)
+
+    model = nets.get_model((g['C'], g['H'], g['W']), cfg, dev)
+    gc.fill_state(model, seed=1000)
+    model.train()
+    crit = losses.get_loss_function(cfg, dev)
+    opt = create_optimizer([{'params': model.parameters()}, {'params': crit.parameters()}], cfg, args)
+    sched = misc.PolynomialLRDecay(opt, max_decay_steps=30, end_learning_rate=1e-6, power=2.0)
+    omodel = om.get_model((g['C'], g['H'], g['W']), cfg)
+    gc.fill_state(omodel, seed=1000)
+    omodel.train()
+    ocrit = om.get_loss_function(cfg)
+    oopt = torch.optim.Adam([{'params': omodel.parameters()}, {'params': ocrit.parameters()}], lr=1e-3, weight_decay=1e-4)
+    bounds = [1e-4, 2e-3, 5e-2]          # new batch per iteration: the chaotic envelope of test_adam_trajectory, a little wider
+    for it in range(3):
+        batch = gc.make_batch(2000 + it, g['B'], g['S'], g['C'], g['H'], g['W'], g['T'])
+        mine = iteration(model, crit, opt, se3_to_SE3, tuple(t.to(dev) for t in batch))
+        ref = iteration(omodel, ocrit, oopt, ose3.se3_to_SE3, batch)
+        assert abs(mine[0] - ref[0]) <= bounds[it] * abs(ref[0]), (it, mine, ref)
+        # gradient norm: inside the fp32 gradient envelope of this tiny geometry (test_train_forward_backward_vs_oracle);
+        # after an Adam step (sign-like first updates, test_adam_trajectory) the two fp32 trajectories are 10 % apart in it
+        assert abs(mine[1] - ref[1]) <= (2e-2 if it == 0 else 0.2) * abs(ref[1]), (it, mine, ref)
+        assert abs(mine[2] - ref[2]) <= 1e-5 + bounds[it] and abs(mine[3] - ref[3]) <= 1e-5 + bounds[it]
+    # a bad batch is refused by the guards exactly as the reference does
+    bad = [t.to(dev) for t in gc.make_batch(1, g['B'], g['S'], g['C'], g['H'], g['W'], g['T'])]
+    bad[3][0, 0, 0] = float("nan")
+    with pytest.raises(ValueError, match="gt-f2f"):
+        iteration(model, crit, opt, se3_to_SE3, tuple(bad))
+    # epoch end (trainer.py:150-170)
+    state = {'epoch': 0, 'state_dict': model.state_dict(), 'best_acc': 1.0, 'optimizer': opt.state_dict(),
+             'criterion': crit.state_dict()}
+    path = str(tmp_path / "cpkt_deeplio.tar")
+    torch.save(state, path)
+    for feat_net in model.get_feat_networks():
+        torch.save({'state_dict': feat_net.state_dict()}, str(tmp_path / ("cpkt_%s.tar" % feat_net.name)))
+    sched.step()
+    assert opt.param_groups[0]['lr'] < 1e-3
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(ck) == {'epoch', 'state_dict', 'best_acc', 'optimizer', 'criterion'}
+    assert set(ck['state_dict']) == set(omodel.state_dict()) and set(ck['criterion']) == set(ocrit.state_dict())
+    oopt.load_state_dict(ck['optimizer'])                                   # the reference resumes from it
+    omodel.load_state_dict(ck['state_dict'])

@@ -31,7 +31,7 @@ class _DecisionMargin:
     """Records, during an fp64 oracle forward, how close any ReLU input / max-pool runner-up
     comes to its decision boundary (relative to the tensor's scale).  A gradient comparison is
     only meaningful where no decision can flip under fp32 rounding: ONE flipped ReLU among 1e6
-    activations moves a whole weight-gradient row by 1e-2 (measured: tools/debug_cbr2.py)."""
+    activations moves a whole weight-gradient row by 1e-2 (measured: tools/relu_flip_probe.py)."""
 
     def __enter__(self):
         self.margin = float("inf")
@@ -155,27 +155,6 @@ def test_fire_pair_apply_on_load(dev, case):
     hmk = lambda ci, sq, e1, e3, byp: nets.Fire(ci, sq, e1, e3, bypass=byp)
     omk = lambda ci, sq, e1, e3, byp: om.Fire(ci, sq, e1, e3, 0.1, byp)
     compare(_FirePair(hmk, a, b, True), _FirePair(omk, a, b, False), x, dev, True)
-
-
-@pytest.mark.parametrize("case", PAIR_CASES)
-def test_fire_pair_squeeze_apply_on_load(dev, case):
-    """DLIO_SQUEEZE_AOL=1 (off by default: measured no faster): the squeeze BatchNorm + ReLU is applied by expand1x1 /
-    expand3x3 (conv3x3_bx3_kernel<AFF>: padding stays 0 AFTER the activation) and by their weight gradients
-    (conv_wgrad_adirect_kernel<AFF>, wgrad1x1_direct_kernel<AFF>) while they stage the raw squeeze output.
-    Same oracle, same bars."""
-    from deeplio_amd import functional as Fh, nets
-    from oracle import model as om
-    N, H, W, a, b = case
-    x = torch.randn(N, a[0], H, W, generator=torch.Generator().manual_seed(1))
-    hmk = lambda ci, sq, e1, e3, byp: nets.Fire(ci, sq, e1, e3, bypass=byp)
-    omk = lambda ci, sq, e1, e3, byp: om.Fire(ci, sq, e1, e3, 0.1, byp)
-    saved = Fh._SQUEEZE_AOL[0]
-    Fh._SQUEEZE_AOL[0] = True
-    try:
-        compare(_FirePair(hmk, a, b, True), _FirePair(omk, a, b, False), x, dev, True)
-        compare(_FirePair(hmk, a, b, False), _FirePair(omk, a, b, False), x, dev, True)
-    finally:
-        Fh._SQUEEZE_AOL[0] = saved
 
 
 CBR_CASES = [  # N, cin, cout, k, stride, pad, H, W, pre_relu, bias

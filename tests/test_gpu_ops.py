@@ -902,42 +902,6 @@ def test_conv1x1_split_bf16_matches_fp64(dev, case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", [(3, 3, 2, 24, 40, 9, 37), (3, 3, 1, 16, 64, 8, 70), (3, 3, 3, 70, 100, 5, 33), (3, 3, 2, 48, 192, 16, 128),
-                                  (1, 1, 2, 24, 40, 8, 36), (1, 1, 3, 70, 100, 4, 132), (1, 1, 2, 128, 16, 16, 64), (1, 1, 1, 48, 192, 64, 128)])
-def test_bn_statistics_from_the_convolution_epilogue(dev, case):
-    """split-bf16 convolutions write per-workgroup (sum, sum of squares) of their output channels on request;
-    dlio_chan_partials_reduce + the phase-2 finalize give the statistics (and running-stat updates) of
-    dlio_bn_train_stats without reading the output again -- ragged tiles, channel counts off the tile grid and
-    channel-sliced outputs included"""
-    from deeplio_amd import ops
-    KH, KW, N, Cin, Cout, H, W = case
-    g = _g(77)
-    x = torch.randn(N, Cin, H, W, generator=g).to(dev)
-    w = (torch.randn(Cout, Cin, KH, KW, generator=g) / (Cin * KH * KW) ** 0.5).to(dev)
-    b = torch.randn(Cout, generator=g).to(dev)
-    gamma = (torch.rand(Cout, generator=g) + 0.5).to(dev)
-    pad = KH // 2
-    d = ops.conv_desc(N, Cin, H, W, Cout, KH, KW, 1, 1, pad, pad, out_ctot=Cout + 3, out_coff=2)
-    y = torch.zeros(N, Cout + 3, H, W, device=dev)
-    st, slots = ops.conv_bx3_stats_buffer(d, dev)
-    st.fill_(float("nan"))                                   # every slot of every channel must be written
-    if KH == 3:
-        ops.conv3x3_bx3_fwd(x, ops.conv3x3_bx3_prep(w, 0), b, y, d, stats=st)
-    else:
-        ops.conv1x1_bx3_fwd(x, ops.conv1x1_bx3_prep(w, 0), b, y, d, stats=st)
-    rm_a, rv_a = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
-    rm_b, rv_b = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
-    fused = ops.bn_train_stats(y, N, Cout + 3, 2, Cout, H * W, False, gamma, 1e-5, 0.1, rm_a, rv_a, fused=(st, slots))
-    plain = ops.bn_train_stats(y, N, Cout + 3, 2, Cout, H * W, False, gamma, 1e-5, 0.1, rm_b, rv_b)
-    yd = y[:, 2:2 + Cout].double()
-    mean, var = yd.mean((0, 2, 3)), yd.var((0, 2, 3), unbiased=False)
-    assert rel_err(fused[0], mean) < 2e-6 and rel_err(fused[1], 1 / (var + 1e-5).sqrt()) < 2e-6
-    for a, c in zip(fused, plain):
-        assert rel_err(a, c.double()) < 2e-6
-    assert rel_err(rm_a, rm_b.double()) < 2e-6 and rel_err(rv_a, rv_b.double()) < 2e-6
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("case", [(16, 512, 80, 16, 32), (4, 768, 80, 8, 64), (2, 384, 48, 16, 16), (1, 200, 24, 4, 32)])
 def test_conv1x1_split_bf16_k_split_over_workgroups(dev, case):
     """narrowing 1x1 layers on few pixels: the channel loop is split over workgroups, fp32 partial tiles summed in a

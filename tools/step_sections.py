@@ -3,7 +3,7 @@
 ~20 % and makes the serial middle look host-bound): hipEvents on the main stream at
   t0 step start | t1 encoders + IMU net done (features joined) | t2 loss computed | t3 tail backward done (feature
   gradients available) | t4 optimizer step issued
-and the host time at which each of those points was ISSUED.  DLIO_TAIL_GRAPH=0/1 selects the eager / replayed tail."""
+and the host time at which each of those points was ISSUED."""
 import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import bench
@@ -44,14 +44,6 @@ def tail_w(*a, **k):
 
 
 ts.model.forward_features, ts._tail = ff_w, tail_w
-if ts.tail_mode:       # graph mode: t2/t3 = after the replay
-    from deeplio_amd import tail_graph
-    rp = tail_graph.TailGraph.replay
-    def rp_w(self, *a, **k):
-        r = rp(self, *a, **k)
-        mark("t2"); mark("t3")
-        return r
-    tail_graph.TailGraph.replay = rp_w
 for _ in range(6):
     ts.step(*batch)
 torch.cuda.synchronize()
@@ -68,7 +60,6 @@ for _ in range(N):
         if n in d:
             g, h = acc.get(n, (0., 0.))
             acc[n] = (g + e0.elapsed_time(d[n][0]), h + (d[n][1] - h0) * 1e3)
-print("tail graph", ts.tail_mode)
 for n in ("t1", "t2", "t3", "t4"):
     if n in acc:
         print("%s  gpu %.2f ms   host issued at %.2f ms" % (n, acc[n][0] / N, acc[n][1] / N))
