@@ -131,9 +131,9 @@ SIGNATURES = {
     "dlio_bf16_stats_splits": (_i, [_i, _i, _i]),
     "dlio_bf16_stats_ws_bytes": (_sz, [_i, _i, _i]),
     "dlio_bn_bf16_apply": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _i, _i, _p, _i, _i,
-                                _p, _i, _i, _i, _p, _sz, _p]),
+                                _p, _i, _i, _i, _p, _sz, _i, _d, _p]),
     "dlio_bn_bf16_bwd": (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _i,
-                              _p, _sz, _p]),
+                              _p, _sz, _i, _d, _p, _p]),
     "dlio_maxpool_bf16_fwd": (_i, [_p, _p, _p, _p] + [_i] * 11 + [_p]),
     "dlio_maxpool_bf16_bwd": (_i, [_p, _p, _p, _p, _p] + [_i] * 11 + [_p]),
     "dlio_maxpool_bf16_bwd_dot": (_i, [_p, _p, _p, _p] + [_i] * 11 + [_p]),

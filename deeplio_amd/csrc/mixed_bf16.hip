@@ -171,19 +171,26 @@ __global__ __launch_bounds__(256) void bn16_plane_apply_kernel(
 __global__ __launch_bounds__(256) void bn16_plane_bwd_kernel(
     const __bf16* __restrict__ dy, int dy_ctot, int dy_coff, const __bf16* __restrict__ x, int x_ctot, int x_coff,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ scale,
-    const float* __restrict__ beta, const double* __restrict__ part, double inv_cnt, int splits, __bf16* dx,
-    int dx_ctot, int dx_coff, float* dgamma, float* dbeta, int accumulate, int N, int C, int HW, int post_relu,
-    int use_batch_stats, int chunks, int chunk_len) {
+    const float* __restrict__ beta, const double* __restrict__ part, const double* __restrict__ lpart, double inv_cnt,
+    int splits, __bf16* dx, int dx_ctot, int dx_coff, float* dgamma, float* dbeta, int accumulate, int N, int C, int HW,
+    int post_relu, int use_batch_stats, int chunks, int chunk_len) {
   __shared__ double sm[2][16];
   const int chunk = blockIdx.x % chunks;
   const int pl = blockIdx.x / chunks;
   const int n = pl / C, c = pl - n * C;
   double sg, sgx;
-  plane_partials16(part, c, splits, sm[0], sm[1], sg, sgx);
-  if (n == 0 && chunk == 0 && threadIdx.x == 0) {
-    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)sg : (float)sg;
-    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)sgx : (float)sgx;
+  if (n == 0 && chunk == 0) {
+    // synchronised statistics: `part` holds the sums over all replicas, `lpart` this replica's -- dgamma / dbeta are
+    // local sums (the gradient all-reduce adds the replicas')
+    double lg, lgx;
+    plane_partials16(lpart ? lpart : part, c, splits, sm[0], sm[1], lg, lgx);
+    if (threadIdx.x == 0) {
+      if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)lg : (float)lg;
+      if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)lgx : (float)lgx;
+    }
+    __syncthreads();
   }
+  plane_partials16(part, c, splits, sm[0], sm[1], sg, sgx);
   const float mu = mean[c], is = invstd[c], sc = scale[c], be = beta ? beta[c] : 0.f;
   float mg = 0.f, mgx = 0.f;
   if (use_batch_stats) { mg = (float)(sg * inv_cnt); mgx = (float)(sgx * inv_cnt); }
@@ -421,8 +428,9 @@ extern "C" int dlio_bn_bf16_apply(const void* x, int N, int x_ctot, int x_coff, 
                                   float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
                                   const void* residual, int r_ctot, int r_coff, void* y, int y_ctot, int y_coff,
                                   float* gap_out, int gap_ctot, int gap_coff, int eval_mode, void* ws, size_t ws_bytes,
-                                  dlio_stream_t stream) {
+                                  int phase, double count_scale, dlio_stream_t stream) {
   if (!x || !y || !mean || !invstd || !scale || N <= 0 || C <= 0 || HW <= 0 || !ws) return DLIO_EINVAL;
+  if (phase < 0 || phase > 2 || !(count_scale > 0.0)) return DLIO_EINVAL;
   if (HW & 7) return DLIO_EUNSUP;
   const int splits = splits16(N, C, HW);
   if (ws_bytes < (size_t)C * splits * 2 * sizeof(double)) return DLIO_EWS;
@@ -430,19 +438,19 @@ extern "C" int dlio_bn_bf16_apply(const void* x, int N, int x_ctot, int x_coff, 
   double* part = reinterpret_cast<double*>(ws);
   const __bf16* xb = reinterpret_cast<const __bf16*>(x);
   const double tensor_bytes = 2.0 * N * (double)C * HW;
-  if (!eval_mode) {
+  if (!eval_mode && phase != 2) {
     DlioProfScope prof(6, s, 0.0, tensor_bytes);
     hipLaunchKernelGGL(bn16_reduce_kernel<0>, dim3((unsigned)(C * splits)), dim3(RB), 0, s, xb, x_ctot, x_coff,
                        (const __bf16*)nullptr, 0, 0, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, N, C, HW, 0, splits, part);
     const int rc = dlio_check_launch();
-    if (rc) return rc;
+    if (rc || phase == 1) return rc;
   }
   int chunks, chunk_len;
   plane_chunks16(N * C, HW / 8, gap_out != nullptr, chunks, chunk_len);
   DlioProfScope prof(7, s, 0.0, tensor_bytes * (residual ? 3.0 : 2.0));
   hipLaunchKernelGGL(bn16_plane_apply_kernel, dim3((unsigned)(N * C * chunks)), dim3(256), 0, s, xb, x_ctot, x_coff, part,
-                     splits, (double)N * HW, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale,
+                     splits, (double)N * HW * count_scale, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale,
                      reinterpret_cast<const __bf16*>(residual), r_ctot, r_coff, reinterpret_cast<__bf16*>(y), y_ctot,
                      y_coff, N, C, HW, post_relu, chunks, chunk_len, gap_out, gap_ctot, gap_coff, eval_mode);
   return dlio_check_launch();
@@ -451,9 +459,10 @@ extern "C" int dlio_bn_bf16_apply(const void* x, int N, int x_ctot, int x_coff, 
 extern "C" int dlio_bn_bf16_bwd(const void* dy, int dy_ctot, int dy_coff, const void* x, int x_ctot, int x_coff,
                                 const float* mean, const float* invstd, const float* scale, const float* beta, void* dx,
                                 int dx_ctot, int dx_coff, float* dgamma, float* dbeta, int accumulate, int N, int C,
-                                int HW, int post_relu, int use_batch_stats, void* ws, size_t ws_bytes,
-                                dlio_stream_t stream) {
+                                int HW, int post_relu, int use_batch_stats, void* ws, size_t ws_bytes, int phase,
+                                double count_scale, const void* local_ws, dlio_stream_t stream) {
   if (!dy || !x || !mean || !invstd || !scale || !dx || N <= 0 || C <= 0 || HW <= 0 || !ws) return DLIO_EINVAL;
+  if (phase < 0 || phase > 2 || !(count_scale > 0.0)) return DLIO_EINVAL;
   if (HW & 7) return DLIO_EUNSUP;
   const int splits = splits16(N, C, HW);
   if (ws_bytes < (size_t)C * splits * 2 * sizeof(double)) return DLIO_EWS;
@@ -462,18 +471,19 @@ extern "C" int dlio_bn_bf16_bwd(const void* dy, int dy_ctot, int dy_coff, const 
   const __bf16* gb = reinterpret_cast<const __bf16*>(dy);
   const __bf16* xb = reinterpret_cast<const __bf16*>(x);
   const double tensor_bytes = 2.0 * N * (double)C * HW;
-  {
+  if (phase != 2) {
     DlioProfScope prof(8, s, 0.0, 2.0 * tensor_bytes);
     hipLaunchKernelGGL(bn16_reduce_kernel<1>, dim3((unsigned)(C * splits)), dim3(RB), 0, s, gb, dy_ctot, dy_coff, xb,
                        x_ctot, x_coff, mean, invstd, scale, beta, N, C, HW, post_relu, splits, part);
     const int rc = dlio_check_launch();
-    if (rc) return rc;
+    if (rc || phase == 1) return rc;
   }
   int chunks, chunk_len;
   plane_chunks16(N * C, HW / 8, false, chunks, chunk_len);
   DlioProfScope prof(9, s, 0.0, 3.0 * tensor_bytes);
   hipLaunchKernelGGL(bn16_plane_bwd_kernel, dim3((unsigned)(N * C * chunks)), dim3(256), 0, s, gb, dy_ctot, dy_coff, xb,
-                     x_ctot, x_coff, mean, invstd, scale, beta, part, 1.0 / ((double)N * HW), splits,
+                     x_ctot, x_coff, mean, invstd, scale, beta, part, reinterpret_cast<const double*>(local_ws),
+                     1.0 / ((double)N * HW * count_scale), splits,
                      reinterpret_cast<__bf16*>(dx), dx_ctot, dx_coff, dgamma, dbeta, accumulate, N, C, HW, post_relu,
                      use_batch_stats, chunks, chunk_len);
   return dlio_check_launch();

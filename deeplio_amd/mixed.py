@@ -69,29 +69,52 @@ def _stats_ws(N, C_, HW, device):
     return workspace(lib.dlio_bf16_stats_ws_bytes(N, C_, HW), device, slot=1)
 
 
+def _partials16(ws, N, C_, HW):
+    n = C_ * lib.dlio_bf16_stats_splits(N, C_, HW) * 2
+    return ws[:n * 8].view(torch.float64)
+
+
 def bn_apply(x, x_ctot, x_coff, gamma, beta, eps, momentum, rmean, rvar, y, y_ctot, y_coff, N, C_, HW, post_relu,
              residual=None, r_ctot=0, r_coff=0, gap_out=None, gap_ctot=0, gap_coff=0, eval_prm=None):
-    """train: statistics + apply -> prm [3][C] (mean, invstd, scale); eval: apply with eval_prm"""
-    if eval_prm is None and ops._SYNC_BN[0] is not None:
-        raise NotImplementedError("synchronised BatchNorm statistics (GradSync.enable_sync_bn) exist on the fp32 path only; "
-                                  "the bf16 path takes per-replica statistics")
+    """train: statistics + apply -> prm [3][C] (mean, invstd, scale); eval: apply with eval_prm.  With synchronised
+    statistics (GradSync.enable_sync_bn) the per-channel partial sums are all-reduced between the two launches."""
     prm = eval_prm if eval_prm is not None else torch.empty(3, C_, dtype=torch.float32, device=x.device)
     ws = _stats_ws(N, C_, HW, x.device)
-    check(lib.dlio_bn_bf16_apply(_ptr(x), N, x_ctot, x_coff, C_, HW, int(post_relu), _ptr(gamma), _ptr(beta),
-                                 float(eps), float(momentum), _ptr(rmean), _ptr(rvar), _ptr(prm[0]), _ptr(prm[1]),
-                                 _ptr(prm[2]), _ptr(residual), r_ctot, r_coff, _ptr(y), y_ctot, y_coff,
-                                 _ptr(gap_out), gap_ctot, gap_coff, int(eval_prm is not None), _ptr(ws), ws.numel(),
-                                 _stream()), "bn_bf16_apply")
+
+    def call(phase, scale):
+        check(lib.dlio_bn_bf16_apply(_ptr(x), N, x_ctot, x_coff, C_, HW, int(post_relu), _ptr(gamma), _ptr(beta),
+                                     float(eps), float(momentum), _ptr(rmean), _ptr(rvar), _ptr(prm[0]), _ptr(prm[1]),
+                                     _ptr(prm[2]), _ptr(residual), r_ctot, r_coff, _ptr(y), y_ctot, y_coff,
+                                     _ptr(gap_out), gap_ctot, gap_coff, int(eval_prm is not None), _ptr(ws), ws.numel(),
+                                     phase, float(scale), _stream()), "bn_bf16_apply")
+    sync = ops._SYNC_BN[0]
+    if sync is None or eval_prm is not None:
+        call(0, 1.0)
+    else:
+        call(1, 1.0)
+        sync[0](_partials16(ws, N, C_, HW))
+        call(2, sync[1])
     return prm
 
 
 def bn_bwd(dy, dy_ctot, dy_coff, x, x_ctot, x_coff, prm, beta, dx, dx_ctot, dx_coff, N, C_, HW, post_relu,
            use_batch_stats, dgamma=None, dbeta=None, accumulate=False):
     ws = _stats_ws(N, C_, HW, x.device)
-    check(lib.dlio_bn_bf16_bwd(_ptr(dy), dy_ctot, dy_coff, _ptr(x), x_ctot, x_coff, _ptr(prm[0]), _ptr(prm[1]),
-                               _ptr(prm[2]), _ptr(beta), _ptr(dx), dx_ctot, dx_coff, _ptr(dgamma), _ptr(dbeta),
-                               int(accumulate), N, C_, HW, int(post_relu), int(use_batch_stats), _ptr(ws),
-                               ws.numel(), _stream()), "bn_bf16_bwd")
+
+    def call(phase, scale, local):
+        check(lib.dlio_bn_bf16_bwd(_ptr(dy), dy_ctot, dy_coff, _ptr(x), x_ctot, x_coff, _ptr(prm[0]), _ptr(prm[1]),
+                                   _ptr(prm[2]), _ptr(beta), _ptr(dx), dx_ctot, dx_coff, _ptr(dgamma), _ptr(dbeta),
+                                   int(accumulate), N, C_, HW, int(post_relu), int(use_batch_stats), _ptr(ws),
+                                   ws.numel(), phase, float(scale), _ptr(local), _stream()), "bn_bf16_bwd")
+    sync = ops._SYNC_BN[0]
+    if sync is None or not use_batch_stats:
+        call(0, 1.0, None)
+    else:
+        call(1, 1.0, None)
+        part = _partials16(ws, N, C_, HW)
+        local = part.clone()
+        sync[0](part)
+        call(2, sync[1], local)
     return dx
 
 

@@ -510,19 +510,24 @@ int dlio_conv2d_wgrad_bf16(const void* x, const void* dy, float* dw, void* ws, s
                            const DlioConvDesc* desc, dlio_stream_t stream);
 /* train-mode BatchNorm (+ReLU, + residual, + plane averages of the stored output) over bf16:
  * statistics and apply in two launches; eval_mode != 0: apply only, mean / invstd / scale are inputs
- * (dlio_bn_eval_params).  ws: dlio_bf16_stats_ws_bytes(N, C, HW). */
+ * (dlio_bn_eval_params).  ws: dlio_bf16_stats_ws_bytes(N, C, HW).  phase / count_scale as dlio_bn_train_apply:
+ * 0 = both launches, 1 = the partial sums only ([C][splits][2] doubles at the start of ws: the caller all-reduces
+ * them over the data-parallel replicas), 2 = apply from the partials in ws with count = N * HW * count_scale. */
 int dlio_bf16_stats_splits(int N, int C, int HW);
 size_t dlio_bf16_stats_ws_bytes(int N, int C, int HW);
 int dlio_bn_bf16_apply(const void* x, int N, int x_ctot, int x_coff, int C, int HW, int post_relu,
                        const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                        float* running_var, float* mean, float* invstd, float* scale, const void* residual,
                        int r_ctot, int r_coff, void* y, int y_ctot, int y_coff, float* gap_out, int gap_ctot,
-                       int gap_coff, int eval_mode, void* ws, size_t ws_bytes, dlio_stream_t stream);
-/* backward: reductions + dx (bf16), dgamma / dbeta (fp32, accumulated when accumulate != 0) */
+                       int gap_coff, int eval_mode, void* ws, size_t ws_bytes, int phase, double count_scale,
+                       dlio_stream_t stream);
+/* backward: reductions + dx (bf16), dgamma / dbeta (fp32, accumulated when accumulate != 0); phase / count_scale as
+ * above, local_ws (phase 2, nullable) = this replica's partials before the all-reduce: dgamma / dbeta come from them */
 int dlio_bn_bf16_bwd(const void* dy, int dy_ctot, int dy_coff, const void* x, int x_ctot, int x_coff,
                      const float* mean, const float* invstd, const float* scale, const float* beta, void* dx,
                      int dx_ctot, int dx_coff, float* dgamma, float* dbeta, int accumulate, int N, int C, int HW,
-                     int post_relu, int use_batch_stats, void* ws, size_t ws_bytes, dlio_stream_t stream);
+                     int post_relu, int use_batch_stats, void* ws, size_t ws_bytes, int phase, double count_scale,
+                     const void* local_ws, dlio_stream_t stream);
 /* 3x3 max-pool, padding 1, stride (1|2, 2), W % 16 == 0, with the fused SELayer scale (x_scale [N*C] fp32,
  * nullable); idx uint8 = kh*3 + kw of the first maximum.  bwd: dx = x_scale * scatter(dy) + x_add[plane];
  * bwd_dot: ds[plane] = sum dy * x[arg-max]. */

@@ -412,18 +412,81 @@ def test_model_bf16_training_tracks_fp32(dev):
 
 
 @pytest.mark.gpu
-def test_bf16_path_refuses_synchronised_batchnorm(dev):
-    """SyncBN (partials all-reduced between the statistics and the apply launch) exists on the fp32 path only: the bf16
-    kernels take per-replica statistics, so a training-mode bf16 BatchNorm with SyncBN switched on fails loudly"""
+@pytest.mark.parametrize("shape", [(4, 24, 8, 64), (4, 16, 16, 32)])
+def test_bf16_batchnorm_synchronised_statistics_equal_the_whole_batch(dev, shape):
+    """SyncBN on the bf16 path (BASELINE configs[4] is a DP = 8 config): the per-channel partial sums are all-reduced
+    between the statistics and the apply launch (dlio_bn_bf16_apply / _bwd phases 1 / 2, as the fp32 kernels).  Two
+    "ranks" are played in one process -- each half of the batch is run once to collect its partials, then again with an
+    all-reduce callable that returns the sum: outputs, statistics, running statistics and dx of the halves equal the
+    whole batch's, dgamma / dbeta add up to it."""
     from deeplio_amd import mixed, ops
-    x = torch.randn(2, 8, 4, 8, device=dev).to(torch.bfloat16)
-    y = torch.empty_like(x)
-    g, b = torch.ones(8, device=dev), torch.zeros(8, device=dev)
-    rm, rv = torch.zeros(8, device=dev), torch.ones(8, device=dev)
-    ops.set_sync_bn(lambda t: t, 2)
-    try:
-        with pytest.raises(NotImplementedError):
-            mixed.bn_apply(x, 8, 0, g, b, 1e-5, 0.1, rm, rv, y, 8, 0, 2, 8, 32, True)
-    finally:
-        ops.set_sync_bn(None, 1)
-    mixed.bn_apply(x, 8, 0, g, b, 1e-5, 0.1, rm, rv, y, 8, 0, 2, 8, 32, True)      # per-replica statistics: fine
+    N, C_, H, W = shape
+    HW = H * W
+    g0 = _g(21)
+    x = torch.randn(N, C_, H, W, generator=g0).to(dev).bfloat16()
+    dy = torch.randn(N, C_, H, W, generator=g0).to(dev).bfloat16()
+    gamma = (1.0 + 0.2 * torch.randn(C_, generator=g0)).to(dev)
+    beta = (0.2 * torch.randn(C_, generator=g0)).to(dev)
+
+    def run(xs, dys, n):
+        rm, rv = torch.zeros(C_, device=dev), torch.ones(C_, device=dev)
+        y = torch.empty_like(xs)
+        prm = mixed.bn_apply(xs, C_, 0, gamma, beta, 1e-5, 0.1, rm, rv, y, C_, 0, n, C_, HW, True)
+        dx = torch.empty_like(xs)
+        dg, db = torch.zeros(C_, device=dev), torch.zeros(C_, device=dev)
+        mixed.bn_bwd(dys, C_, 0, xs, C_, 0, prm, beta, dx, C_, 0, n, C_, HW, True, True, dg, db)
+        torch.cuda.synchronize()
+        return y, prm.clone(), rm, rv, dx, dg, db
+    whole = run(x, dy, N)
+    h = N // 2
+    halves = [(x[:h].contiguous(), dy[:h].contiguous()), (x[h:].contiguous(), dy[h:].contiguous())]
+    # pass 1: collect every all-reduce operand of both ranks, in call order (forward, backward)
+    seen = [[], []]
+    for r, (xs, dys) in enumerate(halves):
+        ops.set_sync_bn(lambda t, r=r: seen[r].append(t.clone()), 2)
+        try:
+            run(xs, dys, h)
+        finally:
+            ops.set_sync_bn(None, 1)
+    assert len(seen[0]) == 2 and len(seen[1]) == 2
+    fwd_sum = seen[0][0] + seen[1][0]
+    # pass 2: the all-reduce returns the sum over the two ranks (the backward partials depend on the synchronised forward
+    # statistics, so they are collected again under them)
+    bwd = [None, None]
+    for r, (xs, dys) in enumerate(halves):
+        calls = []
+
+        def reduce_(t, r=r, calls=calls):
+            if not calls:
+                t.copy_(fwd_sum)
+            else:
+                bwd[r] = t.clone()
+            calls.append(1)
+        ops.set_sync_bn(reduce_, 2)
+        try:
+            run(xs, dys, h)
+        finally:
+            ops.set_sync_bn(None, 1)
+    bwd_sum = bwd[0] + bwd[1]
+    outs = []
+    for r, (xs, dys) in enumerate(halves):
+        calls = []
+
+        def reduce2(t, calls=calls):
+            t.copy_(fwd_sum if not calls else bwd_sum)
+            calls.append(1)
+        ops.set_sync_bn(reduce2, 2)
+        try:
+            outs.append(run(xs, dys, h))
+        finally:
+            ops.set_sync_bn(None, 1)
+    y = torch.cat([outs[0][0], outs[1][0]])
+    dx = torch.cat([outs[0][4], outs[1][4]])
+    # the same statistics up to fp64 summation order -> the same bf16 roundings (a last-bit difference of a mean may flip one)
+    assert float((y.float() - whole[0].float()).abs().mean()) < 1e-5 and rel_err(y.float(), whole[0].float().double()) < 1e-2
+    for r in range(2):
+        assert rel_err(outs[r][1], whole[1].double()) < 1e-6      # mean, invstd, scale
+        assert rel_err(outs[r][2], whole[2].double()) < 1e-6 and rel_err(outs[r][3], whole[3].double()) < 1e-6
+    assert rel_err(dx.float(), whole[4].float().double()) < 1e-2 and float((dx.float() - whole[4].float()).abs().mean()) < 1e-4
+    assert rel_err(outs[0][5] + outs[1][5], whole[5].double()) < 1e-5
+    assert rel_err(outs[0][6] + outs[1][6], whole[6].double()) < 1e-5
