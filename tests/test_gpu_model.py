@@ -595,3 +595,30 @@ def test_reference_iteration_protocol_on_hip_objects(dev, tmp_path, loss_type):
     assert set(ck['state_dict']) == set(omodel.state_dict()) and set(ck['criterion']) == set(ocrit.state_dict())
     oopt.load_state_dict(ck['optimizer'])                                   # the reference resumes from it
     omodel.load_state_dict(ck['state_dict'])
+
+
+@pytest.mark.parametrize("lidar,imu_type,C", [("lidar-feat-flownet", "gru", 3), ("lidar-feat-resnet", "lstm", 3)])
+def test_full_size_eval_forward_other_families_vs_oracle(dev, lidar, imu_type, C):
+    """BASELINE configs[2] / configs[3] at their real geometry (64x2048, C = 3 per stream: xyz + normals as kitti.py
+    delivers them), B = 1, S = 2, eval mode, fill_state weights: FlowNet (lidar_feat_nets.py:240-267: 5x7 / 3x5 strided
+    stems, 3x3 stride-2 layers, 1024 channels at 8x32) and ResNet (resnet.py:14-112: 5x7 stem at full resolution,
+    BasicBlocks with (1,2) / (2,2) downsampling) against the CPU oracle <= 1e-4 of the output scale -- the launch sizes
+    at which the strided kernels, the phase-decomposed data gradients' forward twins and the 512 / 1024-channel 3x3 layers
+    pick their large-tile branches."""
+    from deeplio_amd import misc, nets
+    from deeplio_amd.config import make_config
+    from oracle import model as om
+    cfg = make_config(lidar=lidar, imu="imu-feat-rnn", fusion="fusion-layer-cat", odom="odom-feat-rnn", seq=2,
+                      overrides=dict(gc.NO_DROP, **{'imu-feat-rnn/type': imu_type}))
+    misc.build_config_container(cfg, types.SimpleNamespace(device=str(dev), batch_size=1))
+    model = nets.get_model((C, 64, 2048), cfg, dev)
+    gc.fill_state(model, seed=1000)
+    model.eval()
+    omodel = om.get_model((C, 64, 2048), cfg)
+    gc.fill_state(omodel, seed=1000)
+    omodel.eval()
+    batch = gc.make_batch(9, 1, 2, C, 64, 2048, 50)
+    with torch.no_grad():
+        pos, ori = model([[batch[0].to(dev), batch[1].to(dev)], batch[2].to(dev)])
+        opos, oori = omodel([[batch[0], batch[1]], batch[2]])
+    assert rel_err(pos, opos) < TOL and rel_err(ori, oori) < TOL, (rel_err(pos, opos), rel_err(ori, oori))
