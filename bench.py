@@ -244,15 +244,13 @@ def main():
     for _ in range(args.warmup):
         ts.step(*batch)
     ts.check()
-    wg_bx3 = os.environ.get("DLIO_WGRAD_BX3", "1") != "0"
     # family -> (profiler kinds, bound, peak, description)
     FAMILIES = {
         "conv3x3_bx3": ((3,), "mfma", PEAK_BX3_TFLOPS, "conv3x3 split-bf16 MFMA (forward + data gradient)"),
         "conv2d_1x1": ((2,), "hbm", PEAK_HBM_GBS, "conv2d_1x1 (forward + data gradient, HBM-bound)"),
         "batchnorm": ((6, 7, 8, 9), "hbm", PEAK_HBM_GBS,
                       "batchnorm (train-mode statistics, apply, backward reductions, backward apply; HBM-bound)"),
-        "wgrad3x3": ((4,), "mfma", PEAK_BX3_TFLOPS if wg_bx3 else PEAK_F32_MFMA_TFLOPS,
-                     "conv3x3 weight gradient" + (" (split-bf16 MFMA)" if wg_bx3 else " (fp32 MFMA)")),
+        "wgrad3x3": ((4,), "mfma", PEAK_BX3_TFLOPS, "conv3x3 weight gradient (split-bf16 MFMA, conv_wgrad3.hip)"),
         "wgrad1x1": ((5,), "hbm", PEAK_HBM_GBS, "conv1x1 weight gradient (HBM-bound)"),
         "pool_se": ((10,), "hbm", PEAK_HBM_GBS, "max-pool with fused SE scale (forward + backward, HBM-bound)"),
         "conv2d_fwd_mfma": ((0,), "mfma", PEAK_F32_MFMA_TFLOPS,

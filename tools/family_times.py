@@ -13,7 +13,7 @@ FAMILIES = [
     ("conv3x3 fwd+dgrad (split-bf16 MFMA)", ("conv3x3_bx3_kernel", "conv3x3_bx3_alds_kernel", "conv3x3_bf16")),
     ("stem conv fwd (fp32 MFMA)", ("conv_fwd_kernel",)),
     ("conv1x1 fwd+dgrad", ("conv1x1_",)),
-    ("conv3x3 wgrad", ("conv_wgrad_adirect",)),
+    ("conv3x3 wgrad", ("wgrad3_kernel", "conv_wgrad_adirect")),
     ("conv1x1 wgrad", ("wgrad1x1_",)),
     ("other wgrad + slab reduce", ("conv_wgrad_kernel", "wgrad_reduce_kernel")),
     ("BN fwd statistics", ("chan_reduce_kernel<0", "bn16_reduce_kernel<0")),

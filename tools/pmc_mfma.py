@@ -53,7 +53,7 @@ def main(db, out):
         f.write("| kernel | launches | GPU-active cycles (M) | MfmaUtil %% | on duration x 2.4 GHz %% | = TFLOP/s incl. padding | WAIT_ANY %% | WAIT_INST_ANY %% | ACTIVE_INST %% |\n".replace("%%", "%"))
         f.write("|---|---|---|---|---|---|---|---|---|\n")
         for act, k, n, util, util_d, wa, wi, ai in lines:
-            tf = "%.1f (fp32-equivalent: util x 419.5)" % (util * 4.195) if ("bx3" in k or (("conv_wgrad_adirect" in k or "wgrad1x1_direct" in k) and k.rstrip().endswith("true>"))) else "%.1f" % (util * 1.573)
+            tf = "%.1f (fp32-equivalent: util x 419.5)" % (util * 4.195) if ("bx3" in k or ("wgrad3_kernel" in k and k.rstrip().endswith("false>")) or ("wgrad1x1_direct" in k and k.rstrip().endswith("true>"))) else "%.1f" % (util * 1.573)
             f.write("| `%s` | %d | %.1f | %.1f | %.1f | %s | %.0f | %.0f | %.0f |\n" % (k[:70], n, act / 1e6, util, util_d, tf, wa, wi, ai))
         f.write("\nAll kernels of the pass: MFMA busy %.1f %% of GPU-active cycles (MFMA kernels only: %.1f %%).\n"
                 % (100.0 * tot_busy / (tot_act * 1024), 100.0 * tot_busy / (sum(l[0] for l in lines) * 1024)))

@@ -20,7 +20,7 @@ FAMILIES = {
     "conv3x3_bx3": ("conv3x3_bx3_kernel", "conv3x3_bx3_alds_kernel"),
     "conv2d_1x1": ("conv1x1_",),
     "conv2d_wgrad_mfma": ("conv_wgrad_kernel",),
-    "wgrad3x3": ("conv_wgrad_adirect",),
+    "wgrad3x3": ("wgrad3_kernel", "conv_wgrad_adirect"),
     "wgrad1x1": ("wgrad1x1_direct",),
     "wgrad_reduce": ("wgrad_reduce",),
     "batchnorm": ("chan_reduce", "chan_stats", "bn_apply", "bn_bwd", "bn_plane"),

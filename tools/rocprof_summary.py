@@ -23,7 +23,7 @@ def main(db_path, out_path, steps, note=""):
         # roofline.avg_launch_ms / roofline.isolated.avg_launch_ms of the bench JSON
         fam = {"conv3x3 split-bf16 MFMA (forward + data gradient)": ("conv3x3_bx3_kernel",),
                "conv2d_fwd_mfma, multi-tap on the fp32 MFMA (forward + data gradient)": ("conv_fwd_kernel",),
-               "conv3x3 weight gradient (split-bf16 MFMA, dY-direct kernel)": ("conv_wgrad_adirect",),
+               "conv3x3 weight gradient (split-bf16 MFMA, wgrad3 kernel)": ("wgrad3_kernel", "conv_wgrad_adirect"),
                "conv1x1 weight gradient": ("wgrad1x1_direct",),
                "other weight gradients (staged fp32-MFMA kernel)": ("conv_wgrad_kernel",),
                "conv2d_1x1 (forward + data gradient)": ("conv1x1_",)}
