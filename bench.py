@@ -370,7 +370,7 @@ def main():
         # PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction of
         # the guide applied): collected by tools/pmc_traffic.py, committed under profiles/
         pmc = None
-        for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for fn in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             path = os.path.join(ROOT, "profiles", fn)
             if os.path.exists(path) and B == 8 and S == 2 and headline:
                 with open(path) as f:
