@@ -336,7 +336,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
 template <int MR, int TWN>
 __global__ __launch_bounds__(256, 2) void conv3x3_bx3_alds_kernel(
     const float* __restrict__ x, const __bf16* __restrict__ wt, const float* __restrict__ bias,
-    const float* residual, float* y, DlioConvDesc d, int tiles_w, int tiles_h, int co_tiles, int vec_out) {
+    const float* residual, float* y, DlioConvDesc d, int tiles_w, int tiles_h, int co_tiles, int vec_out, int ksplit,
+    float* __restrict__ slab) {
   constexpr int TH = 4, TW = 32 * TWN, PR = TH + 2, PC = TW + 2, NPOSP = PR * PC;
   constexpr int NPOS = (NPOSP + 255) / 256;
   constexpr int PLANE = NPOSP * 16;                      // bf16 per patch plane
@@ -351,6 +352,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_alds_kernel(
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
   int bid = xcd_block_index();
+  // K split over workgroups (slab != nullptr: long channel loops on small feature maps -- blk4 / blk5 data gradients fill
+  // half of the chip's workgroup slots or less): this workgroup takes chunks [kc_lo, kc_hi) and writes its partial tile
+  // to slab[ks] ([ks][n][co][pixel] fp32); slab_sum_kernel adds the slices in a fixed order + bias + residual
+  const int ks = slab ? bid % ksplit : 0;
+  if (slab) bid /= ksplit;
   const int cot = bid % co_tiles; bid /= co_tiles;
   const int tw = bid % tiles_w; bid /= tiles_w;
   const int th = bid % tiles_h;
@@ -358,6 +364,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_alds_kernel(
   const int co0 = cot * 32 * MR, oh0 = th * TH, ow0 = tw * TW;
   const int Cin = d.Cin, Cout = d.Cout, HW = d.H * d.W;
   const int KC = (Cin + 15) >> 4;
+  const int kc_lo = slab ? (int)((int64_t)KC * ks / ksplit) : 0, kc_hi = slab ? (int)((int64_t)KC * (ks + 1) / ksplit) : KC;
 
   // ---- patch staging (as conv3x3_bx3_kernel)
   bool pval[NPOS];
@@ -474,14 +481,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_alds_kernel(
   };
 
   // ---- pipeline: weight groups double-slotted, patch single-buffered
-  load_agroup(0, 0, 0);
-  load_patch(0);
-  store_patch(0);
+  load_agroup(kc_lo, 0, 0);
+  load_patch(kc_lo);
+  store_patch(kc_lo);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int gi = 0;                                            // running group index -> ring slot
-  for (int kc = 0; kc < KC; ++kc) {
-    const bool more = kc + 1 < KC;
+  for (int kc = kc_lo; kc < kc_hi; ++kc) {
+    const bool more = kc + 1 < kc_hi;
 #pragma unroll
     for (int g = 0; g < 3; ++g, ++gi) {
       const bool anext = g < 2 || more;
@@ -515,15 +522,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_alds_kernel(
         for (int r = 0; r < 16; ++r)
           wbuf[(32 * m + (r & 3) + 8 * (r >> 2) + 4 * half) * TWP + 32 * t + l31] = acc[m][t][r];
     constexpr int Q = TW / 4;
-    float* yrow = y + ((size_t)n * d.out_ctot + d.out_coff) * ohw + (size_t)oh * d.OW + ow0;
-    const float* rrow = residual ? residual + ((size_t)n * d.res_ctot + d.res_coff) * ohw + (size_t)oh * d.OW + ow0 : nullptr;
+    // (K split: the raw partial tile goes to this slice's slab, bias / residual are added by slab_sum_kernel)
+    float* yrow = slab ? slab + (((size_t)ks * d.N + n) * Cout) * ohw + (size_t)oh * d.OW + ow0
+                       : y + ((size_t)n * d.out_ctot + d.out_coff) * ohw + (size_t)oh * d.OW + ow0;
+    const float* rrow = (residual && !slab) ? residual + ((size_t)n * d.res_ctot + d.res_coff) * ohw + (size_t)oh * d.OW + ow0 : nullptr;
 #pragma unroll
     for (int i = 0; i < (32 * MR * Q) / 64; ++i) {
       const int idx = i * 64 + lane, cl = idx / Q, q = idx - cl * Q;
       const int co = co0 + cl;
       if (co >= Cout || ow0 + 4 * q >= d.OW) continue;
       float4 v = *reinterpret_cast<const float4*>(wbuf + cl * TWP + 4 * q);
-      const float bv = bias ? bias[co] : 0.f;
+      const float bv = (bias && !slab) ? bias[co] : 0.f;
       v.x += bv; v.y += bv; v.z += bv; v.w += bv;
       if (rrow) {
         const float4 rv = *reinterpret_cast<const float4*>(rrow + (size_t)co * ohw + 4 * q);
@@ -752,10 +761,11 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
 
 template <int MR, int TWN>
 int launch_bx3_alds(const float* x, const __bf16* wt, const float* bias, const float* residual, float* y,
-                    const DlioConvDesc& d, hipStream_t s) {
+                    const DlioConvDesc& d, hipStream_t s, int ksplit = 1, float* slab = nullptr) {
   constexpr int TH = 4, TW = 32 * TWN;
   const int tiles_w = cdiv(d.OW, TW), tiles_h = cdiv(d.OH, TH), co_tiles = cdiv(d.Cout, 32 * MR);
-  const int64_t blocks = (int64_t)d.N * tiles_h * tiles_w * co_tiles;
+  if (!slab) ksplit = 1;
+  const int64_t blocks = (int64_t)d.N * tiles_h * tiles_w * co_tiles * ksplit;
   if (blocks <= 0 || blocks > 0x7fffffff) return DLIO_EINVAL;
   const size_t patch_b = (size_t)3 * (TH + 2) * (TW + 2) * 16 * sizeof(__bf16);
   const size_t ring_b = (size_t)2 * 3 * 3 * 32 * MR * 16 * sizeof(__bf16);
@@ -770,8 +780,9 @@ int launch_bx3_alds(const float* x, const __bf16* wt, const float* bias, const f
   static const int vec_on = getenv("DLIO_BX3_VEC_OUT") ? atoi(getenv("DLIO_BX3_VEC_OUT")) : 1;
   const int vec_out = vec_on && (d.OW & 3) == 0 && (((size_t)d.OH * d.OW) & 3) == 0 &&
                       ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0 && epi_b <= lds;
+  if (slab && !vec_out) return DLIO_EUNSUP;              // (the caller only splits when the float4 store path applies)
   hipLaunchKernelGGL((conv3x3_bx3_alds_kernel<MR, TWN>), dim3((unsigned)blocks), dim3(256), lds, s, x, wt, bias, residual, y,
-                     d, tiles_w, tiles_h, co_tiles, vec_out);
+                     d, tiles_w, tiles_h, co_tiles, vec_out, ksplit, slab);
   return dlio_check_launch();
 }
 
@@ -948,8 +959,43 @@ extern "C" int dlio_conv3x3_bx3_prep_batched(const DlioPrepItem* items_dev, int 
   return dlio_check_launch();
 }
 
-extern "C" int dlio_conv3x3_bx3_fwd(const float* x, const void* wt, const float* bias, const float* residual,
-                                    float* y, const DlioConvDesc* dp, dlio_stream_t stream) {
+// the tile a layer gets when workgroup count is no concern
+static void bx3_3x3_shape_large(const DlioConvDesc& d, int& mr, int& twn) {
+  static const int twn_cin = getenv("DLIO_BX3_TWN_CIN") ? atoi(getenv("DLIO_BX3_TWN_CIN")) : 48;
+  mr = d.Cout <= 32 ? 1 : 2;
+  twn = (d.OW > 32 && d.Cin >= twn_cin) ? 2 : 1;
+}
+
+// K split over workgroups for long channel loops on small feature maps (1 = none): even the narrowed tile of
+// bx3_3x3_shape fills at most 3/4 of the chip's workgroup slots (two per CU); the split launch then runs the LARGE tile
+// with the channel loop cut in slices of at least three 16-channel chunks.  (blk5 data gradient 384 -> 80 @16x32: 67 -> 48 us;
+// blk4's 256 -> 64 @32x64 fills the slots with 32 x 32 tiles already and gains nothing from 2-8 slices: 62-72 us.)
+static int bx3_3x3_ksplit(const DlioConvDesc& d) {
+  static const int maxks = getenv("DLIO_BX3_3X3_KSPLIT") ? atoi(getenv("DLIO_BX3_3X3_KSPLIT")) : 8;    // 0 / 1: off
+  if (maxks < 2) return 1;
+  const int KC = (d.Cin + 15) / 16;
+  auto nblocks = [&](int m, int t) { return (int64_t)d.N * cdiv(d.OH, 4) * cdiv(d.OW, 32 * t) * cdiv(d.Cout, 32 * m); };
+  int mr, twn;
+  bx3_3x3_shape(d, mr, twn);
+  const int64_t slots = 2 * (int64_t)dlio_num_cus();
+  if (KC < 6 || nblocks(mr, twn) * 4 > slots * 3 || (d.OW & 3) || (((size_t)d.OH * d.OW) & 3)) return 1;
+  bx3_3x3_shape_large(d, mr, twn);
+  const int64_t blocks = nblocks(mr, twn);
+  int ks = (int)((slots + blocks - 1) / blocks);
+  if (ks > KC / 3) ks = KC / 3;
+  if (ks > maxks) ks = maxks;
+  return ks < 2 ? 1 : ks;
+}
+
+extern "C" size_t dlio_conv3x3_bx3_ws_bytes(const DlioConvDesc* dp) {
+  if (!dp || dp->KH != 3 || dp->KW != 3 || dp->SH != 1 || dp->SW != 1) return 0;
+  if ((size_t)9 * ((dp->Cin + 15) / 16) * 3 * dp->Cout * 32 >= 0x7fffffffull) return 0;
+  const int ks = bx3_3x3_ksplit(*dp);
+  return ks < 2 ? 0 : (size_t)ks * dp->N * dp->Cout * dp->OH * dp->OW * sizeof(float);
+}
+
+extern "C" int dlio_conv3x3_bx3_fwd_ws(const float* x, const void* wt, const float* bias, const float* residual,
+                                       float* y, void* ws, size_t ws_bytes, const DlioConvDesc* dp, dlio_stream_t stream) {
   if (!x || !wt || !y || !dp) return DLIO_EINVAL;
   const DlioConvDesc& d = *dp;
   if (d.KH != 3 || d.KW != 3 || d.SH != 1 || d.SW != 1) return DLIO_EUNSUP;
@@ -967,15 +1013,35 @@ extern "C" int dlio_conv3x3_bx3_fwd(const float* x, const void* wt, const float*
   // weight fragments through LDS (conv3x3_bx3_alds_kernel)
   // (DLIO_BX3_ALDS: 0 off, 1 the 64-channel tiles only, 2 = default all tiles: 25.39 / 25.61 / 26.3 ms for 2 / 1 / 0)
   static const int alds = getenv("DLIO_BX3_ALDS") ? atoi(getenv("DLIO_BX3_ALDS")) : 2;
-  const bool use_alds = alds && (size_t)9 * ((d.Cin + 15) / 16) * 3 * d.Cout * 32 < 0x7fffffffull &&
-                        (alds == 2 || mr == 2);
-#define L3(MRV, TWV) (use_alds ? launch_bx3_alds<MRV, TWV>(x, w, bias, residual, y, d, s) \
+  bool use_alds = alds && (size_t)9 * ((d.Cin + 15) / 16) * 3 * d.Cout * 32 < 0x7fffffffull && (alds == 2 || mr == 2);
+  // K split: the LARGE tile (which bx3_3x3_shape gave up to get more workgroups) with the channel loop cut in slices
+  int mrs, twns;
+  bx3_3x3_shape_large(d, mrs, twns);
+  int ksplit = alds ? bx3_3x3_ksplit(d) : 1;
+  const size_t ohw = (size_t)d.OH * d.OW;
+  if (ksplit > 1 && (!ws || ws_bytes < (size_t)ksplit * d.N * d.Cout * ohw * sizeof(float) ||
+                     ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(ws)) & 15)))
+    ksplit = 1;
+  if (ksplit > 1) { mr = mrs; twn = twns; use_alds = true; }
+  float* slab = ksplit > 1 ? reinterpret_cast<float*>(ws) : nullptr;
+#define L3(MRV, TWV) (use_alds ? launch_bx3_alds<MRV, TWV>(x, w, bias, residual, y, d, s, ksplit, slab) \
                                : launch_bx3<MRV, TWV>(x, w, bias, residual, y, d, s))
   if (mr == 1) rc = twn == 2 ? L3(1, 2) : L3(1, 1);
   else rc = twn == 2 ? L3(2, 2) : L3(2, 1);
 #undef L3
+  if (!rc && slab) {
+    const int64_t total = (int64_t)d.N * d.Cout * (int64_t)(ohw / 4);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, s, slab, ksplit, d.N, d.Cout, (int)(ohw / 4), bias,
+                       residual, d.res_ctot, d.res_coff, y, d.out_ctot, d.out_coff);
+    rc = dlio_check_launch();
+  }
   dlio_prof_end(3, s);
   return rc;
+}
+
+extern "C" int dlio_conv3x3_bx3_fwd(const float* x, const void* wt, const float* bias, const float* residual,
+                                    float* y, const DlioConvDesc* dp, dlio_stream_t stream) {
+  return dlio_conv3x3_bx3_fwd_ws(x, wt, bias, residual, y, nullptr, 0, dp, stream);
 }
 
 // 3x5 taps, stride (1, 2) (the PointSeg stem, pointseg_net.py:18-20: 2C -> 64 channels at 64 x 2048 -> 64 x 1024) on the

@@ -327,19 +327,30 @@ __device__ __forceinline__ float f4e(const float4& v, int i) {
   return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
 }
 
-// ---- stride-1 multi-tap weight gradient with the dY operand straight from global memory ----
-
 typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wg_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int wg_u32x4 __attribute__((ext_vector_type(4)));
 
-// x = hi + mid + lo in bf16 pieces (see conv_bx3.hip): eight values -> three MFMA fragments
+// x = hi + mid + lo in bf16 pieces (see conv_bx3.hip): eight values -> three MFMA fragments, pair by pair as in
+// conv_wgrad3.hip (v_cvt_pk_bf16_f32 rounds two values at once; a bf16 widens to fp32 by a shift / a mask of the
+// packed dword): 11 VALU per pair instead of 7 per value, the same roundings
+__device__ __forceinline__ unsigned wg_cvt_pk(float a, float b) {
+  return __builtin_bit_cast(unsigned, wg_bf16x2{(__bf16)a, (__bf16)b});
+}
+__device__ __forceinline__ float wg_as_f(unsigned u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ void wg_split8(const float (&v)[8], wg_bf16x8& h, wg_bf16x8& m, wg_bf16x8& l) {
+  unsigned hh[4], mm[4], ll[4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const __bf16 hh = (__bf16)v[j];
-    const float r = v[j] - (float)hh;
-    const __bf16 mm = (__bf16)r;
-    h[j] = hh; m[j] = mm; l[j] = (__bf16)(r - (float)mm);
+  for (int j = 0; j < 4; ++j) {
+    const float a = v[2 * j], b = v[2 * j + 1];
+    hh[j] = wg_cvt_pk(a, b);
+    const float ra = a - wg_as_f(hh[j] << 16), rb = b - wg_as_f(hh[j] & 0xffff0000u);
+    mm[j] = wg_cvt_pk(ra, rb);
+    ll[j] = wg_cvt_pk(ra - wg_as_f(mm[j] << 16), rb - wg_as_f(mm[j] & 0xffff0000u));
   }
+  h = __builtin_bit_cast(wg_bf16x8, wg_u32x4{hh[0], hh[1], hh[2], hh[3]});
+  m = __builtin_bit_cast(wg_bf16x8, wg_u32x4{mm[0], mm[1], mm[2], mm[3]});
+  l = __builtin_bit_cast(wg_bf16x8, wg_u32x4{ll[0], ll[1], ll[2], ll[3]});
 }
 
 // ---- 1x1 stride-1 weight gradient straight from global memory -------------------------------

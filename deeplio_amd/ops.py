@@ -283,8 +283,10 @@ def conv1x1_bx3_fwd(x, wt, bias, y, desc, residual=None, in_aff=None):
 
 
 def conv3x3_bx3_fwd(x, wt, bias, y, desc, residual=None):
-    check(lib.dlio_conv3x3_bx3_fwd(_ptr(x), _ptr(wt), _ptr(bias), _ptr(residual), _ptr(y), C.byref(desc), _stream()),
-          "conv3x3_bx3_fwd")
+    nbytes = lib.dlio_conv3x3_bx3_ws_bytes(C.byref(desc))
+    ws = workspace(nbytes, x.device, slot=4) if nbytes else None       # K split over workgroups (small feature maps)
+    check(lib.dlio_conv3x3_bx3_fwd_ws(_ptr(x), _ptr(wt), _ptr(bias), _ptr(residual), _ptr(y), _ptr(ws),
+                                      ws.numel() if ws is not None else 0, C.byref(desc), _stream()), "conv3x3_bx3_fwd")
     return y
 
 

@@ -156,6 +156,13 @@ int dlio_conv1x1_bx3_fwd_ws(const float* x, const void* wt, const float* bias, c
                             const float* in_scale, const float* in_shift, const float* residual,
                             float* y, void* ws, size_t ws_bytes, const DlioConvDesc* desc,
                             dlio_stream_t stream);
+/* dlio_conv3x3_bx3_fwd with scratch: long channel loops on small feature maps (>= 6 chunks of 16 channels, a launch that
+ * fills at most 3/4 of the chip's workgroup slots: the blk4 / blk5 data gradients) split their channel loop over
+ * workgroups, write fp32 partial tiles to ws and sum them (fixed order, + bias + residual) in a second launch.
+ * dlio_conv3x3_bx3_ws_bytes(desc) = bytes that split wants (0: unsplit); with less (or ws NULL) the call runs unsplit. */
+size_t dlio_conv3x3_bx3_ws_bytes(const DlioConvDesc* desc);
+int dlio_conv3x3_bx3_fwd_ws(const float* x, const void* wt, const float* bias, const float* residual, float* y,
+                            void* ws, size_t ws_bytes, const DlioConvDesc* desc, dlio_stream_t stream);
 size_t dlio_conv3x3_bx3_prep_floats(int Cout, int Cin, int mode);
 int dlio_conv3x3_bx3_prep(const float* w, void* wt, int Cout, int Cin, int mode, dlio_stream_t stream);
 /* every split-bf16 layout of a model in one launch (DlioPrepItem as for dlio_conv2d_prep_weights_batched;

@@ -1037,3 +1037,38 @@ def test_bn_bwd_pool_matches_pool_backward_then_bn_backward(dev, sh, H):
     dg2, db2 = torch.ones(C_, device=dev), torch.ones(C_, device=dev)
     ops.bn_bwd_pool(dyp, idx, raw, prm, beta, dx, sh, dg2, db2, accumulate=True)
     assert rel_err(dg2 - 1.0, dg_ref) < 1e-5 and rel_err(db2 - 1.0, db_ref) < 1e-5
+
+
+@pytest.mark.parametrize("case", [(16, 384, 80, 16, 32), (16, 256, 64, 32, 64), (4, 200, 24, 8, 32), (2, 96, 40, 12, 36)])
+def test_conv3x3_split_bf16_k_split_over_workgroups(dev, case):
+    """long channel loops on small feature maps (the blk4 / blk5 data gradients: 256 -> 64 @32x64, 384 -> 80 @16x32 fill half
+    of the chip's workgroup slots or less): dlio_conv3x3_bx3_fwd_ws splits the channel loop over workgroups, fp32 partial
+    tiles summed in a second launch with bias + residual into a channel slice; same result as the unsplit kernel's to
+    rounding, fp64 error as everywhere; without scratch the call runs unsplit"""
+    from deeplio_amd import ops
+    from deeplio_amd._lib import lib
+    import ctypes as C
+    N, Cin, Cout, H, W = case
+    g = _g(57)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(N, Cout + 2, H, W, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1) + res[:, 1:1 + Cout].double()
+    d = ops.conv_desc(N, Cin, H, W, Cout, 3, 3, 1, 1, 1, 1, out_ctot=Cout + 3, out_coff=2, res_ctot=Cout + 2, res_coff=1)
+    wt = ops.conv3x3_bx3_prep(w.to(dev), 0)
+    y = torch.zeros(N, Cout + 3, H, W, device=dev)
+    ops.conv3x3_bx3_fwd(x.to(dev), wt, b.to(dev), y, d, residual=res.to(dev))
+    split = lib.dlio_conv3x3_bx3_ws_bytes(C.byref(d)) > 0
+    if case == (16, 384, 80, 16, 32):
+        assert split                       # blk5's data gradient: 192 workgroups of 32 x 32 tiles on 512 slots
+    if case == (16, 256, 64, 32, 64):
+        assert not split                   # blk4's fills the slots with its narrowed tile
+    assert rel_err(y[:, 2:2 + Cout], ref) < 3e-6
+    assert float(y[:, :2].abs().max()) == 0 and float(y[:, 2 + Cout:].abs().max()) == 0
+    y0 = torch.zeros_like(y)             # no scratch: unsplit
+    xd, bd, rd = x.to(dev), b.to(dev), res.to(dev)
+    ops.check(lib.dlio_conv3x3_bx3_fwd(ops._ptr(xd), ops._ptr(wt), ops._ptr(bd), ops._ptr(rd), ops._ptr(y0), C.byref(d),
+                                       ops._stream()), "conv3x3_bx3_fwd")
+    torch.cuda.synchronize()
+    assert rel_err(y0[:, 2:2 + Cout], ref) < 3e-6 and rel_err(y, y0.double()) < 2e-6
