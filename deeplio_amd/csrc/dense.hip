@@ -77,6 +77,102 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
   }
 }
 
+// ---- skinny-M forward with the activations in LDS (the recurrent / projection layers of the odometry LSTM, M = 8 / 16 rows
+// against 4096 x 1024..2048 weights): the wave-per-feature kernel above re-reads all M rows of x from L1 / L2 for every
+// output feature (8x the weight bytes); here a workgroup stages x once ([M][K] floats, <= 128 KB), a wave streams the
+// weight rows of FOUR features at a time (four 16-byte loads in flight per lane and k block) and the 4 MROWS partial sums
+// of a lane are reduced over the wave by halving exchanges (reduce-scatter: 4 MROWS - 1 shuffles instead of 6 per value;
+// lane i ends with value i), fixed order.
+template <int MROWS>
+__global__ __launch_bounds__(256) void linear_fwd_skinny_kernel(
+    const float* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ b,
+    const float* __restrict__ addend, int ldadd, float* __restrict__ y, int ldy, int M, int N, int K, int act) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];          // [MROWS][K]
+  constexpr int NV = 4 * MROWS;                                         // values per lane: (feature u, row m)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int K4 = K >> 2;
+  const int groups = (N + 3) >> 2;
+  // weight rows: two k steps (2 x 4 features x 16 bytes per lane) per register set, the next set prefetched while the
+  // current one is multiplied; the first set of the first group is in flight while x is staged
+  float4 wa[2][4], wb[2][4];
+  const float* wr[4];
+  auto rows_of = [&](int g) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wr[u] = w + (size_t)min(g * 4 + u, N - 1) * K;
+  };
+  auto load_w = [&](float4 (&wv)[2][4], int kb) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int k = kb + c * 256 + lane * 4;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        wv[c][u] = k < K ? *reinterpret_cast<const float4*>(wr[u] + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  int g = blockIdx.x * 4 + wave;
+  if (g < groups) { rows_of(g); load_w(wa, 0); }
+  for (int i = threadIdx.x; i < MROWS * K4; i += 256) {
+    const int m = i / K4, k4 = i - m * K4;
+    reinterpret_cast<float4*>(xs)[i] = m < M ? *reinterpret_cast<const float4*>(x + (size_t)m * ldx + 4 * k4)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  float v[NV];
+  auto mul_w = [&](const float4 (&wv)[2][4], int kb) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int k = min(kb + c * 256 + lane * 4, K - 4);   // past K the weights are zero, the read stays inside xs
+#pragma unroll
+      for (int m = 0; m < MROWS; ++m) {
+        const float4 xv = *reinterpret_cast<const float4*>(xs + m * K + k);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          v[u * MROWS + m] += (wv[c][u].x * xv.x + wv[c][u].y * xv.y) + (wv[c][u].z * xv.z + wv[c][u].w * xv.w);
+      }
+    }
+  };
+  bool first = true;
+  for (; g < groups; g += gridDim.x * 4) {
+    const int n0 = g * 4;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = 0.f;
+    if (!first) { rows_of(g); load_w(wa, 0); }
+    first = false;
+    for (int kb = 0; kb < K; kb += 1024) {
+      if (kb + 512 < K) load_w(wb, kb + 512);
+      mul_w(wa, kb);
+      if (kb + 512 < K) {
+        if (kb + 1024 < K) load_w(wa, kb + 1024);
+        mul_w(wb, kb + 512);
+      }
+    }
+    // reduce-scatter over the wave: after the step with offset o a lane keeps the half of its values selected by its
+    // bit o; NV = 64: lane i ends with the wave sum of value i; NV = 32: offsets 16..1, then one pair sum over offset 32
+    int cnt = NV;
+#pragma unroll
+    for (int o = (NV == 64 ? 32 : 16); o >= 1; o >>= 1) {
+      const int hcnt = cnt >> 1;
+      const bool up = (lane & o) != 0;
+#pragma unroll
+      for (int i = 0; i < NV / 2; ++i) {
+        if (i < hcnt) {
+          const float send = up ? v[i] : v[i + hcnt], keep = up ? v[i + hcnt] : v[i];
+          v[i] = keep + __shfl_xor(send, o, 64);
+        }
+      }
+      cnt = hcnt;
+    }
+    float r = v[0];
+    if (NV == 32) r += __shfl_xor(r, 32, 64);
+    const int idx = lane & (NV - 1), u = idx / MROWS, m = idx - u * MROWS, n = n0 + u;
+    if ((NV == 64 || lane < 32) && n < N && m < M) {
+      float o = r + (b ? b[n] : 0.f);
+      if (addend) o += addend[(size_t)m * ldadd + n];
+      y[(size_t)m * ldy + n] = act_fwd(o, act);
+    }
+  }
+}
+
 __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                float* __restrict__ dz, int64_t n, int act) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
@@ -156,54 +252,98 @@ __global__ __launch_bounds__(256) void linear_bwd_data_kernel(
 }
 
 // ---- data gradient, weight-streaming form for large N*K (the 1024-wide odometry LSTM):
-// every block walks a chunk of W's rows (coalesced float4 row reads, each weight byte read
-// once) and keeps its partial dx[16][4 columns per thread] in registers; partials go to the
-// caller's workspace and are summed in a fixed order.
+// a block owns 256 columns k (one float4 per lane) and a slab of `per` weight rows; its four waves take the slab's rows in
+// interleaved groups of eight (eight coalesced 16-byte row loads in flight per lane, the next group prefetched while the
+// current one is multiplied), the dz slab sits in LDS (broadcast reads), the four wave partials are combined through LDS in
+// a fixed order and ONE partial per block goes to the caller's workspace ([nsplit][M][K]); linear_bwd_data_reduce_kernel
+// sums the slabs in slab order.  Each weight byte is read once; the workspace traffic is nsplit*M*K*8 bytes.
+constexpr int DG_PER_MAX = 128;
+template <int MROWS>
 __global__ __launch_bounds__(256) void linear_bwd_data_split_kernel(
     const float* __restrict__ dz, int lddz, const float* __restrict__ w, float* __restrict__ part,
     int M, int N, int K, int m0, int nsplit) {
-  const int k = (blockIdx.x * 256 + threadIdx.x) * 4;
+  __shared__ __attribute__((aligned(16))) float sdz[MROWS][DG_PER_MAX];
+  __shared__ float4 red[3][MROWS][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int k = (blockIdx.x * 64 + lane) * 4;
+  const int kc = k < K ? k : K - 4;
   const int sp = blockIdx.y;
-  const int per = (N + nsplit - 1) / nsplit;
+  const int per = (N + nsplit - 1) / nsplit;           // <= DG_PER_MAX (launcher)
   const int n_lo = sp * per, n_hi = min(N, n_lo + per);
-  float acc[BM][4];
+  float4 wa[8], wb[8];
+  auto load_rows = [&](float4 (&wv)[8], int r) {        // r = slab-relative first row of the group
 #pragma unroll
-  for (int j = 0; j < BM; ++j) { acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.f; }
-  if (k < K) {
-    for (int n = n_lo; n < n_hi; ++n) {
-      const float4 wv = *reinterpret_cast<const float4*>(w + (size_t)n * K + k);
+    for (int u = 0; u < 8; ++u) {
+      const int n = n_lo + r + u;
+      wv[u] = n < n_hi ? *reinterpret_cast<const float4*>(w + (size_t)n * K + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  load_rows(wa, wave * 8);                              // in flight while the dz slab is staged
+  for (int i = threadIdx.x; i < MROWS * DG_PER_MAX; i += 256) {
+    const int j = i / DG_PER_MAX, r = i - j * DG_PER_MAX, n = n_lo + r;
+    sdz[j][r] = (m0 + j < M && n < n_hi) ? dz[(size_t)(m0 + j) * lddz + n] : 0.f;
+  }
+  float4 acc[MROWS];
 #pragma unroll
-      for (int j = 0; j < BM; ++j) {
-        if (m0 + j < M) {
-          const float a = dz[(size_t)(m0 + j) * lddz + n];
-          acc[j][0] += a * wv.x; acc[j][1] += a * wv.y; acc[j][2] += a * wv.z; acc[j][3] += a * wv.w;
-        }
+  for (int j = 0; j < MROWS; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  auto mul_rows = [&](const float4 (&wv)[8], int r) {
+#pragma unroll
+    for (int j = 0; j < MROWS; ++j) {
+      const float4 d0 = *reinterpret_cast<const float4*>(&sdz[j][r]);
+      const float4 d1 = *reinterpret_cast<const float4*>(&sdz[j][r + 4]);
+      const float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        acc[j].x += d[u] * wv[u].x; acc[j].y += d[u] * wv[u].y; acc[j].z += d[u] * wv[u].z; acc[j].w += d[u] * wv[u].w;
       }
     }
+  };
+  for (int r = wave * 8; r < per; r += 64) {             // two groups per trip (register double buffer, static indices)
+    if (r + 32 < per) load_rows(wb, r + 32);
+    mul_rows(wa, r);
+    if (r + 32 < per) {
+      if (r + 64 < per) load_rows(wa, r + 64);
+      mul_rows(wb, r + 32);
+    }
+  }
+  if (wave) {
 #pragma unroll
-    for (int j = 0; j < BM; ++j)
-      *reinterpret_cast<float4*>(part + ((size_t)sp * BM + j) * K + k) =
-          make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+    for (int j = 0; j < MROWS; ++j) red[wave - 1][j][lane] = acc[j];
+  }
+  __syncthreads();
+  if (wave == 0 && k < K) {
+    const int rows = min(MROWS, M - m0);
+#pragma unroll
+    for (int j = 0; j < MROWS; ++j) {
+      if (j < rows) {
+        const float4 a = red[0][j][lane], b = red[1][j][lane], c = red[2][j][lane];
+        float4 o;
+        o.x = ((acc[j].x + a.x) + b.x) + c.x; o.y = ((acc[j].y + a.y) + b.y) + c.y;
+        o.z = ((acc[j].z + a.z) + b.z) + c.z; o.w = ((acc[j].w + a.w) + b.w) + c.w;
+        *reinterpret_cast<float4*>(part + ((size_t)sp * rows + j) * K + k) = o;
+      }
+    }
   }
 }
 
 __global__ void linear_bwd_data_reduce_kernel(const float* __restrict__ part, float* __restrict__ dx,
-                                              int lddx, int M, int K, int m0, int nsplit,
+                                              int lddx, int rows, int K, int m0, int nsplit,
                                               int accumulate) {
-  const int total = BM * K;
+  const int total = rows * K;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int j = i / K, k = i - j * K;
-    if (m0 + j >= M) continue;
     float s = 0.f;
     int sp = 0;
     for (; sp + 8 <= nsplit; sp += 8) {        // 8 loads in flight, same summation order
       float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = part[((size_t)(sp + u) * BM + j) * K + k];
+      for (int u = 0; u < 8; ++u) v[u] = part[((size_t)(sp + u) * rows + j) * K + k];
 #pragma unroll
       for (int u = 0; u < 8; ++u) s += v[u];
     }
-    for (; sp < nsplit; ++sp) s += part[((size_t)sp * BM + j) * K + k];
+    for (; sp < nsplit; ++sp) s += part[((size_t)sp * rows + j) * K + k];
     float* p = dx + (size_t)(m0 + j) * lddx + k;
     *p = accumulate ? *p + s : s;
   }
@@ -211,10 +351,11 @@ __global__ void linear_bwd_data_reduce_kernel(const float* __restrict__ part, fl
 
 static int bwd_data_nsplit(int N, int K) {
   if ((K & 3) != 0 || (int64_t)N * K < (1 << 18)) return 0;   // small problems: direct kernel
-  const int kblocks = (K / 4 + 255) / 256;
-  int ns = 768 / kblocks;
-  if (ns > N / 8) ns = N / 8;
-  if (ns > 256) ns = 256;
+  const int kblocks = (K / 4 + 63) / 64;
+  int ns = (2 * dlio_num_cus()) / kblocks;                     // about two workgroups per CU
+  if (ns > N / 32) ns = N / 32;                                // at least eight rows per wave
+  const int floor_ns = (N + DG_PER_MAX - 1) / DG_PER_MAX;      // slab fits the LDS tile
+  if (ns < floor_ns) ns = floor_ns;
   return ns < 2 ? 0 : ns;
 }
 
@@ -237,6 +378,35 @@ __global__ __launch_bounds__(256) void linear_bwd_weight_kernel(
     if (n0 + j < N) {
       float* p = dw + (size_t)(n0 + j) * K + k;
       *p = accumulate ? *p + acc[j] : acc[j];
+    }
+  }
+}
+
+// 16-byte form (K % 4 == 0): thread per (4 n, 4 k) -- the x row is one float4 load per sample and serves four weight rows,
+// dW is read (accumulate) and written as float4
+__global__ __launch_bounds__(256) void linear_bwd_weight_v4_kernel(
+    const float* __restrict__ dz, int lddz, const float* __restrict__ x, int ldx,
+    float* __restrict__ dw, int M, int N, int K, int accumulate) {
+  const int k = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int n0 = blockIdx.y * 4;
+  if (k >= K) return;
+  float4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int m = 0; m < M; ++m) {
+    const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)m * ldx + k);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = n0 + j < N ? dz[(size_t)m * lddz + n0 + j] : 0.f;
+      acc[j].x += a * xv.x; acc[j].y += a * xv.y; acc[j].z += a * xv.z; acc[j].w += a * xv.w;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (n0 + j < N) {
+      float4* p = reinterpret_cast<float4*>(dw + (size_t)(n0 + j) * K + k);
+      if (accumulate) { const float4 o = *p; acc[j].x += o.x; acc[j].y += o.y; acc[j].z += o.z; acc[j].w += o.w; }
+      *p = acc[j];
     }
   }
 }
@@ -497,6 +667,26 @@ extern "C" int dlio_linear_fwd(const float* x, int ldx, const float* w, const fl
                        w, b, addend, ldadd, y, ldy, M, N, K, act, kvec);
     return dlio_check_launch();
   }
+  // skinny M against a large weight matrix (the odometry LSTM): x staged once per workgroup
+  static const int skinny = getenv("DLIO_LINEAR_SKINNY") ? atoi(getenv("DLIO_LINEAR_SKINNY")) : 1;
+  if (skinny && M <= 16 && (K & 3) == 0 && (ldx & 3) == 0 && (int64_t)N * K >= (1 << 18) &&
+      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15) == 0) {
+    const int mrows = M <= 8 ? 8 : 16;
+    const size_t lds = (size_t)mrows * K * sizeof(float);
+    if (lds <= 128 * 1024) {
+      int grid = cdiv(cdiv(N, 4), 4);
+      if (grid > 2 * dlio_num_cus()) grid = 2 * dlio_num_cus();
+      auto kern = mrows == 8 ? linear_fwd_skinny_kernel<8> : linear_fwd_skinny_kernel<16>;
+      static bool attr8 = false, attr16 = false;
+      bool& done = mrows == 8 ? attr8 : attr16;
+      if (!done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        done = true;
+      }
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, as_stream(stream), x, ldx, w, b, addend, ldadd, y, ldy, M, N, K, act);
+      return dlio_check_launch();
+    }
+  }
   int grid = cdiv(N, 4);
   if (grid > 8192) grid = 8192;
   hipLaunchKernelGGL(linear_fwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, ldx, w, b,
@@ -528,10 +718,15 @@ extern "C" int dlio_linear_bwd_data(const float* dz, int lddz, const float* w, f
   if (ns && aligned && ws && ws_bytes >= (size_t)ns * BM * K * sizeof(float)) {
     float* part = reinterpret_cast<float*>(ws);
     for (int m0 = 0; m0 < M; m0 += BM) {
-      hipLaunchKernelGGL(linear_bwd_data_split_kernel, dim3((K / 4 + 255) / 256, ns), dim3(256), 0, s,
-                         dz, lddz, w, part, M, N, K, m0, ns);
-      hipLaunchKernelGGL(linear_bwd_data_reduce_kernel, dim3(cdiv(BM * K, 256)), dim3(256), 0, s, part,
-                         dx, lddx, M, K, m0, ns, accumulate);
+      const int rows = M - m0 < BM ? M - m0 : BM;
+      if (rows <= 8)
+        hipLaunchKernelGGL(linear_bwd_data_split_kernel<8>, dim3((K / 4 + 63) / 64, ns), dim3(256), 0, s, dz, lddz, w, part,
+                           M, N, K, m0, ns);
+      else
+        hipLaunchKernelGGL(linear_bwd_data_split_kernel<BM>, dim3((K / 4 + 63) / 64, ns), dim3(256), 0, s, dz, lddz, w, part,
+                           M, N, K, m0, ns);
+      hipLaunchKernelGGL(linear_bwd_data_reduce_kernel, dim3(cdiv(rows * K, 256)), dim3(256), 0, s, part,
+                         dx, lddx, rows, K, m0, ns, accumulate);
     }
     return dlio_check_launch();
   }
@@ -551,8 +746,13 @@ extern "C" int dlio_linear_bwd_weight(const float* dz, int lddz, const float* x,
                        db, M, N, K, accumulate);
     return dlio_check_launch();
   }
-  hipLaunchKernelGGL(linear_bwd_weight_kernel, dim3(cdiv(K, 256), cdiv(N, 4)), dim3(256), 0, s, dz,
-                     lddz, x, ldx, dw, M, N, K, accumulate);
+  if ((K & 3) == 0 && (ldx & 3) == 0 && K >= 256 &&
+      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dw)) & 15) == 0)
+    hipLaunchKernelGGL(linear_bwd_weight_v4_kernel, dim3(cdiv(K / 4, 256), cdiv(N, 4)), dim3(256), 0, s, dz, lddz, x, ldx, dw,
+                       M, N, K, accumulate);
+  else
+    hipLaunchKernelGGL(linear_bwd_weight_kernel, dim3(cdiv(K, 256), cdiv(N, 4)), dim3(256), 0, s, dz,
+                       lddz, x, ldx, dw, M, N, K, accumulate);
   int rc = dlio_check_launch();
   if (rc) return rc;
   if (db) {
