@@ -26,6 +26,18 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print("issue %.2f ms/step, wall %.2f ms/step" % (1e3 * (t1 - t0) / N, 1e3 * (t2 - t0) / N))
+if "--st" in sys.argv:                 # backward on the calling thread: cProfile sees the backward functions too
+    torch.autograd.set_multithreading_enabled(False)
+    for _ in range(3):
+        ts.step(*batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(N):
+        ts.step(*batch)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print("single-threaded autograd: issue %.2f ms/step, wall %.2f ms/step" % (1e3 * (t1 - t0) / N, 1e3 * (t2 - t0) / N))
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(N):
@@ -33,4 +45,4 @@ for _ in range(N):
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(35)
+st.sort_stats("tottime").print_stats(60)
