@@ -751,6 +751,60 @@ int launch_1x1(const float* x, const float* dy, float* dw, float* wsp, const Dli
   return dlio_check_launch();
 }
 
+// ---- 3x5 taps, stride (1, 2), padding (1, 2) (the PointSeg stem, pointseg_net.py:18-20; FlowNet conv2 / conv3,
+// lidar_feat_nets.py:248-251) through the 3x3 stride-1 kernel: input column 2 ow + kw - 2 is column ow + kw/2 - 1 of the
+// EVEN-column image for even kw and column ow + (kw-1)/2 - 1 of the ODD-column image for odd kw, i.e. the five column taps
+// are the three taps of a "same" 3x3 correlation with the even image plus the first two of one with the odd image.  The
+// input is split into its two column phases once (one pass, 16-byte accesses), wgrad3_kernel runs on each, and the merge
+// scatters the two [Cout][Cin][3][3] sums into dW[Cout][Cin][3][5] (the odd phase's third column tap is a tap the layer
+// does not have: computed and dropped, 18 taps of MFMA work for 15).
+__global__ __launch_bounds__(256) void deinterleave_cols_kernel(const float* __restrict__ x, float* __restrict__ xe,
+                                                                float* __restrict__ xo, int64_t rows, int W8, int64_t in_row_stride_c,
+                                                                int Cin, int in_ctot, int in_coff, int H) {
+  // one thread: 8 consecutive input columns of one row -> 4 even + 4 odd
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * W8) return;
+  const int64_t row = i / W8;                 // (n * Cin + c) * H + h over the DENSE phase images
+  const int q = (int)(i - row * W8);
+  const int64_t nc = row / H;
+  const int h = (int)(row - nc * H);
+  const int64_t n = nc / Cin;
+  const int c = (int)(nc - n * Cin);
+  const float* src = x + (((size_t)n * in_ctot + in_coff + c) * H + h) * (size_t)(8 * W8) + 8 * q;
+  (void)in_row_stride_c;
+  const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+  *reinterpret_cast<float4*>(xe + (size_t)row * (4 * W8) + 4 * q) = make_float4(a.x, a.z, b.x, b.z);
+  *reinterpret_cast<float4*>(xo + (size_t)row * (4 * W8) + 4 * q) = make_float4(a.y, a.w, b.y, b.w);
+}
+
+__global__ __launch_bounds__(256) void wgrad_merge_3x5_kernel(const float* __restrict__ te, const float* __restrict__ to,
+                                                              float* __restrict__ dw, int64_t n15, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n15) return;
+  const int64_t cc = i / 15;
+  const int t = (int)(i - cc * 15), kh = t / 5, kw = t - 5 * kh;
+  const float v = (kw & 1) ? to[cc * 9 + kh * 3 + (kw >> 1)] : te[cc * 9 + kh * 3 + (kw >> 1)];
+  dw[i] = accumulate ? dw[i] + v : v;
+}
+
+struct Wg35Plan { DlioConvDesc sub; DlioWgrad3Plan p3; size_t phase_floats, ws_bytes; };
+
+bool make_plan_3x5s2(const DlioConvDesc& d, Wg35Plan& q) {
+  static const int on = getenv("DLIO_WGRAD_3X5_PHASES") ? atoi(getenv("DLIO_WGRAD_3X5_PHASES")) : 1;
+  // (the 5-channel PointSeg stem fills 5 of the kernel's 16-channel slots: 24.09 vs 23.92 ms per step, it stays on the staged kernel)
+  if (!on || d.Cin < 16 || d.KH != 3 || d.KW != 5 || d.SH != 1 || d.SW != 2 || d.PH != 1 || d.PW != 2 || (d.W & 7) != 0 ||
+      d.OW != d.W / 2 || d.OH != d.H)
+    return false;
+  q.sub = d;
+  q.sub.W = d.W / 2; q.sub.KW = 3; q.sub.SW = 1; q.sub.PW = 1;
+  q.sub.in_ctot = d.Cin; q.sub.in_coff = 0; q.sub.in_relu = 0;
+  if (!dlio_wgrad3_plan(q.sub, 4, q.p3)) return false;
+  q.phase_floats = (size_t)d.N * d.Cin * d.H * (d.W / 2);
+  const size_t t9 = (size_t)d.Cout * d.Cin * 9 * sizeof(float);
+  q.ws_bytes = 2 * q.phase_floats * sizeof(float) + 2 * q.p3.ws_bytes + 2 * t9 + 64;
+  return true;
+}
+
 }  // namespace
 
 // bf16 x / dy (mixed-precision path): 3x3 stride-1 (dY-direct kernel) and 1x1 stride-1 (direct kernel),
@@ -808,6 +862,8 @@ extern "C" size_t dlio_conv2d_wgrad_ws_bytes(const DlioConvDesc* d) {
   if (make_plan_1x1(*d, q) && q.ws_bytes > need) need = q.ws_bytes;
   DlioWgrad3Plan p3;
   if (dlio_wgrad3_plan(*d, 4, p3) && p3.ws_bytes > need) need = p3.ws_bytes;
+  Wg35Plan q35;
+  if (make_plan_3x5s2(*d, q35) && q35.ws_bytes > need) need = q35.ws_bytes;
   return need;
 }
 
@@ -844,6 +900,31 @@ extern "C" int dlio_conv2d_wgrad(const float* x, const float* dy, float* dw,
       const int64_t n = (int64_t)d.Cout * d.Cin * 9;
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(n, 64)), dim3(256), 0, s, wsp, dw, n, p3.splits,
                          accumulate);
+      rc = dlio_check_launch();
+    }
+    dlio_prof_end(pkind, s);
+    return rc;
+  }
+  Wg35Plan q35;
+  if (!in_scale && make_plan_3x5s2(d, q35) && ws_bytes >= q35.ws_bytes &&
+      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(ws)) & 15) == 0) {
+    // column phases -> two 3x3 stride-1 launches -> merge (see deinterleave_cols_kernel)
+    const size_t pf = (q35.phase_floats + 3) & ~(size_t)3, sl = (q35.p3.ws_bytes / sizeof(float) + 3) & ~(size_t)3;
+    const size_t t9 = (size_t)d.Cout * d.Cin * 9;
+    float* xe = wsp; float* xo = xe + pf; float* se = xo + pf; float* so = se + sl; float* te = so + sl; float* to = te + t9;
+    const int64_t rows = (int64_t)d.N * d.Cin * d.H;
+    const int W8 = d.W / 8;
+    hipLaunchKernelGGL(deinterleave_cols_kernel, dim3((unsigned)cdiv64(rows * W8, 256)), dim3(256), 0, s, x, xe, xo, rows, W8,
+                       (int64_t)0, d.Cin, d.in_ctot, d.in_coff, d.H);
+    rc = dlio_check_launch();
+    if (!rc) rc = dlio_wgrad3_launch(xe, dy, se, q35.sub, q35.p3, 4, s);
+    if (!rc) rc = dlio_wgrad3_launch(xo, dy, so, q35.sub, q35.p3, 4, s);
+    if (!rc) {
+      const int64_t n9 = (int64_t)t9;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(n9, 64)), dim3(256), 0, s, se, te, n9, q35.p3.splits, 0);
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(n9, 64)), dim3(256), 0, s, so, to, n9, q35.p3.splits, 0);
+      const int64_t n15 = (int64_t)d.Cout * d.Cin * 15;
+      hipLaunchKernelGGL(wgrad_merge_3x5_kernel, dim3((unsigned)cdiv64(n15, 256)), dim3(256), 0, s, te, to, dw, n15, accumulate);
       rc = dlio_check_launch();
     }
     dlio_prof_end(pkind, s);
