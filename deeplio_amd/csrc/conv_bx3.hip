@@ -1065,3 +1065,37 @@ extern "C" int dlio_conv3x5s2_bx3_fwd(const float* x, const void* wt, const floa
   dlio_prof_end(3, s);
   return rc;
 }
+
+// stride-1 convolution with a small tap window and an explicit output extent on the split-bf16 kernel: the phases of a
+// strided layer's data gradient (functional._dgrad_phases: dx[a::SH, b::SW] is a stride-1 correlation of dy with the tap
+// subset w[:, :, rh::SH, rw::SW], reversed, under a top / left padding of (PH, PW); rows / columns behind the input read
+// zero, so OH / OW may exceed the symmetric-padding formula).  FlowNet conv2-6 / ResNet layer2-4 (lidar_feat_nets.py:248-257,
+// resnet.py:27-47).  Weights from dlio_conv_bx3_prep(taps = KH * KW, mode).
+extern "C" int dlio_conv_bx3_fwd_taps(const float* x, const void* wt, const float* bias, const float* residual, float* y,
+                                      const DlioConvDesc* dp, dlio_stream_t stream) {
+  if (!x || !wt || !y || !dp) return DLIO_EINVAL;
+  const DlioConvDesc& d = *dp;
+  if (d.SH != 1 || d.SW != 1) return DLIO_EUNSUP;
+  if (d.N <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.H <= 0 || d.W <= 0 || d.PH < 0 || d.PW < 0 || d.OH < 1 || d.OW < 1)
+    return DLIO_EINVAL;
+  if (d.OH > d.H + 2 * d.PH || d.OW > d.W + 2 * d.PW) return DLIO_EINVAL;
+  hipStream_t s = as_stream(stream);
+  const double flops = 2.0 * d.N * (double)d.OH * d.OW * d.Cout * (double)d.Cin * d.KH * d.KW;
+  const double bytes = 4.0 * d.N * ((double)d.Cin * d.H * d.W + (double)d.Cout * d.OH * d.OW * (residual ? 2.0 : 1.0));
+  const __bf16* w = reinterpret_cast<const __bf16*>(wt);
+  const bool wide = d.OW >= 48;
+  int rc = DLIO_EUNSUP;
+  dlio_prof_begin(3, s, flops, bytes);
+#define BX3_TAPS(kh, kw)                                                                        \
+  if (d.KH == kh && d.KW == kw)                                                                 \
+    rc = wide ? launch_bx3<2, 2, kh, kw, 1>(x, w, bias, residual, y, d, s) : launch_bx3<2, 1, kh, kw, 1>(x, w, bias, residual, y, d, s);
+  BX3_TAPS(3, 3)
+  else BX3_TAPS(3, 2)
+  else BX3_TAPS(2, 2)
+  else BX3_TAPS(2, 1)
+  else BX3_TAPS(1, 2)
+  else BX3_TAPS(1, 1)
+#undef BX3_TAPS
+  dlio_prof_end(3, s);
+  return rc;
+}

@@ -272,7 +272,9 @@ class _CBR:
             if (d.SH > 1 or d.SW > 1) and need_dx and _DGRAD_PHASES[0]:
                 plan = _phase_plan(d)
                 if plan is not None:           # tap-subset layouts of the phase-decomposed data gradient
-                    d.wt_ph = {(it[0], it[1]): ops.conv2d_prepped_phase(weight, d.SH, d.SW, it[0], it[1])
+                    d.wt_ph = {(it[0], it[1]): (ops.conv_bx3_prepped_phase(weight, d.SH, d.SW, it[0], it[1])
+                                                if _phase_on_bx3(d, it[2], it[3]) else
+                                                ops.conv2d_prepped_phase(weight, d.SH, d.SW, it[0], it[1]))
                                for it in plan if it is not None}
         if stem:
             ops.conv3x5s2_bx3_fwd(x, wt, bias, raw, d)
@@ -447,8 +449,22 @@ _DGRAD_PHASES = [os.environ.get("DLIO_DGRAD_PHASES", "1") != "0"]
 _PHASE_KERNELS = {(3, 3), (3, 2), (3, 1), (2, 2), (2, 1), (1, 2), (1, 1), (3, 5), (5, 7)}   # stride-1 instantiations
 
 
-def set_dgrad_phases(on):
+def set_dgrad_phases(on, bx3=None, bx3_min_k=None):
     _DGRAD_PHASES[0] = bool(on)
+    if bx3 is not None:
+        _DGRAD_PHASES_BX3[0] = bool(bx3)
+    if bx3_min_k is not None:
+        _PHASE_BX3_MIN_K[0] = int(bx3_min_k)
+
+
+# the phases' stride-1 convolutions on the split-bf16 kernel (dlio_conv_bx3_fwd_taps) instead of the fp32 MFMA
+_DGRAD_PHASES_BX3 = [os.environ.get("DLIO_DGRAD_PHASES_BX3", "1") != "0"]
+_PHASE_BX3_KERNELS = {(3, 3), (3, 2), (2, 2), (2, 1), (1, 2), (1, 1)}
+_PHASE_BX3_MIN_K = [16]      # channels of dy below which the 16-channel chunks of the split-bf16 kernel are mostly padding
+
+
+def _phase_on_bx3(d, Mh, Mw):
+    return _CONV_BX3[0] and _DGRAD_PHASES_BX3[0] and (Mh, Mw) in _PHASE_BX3_KERNELS and d.Cout >= _PHASE_BX3_MIN_K[0]
 
 
 def _phase_plan(d):
@@ -500,13 +516,17 @@ def _dgrad_phases(dy, weight, d, dx, dx_ctot, dx_coff, residual, r_ctot, r_coff)
             phases.append(None)
             continue
         rh, rw, Mh, Mw, pt, pl, Hp, Wp = item
+        bx3 = _phase_on_bx3(d, Mh, Mw)
         wt = stash.get((rh, rw)) if stash else None
         if wt is None:                      # direct call (no forward ran on this descriptor)
-            wt = ops.conv2d_prepped_phase(weight, d.SH, d.SW, rh, rw, cache=False)
+            wt = (ops.conv_bx3_prepped_phase if bx3 else ops.conv2d_prepped_phase)(weight, d.SH, d.SW, rh, rw, cache=False)
         out = _new((N, Cin, Hp, Wp), dy)
         g = ops.conv_desc(N, Cout, d.OH, d.OW, Cin, Mh, Mw, 1, 1, pt, pl, OH=Hp, OW=Wp, in_ctot=Cout, in_coff=0,
                           out_ctot=Cin, out_coff=0)
-        ops.conv2d_fwd(dy, wt, None, out, g)
+        if bx3:
+            ops.conv_bx3_taps_fwd(dy, wt, None, out, g)
+        else:
+            ops.conv2d_fwd(dy, wt, None, out, g)
         phases.append(out)
     ops.phase_interleave2d(phases, d.SH, d.SW, dx, dx_ctot, dx_coff, N, Cin, d.H, d.W, residual, r_ctot, r_coff)
     return True

@@ -339,6 +339,40 @@ def conv2d_prepped_phase(w, SH, SW, rh, rw, cache=True):
     return out
 
 
+def conv_bx3_prepped_phase(w, SH, SW, rh, rw, cache=True):
+    """split-bf16 data-gradient (mode 1) layout of w[:, :, rh::SH, rw::SW] (dlio_conv_bx3_fwd_taps)"""
+    Cout, Cin, KH, KW = w.shape
+    Mh, Mw = len(range(rh, KH, SH)), len(range(rw, KW, SW))
+    nfl = lib.dlio_conv_bx3_prep_floats(Cout, Cin, Mh * Mw, 1)
+    e = None
+    if cache:
+        key = ("bx3", w.data_ptr(), tuple(w.shape), SH, SW, rh, rw)
+        e = _PHASE_W.get(key)
+        if e is None or e["ref"]() is not w:
+            e = _PHASE_W[key] = dict(ref=_weakref.ref(w), epoch=-1, version=-1,
+                                     out=torch.empty(nfl, dtype=torch.float32, device=w.device))
+            for k in [k for k, v in _PHASE_W.items() if v["ref"]() is None]:
+                del _PHASE_W[k]
+        if e["epoch"] == _PREP.epoch and e["version"] == w._version:
+            return e["out"]
+        out = e["out"]
+    else:
+        out = torch.empty(nfl, dtype=torch.float32, device=w.device)
+    sub = w.detach()[:, :, rh::SH, rw::SW].contiguous()
+    check(lib.dlio_conv_bx3_prep(_ptr(sub), _ptr(out), Cout, Cin, Mh * Mw, 1, _stream()), "conv_bx3_prep")
+    sub.record_stream(torch.cuda.current_stream())
+    if e is not None:
+        e.update(epoch=_PREP.epoch, version=w._version)
+    return out
+
+
+def conv_bx3_taps_fwd(x, wt, bias, y, desc, residual=None):
+    """stride-1 convolution with a small tap window and an explicit output extent on the split-bf16 kernel"""
+    check(lib.dlio_conv_bx3_fwd_taps(_ptr(x), _ptr(wt), _ptr(bias), _ptr(residual), _ptr(y), C.byref(desc), _stream()),
+          "conv_bx3_fwd_taps")
+    return y
+
+
 def zero_upsample2d(src, HU, WU, SH, SW):
     """[N,C,OH,OW] -> [N,C,HU,WU] with the stride's zeros inserted"""
     _chk(src)

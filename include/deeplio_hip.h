@@ -143,6 +143,13 @@ int dlio_conv1x1_bx3_fwd(const float* x, const void* wt, const float* bias, cons
 int dlio_conv1x1_bx3_fwd_aff(const float* x, const void* wt, const float* bias, const float* in_mean,
                              const float* in_scale, const float* in_shift, const float* residual,
                              float* y, const DlioConvDesc* desc, dlio_stream_t stream);
+/* stride-1 convolution with 3x3 / 3x2 / 2x2 / 2x1 / 1x2 / 1x1 taps and an EXPLICIT output extent (desc->OH / OW up to
+ * K-1 beyond the symmetric-padding formula: the extra outputs read zero padding) on the split-bf16 kernel: the input phases
+ * of a strided layer's data gradient (FlowNet conv2-6, ResNet layer2-4: lidar_feat_nets.py:248-257, resnet.py:27-47, whose
+ * backward is torch autograd's conv2d data gradient).  weights from dlio_conv_bx3_prep(taps = KH * KW, mode).
+ * DLIO_EUNSUP for other tap windows or strides (use dlio_conv2d_fwd). */
+int dlio_conv_bx3_fwd_taps(const float* x, const void* wt, const float* bias, const float* residual, float* y,
+                           const DlioConvDesc* desc, dlio_stream_t stream);
 /* the split-bf16 kernel with 3x5 taps and stride (1, 2): the PointSeg stem (pointseg_net.py:18-20), forward only;
  * weights from dlio_conv_bx3_prep(taps = 15, mode 0) */
 int dlio_conv3x5s2_bx3_fwd(const float* x, const void* wt, const float* bias, const float* residual, float* y,

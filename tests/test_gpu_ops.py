@@ -755,7 +755,7 @@ def test_adam_sgd_match_torch_optim(dev):
 @pytest.mark.parametrize("case", [((2, 6, 18, 36), 10, 3, 3, 2, 2, 1, 1), ((2, 8, 17, 33), 12, 3, 5, 1, 2, 1, 2),
                                   ((1, 16, 16, 32), 8, 1, 1, 2, 2, 0, 0), ((2, 5, 9, 20), 7, 3, 3, 1, 2, 1, 1),
                                   ((1, 4, 15, 15), 6, 5, 7, 1, 2, 2, 3)])
-@pytest.mark.parametrize("phases", [True, False])
+@pytest.mark.parametrize("phases", [True, "fp32", False])
 def test_strided_dgrad_via_zero_upsample(dev, case, phases):
     """data gradient of strided convs, both production routes: phase decomposition (SH*SW stride-1
     MFMA convs over dy with the taps of each input phase, woven together) and the stride-1 MFMA conv
@@ -763,7 +763,7 @@ def test_strided_dgrad_via_zero_upsample(dev, case, phases):
     operand and a channel-sliced dx; checked against torch and against the scalar reference kernel
     behind the C-ABI"""
     from deeplio_amd import functional as Fh, ops
-    Fh.set_dgrad_phases(phases)
+    Fh.set_dgrad_phases(bool(phases), bx3=phases is True, bx3_min_k=1)      # True: phases on the split-bf16 kernel where it has the taps
     shape, Cout, KH, KW, SH, SW, PH, PW = case
     N, Cin, H, W = shape
     g = _g(21)
@@ -785,7 +785,7 @@ def test_strided_dgrad_via_zero_upsample(dev, case, phases):
     if phases:     # the decomposition itself must have run for the layer shapes of FlowNet / ResNet
         took = Fh._dgrad_phases(dy.to(dev), w.to(dev), d, torch.empty(N, Cin, H, W, device=dev), Cin, 0, None, 0, 0)
         assert took == ((KH, KW) != (5, 7))
-    Fh.set_dgrad_phases(True)
+    Fh.set_dgrad_phases(True, bx3=True, bx3_min_k=16)
     ref = torch.empty(N, Cin, H, W, device=dev)
     ops.conv2d_dgrad_strided(dy.to(dev), w.to(dev), ref, d)
     assert rel_err(ref, x.grad) < TOL
