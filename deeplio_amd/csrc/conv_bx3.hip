@@ -105,13 +105,13 @@ __global__ void prep_bx3_batched_kernel(const DlioPrepItem* __restrict__ items, 
 
 // KH x KW taps, row stride 1, column stride SW (3x3 / 1: Fire expand3x3 & co; 3x5 / 2: the PointSeg stem,
 // pointseg_net.py:18-20): output column c of a tile reads patch columns SW * c + kw.
-template <int MR, int TWN, int KH = 3, int KW = 3, int SW = 1>
+template <int MR, int TWN, int KH = 3, int KW = 3, int SW = 1, int SH = 1>
 __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
     const float* __restrict__ x, const __bf16* __restrict__ wt, const float* __restrict__ bias,
     const float* residual, float* y, DlioConvDesc d, int tiles_w, int tiles_h, int co_tiles, int patch_at,
     int vec_out) {
   constexpr int TH = 4, TW = 32 * TWN, NT = KH * KW;
-  constexpr int PR = TH + KH - 1, PC = SW * (TW - 1) + KW, NPOSP = PR * PC;
+  constexpr int PR = SH * (TH - 1) + KH, PC = SW * (TW - 1) + KW, NPOSP = PR * PC;
   constexpr int NPOS = (NPOSP + 255) / 256;              // patch positions per thread
   constexpr int PLANE = NPOSP * 16;                      // bf16 per plane
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
   for (int j = 0; j < NPOS; ++j) {
     const int pos = tid + j * 256;
     const int r = pos / PC, c = pos - r * PC;
-    const int ih = oh0 - d.PH + r, iw = ow0 * SW - d.PW + c;
+    const int ih = oh0 * SH - d.PH + r, iw = ow0 * SW - d.PW + c;
     pval[j] = pos < NPOSP && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W;
     poff[j] = pval[j] ? ih * d.W + iw : 0;
   }
@@ -231,8 +231,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
       bf16x8 b[TWN][3];
 #pragma unroll
       for (int t = 0; t < TWN; ++t) {
-        const int pos = SW == 2 ? (wave + kh) * PC + (kw & 1) * PCH + (32 * t + l31) + (kw >> 1)
-                                : (wave + kh) * PC + 32 * t + l31 + kw;
+        const int pos = SW == 2 ? (wave * SH + kh) * PC + (kw & 1) * PCH + (32 * t + l31) + (kw >> 1)
+                                : (wave * SH + kh) * PC + 32 * t + l31 + kw;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
           if constexpr (BX3_ABLATE & 8) opaque(b[t][p]);
@@ -786,20 +786,20 @@ int launch_bx3_alds(const float* x, const __bf16* wt, const float* bias, const f
   return dlio_check_launch();
 }
 
-template <int MR, int TWN, int KH = 3, int KW = 3, int SW = 1>
+template <int MR, int TWN, int KH = 3, int KW = 3, int SW = 1, int SH = 1>
 int launch_bx3(const float* x, const __bf16* wt, const float* bias, const float* residual, float* y,
                const DlioConvDesc& d, hipStream_t s) {
   constexpr int TH = 4, TW = 32 * TWN;
+  constexpr size_t BUF = (size_t)3 * (SH * (TH - 1) + KH) * (SW * (TW - 1) + KW) * 16 * sizeof(__bf16);
   const int tiles_w = cdiv(d.OW, TW), tiles_h = cdiv(d.OH, TH), co_tiles = cdiv(d.Cout, 32 * MR);
   const int64_t blocks = (int64_t)d.N * tiles_h * tiles_w * co_tiles;
   if (blocks <= 0 || blocks > 0x7fffffff) return DLIO_EINVAL;
   // one patch buffer is enough for a single-chunk layer (<= 16 input channels: the stem) -- twice the workgroups per CU
-  const size_t lds = (size_t)(d.Cin <= 16 ? 1 : 2) * 3 * (TH + KH - 1) * (SW * (TW - 1) + KW) * 16 * sizeof(__bf16);
+  const size_t lds = (size_t)(d.Cin <= 16 ? 1 : 2) * BUF;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bx3_kernel<MR, TWN, KH, KW, SW>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)((size_t)2 * 3 * (TH + KH - 1) * (SW * (TW - 1) + KW) * 16 * sizeof(__bf16)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bx3_kernel<MR, TWN, KH, KW, SW, SH>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * BUF));
     attr_done = true;
   }
   // when the next chunk's patch loads are issued: behind the first three taps' weight fragments for
@@ -814,7 +814,7 @@ int launch_bx3(const float* x, const __bf16* wt, const float* bias, const float*
   const int vec_out = vec_on && (d.OW & 3) == 0 && (((size_t)d.OH * d.OW) & 3) == 0 &&
                       ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0 &&
                       (size_t)4 * 32 * MR * (TWN == 1 ? TW + 4 : TW + 8) * sizeof(float) <= lds;
-  hipLaunchKernelGGL((conv3x3_bx3_kernel<MR, TWN, KH, KW, SW>), dim3((unsigned)blocks), dim3(256), lds, s, x, wt, bias, residual, y,
+  hipLaunchKernelGGL((conv3x3_bx3_kernel<MR, TWN, KH, KW, SW, SH>), dim3((unsigned)blocks), dim3(256), lds, s, x, wt, bias, residual, y,
                      d, tiles_w, tiles_h, co_tiles, patch_at, vec_out);
   return dlio_check_launch();
 }
@@ -1050,10 +1050,22 @@ extern "C" int dlio_conv3x5s2_bx3_fwd(const float* x, const void* wt, const floa
                                       const DlioConvDesc* dp, dlio_stream_t stream) {
   if (!x || !wt || !y || !dp) return DLIO_EINVAL;
   const DlioConvDesc& d = *dp;
-  if (d.KH != 3 || d.KW != 5 || d.SH != 1 || d.SW != 2) return DLIO_EUNSUP;
+  const bool s35 = d.KH == 3 && d.KW == 5 && d.SH == 1 && d.SW == 2;
+  const bool s33 = d.KH == 3 && d.KW == 3 && d.SH == 2 && d.SW == 2;      // FlowNet conv4-6, ResNet layer2-4 (stride 2)
+  if (!s35 && !s33) return DLIO_EUNSUP;
   if (d.N <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.H <= 0 || d.W <= 0 || d.PH < 0 || d.PW < 0) return DLIO_EINVAL;
-  if (d.OH != d.H + 2 * d.PH - 2 || d.OW != (d.W + 2 * d.PW - 5) / 2 + 1 || d.OH < 1 || d.OW < 1) return DLIO_EINVAL;
+  if (d.OH != (d.H + 2 * d.PH - d.KH) / d.SH + 1 || d.OW != (d.W + 2 * d.PW - d.KW) / d.SW + 1 || d.OH < 1 || d.OW < 1)
+    return DLIO_EINVAL;
   hipStream_t s = as_stream(stream);
+  if (s33) {
+    const double flops33 = 2.0 * d.N * (double)d.OH * d.OW * d.Cout * (double)d.Cin * 9;
+    const double bytes33 = 4.0 * d.N * ((double)d.Cin * d.H * d.W + (double)d.Cout * d.OH * d.OW * (residual ? 2.0 : 1.0));
+    dlio_prof_begin(3, s, flops33, bytes33);
+    const int rc33 = d.Cout <= 32 ? launch_bx3<1, 1, 3, 3, 2, 2>(x, reinterpret_cast<const __bf16*>(wt), bias, residual, y, d, s)
+                                  : launch_bx3<2, 1, 3, 3, 2, 2>(x, reinterpret_cast<const __bf16*>(wt), bias, residual, y, d, s);
+    dlio_prof_end(3, s);
+    return rc33;
+  }
   const double flops = 2.0 * d.N * (double)d.OH * d.OW * d.Cout * (double)d.Cin * 15;
   const double bytes = 4.0 * d.N * ((double)d.Cin * d.H * d.W + (double)d.Cout * d.OH * d.OW * (residual ? 2.0 : 1.0));
   dlio_prof_begin(3, s, flops, bytes);

@@ -255,8 +255,9 @@ class _CBR:
         bx3 = bx3 and (KH == 3 or (pad[0] == 0 and pad[1] == 0))
         # the PointSeg stem (3x5, stride (1, 2), pointseg_net.py:18-20), forward only: MFMA-bound on the fp32 matrix
         # cores (61 % busy), half the MFMA time on the split-bf16 kernel
-        stem = (not bx3 and _CONV_BX3[0] and _CONV_BX3_STEM[0] and (KH, KW) == (3, 5) and tuple(stride) == (1, 2)
-                and in_aff is None and (not need_dx or _CONV_BX3_3X5[0]))
+        stem = (not bx3 and _CONV_BX3[0] and _CONV_BX3_STEM[0] and in_aff is None
+                and (((KH, KW) == (3, 5) and tuple(stride) == (1, 2) and (not need_dx or _CONV_BX3_3X5[0]))
+                     or ((KH, KW) == (3, 3) and tuple(stride) == (2, 2) and _CONV_BX3_3X5[0] and Cin >= 16)))
         bx3 = bx3 or stem
         if bx3:
             wt = ops.conv_bx3_prepped(weight, 0)
@@ -405,7 +406,8 @@ def conv_dgrad(dy, weight, d, dx, dx_ctot, dx_coff, residual=None, r_ctot=0, r_c
 _CONV_BX3 = [os.environ.get("DLIO_CONV_BX3", "1") != "0"]
 _CONV_BX3_1X1 = [os.environ.get("DLIO_CONV_BX3_1X1", "1") != "0"]
 _CONV_BX3_STEM = [os.environ.get("DLIO_CONV_BX3_STEM", "1") != "0"]
-_CONV_BX3_3X5 = [os.environ.get("DLIO_CONV_BX3_3X5", "1") != "0"]     # FlowNet conv2 / conv3 (3x5, stride (1, 2), 64 / 128 input channels)
+# FlowNet conv2 / conv3 (3x5, stride (1, 2), 64 / 128 input channels) and the 3x3 stride-2 layers (FlowNet conv4-6, ResNet)
+_CONV_BX3_3X5 = [os.environ.get("DLIO_CONV_BX3_3X5", "1") != "0"]
 _BX3_1X1_KSPLIT = [os.environ.get("DLIO_BX3_1X1_KSPLIT", "1") != "0"]
 _BX3_1X1_KSPLIT_PIX = [int(os.environ.get("DLIO_BX3_1X1_KSPLIT_PIX", "16384"))]
 _BX3_1X1_MIN = [int(v) for v in os.environ.get("DLIO_BX3_1X1_MIN", "16,16,65536,8192").split(",")]   # Cin, Cout, pixels, pixels (widening layers)

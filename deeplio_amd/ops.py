@@ -250,7 +250,7 @@ def conv_bx3_prepped(w, mode):
     _PrepCache.  Call with the long-lived Parameter (forward); backward receives the layouts on the
     ConvDesc."""
     _chk(w)
-    if tuple(w.shape[2:]) not in ((3, 3), (1, 1), (3, 5)):
+    if tuple(w.shape[2:]) not in ((3, 3), (1, 1), (3, 5)):     # (3x3 also covers the stride-2 forward: same tap layout)
         raise ValueError("split-bf16 kernels exist for 3x3, 1x1 and (forward, stride (1, 2)) 3x5 weights")
     return _PREP.get(w, mode + 2)
 

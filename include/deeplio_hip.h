@@ -150,8 +150,9 @@ int dlio_conv1x1_bx3_fwd_aff(const float* x, const void* wt, const float* bias, 
  * DLIO_EUNSUP for other tap windows or strides (use dlio_conv2d_fwd). */
 int dlio_conv_bx3_fwd_taps(const float* x, const void* wt, const float* bias, const float* residual, float* y,
                            const DlioConvDesc* desc, dlio_stream_t stream);
-/* the split-bf16 kernel with 3x5 taps and stride (1, 2): the PointSeg stem (pointseg_net.py:18-20), forward only;
- * weights from dlio_conv_bx3_prep(taps = 15, mode 0) */
+/* the split-bf16 kernel on strided layers, forward: 3x5 taps with stride (1, 2) (the PointSeg stem, pointseg_net.py:18-20;
+ * FlowNet conv2 / conv3) and 3x3 taps with stride (2, 2) (FlowNet conv4-6, lidar_feat_nets.py:252-257; ResNet layer2-4,
+ * resnet.py:27-47); weights from dlio_conv_bx3_prep(taps = KH * KW, mode 0); DLIO_EUNSUP for anything else */
 int dlio_conv3x5s2_bx3_fwd(const float* x, const void* wt, const float* bias, const float* residual, float* y,
                            const DlioConvDesc* desc, dlio_stream_t stream);
 /* dlio_conv1x1_bx3_fwd_aff with scratch: narrowing layers on few pixels (>= 192 input channels, < 65536 pixels, too

@@ -946,6 +946,55 @@ def test_stem_conv3x5_stride2_split_bf16_matches_fp64(dev, case):
     assert e_bx3 < 3e-6 and e_bx3 < 4 * e_f32 + 2e-7, (e_bx3, e_f32)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 24, 40, 9, 37), (1, 64, 128, 16, 64), (2, 16, 20, 8, 130), (1, 70, 33, 5, 6)])
+def test_conv3x3_stride2_split_bf16_matches_fp64(dev, case):
+    """3x3 taps, stride (2, 2), padding 1 (FlowNet conv4-6, lidar_feat_nets.py:252-257; ResNet layer2-4) on the split-bf16
+    kernel with a row stride: odd / even extents, ragged channel counts, a residual operand"""
+    from deeplio_amd import ops
+    N, Cin, Cout, H, W = case
+    g = _g(56)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), (2, 2), (1, 1))
+    res = torch.randn(ref.shape, generator=g)
+    d = ops.conv_desc(N, Cin, H, W, Cout, 3, 3, 2, 2, 1, 1, res_ctot=Cout)
+    assert (d.OH, d.OW) == tuple(ref.shape[2:])
+    y = torch.empty(N, Cout, d.OH, d.OW, device=dev)
+    ops.conv3x5s2_bx3_fwd(x.to(dev), ops.conv3x3_bx3_prep(w.to(dev), 0), b.to(dev), y, d, residual=res.to(dev))
+    y32 = torch.empty_like(y)
+    ops.conv2d_fwd(x.to(dev), ops.conv2d_prep_weight(w.to(dev), 0), b.to(dev), y32, d, residual=res.to(dev))
+    e_bx3, e_f32 = rel_err(y, ref + res.double()), rel_err(y32, ref + res.double())
+    assert e_bx3 < 3e-6 and e_bx3 < 4 * e_f32 + 2e-7, (e_bx3, e_f32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,pad,extra", [((3, 3), (1, 1), (0, 0)), ((3, 2), (1, 0), (0, 1)), ((2, 2), (1, 1), (0, 0)),
+                                         ((2, 1), (0, 0), (1, 0)), ((1, 2), (0, 1), (0, 0)), ((1, 1), (0, 0), (0, 0))])
+def test_conv_bx3_taps_explicit_output_extent(dev, k, pad, extra):
+    """dlio_conv_bx3_fwd_taps: the tap windows of the strided layers' data-gradient phases, stride 1, top / left padding
+    `pad`, output extent `extra` rows / columns beyond the symmetric formula (they read the zero padding behind the input)"""
+    from deeplio_amd import ops
+    N, Cin, Cout, H, W = 2, 20, 40, 9, 70
+    g = _g(57)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, *k, generator=g) / (Cin * k[0] * k[1]) ** 0.5
+    OH, OW = H + 2 * pad[0] - k[0] + 1 + extra[0], W + 2 * pad[1] - k[1] + 1 + extra[1]
+    xp = F.pad(x.double(), (pad[1], pad[1] + extra[1], pad[0], pad[0] + extra[0]))
+    ref = F.conv2d(xp, w.double())
+    assert tuple(ref.shape[2:]) == (OH, OW)
+    d = ops.conv_desc(N, Cin, H, W, Cout, k[0], k[1], 1, 1, pad[0], pad[1], OH=OH, OW=OW)
+    wt = torch.empty(ops.lib.dlio_conv_bx3_prep_floats(Cout, Cin, k[0] * k[1], 0), dtype=torch.float32, device=dev)
+    wd = w.to(dev)
+    ops.check(ops.lib.dlio_conv_bx3_prep(ops._ptr(wd), ops._ptr(wt), Cout, Cin, k[0] * k[1], 0, ops._stream()), "prep")
+    y = torch.empty(N, Cout, OH, OW, device=dev)
+    ops.conv_bx3_taps_fwd(x.to(dev), wt, None, y, d)
+    assert rel_err(y, ref) < 3e-6
+    with pytest.raises(ValueError):          # a tap window the kernel is not built for
+        ops.conv_bx3_taps_fwd(x.to(dev), wt, None, y, ops.conv_desc(N, Cin, H, W, Cout, 3, 1, 1, 1, 0, 0))
+
+
 # Fire layers of the PointSeg encoders at the LAUNCH sizes bench.py times (N = B*S = 16 frame pairs of BASELINE
 # configs[1]): the XCD-ordered / one-workgroup-per-CU weight gradients, the split-K and k-split 1x1 kernels and the
 # TWN = 2 data gradients only take these branches at full size.
