@@ -288,6 +288,9 @@ def test_gap_and_channel_scale(dev):
 
 @pytest.mark.parametrize("M,N,K", [(16, 128, 768), (16, 4096, 256), (5, 3, 1024), (100, 64, 6),
                                    (37, 130, 50),
+                                   # skinny M against a large weight matrix (the odometry LSTM): x staged in LDS, wave-split
+                                   # slabs in the data gradient, 16-byte weight gradient -- ragged N / K / M
+                                   (8, 4096, 1024), (3, 1030, 260), (13, 515, 2048), (16, 2048, 2048), (8, 262, 1028),
                                    # tall M (IMU windows: B*T rows): the fp32-MFMA kernels of dense.hip
                                    (400, 512, 6), (400, 512, 256), (400, 512, 128), (801, 130, 50), (1600, 96, 512),
                                    (129, 33, 8)])
