@@ -15,24 +15,33 @@
 
 namespace {
 
-constexpr int BC = 8;  // batch rows per persistent workgroup
+constexpr int BC = 8;  // batch rows per persistent workgroup (GRU; the LSTM kernels take it as a template parameter)
+
+// batch rows per persistent LSTM workgroup: the recurrent product is VALU work (H FMAs per row and thread and step), so a
+// small batch is spread over more workgroups -- with 8 rows in ONE workgroup the headline's IMU net (B = 8) ran every
+// recurrence on a single CU at 5.9 us per step; one row per workgroup (8 CUs): same results bit for bit
+static int lstm_rows_per_wg(int B) {
+  static const int forced = getenv("DLIO_RNN_BC") ? atoi(getenv("DLIO_RNN_BC")) : 0;
+  if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced;
+  return B <= 16 ? 1 : B <= 64 ? 2 : 8;   // (B = 8: IMU forward chain 2.16 / 1.35 / 1.24 / 0.92 ms at 8 / 4 / 2 / 1 rows)
+}
 
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // ------------------------------------------------------------------ LSTM forward
-template <int H>
+template <int H, int BCT>
 __global__ __launch_bounds__(4 * H) void lstm_persist_fwd(
     const float* __restrict__ gx, const float* __restrict__ w_hh, const float* __restrict__ b_hh,
     const float* __restrict__ h0, const float* __restrict__ c0, float* __restrict__ hs, int ldhs,
     float* __restrict__ cs, float* __restrict__ hp, float* __restrict__ gates,
     float* __restrict__ hT, float* __restrict__ cT, int T, int B, int rst, int rsb, int reverse) {
   constexpr int G = 4 * H;
-  __shared__ __attribute__((aligned(16))) float hl[BC * H];
-  __shared__ __attribute__((aligned(16))) float cl[BC * H];
-  __shared__ __attribute__((aligned(16))) float gl[BC * G];
+  __shared__ __attribute__((aligned(16))) float hl[BCT * H];
+  __shared__ __attribute__((aligned(16))) float cl[BCT * H];
+  __shared__ __attribute__((aligned(16))) float gl[BCT * G];
   const int j = threadIdx.x;
-  const int b0 = blockIdx.x * BC;
-  const int nb = min(BC, B - b0);
+  const int b0 = blockIdx.x * BCT;
+  const int nb = min(BCT, B - b0);
 
   float w[H];
 #pragma unroll
@@ -42,18 +51,18 @@ __global__ __launch_bounds__(4 * H) void lstm_persist_fwd(
   }
   const float bj = b_hh ? b_hh[j] : 0.f;
 
-  for (int e = j; e < BC * H; e += G) {
+  for (int e = j; e < BCT * H; e += G) {
     const int b = e / H, k = e - b * H;
     const bool live = b < nb;
     hl[e] = (live && h0) ? h0[(size_t)(b0 + b) * H + k] : 0.f;
     cl[e] = (live && c0) ? c0[(size_t)(b0 + b) * H + k] : 0.f;
   }
 
-  float gcur[BC], gnext[BC];
+  float gcur[BCT], gnext[BCT];
   {
     const int t = reverse ? T - 1 : 0;
 #pragma unroll
-    for (int bb = 0; bb < BC; ++bb)
+    for (int bb = 0; bb < BCT; ++bb)
       gcur[bb] = bb < nb ? gx[((size_t)t * rst + (size_t)(b0 + bb) * rsb) * G + j] : 0.f;
   }
   __syncthreads();
@@ -63,17 +72,17 @@ __global__ __launch_bounds__(4 * H) void lstm_persist_fwd(
     if (step + 1 < T) {
       const int tn = reverse ? t - 1 : t + 1;
 #pragma unroll
-      for (int bb = 0; bb < BC; ++bb)
+      for (int bb = 0; bb < BCT; ++bb)
         gnext[bb] = bb < nb ? gx[((size_t)tn * rst + (size_t)(b0 + bb) * rsb) * G + j] : 0.f;
     }
     // phase 1: gate pre-activations
-    float acc[BC];
+    float acc[BCT];
 #pragma unroll
-    for (int bb = 0; bb < BC; ++bb) acc[bb] = gcur[bb] + bj;
+    for (int bb = 0; bb < BCT; ++bb) acc[bb] = gcur[bb] + bj;
 #pragma unroll
     for (int k = 0; k < H; k += 4) {
 #pragma unroll
-      for (int bb = 0; bb < BC; ++bb) {
+      for (int bb = 0; bb < BCT; ++bb) {
         const float4 hv = *reinterpret_cast<const float4*>(&hl[bb * H + k]);
         acc[bb] = fmaf(w[k], hv.x, acc[bb]);
         acc[bb] = fmaf(w[k + 1], hv.y, acc[bb]);
@@ -82,7 +91,7 @@ __global__ __launch_bounds__(4 * H) void lstm_persist_fwd(
       }
     }
 #pragma unroll
-    for (int bb = 0; bb < BC; ++bb) gl[bb * G + j] = acc[bb];
+    for (int bb = 0; bb < BCT; ++bb) gl[bb * G + j] = acc[bb];
     __syncthreads();
     // phase 2: cell update
     for (int e = j; e < nb * H; e += G) {
@@ -104,7 +113,7 @@ __global__ __launch_bounds__(4 * H) void lstm_persist_fwd(
       hl[e] = h;
     }
 #pragma unroll
-    for (int bb = 0; bb < BC; ++bb) gcur[bb] = gnext[bb];
+    for (int bb = 0; bb < BCT; ++bb) gcur[bb] = gnext[bb];
     __syncthreads();
   }
   for (int e = j; e < nb * H; e += G) {
@@ -115,7 +124,7 @@ __global__ __launch_bounds__(4 * H) void lstm_persist_fwd(
 }
 
 // ------------------------------------------------------------------ LSTM backward
-template <int H>
+template <int H, int BCT>
 __global__ __launch_bounds__(4 * H) void lstm_persist_bwd(
     const float* __restrict__ dhs, int lddhs, const float* __restrict__ dhT,
     const float* __restrict__ dcT, const float* __restrict__ gates, const float* __restrict__ cs,
@@ -123,27 +132,27 @@ __global__ __launch_bounds__(4 * H) void lstm_persist_bwd(
     float* __restrict__ dh0, float* __restrict__ dc0, int T, int B, int rst, int rsb,
     int reverse) {
   constexpr int G = 4 * H;
-  constexpr int EPT = (BC * H) / G;  // pointwise elements per thread (= 2)
-  __shared__ __attribute__((aligned(16))) float dGl[BC * G];
-  __shared__ float part[4][BC * H];
-  __shared__ float dhl[BC * H];
-  __shared__ float dcl[BC * H];
+  constexpr int EPT = (BCT * H + G - 1) / G;  // pointwise elements per thread (2 for 8 rows, 1 below 5)
+  __shared__ __attribute__((aligned(16))) float dGl[BCT * G];
+  __shared__ float part[4][BCT * H];
+  __shared__ float dhl[BCT * H];
+  __shared__ float dcl[BCT * H];
   const int tid = threadIdx.x;
   const int q = tid / H, k = tid - q * H;
-  const int b0 = blockIdx.x * BC;
-  const int nb = min(BC, B - b0);
+  const int b0 = blockIdx.x * BCT;
+  const int nb = min(BCT, B - b0);
 
   float wc[H];  // column k of gate block q:  W_hh[q*H + jj][k]
 #pragma unroll
   for (int jj = 0; jj < H; ++jj) wc[jj] = w_hh[((size_t)q * H + jj) * H + k];
 
-  for (int e = tid; e < BC * H; e += G) {
+  for (int e = tid; e < BCT * H; e += G) {
     const int b = e / H, kk = e - b * H;
     const bool live = b < nb;
     dhl[e] = (live && dhT) ? dhT[(size_t)(b0 + b) * H + kk] : 0.f;
     dcl[e] = (live && dcT) ? dcT[(size_t)(b0 + b) * H + kk] : 0.f;
   }
-  for (int e = tid; e < BC * G; e += G) dGl[e] = 0.f;
+  for (int e = tid; e < BCT * G; e += G) dGl[e] = 0.f;
 
   // per-thread prefetch registers for the pointwise phase
   float p_i[EPT], p_f[EPT], p_g[EPT], p_o[EPT], p_c[EPT], p_cp[EPT], p_dh[EPT];
@@ -155,7 +164,7 @@ __global__ __launch_bounds__(4 * H) void lstm_persist_bwd(
     for (int u = 0; u < EPT; ++u) {
       const int e = tid + u * G;
       const int b = e / H, kk = e - b * H;
-      if (b < nb) {
+      if (e < BCT * H && b < nb) {
         const size_t r = (size_t)t * rst + (size_t)(b0 + b) * rsb;
         const float* gr = gates + r * G;
         p_i[u] = gr[kk]; p_f[u] = gr[H + kk]; p_g[u] = gr[2 * H + kk]; p_o[u] = gr[3 * H + kk];
@@ -176,7 +185,7 @@ __global__ __launch_bounds__(4 * H) void lstm_persist_bwd(
     for (int u = 0; u < EPT; ++u) {
       const int e = tid + u * G;
       const int b = e / H, kk = e - b * H;
-      if (b < nb) {
+      if (e < BCT * H && b < nb) {
         const size_t r = (size_t)t * rst + (size_t)(b0 + b) * rsb;
         const float ig = p_i[u], fg = p_f[u], gg = p_g[u], og = p_o[u];
         const float dh = p_dh[u] + dhl[e];
@@ -197,13 +206,13 @@ __global__ __launch_bounds__(4 * H) void lstm_persist_bwd(
     __syncthreads();
     // phase B: partial dh_{prev}[b][k] over gate block q
     {
-      float acc[BC];
+      float acc[BCT];
 #pragma unroll
-      for (int bb = 0; bb < BC; ++bb) acc[bb] = 0.f;
+      for (int bb = 0; bb < BCT; ++bb) acc[bb] = 0.f;
 #pragma unroll
       for (int jj = 0; jj < H; jj += 4) {
 #pragma unroll
-        for (int bb = 0; bb < BC; ++bb) {
+        for (int bb = 0; bb < BCT; ++bb) {
           const float4 gv = *reinterpret_cast<const float4*>(&dGl[bb * G + q * H + jj]);
           acc[bb] = fmaf(wc[jj], gv.x, acc[bb]);
           acc[bb] = fmaf(wc[jj + 1], gv.y, acc[bb]);
@@ -212,11 +221,11 @@ __global__ __launch_bounds__(4 * H) void lstm_persist_bwd(
         }
       }
 #pragma unroll
-      for (int bb = 0; bb < BC; ++bb) part[q][bb * H + k] = acc[bb];
+      for (int bb = 0; bb < BCT; ++bb) part[q][bb * H + k] = acc[bb];
     }
     __syncthreads();
     // phase C: fixed-order sum of the four blocks
-    for (int e = tid; e < BC * H; e += G)
+    for (int e = tid; e < BCT * H; e += G)
       dhl[e] = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
     __syncthreads();
   }
@@ -539,17 +548,21 @@ extern "C" int dlio_lstm_seq_fwd(const float* gx, const float* w_hh, const float
   if (!gx || !w_hh || !hs || !cs || !hp || !gates || T <= 0 || B <= 0 || H <= 0 || ldhs < H)
     return DLIO_EINVAL;
   hipStream_t s = as_stream(stream);
-  const int nblk = cdiv(B, BC);
+  const int rows = lstm_rows_per_wg(B);
+#define LSTM_FWD_B(HH, RB)                                                                   \
+  if (rows == RB)                                                                            \
+    hipLaunchKernelGGL((lstm_persist_fwd<HH, RB>), dim3(cdiv(B, RB)), dim3(4 * HH), 0, s, gx, w_hh, b_hh, h0, c0, hs, ldhs, \
+                       cs, hp, gates, hT, cT, T, B, rst, rsb, reverse);
 #define LSTM_FWD_P(HH)                                                                         \
   if (H == HH) {                                                                               \
-    hipLaunchKernelGGL(lstm_persist_fwd<HH>, dim3(nblk), dim3(4 * HH), 0, s, gx, w_hh, b_hh,   \
-                       h0, c0, hs, ldhs, cs, hp, gates, hT, cT, T, B, rst, rsb, reverse);      \
+    LSTM_FWD_B(HH, 1) else LSTM_FWD_B(HH, 2) else LSTM_FWD_B(HH, 4) else LSTM_FWD_B(HH, 8)            \
     return dlio_check_launch();                                                                \
   }
   LSTM_FWD_P(32)
   LSTM_FWD_P(64)
   LSTM_FWD_P(128)
 #undef LSTM_FWD_P
+#undef LSTM_FWD_B
   // streamed path
   if (!ws || ws_bytes < dlio_rnn_ws_bytes(T, B, H)) return DLIO_EWS;
   float* f = reinterpret_cast<float*>(ws);
@@ -579,17 +592,21 @@ extern "C" int dlio_lstm_seq_bwd(const float* dhs, int lddhs, const float* dhT, 
                                  size_t ws_bytes, dlio_stream_t stream) {
   if (!gates || !cs || !w_hh || !dgates || T <= 0 || B <= 0 || H <= 0) return DLIO_EINVAL;
   hipStream_t s = as_stream(stream);
-  const int nblk = cdiv(B, BC);
+  const int rows = lstm_rows_per_wg(B);
+#define LSTM_BWD_B(HH, RB)                                                                  \
+  if (rows == RB)                                                                           \
+    hipLaunchKernelGGL((lstm_persist_bwd<HH, RB>), dim3(cdiv(B, RB)), dim3(4 * HH), 0, s, dhs, lddhs, dhT, dcT, gates, cs, \
+                       c0, w_hh, dgates, dh0, dc0, T, B, rst, rsb, reverse);
 #define LSTM_BWD_P(HH)                                                                        \
   if (H == HH) {                                                                              \
-    hipLaunchKernelGGL(lstm_persist_bwd<HH>, dim3(nblk), dim3(4 * HH), 0, s, dhs, lddhs, dhT, \
-                       dcT, gates, cs, c0, w_hh, dgates, dh0, dc0, T, B, rst, rsb, reverse);  \
+    LSTM_BWD_B(HH, 1) else LSTM_BWD_B(HH, 2) else LSTM_BWD_B(HH, 4) else LSTM_BWD_B(HH, 8)           \
     return dlio_check_launch();                                                               \
   }
   LSTM_BWD_P(32)
   LSTM_BWD_P(64)
   LSTM_BWD_P(128)
 #undef LSTM_BWD_P
+#undef LSTM_BWD_B
   if (!ws || ws_bytes < dlio_rnn_ws_bytes(T, B, H)) return DLIO_EWS;
   float* f = reinterpret_cast<float*>(ws);
   float* dhrec = f;
