@@ -1,6 +1,6 @@
 // LSTM / GRU sequence recurrences (one layer, one direction per call).
 //
-// Persistent path (H = 32/64/128): one 4H-thread workgroup per chunk of 8 batch rows walks
+// Persistent path (H = 32/64/128): one 4H-thread workgroup per chunk of 1 / 2 / 8 batch rows (lstm_rows_per_wg) walks
 // all T steps inside ONE launch.  Forward: thread j keeps row j of W_hh (H floats) in VGPRs
 // for the whole sequence, h_{t-1}/c live in LDS and are read as wave-uniform ds_read_b128
 // broadcasts, gx of step t+1 is prefetched into registers while step t computes.
@@ -15,9 +15,7 @@
 
 namespace {
 
-constexpr int BC = 8;  // batch rows per persistent workgroup (GRU; the LSTM kernels take it as a template parameter)
-
-// batch rows per persistent LSTM workgroup: the recurrent product is VALU work (H FMAs per row and thread and step), so a
+// batch rows per persistent LSTM / GRU workgroup (template parameter BCT): the recurrent product is VALU work (H FMAs per row and thread and step), so a
 // small batch is spread over more workgroups -- with 8 rows in ONE workgroup the headline's IMU net (B = 8) ran every
 // recurrence on a single CU at 5.9 us per step; one row per workgroup (8 CUs): same results bit for bit
 static int lstm_rows_per_wg(int B) {
@@ -365,18 +363,18 @@ __global__ void gru_cell_bwd_kernel(const float* __restrict__ dhs, int lddhs,
 // keeps row j of W_hh (forward) / a column of one gate block (backward) in registers for all T
 // steps, h and the gate pre-activations live in LDS, the next step's gx is prefetched.
 // gates saved per row: r, z, n, hn (= W_hn h + b_hn), as the streamed cells do.
-template <int H>
+template <int H, int BCT>
 __global__ __launch_bounds__(3 * H) void gru_persist_fwd(
     const float* __restrict__ gx, const float* __restrict__ w_hh, const float* __restrict__ b_hh,
     const float* __restrict__ h0, float* __restrict__ hs, int ldhs, float* __restrict__ hp,
     float* __restrict__ gates, float* __restrict__ hT, int T, int B, int rst, int rsb, int reverse) {
   constexpr int G = 3 * H;
-  __shared__ __attribute__((aligned(16))) float hl[BC * H];
-  __shared__ __attribute__((aligned(16))) float gl[BC * G];    // r,z: gx+gh ; n: gh only
-  __shared__ float gxn[BC * H];                                // gx of the n gate
+  __shared__ __attribute__((aligned(16))) float hl[BCT * H];
+  __shared__ __attribute__((aligned(16))) float gl[BCT * G];    // r,z: gx+gh ; n: gh only
+  __shared__ float gxn[BCT * H];                                // gx of the n gate
   const int j = threadIdx.x;
-  const int b0 = blockIdx.x * BC;
-  const int nb = min(BC, B - b0);
+  const int b0 = blockIdx.x * BCT;
+  const int nb = min(BCT, B - b0);
 
   float w[H];
 #pragma unroll
@@ -385,15 +383,15 @@ __global__ __launch_bounds__(3 * H) void gru_persist_fwd(
     w[k] = v.x; w[k + 1] = v.y; w[k + 2] = v.z; w[k + 3] = v.w;
   }
   const float bj = b_hh ? b_hh[j] : 0.f;
-  for (int e = j; e < BC * H; e += G) {
+  for (int e = j; e < BCT * H; e += G) {
     const int b = e / H, k = e - b * H;
     hl[e] = (b < nb && h0) ? h0[(size_t)(b0 + b) * H + k] : 0.f;
   }
-  float gcur[BC], gnext[BC];
+  float gcur[BCT], gnext[BCT];
   {
     const int t = reverse ? T - 1 : 0;
 #pragma unroll
-    for (int bb = 0; bb < BC; ++bb)
+    for (int bb = 0; bb < BCT; ++bb)
       gcur[bb] = bb < nb ? gx[((size_t)t * rst + (size_t)(b0 + bb) * rsb) * G + j] : 0.f;
   }
   __syncthreads();
@@ -403,16 +401,16 @@ __global__ __launch_bounds__(3 * H) void gru_persist_fwd(
     if (step + 1 < T) {
       const int tn = reverse ? t - 1 : t + 1;
 #pragma unroll
-      for (int bb = 0; bb < BC; ++bb)
+      for (int bb = 0; bb < BCT; ++bb)
         gnext[bb] = bb < nb ? gx[((size_t)tn * rst + (size_t)(b0 + bb) * rsb) * G + j] : 0.f;
     }
-    float acc[BC];
+    float acc[BCT];
 #pragma unroll
-    for (int bb = 0; bb < BC; ++bb) acc[bb] = bj;
+    for (int bb = 0; bb < BCT; ++bb) acc[bb] = bj;
 #pragma unroll
     for (int k = 0; k < H; k += 4) {
 #pragma unroll
-      for (int bb = 0; bb < BC; ++bb) {
+      for (int bb = 0; bb < BCT; ++bb) {
         const float4 hv = *reinterpret_cast<const float4*>(&hl[bb * H + k]);
         acc[bb] = fmaf(w[k], hv.x, acc[bb]);
         acc[bb] = fmaf(w[k + 1], hv.y, acc[bb]);
@@ -422,10 +420,10 @@ __global__ __launch_bounds__(3 * H) void gru_persist_fwd(
     }
     if (j < 2 * H) {
 #pragma unroll
-      for (int bb = 0; bb < BC; ++bb) gl[bb * G + j] = gcur[bb] + acc[bb];
+      for (int bb = 0; bb < BCT; ++bb) gl[bb * G + j] = gcur[bb] + acc[bb];
     } else {
 #pragma unroll
-      for (int bb = 0; bb < BC; ++bb) { gl[bb * G + j] = acc[bb]; gxn[bb * H + j - 2 * H] = gcur[bb]; }
+      for (int bb = 0; bb < BCT; ++bb) { gl[bb * G + j] = acc[bb]; gxn[bb * H + j - 2 * H] = gcur[bb]; }
     }
     __syncthreads();
     for (int e = j; e < nb * H; e += G) {
@@ -444,38 +442,38 @@ __global__ __launch_bounds__(3 * H) void gru_persist_fwd(
       hl[e] = h;
     }
 #pragma unroll
-    for (int bb = 0; bb < BC; ++bb) gcur[bb] = gnext[bb];
+    for (int bb = 0; bb < BCT; ++bb) gcur[bb] = gnext[bb];
     __syncthreads();
   }
   if (hT)
     for (int e = j; e < nb * H; e += G) hT[(size_t)(b0 + e / H) * H + e % H] = hl[e];
 }
 
-template <int H>
+template <int H, int BCT>
 __global__ __launch_bounds__(3 * H) void gru_persist_bwd(
     const float* __restrict__ dhs, int lddhs, const float* __restrict__ dhT,
     const float* __restrict__ gates, const float* __restrict__ hp, const float* __restrict__ w_hh,
     float* __restrict__ dgx, float* __restrict__ dgh, float* __restrict__ dh0, int T, int B, int rst,
     int rsb, int reverse) {
   constexpr int G = 3 * H;
-  __shared__ __attribute__((aligned(16))) float dGl[BC * G];
-  __shared__ float part[3][BC * H];
-  __shared__ float dhl[BC * H];      // gradient arriving from the later step
-  __shared__ float dir[BC * H];      // dh * z : the path that bypasses W_hh
+  __shared__ __attribute__((aligned(16))) float dGl[BCT * G];
+  __shared__ float part[3][BCT * H];
+  __shared__ float dhl[BCT * H];      // gradient arriving from the later step
+  __shared__ float dir[BCT * H];      // dh * z : the path that bypasses W_hh
   const int tid = threadIdx.x;
   const int q = tid / H, k = tid - q * H;
-  const int b0 = blockIdx.x * BC;
-  const int nb = min(BC, B - b0);
+  const int b0 = blockIdx.x * BCT;
+  const int nb = min(BCT, B - b0);
 
   float wc[H];  // column k of gate block q:  W_hh[q*H + jj][k]
 #pragma unroll
   for (int jj = 0; jj < H; ++jj) wc[jj] = w_hh[((size_t)q * H + jj) * H + k];
-  for (int e = tid; e < BC * H; e += G) {
+  for (int e = tid; e < BCT * H; e += G) {
     const int b = e / H, kk = e - b * H;
     dhl[e] = (b < nb && dhT) ? dhT[(size_t)(b0 + b) * H + kk] : 0.f;
     dir[e] = 0.f;
   }
-  for (int e = tid; e < BC * G; e += G) dGl[e] = 0.f;
+  for (int e = tid; e < BCT * G; e += G) dGl[e] = 0.f;
   __syncthreads();
 
   for (int step = 0; step < T; ++step) {
@@ -503,13 +501,13 @@ __global__ __launch_bounds__(3 * H) void gru_persist_bwd(
     }
     __syncthreads();
     {
-      float acc[BC];
+      float acc[BCT];
 #pragma unroll
-      for (int bb = 0; bb < BC; ++bb) acc[bb] = 0.f;
+      for (int bb = 0; bb < BCT; ++bb) acc[bb] = 0.f;
 #pragma unroll
       for (int jj = 0; jj < H; jj += 4) {
 #pragma unroll
-        for (int bb = 0; bb < BC; ++bb) {
+        for (int bb = 0; bb < BCT; ++bb) {
           const float4 gv = *reinterpret_cast<const float4*>(&dGl[bb * G + q * H + jj]);
           acc[bb] = fmaf(wc[jj], gv.x, acc[bb]);
           acc[bb] = fmaf(wc[jj + 1], gv.y, acc[bb]);
@@ -518,10 +516,10 @@ __global__ __launch_bounds__(3 * H) void gru_persist_bwd(
         }
       }
 #pragma unroll
-      for (int bb = 0; bb < BC; ++bb) part[q][bb * H + k] = acc[bb];
+      for (int bb = 0; bb < BCT; ++bb) part[q][bb * H + k] = acc[bb];
     }
     __syncthreads();
-    for (int e = tid; e < BC * H; e += G) dhl[e] = dir[e] + ((part[0][e] + part[1][e]) + part[2][e]);
+    for (int e = tid; e < BCT * H; e += G) dhl[e] = dir[e] + ((part[0][e] + part[1][e]) + part[2][e]);
     __syncthreads();
   }
   if (dh0)
@@ -642,7 +640,14 @@ extern "C" int dlio_gru_seq_fwd(const float* gx, const float* w_hh, const float*
   static const int persist = getenv("DLIO_GRU_PERSIST") ? atoi(getenv("DLIO_GRU_PERSIST")) : 1;
 #define GRU_FWD_P(HH)                                                                          \
   if (persist && H == HH) {                                                                    \
-    hipLaunchKernelGGL(gru_persist_fwd<HH>, dim3(cdiv(B, BC)), dim3(3 * HH), 0, s, gx, w_hh,   \
+    const int rows = lstm_rows_per_wg(B);                                                       \
+    if (rows == 1) hipLaunchKernelGGL((gru_persist_fwd<HH, 1>), dim3(B), dim3(3 * HH), 0, s, gx, w_hh,   \
+                       b_hh, h0, hs, ldhs, hp, gates, hT, T, B, rst, rsb, reverse); \
+    else if (rows == 2) hipLaunchKernelGGL((gru_persist_fwd<HH, 2>), dim3(cdiv(B, 2)), dim3(3 * HH), 0, s, gx, w_hh,   \
+                       b_hh, h0, hs, ldhs, hp, gates, hT, T, B, rst, rsb, reverse); \
+    else if (rows == 4) hipLaunchKernelGGL((gru_persist_fwd<HH, 4>), dim3(cdiv(B, 4)), dim3(3 * HH), 0, s, gx, w_hh,   \
+                       b_hh, h0, hs, ldhs, hp, gates, hT, T, B, rst, rsb, reverse); \
+    else hipLaunchKernelGGL((gru_persist_fwd<HH, 8>), dim3(cdiv(B, 8)), dim3(3 * HH), 0, s, gx, w_hh,   \
                        b_hh, h0, hs, ldhs, hp, gates, hT, T, B, rst, rsb, reverse);            \
     return dlio_check_launch();                                                                \
   }
@@ -676,7 +681,14 @@ extern "C" int dlio_gru_seq_bwd(const float* dhs, int lddhs, const float* dhT, c
   static const int persist = getenv("DLIO_GRU_PERSIST") ? atoi(getenv("DLIO_GRU_PERSIST")) : 1;
 #define GRU_BWD_P(HH)                                                                          \
   if (persist && H == HH) {                                                                    \
-    hipLaunchKernelGGL(gru_persist_bwd<HH>, dim3(cdiv(B, BC)), dim3(3 * HH), 0, s, dhs, lddhs, \
+    const int rows = lstm_rows_per_wg(B);                                                      \
+    if (rows == 1) hipLaunchKernelGGL((gru_persist_bwd<HH, 1>), dim3(B), dim3(3 * HH), 0, s, dhs, lddhs, \
+                       dhT, gates, hp, w_hh, dgx, dgh, dh0, T, B, rst, rsb, reverse); \
+    else if (rows == 2) hipLaunchKernelGGL((gru_persist_bwd<HH, 2>), dim3(cdiv(B, 2)), dim3(3 * HH), 0, s, dhs, lddhs, \
+                       dhT, gates, hp, w_hh, dgx, dgh, dh0, T, B, rst, rsb, reverse); \
+    else if (rows == 4) hipLaunchKernelGGL((gru_persist_bwd<HH, 4>), dim3(cdiv(B, 4)), dim3(3 * HH), 0, s, dhs, lddhs, \
+                       dhT, gates, hp, w_hh, dgx, dgh, dh0, T, B, rst, rsb, reverse); \
+    else hipLaunchKernelGGL((gru_persist_bwd<HH, 8>), dim3(cdiv(B, 8)), dim3(3 * HH), 0, s, dhs, lddhs, \
                        dhT, gates, hp, w_hh, dgx, dgh, dh0, T, B, rst, rsb, reverse);          \
     return dlio_check_launch();                                                                \
   }
