@@ -363,6 +363,188 @@ __global__ __launch_bounds__(256) void pool16_bwd_dot_kernel(const __bf16* __res
   }
 }
 
+// ---- the same three pools as rolling windows (pool.hip's strip kernels on bf16 storage): the kernels above read every
+// input row once per output row that touches it (3x for row stride 1) and the scale gradient one element per thread and trip;
+// here a thread owns a strip of rows and reads each row it needs ONCE.
+// forward: 4 output columns (8 input columns = one 16-byte load + the left neighbour) x FR output rows; a row is reduced to
+// (row maximum, kw) per output column, an output is the first maximum over its three row results -- row-then-column "first
+// strictly greater wins" is the same total order as the flat kh-major scan of pool16_fwd_kernel: bit-identical values / codes
+template <int SH>
+__global__ __launch_bounds__(256) void pool16_fwd_strip(const __bf16* __restrict__ x, const float* __restrict__ xs,
+                                                        __bf16* __restrict__ y, uint8_t* __restrict__ idx, int64_t planes,
+                                                        int H, int W, int OH, int OW) {
+  constexpr int FR = SH == 1 ? 8 : 4, NIN = (FR - 1) * SH + 3;
+  const int ow4 = OW >> 2, strips = (OH + FR - 1) / FR;
+  const int64_t total = planes * strips * ow4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i % ow4);
+    int64_t t = i / ow4;
+    const int oh0 = (int)(t % strips) * FR;
+    const int64_t pl = t / strips;
+    const float s = xs ? xs[pl] : 1.f;
+    const __bf16* xp = x + pl * (int64_t)H * W;
+    bf16x8 rows[NIN];
+    __bf16 hal[NIN];
+    bool rv[NIN];
+#pragma unroll
+    for (int j = 0; j < NIN; ++j) {                       // loads first, unconditional (clamped addresses)
+      const int ih = oh0 * SH - 1 + j;
+      rv[j] = ih >= 0 && ih < H;
+      const __bf16* row = xp + (int64_t)min(max(ih, 0), H - 1) * W + 8 * b;
+      rows[j] = *reinterpret_cast<const bf16x8*>(row);
+      hal[j] = row[b > 0 ? -1 : 0];
+    }
+    float rb[NIN][4];
+    int rk[NIN][4];
+#pragma unroll
+    for (int j = 0; j < NIN; ++j) {
+      float v[9];
+      v[0] = b > 0 ? (float)hal[j] * s : -INFINITY;       // left padding never wins (s > 0: a sigmoid)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[1 + k] = (float)rows[j][k] * s;
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        rb[j][o] = -INFINITY; rk[j][o] = 0;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+          if (v[2 * o + kw] > rb[j][o]) { rb[j][o] = v[2 * o + kw]; rk[j][o] = kw; }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < FR; ++r) {
+      const int oh = oh0 + r;
+      if (oh >= OH) continue;
+      float best[4];
+      unsigned code = 0;
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        best[o] = -INFINITY;
+        int bi = 0;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int j = r * SH + kh;
+          if (rv[j] && rb[j][o] > best[o]) { best[o] = rb[j][o]; bi = kh * 3 + rk[j][o]; }
+        }
+        code |= (unsigned)bi << (8 * o);
+      }
+      const int64_t oo = (pl * OH + oh) * (int64_t)OW + 4 * b;
+      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      *reinterpret_cast<bf16x4*>(y + oo) = bf16x4{(__bf16)best[0], (__bf16)best[1], (__bf16)best[2], (__bf16)best[3]};
+      if (idx) *reinterpret_cast<unsigned*>(idx + oo) = code;
+    }
+  }
+}
+
+// routed gradient of a strip: G[r][c] = sum of the dy whose arg-max is input element (ih0 + r, 8 b + c); every output row
+// the strip's rows can be the arg-max of is read once (4 dy + 4 codes + the first output of the next thread's group)
+constexpr int PR16 = 8;
+template <int SH>
+__device__ __forceinline__ void pool16_strip(const __bf16* __restrict__ dyp, const uint8_t* __restrict__ ip, int ih0, int b,
+                                             int OH, int OW, float (&G)[PR16][8]) {
+#pragma unroll
+  for (int r = 0; r < PR16; ++r)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) G[r][c] = 0.f;
+  constexpr int J0 = SH == 1 ? -1 : 0, J1 = SH == 1 ? PR16 : PR16 / 2, NJ = J1 - J0 + 1;
+  const bool has4 = 4 * b + 4 < OW;
+  uint2 gv[NJ];
+  unsigned iv[NJ];
+  __bf16 g4[NJ];
+  uint8_t i4[NJ];
+  const int c4 = has4 ? 4 : 3;
+#pragma unroll
+  for (int j = J0; j <= J1; ++j) {
+    const int oh = min(max(ih0 / SH + j, 0), OH - 1);
+    const int64_t ro = (int64_t)oh * OW + 4 * b;
+    gv[j - J0] = *reinterpret_cast<const uint2*>(dyp + ro);
+    iv[j - J0] = *reinterpret_cast<const unsigned*>(ip + ro);
+    g4[j - J0] = dyp[ro + c4];
+    i4[j - J0] = ip[ro + c4];
+  }
+#pragma unroll
+  for (int j = J0; j <= J1; ++j) {
+    const int oh = ih0 / SH + j;
+    if (oh < 0 || oh >= OH) continue;
+    const uint2 g2 = gv[j - J0];
+    const unsigned id = iv[j - J0];
+    const float v[5] = {__builtin_bit_cast(float, g2.x << 16), __builtin_bit_cast(float, g2.x & 0xffff0000u),
+                        __builtin_bit_cast(float, g2.y << 16), __builtin_bit_cast(float, g2.y & 0xffff0000u),
+                        has4 ? (float)g4[j - J0] : 0.f};
+    const int k[5] = {(int)(id & 255u), (int)((id >> 8) & 255u), (int)((id >> 16) & 255u), (int)(id >> 24),
+                      has4 ? (int)i4[j - J0] : 4};              // 4 = (kh 1, kw 1): never column 7 of this group
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const int kh = k[c] / 3, kw = k[c] - 3 * kh;
+#pragma unroll
+      for (int khv = 0; khv < 3; ++khv) {
+        const int r = j * SH - 1 + khv;                         // input row inside the strip (compile time)
+        if (r < 0 || r >= PR16) continue;
+        const float val = kh == khv ? v[c] : 0.f;
+        // output c covers input columns 2c - 1 + kw (relative to 8 b): c = 0 -> (-1), 0, 1; c = 4 -> 7 only
+        if (c == 0) { G[r][0] += kw == 1 ? val : 0.f; G[r][1] += kw == 2 ? val : 0.f; }
+        else if (c < 4) { G[r][2 * c - 1] += kw == 0 ? val : 0.f; G[r][2 * c] += kw == 1 ? val : 0.f; G[r][2 * c + 1] += kw == 2 ? val : 0.f; }
+        else { G[r][7] += kw == 0 ? val : 0.f; }
+      }
+    }
+  }
+}
+
+template <int SH>
+__global__ __launch_bounds__(256) void pool16_bwd_strip(const __bf16* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                        const float* __restrict__ xs, const float* __restrict__ xadd,
+                                                        __bf16* __restrict__ dx, int64_t planes, int H, int W, int OH, int OW) {
+  const int w8 = W >> 3, strips = (H + PR16 - 1) / PR16;
+  const int64_t total = planes * strips * w8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i % w8);
+    int64_t t = i / w8;
+    const int ih0 = (int)(t % strips) * PR16;
+    const int64_t pl = t / strips;
+    float G[PR16][8];
+    pool16_strip<SH>(dy + pl * (int64_t)OH * OW, idx + pl * (int64_t)OH * OW, ih0, b, OH, OW, G);
+    const float s = xs ? xs[pl] : 1.f, ad = xadd ? xadd[pl] : 0.f;
+#pragma unroll
+    for (int r = 0; r < PR16; ++r) {
+      if (ih0 + r >= H) continue;
+      float o[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) o[c] = G[r][c] * s + ad;
+      st8(dx + (pl * H + ih0 + r) * (int64_t)W + 8 * b, o);
+    }
+  }
+}
+
+template <int SH>
+__global__ __launch_bounds__(256) void pool16_bwd_dot_strip(const __bf16* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                            const __bf16* __restrict__ x, float* __restrict__ ds, int planes,
+                                                            int H, int W, int OH, int OW) {
+  __shared__ double sm[16];
+  const int w8 = W >> 3, strips = (H + PR16 - 1) / PR16;
+  for (int pl = blockIdx.x; pl < planes; pl += gridDim.x) {
+    const __bf16* xp = x + (int64_t)pl * H * W;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < strips * w8; i += 256) {
+      const int b = i % w8, ih0 = (i / w8) * PR16;
+      float G[PR16][8];
+      pool16_strip<SH>(dy + (int64_t)pl * OH * OW, idx + (int64_t)pl * OH * OW, ih0, b, OH, OW, G);
+      bf16x8 xv[PR16];
+#pragma unroll
+      for (int r = 0; r < PR16; ++r) xv[r] = *reinterpret_cast<const bf16x8*>(xp + (int64_t)min(ih0 + r, H - 1) * W + 8 * b);
+#pragma unroll
+      for (int r = 0; r < PR16; ++r) {
+        if (ih0 + r >= H) continue;
+        float f = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) f += G[r][c] * (float)xv[r][c];
+        acc += (double)f;
+      }
+    }
+    const double rsum = block_sum_d(acc, sm);
+    if (threadIdx.x == 0) ds[pl] = (float)rsum;
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256) void gap16_fwd_kernel(const __bf16* __restrict__ x, int ctot, int coff,
                                                         float* __restrict__ out, int N, int C, int HW) {
   __shared__ double sm[16];
@@ -489,6 +671,12 @@ extern "C" int dlio_bn_bf16_bwd(const void* dy, int dy_ctot, int dy_coff, const 
   return dlio_check_launch();
 }
 
+// rolling-window kernels (DLIO_POOL16_STRIP, default 1) vs one output row / one element per thread
+static bool pool16_strips() {
+  static const int v = getenv("DLIO_POOL16_STRIP") ? atoi(getenv("DLIO_POOL16_STRIP")) : 1;
+  return v != 0;
+}
+
 static bool pool16_ok(int H, int W, int OH, int OW, int K, int SH, int SW, int PH, int PW) {
   return K == 3 && SW == 2 && PH == 1 && PW == 1 && (SH == 1 || SH == 2) && (W & 15) == 0 && OW * 2 == W &&
          OH == (H + 2 - 3) / SH + 1;
@@ -501,6 +689,16 @@ extern "C" int dlio_maxpool_bf16_fwd(const void* x, const float* x_scale, void* 
   hipStream_t s = as_stream(stream);
   const int64_t planes = (int64_t)N * C, work = planes * OH * (OW / 8);
   DlioProfScope prof(10, s, 0.0, (double)planes * (2.0 * H * W + (idx ? 3.0 : 2.0) * OH * OW));
+  if (pool16_strips()) {
+    const int64_t wk = planes * cdiv(OH, SH == 1 ? 8 : 4) * (OW / 4);
+    if (SH == 1)
+      hipLaunchKernelGGL(pool16_fwd_strip<1>, dim3(ew_grid(wk, 256)), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x),
+                         x_scale, reinterpret_cast<__bf16*>(y), idx, planes, H, W, OH, OW);
+    else
+      hipLaunchKernelGGL(pool16_fwd_strip<2>, dim3(ew_grid(wk, 256)), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x),
+                         x_scale, reinterpret_cast<__bf16*>(y), idx, planes, H, W, OH, OW);
+    return dlio_check_launch();
+  }
   if (SH == 1)
     hipLaunchKernelGGL(pool16_fwd_kernel<1>, dim3(ew_grid(work, 256)), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x),
                        x_scale, reinterpret_cast<__bf16*>(y), idx, planes, H, W, OH, OW);
@@ -518,6 +716,16 @@ extern "C" int dlio_maxpool_bf16_bwd(const void* dy, const uint8_t* idx, const f
   hipStream_t s = as_stream(stream);
   const int64_t planes = (int64_t)N * C, work = planes * H * (W / 8);
   DlioProfScope prof(10, s, 0.0, (double)planes * (2.0 * H * W + 3.0 * OH * OW));
+  if (pool16_strips()) {
+    const int64_t wk = planes * cdiv(H, PR16) * (W / 8);
+    if (SH == 1)
+      hipLaunchKernelGGL(pool16_bwd_strip<1>, dim3(ew_grid(wk, 256)), dim3(256), 0, s, reinterpret_cast<const __bf16*>(dy),
+                         idx, x_scale, x_add, reinterpret_cast<__bf16*>(dx), planes, H, W, OH, OW);
+    else
+      hipLaunchKernelGGL(pool16_bwd_strip<2>, dim3(ew_grid(wk, 256)), dim3(256), 0, s, reinterpret_cast<const __bf16*>(dy),
+                         idx, x_scale, x_add, reinterpret_cast<__bf16*>(dx), planes, H, W, OH, OW);
+    return dlio_check_launch();
+  }
   if (SH == 1)
     hipLaunchKernelGGL(pool16_bwd_kernel<1>, dim3(ew_grid(work, 256)), dim3(256), 0, s, reinterpret_cast<const __bf16*>(dy),
                        idx, x_scale, x_add, reinterpret_cast<__bf16*>(dx), planes, H, W, OH, OW);
@@ -536,6 +744,15 @@ extern "C" int dlio_maxpool_bf16_bwd_dot(const void* dy, const uint8_t* idx, con
   int grid = N * C;
   if (grid > 65535) grid = 65535;
   DlioProfScope prof(10, s, 0.0, (double)N * C * (2.0 * H * W + 3.0 * OH * OW));
+  if (pool16_strips()) {
+    if (SH == 1)
+      hipLaunchKernelGGL(pool16_bwd_dot_strip<1>, dim3(grid), dim3(256), 0, s, reinterpret_cast<const __bf16*>(dy), idx,
+                         reinterpret_cast<const __bf16*>(x), ds, N * C, H, W, OH, OW);
+    else
+      hipLaunchKernelGGL(pool16_bwd_dot_strip<2>, dim3(grid), dim3(256), 0, s, reinterpret_cast<const __bf16*>(dy), idx,
+                         reinterpret_cast<const __bf16*>(x), ds, N * C, H, W, OH, OW);
+    return dlio_check_launch();
+  }
   if (SH == 1)
     hipLaunchKernelGGL(pool16_bwd_dot_kernel<1>, dim3(grid), dim3(256), 0, s, reinterpret_cast<const __bf16*>(dy), idx,
                        reinterpret_cast<const __bf16*>(x), ds, N * C, H, W, OH, OW);
