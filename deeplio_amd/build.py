@@ -30,7 +30,9 @@ def _newer(src, dst, extra=()):
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
-    hdrs = (os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "deeplio_hip.h"))
+    # every internal header (common.h, wgrad3.h, pool_strip.h ...) + the public one: a header edit rebuilds all objects
+    hdrs = tuple(os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")) + (
+        os.path.join(HERE, "..", "include", "deeplio_hip.h"),)
     jobs = []
     for f in srcs:
         src = os.path.join(CSRC, f)

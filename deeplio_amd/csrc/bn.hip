@@ -6,6 +6,7 @@
 // base_net.py:63, resnet.py:38, lidar_feat_nets.py:280-301 and the conv-bias gradient
 // reduction of nn.Conv2d backward.
 #include "common.h"
+#include "pool_strip.h"
 
 namespace {
 
@@ -620,6 +621,97 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(
   }
 }
 
+// the same two kernels as rolling windows (pool_strip.h): a thread owns 4 columns x PR rows, reads each pooled-gradient row
+// the strip can be the arg-max of ONCE (the per-element gather above reads it up to three times, under branches) and its
+// PR float4 of x; item = (strip, float4 column) of a plane
+template <int SH>
+__global__ __launch_bounds__(RB) void bn_pool_bwd_reduce_strip(
+    const float* __restrict__ dyp, const uint8_t* __restrict__ idx, const float* __restrict__ x,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ scale,
+    const float* __restrict__ beta, int N, int C, int H, int W, int OH, int OW, int splits, double* __restrict__ part) {
+  __shared__ double sm[2][16];
+  const int c = blockIdx.x / splits, sp = blockIdx.x % splits;
+  const float mu = mean[c], is = invstd[c], sc = scale[c], be = beta ? beta[c] : 0.f;
+  const int w4 = W >> 2, strips = (H + PR - 1) / PR;
+  const int64_t per = (int64_t)strips * w4, total = (int64_t)N * per;
+  double s0 = 0.0, s1 = 0.0;
+  for (int64_t i = (int64_t)sp * RB + threadIdx.x; i < total; i += (int64_t)splits * RB) {
+    const int n = (int)(i / per);
+    const int r = (int)(i - (int64_t)n * per);
+    const int ih0 = (r / w4) * PR, b = r - (r / w4) * w4;
+    const size_t pl = (size_t)n * C + c;
+    float G[PR][4];
+    pool3_strip<SH>(dyp + pl * OH * OW, idx + pl * OH * OW, ih0, b, OH, OW, G);
+    float4 xvs[PR];
+#pragma unroll
+    for (int q = 0; q < PR; ++q) xvs[q] = *reinterpret_cast<const float4*>(x + (pl * H + min(ih0 + q, H - 1)) * W + 4 * b);
+#pragma unroll
+    for (int q = 0; q < PR; ++q) {
+      if (ih0 + q >= H) continue;
+      const float xe[4] = {xvs[q].x, xvs[q].y, xvs[q].z, xvs[q].w};
+      float f0 = 0.f, f1 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float xh = (xe[k] - mu) * is;
+        const float gg = ((xe[k] - mu) * sc + be > 0.f) ? G[q][k] : 0.f;
+        f0 += gg; f1 += gg * xh;
+      }
+      s0 += f0; s1 += f1;
+    }
+  }
+  const double r0 = block_sum_d(s0, sm[0]);
+  const double r1 = block_sum_d(s1, sm[1]);
+  if (threadIdx.x == 0) {
+    part[((size_t)c * splits + sp) * 2 + 0] = r0;
+    part[((size_t)c * splits + sp) * 2 + 1] = r1;
+  }
+}
+
+template <int SH>
+__global__ __launch_bounds__(256) void bn_pool_bwd_apply_strip(
+    const float* __restrict__ dyp, const uint8_t* __restrict__ idx, const float* __restrict__ x,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ scale,
+    const float* __restrict__ beta, const double* __restrict__ part, double inv_cnt, int splits, float* __restrict__ dx,
+    float* dgamma, float* dbeta, int accumulate, int N, int C, int H, int W, int OH, int OW, int chunks, int chunk_len) {
+  __shared__ double sm[2][16];
+  const int chunk = blockIdx.x % chunks;
+  const int pl = blockIdx.x / chunks;
+  const int n = pl / C, c = pl - n * C;
+  double sg, sgx;
+  plane_partials(part, c, splits, sm[0], sm[1], sg, sgx);
+  if (n == 0 && chunk == 0 && threadIdx.x == 0) {
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)sg : (float)sg;
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)sgx : (float)sgx;
+  }
+  const float mu = mean[c], is = invstd[c], sc = scale[c], be = beta ? beta[c] : 0.f;
+  const float mg = (float)(sg * inv_cnt), mgx = (float)(sgx * inv_cnt);
+  const int w4 = W >> 2, strips = (H + PR - 1) / PR, per = strips * w4;
+  const int i1 = min(per, (chunk + 1) * chunk_len);
+  const float* gp = dyp + (size_t)pl * OH * OW;
+  const uint8_t* ip = idx + (size_t)pl * OH * OW;
+  for (int i = chunk * chunk_len + threadIdx.x; i < i1; i += 256) {
+    const int ih0 = (i / w4) * PR, b = i - (i / w4) * w4;
+    float G[PR][4];
+    pool3_strip<SH>(gp, ip, ih0, b, OH, OW, G);
+    float4 xvs[PR];
+#pragma unroll
+    for (int q = 0; q < PR; ++q) xvs[q] = *reinterpret_cast<const float4*>(x + ((size_t)pl * H + min(ih0 + q, H - 1)) * W + 4 * b);
+#pragma unroll
+    for (int q = 0; q < PR; ++q) {
+      if (ih0 + q >= H) continue;
+      const float xe[4] = {xvs[q].x, xvs[q].y, xvs[q].z, xvs[q].w};
+      float oe[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float xh = (xe[k] - mu) * is;
+        const float gg = ((xe[k] - mu) * sc + be > 0.f) ? G[q][k] : 0.f;
+        oe[k] = sc * (gg - mg - xh * mgx);
+      }
+      *reinterpret_cast<float4*>(dx + ((size_t)pl * H + ih0 + q) * W + 4 * b) = make_float4(oe[0], oe[1], oe[2], oe[3]);
+    }
+  }
+}
+
 static void plane_chunks(int planes, int per, bool whole_plane, int& chunks, int& chunk_len) {
   chunks = 1;
   if (!whole_plane && planes < 2048) {
@@ -727,6 +819,32 @@ extern "C" int dlio_bn_bwd_pool(const float* dy_pool, const uint8_t* idx, const 
   hipStream_t s = as_stream(stream);
   double* part = reinterpret_cast<double*>(ws);
   const double tensor_bytes = 4.0 * N * (double)C * HW;
+  static const int strip = getenv("DLIO_BN_POOL_STRIP") ? atoi(getenv("DLIO_BN_POOL_STRIP")) : 1;
+  if (strip) {
+    {
+      DlioProfScope prof(8, s, 0.0, tensor_bytes * 1.6);
+      if (SH == 1)
+        hipLaunchKernelGGL(bn_pool_bwd_reduce_strip<1>, dim3((unsigned)(C * splits)), dim3(RB), 0, s, dy_pool, idx, x, mean,
+                           invstd, scale, beta, N, C, H, W, OH, OW, splits, part);
+      else
+        hipLaunchKernelGGL(bn_pool_bwd_reduce_strip<2>, dim3((unsigned)(C * splits)), dim3(RB), 0, s, dy_pool, idx, x, mean,
+                           invstd, scale, beta, N, C, H, W, OH, OW, splits, part);
+      const int rc = dlio_check_launch();
+      if (rc) return rc;
+    }
+    int chunks, chunk_len;
+    plane_chunks(N * C, cdiv(H, PR) * (W / 4), false, chunks, chunk_len);
+    const dim3 grid((unsigned)(N * C * chunks));
+    const double inv_cnt = 1.0 / ((double)N * HW);
+    DlioProfScope prof(9, s, 0.0, tensor_bytes * 2.6);
+    if (SH == 1)
+      hipLaunchKernelGGL(bn_pool_bwd_apply_strip<1>, grid, dim3(256), 0, s, dy_pool, idx, x, mean, invstd, scale, beta, part,
+                         inv_cnt, splits, dx, dgamma, dbeta, accumulate, N, C, H, W, OH, OW, chunks, chunk_len);
+    else
+      hipLaunchKernelGGL(bn_pool_bwd_apply_strip<2>, grid, dim3(256), 0, s, dy_pool, idx, x, mean, invstd, scale, beta, part,
+                         inv_cnt, splits, dx, dgamma, dbeta, accumulate, N, C, H, W, OH, OW, chunks, chunk_len);
+    return dlio_check_launch();
+  }
   {
     DlioProfScope prof(8, s, 0.0, tensor_bytes * 1.6);
     if (SH == 1)
