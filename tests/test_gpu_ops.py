@@ -465,6 +465,15 @@ def test_gru_layer_large_batch_long_seq(dev):
     _run_rnn(dev, "gru", T=3, B=4, I=256, H=1024, reverse=True, batch_first=True)      # streamed path
 
 
+def test_persistent_rnn_rows_per_workgroup(dev):
+    """the persistent kernels take 1 / 2 / 8 batch rows per workgroup by batch size (rnn.hip lstm_rows_per_wg: <= 16, <= 64,
+    beyond): the two wider variants with a ragged last workgroup"""
+    _run_rnn(dev, "lstm", T=6, B=21, I=6, H=128, reverse=True, batch_first=True)      # 2 rows, 11 workgroups
+    _run_rnn(dev, "lstm", T=5, B=70, I=6, H=64, reverse=False, batch_first=False)     # 8 rows, 9 workgroups
+    _run_rnn(dev, "gru", T=5, B=70, I=6, H=32, reverse=True, batch_first=True)
+    _run_rnn(dev, "gru", T=6, B=33, I=6, H=128, reverse=False, batch_first=True)
+
+
 @pytest.mark.parametrize("order", [0, 1])
 def test_se3_chain_and_loss(dev, order):
     from deeplio_amd import ops
