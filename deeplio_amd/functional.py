@@ -267,16 +267,20 @@ class _CBR:
                 and (KH == 3 or (pad[0] == 0 and pad[1] == 0))):
             d.wbx3_1 = ops.conv_bx3_prepped(weight, 1)          # data-gradient direction: roles swapped
         if training:
-            # data-gradient layout for backward: fetched here, where `weight` is the long-lived
+            # data-gradient layouts for backward: fetched here, where `weight` is the long-lived
             # Parameter (the cache identifies weights by object; backward only sees unpacked copies)
-            d.wt2 = ops.conv2d_prepped(weight, 1)
+            plan = None
             if (d.SH > 1 or d.SW > 1) and need_dx and _DGRAD_PHASES[0]:
                 plan = _phase_plan(d)
-                if plan is not None:           # tap-subset layouts of the phase-decomposed data gradient
-                    d.wt_ph = {(it[0], it[1]): (ops.conv_bx3_prepped_phase(weight, d.SH, d.SW, it[0], it[1])
-                                                if _phase_on_bx3(d, it[2], it[3]) else
-                                                ops.conv2d_prepped_phase(weight, d.SH, d.SW, it[0], it[1]))
-                               for it in plan if it is not None}
+            # the fp32 layout only where conv_dgrad will run the fp32-MFMA kernel on it (every registered layout is
+            # rebuilt once per optimizer step: the split-bf16 layers' fp32 copies were a third of that launch)
+            if need_dx and getattr(d, "wbx3_1", None) is None and plan is None:
+                d.wt2 = ops.conv2d_prepped(weight, 1)
+            if plan is not None:               # tap-subset layouts of the phase-decomposed data gradient
+                d.wt_ph = {(it[0], it[1]): (ops.conv_bx3_prepped_phase(weight, d.SH, d.SW, it[0], it[1])
+                                            if _phase_on_bx3(d, it[2], it[3]) else
+                                            ops.conv2d_prepped_phase(weight, d.SH, d.SW, it[0], it[1]))
+                           for it in plan if it is not None}
         if stem:
             ops.conv3x5s2_bx3_fwd(x, wt, bias, raw, d)
         elif bx3 and KH == 1:
