@@ -386,9 +386,17 @@ __global__ __launch_bounds__(256) void linear_bwd_weight_kernel(
 // dW is read (accumulate) and written as float4
 __global__ __launch_bounds__(256) void linear_bwd_weight_v4_kernel(
     const float* __restrict__ dz, int lddz, const float* __restrict__ x, int ldx,
-    float* __restrict__ dw, int M, int N, int K, int accumulate) {
+    float* __restrict__ dw, float* __restrict__ db, int M, int N, int K, int accumulate) {
   const int k = (blockIdx.x * 256 + threadIdx.x) * 4;
   const int n0 = blockIdx.y * 4;
+  // the bias gradient of the block's four rows rides along (first k block, one lane per row; same m order as
+  // col_sum_kernel): one launch less per weight in the serial middle of the step
+  if (db && blockIdx.x == 0 && threadIdx.x >= 252 && n0 + (int)threadIdx.x - 252 < N) {
+    const int n = n0 + (int)threadIdx.x - 252;
+    float sb = 0.f;
+    for (int m = 0; m < M; ++m) sb += dz[(size_t)m * lddz + n];
+    db[n] = accumulate ? db[n] + sb : sb;
+  }
   if (k >= K) return;
   float4 acc[4];
 #pragma unroll
@@ -748,8 +756,11 @@ extern "C" int dlio_linear_bwd_weight(const float* dz, int lddz, const float* x,
   }
   if ((K & 3) == 0 && (ldx & 3) == 0 && K >= 256 &&
       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dw)) & 15) == 0)
+  {
     hipLaunchKernelGGL(linear_bwd_weight_v4_kernel, dim3(cdiv(K / 4, 256), cdiv(N, 4)), dim3(256), 0, s, dz, lddz, x, ldx, dw,
-                       M, N, K, accumulate);
+                       db, M, N, K, accumulate);
+    return dlio_check_launch();
+  }
   else
     hipLaunchKernelGGL(linear_bwd_weight_kernel, dim3(cdiv(K, 256), cdiv(N, 4)), dim3(256), 0, s, dz,
                        lddz, x, ldx, dw, M, N, K, accumulate);
