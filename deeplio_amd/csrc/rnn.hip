@@ -235,19 +235,23 @@ __global__ __launch_bounds__(4 * H) void lstm_persist_bwd(
 }
 
 // ------------------------------------------------------------------ streamed cells
-__global__ void lstm_cell_fwd_kernel(const float* __restrict__ pre, float* __restrict__ hcur,
-                                     float* __restrict__ ccur, float* __restrict__ hs, int ldhs,
+// zero_state (first step of a sequence that starts from zeros): the recurrent product is zero, the pre-activations are
+// gx[t] + b_hh read straight from `pre` = gx with row stride ldpre and the bias `bh` -- no state initialisation launch, no
+// weight-streaming launch for that step
+__global__ void lstm_cell_fwd_kernel(const float* __restrict__ pre, int ldpre, const float* __restrict__ bh,
+                                     float* __restrict__ hcur, float* __restrict__ ccur, float* __restrict__ hs, int ldhs,
                                      float* __restrict__ cs, float* __restrict__ hp,
                                      float* __restrict__ gates, int t, int B, int H, int rst,
-                                     int rsb) {
+                                     int rsb, int zero_state) {
   const int G = 4 * H;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < B * H; e += gridDim.x * blockDim.x) {
     const int b = e / H, k = e - b * H;
     const size_t r = (size_t)t * rst + (size_t)b * rsb;
-    const float* p = pre + (size_t)b * G;
-    const float ig = sigm(p[k]), fg = sigm(p[H + k]), gg = tanhf(p[2 * H + k]),
-                og = sigm(p[3 * H + k]);
-    const float cprev = ccur[e], hprev = hcur[e];
+    const float* p = pre + (size_t)b * ldpre;
+    const float b0 = bh ? bh[k] : 0.f, b1 = bh ? bh[H + k] : 0.f, b2 = bh ? bh[2 * H + k] : 0.f, b3 = bh ? bh[3 * H + k] : 0.f;
+    const float ig = sigm(p[k] + b0), fg = sigm(p[H + k] + b1), gg = tanhf(p[2 * H + k] + b2),
+                og = sigm(p[3 * H + k] + b3);
+    const float cprev = zero_state ? 0.f : ccur[e], hprev = zero_state ? 0.f : hcur[e];
     const float c = fmaf(fg, cprev, ig * gg);
     const float h = og * tanhf(c);
     hp[r * H + k] = hprev;
@@ -568,14 +572,21 @@ extern "C" int dlio_lstm_seq_fwd(const float* gx, const float* w_hh, const float
   float* ccur = f + (size_t)B * H;
   float* pre = f + (size_t)2 * B * H;  // [B][4H]
   const int n = B * H;
-  hipLaunchKernelGGL(init_state2_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, h0, hcur, c0, ccur, n);
+  const bool from_zero = !h0 && !c0;           // (the odometry LSTM: every sequence starts from zeros)
+  if (!from_zero) hipLaunchKernelGGL(init_state2_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, h0, hcur, c0, ccur, n);
   for (int step = 0; step < T; ++step) {
     const int t = reverse ? T - 1 - step : step;
+    if (step == 0 && from_zero) {
+      // the sum a + b_hh + 0 the linear launch would have produced, formed in the cell kernel: fl(gx + b) in both cases
+      hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, gx + (size_t)t * rst * 4 * H,
+                         rsb * 4 * H, b_hh, hcur, ccur, hs, ldhs, cs, hp, gates, t, B, H, rst, rsb, 1);
+      continue;
+    }
     int rc = dlio_linear_fwd(hcur, H, w_hh, b_hh, gx + (size_t)t * rst * 4 * H, rsb * 4 * H, pre,
                              4 * H, B, 4 * H, H, 0, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, pre, hcur, ccur,
-                       hs, ldhs, cs, hp, gates, t, B, H, rst, rsb);
+    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, (const float*)pre, 4 * H,
+                       (const float*)nullptr, hcur, ccur, hs, ldhs, cs, hp, gates, t, B, H, rst, rsb, 0);
   }
   if (hT || cT)
     hipLaunchKernelGGL(init_state2_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, (const float*)hcur, hT,

@@ -1029,8 +1029,11 @@ class RNNFn(Function):
                         ops.linear_fwd(inp, w_ih, b_ih, M=rows, out=bb["gx"])
                         if mode == "lstm":
                             c0 = state_c[l][d]
+                            # (nobody reads the state behind the last sub-sequence: no copy-out launch there)
+                            last = s == Sg - 1
                             ops.lstm_seq_fwd(bb["gx"], w_hh, b_hh, h0, c0, out_l, d * H, D * H, bb["cs"], bb["hp"],
-                                             bb["gates"], bb["hT"], bb["cT"], T, B, H, 1, T, d == 1)
+                                             bb["gates"], None if last else bb["hT"], None if last else bb["cT"], T, B, H,
+                                             1, T, d == 1)
                             rec["dirs"].append({"gates": bb["gates"], "cs": bb["cs"], "hp": bb["hp"], "c0": c0})
                             state_c[l][d] = bb["cT"]
                         else:
