@@ -367,7 +367,7 @@ __device__ __forceinline__ void wg_split8(const float (&v)[8], wg_bf16x8& h, wg_
 // (apply-on-load: the producer's activated output is never materialised); a lane owns one channel, so
 // the three constants are per-lane registers and the transform is 2 VALU per loaded value.
 template <int MR, int NT, bool BX3 = false, bool NAT = false, bool AFF = false>
-__global__ __launch_bounds__(256, 2) void wgrad1x1_direct_kernel(
+__global__ __launch_bounds__(256, (BX3 && AFF) ? 1 : 2) void wgrad1x1_direct_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ wsp,
     DlioConvDesc d, int co_tiles, int ci_chunks, int splits, int segs_per_img,
     const float* __restrict__ in_mean = nullptr, const float* __restrict__ in_scale = nullptr,
@@ -727,8 +727,10 @@ int launch_1x1(const float* x, const float* dy, float* dw, float* wsp, const Dli
                const float* in_scale = nullptr, const float* in_shift = nullptr) {
   // split-bf16 MFMAs where the fp32 MFMA time shows (64 x 64-channel tiles); narrow layers are HBM-bound
   static const int bx3 = getenv("DLIO_WGRAD_1X1_BX3") ? atoi(getenv("DLIO_WGRAD_1X1_BX3")) : 1;
-  static const int aff_bx3 = getenv("DLIO_WGRAD_1X1_AFF_BX3") ? atoi(getenv("DLIO_WGRAD_1X1_AFF_BX3")) : 0;
-  // in-affine + split-bf16 on the 64 x 64 tile needs 26 registers more than there are (scratch spills): fp32 MFMAs there
+  static const int aff_bx3 = getenv("DLIO_WGRAD_1X1_AFF_BX3") ? atoi(getenv("DLIO_WGRAD_1X1_AFF_BX3")) : 1;
+  // in-affine + split-bf16 on the 64 x 64 tile needs 26 registers more than two waves per SIMD leave: that instantiation is
+  // built for one wave per SIMD (launch bounds (256, 1): 210 VGPR + 64 AGPR, no scratch) -- the kernel runs one workgroup per
+  // CU anyway; family 2.30 -> 2.21 ms exclusive
   if (in_scale && aff_bx3 && (bx3 == 2 || (bx3 && MR == 2 && NT == 2)))
     hipLaunchKernelGGL((wgrad1x1_direct_kernel<MR, NT, true, false, true>), dim3(p.co_tiles * p.ci_chunks * p.splits),
                        dim3(256), 0, s, x, dy, wsp, d, p.co_tiles, p.ci_chunks, p.splits, p.segs, in_mean, in_scale,
