@@ -789,6 +789,101 @@ __global__ __launch_bounds__(256) void wgrad_merge_3x5_kernel(const float* __res
   dw[i] = accumulate ? dw[i] + v : v;
 }
 
+// ---- 3x3 taps, stride (2, 2), padding 1 (FlowNet conv4-6, lidar_feat_nets.py:252-257; ResNet layer3 / layer4) as NINE 1x1
+// weight gradients: tap (kh, kw) pairs dY[oh][ow] with X[2 oh + kh - 1][2 ow + kw - 1], i.e. with the (row parity, column
+// parity) phase image of X at index (oh + dr, ow + dc), dr = -1 for kh = 0, dc = -1 for kw = 0, else 0.  dY and the four
+// phase images are copied once into planes of the SAME padded geometry ((OH + 2) rows x PW columns, PW % 4 == 0, zero
+// rows / column in front), so a shift is a flat pointer offset and the zero padding of dY silences whatever a shifted
+// read wraps onto; the two odd-column phases also get a copy shifted by one column, so every operand stays 16-byte
+// aligned.  Each tap is then the HBM-bound direct 1x1 kernel (wgrad1x1_direct_kernel) on (dY plane, phase plane).
+__global__ __launch_bounds__(256) void s2_pad_dy_kernel(const float* __restrict__ dy, float* __restrict__ dyp, int64_t planes_out,
+                                                        int Cout, int out_ctot, int out_coff, int OH, int OW, int PW, int S) {
+  const int S4 = S >> 2;
+  const int64_t total = planes_out * S4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pl = i / S4;
+    const int f = (int)(i - pl * S4) * 4;
+    const int rp = f / PW, cp = f - rp * PW;              // PW % 4 == 0: the four elements share a row
+    const int64_t n = pl / Cout;
+    const int c = (int)(pl - n * Cout);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const int oh = rp - 2;
+    if (oh >= 0 && oh < OH) {
+      const float* src = dy + ((n * out_ctot + out_coff + c) * (int64_t)OH + oh) * OW;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ow = cp + e - 1;
+        if (ow >= 0 && ow < OW) v[e] = src[ow];
+      }
+    }
+    *reinterpret_cast<float4*>(dyp + pl * S + f) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// images: 0 = (even rows, even cols), 1 = (even, odd), 2 = (even, odd) shifted one column, 3 = (odd, even), 4 = (odd, odd),
+// 5 = (odd, odd) shifted
+__global__ __launch_bounds__(256) void s2_phase_split_kernel(const float* __restrict__ x, float* __restrict__ img, int64_t planes,
+                                                             int Cin, int in_ctot, int in_coff, int H, int W, int OH, int PW,
+                                                             int S, int64_t img_stride) {
+  const int S4 = S >> 2;
+  const int64_t total = planes * S4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pl = i / S4;
+    const int f = (int)(i - pl * S4) * 4;
+    const int rp = f / PW, cp = f - rp * PW;
+    const int64_t n = pl / Cin;
+    const int c = (int)(pl - n * Cin);
+    const float* xp = x + (n * in_ctot + in_coff + c) * (int64_t)H * W;
+    const int r = rp - 2;
+#pragma unroll
+    for (int im = 0; im < 6; ++im) {
+      const int rodd = im >= 3, codd = (im % 3) != 0, sh = (im % 3) == 2;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      const int ih = 2 * r + rodd;
+      if (r >= 0 && r < OH && ih < H) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int cc = cp + e - 1 - sh;                // phase column
+          const int iw = 2 * cc + codd;
+          if (cc >= 0 && iw < W) v[e] = xp[(int64_t)ih * W + iw];
+        }
+      }
+      *reinterpret_cast<float4*>(img + im * img_stride + pl * S + f) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_scatter_taps_kernel(const float* __restrict__ t9, float* __restrict__ dw,
+                                                                 int64_t ncc, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= ncc * 9) return;
+  const int64_t cc = i / 9;
+  const int tap = (int)(i - cc * 9);
+  const float v = t9[(int64_t)tap * ncc + cc];
+  dw[i] = accumulate ? dw[i] + v : v;
+}
+
+struct WgS2Plan { DlioConvDesc sub; Wg1Plan q; int PW, S; size_t dyp_floats, img_floats, ws_bytes; };
+
+bool make_plan_s2_taps(const DlioConvDesc& d, WgS2Plan& p) {
+  static const int on = getenv("DLIO_WGRAD_S2_TAPS") ? atoi(getenv("DLIO_WGRAD_S2_TAPS")) : 1;
+  if (!on || d.KH != 3 || d.KW != 3 || d.SH != 2 || d.SW != 2 || d.PH != 1 || d.PW != 1 || d.Cin < 32 || d.Cout < 32 ||
+      d.OH != (d.H - 1) / 2 + 1 || d.OW != (d.W - 1) / 2 + 1 || (int64_t)d.N * d.OH * d.OW < 8192)
+    return false;
+  p.PW = (d.OW + 1 + 3) & ~3;
+  p.S = ((d.OH + 2) * p.PW + 31) & ~31;
+  p.sub = d;
+  p.sub.H = 1; p.sub.W = p.S; p.sub.OH = 1; p.sub.OW = p.S;
+  p.sub.KH = p.sub.KW = 1; p.sub.SH = p.sub.SW = 1; p.sub.PH = p.sub.PW = 0;
+  p.sub.in_ctot = d.Cin; p.sub.in_coff = 0; p.sub.out_ctot = d.Cout; p.sub.out_coff = 0; p.sub.in_relu = 0;
+  if (!make_plan_1x1(p.sub, p.q)) return false;
+  p.dyp_floats = (size_t)d.N * d.Cout * p.S;
+  p.img_floats = (size_t)d.N * d.Cin * p.S;
+  if ((p.dyp_floats + 6 * p.img_floats) * 4 >= 0xffffff00ull) return false;       // 32-bit buffer offsets per operand
+  p.ws_bytes = (p.dyp_floats + 6 * p.img_floats + (size_t)9 * d.Cout * d.Cin) * sizeof(float) + p.q.ws_bytes + 256;
+  return true;
+}
+
 struct Wg35Plan { DlioConvDesc sub; DlioWgrad3Plan p3; size_t phase_floats, ws_bytes; };
 
 bool make_plan_3x5s2(const DlioConvDesc& d, Wg35Plan& q) {
@@ -866,6 +961,8 @@ extern "C" size_t dlio_conv2d_wgrad_ws_bytes(const DlioConvDesc* d) {
   if (dlio_wgrad3_plan(*d, 4, p3) && p3.ws_bytes > need) need = p3.ws_bytes;
   Wg35Plan q35;
   if (make_plan_3x5s2(*d, q35) && q35.ws_bytes > need) need = q35.ws_bytes;
+  WgS2Plan qs2;
+  if (make_plan_s2_taps(*d, qs2) && qs2.ws_bytes > need) need = qs2.ws_bytes;
   return need;
 }
 
@@ -902,6 +999,38 @@ extern "C" int dlio_conv2d_wgrad(const float* x, const float* dy, float* dw,
       const int64_t n = (int64_t)d.Cout * d.Cin * 9;
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(n, 64)), dim3(256), 0, s, wsp, dw, n, p3.splits,
                          accumulate);
+      rc = dlio_check_launch();
+    }
+    dlio_prof_end(pkind, s);
+    return rc;
+  }
+  WgS2Plan qs2;
+  if (!in_scale && make_plan_s2_taps(d, qs2) && ws_bytes >= qs2.ws_bytes && (reinterpret_cast<uintptr_t>(ws) & 15) == 0) {
+    const size_t ncc = (size_t)d.Cout * d.Cin;
+    float* dyp = wsp;                                    // first: shifted reads in front of image 0 land in here
+    float* img = dyp + qs2.dyp_floats;
+    float* t9 = img + 6 * qs2.img_floats;
+    float* slabs = t9 + ((9 * ncc + 3) & ~(size_t)3);
+    const int64_t po = (int64_t)d.N * d.Cout, pi = (int64_t)d.N * d.Cin;
+    hipLaunchKernelGGL(s2_pad_dy_kernel, dim3(ew_grid(po * (qs2.S / 4), 256)), dim3(256), 0, s, dy, dyp, po, d.Cout, d.out_ctot,
+                       d.out_coff, d.OH, d.OW, qs2.PW, qs2.S);
+    hipLaunchKernelGGL(s2_phase_split_kernel, dim3(ew_grid(pi * (qs2.S / 4), 256)), dim3(256), 0, s, x, img, pi, d.Cin,
+                       d.in_ctot, d.in_coff, d.H, d.W, d.OH, qs2.PW, qs2.S, (int64_t)qs2.img_floats);
+    rc = dlio_check_launch();
+    for (int tap = 0; tap < 9 && !rc; ++tap) {
+      const int kh = tap / 3, kw = tap - 3 * kh;
+      const int im = (kh == 1 ? 0 : 3) + (kw == 1 ? 0 : kw == 0 ? 2 : 1);
+      const float* xi = img + (size_t)im * qs2.img_floats + (kh == 0 ? -qs2.PW : 0);
+      float* out = t9 + (size_t)tap * ncc;
+      const Wg1Plan& q = qs2.q;
+      if (q.mr == 1 && q.nt == 1) rc = launch_1x1<1, 1>(xi, dyp, out, slabs, qs2.sub, q, 0, s);
+      else if (q.mr == 1) rc = launch_1x1<1, 2>(xi, dyp, out, slabs, qs2.sub, q, 0, s);
+      else if (q.nt == 1) rc = launch_1x1<2, 1>(xi, dyp, out, slabs, qs2.sub, q, 0, s);
+      else rc = launch_1x1<2, 2>(xi, dyp, out, slabs, qs2.sub, q, 0, s);
+    }
+    if (!rc) {
+      hipLaunchKernelGGL(wgrad_scatter_taps_kernel, dim3((unsigned)cdiv64((int64_t)ncc * 9, 256)), dim3(256), 0, s, t9, dw,
+                         (int64_t)ncc, accumulate);
       rc = dlio_check_launch();
     }
     dlio_prof_end(pkind, s);

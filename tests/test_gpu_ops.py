@@ -1007,6 +1007,33 @@ def test_conv_bx3_taps_explicit_output_extent(dev, k, pad, extra):
         ops.conv_bx3_taps_fwd(x.to(dev), wt, None, y, ops.conv_desc(N, Cin, H, W, Cout, 3, 1, 1, 1, 0, 0))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 32, 40, 130, 131), (1, 70, 33, 192, 190), (3, 48, 64, 65, 256)])
+def test_conv3x3_stride2_wgrad_as_nine_1x1(dev, case):
+    """weight gradient of 3x3 / stride 2 / padding 1 layers (FlowNet conv4-6, ResNet layer3 / layer4) through nine direct 1x1
+    weight gradients on padded phase images (conv_wgrad.hip make_plan_s2_taps): odd and even extents, channel slices of
+    both operands, accumulation into an existing dW"""
+    from deeplio_amd import ops
+    N, Cin, Cout, H, W = case
+    g = _g(58)
+    xb = torch.randn(N, Cin + 3, H, W, generator=g)
+    x = xb[:, 2:2 + Cin]
+    w = torch.randn(Cout, Cin, 3, 3, generator=g).double().requires_grad_(True)
+    y = F.conv2d(x.double(), w, None, (2, 2), (1, 1))
+    dyb = torch.randn(N, Cout + 2, y.shape[2], y.shape[3], generator=g)
+    dy = dyb[:, 1:1 + Cout]
+    y.backward(dy.double())
+    d = ops.conv_desc(N, Cin, H, W, Cout, 3, 3, 2, 2, 1, 1, in_ctot=Cin + 3, in_coff=2, out_ctot=Cout + 2, out_coff=1)
+    assert (d.OH, d.OW) == tuple(y.shape[2:])
+    dw0 = torch.randn(Cout, Cin, 3, 3, generator=g)
+    dw = dw0.clone().to(dev)
+    ops.conv2d_wgrad(xb.to(dev), dyb.to(dev), dw, d, accumulate=True)
+    assert rel_err(dw, dw0.double() + w.grad) < 1e-5
+    dw2 = torch.empty(Cout, Cin, 3, 3, device=dev)
+    ops.conv2d_wgrad(xb.to(dev), dyb.to(dev), dw2, d)
+    assert rel_err(dw2, w.grad) < 1e-5
+
+
 # Fire layers of the PointSeg encoders at the LAUNCH sizes bench.py times (N = B*S = 16 frame pairs of BASELINE
 # configs[1]): the XCD-ordered / one-workgroup-per-CU weight gradients, the split-K and k-split 1x1 kernels and the
 # TWN = 2 data gradients only take these branches at full size.
