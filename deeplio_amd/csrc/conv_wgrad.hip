@@ -863,7 +863,116 @@ __global__ __launch_bounds__(256) void wgrad_scatter_taps_kernel(const float* __
   dw[i] = accumulate ? dw[i] + v : v;
 }
 
-struct WgS2Plan { DlioConvDesc sub; Wg1Plan q; int PW, S; size_t dyp_floats, img_floats, ws_bytes; };
+// ---- C[m][n] = sum_k A[m][k] B[n][k] over the planes above ([image][channel][S] rows, K = pixels contiguous) on the split-bf16
+// scheme with 128 x 128 tiles: the tap products of wide layers (256 x 512 channels) through the direct 1x1 kernel's
+// 64 x 64 tiles re-read both operands 4x / 8x.  Workgroup = 4 waves, each 64 x 64 (2 x 2 MFMA tiles); a stage = 32 pixels of
+// 128 + 128 rows, loaded as float4 (eight lanes cover the 128 contiguous bytes of a row), split ONCE into three bf16 planes
+// and stored k-contiguous in LDS (row stride 40 bf16 = 80 bytes: 16-byte aligned fragments, banks spread); global loads of
+// stage s + 1 fly under the MFMAs of stage s, one barrier per stage; the pixel range of all images is cut into `splits`
+// slabs (fixed-order reduction by wgrad_reduce_kernel).  M % 128 == 0, N % 128 == 0, S % 32 == 0.
+constexpr int GT = 128, GK = 32, GLDK = 40;
+__global__ __launch_bounds__(256, 1) void gemm_nt_bx3_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                             float* __restrict__ slab, int M, int N, int S, int nimg,
+                                                             int tiles_n, int splits) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 gsm[];      // [2 stages][A | B][3 planes][128][GLDK]
+  constexpr int PLANE = GT * GLDK, OPER = 3 * PLANE, STAGE = 2 * OPER;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  int bid = blockIdx.x;
+  const int split = bid % splits; bid /= splits;
+  const int tn = bid % tiles_n, tm = bid / tiles_n;
+  const int spi = S / GK;                                            // stages per image
+  const int64_t total = (int64_t)nimg * spi;
+  const int64_t g0 = total * split / splits, g1 = total * (split + 1) / splits;
+  const size_t a_img = (size_t)M * S, b_img = (size_t)N * S;
+  const float* Ab = A + (size_t)tm * GT * S;
+  const float* Bb = B + (size_t)tn * GT * S;
+  const int lr = tid >> 3, lk = (tid & 7) * 4;                       // row (+32 per pass), first k of the thread's float4
+  float4 ra[4], rb[4];
+  auto gload = [&](int64_t g) {
+    const int64_t img = g / spi;
+    const int ks = (int)(g - img * spi) * GK + lk;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = *reinterpret_cast<const float4*>(Ab + img * a_img + (size_t)(lr + 32 * i) * S + ks);
+      rb[i] = *reinterpret_cast<const float4*>(Bb + img * b_img + (size_t)(lr + 32 * i) * S + ks);
+    }
+  };
+  auto sstore = [&](int st) {
+    __bf16* base = gsm + (size_t)st * STAGE;
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 v = o == 0 ? ra[i] : rb[i];
+        const unsigned h0 = wg_cvt_pk(v.x, v.y), h1 = wg_cvt_pk(v.z, v.w);
+        const float r0 = v.x - wg_as_f(h0 << 16), r1 = v.y - wg_as_f(h0 & 0xffff0000u);
+        const float r2 = v.z - wg_as_f(h1 << 16), r3 = v.w - wg_as_f(h1 & 0xffff0000u);
+        const unsigned m0 = wg_cvt_pk(r0, r1), m1 = wg_cvt_pk(r2, r3);
+        const unsigned q0 = wg_cvt_pk(r0 - wg_as_f(m0 << 16), r1 - wg_as_f(m0 & 0xffff0000u));
+        const unsigned q1 = wg_cvt_pk(r2 - wg_as_f(m1 << 16), r3 - wg_as_f(m1 & 0xffff0000u));
+        __bf16* dst = base + o * OPER + (lr + 32 * i) * GLDK + lk;
+        *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(dst + PLANE) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(dst + 2 * PLANE) = make_uint2(q0, q1);
+      }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+  const int wm = wave >> 1, wn = wave & 1;
+  auto compute = [&](int st) {
+    const __bf16* base = gsm + (size_t)st * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < GK; kk += 16) {
+      wg_bf16x8 a[2][3], b[2][3];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          a[m][p] = *reinterpret_cast<const wg_bf16x8*>(base + p * PLANE + (64 * wm + 32 * m + l31) * GLDK + kk + 8 * half);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          b[t][p] = *reinterpret_cast<const wg_bf16x8*>(base + OPER + p * PLANE + (64 * wn + 32 * t + l31) * GLDK + kk + 8 * half);
+      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};     // smallest products first
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][PA[q]], b[t][PB[q]], acc[m][t], 0, 0, 0);
+    }
+  };
+  if (g0 < g1) {
+    gload(g0);
+    sstore(0);
+    __syncthreads();
+    int st = 0;
+    for (int64_t g = g0; g < g1; ++g, st ^= 1) {
+      const bool more = g + 1 < g1;
+      if (more) gload(g + 1);
+      compute(st);
+      if (more) sstore(st ^ 1);          // the other stage was read last during step g - 1: every wave is past that barrier
+      __syncthreads();
+    }
+  }
+  float* out = slab + (size_t)split * M * N + (size_t)(tm * GT + 64 * wm) * N + tn * GT + 64 * wn;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        out[(size_t)(32 * m + (r & 3) + 8 * (r >> 2) + 4 * half) * N + 32 * t + l31] = acc[m][t][r];
+}
+
+struct WgS2Plan { DlioConvDesc sub; Wg1Plan q; int PW, S, gemm, gsplits; size_t dyp_floats, img_floats, ws_bytes; };
 
 bool make_plan_s2_taps(const DlioConvDesc& d, WgS2Plan& p) {
   static const int on = getenv("DLIO_WGRAD_S2_TAPS") ? atoi(getenv("DLIO_WGRAD_S2_TAPS")) : 1;
@@ -880,7 +989,22 @@ bool make_plan_s2_taps(const DlioConvDesc& d, WgS2Plan& p) {
   p.dyp_floats = (size_t)d.N * d.Cout * p.S;
   p.img_floats = (size_t)d.N * d.Cin * p.S;
   if ((p.dyp_floats + 6 * p.img_floats) * 4 >= 0xffffff00ull) return false;       // 32-bit buffer offsets per operand
-  p.ws_bytes = (p.dyp_floats + 6 * p.img_floats + (size_t)9 * d.Cout * d.Cin) * sizeof(float) + p.q.ws_bytes + 256;
+  // wide layers: the tap products on the 128 x 128-tile GEMM (DLIO_WGRAD_S2_GEMM, default 1)
+  static const int gemm_on = getenv("DLIO_WGRAD_S2_GEMM") ? atoi(getenv("DLIO_WGRAD_S2_GEMM")) : 1;
+  p.gemm = gemm_on && d.Cout % GT == 0 && d.Cin % GT == 0;
+  p.gsplits = 1;
+  size_t slab_bytes = p.q.ws_bytes;
+  if (p.gemm) {
+    const int tiles = (d.Cout / GT) * (d.Cin / GT);
+    const int64_t stages = (int64_t)d.N * (p.S / GK);
+    int sp = dlio_num_cus() / tiles;
+    if (sp < 1) sp = 1;
+    if (sp > stages / 4) sp = (int)(stages / 4 > 0 ? stages / 4 : 1);       // at least four stages per workgroup
+    p.gsplits = sp;
+    const size_t g = (size_t)sp * d.Cout * d.Cin * sizeof(float);
+    if (g > slab_bytes) slab_bytes = g;
+  }
+  p.ws_bytes = (p.dyp_floats + 6 * p.img_floats + (size_t)9 * d.Cout * d.Cin) * sizeof(float) + slab_bytes + 256;
   return true;
 }
 
@@ -1023,6 +1147,21 @@ extern "C" int dlio_conv2d_wgrad(const float* x, const float* dy, float* dw,
       const float* xi = img + (size_t)im * qs2.img_floats + (kh == 0 ? -qs2.PW : 0);
       float* out = t9 + (size_t)tap * ncc;
       const Wg1Plan& q = qs2.q;
+      if (qs2.gemm) {
+        static bool attr_done = false;
+        constexpr int lds = 2 * 2 * 3 * GT * GLDK * (int)sizeof(__bf16);
+        if (!attr_done) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bx3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+          attr_done = true;
+        }
+        const int tiles_n = d.Cin / GT, tiles_m = d.Cout / GT;
+        hipLaunchKernelGGL(gemm_nt_bx3_kernel, dim3((unsigned)(tiles_m * tiles_n * qs2.gsplits)), dim3(256), lds, s, dyp, xi, slabs,
+                           d.Cout, d.Cin, qs2.S, d.N, tiles_n, qs2.gsplits);
+        const int64_t nn = (int64_t)ncc;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(nn, 64)), dim3(256), 0, s, slabs, out, nn, qs2.gsplits, 0);
+        rc = dlio_check_launch();
+        continue;
+      }
       if (q.mr == 1 && q.nt == 1) rc = launch_1x1<1, 1>(xi, dyp, out, slabs, qs2.sub, q, 0, s);
       else if (q.mr == 1) rc = launch_1x1<1, 2>(xi, dyp, out, slabs, qs2.sub, q, 0, s);
       else if (q.nt == 1) rc = launch_1x1<2, 1>(xi, dyp, out, slabs, qs2.sub, q, 0, s);

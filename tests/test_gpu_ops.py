@@ -1008,7 +1008,8 @@ def test_conv_bx3_taps_explicit_output_extent(dev, k, pad, extra):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", [(2, 32, 40, 130, 131), (1, 70, 33, 192, 190), (3, 48, 64, 65, 256)])
+@pytest.mark.parametrize("case", [(2, 32, 40, 130, 131), (1, 70, 33, 192, 190), (3, 48, 64, 65, 256),
+                                  (2, 128, 256, 130, 131), (5, 256, 128, 66, 64)])      # the last two: 128 x 128-tile GEMM per tap
 def test_conv3x3_stride2_wgrad_as_nine_1x1(dev, case):
     """weight gradient of 3x3 / stride 2 / padding 1 layers (FlowNet conv4-6, ResNet layer3 / layer4) through nine direct 1x1
     weight gradients on padded phase images (conv_wgrad.hip make_plan_s2_taps): odd and even extents, channel slices of
