@@ -871,10 +871,14 @@ __global__ __launch_bounds__(256) void wgrad_scatter_taps_kernel(const float* __
 // stage s + 1 fly under the MFMAs of stage s, one barrier per stage; the pixel range of all images is cut into `splits`
 // slabs (fixed-order reduction by wgrad_reduce_kernel).  M % 128 == 0, N % 128 == 0, S % 32 == 0.
 constexpr int GT = 128, GK = 32, GLDK = 40;
-__global__ __launch_bounds__(256, 1) void gemm_nt_bx3_kernel(const float* __restrict__ A, const float* __restrict__ B,
-                                                             float* __restrict__ slab, int M, int N, int S, int nimg,
-                                                             int tiles_n, int splits) {
-  extern __shared__ __attribute__((aligned(16))) __bf16 gsm[];      // [2 stages][A | B][3 planes][128][GLDK]
+struct GemmTaps { long long boff[9]; };      // float offset of each tap's B operand (phase image + row shift) from B
+__global__ __launch_bounds__(256, 2) void gemm_nt_bx3_kernel(const float* __restrict__ A, const float* __restrict__ B0,
+                                                             float* __restrict__ slab0, int M, int N, int S, int nimg,
+                                                             int tiles_n, int splits, GemmTaps taps) {
+  // blockIdx.y = tap: the nine products of a layer in ONE launch (they share A = dY; 9 x the workgroups, so few pixel slabs)
+  const float* B = B0 + taps.boff[blockIdx.y];
+  float* slab = slab0 + (size_t)blockIdx.y * splits * M * N;
+  extern __shared__ __attribute__((aligned(16))) __bf16 gsm[];      // [A | B][3 planes][128][GLDK]
   constexpr int PLANE = GT * GLDK, OPER = 3 * PLANE, STAGE = 2 * OPER;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
   int bid = blockIdx.x;
@@ -950,15 +954,17 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bx3_kernel(const float* __rest
     }
   };
   if (g0 < g1) {
+    // ONE LDS stage per workgroup (61 KB) so that two workgroups share a CU: a stage of MFMAs is shorter than a memory
+    // round trip, the second workgroup's MFMAs are what covers it (single workgroup with two LDS stages: 35 % MFMA busy)
     gload(g0);
     sstore(0);
     __syncthreads();
-    int st = 0;
-    for (int64_t g = g0; g < g1; ++g, st ^= 1) {
+    for (int64_t g = g0; g < g1; ++g) {
       const bool more = g + 1 < g1;
       if (more) gload(g + 1);
-      compute(st);
-      if (more) sstore(st ^ 1);          // the other stage was read last during step g - 1: every wave is past that barrier
+      compute(0);
+      __syncthreads();
+      if (more) sstore(0);
       __syncthreads();
     }
   }
@@ -970,6 +976,20 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bx3_kernel(const float* __rest
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         out[(size_t)(32 * m + (r & 3) + 8 * (r >> 2) + 4 * half) * N + 32 * t + l31] = acc[m][t][r];
+}
+
+// dW[cc][tap] (+)= sum over the tap's slabs, fixed order (slabs [tap][split][ncc])
+__global__ __launch_bounds__(256) void wgrad_reduce_taps_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
+                                                                int64_t ncc, int splits, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= ncc * 9) return;
+  const int tap = (int)(i / ncc);
+  const int64_t cc = i - (int64_t)tap * ncc;
+  const float* p = slabs + (size_t)tap * splits * ncc + cc;
+  float v = 0.f;
+  for (int k = 0; k < splits; ++k) v += p[(size_t)k * ncc];
+  float* o = dw + cc * 9 + tap;
+  *o = accumulate ? *o + v : v;
 }
 
 struct WgS2Plan { DlioConvDesc sub; Wg1Plan q; int PW, S, gemm, gsplits; size_t dyp_floats, img_floats, ws_bytes; };
@@ -997,11 +1017,11 @@ bool make_plan_s2_taps(const DlioConvDesc& d, WgS2Plan& p) {
   if (p.gemm) {
     const int tiles = (d.Cout / GT) * (d.Cin / GT);
     const int64_t stages = (int64_t)d.N * (p.S / GK);
-    int sp = dlio_num_cus() / tiles;
+    int sp = 2 * dlio_num_cus() / (tiles * 9);                              // nine taps per launch, two workgroups per CU
     if (sp < 1) sp = 1;
     if (sp > stages / 4) sp = (int)(stages / 4 > 0 ? stages / 4 : 1);       // at least four stages per workgroup
     p.gsplits = sp;
-    const size_t g = (size_t)sp * d.Cout * d.Cin * sizeof(float);
+    const size_t g = (size_t)9 * sp * d.Cout * d.Cin * sizeof(float);
     if (g > slab_bytes) slab_bytes = g;
   }
   p.ws_bytes = (p.dyp_floats + 6 * p.img_floats + (size_t)9 * d.Cout * d.Cin) * sizeof(float) + slab_bytes + 256;
@@ -1141,27 +1161,34 @@ extern "C" int dlio_conv2d_wgrad(const float* x, const float* dy, float* dw,
     hipLaunchKernelGGL(s2_phase_split_kernel, dim3(ew_grid(pi * (qs2.S / 4), 256)), dim3(256), 0, s, x, img, pi, d.Cin,
                        d.in_ctot, d.in_coff, d.H, d.W, d.OH, qs2.PW, qs2.S, (int64_t)qs2.img_floats);
     rc = dlio_check_launch();
+    if (!rc && qs2.gemm) {
+      static bool attr_done = false;
+      constexpr int lds = 2 * 3 * GT * GLDK * (int)sizeof(__bf16);
+      if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bx3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+      }
+      GemmTaps taps;
+      for (int tap = 0; tap < 9; ++tap) {
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        const int im = (kh == 1 ? 0 : 3) + (kw == 1 ? 0 : kw == 0 ? 2 : 1);
+        taps.boff[tap] = (long long)im * (long long)qs2.img_floats + (kh == 0 ? -qs2.PW : 0);
+      }
+      const int tiles_n = d.Cin / GT, tiles_m = d.Cout / GT;
+      hipLaunchKernelGGL(gemm_nt_bx3_kernel, dim3((unsigned)(tiles_m * tiles_n * qs2.gsplits), 9), dim3(256), lds, s, dyp, img,
+                         slabs, d.Cout, d.Cin, qs2.S, d.N, tiles_n, qs2.gsplits, taps);
+      hipLaunchKernelGGL(wgrad_reduce_taps_kernel, dim3((unsigned)cdiv64((int64_t)ncc * 9, 256)), dim3(256), 0, s, slabs, dw,
+                         (int64_t)ncc, qs2.gsplits, accumulate);
+      rc = dlio_check_launch();
+      dlio_prof_end(pkind, s);
+      return rc;
+    }
     for (int tap = 0; tap < 9 && !rc; ++tap) {
       const int kh = tap / 3, kw = tap - 3 * kh;
       const int im = (kh == 1 ? 0 : 3) + (kw == 1 ? 0 : kw == 0 ? 2 : 1);
       const float* xi = img + (size_t)im * qs2.img_floats + (kh == 0 ? -qs2.PW : 0);
       float* out = t9 + (size_t)tap * ncc;
       const Wg1Plan& q = qs2.q;
-      if (qs2.gemm) {
-        static bool attr_done = false;
-        constexpr int lds = 2 * 2 * 3 * GT * GLDK * (int)sizeof(__bf16);
-        if (!attr_done) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bx3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-          attr_done = true;
-        }
-        const int tiles_n = d.Cin / GT, tiles_m = d.Cout / GT;
-        hipLaunchKernelGGL(gemm_nt_bx3_kernel, dim3((unsigned)(tiles_m * tiles_n * qs2.gsplits)), dim3(256), lds, s, dyp, xi, slabs,
-                           d.Cout, d.Cin, qs2.S, d.N, tiles_n, qs2.gsplits);
-        const int64_t nn = (int64_t)ncc;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(nn, 64)), dim3(256), 0, s, slabs, out, nn, qs2.gsplits, 0);
-        rc = dlio_check_launch();
-        continue;
-      }
       if (q.mr == 1 && q.nt == 1) rc = launch_1x1<1, 1>(xi, dyp, out, slabs, qs2.sub, q, 0, s);
       else if (q.mr == 1) rc = launch_1x1<1, 2>(xi, dyp, out, slabs, qs2.sub, q, 0, s);
       else if (q.nt == 1) rc = launch_1x1<2, 1>(xi, dyp, out, slabs, qs2.sub, q, 0, s);
