@@ -870,9 +870,12 @@ __global__ __launch_bounds__(256) void wgrad_scatter_taps_kernel(const float* __
 // and stored k-contiguous in LDS (row stride 40 bf16 = 80 bytes: 16-byte aligned fragments, banks spread); global loads of
 // stage s + 1 fly under the MFMAs of stage s, one barrier per stage; the pixel range of all images is cut into `splits`
 // slabs (fixed-order reduction by wgrad_reduce_kernel).  M % 128 == 0, N % 128 == 0, S % 32 == 0.
-constexpr int GT = 128, GK = 32, GLDK = 40;
+#ifndef DLIO_GEMM_GK
+#define DLIO_GEMM_GK 32
+#endif
+constexpr int GT = 128, GK = DLIO_GEMM_GK, GLDK = GK + 8;
 struct GemmTaps { long long boff[9]; };      // float offset of each tap's B operand (phase image + row shift) from B
-__global__ __launch_bounds__(256, 2) void gemm_nt_bx3_kernel(const float* __restrict__ A, const float* __restrict__ B0,
+__global__ __launch_bounds__(256, GK == 16 ? 4 : 2) void gemm_nt_bx3_kernel(const float* __restrict__ A, const float* __restrict__ B0,
                                                              float* __restrict__ slab0, int M, int N, int S, int nimg,
                                                              int tiles_n, int splits, GemmTaps taps) {
   // blockIdx.y = tap: the nine products of a layer in ONE launch (they share A = dY; 9 x the workgroups, so few pixel slabs)
@@ -890,15 +893,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bx3_kernel(const float* __rest
   const size_t a_img = (size_t)M * S, b_img = (size_t)N * S;
   const float* Ab = A + (size_t)tm * GT * S;
   const float* Bb = B + (size_t)tn * GT * S;
-  const int lr = tid >> 3, lk = (tid & 7) * 4;                       // row (+32 per pass), first k of the thread's float4
-  float4 ra[4], rb[4];
+  constexpr int LPR = GK / 4, RPP = 256 / LPR, NPASS = GT / RPP;     // float4 per row, rows per pass, passes
+  const int lr = tid / LPR, lk = (tid % LPR) * 4;                    // row (+RPP per pass), first k of the thread's float4
+  float4 ra[NPASS], rb[NPASS];
   auto gload = [&](int64_t g) {
     const int64_t img = g / spi;
     const int ks = (int)(g - img * spi) * GK + lk;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ra[i] = *reinterpret_cast<const float4*>(Ab + img * a_img + (size_t)(lr + 32 * i) * S + ks);
-      rb[i] = *reinterpret_cast<const float4*>(Bb + img * b_img + (size_t)(lr + 32 * i) * S + ks);
+    for (int i = 0; i < NPASS; ++i) {
+      ra[i] = *reinterpret_cast<const float4*>(Ab + img * a_img + (size_t)(lr + RPP * i) * S + ks);
+      rb[i] = *reinterpret_cast<const float4*>(Bb + img * b_img + (size_t)(lr + RPP * i) * S + ks);
     }
   };
   auto sstore = [&](int st) {
@@ -906,7 +910,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bx3_kernel(const float* __rest
 #pragma unroll
     for (int o = 0; o < 2; ++o)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NPASS; ++i) {
         const float4 v = o == 0 ? ra[i] : rb[i];
         const unsigned h0 = wg_cvt_pk(v.x, v.y), h1 = wg_cvt_pk(v.z, v.w);
         const float r0 = v.x - wg_as_f(h0 << 16), r1 = v.y - wg_as_f(h0 & 0xffff0000u);
@@ -914,7 +918,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bx3_kernel(const float* __rest
         const unsigned m0 = wg_cvt_pk(r0, r1), m1 = wg_cvt_pk(r2, r3);
         const unsigned q0 = wg_cvt_pk(r0 - wg_as_f(m0 << 16), r1 - wg_as_f(m0 & 0xffff0000u));
         const unsigned q1 = wg_cvt_pk(r2 - wg_as_f(m1 << 16), r3 - wg_as_f(m1 & 0xffff0000u));
-        __bf16* dst = base + o * OPER + (lr + 32 * i) * GLDK + lk;
+        __bf16* dst = base + o * OPER + (lr + RPP * i) * GLDK + lk;
         *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
         *reinterpret_cast<uint2*>(dst + PLANE) = make_uint2(m0, m1);
         *reinterpret_cast<uint2*>(dst + 2 * PLANE) = make_uint2(q0, q1);
@@ -1017,7 +1021,7 @@ bool make_plan_s2_taps(const DlioConvDesc& d, WgS2Plan& p) {
   if (p.gemm) {
     const int tiles = (d.Cout / GT) * (d.Cin / GT);
     const int64_t stages = (int64_t)d.N * (p.S / GK);
-    int sp = 2 * dlio_num_cus() / (tiles * 9);                              // nine taps per launch, two workgroups per CU
+    int sp = (GK == 16 ? 4 : 2) * dlio_num_cus() / (tiles * 9);                // nine taps per launch, two (four) workgroups per CU
     if (sp < 1) sp = 1;
     if (sp > stages / 4) sp = (int)(stages / 4 > 0 ? stages / 4 : 1);       // at least four stages per workgroup
     p.gsplits = sp;
