@@ -72,9 +72,11 @@ def optimizer_from_torch_state(opt, sd):
     step = 0
     with torch.no_grad():
         for g, sg in zip(opt.param_groups, sd['param_groups']):
-            for k in ('lr', 'weight_decay'):
-                if k in sg:
-                    g[k] = sg[k]
+            # every hyper-parameter entry of the group ('lr', 'weight_decay', and 'initial_lr', which the LR
+            # schedule needs to resume from the un-decayed rate) -- 'params' holds indices, not values
+            for k, v in sg.items():
+                if k != 'params':
+                    g[k] = v
             for p, sid in zip(g['params'], sg['params']):
                 st = sd['state'].get(sid)
                 if st is None:

@@ -43,7 +43,18 @@ class PolynomialLRDecay:
         self.max_decay_steps = max_decay_steps
         self.end_learning_rate = end_learning_rate
         self.power = power
-        self.base_lrs = [g['lr'] for g in optimizer.param_groups]
+        # torch.optim.lr_scheduler._LRScheduler's protocol (the reference's class derives from it, misc.py:131):
+        # a fresh schedule records every group's starting rate as 'initial_lr', a resumed one (trainer.py:108-114
+        # builds it with last_epoch = epoch on the loaded optimizer) REQUIRES it -- the group's 'lr' is already decayed
+        if last_epoch == -1:
+            for g in optimizer.param_groups:
+                g.setdefault('initial_lr', g['lr'])
+        else:
+            for i, g in enumerate(optimizer.param_groups):
+                if 'initial_lr' not in g:
+                    raise KeyError("param 'initial_lr' is not specified in param_groups[{}] when resuming an "
+                                   "optimizer".format(i))
+        self.base_lrs = [g['initial_lr'] for g in optimizer.param_groups]
         self.last_epoch = last_epoch
         self.step()
 

@@ -144,6 +144,47 @@ def test_polynomial_lr_decay_matches_reference_table():
     assert np.allclose(lrs, gold['lr_table'], rtol=1e-6)
 
 
+def test_polynomial_lr_decay_resumes_like_a_torch_scheduler():
+    """trainer.py:108-114 rebuilds the schedule with last_epoch = epoch on the LOADED optimizer: the resumed schedule
+    continues the uninterrupted one (base rate = 'initial_lr', not the already-decayed 'lr'), the optimizer state written
+    through the overlay carries 'initial_lr' (torch's own _LRScheduler raises KeyError without it), and a checkpoint
+    torch.optim + a torch scheduler wrote resumes here"""
+    from deeplio_amd.misc import PolynomialLRDecay
+
+    def fresh():
+        return torch.optim.Adam([torch.nn.Parameter(torch.zeros(3))], lr=1e-3)
+
+    opt = fresh()
+    sch = PolynomialLRDecay(opt, max_decay_steps=30, end_learning_rate=1e-6, power=2.0)
+    table = []
+    for _ in range(30):
+        table.append(opt.param_groups[0]['lr'])
+        sch.step()
+    # interrupted at epoch 15: save, load into a new optimizer, rebuild the schedule as the trainer does
+    opt = fresh()
+    sch = PolynomialLRDecay(opt, max_decay_steps=30, end_learning_rate=1e-6, power=2.0)
+    for _ in range(15):
+        sch.step()
+    sd = opt.state_dict()
+    assert sd['param_groups'][0]['initial_lr'] == 1e-3
+    opt2 = fresh()
+    opt2.load_state_dict(sd)
+    sch2 = PolynomialLRDecay(opt2, max_decay_steps=30, end_learning_rate=1e-6, power=2.0, last_epoch=15)
+    resumed = []
+    for _ in range(14):
+        resumed.append(opt2.param_groups[0]['lr'])
+        sch2.step()
+    assert np.allclose(resumed, table[16:30], rtol=1e-12)
+    # the same state resumes under a stock torch scheduler (it needs 'initial_lr' in the groups) ...
+    opt3 = fresh()
+    opt3.load_state_dict(sd)
+    torch.optim.lr_scheduler.StepLR(opt3, 10, last_epoch=15)
+    # ... and a resume without it fails the way torch's does
+    bare = types.SimpleNamespace(param_groups=[{'lr': 1e-3}])
+    with pytest.raises(KeyError):
+        PolynomialLRDecay(bare, max_decay_steps=30, last_epoch=3)
+
+
 def _run_py(code, cwd):
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(HERE, "golden")]))
     return subprocess.run([sys.executable, "-c", code], cwd=str(cwd), env=env, capture_output=True, text=True,

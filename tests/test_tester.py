@@ -104,6 +104,60 @@ def test_optimizer_state_is_torch_optim_layout(dev):
 
 
 @pytest.mark.gpu
+def test_lr_schedule_resumes_across_the_overlay_both_ways(dev):
+    """trainer.py:108-114 on resume: optimizer.load_state_dict, then PolynomialLRDecay(optimizer, ..., last_epoch=epoch).
+    (a) a checkpoint written through the overlay (FlatOptimizer + misc.PolynomialLRDecay) carries 'initial_lr', loads
+    into torch.optim and resumes under a stock torch scheduler; (b) a checkpoint torch.optim + a torch scheduler wrote
+    resumes through the overlay on the UNINTERRUPTED schedule (base rate = 'initial_lr', not the decayed 'lr')."""
+    import types
+    from deeplio_amd.optimizer import create_optimizer
+    from deeplio_amd.misc import PolynomialLRDecay
+    args = types.SimpleNamespace(lr=1e-3, weight_decay=1e-4, momentum=0.9)
+
+    def flat():
+        net = _mlp().to(dev)
+        return net, create_optimizer([{'params': net.parameters()}], {'optimizer': 'adam'}, args)
+
+    # the uninterrupted schedule
+    _, f0 = flat()
+    s0 = PolynomialLRDecay(f0, max_decay_steps=30, end_learning_rate=1e-6, power=2.0)
+    table = []
+    for _ in range(30):
+        table.append(f0.param_groups[0]['lr'])
+        s0.step()
+    # (a) overlay writes at epoch 15
+    net, f1 = flat()
+    s1 = PolynomialLRDecay(f1, max_decay_steps=30, end_learning_rate=1e-6, power=2.0)
+    net(torch.ones(4, 5, device=dev)).square().sum().backward()
+    f1.step()
+    for _ in range(15):
+        s1.step()
+    sd = f1.state_dict()
+    assert sd['param_groups'][0]['initial_lr'] == 1e-3 and abs(sd['param_groups'][0]['lr'] - table[15]) < 1e-15
+    topt = torch.optim.Adam([{'params': _mlp().parameters()}], lr=1e-3, weight_decay=1e-4)
+    topt.load_state_dict({'state': {i: {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in st.items()}
+                                    for i, st in sd['state'].items()}, 'param_groups': sd['param_groups']})
+    torch.optim.lr_scheduler.StepLR(topt, 100, last_epoch=15)           # KeyError without 'initial_lr'
+    _, f2 = flat()
+    f2.load_state_dict(sd)
+    s2 = PolynomialLRDecay(f2, max_decay_steps=30, end_learning_rate=1e-6, power=2.0, last_epoch=15)
+    assert abs(f2.param_groups[0]['lr'] - table[16]) < 1e-15
+    s2.step()
+    assert abs(f2.param_groups[0]['lr'] - table[17]) < 1e-15
+    # (b) torch.optim + a torch scheduler write at epoch 15 (LambdaLR plays the polynomial: same 'initial_lr' protocol)
+    t3 = torch.optim.Adam([{'params': _mlp().parameters()}], lr=1e-3, weight_decay=1e-4)
+    sch3 = torch.optim.lr_scheduler.LambdaLR(t3, lambda e: ((1e-3 - 1e-6) * (1 - e / 30) ** 2 + 1e-6) / 1e-3)
+    for _ in range(15):
+        t3.step()
+        sch3.step()
+    assert abs(t3.param_groups[0]['lr'] - table[15]) < 1e-12
+    _, f3 = flat()
+    f3.load_state_dict(t3.state_dict())
+    PolynomialLRDecay(f3, max_decay_steps=30, end_learning_rate=1e-6, power=2.0, last_epoch=15)
+    assert abs(f3.param_groups[0]['lr'] - table[16]) < 1e-12
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["adam", "sgd", "rmsprop", "adadelta"])
 def test_overlay_optimizer_resumes_from_a_torch_optim_checkpoint(dev, tmp_path, kind):
     """the reference's Trainer calls `self.optimizer.state_dict()` when it saves (trainer.py:161) and
