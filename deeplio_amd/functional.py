@@ -242,7 +242,8 @@ class _CBR:
     def forward(x, x_ctot, x_coff, Cin, H, W, weight, bias, gamma, beta, rmean, rvar, stride, pad,
                 training, momentum, eps, pre_relu, post_relu, raw, raw_ctot, raw_coff, out, out_ctot,
                 out_coff, N, residual=None, r_ctot=0, r_coff=0, gap=None, gap_ctot=0, gap_coff=0,
-                need_dx=True, in_aff=None, r_aff=None, stats_into=None, shift_into=None):
+                need_dx=True, in_aff=None, r_aff=None, stats_into=None, shift_into=None, conv_done=False,
+                split_into=None):
         """in_aff (mean, scale, shift rows over the x_ctot input channels): x is stored BEFORE its producer's
         BatchNorm + ReLU and activated while the convolution loads it; r_aff: the same for the residual;
         stats_into (three [Cout] tensors): train-mode statistics only -- the activated output is not
@@ -281,7 +282,9 @@ class _CBR:
                                             if _phase_on_bx3(d, it[2], it[3]) else
                                             ops.conv2d_prepped_phase(weight, d.SH, d.SW, it[0], it[1]))
                            for it in plan if it is not None}
-        if stem:
+        if conv_done:
+            pass                 # raw already holds this layer's output (fused Fire expand pair, dlio_fire_expand_fwd)
+        elif stem:
             ops.conv3x5s2_bx3_fwd(x, wt, bias, raw, d)
         elif bx3 and KH == 1:
             ops.conv1x1_bx3_fwd(x, wt, bias, raw, d, in_aff=in_aff)
@@ -290,6 +293,11 @@ class _CBR:
         else:
             ops.conv2d_fwd(x, wt, bias, raw, d, in_aff=in_aff)
         OHW = d.OH * d.OW
+        if split_into is not None:
+            # the squeeze BatchNorm of a fused Fire block: activated tensor + its three-piece bf16 planes in one pass
+            prm = ops.bn_split16(raw, raw_ctot, raw_coff, gamma, beta, eps, momentum, rmean, rvar, out, out_ctot, out_coff,
+                                 split_into, N, Cout, d.OH, d.OW, training, post_relu)
+            return d, prm
         if stats_into is not None:
             prm = ops.bn_train_stats(raw, N, raw_ctot, raw_coff, Cout, OHW, pre_relu, gamma, eps, momentum, rmean, rvar,
                                      prm=stats_into, beta=beta, shift_out=shift_into)
@@ -408,6 +416,7 @@ def conv_dgrad(dy, weight, d, dx, dx_ctot, dx_coff, residual=None, r_ctot=0, r_c
 
 
 _CONV_BX3 = [os.environ.get("DLIO_CONV_BX3", "1") != "0"]
+_FIRE_FUSED = [os.environ.get("DLIO_FIRE_FUSED", "1") != "0"]      # expand1x1 || expand3x3 in one launch (fire_expand.hip)
 _CONV_BX3_1X1 = [os.environ.get("DLIO_CONV_BX3_1X1", "1") != "0"]
 _CONV_BX3_STEM = [os.environ.get("DLIO_CONV_BX3_STEM", "1") != "0"]
 # FlowNet conv2 / conv3 (3x5, stride (1, 2), 64 / 128 input channels) and the 3x3 stride-2 layers (FlowNet conv4-6, ResNet)
@@ -634,20 +643,28 @@ class FireFn(Function):
         CE = E1 + E3
         raw_s = _new((N, S_, H, W), x)
         act_s = _new((N, S_, H, W), x)
+        # expand1x1 || expand3x3 as one launch on the squeeze activation's split planes (csrc/fire_expand.hip)
+        fused = (_FIRE_FUSED[0] and x.is_cuda and E1 == E3 and W % 4 == 0 and _CONV_BX3[0]
+                 and tuple(e3w.shape[2:]) == (3, 3) and tuple(e1w.shape[2:]) == (1, 1))
+        planes = ops.fire_planes(N, S_, H, W, x.device) if fused else None
         d_s, prm_s = _CBR.forward(x, Cin, 0, Cin, H, W, sw, sb, sg, sbe, srm, srv, (1, 1), (0, 0),
                                   training, momentum, eps, False, True, raw_s, S_, 0, act_s, S_, 0, N,
-                                  in_aff=x_aff)
+                                  in_aff=x_aff, split_into=planes)
         raw_e = _new((N, CE, H, W), x)
         res = x if bypass else None
+        if fused:
+            ops.fire_expand_fwd(planes, ops.conv_bx3_prepped(e3w, 0), ops.conv_bx3_prepped(e1w, 0), e3b, e1b, raw_e,
+                                N, S_, H, W, E1, CE, 0)
+            del planes
         if defer:
             aff = _new((3, CE), x)
             inv1, inv3 = _new((E1,), x), _new((E3,), x)
             d_1, _ = _CBR.forward(act_s, S_, 0, S_, H, W, e1w, e1b, e1g, e1be, e1rm, e1rv, (1, 1), (0, 0), training,
                                   momentum, eps, False, True, raw_e, CE, 0, None, CE, 0, N,
-                                  stats_into=(aff[0, :E1], inv1, aff[1, :E1]), shift_into=aff[2, :E1])
+                                  stats_into=(aff[0, :E1], inv1, aff[1, :E1]), shift_into=aff[2, :E1], conv_done=fused)
             d_3, _ = _CBR.forward(act_s, S_, 0, S_, H, W, e3w, e3b, e3g, e3be, e3rm, e3rv, (1, 1), (1, 1), training,
                                   momentum, eps, False, True, raw_e, CE, E1, None, CE, E1, N,
-                                  stats_into=(aff[0, E1:], inv3, aff[1, E1:]), shift_into=aff[2, E1:])
+                                  stats_into=(aff[0, E1:], inv3, aff[1, E1:]), shift_into=aff[2, E1:], conv_done=fused)
             ctx.save_for_backward(x, sw, sbe, e1w, e1be, e3w, e3be, raw_s, act_s, raw_e, prm_s, aff, inv1, inv3,
                                   sb, sg, e1b, e1g, e3b, e3g, x_aff)
             ctx.cfg = (d_s, d_1, d_3, training, bypass, True)
@@ -660,10 +677,10 @@ class FireFn(Function):
         gap = _new((N, CE), x) if fused_gap else None
         d_1, prm_1 = _CBR.forward(act_s, S_, 0, S_, H, W, e1w, e1b, e1g, e1be, e1rm, e1rv, (1, 1), (0, 0), training,
                                   momentum, eps, False, True, raw_e, CE, 0, out, CE, 0, N, res, Cin, 0, gap, CE, 0,
-                                  r_aff=x_aff if bypass else None)
+                                  r_aff=x_aff if bypass else None, conv_done=fused)
         d_3, prm_3 = _CBR.forward(act_s, S_, 0, S_, H, W, e3w, e3b, e3g, e3be, e3rm, e3rv, (1, 1),
                                   (1, 1), training, momentum, eps, False, True, raw_e, CE, E1, out,
-                                  CE, E1, N, res, Cin, E1, gap, CE, E1, r_aff=x_aff if bypass else None)
+                                  CE, E1, N, res, Cin, E1, gap, CE, E1, r_aff=x_aff if bypass else None, conv_done=fused)
         ctx.save_for_backward(x, sw, sbe, e1w, e1be, e3w, e3be, raw_s, act_s, raw_e, prm_s, prm_1,
                               prm_3, sb, sg, e1b, e1g, e3b, e3g, x_aff)
         ctx.cfg = (d_s, d_1, d_3, training, bypass, False)

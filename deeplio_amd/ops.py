@@ -489,6 +489,47 @@ def bn_train_apply(x, x_ctot, x_coff, gamma, beta, eps, momentum, running_mean, 
     return prm
 
 
+def fire_planes(N, S, H, W, device):
+    """storage of the split squeeze activation of a Fire block (dlio_bn_split16 -> dlio_fire_expand_fwd)"""
+    return torch.empty(lib.dlio_fire_planes_bytes(N, S, H, W), dtype=torch.uint8, device=device)
+
+
+def bn_split16(x, x_ctot, x_coff, gamma, beta, eps, momentum, running_mean, running_var, y, y_ctot, y_coff, planes,
+               N, C_, H, W, training, post_relu=True):
+    """the squeeze BatchNorm (+ ReLU) of a Fire block: activated fp32 tensor y (or None) + the split planes -> prm [3][C]
+    (train: batch statistics, SyncBN-aware like bn_train_apply; eval: running statistics)"""
+    if not training:
+        prm = bn_eval_params(running_mean, running_var, gamma, eps)
+        check(lib.dlio_bn_split16(_ptr(x), N, x_ctot, x_coff, C_, H, W, int(post_relu), _ptr(gamma), _ptr(beta),
+                                  float(eps), float(momentum), None, None, _ptr(prm[0]), _ptr(prm[1]), _ptr(prm[2]),
+                                  _ptr(y), y_ctot, y_coff, _ptr(planes), None, 0, 3, 1.0, _stream()), "bn_split16")
+        return prm
+    prm = torch.empty(3, C_, dtype=torch.float32, device=x.device)
+    ws = _stats_ws(N, C_, H * W, x.device)
+
+    def call(mode, scale):
+        check(lib.dlio_bn_split16(_ptr(x), N, x_ctot, x_coff, C_, H, W, int(post_relu), _ptr(gamma), _ptr(beta),
+                                  float(eps), float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(prm[0]),
+                                  _ptr(prm[1]), _ptr(prm[2]), _ptr(y), y_ctot, y_coff, _ptr(planes), _ptr(ws), ws.numel(),
+                                  mode, float(scale), _stream()), "bn_split16")
+    sync = _SYNC_BN[0]
+    if sync is None:
+        call(0, 1.0)
+    else:
+        call(1, 1.0)
+        sync[0](_partials_view(ws, N, C_, H * W))
+        call(2, sync[1])
+    return prm
+
+
+def fire_expand_fwd(planes, w3t, w1t, bias3, bias1, y, N, S, H, W, E, y_ctot, y_coff):
+    """y[:, y_coff : y_coff + E] = expand1x1, y[:, y_coff + E : y_coff + 2 E] = expand3x3 of the split squeeze
+    activation (w3t / w1t = conv_bx3_prepped(w, 0) of the two layers)"""
+    check(lib.dlio_fire_expand_fwd(_ptr(planes), _ptr(w3t), _ptr(w1t), _ptr(bias3), _ptr(bias1), _ptr(y), N, S, H, W, E,
+                                   y_ctot, y_coff, _stream()), "fire_expand_fwd")
+    return y
+
+
 def bn_bwd_fused(dy, dy_ctot, dy_coff, x, x_ctot, x_coff, prm, beta, dx, dx_ctot, dx_coff, N, C_, HW,
                  pre_relu, post_relu, use_batch_stats, dgamma=None, dbeta=None, accumulate=False):
     """BN backward (reductions + dx, dgamma, dbeta) in two launches (SyncBN: partials all-reduced in

@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 211
+#define DLIO_ABI_VERSION 212
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);           /* "gfx950" */
@@ -179,6 +179,28 @@ int dlio_conv3x3_bx3_prep_batched(const DlioPrepItem* items_dev, int n_items, in
                                   dlio_stream_t stream);
 int dlio_conv3x3_bx3_fwd(const float* x, const void* wt, const float* bias, const float* residual,
                          float* y, const DlioConvDesc* desc, dlio_stream_t stream);
+
+/* ---- Fire expand pair as one launch (csrc/fire_expand.hip) ----------------------------------------------------------
+ * Replaces  torch.cat([self.expand1x1(s), self.expand3x3(s)], 1)  of Fire.forward (pointseg_modules.py:126-133; the
+ * two Conv2d of pointseg_modules.py:100-106) where both halves have E channels.
+ * The squeeze activation travels as "planes": [N][ceil(S/16)][3][H + 2][W + 2][16] bf16 -- every fp32 value as its
+ * three bf16 pieces (hi, mid, lo: exact), position-major, 16-channel chunks, with the zero border of the 3x3 padding
+ * stored; dlio_fire_planes_bytes(N, S, H, W) bytes.
+ * dlio_bn_split16: the squeeze BatchNorm2d (+ ReLU) (pointseg_modules.py:98-99,122-124) applied to the raw squeeze
+ * output x (channel slice of x_ctot), writing the activated fp32 tensor y (nullable) AND the planes (border included).
+ * mode 0: train-mode statistics + apply (two launches; mean / invstd / scale / running statistics as
+ * dlio_bn_train_apply, ws = dlio_chan_stats_ws_bytes(N, C, H * W)); mode 1: the statistics partials only; mode 2:
+ * apply from the partials in ws with count = N * H * W * count_scale (SyncBN: all-reduce between 1 and 2); mode 3:
+ * eval, mean / scale are inputs (dlio_bn_eval_params).  W % 4 == 0, 16-byte aligned pointers, else DLIO_EUNSUP.
+ * dlio_fire_expand_fwd: y[:, y_coff : y_coff + E] = expand1x1(s) + bias1, y[:, y_coff + E : y_coff + 2 E] =
+ * expand3x3(s) + bias3 (3x3, pad 1); w3t / w1t from dlio_conv_bx3_prep(taps = 9 / 1, mode 0); biases nullable. */
+size_t dlio_fire_planes_bytes(int N, int S, int H, int W);
+int dlio_bn_split16(const float* x, int N, int x_ctot, int x_coff, int C, int H, int W, int post_relu,
+                    const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                    float* running_var, float* mean, float* invstd, float* scale, float* y, int y_ctot, int y_coff,
+                    void* planes, void* ws, size_t ws_bytes, int mode, double count_scale, dlio_stream_t stream);
+int dlio_fire_expand_fwd(const void* planes, const void* w3t, const void* w1t, const float* bias3, const float* bias1,
+                         float* y, int N, int S, int H, int W, int E, int y_ctot, int y_coff, dlio_stream_t stream);
 /* dst [planes][HU][WU] = src [planes][OH][OW] with SH-1 / SW-1 zeros inserted between rows /
  * columns (and zero tail rows/columns up to HU, WU): turns the data gradient of a strided
  * convolution into dlio_conv2d_fwd with stride 1 on the data-gradient weight layout

@@ -566,7 +566,9 @@ def test_reference_iteration_protocol_on_hip_objects(dev, tmp_path, loss_type):
     omodel.train()
     ocrit = om.get_loss_function(cfg)
     oopt = torch.optim.Adam([{'params': omodel.parameters()}, {'params': ocrit.parameters()}], lr=1e-3, weight_decay=1e-4)
-    bounds = [1e-4, 2e-3, 5e-2]          # new batch per iteration: the chaotic envelope of test_adam_trajectory, a little wider
+    bounds = [1e-4, 4e-3, 5e-2]          # new batch per iteration: the chaotic envelope of test_adam_trajectory, a little wider
+    # (iteration 1 sits at 1e-3 ... 2.5e-3 depending on which fp32-accurate kernel the tiny layers run on: the first Adam
+    #  step is sign-like, see test_adam_trajectory)
     for it in range(3):
         batch = gc.make_batch(2000 + it, g['B'], g['S'], g['C'], g['H'], g['W'], g['T'])
         mine = iteration(model, crit, opt, se3_to_SE3, tuple(t.to(dev) for t in batch))

@@ -1161,3 +1161,68 @@ def test_conv3x3_split_bf16_k_split_over_workgroups(dev, case):
                                        ops._stream()), "conv3x3_bx3_fwd")
     torch.cuda.synchronize()
     assert rel_err(y0[:, 2:2 + Cout], ref) < 3e-6 and rel_err(y, y0.double()) < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 16, 64, 8, 64), (1, 48, 192, 12, 40), (2, 80, 384, 16, 32), (1, 20, 70, 5, 132),
+                                  (3, 64, 32, 4, 68), (1, 33, 24, 9, 36), (16, 64, 256, 32, 64)])
+@pytest.mark.parametrize("training", [True, False])
+def test_fire_expand_pair_fused_matches_fp64(dev, case, training):
+    """csrc/fire_expand.hip (pointseg_modules.py:98-106,122-133): the squeeze BatchNorm + ReLU writes the activated tensor
+    AND its three-piece bf16 planes (with the 3x3 zero border), the fused kernel forms expand1x1 and expand3x3 from one LDS
+    patch and writes both halves of the concat buffer.  Against fp64: the split-bf16 kernels' own error (a few 1e-7);
+    against the separate 1x1 / 3x3 split-bf16 kernels: identical accumulation order, so bit-equal; the activated
+    tensor and the statistics against dlio_bn_train_apply: bit-equal.  Ragged H (not a multiple of 4), W not a multiple of
+    32 / 64, channel counts off the 16 / 32 / 64 tile sizes, channel-sliced input and output."""
+    from deeplio_amd import ops
+    N, S, E, H, W = case
+    g = _g(47)
+    raw = torch.randn(N, S + 3, H, W, generator=g) * 2 + 0.5
+    gamma, beta = torch.rand(S, generator=g) + 0.5, torch.randn(S, generator=g)
+    rm, rv = torch.randn(S, generator=g), torch.rand(S, generator=g) + 0.5
+    w3 = torch.randn(E, S, 3, 3, generator=g) / (S * 9) ** 0.5
+    w1 = torch.randn(E, S, 1, 1, generator=g) / S ** 0.5
+    b3, b1 = torch.randn(E, generator=g), torch.randn(E, generator=g)
+    xs = raw[:, 2:2 + S].double()
+    if training:
+        mu, var = xs.mean((0, 2, 3)), xs.var((0, 2, 3), unbiased=False)
+    else:
+        mu, var = rm.double(), rv.double()
+    act = torch.relu((xs - mu.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + 1e-5) * gamma.double().view(1, -1, 1, 1)
+                     + beta.double().view(1, -1, 1, 1))
+    ref1 = F.conv2d(act, w1.double(), b1.double())
+    ref3 = F.conv2d(act, w3.double(), b3.double(), 1, 1)
+    rawd, gd, bd = raw.to(dev), gamma.to(dev), beta.to(dev)
+    rm1, rv1, rm2, rv2 = rm.to(dev), rv.to(dev), rm.to(dev), rv.to(dev)
+    # reference path: BatchNorm apply + the two separate split-bf16 kernels
+    act_a = torch.empty(N, S, H, W, device=dev)
+    if training:
+        prm_a = ops.bn_train_apply(rawd, S + 3, 2, gd, bd, 1e-5, 0.1, rm1, rv1, act_a, S, 0, N, S, H * W, False, True)
+    else:
+        prm_a = ops.bn_eval_params(rm1, rv1, gd, 1e-5)
+        ops.bn_apply(rawd, S + 3, 2, prm_a, bd, act_a, S, 0, N, S, H * W, False, True)
+    w3t, w1t = ops.conv3x3_bx3_prep(w3.to(dev), 0), ops.conv1x1_bx3_prep(w1.to(dev), 0)
+    ya = torch.zeros(N, 2 * E + 3, H, W, device=dev)
+    ops.conv1x1_bx3_fwd(act_a, w1t, b1.to(dev), ya, ops.conv_desc(N, S, H, W, E, 1, 1, 1, 1, 0, 0, out_ctot=2 * E + 3, out_coff=1))
+    ops.conv3x3_bx3_fwd(act_a, w3t, b3.to(dev), ya, ops.conv_desc(N, S, H, W, E, 3, 3, 1, 1, 1, 1, out_ctot=2 * E + 3, out_coff=1 + E))
+    # fused path
+    act_b = torch.empty(N, S, H, W, device=dev)
+    planes = ops.fire_planes(N, S, H, W, dev)
+    planes.fill_(0x7f)                      # the kernel owns the zero border
+    prm_b = ops.bn_split16(rawd, S + 3, 2, gd, bd, 1e-5, 0.1, rm2, rv2, act_b, S, 0, planes, N, S, H, W, training)
+    yb = torch.zeros(N, 2 * E + 3, H, W, device=dev)
+    ops.fire_expand_fwd(planes, w3t, w1t, b3.to(dev), b1.to(dev), yb, N, S, H, W, E, 2 * E + 3, 1)
+    assert torch.equal(act_a, act_b) and torch.equal(prm_a, prm_b)
+    assert torch.equal(rm1, rm2) and torch.equal(rv1, rv2)
+    assert rel_err(act_b, act) < 1e-6
+    assert rel_err(yb[:, 1:1 + E], ref1) < 3e-6 and rel_err(yb[:, 1 + E:1 + 2 * E], ref3) < 3e-6
+    assert float(yb[:, :1].abs().max()) == 0 and float(yb[:, 1 + 2 * E:].abs().max()) == 0
+    assert torch.equal(ya, yb)
+    # the planes hold the exact three-way split: hi + mid + lo == activated value, zero border
+    KC = (S + 15) // 16
+    pv = planes.view(torch.bfloat16).view(N, KC, 3, H + 2, W + 2, 16).float().sum(2)      # [N][KC][H+2][W+2][16]
+    inner = pv[:, :, 1:-1, 1:-1].permute(0, 1, 4, 2, 3).reshape(N, KC * 16, H, W)
+    assert torch.equal(inner[:, :S], act_b) and float(inner[:, S:].abs().max() if KC * 16 > S else 0.) == 0
+    border = pv.clone()
+    border[:, :, 1:-1, 1:-1] = 0
+    assert float(border.abs().max()) == 0
