@@ -62,6 +62,11 @@ SIGNATURES = {
     "dlio_bn_split16": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _sz,
                              _i, _d, _p]),
     "dlio_fire_expand_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "dlio_bn_small_ok": (_i, [_i, _i]),
+    "dlio_bn_small_fwd": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p,
+                               _p, _i, _i, _p, _p, _p, _p, _i, _i, _p, _i, _i, _p]),
+    "dlio_bn_small_bwd": (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i,
+                               _p]),
     "dlio_zero_upsample2d": (_i, [_p, _p, _i64, _i, _i, _i, _i, _i, _i, _p]),
     "dlio_phase_interleave2d": (_i, [_p, _i, _i, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     "dlio_conv2d_dgrad_strided": (_i, [_p, _p, _p, _cd, _p]),

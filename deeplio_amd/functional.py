@@ -243,7 +243,7 @@ class _CBR:
                 training, momentum, eps, pre_relu, post_relu, raw, raw_ctot, raw_coff, out, out_ctot,
                 out_coff, N, residual=None, r_ctot=0, r_coff=0, gap=None, gap_ctot=0, gap_coff=0,
                 need_dx=True, in_aff=None, r_aff=None, stats_into=None, shift_into=None, conv_done=False,
-                split_into=None):
+                split_into=None, skip_bn=False):
         """in_aff (mean, scale, shift rows over the x_ctot input channels): x is stored BEFORE its producer's
         BatchNorm + ReLU and activated while the convolution loads it; r_aff: the same for the residual;
         stats_into (three [Cout] tensors): train-mode statistics only -- the activated output is not
@@ -293,6 +293,8 @@ class _CBR:
         else:
             ops.conv2d_fwd(x, wt, bias, raw, d, in_aff=in_aff)
         OHW = d.OH * d.OW
+        if skip_bn:                   # the caller runs this layer's BatchNorm itself (two layers in one launch, bn_small.hip)
+            return d, None
         if split_into is not None:
             # the squeeze BatchNorm of a fused Fire block: activated tensor + its three-piece bf16 planes in one pass
             prm = ops.bn_split16(raw, raw_ctot, raw_coff, gamma, beta, eps, momentum, rmean, rvar, out, out_ctot, out_coff,
@@ -301,6 +303,13 @@ class _CBR:
         if stats_into is not None:
             prm = ops.bn_train_stats(raw, N, raw_ctot, raw_coff, Cout, OHW, pre_relu, gamma, eps, momentum, rmean, rvar,
                                      prm=stats_into, beta=beta, shift_out=shift_into)
+            return d, prm
+        if (training and _BN_SMALL[0] and not pre_relu and raw.is_cuda and ops.bn_small_ok(N, OHW) and stats_into is None):
+            # small feature maps: statistics + apply in ONE launch, the tensor read once (bn_small.hip)
+            prm = torch.empty(3, Cout, dtype=torch.float32, device=raw.device)
+            ops.bn_small_fwd(raw, raw_ctot, raw_coff, N, Cout, Cout, OHW, (gamma, beta, rmean, rvar), None, eps, momentum,
+                             prm, out, out_ctot, out_coff, post_relu, residual=residual, r_ctot=r_ctot, r_coff=r_coff,
+                             r_aff=r_aff, gap_out=gap, gap_ctot=gap_ctot, gap_coff=gap_coff)
             return d, prm
         if training and _PLANE_BN[0]:
             # statistics + finalise + apply (+ the plane averages an SELayer wants) in 2 launches
@@ -323,18 +332,26 @@ class _CBR:
     @staticmethod
     def backward(dy, dy_ctot, dy_coff, x, d, weight, bias, gamma, prm, beta, raw, training, pre_relu,
                  post_relu, draw, need_dx, dx=None, dx_ctot=0, dx_coff=0, dx_residual=None,
-                 dxr_ctot=0, dxr_coff=0, dx_accumulate=False, in_aff=None, pooled=None):
+                 dxr_ctot=0, dxr_coff=0, dx_accumulate=False, in_aff=None, pooled=None, bn_grads=None):
         """dy: grad wrt the activated output (slice).  draw: scratch [N,Cout,OH,OW] (contiguous).
         Returns (dweight, dbias, dgamma, dbeta); writes dx (slice) if need_dx:
         dx = dgrad (+ dx_residual) (+ previous dx when dx_accumulate)."""
         N, Cout, OHW = d.N, d.Cout, d.OH * d.OW
-        dgamma, acc_g, ret_g = _sink(gamma, (Cout,), dy)
-        dbeta, acc_b, ret_b = _sink(beta, (Cout,), dy)
-        if acc_g != acc_b:           # one flag serves both outputs of the reduce epilogue
-            dgamma, acc_g, ret_g = _new((Cout,), dy), False, None
-            dbeta, acc_b, ret_b = _new((Cout,), dy), False, None
-            ret_g, ret_b = dgamma, dbeta
-        if pooled is not None:
+        if bn_grads is not None:     # draw already holds the BatchNorm's data gradient (bn_small.hip: two layers in one launch)
+            ret_g, ret_b = bn_grads
+        else:
+            dgamma, acc_g, ret_g = _sink(gamma, (Cout,), dy)
+            dbeta, acc_b, ret_b = _sink(beta, (Cout,), dy)
+            if acc_g != acc_b:           # one flag serves both outputs of the reduce epilogue
+                dgamma, acc_g, ret_g = _new((Cout,), dy), False, None
+                dbeta, acc_b, ret_b = _new((Cout,), dy), False, None
+                ret_g, ret_b = dgamma, dbeta
+        if bn_grads is not None:
+            pass
+        elif (training and _BN_SMALL[0] and not pre_relu and dy.is_cuda and ops.bn_small_ok(N, OHW) and pooled is None):
+            ops.bn_small_bwd(dy, dy_ctot, dy_coff, raw, d.out_ctot, d.out_coff, prm, beta, None, draw, None, dgamma, dbeta,
+                             None, None, acc_g, N, Cout, Cout, OHW, post_relu)
+        elif pooled is not None:
             # dy is the POOLED gradient: (arg-max map, pool row stride) -- the BatchNorm passes gather the gradient of the
             # activated tensor themselves (dlio_bn_bwd_pool), the pool's backward pass is not run
             ops.bn_bwd_pool(dy, pooled[0], raw, prm, beta, draw, pooled[1], dgamma, dbeta, accumulate=acc_g)
@@ -416,7 +433,8 @@ def conv_dgrad(dy, weight, d, dx, dx_ctot, dx_coff, residual=None, r_ctot=0, r_c
 
 
 _CONV_BX3 = [os.environ.get("DLIO_CONV_BX3", "1") != "0"]
-_FIRE_FUSED = [os.environ.get("DLIO_FIRE_FUSED", "1") != "0"]      # expand1x1 || expand3x3 in one launch (fire_expand.hip)
+_FIRE_FUSED = [os.environ.get("DLIO_FIRE_FUSED", "1") != "0"]
+_BN_SMALL = [os.environ.get("DLIO_BN_SMALL", "1") != "0"]           # one-launch BatchNorm of small feature maps (bn_small.hip)      # expand1x1 || expand3x3 in one launch (fire_expand.hip)
 _CONV_BX3_1X1 = [os.environ.get("DLIO_CONV_BX3_1X1", "1") != "0"]
 _CONV_BX3_STEM = [os.environ.get("DLIO_CONV_BX3_STEM", "1") != "0"]
 # FlowNet conv2 / conv3 (3x5, stride (1, 2), 64 / 128 input channels) and the 3x3 stride-2 layers (FlowNet conv4-6, ResNet)
@@ -656,6 +674,39 @@ class FireFn(Function):
             ops.fire_expand_fwd(planes, ops.conv_bx3_prepped(e3w, 0), ops.conv_bx3_prepped(e1w, 0), e3b, e1b, raw_e,
                                 N, S_, H, W, E1, CE, 0)
             del planes
+        small = training and _BN_SMALL[0] and x.is_cuda and ops.bn_small_ok(N, H * W)
+        if small:
+            # fire_blk4 / fire_blk5: the two expand BatchNorms as ONE launch that reads the concat buffer once
+            d_1, _ = _CBR.forward(act_s, S_, 0, S_, H, W, e1w, e1b, e1g, e1be, e1rm, e1rv, (1, 1), (0, 0), training,
+                                  momentum, eps, False, True, raw_e, CE, 0, None, CE, 0, N, conv_done=fused, skip_bn=True)
+            d_3, _ = _CBR.forward(act_s, S_, 0, S_, H, W, e3w, e3b, e3g, e3be, e3rm, e3rv, (1, 1), (1, 1), training,
+                                  momentum, eps, False, True, raw_e, CE, E1, None, CE, E1, N, conv_done=fused, skip_bn=True)
+            sets = ((e1g, e1be, e1rm, e1rv), (e3g, e3be, e3rm, e3rv))
+            if defer:
+                aff, inv = _new((3, CE), x), _new((CE,), x)
+                ops.bn_small_fwd(raw_e, CE, 0, N, CE, E1, H * W, sets[0], sets[1], eps, momentum, (aff[0], inv, aff[1]),
+                                 None, CE, 0, True, shift_out=aff[2])
+                ctx.save_for_backward(x, sw, sbe, e1w, e1be, e3w, e3be, raw_s, act_s, raw_e, prm_s, aff, inv[:E1], inv[E1:],
+                                      sb, sg, e1b, e1g, e3b, e3g, x_aff)
+                ctx.cfg = (d_s, d_1, d_3, training, bypass, True)
+                ctx.small_prm = (aff[0], inv, aff[1])
+                ctx.mark_non_differentiable(aff)
+                return raw_e, aff
+            out = _new((N, CE, H, W), x)
+            gap = _new((N, CE), x) if want_gap else None
+            prm = _new((3, CE), x)
+            ops.bn_small_fwd(raw_e, CE, 0, N, CE, E1, H * W, sets[0], sets[1], eps, momentum, prm, out, CE, 0, True,
+                             residual=res, r_ctot=Cin, r_coff=0, r_aff=x_aff if bypass else None, gap_out=gap, gap_ctot=CE,
+                             gap_coff=0)
+            ctx.save_for_backward(x, sw, sbe, e1w, e1be, e3w, e3be, raw_s, act_s, raw_e, prm_s, prm[:, :E1], prm[:, E1:],
+                                  sb, sg, e1b, e1g, e3b, e3g, x_aff)
+            ctx.cfg = (d_s, d_1, d_3, training, bypass, False)
+            ctx.small_prm = (prm[0], prm[1], prm[2])
+            if not want_gap:
+                return out
+            ctx.mark_non_differentiable(gap)
+            return out, gap
+        ctx.small_prm = None
         if defer:
             aff = _new((3, CE), x)
             inv1, inv3 = _new((E1,), x), _new((E3,), x)
@@ -709,12 +760,25 @@ class FireFn(Function):
         CE = E1 + E3
         dact_s = _new((N, S_, H, W), x)
         draw1 = _new((N, E1, H, W), x)
+        bg1 = bg3 = None
+        small_prm = getattr(ctx, "small_prm", None)
+        if small_prm is not None and training and dout.is_cuda and ops.bn_small_ok(N, H * W):
+            # both expand BatchNorms' backward in one launch (dout and the raw concat buffer read once)
+            draw3 = _new((N, E3, H, W), x)
+            sk = [_sink(p, (E1 if i < 2 else E3,), dout) for i, p in enumerate((e1g, e1be, e3g, e3be))]
+            if len({k[1] for k in sk}) > 1:          # one accumulate flag serves the four outputs
+                fresh = [_new((E1 if i < 2 else E3,), dout) for i in range(4)]
+                sk = [(t, False, t) for t in fresh]
+            ops.bn_small_bwd(dout, CE, 0, raw_e, CE, 0, small_prm, e1be, e3be, draw1, draw3, sk[0][0], sk[1][0], sk[2][0],
+                             sk[3][0], sk[0][1], N, CE, E1, H * W, True)
+            bg1, bg3 = (sk[0][2], sk[1][2]), (sk[2][2], sk[3][2])
         g1 = _CBR.backward(dout, CE, 0, act_s, d_1, e1w, e1b, e1g, prm_1, e1be, raw_e, training, False,
-                           True, draw1, True, dact_s, S_, 0)
+                           True, draw1, True, dact_s, S_, 0, bn_grads=bg1)
         del draw1
-        draw3 = _new((N, E3, H, W), x)
+        if bg3 is None:
+            draw3 = _new((N, E3, H, W), x)
         g3 = _CBR.backward(dout, CE, E1, act_s, d_3, e3w, e3b, e3g, prm_3, e3be, raw_e, training, False,
-                           True, draw3, True, dact_s, S_, 0, dx_accumulate=True)
+                           True, draw3, True, dact_s, S_, 0, dx_accumulate=True, bn_grads=bg3)
         del draw3
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty_like(x) if need_dx else None

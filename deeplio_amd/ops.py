@@ -489,6 +489,34 @@ def bn_train_apply(x, x_ctot, x_coff, gamma, beta, eps, momentum, running_mean, 
     return prm
 
 
+def bn_small_ok(N, HW):
+    """the one-launch BatchNorm kernels of csrc/bn_small.hip take this geometry (and SyncBN is off: synchronised
+    statistics need the partial sums between two launches)"""
+    return _SYNC_BN[0] is None and bool(lib.dlio_bn_small_ok(N, HW))
+
+
+def bn_small_fwd(x, x_ctot, x_coff, N, C_, C1, HW, set1, set2, eps, momentum, prm, y, y_ctot, y_coff, post_relu=True,
+                 shift_out=None, residual=None, r_ctot=0, r_coff=0, r_aff=None, gap_out=None, gap_ctot=0, gap_coff=0):
+    """train-mode BatchNorm (+ ReLU, + residual) of a small feature map in one launch; set1 / set2 = (gamma, beta,
+    running_mean, running_var) of the channels [0, C1) / [C1, C_) (set2 None: one layer); prm = (mean, invstd, scale)
+    rows of C_ floats; y None: statistics only"""
+    g2 = set2 if set2 is not None else (None, None, None, None)
+    check(lib.dlio_bn_small_fwd(_ptr(x), N, x_ctot, x_coff, C_, C1, HW, int(post_relu), _ptr(set1[0]), _ptr(set1[1]),
+                                _ptr(set1[2]), _ptr(set1[3]), _ptr(g2[0]), _ptr(g2[1]), _ptr(g2[2]), _ptr(g2[3]), float(eps),
+                                float(momentum), _ptr(prm[0]), _ptr(prm[1]), _ptr(prm[2]), _ptr(shift_out), _ptr(residual),
+                                r_ctot, r_coff, _ptr(r_aff[0]) if r_aff is not None else None,
+                                _ptr(r_aff[1]) if r_aff is not None else None, _ptr(r_aff[2]) if r_aff is not None else None,
+                                _ptr(y), y_ctot, y_coff, _ptr(gap_out), gap_ctot, gap_coff, _stream()), "bn_small_fwd")
+    return prm
+
+
+def bn_small_bwd(dy, dy_ctot, dy_coff, x, x_ctot, x_coff, prm, beta1, beta2, dx1, dx2, dg1, db1, dg2, db2, accumulate, N,
+                 C_, C1, HW, post_relu=True):
+    check(lib.dlio_bn_small_bwd(_ptr(dy), dy_ctot, dy_coff, _ptr(x), x_ctot, x_coff, _ptr(prm[0]), _ptr(prm[1]), _ptr(prm[2]),
+                                _ptr(beta1), _ptr(beta2), _ptr(dx1), _ptr(dx2), _ptr(dg1), _ptr(db1), _ptr(dg2), _ptr(db2),
+                                int(accumulate), N, C_, C1, HW, int(post_relu), _stream()), "bn_small_bwd")
+
+
 def fire_planes(N, S, H, W, device):
     """storage of the split squeeze activation of a Fire block (dlio_bn_split16 -> dlio_fire_expand_fwd)"""
     return torch.empty(lib.dlio_fire_planes_bytes(N, S, H, W), dtype=torch.uint8, device=device)

@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 212
+#define DLIO_ABI_VERSION 213
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);           /* "gfx950" */
@@ -473,6 +473,28 @@ int dlio_bn_train_apply(const float* x, int N, int x_ctot, int x_coff, int C, in
                         void* ws, size_t ws_bytes, int phase, double count_scale,
                         const float* r_mean, const float* r_scale, const float* r_shift,
                         dlio_stream_t stream);
+/* Train-mode BatchNorm2d (+ ReLU, + residual) of SMALL feature maps in ONE launch (csrc/bn_small.hip; the BatchNorm2d of
+ * pointseg_modules.py:98-106 in fire_blk4 / fire_blk5): N <= 16 images, H * W in {256, 512, 1024, 2048} (dlio_bn_small_ok),
+ * 16-byte aligned planes; DLIO_EUNSUP otherwise (use dlio_bn_train_apply / dlio_bn_bwd).  One workgroup holds a channel
+ * in registers: each element is read once.  The launch covers the channels [0, C) of the slice; channels [0, C1) use
+ * parameter set 1, [C1, C) set 2 (the expand1x1 / expand3x3 halves of a Fire block's concat buffer; C1 = C: one layer).
+ * forward: mean / invstd / scale [C] are written (shift_out nullable: receives beta, the third row of an apply-on-load
+ * table); y NULL = statistics only; residual / r_mean / r_scale / r_shift / gap_out as dlio_bn_train_apply.
+ * backward: dx of channels [0, C1) -> dx1 [N][C1][HW], of [C1, C) -> dx2 [N][C - C1][HW]; dgamma / dbeta per set
+ * (nullable; accumulated when accumulate != 0); beta1 / beta2 are needed for the ReLU mask (post_relu). */
+int dlio_bn_small_ok(int N, int HW);
+int dlio_bn_small_fwd(const float* x, int N, int x_ctot, int x_coff, int C, int C1, int HW, int post_relu,
+                      const float* gamma1, const float* beta1, float* running_mean1, float* running_var1,
+                      const float* gamma2, const float* beta2, float* running_mean2, float* running_var2,
+                      float eps, float momentum, float* mean, float* invstd, float* scale, float* shift_out,
+                      const float* residual, int r_ctot, int r_coff, const float* r_mean, const float* r_scale,
+                      const float* r_shift, float* y, int y_ctot, int y_coff, float* gap_out, int gap_ctot,
+                      int gap_coff, dlio_stream_t stream);
+int dlio_bn_small_bwd(const float* dy, int dy_ctot, int dy_coff, const float* x, int x_ctot, int x_coff,
+                      const float* mean, const float* invstd, const float* scale, const float* beta1,
+                      const float* beta2, float* dx1, float* dx2, float* dgamma1, float* dbeta1, float* dgamma2,
+                      float* dbeta2, int accumulate, int N, int C, int C1, int HW, int post_relu,
+                      dlio_stream_t stream);
 /* Train-mode BatchNorm (+ ReLU) backward behind a 3x3 / pad 1 / stride (SH, 2) max-pool (dlio_maxpool2d_fwd_aff): both
  * launches gather the gradient of the activated tensor from the pooled gradient dy_pool [N,C,OH,OW] and the arg-max map
  * while they stream x [N,C,H,W] -- the pool's own backward pass and its output are not needed.  dx contiguous;

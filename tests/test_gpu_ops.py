@@ -1226,3 +1226,68 @@ def test_fire_expand_pair_fused_matches_fp64(dev, case, training):
     border = pv.clone()
     border[:, :, 1:-1, 1:-1] = 0
     assert float(border.abs().max()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(16, 12, 5, 32, 64), (16, 7, 7, 16, 32), (3, 6, 2, 8, 32), (5, 4, 0, 16, 64)])
+@pytest.mark.parametrize("residual", [False, True])
+def test_batchnorm_small_one_launch(dev, case, residual):
+    """csrc/bn_small.hip: train-mode BatchNorm2d + ReLU (+ residual, + plane averages) of small feature maps in one
+    launch, two parameter sets over one channel range (the expand1x1 / expand3x3 halves of a Fire concat buffer,
+    pointseg_modules.py:100-106,126-133), forward and backward, against torch in fp64; statistics-only mode; geometries
+    outside {N <= 16, H * W in 256 .. 2048} are refused"""
+    from deeplio_amd import ops
+    N, C, C1, H, W = case
+    g = _g(53)
+    HW = H * W
+    assert ops.bn_small_ok(N, HW)
+    xw = torch.randn(N, C + 3, H, W, generator=g) * 1.7 + 0.3
+    gam, bet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    res = torch.randn(N, C + 1, H, W, generator=g) if residual else None
+    dyw = torch.randn(N, C + 2, H, W, generator=g)
+    x64 = xw[:, 2:2 + C].double().requires_grad_(True)
+    g64, b64 = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    rm64, rv64 = rm.double().clone(), rv.double().clone()
+    y64 = torch.relu(F.batch_norm(x64, rm64, rv64, g64, b64, True, 0.1, 1e-5))
+    if residual:
+        y64 = y64 + res[:, 1:].double()
+    y64.backward(dyw[:, 1:1 + C].double())
+    d = lambda t: t.to(dev)
+    gd, bd, rmd, rvd = d(gam), d(bet), d(rm), d(rv)
+    set1 = (gd[:C1], bd[:C1], rmd[:C1], rvd[:C1]) if C1 else (None, None, None, None)
+    set2 = (gd[C1:], bd[C1:], rmd[C1:], rvd[C1:])
+    if C1 == 0:
+        set1, set2, c1 = set2, None, C
+    else:
+        c1 = C1
+    prm = torch.empty(3, C, device=dev)
+    shift = torch.empty(C, device=dev)
+    y = torch.zeros(N, C + 2, H, W, device=dev)
+    gap = torch.zeros(N, C + 1, device=dev)
+    ops.bn_small_fwd(d(xw), C + 3, 2, N, C, c1, HW, set1, set2, 1e-5, 0.1, prm, y, C + 2, 1, True, shift_out=shift,
+                     residual=d(res) if residual else None, r_ctot=C + 1, r_coff=1, gap_out=gap, gap_ctot=C + 1, gap_coff=1)
+    assert rel_err(y[:, 1:1 + C], y64.detach()) < 1e-6
+    assert float(y[:, 0].abs().max()) == 0 and float(y[:, 1 + C:].abs().max()) == 0
+    assert rel_err(gap[:, 1:], y64.detach().mean((2, 3))) < 1e-6
+    assert rel_err(rmd, rm64) < 1e-6 and rel_err(rvd, rv64) < 1e-6 and torch.equal(shift, bd)
+    xs = xw[:, 2:2 + C].double()
+    assert rel_err(prm[0], xs.mean((0, 2, 3))) < 1e-6
+    assert rel_err(prm[1], 1.0 / torch.sqrt(xs.var((0, 2, 3), unbiased=False) + 1e-5)) < 1e-6
+    # statistics only: nothing written
+    prm2 = torch.empty(3, C, device=dev)
+    ops.bn_small_fwd(d(xw), C + 3, 2, N, C, c1, HW, (set1[0], set1[1], None, None),
+                     None if set2 is None else (set2[0], set2[1], None, None), 1e-5, 0.1, prm2, None, 0, 0)
+    assert torch.equal(prm, prm2)
+    # backward: two output tensors, parameter gradients per set, accumulate
+    dx1 = torch.empty(N, c1, H, W, device=dev)
+    dx2 = torch.empty(N, C - c1, H, W, device=dev) if c1 < C else None
+    dg, db = torch.ones(C, device=dev), torch.ones(C, device=dev)
+    ops.bn_small_bwd(d(dyw), C + 2, 1, d(xw), C + 3, 2, prm, set1[1], None if set2 is None else set2[1], dx1, dx2,
+                     dg[:c1], db[:c1], dg[c1:] if c1 < C else None, db[c1:] if c1 < C else None, True, N, C, c1, HW, True)
+    dx = dx1 if dx2 is None else torch.cat([dx1, dx2], 1)
+    assert rel_err(dx, x64.grad) < 2e-6
+    assert rel_err(dg - 1, g64.grad) < 2e-6 and rel_err(db - 1, b64.grad) < 2e-6
+    assert not ops.bn_small_ok(17, HW) and not ops.bn_small_ok(N, 300)
+    with pytest.raises((ValueError, RuntimeError)):
+        ops.bn_small_fwd(torch.zeros(2, 4, 10, 30, device=dev), 4, 0, 2, 4, 4, 300, set1, None, 1e-5, 0.1, prm, None, 0, 0)
