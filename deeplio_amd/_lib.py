@@ -67,6 +67,15 @@ SIGNATURES = {
                                _p, _i, _i, _p, _p, _p, _p, _i, _i, _p, _i, _i, _p]),
     "dlio_bn_small_bwd": (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i,
                                _p]),
+    "dlio_bn_coop_ok": (_i, [_i, _i]),
+    "dlio_bn_coop_parts": (_i, [_i, _i]),
+    "dlio_bn_coop_gap_ok": (_i, [_i, _i]),
+    "dlio_bn_coop_ws_bytes": (_sz, [_i, _i]),
+    "dlio_bn_coop_empty": (C.c_uint64, []),
+    "dlio_bn_coop_fwd": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p,
+                              _p, _i, _i, _p, _p, _p, _p, _i, _i, _p, _i, _i, _p, _p, _p]),
+    "dlio_bn_coop_bwd": (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i,
+                              _p, _p, _p]),
     "dlio_zero_upsample2d": (_i, [_p, _p, _i64, _i, _i, _i, _i, _i, _i, _p]),
     "dlio_phase_interleave2d": (_i, [_p, _i, _i, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     "dlio_conv2d_dgrad_strided": (_i, [_p, _p, _p, _cd, _p]),

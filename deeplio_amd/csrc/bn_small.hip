@@ -157,6 +157,248 @@ __global__ __launch_bounds__(1024) void bn_small_bwd_kernel(
   }
 }
 
+// ---- the same for LARGE feature maps: a channel spread over N cooperating workgroups ---------------------------------
+// fire_blk1-3 hold 0.5-2 MB per channel -- more than a CU's register file.  Here a workgroup owns ONE (n, c) plane (T
+// threads x V float4 = H * W floats, 32-128 KB) and the N workgroups of a channel exchange their partial sums through
+// global memory: publish (sum, sum of squares) -> arrive on the channel's counter (release) -> spin until all N have
+// arrived (acquire) -> every workgroup adds the N partials in the same fixed order -> apply from registers.  The tensor is
+// read ONCE (bn.hip's two launches read it twice: statistics, then apply; three times against five in backward).
+// Progress: the grid is PERSISTENT and small (coop_grid: at most ~half of the chip's wave slots, a multiple of N): item i =
+// (c, n) = (i / N, i % N) goes to workgroup i % grid, so the N partners of a channel are N consecutive workgroups in the
+// same trip of their loops, and every workgroup of the grid is resident once the kernel has its slots -- which it gets,
+// because two such kernels (the two encoder streams; nothing else runs BatchNorm) together fit the chip and every other
+// kernel finishes without waiting for anyone.  A bounded spin (coop_spin_limit) turns a broken assumption into wrong
+// numbers and an error flag instead of a hung GPU.
+// Slots and counters are restored by the last workgroup that leaves a channel, so the scratch is initialised only once.
+constexpr int COOP_SPIN_LIMIT = 1 << 20;
+// A slot of `part` is its own arrival flag: it holds COOP_EMPTY (a NaN pattern no sum can produce) until its owner stores
+// the partial sum -- one relaxed 64-bit atomic store at agent scope -- and the partners poll the slots themselves (relaxed
+// atomic loads at agent scope: they bypass the non-coherent per-XCD L2).  No release / acquire: on gfx950 an agent-scope
+// acquire is a buffer_inv of the L2 and a release a write-back of it, per spin iteration (measured: 60 us per exchange).
+constexpr unsigned long long COOP_EMPTY = 0x7ff8dead0badbeefull;
+
+__device__ __forceinline__ unsigned long long coop_poll(unsigned long long* p, int* errflag) {
+  unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int spins = 0;
+  while (v == COOP_EMPTY) {
+    __builtin_amdgcn_s_sleep(2);
+    v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (++spins > COOP_SPIN_LIMIT) { __hip_atomic_store(errflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return 0ull; }
+  }
+  return v;
+}
+
+__device__ __forceinline__ void coop_exchange(double& a, double& b, double* part, int* sync, int C, int c, int n, int N,
+                                              double* vals /* LDS, 2 N doubles */) {
+  // thread 0 publishes this workgroup's pair; the lanes of wave 0 poll the channel's 2 N slots side by side (one after the
+  // other it was 2 N dependent memory round trips: 30 us per exchange at N = 16); thread 0 adds them in slot order
+  unsigned long long* slots = reinterpret_cast<unsigned long long*>(part) + (size_t)c * N * 2;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(slots + 2 * n + 0, __builtin_bit_cast(unsigned long long, a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(slots + 2 * n + 1, __builtin_bit_cast(unsigned long long, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (threadIdx.x < 64)
+    for (int k = threadIdx.x; k < 2 * N; k += 64) vals[k] = __builtin_bit_cast(double, coop_poll(slots + k, sync + C));
+  __syncthreads();
+  double ta = 0.0, tb = 0.0;
+  for (int k = 0; k < N; ++k) { ta += vals[2 * k]; tb += vals[2 * k + 1]; }       // (every thread: same order, same result)
+  a = ta; b = tb;
+}
+
+__device__ __forceinline__ void coop_depart(double* part, int* sync, int c, int N) {
+  // every partner has gathered before it departs (its loads returned before the barrier behind the exchange): the last
+  // one out empties the channel's slots and clears the counter for the next launch
+  if (threadIdx.x == 0) {
+    const int d = __hip_atomic_fetch_add(sync + c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (d == N - 1) {
+      unsigned long long* slots = reinterpret_cast<unsigned long long*>(part) + (size_t)c * N * 2;
+      for (int k = 0; k < 2 * N; ++k) __hip_atomic_store(slots + k, COOP_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sync + c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+template <int T>
+__device__ __forceinline__ double block_sum_t(double v, double* sm) {      // total in thread 0 (others: partial garbage)
+  v = wave_sum_d(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < T / 64; ++i) r += sm[i];
+  }
+  return r;
+}
+
+template <int V, int T>
+__global__ __launch_bounds__(T) void bn_coop_fwd_kernel(
+    const float* __restrict__ x, int x_ctot, int x_coff, int N, int C, int C1, BnSet s1, BnSet s2, float eps, float momentum,
+    float* __restrict__ mean_o, float* __restrict__ invstd_o, float* __restrict__ scale_o, const float* residual, int r_ctot,
+    int r_coff, const float* __restrict__ r_mean, const float* __restrict__ r_scale, const float* __restrict__ r_shift,
+    float* y, int y_ctot, int y_coff, float* __restrict__ gap_out, int gap_ctot, int gap_coff, int post_relu,
+    double* part, int* sync, int P) {
+  constexpr int CH = 4 * V * T;                       // floats per workgroup: 1 / P of a plane
+  const int HW = CH * P, NP = N * P;
+  __shared__ double sm[2][16];
+  __shared__ double bc[512];
+  const int items = C * NP;
+  for (int it = blockIdx.x; it < items; it += gridDim.x) {
+    const int c = it / NP, np = it - c * NP, n = np / P, po = (np - n * P) * CH;
+    const BnSet& ps = c < C1 ? s1 : s2;
+    const int cl = c < C1 ? c : c - C1;
+    const float* xp = x + ((size_t)n * x_ctot + x_coff + c) * HW + po;
+    float4 v[V];
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int j = 0; j < V; ++j) v[j] = *reinterpret_cast<const float4*>(xp + 4 * (threadIdx.x + T * j));
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float f0 = (v[j].x + v[j].y) + (v[j].z + v[j].w);
+      const float f1 = (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+      a += f0; b += f1;
+    }
+    a = block_sum_t<T>(a, sm[0]);
+    b = block_sum_t<T>(b, sm[1]);
+    coop_exchange(a, b, part, sync, C, c, np, NP, bc);
+    const double count = (double)N * HW;
+    const double m = a / count;
+    double var = b / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    const float mu = (float)m, sc = (ps.gamma ? ps.gamma[cl] : 1.f) * is, be = ps.beta ? ps.beta[cl] : 0.f;
+    if (threadIdx.x == 0 && np == 0) {
+      mean_o[c] = mu; invstd_o[c] = is; scale_o[c] = sc;
+      if (ps.running_mean) ps.running_mean[cl] = (1.f - momentum) * ps.running_mean[cl] + momentum * mu;
+      if (ps.running_var) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        ps.running_var[cl] = (1.f - momentum) * ps.running_var[cl] + momentum * (float)unb;
+      }
+    }
+    const float* rp = residual ? residual + ((size_t)n * r_ctot + r_coff + c) * HW + po : nullptr;
+    const bool raff = rp && r_scale;
+    const float rmu = raff ? r_mean[r_coff + c] : 0.f, rsc = raff ? r_scale[r_coff + c] : 1.f, rsh = raff ? r_shift[r_coff + c] : 0.f;
+    float* yp = y + ((size_t)n * y_ctot + y_coff + c) * HW + po;
+    double gs = 0.0;
+    float4 rv[V];
+    if (rp) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) rv[j] = *reinterpret_cast<const float4*>(rp + 4 * (threadIdx.x + T * j));
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float e[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+      float re[4] = {0.f, 0.f, 0.f, 0.f};
+      if (rp) { re[0] = rv[j].x; re[1] = rv[j].y; re[2] = rv[j].z; re[3] = rv[j].w; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float o = (e[k] - mu) * sc + be;
+        if (post_relu) o = fmaxf(o, 0.f);
+        if (raff) re[k] = fmaxf((re[k] - rmu) * rsc + rsh, 0.f);
+        e[k] = o + re[k];
+      }
+      *reinterpret_cast<float4*>(yp + 4 * (threadIdx.x + T * j)) = make_float4(e[0], e[1], e[2], e[3]);
+      gs += (double)((e[0] + e[1]) + (e[2] + e[3]));
+    }
+    if (gap_out) {                                   // (P == 1; uniform: the barriers inside are taken by everyone)
+      gs = block_sum_t<T>(gs, sm[0]);
+      if (threadIdx.x == 0) gap_out[(size_t)n * gap_ctot + gap_coff + c] = (float)(gs / (double)HW);
+    }
+    coop_depart(part, sync, c, NP);
+    __syncthreads();                                 // bc / sm are reused by the next item
+  }
+}
+
+template <int V, int T>
+__global__ __launch_bounds__(T) void bn_coop_bwd_kernel(
+    const float* __restrict__ dy, int dy_ctot, int dy_coff, const float* __restrict__ x, int x_ctot, int x_coff, int N, int C,
+    int C1, BnSet s1, BnSet s2, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ scale, float* __restrict__ dx1, float* __restrict__ dx2, int accumulate, int post_relu,
+    double* part, int* sync, int P) {
+  constexpr int CH = 4 * V * T;                       // floats per workgroup: 1 / P of a plane
+  const int HW = CH * P, NP = N * P;
+  __shared__ double sm[2][16];
+  __shared__ double bc[512];
+  const int items = C * NP;
+  for (int it = blockIdx.x; it < items; it += gridDim.x) {
+    const int c = it / NP, np = it - c * NP, n = np / P, po = (np - n * P) * CH;
+    const BnSet& ps = c < C1 ? s1 : s2;
+    const int cl = c < C1 ? c : c - C1;
+    const float mu = mean[c], is = invstd[c], sc = scale[c], be = ps.beta ? ps.beta[cl] : 0.f;
+    const float* gp = dy + ((size_t)n * dy_ctot + dy_coff + c) * HW + po;
+    const float* xp = x + ((size_t)n * x_ctot + x_coff + c) * HW + po;
+    float4 g[V], xh[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      g[j] = *reinterpret_cast<const float4*>(gp + 4 * (threadIdx.x + T * j));
+      xh[j] = *reinterpret_cast<const float4*>(xp + 4 * (threadIdx.x + T * j));
+    }
+    double sg = 0.0, sgx = 0.0;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float ge[4] = {g[j].x, g[j].y, g[j].z, g[j].w};
+      float xe[4] = {xh[j].x, xh[j].y, xh[j].z, xh[j].w};
+      float f0 = 0.f, f1 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (post_relu && !((xe[k] - mu) * sc + be > 0.f)) ge[k] = 0.f;
+        xe[k] = (xe[k] - mu) * is;
+        f0 += ge[k]; f1 += ge[k] * xe[k];
+      }
+      g[j] = make_float4(ge[0], ge[1], ge[2], ge[3]);
+      xh[j] = make_float4(xe[0], xe[1], xe[2], xe[3]);
+      sg += f0; sgx += f1;
+    }
+    sg = block_sum_t<T>(sg, sm[0]);
+    sgx = block_sum_t<T>(sgx, sm[1]);
+    coop_exchange(sg, sgx, part, sync, C, c, np, NP, bc);
+    if (threadIdx.x == 0 && np == 0) {
+      if (ps.dbeta) ps.dbeta[cl] = accumulate ? ps.dbeta[cl] + (float)sg : (float)sg;
+      if (ps.dgamma) ps.dgamma[cl] = accumulate ? ps.dgamma[cl] + (float)sgx : (float)sgx;
+    }
+    const double inv_cnt = 1.0 / ((double)N * HW);
+    const float mg = (float)(sg * inv_cnt), mgx = (float)(sgx * inv_cnt);
+    float* op = (c < C1 ? dx1 + ((size_t)n * C1 + c) * HW : dx2 + ((size_t)n * (C - C1) + cl) * HW) + po;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float4 o;
+      o.x = sc * (g[j].x - mg - xh[j].x * mgx); o.y = sc * (g[j].y - mg - xh[j].y * mgx);
+      o.z = sc * (g[j].z - mg - xh[j].z * mgx); o.w = sc * (g[j].w - mg - xh[j].w * mgx);
+      *reinterpret_cast<float4*>(op + 4 * (threadIdx.x + T * j)) = o;
+    }
+    coop_depart(part, sync, c, NP);
+    __syncthreads();
+  }
+}
+
+// planes the cooperative kernels take: P parts of T x 8 float4 each
+int coop_t(int N, int HW, int& P, bool whole_plane = false) {
+  static const int tt = getenv("DLIO_BN_COOP_T") ? atoi(getenv("DLIO_BN_COOP_T")) : 256;      // tuning knob: 256 / 512 / 1024
+  P = 0;
+  if (N < 2 || N > 64 || HW < 8192 || HW > 65536) return 0;
+  if (whole_plane) {                                   // plane averages wanted: the plane in ONE workgroup
+    if (HW != 8192 && HW != 16384 && HW != 32768) return 0;
+    P = 1;
+    return HW / 32;
+  }
+  int T = tt;
+  while (T > 256 && HW % (32 * T)) T >>= 1;
+  if (HW % (32 * T)) return 0;
+  P = HW / (32 * T);
+  return N * P <= 256 ? T : 0;
+}
+
+int coop_grid(int NP, int C, int T) {
+  static const int frac = getenv("DLIO_BN_COOP_CUS") ? atoi(getenv("DLIO_BN_COOP_CUS")) : 120;   // CUs' worth of wave slots
+  int g = frac * (1024 / T);
+  g -= g % NP;
+  if (g < NP) g = NP;
+  const int items = C * NP;
+  return g < items ? g : items;
+}
+
 int small_v(int N, int HW) {
   if (N < 1 || N > 16) return 0;
   return HW == 256 ? 1 : HW == 512 ? 2 : HW == 1024 ? 4 : HW == 2048 ? 8 : 0;
@@ -209,5 +451,70 @@ extern "C" int dlio_bn_small_bwd(const float* dy, int dy_ctot, int dy_coff, cons
                                    N, C, C1, s1, s2, mean, invstd, scale, dx1, dx2, accumulate, post_relu)
   if (v == 1) BNS(1); else if (v == 2) BNS(2); else if (v == 4) BNS(4); else BNS(8);
 #undef BNS
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_bn_coop_ok(int N, int HW) { int P; return coop_t(N, HW, P) != 0; }
+extern "C" int dlio_bn_coop_parts(int N, int HW) { int P; coop_t(N, HW, P); return P; }
+extern "C" int dlio_bn_coop_gap_ok(int N, int HW) { int P; return coop_t(N, HW, P, true) != 0; }
+
+extern "C" size_t dlio_bn_coop_ws_bytes(int N, int C) {
+  if (N <= 0 || C <= 0) return 0;
+  return (size_t)C * 256 * 2 * sizeof(double);        // (N * parts <= 256 slots pairs per channel)
+}
+
+extern "C" unsigned long long dlio_bn_coop_empty(void) { return COOP_EMPTY; }
+
+extern "C" int dlio_bn_coop_fwd(const float* x, int N, int x_ctot, int x_coff, int C, int C1, int HW, int post_relu,
+                                const float* gamma1, const float* beta1, float* running_mean1, float* running_var1,
+                                const float* gamma2, const float* beta2, float* running_mean2, float* running_var2,
+                                float eps, float momentum, float* mean, float* invstd, float* scale,
+                                const float* residual, int r_ctot, int r_coff, const float* r_mean, const float* r_scale,
+                                const float* r_shift, float* y, int y_ctot, int y_coff, float* gap_out, int gap_ctot,
+                                int gap_coff, void* part, void* sync, dlio_stream_t stream) {
+  if (!x || !y || !mean || !invstd || !scale || !part || !sync || C <= 0 || C1 < 0 || C1 > C || N <= 0 || HW <= 0)
+    return DLIO_EINVAL;
+  int P;
+  const int T = coop_t(N, HW, P, gap_out != nullptr);
+  if (!T) return DLIO_EUNSUP;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) return DLIO_EUNSUP;
+  hipStream_t s = as_stream(stream);
+  const BnSet s1{gamma1, beta1, running_mean1, running_var1, nullptr, nullptr};
+  const BnSet s2{gamma2, beta2, running_mean2, running_var2, nullptr, nullptr};
+  DlioProfScope prof(7, s, 0.0, 4.0 * N * (double)C * HW * (residual ? 3.0 : 2.0));
+  const int grid = coop_grid(N * P, C, T);
+#define BNC(TT) hipLaunchKernelGGL((bn_coop_fwd_kernel<8, TT>), dim3((unsigned)grid), dim3(TT), 0, s, x, x_ctot, x_coff, N, C, C1, s1, s2, \
+                                   eps, momentum, mean, invstd, scale, residual, r_ctot, r_coff, r_mean, r_scale, r_shift, y, y_ctot,     \
+                                   y_coff, gap_out, gap_ctot, gap_coff, post_relu, reinterpret_cast<double*>(part),                      \
+                                   reinterpret_cast<int*>(sync), P)
+  if (T == 1024) BNC(1024); else if (T == 512) BNC(512); else BNC(256);
+#undef BNC
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_bn_coop_bwd(const float* dy, int dy_ctot, int dy_coff, const float* x, int x_ctot, int x_coff,
+                                const float* mean, const float* invstd, const float* scale, const float* beta1,
+                                const float* beta2, float* dx1, float* dx2, float* dgamma1, float* dbeta1, float* dgamma2,
+                                float* dbeta2, int accumulate, int N, int C, int C1, int HW, int post_relu, void* part,
+                                void* sync, dlio_stream_t stream) {
+  if (!dy || !x || !mean || !invstd || !scale || !part || !sync || C <= 0 || C1 < 0 || C1 > C || N <= 0 || HW <= 0)
+    return DLIO_EINVAL;
+  if ((C1 > 0 && !dx1) || (C1 < C && !dx2)) return DLIO_EINVAL;
+  int P;
+  const int T = coop_t(N, HW, P);
+  if (!T) return DLIO_EUNSUP;
+  if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx1) |
+       reinterpret_cast<uintptr_t>(dx2)) & 15)
+    return DLIO_EUNSUP;
+  hipStream_t s = as_stream(stream);
+  const BnSet s1{nullptr, beta1, nullptr, nullptr, dgamma1, dbeta1};
+  const BnSet s2{nullptr, beta2, nullptr, nullptr, dgamma2, dbeta2};
+  DlioProfScope prof(9, s, 0.0, 3.0 * 4.0 * N * (double)C * HW);
+  const int grid = coop_grid(N * P, C, T);
+#define BNC(TT) hipLaunchKernelGGL((bn_coop_bwd_kernel<8, TT>), dim3((unsigned)grid), dim3(TT), 0, s, dy, dy_ctot, dy_coff, x, x_ctot,  \
+                                   x_coff, N, C, C1, s1, s2, mean, invstd, scale, dx1, dx2, accumulate, post_relu,                    \
+                                   reinterpret_cast<double*>(part), reinterpret_cast<int*>(sync), P)
+  if (T == 1024) BNC(1024); else if (T == 512) BNC(512); else BNC(256);
+#undef BNC
   return dlio_check_launch();
 }

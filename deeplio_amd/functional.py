@@ -304,6 +304,14 @@ class _CBR:
             prm = ops.bn_train_stats(raw, N, raw_ctot, raw_coff, Cout, OHW, pre_relu, gamma, eps, momentum, rmean, rvar,
                                      prm=stats_into, beta=beta, shift_out=shift_into)
             return d, prm
+        if (training and _BN_SMALL[0] and _BN_COOP_FWD[0] and not pre_relu and raw.is_cuda and out is not None and ops.bn_coop_ok(N, OHW)
+                and (gap is None or ops.bn_coop_gap_ok(N, OHW))):
+            # large planes: the N workgroups holding a channel in registers exchange their partial sums (one launch, one read)
+            prm = torch.empty(3, Cout, dtype=torch.float32, device=raw.device)
+            ops.bn_coop_fwd(raw, raw_ctot, raw_coff, N, Cout, Cout, OHW, (gamma, beta, rmean, rvar), None, eps, momentum,
+                            prm, out, out_ctot, out_coff, post_relu, residual=residual, r_ctot=r_ctot, r_coff=r_coff,
+                            r_aff=r_aff, gap_out=gap, gap_ctot=gap_ctot, gap_coff=gap_coff)
+            return d, prm
         if (training and _BN_SMALL[0] and not pre_relu and raw.is_cuda and ops.bn_small_ok(N, OHW) and stats_into is None):
             # small feature maps: statistics + apply in ONE launch, the tensor read once (bn_small.hip)
             prm = torch.empty(3, Cout, dtype=torch.float32, device=raw.device)
@@ -348,6 +356,9 @@ class _CBR:
                 ret_g, ret_b = dgamma, dbeta
         if bn_grads is not None:
             pass
+        elif (training and _BN_SMALL[0] and not pre_relu and dy.is_cuda and ops.bn_coop_ok(N, OHW) and pooled is None):
+            ops.bn_coop_bwd(dy, dy_ctot, dy_coff, raw, d.out_ctot, d.out_coff, prm, beta, None, draw, None, dgamma, dbeta,
+                            None, None, acc_g, N, Cout, Cout, OHW, post_relu)
         elif (training and _BN_SMALL[0] and not pre_relu and dy.is_cuda and ops.bn_small_ok(N, OHW) and pooled is None):
             ops.bn_small_bwd(dy, dy_ctot, dy_coff, raw, d.out_ctot, d.out_coff, prm, beta, None, draw, None, dgamma, dbeta,
                              None, None, acc_g, N, Cout, Cout, OHW, post_relu)
@@ -434,6 +445,7 @@ def conv_dgrad(dy, weight, d, dx, dx_ctot, dx_coff, residual=None, r_ctot=0, r_c
 
 _CONV_BX3 = [os.environ.get("DLIO_CONV_BX3", "1") != "0"]
 _FIRE_FUSED = [os.environ.get("DLIO_FIRE_FUSED", "1") != "0"]
+_BN_COOP_FWD = [os.environ.get("DLIO_BN_COOP_FWD", "1") != "0"]   # A/B switch: cooperative kernels in the forward pass too
 _BN_SMALL = [os.environ.get("DLIO_BN_SMALL", "1") != "0"]           # one-launch BatchNorm of small feature maps (bn_small.hip)      # expand1x1 || expand3x3 in one launch (fire_expand.hip)
 _CONV_BX3_1X1 = [os.environ.get("DLIO_CONV_BX3_1X1", "1") != "0"]
 _CONV_BX3_STEM = [os.environ.get("DLIO_CONV_BX3_STEM", "1") != "0"]
@@ -674,7 +686,10 @@ class FireFn(Function):
             ops.fire_expand_fwd(planes, ops.conv_bx3_prepped(e3w, 0), ops.conv_bx3_prepped(e1w, 0), e3b, e1b, raw_e,
                                 N, S_, H, W, E1, CE, 0)
             del planes
-        small = training and _BN_SMALL[0] and x.is_cuda and ops.bn_small_ok(N, H * W)
+        coop = (training and _BN_SMALL[0] and _BN_COOP_FWD[0] and x.is_cuda and not defer and ops.bn_coop_ok(N, H * W)
+                and (not want_gap or ops.bn_coop_gap_ok(N, H * W)))
+        small = training and _BN_SMALL[0] and x.is_cuda and (coop or ops.bn_small_ok(N, H * W))
+        bn_fwd = ops.bn_coop_fwd if coop else ops.bn_small_fwd
         if small:
             # fire_blk4 / fire_blk5: the two expand BatchNorms as ONE launch that reads the concat buffer once
             d_1, _ = _CBR.forward(act_s, S_, 0, S_, H, W, e1w, e1b, e1g, e1be, e1rm, e1rv, (1, 1), (0, 0), training,
@@ -695,9 +710,8 @@ class FireFn(Function):
             out = _new((N, CE, H, W), x)
             gap = _new((N, CE), x) if want_gap else None
             prm = _new((3, CE), x)
-            ops.bn_small_fwd(raw_e, CE, 0, N, CE, E1, H * W, sets[0], sets[1], eps, momentum, prm, out, CE, 0, True,
-                             residual=res, r_ctot=Cin, r_coff=0, r_aff=x_aff if bypass else None, gap_out=gap, gap_ctot=CE,
-                             gap_coff=0)
+            bn_fwd(raw_e, CE, 0, N, CE, E1, H * W, sets[0], sets[1], eps, momentum, prm, out, CE, 0, True,
+                   residual=res, r_ctot=Cin, r_coff=0, r_aff=x_aff if bypass else None, gap_out=gap, gap_ctot=CE, gap_coff=0)
             ctx.save_for_backward(x, sw, sbe, e1w, e1be, e3w, e3be, raw_s, act_s, raw_e, prm_s, prm[:, :E1], prm[:, E1:],
                                   sb, sg, e1b, e1g, e3b, e3g, x_aff)
             ctx.cfg = (d_s, d_1, d_3, training, bypass, False)
@@ -709,7 +723,9 @@ class FireFn(Function):
         ctx.small_prm = None
         if defer:
             aff = _new((3, CE), x)
-            inv1, inv3 = _new((E1,), x), _new((E3,), x)
+            inv = _new((CE,), x)
+            inv1, inv3 = inv[:E1], inv[E1:]
+            ctx.small_prm = (aff[0], inv, aff[1])       # rows over the whole concat buffer: backward may run both layers at once
             d_1, _ = _CBR.forward(act_s, S_, 0, S_, H, W, e1w, e1b, e1g, e1be, e1rm, e1rv, (1, 1), (0, 0), training,
                                   momentum, eps, False, True, raw_e, CE, 0, None, CE, 0, N,
                                   stats_into=(aff[0, :E1], inv1, aff[1, :E1]), shift_into=aff[2, :E1], conv_done=fused)
@@ -762,15 +778,17 @@ class FireFn(Function):
         draw1 = _new((N, E1, H, W), x)
         bg1 = bg3 = None
         small_prm = getattr(ctx, "small_prm", None)
-        if small_prm is not None and training and dout.is_cuda and ops.bn_small_ok(N, H * W):
+        bcoop = ops.bn_coop_ok(N, H * W)
+        if small_prm is not None and training and dout.is_cuda and (bcoop or ops.bn_small_ok(N, H * W)):
             # both expand BatchNorms' backward in one launch (dout and the raw concat buffer read once)
             draw3 = _new((N, E3, H, W), x)
             sk = [_sink(p, (E1 if i < 2 else E3,), dout) for i, p in enumerate((e1g, e1be, e3g, e3be))]
             if len({k[1] for k in sk}) > 1:          # one accumulate flag serves the four outputs
                 fresh = [_new((E1 if i < 2 else E3,), dout) for i in range(4)]
                 sk = [(t, False, t) for t in fresh]
-            ops.bn_small_bwd(dout, CE, 0, raw_e, CE, 0, small_prm, e1be, e3be, draw1, draw3, sk[0][0], sk[1][0], sk[2][0],
-                             sk[3][0], sk[0][1], N, CE, E1, H * W, True)
+            (ops.bn_coop_bwd if bcoop else ops.bn_small_bwd)(dout, CE, 0, raw_e, CE, 0, small_prm, e1be, e3be, draw1, draw3,
+                                                             sk[0][0], sk[1][0], sk[2][0], sk[3][0], sk[0][1], N, CE, E1,
+                                                             H * W, True)
             bg1, bg3 = (sk[0][2], sk[1][2]), (sk[2][2], sk[3][2])
         g1 = _CBR.backward(dout, CE, 0, act_s, d_1, e1w, e1b, e1g, prm_1, e1be, raw_e, training, False,
                            True, draw1, True, dact_s, S_, 0, bn_grads=bg1)

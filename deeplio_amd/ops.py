@@ -517,6 +517,63 @@ def bn_small_bwd(dy, dy_ctot, dy_coff, x, x_ctot, x_coff, prm, beta1, beta2, dx1
                                 int(accumulate), N, C_, C1, HW, int(post_relu), _stream()), "bn_small_bwd")
 
 
+_COOP_WS = {}
+_BN_COOP = [os.environ.get("DLIO_BN_COOP", "1") != "0"]
+
+
+def bn_coop_ok(N, HW):
+    """the cooperative one-launch BatchNorm kernels (csrc/bn_small.hip, large planes) take this geometry"""
+    return _BN_COOP[0] and _SYNC_BN[0] is None and bool(lib.dlio_bn_coop_ok(N, HW))
+
+
+def bn_coop_gap_ok(N, HW):
+    """the cooperative forward kernel can deliver plane averages (gap_out) for this geometry"""
+    return bn_coop_ok(N, HW) and bool(lib.dlio_bn_coop_gap_ok(N, HW))
+
+
+def _coop_ws(N, C_, device):
+    """(partial-sum slots, departure counters) of the cooperative BatchNorm kernels: one pair per (device, stream),
+    initialised when allocated (slots = the library's "empty" pattern, counters = 0; the kernels restore both)"""
+    key = (device.index if device.index is not None else torch._C._cuda_getDevice(), raw_stream())
+    e = _COOP_WS.get(key)
+    need_p, need_s = lib.dlio_bn_coop_ws_bytes(N, C_) // 8, C_ + 1
+    if e is None or e[0].numel() < need_p or e[1].numel() < need_s:
+        empty = lib.dlio_bn_coop_empty()
+        e = (torch.full((max(need_p, 1 << 15),), empty - (1 << 64) if empty >= (1 << 63) else empty, dtype=torch.int64,
+                        device=device),
+             torch.zeros(max(need_s, 4096), dtype=torch.int32, device=device))
+        _COOP_WS[key] = e
+    return e
+
+
+def bn_coop_fwd(x, x_ctot, x_coff, N, C_, C1, HW, set1, set2, eps, momentum, prm, y, y_ctot, y_coff, post_relu=True,
+                residual=None, r_ctot=0, r_coff=0, r_aff=None, gap_out=None, gap_ctot=0, gap_coff=0):
+    """bn_small_fwd for large planes (N cooperating workgroups per channel)"""
+    g2 = set2 if set2 is not None else (None, None, None, None)
+    part, sync = _coop_ws(N, C_, x.device)
+    check(lib.dlio_bn_coop_fwd(_ptr(x), N, x_ctot, x_coff, C_, C1, HW, int(post_relu), _ptr(set1[0]), _ptr(set1[1]),
+                               _ptr(set1[2]), _ptr(set1[3]), _ptr(g2[0]), _ptr(g2[1]), _ptr(g2[2]), _ptr(g2[3]), float(eps),
+                               float(momentum), _ptr(prm[0]), _ptr(prm[1]), _ptr(prm[2]), _ptr(residual),
+                               r_ctot, r_coff, _ptr(r_aff[0]) if r_aff is not None else None,
+                               _ptr(r_aff[1]) if r_aff is not None else None, _ptr(r_aff[2]) if r_aff is not None else None,
+                               _ptr(y), y_ctot, y_coff, _ptr(gap_out), gap_ctot, gap_coff, _ptr(part), _ptr(sync), _stream()),
+          "bn_coop_fwd")
+    return prm
+
+
+def bn_coop_bwd(dy, dy_ctot, dy_coff, x, x_ctot, x_coff, prm, beta1, beta2, dx1, dx2, dg1, db1, dg2, db2, accumulate, N,
+                C_, C1, HW, post_relu=True):
+    part, sync = _coop_ws(N, C_, x.device)
+    check(lib.dlio_bn_coop_bwd(_ptr(dy), dy_ctot, dy_coff, _ptr(x), x_ctot, x_coff, _ptr(prm[0]), _ptr(prm[1]), _ptr(prm[2]),
+                               _ptr(beta1), _ptr(beta2), _ptr(dx1), _ptr(dx2), _ptr(dg1), _ptr(db1), _ptr(dg2), _ptr(db2),
+                               int(accumulate), N, C_, C1, HW, int(post_relu), _ptr(part), _ptr(sync), _stream()), "bn_coop_bwd")
+
+
+def bn_coop_errors():
+    """number of cooperative BatchNorm launches that hit their spin limit (0 = none)"""
+    return sum(int(e[1][:].ne(0).sum().item() > 0) for e in _COOP_WS.values())
+
+
 def fire_planes(N, S, H, W, device):
     """storage of the split squeeze activation of a Fire block (dlio_bn_split16 -> dlio_fire_expand_fwd)"""
     return torch.empty(lib.dlio_fire_planes_bytes(N, S, H, W), dtype=torch.uint8, device=device)

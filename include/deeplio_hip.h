@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 213
+#define DLIO_ABI_VERSION 217
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);           /* "gfx950" */
@@ -495,6 +495,31 @@ int dlio_bn_small_bwd(const float* dy, int dy_ctot, int dy_coff, const float* x,
                       const float* beta2, float* dx1, float* dx2, float* dgamma1, float* dbeta1, float* dgamma2,
                       float* dbeta2, int accumulate, int N, int C, int C1, int HW, int post_relu,
                       dlio_stream_t stream);
+/* The same for LARGE feature maps (fire_blk1-3: 32-128 KB per (n, c) plane): the N workgroups that hold a channel's planes
+ * in registers exchange partial sums through `part` ([C][N][2] 64-bit slots, every one holding dlio_bn_coop_empty() before the first
+ * use: a slot is its own arrival flag) and per-channel departure counters in `sync` ([C + 1] ints, zero before the first
+ * use); the kernels restore both; sync[C] != 0 afterwards = a spin limit was hit, results invalid.  One launch, each element read once (dlio_bn_train_apply reads twice, dlio_bn_bwd's two launches five times
+ * against three).  A plane may be cut into dlio_bn_coop_parts(N, H * W) workgroups (N * parts <= 256 slots pairs per channel;
+ * with gap_out the plane stays in one workgroup: dlio_bn_coop_gap_ok).  2 <= N <= 64, H * W a multiple of 8192 up to 65536 (dlio_bn_coop_ok), else DLIO_EUNSUP.  Arguments as
+ * dlio_bn_small_fwd / _bwd (no statistics-only mode: y required).  The launch is a persistent grid of at most ~half the
+ * chip, so that two of them (two streams) can always be resident together; do not run more than two concurrently. */
+int dlio_bn_coop_ok(int N, int HW);
+int dlio_bn_coop_parts(int N, int HW);
+int dlio_bn_coop_gap_ok(int N, int HW);        /* gap_out: the plane in one workgroup, H * W in {8192, 16384, 32768} */
+size_t dlio_bn_coop_ws_bytes(int N, int C);      /* bytes of `part` */
+unsigned long long dlio_bn_coop_empty(void);
+int dlio_bn_coop_fwd(const float* x, int N, int x_ctot, int x_coff, int C, int C1, int HW, int post_relu,
+                     const float* gamma1, const float* beta1, float* running_mean1, float* running_var1,
+                     const float* gamma2, const float* beta2, float* running_mean2, float* running_var2,
+                     float eps, float momentum, float* mean, float* invstd, float* scale,
+                     const float* residual, int r_ctot, int r_coff, const float* r_mean, const float* r_scale,
+                     const float* r_shift, float* y, int y_ctot, int y_coff, float* gap_out, int gap_ctot,
+                     int gap_coff, void* part, void* sync, dlio_stream_t stream);
+int dlio_bn_coop_bwd(const float* dy, int dy_ctot, int dy_coff, const float* x, int x_ctot, int x_coff,
+                     const float* mean, const float* invstd, const float* scale, const float* beta1,
+                     const float* beta2, float* dx1, float* dx2, float* dgamma1, float* dbeta1, float* dgamma2,
+                     float* dbeta2, int accumulate, int N, int C, int C1, int HW, int post_relu, void* part,
+                     void* sync, dlio_stream_t stream);
 /* Train-mode BatchNorm (+ ReLU) backward behind a 3x3 / pad 1 / stride (SH, 2) max-pool (dlio_maxpool2d_fwd_aff): both
  * launches gather the gradient of the activated tensor from the pooled gradient dy_pool [N,C,OH,OW] and the arg-max map
  * while they stream x [N,C,H,W] -- the pool's own backward pass and its output are not needed.  dx contiguous;

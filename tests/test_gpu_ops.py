@@ -1229,7 +1229,8 @@ def test_fire_expand_pair_fused_matches_fp64(dev, case, training):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", [(16, 12, 5, 32, 64), (16, 7, 7, 16, 32), (3, 6, 2, 8, 32), (5, 4, 0, 16, 64)])
+@pytest.mark.parametrize("case", [(16, 12, 5, 32, 64), (16, 7, 7, 16, 32), (3, 6, 2, 8, 32), (5, 4, 0, 16, 64),
+                                  (4, 40, 17, 64, 128), (16, 9, 4, 64, 256), (2, 300, 0, 64, 512), (3, 7, 7, 128, 128)])
 @pytest.mark.parametrize("residual", [False, True])
 def test_batchnorm_small_one_launch(dev, case, residual):
     """csrc/bn_small.hip: train-mode BatchNorm2d + ReLU (+ residual, + plane averages) of small feature maps in one
@@ -1240,7 +1241,10 @@ def test_batchnorm_small_one_launch(dev, case, residual):
     N, C, C1, H, W = case
     g = _g(53)
     HW = H * W
-    assert ops.bn_small_ok(N, HW)
+    coop = HW >= 8192        # large planes: the cooperative kernels (N workgroups per channel, partial sums through memory;
+    #                          300 channels x 2 images = more items than the persistent grid: several trips per workgroup)
+    assert ops.bn_coop_ok(N, HW) if coop else ops.bn_small_ok(N, HW)
+    fwd, bwd = (ops.bn_coop_fwd, ops.bn_coop_bwd) if coop else (ops.bn_small_fwd, ops.bn_small_bwd)
     xw = torch.randn(N, C + 3, H, W, generator=g) * 1.7 + 0.3
     gam, bet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
     rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
@@ -1265,29 +1269,33 @@ def test_batchnorm_small_one_launch(dev, case, residual):
     shift = torch.empty(C, device=dev)
     y = torch.zeros(N, C + 2, H, W, device=dev)
     gap = torch.zeros(N, C + 1, device=dev)
-    ops.bn_small_fwd(d(xw), C + 3, 2, N, C, c1, HW, set1, set2, 1e-5, 0.1, prm, y, C + 2, 1, True, shift_out=shift,
-                     residual=d(res) if residual else None, r_ctot=C + 1, r_coff=1, gap_out=gap, gap_ctot=C + 1, gap_coff=1)
+    kw = {} if coop else dict(shift_out=shift)
+    want_gap = not coop or ops.bn_coop_gap_ok(N, HW)         # plane averages: the plane in one workgroup
+    fwd(d(xw), C + 3, 2, N, C, c1, HW, set1, set2, 1e-5, 0.1, prm, y, C + 2, 1, True,
+        residual=d(res) if residual else None, r_ctot=C + 1, r_coff=1, gap_out=gap if want_gap else None, gap_ctot=C + 1,
+        gap_coff=1, **kw)
     assert rel_err(y[:, 1:1 + C], y64.detach()) < 1e-6
     assert float(y[:, 0].abs().max()) == 0 and float(y[:, 1 + C:].abs().max()) == 0
-    assert rel_err(gap[:, 1:], y64.detach().mean((2, 3))) < 1e-6
-    assert rel_err(rmd, rm64) < 1e-6 and rel_err(rvd, rv64) < 1e-6 and torch.equal(shift, bd)
+    assert not want_gap or rel_err(gap[:, 1:], y64.detach().mean((2, 3))) < 1e-6
+    assert rel_err(rmd, rm64) < 1e-6 and rel_err(rvd, rv64) < 1e-6 and (coop or torch.equal(shift, bd))
     xs = xw[:, 2:2 + C].double()
     assert rel_err(prm[0], xs.mean((0, 2, 3))) < 1e-6
     assert rel_err(prm[1], 1.0 / torch.sqrt(xs.var((0, 2, 3), unbiased=False) + 1e-5)) < 1e-6
-    # statistics only: nothing written
-    prm2 = torch.empty(3, C, device=dev)
-    ops.bn_small_fwd(d(xw), C + 3, 2, N, C, c1, HW, (set1[0], set1[1], None, None),
-                     None if set2 is None else (set2[0], set2[1], None, None), 1e-5, 0.1, prm2, None, 0, 0)
-    assert torch.equal(prm, prm2)
+    if not coop:             # statistics only: nothing written
+        prm2 = torch.empty(3, C, device=dev)
+        ops.bn_small_fwd(d(xw), C + 3, 2, N, C, c1, HW, (set1[0], set1[1], None, None),
+                         None if set2 is None else (set2[0], set2[1], None, None), 1e-5, 0.1, prm2, None, 0, 0)
+        assert torch.equal(prm, prm2)
     # backward: two output tensors, parameter gradients per set, accumulate
     dx1 = torch.empty(N, c1, H, W, device=dev)
     dx2 = torch.empty(N, C - c1, H, W, device=dev) if c1 < C else None
     dg, db = torch.ones(C, device=dev), torch.ones(C, device=dev)
-    ops.bn_small_bwd(d(dyw), C + 2, 1, d(xw), C + 3, 2, prm, set1[1], None if set2 is None else set2[1], dx1, dx2,
-                     dg[:c1], db[:c1], dg[c1:] if c1 < C else None, db[c1:] if c1 < C else None, True, N, C, c1, HW, True)
+    bwd(d(dyw), C + 2, 1, d(xw), C + 3, 2, prm, set1[1], None if set2 is None else set2[1], dx1, dx2,
+        dg[:c1], db[:c1], dg[c1:] if c1 < C else None, db[c1:] if c1 < C else None, True, N, C, c1, HW, True)
     dx = dx1 if dx2 is None else torch.cat([dx1, dx2], 1)
     assert rel_err(dx, x64.grad) < 2e-6
     assert rel_err(dg - 1, g64.grad) < 2e-6 and rel_err(db - 1, b64.grad) < 2e-6
-    assert not ops.bn_small_ok(17, HW) and not ops.bn_small_ok(N, 300)
+    assert ops.bn_coop_errors() == 0
+    assert not ops.bn_small_ok(17, 512) and not ops.bn_small_ok(N, 300) and not ops.bn_coop_ok(1, 8192)
     with pytest.raises((ValueError, RuntimeError)):
         ops.bn_small_fwd(torch.zeros(2, 4, 10, 30, device=dev), 4, 0, 2, 4, 4, 300, set1, None, 1e-5, 0.1, prm, None, 0, 0)
