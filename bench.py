@@ -187,6 +187,11 @@ def main():
     from deeplio_amd.trainer import TrainStep
 
     world, rank, local = ddist.init()
+    if (world > 1 and not args.dry_run and torch.distributed.get_backend() != "nccl"
+            and os.environ.get("DLIO_DIST_BACKEND") != torch.distributed.get_backend()):
+        # (DLIO_DIST_BACKEND=gloo is the explicit dry run of this path with ranks sharing a device; the line then says so)
+        raise SystemExit("bench.py --gpus %d needs the nccl (= RCCL) backend, the process group is %r"
+                         % (args.gpus, torch.distributed.get_backend()))
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: launch it with --nproc-per-node %d, "
                          "or without torchrun (it starts its own ranks)" % (args.gpus, world, args.gpus))
@@ -323,6 +328,7 @@ def main():
     barrier()
     ops.prof_reset()
     ops.prof_enable(prof_on)
+    sync.measure_exposed(world > 1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = ts.step(*batch)
@@ -332,6 +338,15 @@ def main():
     ops.prof_sample(1)
     ts.check()
     dt = sync.max_over_ranks(dt)
+    exposed = sync.exposed_ms()
+    dist_info = sync.describe() if world > 1 else None
+    if dist_info is not None:
+        if dist_info["world_size"] != args.gpus or dist_info["rank_sum"] != dist_info["rank_sum_expected"]:
+            raise SystemExit("the process group did not span %d ranks: %r" % (args.gpus, dist_info))
+        dist_info["allreduce_ms_exposed"] = None if exposed is None else round(sync.max_over_ranks(exposed), 3)
+    coop_errors = ops.bn_coop_errors()
+    if coop_errors:
+        raise SystemExit("a cooperative BatchNorm launch hit its spin limit (%d): results invalid" % coop_errors)
     prof_timed = collect()
     ms_per_step = 1e3 * dt / args.steps
     value = world * B * S / (dt / args.steps)
@@ -359,9 +374,13 @@ def main():
                 out["peak_is"] = "bf16 dense MFMA peak 2516.8 TF/s / 6 MFMAs per fp32 product"
                 out["frac_of_fp32_mfma_peak"] = round(a / PEAK_F32_MFMA_TFLOPS, 4)
             if name == "batchnorm":
-                out["bytes_are"] = ("what the four launches move by construction (statistics 1 pass over the conv "
-                                    "output, apply 2-3, backward reductions 2, backward apply 3); SURVEY 8(d)'s fused "
-                                    "minimum counts 0 bytes for BatchNorm, i.e. all of this is overhead relative to it")
+                out["bytes_are"] = ("what the launches move by construction: the one-launch kernels (csrc/bn_small.hip: a "
+                                    "channel's planes held in registers, partial sums exchanged between workgroups) read "
+                                    "every operand once -- forward 2-3 passes over the conv output (read, residual, write; "
+                                    "listed under 'forward apply'), backward 3 (dy, x, dx; under 'backward apply'); the "
+                                    "two-launch kernels that remain (statistics of apply-on-load layers, the stem behind "
+                                    "its pool) 1 + 2-3 and 2 + 3; SURVEY 8(d)'s fused minimum counts 0 bytes for BatchNorm, "
+                                    "i.e. all of this is overhead relative to it")
                 if "sub" in v:
                     out["kernels"] = {k: {"GB/s": round(rate(sv, "hbm"), 1), "ms_per_step": round(sv["ms"] / steps, 3),
                                           "launches_per_step": sv["launches"] / steps} for k, sv in v["sub"].items()}
@@ -370,7 +389,7 @@ def main():
         # PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction of
         # the guide applied): collected by tools/pmc_traffic.py, committed under profiles/
         pmc = None
-        for fn in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for fn in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             path = os.path.join(ROOT, "profiles", fn)
             if os.path.exists(path) and B == 8 and S == 2 and headline:
                 with open(path) as f:
@@ -458,6 +477,10 @@ def main():
                        "parallelism": "dp%d" % world, "loss": float(loss.item())},
             "roofline": roofline,
         }
+        if dist_info is not None:
+            # what the N > 1 line rests on: the backend and the world size read back from the process group, a collective only
+            # N ranks answer correctly, the part of the gradient exchange the step waited for, the overlap switch
+            out["dist"] = dist_info
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, C, H, W, T, S, args.cpu_batch, args.cpu_steps)
         print(json.dumps(out))

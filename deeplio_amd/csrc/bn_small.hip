@@ -390,8 +390,12 @@ int coop_t(int N, int HW, int& P, bool whole_plane = false) {
   return N * P <= 256 ? T : 0;
 }
 
+// CUs' worth of wave slots one cooperative launch may hold: two launches (the two encoder streams) must always fit the
+// chip together; data-parallel runs leave room for the RCCL kernels that spin beside them (dlio_bn_coop_set_cus)
+int g_coop_cus = 0;
 int coop_grid(int NP, int C, int T) {
-  static const int frac = getenv("DLIO_BN_COOP_CUS") ? atoi(getenv("DLIO_BN_COOP_CUS")) : 120;   // CUs' worth of wave slots
+  static const int env = getenv("DLIO_BN_COOP_CUS") ? atoi(getenv("DLIO_BN_COOP_CUS")) : 0;
+  const int frac = env > 0 ? env : (g_coop_cus > 0 ? g_coop_cus : 120);
   int g = frac * (1024 / T);
   g -= g % NP;
   if (g < NP) g = NP;
@@ -452,6 +456,12 @@ extern "C" int dlio_bn_small_bwd(const float* dy, int dy_ctot, int dy_coff, cons
   if (v == 1) BNS(1); else if (v == 2) BNS(2); else if (v == 4) BNS(4); else BNS(8);
 #undef BNS
   return dlio_check_launch();
+}
+
+extern "C" int dlio_bn_coop_set_cus(int cus) {
+  if (cus < 0 || cus > 128) return DLIO_EINVAL;
+  g_coop_cus = cus;                 // 0 = default (120)
+  return DLIO_OK;
 }
 
 extern "C" int dlio_bn_coop_ok(int N, int HW) { int P; return coop_t(N, HW, P) != 0; }

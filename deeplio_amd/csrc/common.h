@@ -82,6 +82,10 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __ex
 // so that workspace queries work on a build host)
 int dlio_num_cus();
 
+// hipFuncAttributeMaxDynamicSharedMemorySize for a kernel, once per (device, kernel) -- the attribute is per DEVICE: a
+// process-wide `static bool done` left a second GPU of the same process without it (runtime.hip; thread-safe)
+void dlio_set_max_lds(const void* kernel, int bytes);
+
 // profiling hooks (runtime.hip); kinds: include/deeplio_hip.h
 void dlio_prof_begin(int kind, hipStream_t s, double flops, double bytes);
 void dlio_prof_end(int kind, hipStream_t s);

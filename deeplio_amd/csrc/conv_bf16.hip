@@ -380,12 +380,7 @@ int launch_3x3(const __bf16* x, const __bf16* wt, const float* bias, const __bf1
     if (need > lds) lds = need;
   }
   {
-    static bool attr_done = false;
-    if (!attr_done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<MR, TWN>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-      attr_done = true;
-    }
+    dlio_set_max_lds(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<MR, TWN>), 64 * 1024);
   }
   hipLaunchKernelGGL((conv3x3_bf16_kernel<MR, TWN>), dim3((unsigned)blocks), dim3(256), lds, s, x, wt, bias, residual,
                      y, d, tiles_w, tiles_h, co_tiles, patch_at, vec_out);
@@ -440,12 +435,10 @@ extern "C" int dlio_conv3x3_bf16_fwd(const void* x, const void* wt, const float*
   int mr = d.Cout <= 32 ? 1 : 2, twn = d.OW > 32 ? 2 : 1;
   if (blocks(mr, twn) < want && twn == 2) twn = 1;
   if (blocks(mr, twn) < want && mr == 2) mr = 1;
-  static bool attr_done = false;
-  if (!attr_done) {
+  {
     const int lds = 2 * 6 * 66 * 16 * 2;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_done = true;
+    dlio_set_max_lds(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<1, 2>), lds);
+    dlio_set_max_lds(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<2, 2>), lds);
   }
   if (mr == 1) return twn == 2 ? launch_3x3<1, 2>(xb, w, bias, rb, yb, d, s) : launch_3x3<1, 1>(xb, w, bias, rb, yb, d, s);
   return twn == 2 ? launch_3x3<2, 2>(xb, w, bias, rb, yb, d, s) : launch_3x3<2, 1>(xb, w, bias, rb, yb, d, s);

@@ -771,12 +771,7 @@ int launch_bx3_alds(const float* x, const __bf16* wt, const float* bias, const f
   const size_t ring_b = (size_t)2 * 3 * 3 * 32 * MR * 16 * sizeof(__bf16);
   const size_t epi_b = (size_t)4 * 32 * MR * (TWN == 1 ? TW + 4 : TW + 8) * sizeof(float);
   const size_t lds = patch_b + ring_b;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bx3_alds_kernel<MR, TWN>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  dlio_set_max_lds(reinterpret_cast<const void*>(&conv3x3_bx3_alds_kernel<MR, TWN>), (int)lds);
   static const int vec_on = getenv("DLIO_BX3_VEC_OUT") ? atoi(getenv("DLIO_BX3_VEC_OUT")) : 1;
   const int vec_out = vec_on && (d.OW & 3) == 0 && (((size_t)d.OH * d.OW) & 3) == 0 &&
                       ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0 && epi_b <= lds;
@@ -796,12 +791,7 @@ int launch_bx3(const float* x, const __bf16* wt, const float* bias, const float*
   if (blocks <= 0 || blocks > 0x7fffffff) return DLIO_EINVAL;
   // one patch buffer is enough for a single-chunk layer (<= 16 input channels: the stem) -- twice the workgroups per CU
   const size_t lds = (size_t)(d.Cin <= 16 ? 1 : 2) * BUF;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bx3_kernel<MR, TWN, KH, KW, SW, SH>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * BUF));
-    attr_done = true;
-  }
+  dlio_set_max_lds(reinterpret_cast<const void*>(&conv3x3_bx3_kernel<MR, TWN, KH, KW, SW, SH>), (int)(2 * BUF));
   // when the next chunk's patch loads are issued: behind the first three taps' weight fragments for
   // long channel loops (loads return in order -- fragments queued behind 16-32 patch loads stall
   // their MFMAs for an HBM round trip: blk4 / blk5 data gradients 100 -> 67 us, 125 -> 60 us), ahead of
@@ -972,7 +962,8 @@ static void bx3_3x3_shape_large(const DlioConvDesc& d, int& mr, int& twn) {
 // blk4's 256 -> 64 @32x64 fills the slots with 32 x 32 tiles already and gains nothing from 2-8 slices: 62-72 us.)
 static int bx3_3x3_ksplit(const DlioConvDesc& d) {
   static const int maxks = getenv("DLIO_BX3_3X3_KSPLIT") ? atoi(getenv("DLIO_BX3_3X3_KSPLIT")) : 8;    // 0 / 1: off
-  if (maxks < 2) return 1;
+  static const int vec_on = getenv("DLIO_BX3_VEC_OUT") ? atoi(getenv("DLIO_BX3_VEC_OUT")) : 1;
+  if (maxks < 2 || !vec_on) return 1;      // (the slabs are written by the float4 store path only)
   const int KC = (d.Cin + 15) / 16;
   auto nblocks = [&](int m, int t) { return (int64_t)d.N * cdiv(d.OH, 4) * cdiv(d.OW, 32 * t) * cdiv(d.Cout, 32 * m); };
   int mr, twn;

@@ -350,12 +350,7 @@ int launch(const float* x, const float* wt, const float* bias, const float* in_m
   const int64_t blocks = (int64_t)tiles_w * tiles_h * co_tiles * d.N;
   if (blocks <= 0 || blocks > 0x7fffffff) return DLIO_EINVAL;
   auto kern = conv_fwd_kernel<KH, KW, SH, SW, CK, TWN, MR, AFF>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
-    attr_set = true;
-  }
+  dlio_set_max_lds(reinterpret_cast<const void*>(kern), (int)C::LDS_BYTES);
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, s, x, wt, bias,
                      in_mean, in_scale, in_shift, residual, y, d, tiles_w, tiles_h, co_tiles);
   return dlio_check_launch();

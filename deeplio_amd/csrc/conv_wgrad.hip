@@ -1166,12 +1166,8 @@ extern "C" int dlio_conv2d_wgrad(const float* x, const float* dy, float* dw,
                        d.in_ctot, d.in_coff, d.H, d.W, d.OH, qs2.PW, qs2.S, (int64_t)qs2.img_floats);
     rc = dlio_check_launch();
     if (!rc && qs2.gemm) {
-      static bool attr_done = false;
       constexpr int lds = 2 * 3 * GT * GLDK * (int)sizeof(__bf16);
-      if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bx3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_done = true;
-      }
+      dlio_set_max_lds(reinterpret_cast<const void*>(&gemm_nt_bx3_kernel), lds);
       GemmTaps taps;
       for (int tap = 0; tap < 9; ++tap) {
         const int kh = tap / 3, kw = tap - 3 * kh;

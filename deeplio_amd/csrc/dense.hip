@@ -685,12 +685,7 @@ extern "C" int dlio_linear_fwd(const float* x, int ldx, const float* w, const fl
       int grid = cdiv(cdiv(N, 4), 4);
       if (grid > 2 * dlio_num_cus()) grid = 2 * dlio_num_cus();
       auto kern = mrows == 8 ? linear_fwd_skinny_kernel<8> : linear_fwd_skinny_kernel<16>;
-      static bool attr8 = false, attr16 = false;
-      bool& done = mrows == 8 ? attr8 : attr16;
-      if (!done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        done = true;
-      }
+      dlio_set_max_lds(reinterpret_cast<const void*>(kern), 128 * 1024);
       hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, as_stream(stream), x, ldx, w, b, addend, ldadd, y, ldy, M, N, K, act);
       return dlio_check_launch();
     }

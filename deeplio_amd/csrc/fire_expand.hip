@@ -354,9 +354,7 @@ int launch_fire_fwd(const __bf16* planes, const __bf16* w3t, const __bf16* w1t, 
   if (blocks <= 0 || blocks > 0x7fffffff) return DLIO_EINVAL;
   constexpr int PINS = (3 * (TH + 2) * (TW + 2) * 2 + 63) / 64;
   constexpr size_t lds = (size_t)PINS * 1024 + (size_t)2 * 2 * 3 * 64 * 16 * sizeof(__bf16);
-  // (per launch: the attribute is per device)
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fire_expand_fwd_kernel<TWN>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  dlio_set_max_lds(reinterpret_cast<const void*>(&fire_expand_fwd_kernel<TWN>), (int)lds);
   hipLaunchKernelGGL((fire_expand_fwd_kernel<TWN>), dim3((unsigned)blocks), dim3(256), lds, s, planes, w3t, w1t, bias3, bias1,
                      y, N, KC, H, W, E, y_ctot, y_coff, tiles_w, tiles_h, co_tiles);
   return dlio_check_launch();

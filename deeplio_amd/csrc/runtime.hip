@@ -3,6 +3,9 @@
 // interval is the kernel's own duration).
 #include "common.h"
 #include <mutex>
+#include <set>
+#include <utility>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -111,6 +114,17 @@ int dlio_num_cus() {
   else
     (void)hipGetLastError();
   return cached > 0 ? cached : 256;
+}
+
+void dlio_set_max_lds(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = -1; }
+  std::lock_guard<std::mutex> lock(mu);
+  if (dev >= 0 && done.count({dev, kernel})) return;
+  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (dev >= 0) done.insert({dev, kernel});
 }
 
 extern "C" const char* dlio_arch(void) { return "gfx950"; }

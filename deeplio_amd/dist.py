@@ -61,6 +61,13 @@ class GradSync:
             optimizer.grad_scale = 1.0 / self.world
         self.tail_lo = None          # element offset where the early bucket starts
         self._tail_work = None
+        self._timing = None          # (start events, end events) of all_reduce_grads when measure_exposed(True)
+        if self.world > 1 and flat_grad.is_cuda:
+            # the cooperative BatchNorm kernels spin for their partners: with RCCL's own persistent kernels beside them two
+            # of them must still fit the chip together (csrc/bn_small.hip)
+            from . import ops
+            # (gloo = the dry run with ranks SHARING a device: four such launches may meet on it)
+            ops.bn_coop_set_cus(88 if dist.get_backend() == "nccl" else 48)
 
     def enable_sync_bn(self, on=True):
         """synchronised BatchNorm statistics: the per-channel partial sums of every train-mode BN
@@ -100,7 +107,47 @@ class GradSync:
             for t in extra:
                 dist.broadcast(t, src=0)
 
+    def measure_exposed(self, on=True):
+        """record a HIP event pair around every all_reduce_grads() call (the part of the exchange the step waits for:
+        everything behind the end of backward); exposed_ms() reads them"""
+        self._timing = ([], []) if on and self.flat_grad.is_cuda else None
+
+    def exposed_ms(self):
+        """mean milliseconds per step between the end of backward and the end of the gradient exchange"""
+        if not self._timing or not self._timing[0]:
+            return None
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in zip(*self._timing)]
+        return sum(ms) / len(ms)
+
+    def describe(self):
+        """what the process group really is (bench.py prints it: a line from an N-GPU run must prove RCCL saw N ranks)"""
+        if not dist.is_initialized():
+            return {"backend": None, "world_size": 1}
+        out = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rank": dist.get_rank(),
+               "dp_overlap": self.tail_lo is not None,
+               "buckets_bytes": ([4 * self.tail_lo, 4 * (self.flat_grad.numel() - self.tail_lo)] if self.tail_lo is not None
+                                 else [4 * self.flat_grad.numel()])}
+        # one collective whose result only the right world size gives: sum over ranks of (rank + 1)
+        t = torch.tensor([float(dist.get_rank() + 1)], dtype=torch.float64, device=self.flat_grad.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        out["rank_sum"] = float(t.item())
+        out["rank_sum_expected"] = self.world * (self.world + 1) / 2.0
+        return out
+
     def all_reduce_grads(self):
+        if self.world > 1:
+            if self._timing is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                self._timing[0].append(e)
+            self._all_reduce_grads()
+            if self._timing is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                self._timing[1].append(e)
+
+    def _all_reduce_grads(self):
         if self.world > 1:
             if self.flat_grad.is_cuda:
                 from .functional import join_aux_streams

@@ -288,8 +288,11 @@ class _CBR:
             ops.conv3x5s2_bx3_fwd(x, wt, bias, raw, d)
         elif bx3 and KH == 1:
             ops.conv1x1_bx3_fwd(x, wt, bias, raw, d, in_aff=in_aff)
-        elif bx3:
+        elif bx3 and in_aff is None:
             ops.conv3x3_bx3_fwd(x, wt, bias, raw, d)
+        elif bx3:
+            # (the 3x3 split-bf16 kernel has no apply-on-load input: the fp32 kernel takes the transform)
+            ops.conv2d_fwd(x, ops.conv2d_prepped(weight, 0), bias, raw, d, in_aff=in_aff)
         else:
             ops.conv2d_fwd(x, wt, bias, raw, d, in_aff=in_aff)
         OHW = d.OH * d.OW

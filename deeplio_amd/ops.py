@@ -526,6 +526,11 @@ def bn_coop_ok(N, HW):
     return _BN_COOP[0] and _SYNC_BN[0] is None and bool(lib.dlio_bn_coop_ok(N, HW))
 
 
+def bn_coop_set_cus(cus):
+    """wave-slot budget of one cooperative BatchNorm launch in CUs (0 = default); see dlio_bn_coop_set_cus"""
+    check(lib.dlio_bn_coop_set_cus(int(cus)), "bn_coop_set_cus")
+
+
 def bn_coop_gap_ok(N, HW):
     """the cooperative forward kernel can deliver plane averages (gap_out) for this geometry"""
     return bn_coop_ok(N, HW) and bool(lib.dlio_bn_coop_gap_ok(N, HW))

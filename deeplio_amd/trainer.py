@@ -17,6 +17,9 @@ from .optimizer import create_optimizer
 from .se3 import se3_to_SE3
 
 
+_GC_ARMED = [0]       # TrainSteps that froze the collector's generations / switched it to manual (release_gc)
+_GC_MANUAL = [0]
+
 class TrainStep:
     def __init__(self, cfg, input_shape, device, batch_size, lr=1e-3, weight_decay=1e-4, momentum=0.9,
                  max_glob_seq=2, grad_sync=None):
@@ -71,7 +74,9 @@ class TrainStep:
             self._gc_armed = True
             gc.collect()
             gc.freeze()
+            _GC_ARMED[0] += 1             # gc.freeze() / disable() are process-global: counted over all live TrainSteps
             if self.gc_mode == "manual":
+                _GC_MANUAL[0] += 1
                 gc.disable()
         elif self.gc_mode == "manual" and self._steps % self.gc_every == 0:
             gc.collect()
@@ -81,9 +86,15 @@ class TrainStep:
         collector's generations (gc.freeze() is process-global -- an embedding program, e.g. the reference's Trainer
         building several steps, must not keep them exempt for good)"""
         if self._gc_armed:
-            gc.unfreeze()
+            _GC_ARMED[0] -= 1
+            if _GC_ARMED[0] <= 0:         # the last armed step releases: another TrainStep (train + validate) keeps its freeze
+                _GC_ARMED[0] = 0
+                gc.unfreeze()
             if self.gc_mode == "manual":
-                gc.enable()
+                _GC_MANUAL[0] -= 1
+                if _GC_MANUAL[0] <= 0:
+                    _GC_MANUAL[0] = 0
+                    gc.enable()
         self._gc_armed = False
 
     def __enter__(self):

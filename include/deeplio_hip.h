@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 217
+#define DLIO_ABI_VERSION 218
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);           /* "gfx950" */
@@ -504,6 +504,9 @@ int dlio_bn_small_bwd(const float* dy, int dy_ctot, int dy_coff, const float* x,
  * dlio_bn_small_fwd / _bwd (no statistics-only mode: y required).  The launch is a persistent grid of at most ~half the
  * chip, so that two of them (two streams) can always be resident together; do not run more than two concurrently. */
 int dlio_bn_coop_ok(int N, int HW);
+/* CUs' worth of wave slots one cooperative launch may occupy (default 120 of 256; at most 128: two launches must fit the
+ * chip together).  Data-parallel runs lower it to leave room for the RCCL kernels that spin beside them. */
+int dlio_bn_coop_set_cus(int cus);
 int dlio_bn_coop_parts(int N, int HW);
 int dlio_bn_coop_gap_ok(int N, int HW);        /* gap_out: the plane in one workgroup, H * W in {8192, 16384, 32768} */
 size_t dlio_bn_coop_ws_bytes(int N, int C);      /* bytes of `part` */

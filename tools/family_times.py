@@ -10,14 +10,17 @@ import sqlite3
 import sys
 
 FAMILIES = [
-    ("conv3x3 fwd+dgrad (split-bf16 MFMA)", ("conv3x3_bx3_kernel", "conv3x3_bx3_alds_kernel", "conv3x3_bf16")),
+    ("conv3x3 fwd+dgrad (split-bf16 MFMA; fused Fire expand pair)", ("conv3x3_bx3_kernel", "conv3x3_bx3_alds_kernel", "conv3x3_bf16",
+                                                                     "fire_expand_fwd_kernel")),
     ("stem conv fwd (fp32 MFMA)", ("conv_fwd_kernel",)),
     ("conv1x1 fwd+dgrad", ("conv1x1_",)),
     ("conv3x3 wgrad", ("wgrad3_kernel", "conv_wgrad_adirect")),
     ("conv1x1 wgrad", ("wgrad1x1_",)),
     ("other wgrad + slab reduce", ("conv_wgrad_kernel", "wgrad_reduce_kernel")),
     ("BN fwd statistics", ("chan_reduce_kernel<0", "bn16_reduce_kernel<0")),
-    ("BN fwd apply", ("bn_plane_apply_kernel", "bn_apply_kernel", "bn16_plane_apply")),
+    ("BN fwd apply", ("bn_plane_apply_kernel", "bn_apply_kernel", "bn16_plane_apply", "bn_split16_kernel")),
+    ("BN fwd, one launch (statistics + apply, one read)", ("bn_coop_fwd_kernel", "bn_small_fwd_kernel")),
+    ("BN bwd, one launch (reductions + apply, one read)", ("bn_coop_bwd_kernel", "bn_small_bwd_kernel")),
     ("BN bwd reduce", ("chan_reduce_kernel<1", "chan_reduce_kernel<2", "bn16_reduce_kernel<1")),
     ("BN bwd apply", ("bn_plane_bwd_kernel", "bn_bwd_apply_kernel", "bn16_plane_bwd")),
     ("max-pool / SE scale", ("maxpool", "chan_scale", "gap_", "pool16_", "gap16_", "cast_")),

@@ -17,13 +17,13 @@ import sys
 
 FAMILIES = {
     "conv2d_fwd_mfma": ("conv_fwd_kernel",),
-    "conv3x3_bx3": ("conv3x3_bx3_kernel", "conv3x3_bx3_alds_kernel"),
+    "conv3x3_bx3": ("conv3x3_bx3_kernel", "conv3x3_bx3_alds_kernel", "fire_expand_fwd_kernel"),
     "conv2d_1x1": ("conv1x1_",),
     "conv2d_wgrad_mfma": ("conv_wgrad_kernel",),
     "wgrad3x3": ("wgrad3_kernel", "conv_wgrad_adirect"),
     "wgrad1x1": ("wgrad1x1_direct",),
     "wgrad_reduce": ("wgrad_reduce",),
-    "batchnorm": ("chan_reduce", "chan_stats", "bn_apply", "bn_bwd", "bn_plane"),
+    "batchnorm": ("chan_reduce", "chan_stats", "bn_apply", "bn_bwd", "bn_plane", "bn_coop_", "bn_small_", "bn_split16", "bn_pool_"),
     "pool_se": ("maxpool", "gap_", "chan_scale", "pool3"),
 }
 
