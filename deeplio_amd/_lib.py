@@ -99,6 +99,7 @@ SIGNATURES = {
     "dlio_bn_bwd_pool": (_i, [_p] * 10 + [_i] * 8 + [_p, _sz, _p]),
     "dlio_maxpool2d_bwd": (_i, [_p, _p, _p, _p, _p] + [_i] * 11 + [_p]),
     "dlio_maxpool2d_bwd_dot": (_i, [_p, _p, _p, _p] + [_i] * 11 + [_p]),
+    "dlio_plane_dot": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "dlio_gap_fwd": (_i, [_p, _i, _i, _p, _i, _i, _i, _p]),
     "dlio_gap_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "dlio_chan_scale_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),

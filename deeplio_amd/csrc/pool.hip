@@ -394,6 +394,43 @@ __global__ __launch_bounds__(256) void gap_fwd_kernel(const float* __restrict__ 
   }
 }
 
+// out[plane] = (sum_hw a * b) / div[plane]: the SELayer scale gradient behind a max-pool from POOLED tensors.  With
+// y = maxpool(x * s), s > 0 per plane: d loss / d s = sum_o dy[o] * x[argmax(o)] = sum_o dy[o] * y[o] / s -- the pooled
+// gradient and the pooled output instead of the full-resolution x and the arg-max map (dlio_maxpool2d_bwd_dot reads 1.6-2.6x
+// the bytes).  s == 0 (a sigmoid that underflowed): y is all zero, the result is 0.  UN float4 pairs in flight per thread.
+__global__ __launch_bounds__(256) void plane_dot_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        const float* __restrict__ div, float* __restrict__ out, int planes,
+                                                        int HW) {
+  __shared__ double sm[16];
+  for (int pl = blockIdx.x; pl < planes; pl += gridDim.x) {
+    const float* ap = a + (size_t)pl * HW;
+    const float* bp = b + (size_t)pl * HW;
+    double s = 0.0;
+    if ((HW & 3) == 0) {
+      const int n4 = HW >> 2;
+      int i = threadIdx.x;
+      for (; i + 256 < n4; i += 512) {
+        const float4 u0 = *reinterpret_cast<const float4*>(ap + ((size_t)i << 2)), v0 = *reinterpret_cast<const float4*>(bp + ((size_t)i << 2));
+        const float4 u1 = *reinterpret_cast<const float4*>(ap + ((size_t)(i + 256) << 2)), v1 = *reinterpret_cast<const float4*>(bp + ((size_t)(i + 256) << 2));
+        s += (double)((u0.x * v0.x + u0.y * v0.y) + (u0.z * v0.z + u0.w * v0.w));
+        s += (double)((u1.x * v1.x + u1.y * v1.y) + (u1.z * v1.z + u1.w * v1.w));
+      }
+      for (; i < n4; i += 256) {
+        const float4 u = *reinterpret_cast<const float4*>(ap + ((size_t)i << 2)), v = *reinterpret_cast<const float4*>(bp + ((size_t)i << 2));
+        s += (double)((u.x * v.x + u.y * v.y) + (u.z * v.z + u.w * v.w));
+      }
+    } else {
+      for (int i = threadIdx.x; i < HW; i += 256) s += (double)ap[i] * bp[i];
+    }
+    const double r = block_sum_d(s, sm);
+    if (threadIdx.x == 0) {
+      const float dv = div ? div[pl] : 1.f;
+      out[pl] = dv != 0.f ? (float)(r / (double)dv) : 0.f;
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ dout,
                                                       float* __restrict__ dx, int64_t planes,
                                                       int HW, int accumulate) {
@@ -556,6 +593,16 @@ extern "C" int dlio_gap_fwd(const float* x, int ctot, int coff, float* out, int 
   if (grid > 65535) grid = 65535;
   hipLaunchKernelGGL(gap_fwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, ctot, coff,
                      out, N, C, HW);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_plane_dot(const float* a, const float* b, const float* div, float* out, int planes, int HW,
+                              dlio_stream_t stream) {
+  if (!a || !b || !out || planes <= 0 || HW <= 0) return DLIO_EINVAL;
+  if ((HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15)) return DLIO_EUNSUP;
+  hipStream_t s = as_stream(stream);
+  DlioProfScope prof(10, s, 0.0, 8.0 * planes * (double)HW);
+  hipLaunchKernelGGL(plane_dot_kernel, dim3(planes > 65535 ? 65535 : planes), dim3(256), 0, s, a, b, div, out, planes, HW);
   return dlio_check_launch();
 }
 

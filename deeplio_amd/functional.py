@@ -448,6 +448,7 @@ def conv_dgrad(dy, weight, d, dx, dx_ctot, dx_coff, residual=None, r_ctot=0, r_c
 
 _CONV_BX3 = [os.environ.get("DLIO_CONV_BX3", "1") != "0"]
 _FIRE_FUSED = [os.environ.get("DLIO_FIRE_FUSED", "1") != "0"]
+_SE_POOLED_DOT = [os.environ.get("DLIO_SE_POOLED_DOT", "1") != "0"]   # SELayer scale gradient from pooled tensors
 _BN_COOP_FWD = [os.environ.get("DLIO_BN_COOP_FWD", "1") != "0"]   # A/B switch: cooperative kernels in the forward pass too
 _BN_SMALL = [os.environ.get("DLIO_BN_SMALL", "1") != "0"]           # one-launch BatchNorm of small feature maps (bn_small.hip)      # expand1x1 || expand3x3 in one launch (fire_expand.hip)
 _CONV_BX3_1X1 = [os.environ.get("DLIO_CONV_BX3_1X1", "1") != "0"]
@@ -882,13 +883,14 @@ class SEPoolFn(Function):
         else:
             k, stride, pad = pool
             y, idx = ops.maxpool2d_fwd(x, k, stride[0], stride[1], pad[0], pad[1], False, x_scale=s)
-        ctx.save_for_backward(x, w1, w2, g, h, s, idx)
+        # (the pooled output is kept: the scale gradient is sum dy * y / s over POOLED planes, see backward)
+        ctx.save_for_backward(x, w1, w2, g, h, s, idx, y if (pool is not None and _SE_POOLED_DOT[0]) else None)
         ctx.pool = pool
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w1, w2, g, h, s, idx = ctx.saved_tensors
+        x, w1, w2, g, h, s, idx, y = ctx.saved_tensors
         N, C_, H, W = x.shape
         dy = dy.contiguous()
         fused = False
@@ -900,7 +902,12 @@ class SEPoolFn(Function):
             if fused:
                 # two passes over the full-resolution tensor instead of six: ds from (dy, idx, x) with
                 # the pooled gradient recomputed on the fly; dx written once at the end
-                ds = ops.maxpool2d_bwd_dot(dy, idx, x, k, stride[0], stride[1], pad[0], pad[1])
+                if y is not None:
+                    # y = maxpool(x * s), s = sigmoid > 0: sum_o dy[o] * x[argmax(o)] = sum_o dy[o] * y[o] / s -- two POOLED
+                    # tensors instead of the full-resolution x and the arg-max map
+                    ds = ops.plane_dot(dy, y, s)
+                else:
+                    ds = ops.maxpool2d_bwd_dot(dy, idx, x, k, stride[0], stride[1], pad[0], pad[1])
             else:
                 dxs = ops.maxpool2d_bwd(dy, idx, tuple(x.shape), k, stride[0], stride[1], pad[0], pad[1])
                 dx, ds = ops.chan_scale_bwd(dxs, x, s)

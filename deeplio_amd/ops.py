@@ -754,6 +754,14 @@ def maxpool2d_bwd_dot(dy, idx, x, k, sh, sw, ph, pw):
     return ds
 
 
+def plane_dot(a, b, div=None):
+    """out[n, c] = sum_hw a * b / div[n, c] over contiguous [N, C, H, W] tensors"""
+    N, C_, H, W = a.shape
+    out = torch.empty(N, C_, dtype=torch.float32, device=a.device)
+    check(lib.dlio_plane_dot(_ptr(a), _ptr(b), _ptr(div), _ptr(out), N * C_, H * W, _stream()), "plane_dot")
+    return out
+
+
 def gap_fwd(x, N, ctot, coff, C_, HW):
     out = torch.empty(N, C_, dtype=torch.float32, device=x.device)
     check(lib.dlio_gap_fwd(_ptr(x), ctot, coff, _ptr(out), N, C_, HW, _stream()), "gap_fwd")

@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 218
+#define DLIO_ABI_VERSION 219
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);           /* "gfx950" */
@@ -302,6 +302,10 @@ int dlio_maxpool2d_fwd_aff(const float* x, const float* aff, float* y, uint8_t* 
 int dlio_maxpool2d_bwd(const float* dy, const uint8_t* idx, const float* x_scale,
                        const float* x_add, float* dx, int N, int C, int H, int W, int OH, int OW,
                        int K, int SH, int SW, int PH, int PW, dlio_stream_t stream);
+/* out[plane] = (sum_hw a[plane][hw] * b[plane][hw]) / div[plane]  (div nullable = 1; div == 0 gives 0): the SELayer scale
+ * gradient behind a max-pool from POOLED tensors -- with y = maxpool(x * s), s > 0: d loss / d s = sum dy * y / s
+ * (pointseg_modules.py:203-221 + the MaxPool2d behind it; autograd's mul / max_pool2d backward) */
+int dlio_plane_dot(const float* a, const float* b, const float* div, float* out, int planes, int HW, dlio_stream_t stream);
 /* ds[n][c] = sum_hw scatter(dy) * x  without materialising scatter(dy) (fast-path shapes only,
  * DLIO_EUNSUP otherwise) */
 int dlio_maxpool2d_bwd_dot(const float* dy, const uint8_t* idx, const float* x, float* ds, int N,
