@@ -247,7 +247,7 @@ class _CBR:
         """in_aff (mean, scale, shift rows over the x_ctot input channels): x is stored BEFORE its producer's
         BatchNorm + ReLU and activated while the convolution loads it; r_aff: the same for the residual;
         stats_into (three [Cout] tensors): train-mode statistics only -- the activated output is not
-        written, the consumers apply (mean, scale, beta) on load (apply-on-load)."""
+        written, the consumers apply (mean, scale, beta) on load (apply-on-load, HISTORY 11)."""
         Cout, _, KH, KW = weight.shape
         d = ops.conv_desc(N, Cin, H, W, Cout, KH, KW, stride[0], stride[1], pad[0], pad[1],
                           in_ctot=x_ctot, in_coff=x_coff, out_ctot=raw_ctot, out_coff=raw_coff,

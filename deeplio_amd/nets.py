@@ -20,7 +20,7 @@ from .misc import get_config_container
 
 # IMU branch backward scheduled at the fusion layer instead of at the end of the backward pass
 _DEFER_IMU = os.environ.get("DLIO_DEFER_IMU_BWD", "1") != "0"
-# BatchNorm + ReLU of bypass-free Fire blocks applied by their consumer instead of being written
+# BatchNorm + ReLU of bypass-free Fire blocks applied by their consumer instead of being written (HISTORY 11)
 _APPLY_ON_LOAD = os.environ.get("DLIO_APPLY_ON_LOAD", "1") != "0"
 _STEM_AOL = os.environ.get("DLIO_STEM_AOL", "1") != "0"      # ... and of the stem by pool1
 

@@ -71,7 +71,7 @@ def _run_two_ranks(tmp_path, sync_bn, port, pin=True):
 
 # The 1x1 routing looks at the pixel count of the launch (functional._use_bx3), which halves per rank: a layer may
 # run on the split-bf16 kernel in one process and on the fp32-MFMA kernel in two.  Both are fp32-accurate, but their
-# roundings differ and the encoder gradients amplify 1e-7 in an activation to 1e-3 (ReLU flips, DESIGN 11) -- the
+# roundings differ and the encoder gradients amplify 1e-7 in an activation to 1e-3 (ReLU flips, DESIGN 5) -- the
 # comparison WITHOUT synchronised statistics pins the kernels on both sides.  With synchronised statistics (the parity
 # mode) GradSync.enable_sync_bn routes by the global launch size, so the production defaults are what is compared.
 SAME_KERNELS = "16,16,1,1"
