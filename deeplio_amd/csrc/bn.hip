@@ -730,7 +730,7 @@ static void plane_chunks(int planes, int per, bool whole_plane, int& chunks, int
 // beside a resident MFMA kernel few wave slots are free, so bandwidth has to come from bytes in
 // flight per wave (measured on the full step: 1 -> 33.1 ms, 4 -> 32.8 ms, 8 -> 33.1 ms)
 static int bn_unroll() {
-  static const int v = getenv("DLIO_BN_UNROLL") ? atoi(getenv("DLIO_BN_UNROLL")) : 4;
+  static const int v = 4;
   return v;
 }
 
@@ -819,7 +819,7 @@ extern "C" int dlio_bn_bwd_pool(const float* dy_pool, const uint8_t* idx, const 
   hipStream_t s = as_stream(stream);
   double* part = reinterpret_cast<double*>(ws);
   const double tensor_bytes = 4.0 * N * (double)C * HW;
-  static const int strip = getenv("DLIO_BN_POOL_STRIP") ? atoi(getenv("DLIO_BN_POOL_STRIP")) : 1;
+  static const int strip = 1;
   if (strip) {
     {
       DlioProfScope prof(8, s, 0.0, tensor_bytes * 1.6);

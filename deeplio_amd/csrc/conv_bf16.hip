@@ -372,7 +372,7 @@ int launch_3x3(const __bf16* x, const __bf16* wt, const float* bias, const __bf1
   const int patch_at = (d.Cin + 15) / 16 > 5 ? 0 : -1;
   // 16-byte stores through LDS: rows of 8-pixel groups, 16-byte aligned planes; the fp32 transposed tiles of the four
   // waves (32 channels at a time) need more LDS than the bf16 patch buffers
-  static const int vec_on = getenv("DLIO_BF16_VEC_OUT") ? atoi(getenv("DLIO_BF16_VEC_OUT")) : 1;
+  static const int vec_on = 1;
   const int vec_out = vec_on && (d.OW & 7) == 0 && (((size_t)d.OH * d.OW) & 7) == 0 &&
                       ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0;
   if (vec_out) {

@@ -796,7 +796,7 @@ int launch_bx3(const float* x, const __bf16* wt, const float* bias, const float*
   // long channel loops (loads return in order -- fragments queued behind 16-32 patch loads stall
   // their MFMAs for an HBM round trip: blk4 / blk5 data gradients 100 -> 67 us, 125 -> 60 us), ahead of
   // everything for short loops (<= 5 chunks: 3-6 % faster there)
-  static const int force_at = getenv("DLIO_BX3_PATCH_AT") ? atoi(getenv("DLIO_BX3_PATCH_AT")) : -2;
+  static const int force_at = -2;
   const int patch_at = force_at >= -1 ? force_at : ((d.Cin + 15) / 16 > 5 ? 0 : -1);
   // float4 stores through LDS: rows of 4-pixel groups (OW % 4 == 0, 16-byte aligned planes), the transposed tile fits the
   // (possibly single) patch buffer
@@ -837,7 +837,7 @@ extern "C" int dlio_conv3x3_bx3_prep(const float* w, void* wt, int Cout, int Cin
 
 // which tile shape a launch gets
 static void bx3_1x1_shape(const DlioConvDesc& d, int& mr, int& pix_blocks) {
-  static const int force_mr = getenv("DLIO_BX3_1X1_MR") ? atoi(getenv("DLIO_BX3_1X1_MR")) : 0;
+  static const int force_mr = 0;
   mr = force_mr ? force_mr : (d.Cout <= 32 ? 1 : 2);
   pix_blocks = (int)(((int64_t)d.H * d.W + 511) / 512);
 }
@@ -845,8 +845,8 @@ static void bx3_1x1_shape(const DlioConvDesc& d, int& mr, int& pix_blocks) {
 static void bx3_3x3_shape(const DlioConvDesc& d, int& mr, int& twn) {
   // tile: 64 channels x 64 columns per wave when that still gives every CU a few workgroups,
   // else narrower tiles (small feature maps / few output channels)
-  static const int force_mr = getenv("DLIO_BX3_MR") ? atoi(getenv("DLIO_BX3_MR")) : 0;     // tuning knobs
-  static const int force_twn = getenv("DLIO_BX3_TWN") ? atoi(getenv("DLIO_BX3_TWN")) : 0;
+  static const int force_mr = 0;     // tuning knobs
+  static const int force_twn = 0;
   auto blocks = [&](int m, int t) {
     return (int64_t)d.N * cdiv(d.OH, 4) * cdiv(d.OW, 32 * t) * cdiv(d.Cout, 32 * m);
   };
@@ -854,7 +854,7 @@ static void bx3_3x3_shape(const DlioConvDesc& d, int& mr, int& twn) {
   // two pixel blocks per wave halve the weight-fragment traffic (the 16-byte fragment loads run at
   // the L1 bandwidth limit with one block): in isolation that pays from ~192 input channels on
   // (tools/bench_bx3.py), inside the training step from 48 on (full-step sweep: 29.05 -> 28.8 ms)
-  static const int twn_cin = getenv("DLIO_BX3_TWN_CIN") ? atoi(getenv("DLIO_BX3_TWN_CIN")) : 48;
+  static const int twn_cin = 48;
   mr = d.Cout <= 32 ? 1 : 2; twn = (d.OW > 32 && d.Cin >= twn_cin) ? 2 : 1;
   if (blocks(mr, twn) < want && twn == 2) twn = 1;
   if (blocks(mr, twn) < want && mr == 2) mr = 1;
@@ -874,7 +874,7 @@ static int bx3_1x1_ksplit(const DlioConvDesc& d) {
   int ks = (int)((1024 + blocks - 1) / blocks);
   if (ks > KC / 3) ks = KC / 3;                 // at least three chunks per slice
   if (ks > 16) ks = 16;
-  static const int force = getenv("DLIO_BX3_1X1_KS_FORCE") ? atoi(getenv("DLIO_BX3_1X1_KS_FORCE")) : 0;   // tuning knob
+  static const int force = 0;   // tuning knob
   if (force && (int64_t)d.N * d.H * d.W > 16384) ks = force;
   return ks < 2 ? 1 : ks;
 }
@@ -951,7 +951,7 @@ extern "C" int dlio_conv3x3_bx3_prep_batched(const DlioPrepItem* items_dev, int 
 
 // the tile a layer gets when workgroup count is no concern
 static void bx3_3x3_shape_large(const DlioConvDesc& d, int& mr, int& twn) {
-  static const int twn_cin = getenv("DLIO_BX3_TWN_CIN") ? atoi(getenv("DLIO_BX3_TWN_CIN")) : 48;
+  static const int twn_cin = 48;
   mr = d.Cout <= 32 ? 1 : 2;
   twn = (d.OW > 32 && d.Cin >= twn_cin) ? 2 : 1;
 }
@@ -1003,7 +1003,7 @@ extern "C" int dlio_conv3x3_bx3_fwd_ws(const float* x, const void* wt, const flo
   int rc;
   // weight fragments through LDS (conv3x3_bx3_alds_kernel)
   // (DLIO_BX3_ALDS: 0 off, 1 the 64-channel tiles only, 2 = default all tiles: 25.39 / 25.61 / 26.3 ms for 2 / 1 / 0)
-  static const int alds = getenv("DLIO_BX3_ALDS") ? atoi(getenv("DLIO_BX3_ALDS")) : 2;
+  static const int alds = 2;
   bool use_alds = alds && (size_t)9 * ((d.Cin + 15) / 16) * 3 * d.Cout * 32 < 0x7fffffffull && (alds == 2 || mr == 2);
   // K split: the LARGE tile (which bx3_3x3_shape gave up to get more workgroups) with the channel loop cut in slices
   int mrs, twns;
@@ -1061,7 +1061,7 @@ extern "C" int dlio_conv3x5s2_bx3_fwd(const float* x, const void* wt, const floa
   const double bytes = 4.0 * d.N * ((double)d.Cin * d.H * d.W + (double)d.Cout * d.OH * d.OW * (residual ? 2.0 : 1.0));
   dlio_prof_begin(3, s, flops, bytes);
   const __bf16* w = reinterpret_cast<const __bf16*>(wt);
-  static const int force_mr = getenv("DLIO_BX3_STEM_MR") ? atoi(getenv("DLIO_BX3_STEM_MR")) : 0;   // tuning knob
+  static const int force_mr = 0;   // tuning knob
   const int mr = force_mr ? force_mr : (d.Cout <= 32 ? 1 : 2);
   const int rc = mr == 1 ? launch_bx3<1, 1, 3, 5, 2>(x, w, bias, residual, y, d, s)
                          : launch_bx3<2, 1, 3, 5, 2>(x, w, bias, residual, y, d, s);

@@ -365,12 +365,12 @@ int launch_tw(const float* x, const float* wt, const float* bias, const float* i
   // fused producer-affine on load (not on the headline path): one small-tile instantiation
   if (in_scale)
     return launch<KH, KW, SH, SW, CK, 1, 1, true>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
-  static const int force_twn = getenv("DLIO_CONV_TWN") ? atoi(getenv("DLIO_CONV_TWN")) : 0;   // tuning knob
+  static const int force_twn = 0;   // tuning knob
   // sweep (tools/conv_table.py, DLIO_CONV_TWN x DLIO_CONV_MR): 32-pixel tiles win everywhere
   // (fewer registers, more resident workgroups) except for the <=32-channel outputs of blk1
   const int twn = force_twn ? force_twn : ((d.OW > 32 && d.Cout <= 32) ? 2 : 1);
   const int64_t blocks2 = (int64_t)cdiv(d.OW, 32 * twn) * cdiv(d.OH, 4) * cdiv(d.Cout, 64) * d.N;
-  static const int force_mr = getenv("DLIO_CONV_MR") ? atoi(getenv("DLIO_CONV_MR")) : 0;   // tuning knob
+  static const int force_mr = 0;   // tuning knob
   // micro-bench (tools/bench_conv.py): 32-channel tiles win for Cout <= 32 (234 vs 414 us on the
   // blk1 expand3x3 data gradient) and whenever 64-channel tiles give < 2 workgroups per CU
   const bool small = force_mr ? force_mr == 1 : (blocks2 < 512 || d.Cout <= 32);
@@ -815,14 +815,14 @@ int launch_1x1_nr(const float* x, const float* wt, const float* bias, const floa
                   const DlioConvDesc& d, hipStream_t s) {
   // 64-pixel waves only when that still gives >= 4 waves per SIMD over the chip
   const int P = d.OH * d.OW;
-  static const int use_v4 = getenv("DLIO_1X1_V4") ? atoi(getenv("DLIO_1X1_V4")) : 1;    // tuning knob
+  static const int use_v4 = 1;    // tuning knob
   const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
                        reinterpret_cast<uintptr_t>(residual);
   const int64_t waves4 = (int64_t)cdiv(P, 128) * cdiv(d.Cout, 32 * MR) * d.N;
   if (use_v4 && (P & 3) == 0 && (al & 15) == 0 && waves4 >= 2048)
     return launch_1x1_v4<MR>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
   // under-filled float4 launch with a long K: split K over the workgroup's waves
-  static const int splitk = getenv("DLIO_1X1_SPLITK") ? atoi(getenv("DLIO_1X1_SPLITK")) : 1;   // tuning knob
+  static const int splitk = 1;   // tuning knob
   if constexpr (MR <= 2) {
     if (splitk && use_v4 && (P & 3) == 0 && (al & 15) == 0 && d.Cin >= 256)   // sweep: 192-channel layers lose
       return launch_1x1_splitk<MR>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
@@ -831,7 +831,7 @@ int launch_1x1_nr(const float* x, const float* wt, const float* bias, const floa
       return launch_1x1_v4<MR>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
   }
   const int64_t waves2 = (int64_t)cdiv(d.OH * d.OW, 64) * cdiv(d.Cout, 32 * MR) * d.N;
-  static const int force_nr = getenv("DLIO_1X1_NR") ? atoi(getenv("DLIO_1X1_NR")) : 0;   // tuning knob
+  static const int force_nr = 0;   // tuning knob
   if (MR < 3 && (force_nr == 2 || (force_nr == 0 && waves2 >= 4096)))
     return launch_1x1<MR, 2>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
   return launch_1x1<MR, 1>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
@@ -932,12 +932,12 @@ extern "C" int dlio_conv2d_fwd(const float* x, const float* wt, const float* bia
   const int pkind = (d.KH == 1 && d.KW == 1) ? 2 : 0;
   dlio_prof_begin(pkind, s, flops, bytes);
   int rc = DLIO_EUNSUP;
-  static const int ck8 = getenv("DLIO_CONV_CK8") ? atoi(getenv("DLIO_CONV_CK8")) : 1;   // tuning knob
+  static const int ck8 = 1;   // tuning knob
 #define CONV_CASE(kh, kw, sh, sw, ck)                                                        \
   if (d.KH == kh && d.KW == kw && d.SH == sh && d.SW == sw)                                  \
     rc = launch_tw<kh, kw, sh, sw, ck>(x, wt, bias, in_mean, in_scale, in_shift, residual, y, d, s);
   if (d.KH == 1 && d.KW == 1 && d.SH == 1 && d.SW == 1 && d.PH == 0 && d.PW == 0 && d.OH == d.H && d.OW == d.W) {
-    static const int shortk_mr1 = getenv("DLIO_1X1_SHORTK_MR1") ? atoi(getenv("DLIO_1X1_SHORTK_MR1")) : 80;
+    static const int shortk_mr1 = 80;
     // short K (squeeze data gradient, expand1x1 forward: <= 80 input channels) is store-bound:
     // 32-channel tiles (twice the waves, half the registers) are 8-12 % faster there (sweep)
     if (d.Cout <= 32 || (shortk_mr1 && d.Cin <= shortk_mr1))

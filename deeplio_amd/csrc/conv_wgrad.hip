@@ -601,7 +601,7 @@ struct WgPlan {
 
 int nt_for(const DlioConvDesc& d) {
   if (d.KH == 1 && d.KW == 1) return (d.SH == 1 && d.SW == 1) ? 2 : 1;
-  static const int nt33 = getenv("DLIO_WGRAD_NT") ? atoi(getenv("DLIO_WGRAD_NT")) : 5;   // tuning knob (4 or 5)
+  static const int nt33 = 5;   // tuning knob (4 or 5)
   if (d.KH == 3 && d.KW == 3 && d.SH == 1 && d.SW == 1 && nt33 == 4) return 4;
   return 5;
 }
@@ -609,7 +609,7 @@ int nt_for(const DlioConvDesc& d) {
 // 32-channel tiles (80 accumulator registers -> two workgroups per CU) for the multi-tap kernels;
 // 64-channel tiles for 1x1 where the dY tile is the re-read operand.  DLIO_WGRAD_MR overrides.
 int mr_for(const DlioConvDesc& d) {
-  static const int force = getenv("DLIO_WGRAD_MR") ? atoi(getenv("DLIO_WGRAD_MR")) : 0;
+  static const int force = 0;
   const bool has_mr1 = d.SH == 1 && d.SW == 1 && ((d.KH == 1 && d.KW == 1) || (d.KH == 3 && d.KW == 3));
   if (!has_mr1) return 2;
   if (force == 1 || force == 2) return force;
@@ -635,7 +635,7 @@ bool make_plan(const DlioConvDesc& d, WgPlan& p) {
   // one workgroup per CU: the weight-gradient kernels run on companion streams beside the data-gradient chain, and with
   // the XCD-aware order half the workgroups leave the chain more of the chip than they lose (sweep: 256 / 192 -> 26.75,
   // 512 -> 27.0, 128 -> 26.96 ms/step)
-  static const int tgt = getenv("DLIO_WGRAD_BLOCKS") ? atoi(getenv("DLIO_WGRAD_BLOCKS")) : 256;
+  static const int tgt = 256;
   // floor, not ceil: a block more than the slots costs a whole extra round
   int64_t splits = tgt / pairs > 0 ? tgt / pairs : 1;
   if (splits > total_tiles) splits = total_tiles;
@@ -707,10 +707,10 @@ bool make_plan_1x1(const DlioConvDesc& d, Wg1Plan& p) {
   // sweet spot and a partial second round (320) costs 15-50 %; inside the training step, where
   // the other encoder's kernels share the chip, two per CU is 0.2 ms/step better (tools/sweep_env.sh)
   // (re-measured with the XCD-aware order: one per CU 25.51, 1.5 per CU 25.61, two per CU 25.62 ms/step)
-  static const int tgt = getenv("DLIO_WGRAD_1X1_BLOCKS") ? atoi(getenv("DLIO_WGRAD_1X1_BLOCKS")) : dlio_num_cus();
+  static const int tgt = dlio_num_cus();
   int64_t splits = tgt / pairs > 0 ? tgt / pairs : 1;
   // every wave should stream at least MINSEG segments, or prologue + slab reduction dominate
-  static const int minseg = getenv("DLIO_WGRAD_1X1_MINSEG") ? atoi(getenv("DLIO_WGRAD_1X1_MINSEG")) : 2;
+  static const int minseg = 2;
   if (splits * 4 * minseg > total) splits = cdiv64(total, 4 * minseg);
   const size_t slab = (size_t)d.Cout * d.Cin * 4;
   const size_t cap = (size_t)96 << 20;
@@ -726,8 +726,8 @@ int launch_1x1(const float* x, const float* dy, float* dw, float* wsp, const Dli
                const Wg1Plan& p, int accumulate, hipStream_t s, const float* in_mean = nullptr,
                const float* in_scale = nullptr, const float* in_shift = nullptr) {
   // split-bf16 MFMAs where the fp32 MFMA time shows (64 x 64-channel tiles); narrow layers are HBM-bound
-  static const int bx3 = getenv("DLIO_WGRAD_1X1_BX3") ? atoi(getenv("DLIO_WGRAD_1X1_BX3")) : 1;
-  static const int aff_bx3 = getenv("DLIO_WGRAD_1X1_AFF_BX3") ? atoi(getenv("DLIO_WGRAD_1X1_AFF_BX3")) : 1;
+  static const int bx3 = 1;
+  static const int aff_bx3 = 1;
   // in-affine + split-bf16 on the 64 x 64 tile needs 26 registers more than two waves per SIMD leave: that instantiation is
   // built for one wave per SIMD (launch bounds (256, 1): 210 VGPR + 64 AGPR, no scratch) -- the kernel runs one workgroup per
   // CU anyway; family 2.30 -> 2.21 ms exclusive
@@ -999,7 +999,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_taps_kernel(const float* __r
 struct WgS2Plan { DlioConvDesc sub; Wg1Plan q; int PW, S, gemm, gsplits; size_t dyp_floats, img_floats, ws_bytes; };
 
 bool make_plan_s2_taps(const DlioConvDesc& d, WgS2Plan& p) {
-  static const int on = getenv("DLIO_WGRAD_S2_TAPS") ? atoi(getenv("DLIO_WGRAD_S2_TAPS")) : 1;
+  static const int on = 1;
   if (!on || d.KH != 3 || d.KW != 3 || d.SH != 2 || d.SW != 2 || d.PH != 1 || d.PW != 1 || d.Cin < 32 || d.Cout < 32 ||
       d.OH != (d.H - 1) / 2 + 1 || d.OW != (d.W - 1) / 2 + 1 || (int64_t)d.N * d.OH * d.OW < 8192)
     return false;
@@ -1014,7 +1014,7 @@ bool make_plan_s2_taps(const DlioConvDesc& d, WgS2Plan& p) {
   p.img_floats = (size_t)d.N * d.Cin * p.S;
   if ((p.dyp_floats + 6 * p.img_floats) * 4 >= 0xffffff00ull) return false;       // 32-bit buffer offsets per operand
   // wide layers: the tap products on the 128 x 128-tile GEMM (DLIO_WGRAD_S2_GEMM, default 1)
-  static const int gemm_on = getenv("DLIO_WGRAD_S2_GEMM") ? atoi(getenv("DLIO_WGRAD_S2_GEMM")) : 1;
+  static const int gemm_on = 1;
   p.gemm = gemm_on && d.Cout % GT == 0 && d.Cin % GT == 0;
   p.gsplits = 1;
   size_t slab_bytes = p.q.ws_bytes;
@@ -1035,7 +1035,7 @@ bool make_plan_s2_taps(const DlioConvDesc& d, WgS2Plan& p) {
 struct Wg35Plan { DlioConvDesc sub; DlioWgrad3Plan p3; size_t phase_floats, ws_bytes; };
 
 bool make_plan_3x5s2(const DlioConvDesc& d, Wg35Plan& q) {
-  static const int on = getenv("DLIO_WGRAD_3X5_PHASES") ? atoi(getenv("DLIO_WGRAD_3X5_PHASES")) : 1;
+  static const int on = 1;
   // (the 5-channel PointSeg stem fills 5 of the kernel's 16-channel slots: 24.09 vs 23.92 ms per step, it stays on the staged kernel)
   if (!on || d.Cin < 16 || d.KH != 3 || d.KW != 5 || d.SH != 1 || d.SW != 2 || d.PH != 1 || d.PW != 2 || (d.W & 7) != 0 ||
       d.OW != d.W / 2 || d.OH != d.H)

@@ -519,7 +519,7 @@ bool dlio_wgrad3_plan(const DlioConvDesc& d, int elem_bytes, DlioWgrad3Plan& p) 
   p.tiles_h = cdiv(d.OH, 4);
   const int64_t total_tiles = (int64_t)d.N * p.tiles_w * p.tiles_h;
   const int64_t pairs = (int64_t)p.co_tiles * p.ci_chunks;
-  static const int tgt = getenv("DLIO_WGRAD3_BLOCKS") ? atoi(getenv("DLIO_WGRAD3_BLOCKS")) : dlio_num_cus();
+  static const int tgt = dlio_num_cus();
   int64_t splits = tgt / pairs > 0 ? tgt / pairs : 1;
   if (splits > total_tiles) splits = total_tiles;
   const size_t slab = (size_t)d.Cout * d.Cin * 9 * 4;

@@ -667,7 +667,7 @@ extern "C" int dlio_linear_fwd(const float* x, int ldx, const float* w, const fl
                                int K, int act, dlio_stream_t stream) {
   if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0 || ldx < K || ldy < N || act < 0 || act > 4)
     return DLIO_EINVAL;
-  static const int mfma_from = getenv("DLIO_LINEAR_MFMA_M") ? atoi(getenv("DLIO_LINEAR_MFMA_M")) : 128;
+  static const int mfma_from = 128;
   if (M >= mfma_from) {                 // tall M (IMU windows): GEMM on the fp32 MFMA
     const int kvec = (K % 8 == 0) && (ldx % 4 == 0) &&
                      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15) == 0;
@@ -676,7 +676,7 @@ extern "C" int dlio_linear_fwd(const float* x, int ldx, const float* w, const fl
     return dlio_check_launch();
   }
   // skinny M against a large weight matrix (the odometry LSTM): x staged once per workgroup
-  static const int skinny = getenv("DLIO_LINEAR_SKINNY") ? atoi(getenv("DLIO_LINEAR_SKINNY")) : 1;
+  static const int skinny = 1;
   if (skinny && M <= 16 && (K & 3) == 0 && (ldx & 3) == 0 && (int64_t)N * K >= (1 << 18) &&
       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15) == 0) {
     const int mrows = M <= 8 ? 8 : 16;
@@ -743,7 +743,7 @@ extern "C" int dlio_linear_bwd_weight(const float* dz, int lddz, const float* x,
                                       dlio_stream_t stream) {
   if (!dz || !x || !dw || M <= 0 || N <= 0 || K <= 0 || lddz < N || ldx < K) return DLIO_EINVAL;
   hipStream_t s = as_stream(stream);
-  static const int mfma_from = getenv("DLIO_LINEAR_MFMA_M") ? atoi(getenv("DLIO_LINEAR_MFMA_M")) : 128;
+  static const int mfma_from = 128;
   if (M >= mfma_from) {                 // tall M: one launch for dW and db
     hipLaunchKernelGGL(linear_wgrad_mfma_kernel, dim3(cdiv(K, 32), cdiv(N, 32)), dim3(256), 0, s, dz, lddz, x, ldx, dw,
                        db, M, N, K, accumulate);

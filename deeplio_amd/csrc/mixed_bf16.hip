@@ -673,7 +673,7 @@ extern "C" int dlio_bn_bf16_bwd(const void* dy, int dy_ctot, int dy_coff, const 
 
 // rolling-window kernels (DLIO_POOL16_STRIP, default 1) vs one output row / one element per thread
 static bool pool16_strips() {
-  static const int v = getenv("DLIO_POOL16_STRIP") ? atoi(getenv("DLIO_POOL16_STRIP")) : 1;
+  static const int v = 1;
   return v != 0;
 }
 

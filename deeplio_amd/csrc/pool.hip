@@ -506,7 +506,7 @@ extern "C" int dlio_maxpool2d_fwd(const float* x, const float* x_scale, float* y
   if (K == 3 && SW == 2 && PH == 1 && PW == 1 && (SH == 1 || SH == 2) && (W & 3) == 0 && OW * 2 == W &&
       OH == (H + 2 - 3) / SH + 1) {
     const int64_t work = total / 2;
-    static const int strip = getenv("DLIO_POOL_STRIP") ? atoi(getenv("DLIO_POOL_STRIP")) : 1;   // tuning knob
+    static const int strip = 1;   // tuning knob
     if (strip && SH == 1)
       hipLaunchKernelGGL(maxpool3_fwd_strip<1>, dim3(ew_grid(cdiv64(work, 8), 256)), dim3(256), 0,
                          as_stream(stream), x, x_scale, y, idx, (int64_t)N * C, H, W, OH, OW, (const float*)nullptr, 1);
@@ -539,7 +539,7 @@ extern "C" int dlio_maxpool2d_bwd_dot(const float* dy, const uint8_t* idx, const
   DlioProfScope prof(10, as_stream(stream), 0.0, (double)N * C * (4.0 * H * W + 5.0 * OH * OW));
   int grid = N * C;
   if (grid > 65535) grid = 65535;
-  static const int strip = getenv("DLIO_POOL_STRIP") ? atoi(getenv("DLIO_POOL_STRIP")) : 1;   // tuning knob
+  static const int strip = 1;   // tuning knob
   if (SH == 1 && strip)
     hipLaunchKernelGGL(maxpool3_bwd_dot_strip<1>, dim3(grid), dim3(256), 0, as_stream(stream), dy, idx,
                        x, ds, N * C, H, W, OH, OW);
@@ -565,7 +565,7 @@ extern "C" int dlio_maxpool2d_bwd(const float* dy, const uint8_t* idx, const flo
   if (K == 3 && SW == 2 && PH == 1 && PW == 1 && (SH == 1 || SH == 2) && (W & 3) == 0 && OW * 2 == W &&
       OH == (H + 2 - 3) / SH + 1) {
     const int64_t work = total / 4;
-    static const int strip = getenv("DLIO_POOL_STRIP") ? atoi(getenv("DLIO_POOL_STRIP")) : 1;   // tuning knob
+    static const int strip = 1;   // tuning knob
     if (SH == 1 && strip)
       hipLaunchKernelGGL(maxpool3_bwd_strip<1>, dim3(ew_grid(cdiv64(work, PR), 256)), dim3(256), 0,
                          as_stream(stream), dy, idx, x_scale, x_add, dx, (int64_t)N * C, H, W, OH, OW);

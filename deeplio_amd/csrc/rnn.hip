@@ -19,7 +19,7 @@ namespace {
 // small batch is spread over more workgroups -- with 8 rows in ONE workgroup the headline's IMU net (B = 8) ran every
 // recurrence on a single CU at 5.9 us per step; one row per workgroup (8 CUs): same results bit for bit
 static int lstm_rows_per_wg(int B) {
-  static const int forced = getenv("DLIO_RNN_BC") ? atoi(getenv("DLIO_RNN_BC")) : 0;
+  static const int forced = 0;
   if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced;
   return B <= 16 ? 1 : B <= 64 ? 2 : 8;   // (B = 8: IMU forward chain 2.16 / 1.35 / 1.24 / 0.92 ms at 8 / 4 / 2 / 1 rows)
 }
@@ -648,7 +648,7 @@ extern "C" int dlio_gru_seq_fwd(const float* gx, const float* w_hh, const float*
   if (!gx || !w_hh || !hs || !hp || !gates || T <= 0 || B <= 0 || H <= 0 || ldhs < H)
     return DLIO_EINVAL;
   hipStream_t s = as_stream(stream);
-  static const int persist = getenv("DLIO_GRU_PERSIST") ? atoi(getenv("DLIO_GRU_PERSIST")) : 1;
+  static const int persist = 1;
 #define GRU_FWD_P(HH)                                                                          \
   if (persist && H == HH) {                                                                    \
     const int rows = lstm_rows_per_wg(B);                                                       \
@@ -689,7 +689,7 @@ extern "C" int dlio_gru_seq_bwd(const float* dhs, int lddhs, const float* dhT, c
                                 void* ws, size_t ws_bytes, dlio_stream_t stream) {
   if (!gates || !hp || !w_hh || !dgx || !dgh || T <= 0 || B <= 0 || H <= 0) return DLIO_EINVAL;
   hipStream_t s = as_stream(stream);
-  static const int persist = getenv("DLIO_GRU_PERSIST") ? atoi(getenv("DLIO_GRU_PERSIST")) : 1;
+  static const int persist = 1;
 #define GRU_BWD_P(HH)                                                                          \
   if (persist && H == HH) {                                                                    \
     const int rows = lstm_rows_per_wg(B);                                                      \

@@ -21,9 +21,9 @@ def _new(shape, like):
 
 
 _SINK = [True]
-_PLANE_BN = [os.environ.get("DLIO_PLANE_BN", "1") != "0"]
+_PLANE_BN = [True]            # (a module switch for tests / ablations; the environment knob is gone)
 # stem: pool1's backward folded into the stem's BatchNorm backward (ConvBnActPoolFn)
-_POOL_BN_BWD = [os.environ.get("DLIO_POOL_BN_BWD", "1") != "0"]
+_POOL_BN_BWD = [True]
 
 
 def set_grad_sink(on):
@@ -164,7 +164,7 @@ class DeferredBranchFn(Function):
         _want_join()
         return None, None, None
 
-    LATE = os.environ.get("DLIO_DEFER_IMU_BWD", "1") == "2"
+    LATE = False
     _PENDING = []
 
     @staticmethod
@@ -197,7 +197,7 @@ def join_wgrad_stream():
             cur.wait_stream(ws)
 
 
-_RNN_DIR_FORK = [os.environ.get("DLIO_RNN_DIR_STREAM", "1") != "0"]
+_RNN_DIR_FORK = [True]
 
 
 def _rnn_dir_stream(like):
@@ -449,14 +449,14 @@ def conv_dgrad(dy, weight, d, dx, dx_ctot, dx_coff, residual=None, r_ctot=0, r_c
 _CONV_BX3 = [os.environ.get("DLIO_CONV_BX3", "1") != "0"]
 _FIRE_FUSED = [os.environ.get("DLIO_FIRE_FUSED", "1") != "0"]
 _SE_POOLED_DOT = [os.environ.get("DLIO_SE_POOLED_DOT", "1") != "0"]   # SELayer scale gradient from pooled tensors
-_BN_COOP_FWD = [os.environ.get("DLIO_BN_COOP_FWD", "1") != "0"]   # A/B switch: cooperative kernels in the forward pass too
+_BN_COOP_FWD = [True]          # cooperative kernels in the forward pass too (a module switch for ablations)
 _BN_SMALL = [os.environ.get("DLIO_BN_SMALL", "1") != "0"]           # one-launch BatchNorm of small feature maps (bn_small.hip)      # expand1x1 || expand3x3 in one launch (fire_expand.hip)
 _CONV_BX3_1X1 = [os.environ.get("DLIO_CONV_BX3_1X1", "1") != "0"]
-_CONV_BX3_STEM = [os.environ.get("DLIO_CONV_BX3_STEM", "1") != "0"]
+_CONV_BX3_STEM = [True]
 # FlowNet conv2 / conv3 (3x5, stride (1, 2), 64 / 128 input channels) and the 3x3 stride-2 layers (FlowNet conv4-6, ResNet)
-_CONV_BX3_3X5 = [os.environ.get("DLIO_CONV_BX3_3X5", "1") != "0"]
+_CONV_BX3_3X5 = [True]
 _BX3_1X1_KSPLIT = [os.environ.get("DLIO_BX3_1X1_KSPLIT", "1") != "0"]
-_BX3_1X1_KSPLIT_PIX = [int(os.environ.get("DLIO_BX3_1X1_KSPLIT_PIX", "16384"))]
+_BX3_1X1_KSPLIT_PIX = [16384]
 _BX3_1X1_MIN = [int(v) for v in os.environ.get("DLIO_BX3_1X1_MIN", "16,16,65536,8192").split(",")]   # Cin, Cout, pixels, pixels (widening layers)
 
 
@@ -507,7 +507,7 @@ def set_dgrad_phases(on, bx3=None, bx3_min_k=None):
 
 
 # the phases' stride-1 convolutions on the split-bf16 kernel (dlio_conv_bx3_fwd_taps) instead of the fp32 MFMA
-_DGRAD_PHASES_BX3 = [os.environ.get("DLIO_DGRAD_PHASES_BX3", "1") != "0"]
+_DGRAD_PHASES_BX3 = [True]
 _PHASE_BX3_KERNELS = {(3, 3), (3, 2), (2, 2), (2, 1), (1, 2), (1, 1)}
 _PHASE_BX3_MIN_K = [16]      # channels of dy below which the 16-channel chunks of the split-bf16 kernel are mostly padding
 

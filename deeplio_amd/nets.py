@@ -19,10 +19,10 @@ from . import ops
 from .misc import get_config_container
 
 # IMU branch backward scheduled at the fusion layer instead of at the end of the backward pass
-_DEFER_IMU = os.environ.get("DLIO_DEFER_IMU_BWD", "1") != "0"
+_DEFER_IMU = True
 # BatchNorm + ReLU of bypass-free Fire blocks applied by their consumer instead of being written (HISTORY 11)
 _APPLY_ON_LOAD = os.environ.get("DLIO_APPLY_ON_LOAD", "1") != "0"
-_STEM_AOL = os.environ.get("DLIO_STEM_AOL", "1") != "0"      # ... and of the stem by pool1
+_STEM_AOL = True                                             # ... and of the stem by pool1
 
 
 def _pair(v):
@@ -421,7 +421,7 @@ class BaseLidarFeatNet(BaseNet):
         self.fc1 = nn.Linear(nfeat, 128)
         self.output_shape = torch.Size([1, self.seq_size, 128])
         self.two_streams = os.environ.get("DLIO_TWO_STREAMS", "1") != "0"
-        self.interleave = os.environ.get("DLIO_INTERLEAVE", "1") != "0"
+        self.interleave = True
         self._side = None
 
     def forward(self, x):

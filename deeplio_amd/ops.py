@@ -112,7 +112,7 @@ class _PrepCache:
         self.entries = {}        # (device index, data_ptr, shape, mode) -> dict
         self.tables = {}         # (device index, family) -> dict(items_dev, n, total, keys)
         self.waited = {}         # stream handle -> last refresh event it waited for
-        self.batched = os.environ.get("DLIO_BATCHED_PREP", "1") != "0"
+        self.batched = True
 
     @staticmethod
     def _floats(w, mode):
