@@ -52,6 +52,7 @@ SIGNATURES = {
     "dlio_conv_bx3_fwd_taps": (_i, [_p, _p, _p, _p, _p, _cd, _p]),
     "dlio_conv1x1_bx3_ws_bytes": (_sz, [_cd]),
     "dlio_conv1x1_bx3_fwd_ws": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _cd, _p]),
+    "dlio_fire_expand_dgrad": (_i, [_p, _p, _p, _p, _i, _p, _p, _p, _sz, _cd, _p]),
     "dlio_conv3x3_bx3_prep_floats": (_sz, [_i, _i, _i]),
     "dlio_conv3x3_bx3_prep": (_i, [_p, _p, _i, _i, _i, _p]),
     "dlio_conv3x3_bx3_prep_batched": (_i, [_p, _i, _i64, _p]),

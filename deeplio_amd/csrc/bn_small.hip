@@ -233,6 +233,22 @@ __device__ __forceinline__ double block_sum_t(double v, double* sm) {      // to
   return r;
 }
 
+template <int T>
+__device__ __forceinline__ void block_sum2_t(double& a, double& b, double (*sm)[16]) {   // totals in thread 0; one barrier pair
+  a = wave_sum_d(a);
+  b = wave_sum_d(b);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) { sm[0][w] = a; sm[1][w] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ra = 0.0, rb = 0.0;
+#pragma unroll
+    for (int i = 0; i < T / 64; ++i) { ra += sm[0][i]; rb += sm[1][i]; }
+    a = ra; b = rb;
+  }
+}
+
 template <int V, int T>
 __global__ __launch_bounds__(T) void bn_coop_fwd_kernel(
     const float* __restrict__ x, int x_ctot, int x_coff, int N, int C, int C1, BnSet s1, BnSet s2, float eps, float momentum,
@@ -260,8 +276,7 @@ __global__ __launch_bounds__(T) void bn_coop_fwd_kernel(
       const float f1 = (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
       a += f0; b += f1;
     }
-    a = block_sum_t<T>(a, sm[0]);
-    b = block_sum_t<T>(b, sm[1]);
+    block_sum2_t<T>(a, b, sm);
     coop_exchange(a, b, part, sync, C, c, np, NP, bc);
     const double count = (double)N * HW;
     const double m = a / count;
@@ -351,8 +366,7 @@ __global__ __launch_bounds__(T) void bn_coop_bwd_kernel(
       xh[j] = make_float4(xe[0], xe[1], xe[2], xe[3]);
       sg += f0; sgx += f1;
     }
-    sg = block_sum_t<T>(sg, sm[0]);
-    sgx = block_sum_t<T>(sgx, sm[1]);
+    block_sum2_t<T>(sg, sgx, sm);
     coop_exchange(sg, sgx, part, sync, C, c, np, NP, bc);
     if (threadIdx.x == 0 && np == 0) {
       if (ps.dbeta) ps.dbeta[cl] = accumulate ? ps.dbeta[cl] + (float)sg : (float)sg;

@@ -337,7 +337,7 @@ template <int MR, int TWN>
 __global__ __launch_bounds__(256, 2) void conv3x3_bx3_alds_kernel(
     const float* __restrict__ x, const __bf16* __restrict__ wt, const float* __restrict__ bias,
     const float* residual, float* y, DlioConvDesc d, int tiles_w, int tiles_h, int co_tiles, int vec_out, int ksplit,
-    float* __restrict__ slab) {
+    float* __restrict__ slab, const float* __restrict__ x1, const __bf16* __restrict__ wt1, int C1) {
   constexpr int TH = 4, TW = 32 * TWN, PR = TH + 2, PC = TW + 2, NPOSP = PR * PC;
   constexpr int NPOS = (NPOSP + 255) / 256;
   constexpr int PLANE = NPOSP * 16;                      // bf16 per patch plane
@@ -364,7 +364,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_alds_kernel(
   const int co0 = cot * 32 * MR, oh0 = th * TH, ow0 = tw * TW;
   const int Cin = d.Cin, Cout = d.Cout, HW = d.H * d.W;
   const int KC = (Cin + 15) >> 4;
-  const int kc_lo = slab ? (int)((int64_t)KC * ks / ksplit) : 0, kc_hi = slab ? (int)((int64_t)KC * (ks + 1) / ksplit) : KC;
+  // second input (x1 [N][C1][H][W], weights wt1 [1][KC1][3][Cout][16]: a 1x1 layer that adds to the same output -- the
+  // expand1x1 half of a Fire block's data gradient): KC1 more chunks that use the CENTRE tap only
+  const int KC1 = x1 ? (C1 + 15) >> 4 : 0, KCT = KC + KC1;
+  const int kc_lo = slab ? (int)((int64_t)KCT * ks / ksplit) : 0, kc_hi = slab ? (int)((int64_t)KCT * (ks + 1) / ksplit) : KCT;
 
   // ---- patch staging (as conv3x3_bx3_kernel)
   bool pval[NPOS];
@@ -378,16 +381,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_alds_kernel(
     poff[j] = pval[j] ? ih * d.W + iw : 0;
   }
   const float* xn = x + ((size_t)n * d.in_ctot + d.in_coff) * HW;
+  const float* xn1 = x1 ? x1 + (size_t)n * C1 * HW : nullptr;
   float reg[NPOS][16];
   auto load_patch = [&](int kc) {
+    const bool second = kc >= KC;
+    const float* xb = second ? xn1 : xn;
+    const int cb = second ? (kc - KC) * 16 : kc * 16, cmax = (second ? C1 : Cin) - 1;
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-      const float* xc = xn + (size_t)min(kc * 16 + c, Cin - 1) * HW;
+      const float* xc = xb + (size_t)min(cb + c, cmax) * HW;
 #pragma unroll
       for (int j = 0; j < NPOS; ++j) reg[j][c] = xc[poff[j]];
     }
   };
   auto store_patch = [&](int kc) {
+    const int cend = kc >= KC ? C1 - (kc - KC) * 16 : Cin - kc * 16;       // valid channels of this chunk
 #pragma unroll
     for (int j = 0; j < NPOS; ++j) {
       const int pos = tid + j * 256;
@@ -395,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_alds_kernel(
         bf16x8 ph[2], pm[2], pl[2];
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-          const float v = (kc * 16 + c < Cin && pval[j]) ? reg[j][c] : 0.f;
+          const float v = (c < cend && pval[j]) ? reg[j][c] : 0.f;
           __bf16 h, m, l;
           split3(v, h, m, l);
           ph[c >> 3][c & 7] = h; pm[c >> 3][c & 7] = m; pl[c >> 3][c & 7] = l;
@@ -421,14 +429,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_alds_kernel(
   unsigned awoff[MR];
 #pragma unroll
   for (int m = 0; m < MR; ++m) awoff[m] = ((unsigned)min(co0 + m * 32 + (lane >> 1), Cout - 1) * 16u + 8u * (unsigned)(lane & 1)) * 2u;
+  const __amdgpu_buffer_rsrc_t wrsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__bf16*>(wt1 ? wt1 : wt), 0, (int)((size_t)(KC1 ? KC1 : 1) * 3 * wplane * 2), 0x00020000);
   auto load_agroup = [&](int kc, int g, int slot) {
+    const bool second = kc >= KC;            // (one group of ONE tap: the first 3 MR instructions of a group's 9 MR)
 #pragma unroll
     for (int i = 0; i < (AINS + 3) / 4; ++i) {
       const int t = i * 4 + wave;
-      if (t < AINS) {
+      if (t < AINS && (!second || t < 3 * MR)) {
         const int m = t % MR, tp = t / MR, tap = g * TG + tp / 3, pl = tp - 3 * (tp / 3);
         __bf16* dst = ring + (size_t)slot * AGRP + (size_t)t * 64 * 8;
 #if defined(__HIP_DEVICE_COMPILE__)     // (the host pass cannot instantiate the address-space cast)
+        if (second)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc1, (__attribute__((address_space(3))) void*)dst, 16, awoff[m],
+                                                   (unsigned)(((size_t)(kc - KC) * 3 + pl) * wplane * 2), 0, 0);
+        else
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, awoff[m],
                                                  (unsigned)((((size_t)tap * KC + kc) * 3 + pl) * wplane * 2), 0, 0);
 #else
@@ -480,6 +495,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_alds_kernel(
     }
   };
 
+  auto compute_centre = [&](const __bf16* slot) {       // the 1x1 chunk: tap (1, 1), fragments at ring position 0
+    bf16x8 a[MR][3], b[TWN][3];
+    read_a(slot, 0, a);
+#pragma unroll
+    for (int t = 0; t < TWN; ++t) {
+      const int pos = (wave + 1) * PC + 32 * t + l31 + 1;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) b[t][p] = *reinterpret_cast<const bf16x8*>(patch + p * PLANE + pos * 16 + 8 * half);
+    }
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int t = 0; t < TWN; ++t)
+          acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][PA[q]], b[t][PB[q]], acc[m][t], 0, 0, 0);
+  };
+
   // ---- pipeline: weight groups double-slotted, patch single-buffered
   load_agroup(kc_lo, 0, 0);
   load_patch(kc_lo);
@@ -489,17 +523,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_alds_kernel(
   int gi = 0;                                            // running group index -> ring slot
   for (int kc = kc_lo; kc < kc_hi; ++kc) {
     const bool more = kc + 1 < kc_hi;
+    const int ngroups = kc >= KC ? 1 : 3;                // (a 1x1 chunk is one group of one tap)
 #pragma unroll
-    for (int g = 0; g < 3; ++g, ++gi) {
-      const bool anext = g < 2 || more;
+    for (int g = 0; g < 3; ++g) {
+      if (g >= ngroups) break;
+      const bool last = g == ngroups - 1;
+      const bool anext = !last || more;
       // the other slot was read last during group gi - 1: every wave is past that barrier
-      if (anext) load_agroup(g < 2 ? kc : kc + 1, g < 2 ? g + 1 : 0, (gi + 1) & 1);
+      if (anext) load_agroup(last ? kc + 1 : kc, last ? 0 : g + 1, (gi + 1) & 1);
       if (g == 0 && more) load_patch(kc + 1);
-      compute_group(ring + (size_t)(gi & 1) * AGRP, g);
+      if (kc >= KC) compute_centre(ring + (size_t)(gi & 1) * AGRP);
+      else compute_group(ring + (size_t)(gi & 1) * AGRP, g);
       // the group's pieces have landed; the patch loads issued behind them (group 0) stay in flight
       if (g == 0 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPOS * 16) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      ++gi;
     }
     if (more) {
       store_patch(kc + 1);                               // every wave is past the last group's barrier: the patch is free
@@ -761,7 +800,8 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
 
 template <int MR, int TWN>
 int launch_bx3_alds(const float* x, const __bf16* wt, const float* bias, const float* residual, float* y,
-                    const DlioConvDesc& d, hipStream_t s, int ksplit = 1, float* slab = nullptr) {
+                    const DlioConvDesc& d, hipStream_t s, int ksplit = 1, float* slab = nullptr, const float* x1 = nullptr,
+                    const __bf16* wt1 = nullptr, int C1 = 0) {
   constexpr int TH = 4, TW = 32 * TWN;
   const int tiles_w = cdiv(d.OW, TW), tiles_h = cdiv(d.OH, TH), co_tiles = cdiv(d.Cout, 32 * MR);
   if (!slab) ksplit = 1;
@@ -777,7 +817,7 @@ int launch_bx3_alds(const float* x, const __bf16* wt, const float* bias, const f
                       ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0 && epi_b <= lds;
   if (slab && !vec_out) return DLIO_EUNSUP;              // (the caller only splits when the float4 store path applies)
   hipLaunchKernelGGL((conv3x3_bx3_alds_kernel<MR, TWN>), dim3((unsigned)blocks), dim3(256), lds, s, x, wt, bias, residual, y,
-                     d, tiles_w, tiles_h, co_tiles, vec_out, ksplit, slab);
+                     d, tiles_w, tiles_h, co_tiles, vec_out, ksplit, slab, x1, wt1, C1);
   return dlio_check_launch();
 }
 
@@ -985,8 +1025,29 @@ extern "C" size_t dlio_conv3x3_bx3_ws_bytes(const DlioConvDesc* dp) {
   return ks < 2 ? 0 : (size_t)ks * dp->N * dp->Cout * dp->OH * dp->OW * sizeof(float);
 }
 
+static int bx3_3x3_run(const float* x, const void* wt, const float* bias, const float* residual, float* y, void* ws,
+                       size_t ws_bytes, const DlioConvDesc* dp, dlio_stream_t stream, const float* x1, const void* wt1, int C1);
+
 extern "C" int dlio_conv3x3_bx3_fwd_ws(const float* x, const void* wt, const float* bias, const float* residual,
                                        float* y, void* ws, size_t ws_bytes, const DlioConvDesc* dp, dlio_stream_t stream) {
+  return bx3_3x3_run(x, wt, bias, residual, y, ws, ws_bytes, dp, stream, nullptr, nullptr, 0);
+}
+
+/* y = conv3x3(x, wt) + conv1x1(x1, wt1) (+ bias, + residual): the data gradient of a Fire block's expand pair,
+ * dS = W3^T * dE3 + W1^T dE1 (autograd's conv2d backward of pointseg_modules.py:126-133), in ONE launch: the 1x1 layer's
+ * channels are further K chunks of the 3x3 kernel that use the centre tap only.  x1 contiguous [N][C1][H][W]; wt1 from
+ * dlio_conv_bx3_prep(taps = 1, mode 1). */
+extern "C" int dlio_fire_expand_dgrad(const float* x, const void* wt, const float* x1, const void* wt1, int C1,
+                                      const float* residual, float* y, void* ws, size_t ws_bytes, const DlioConvDesc* dp,
+                                      dlio_stream_t stream) {
+  if (!x1 || !wt1 || C1 <= 0 || !dp) return DLIO_EINVAL;
+  if (dp->PH != 1 || dp->PW != 1 || dp->OH != dp->H || dp->OW != dp->W) return DLIO_EUNSUP;     // "same" 3x3: the centre tap is the pixel itself
+  if ((size_t)((C1 + 15) / 16) * 3 * dp->Cout * 32 >= 0x7fffffffull) return DLIO_EUNSUP;
+  return bx3_3x3_run(x, wt, nullptr, residual, y, ws, ws_bytes, dp, stream, x1, wt1, C1);
+}
+
+static int bx3_3x3_run(const float* x, const void* wt, const float* bias, const float* residual, float* y, void* ws,
+                       size_t ws_bytes, const DlioConvDesc* dp, dlio_stream_t stream, const float* x1, const void* wt1, int C1) {
   if (!x || !wt || !y || !dp) return DLIO_EINVAL;
   const DlioConvDesc& d = *dp;
   if (d.KH != 3 || d.KW != 3 || d.SH != 1 || d.SW != 1) return DLIO_EUNSUP;
@@ -994,8 +1055,8 @@ extern "C" int dlio_conv3x3_bx3_fwd_ws(const float* x, const void* wt, const flo
   const int oh_lo = d.H + 2 * d.PH - 2, ow_lo = d.W + 2 * d.PW - 2;
   if (d.OH < oh_lo || d.OH > oh_lo + 2 || d.OW < ow_lo || d.OW > ow_lo + 2 || d.OH < 1 || d.OW < 1) return DLIO_EINVAL;
   hipStream_t s = as_stream(stream);
-  const double flops = 2.0 * d.N * (double)d.OH * d.OW * d.Cout * (double)d.Cin * 9;
-  const double bytes = 4.0 * d.N * ((double)d.Cin * d.H * d.W + (double)d.Cout * d.OH * d.OW * (residual ? 2.0 : 1.0));
+  const double flops = 2.0 * d.N * (double)d.OH * d.OW * d.Cout * ((double)d.Cin * 9 + (x1 ? C1 : 0));
+  const double bytes = 4.0 * d.N * ((double)(d.Cin + (x1 ? C1 : 0)) * d.H * d.W + (double)d.Cout * d.OH * d.OW * (residual ? 2.0 : 1.0));
   dlio_prof_begin(3, s, flops, bytes);      // profiler kind 3: split-bf16 3x3 convolutions
   const __bf16* w = reinterpret_cast<const __bf16*>(wt);
   int mr, twn;
@@ -1005,6 +1066,8 @@ extern "C" int dlio_conv3x3_bx3_fwd_ws(const float* x, const void* wt, const flo
   // (DLIO_BX3_ALDS: 0 off, 1 the 64-channel tiles only, 2 = default all tiles: 25.39 / 25.61 / 26.3 ms for 2 / 1 / 0)
   static const int alds = 2;
   bool use_alds = alds && (size_t)9 * ((d.Cin + 15) / 16) * 3 * d.Cout * 32 < 0x7fffffffull && (alds == 2 || mr == 2);
+  if (x1 && !use_alds) return DLIO_EUNSUP;
+  const __bf16* w1 = reinterpret_cast<const __bf16*>(wt1);
   // K split: the LARGE tile (which bx3_3x3_shape gave up to get more workgroups) with the channel loop cut in slices
   int mrs, twns;
   bx3_3x3_shape_large(d, mrs, twns);
@@ -1015,7 +1078,7 @@ extern "C" int dlio_conv3x3_bx3_fwd_ws(const float* x, const void* wt, const flo
     ksplit = 1;
   if (ksplit > 1) { mr = mrs; twn = twns; use_alds = true; }
   float* slab = ksplit > 1 ? reinterpret_cast<float*>(ws) : nullptr;
-#define L3(MRV, TWV) (use_alds ? launch_bx3_alds<MRV, TWV>(x, w, bias, residual, y, d, s, ksplit, slab) \
+#define L3(MRV, TWV) (use_alds ? launch_bx3_alds<MRV, TWV>(x, w, bias, residual, y, d, s, ksplit, slab, x1, w1, C1) \
                                : launch_bx3<MRV, TWV>(x, w, bias, residual, y, d, s))
   if (mr == 1) rc = twn == 2 ? L3(1, 2) : L3(1, 1);
   else rc = twn == 2 ? L3(2, 2) : L3(2, 1);

@@ -450,6 +450,9 @@ _CONV_BX3 = [os.environ.get("DLIO_CONV_BX3", "1") != "0"]
 _FIRE_FUSED = [os.environ.get("DLIO_FIRE_FUSED", "1") != "0"]
 _SE_POOLED_DOT = [os.environ.get("DLIO_SE_POOLED_DOT", "1") != "0"]   # SELayer scale gradient from pooled tensors
 _BN_COOP_FWD = [True]          # cooperative kernels in the forward pass too (a module switch for ablations)
+# both expand data gradients in one launch (dlio_fire_expand_dgrad): built, tested, OFF -- the expand1x1 chunks pay the full
+# patch staging for a ninth of the MFMA work (isolated 169 vs 155 us at blk1, step 23.0 vs 22.7 ms: DESIGN 9)
+_FIRE_FUSED_DGRAD = [os.environ.get("DLIO_FIRE_FUSED_DGRAD", "0") != "0"]
 _BN_SMALL = [os.environ.get("DLIO_BN_SMALL", "1") != "0"]           # one-launch BatchNorm of small feature maps (bn_small.hip)      # expand1x1 || expand3x3 in one launch (fire_expand.hip)
 _CONV_BX3_1X1 = [os.environ.get("DLIO_CONV_BX3_1X1", "1") != "0"]
 _CONV_BX3_STEM = [True]
@@ -690,6 +693,12 @@ class FireFn(Function):
             ops.fire_expand_fwd(planes, ops.conv_bx3_prepped(e3w, 0), ops.conv_bx3_prepped(e1w, 0), e3b, e1b, raw_e,
                                 N, S_, H, W, E1, CE, 0)
             del planes
+        # both expand data gradients in one launch (backward): the layouts are fetched here, where the weights are the
+        # long-lived Parameters the cache knows
+        wdg = ((ops.conv_bx3_prepped(e3w, 1), ops.conv_bx3_prepped(e1w, 1))
+               if (training and _FIRE_FUSED_DGRAD[0] and _CONV_BX3[0] and x.is_cuda and tuple(e3w.shape[2:]) == (3, 3)
+                   and tuple(e1w.shape[2:]) == (1, 1)) else None)
+        ctx.wdg = wdg
         coop = (training and _BN_SMALL[0] and _BN_COOP_FWD[0] and x.is_cuda and not defer and ops.bn_coop_ok(N, H * W)
                 and (not want_gap or ops.bn_coop_gap_ok(N, H * W)))
         small = training and _BN_SMALL[0] and x.is_cuda and (coop or ops.bn_small_ok(N, H * W))
@@ -794,14 +803,19 @@ class FireFn(Function):
                                                              sk[0][0], sk[1][0], sk[2][0], sk[3][0], sk[0][1], N, CE, E1,
                                                              H * W, True)
             bg1, bg3 = (sk[0][2], sk[1][2]), (sk[2][2], sk[3][2])
+        wdg = getattr(ctx, "wdg", None)
         g1 = _CBR.backward(dout, CE, 0, act_s, d_1, e1w, e1b, e1g, prm_1, e1be, raw_e, training, False,
-                           True, draw1, True, dact_s, S_, 0, bn_grads=bg1)
-        del draw1
+                           True, draw1, wdg is None, dact_s, S_, 0, bn_grads=bg1)
         if bg3 is None:
             draw3 = _new((N, E3, H, W), x)
         g3 = _CBR.backward(dout, CE, E1, act_s, d_3, e3w, e3b, e3g, prm_3, e3be, raw_e, training, False,
-                           True, draw3, True, dact_s, S_, 0, dx_accumulate=True, bn_grads=bg3)
-        del draw3
+                           True, draw3, wdg is None, dact_s, S_, 0, dx_accumulate=True, bn_grads=bg3)
+        if wdg is not None:
+            # dS = W3^T * dE3 + W1^T dE1 in one launch: the expand1x1 gradient's channels are centre-tap chunks of the 3x3
+            # data-gradient kernel (no second launch, no accumulate pass over dS)
+            gd = ops.conv_desc(N, E3, H, W, S_, 3, 3, 1, 1, 1, 1, OH=H, OW=W, in_ctot=E3, in_coff=0, out_ctot=S_, out_coff=0)
+            ops.fire_expand_dgrad(draw3, wdg[0], draw1, wdg[1], dact_s, gd)
+        del draw1, draw3
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty_like(x) if need_dx else None
         draw_s = _new((N, S_, H, W), x)

@@ -290,6 +290,17 @@ def conv3x3_bx3_fwd(x, wt, bias, y, desc, residual=None):
     return y
 
 
+def fire_expand_dgrad(dy3, wt3, dy1, wt1, dx, desc, residual=None):
+    """dx = conv3x3(dy3, wt3) + conv1x1(dy1, wt1) (+ residual): both expand data gradients of a Fire block in one launch
+    (wt3 / wt1 = conv_bx3_prepped(w, 1) of the two layers; dy1 contiguous)"""
+    nbytes = lib.dlio_conv3x3_bx3_ws_bytes(C.byref(desc))
+    ws = workspace(nbytes, dy3.device, slot=4) if nbytes else None
+    check(lib.dlio_fire_expand_dgrad(_ptr(dy3), _ptr(wt3), _ptr(dy1), _ptr(wt1), dy1.shape[1], _ptr(residual), _ptr(dx),
+                                     _ptr(ws), ws.numel() if ws is not None else 0, C.byref(desc), _stream()),
+          "fire_expand_dgrad")
+    return dx
+
+
 def conv3x5s2_bx3_fwd(x, wt, bias, y, desc, residual=None):
     """the PointSeg stem (3x5 taps, stride (1, 2)) on the split-bf16 kernel; wt = conv_bx3_prepped(w, 0)"""
     check(lib.dlio_conv3x5s2_bx3_fwd(_ptr(x), _ptr(wt), _ptr(bias), _ptr(residual), _ptr(y), C.byref(desc), _stream()),

@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 219
+#define DLIO_ABI_VERSION 220
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);           /* "gfx950" */
@@ -171,6 +171,12 @@ int dlio_conv1x1_bx3_fwd_ws(const float* x, const void* wt, const float* bias, c
 size_t dlio_conv3x3_bx3_ws_bytes(const DlioConvDesc* desc);
 int dlio_conv3x3_bx3_fwd_ws(const float* x, const void* wt, const float* bias, const float* residual, float* y,
                             void* ws, size_t ws_bytes, const DlioConvDesc* desc, dlio_stream_t stream);
+/* y = conv3x3(x, wt) + conv1x1(x1, wt1) (+ residual) in one launch: the data gradient of a Fire block's expand pair,
+ * dS = W3^T * dE3 + W1^T dE1 (autograd's conv2d backward of pointseg_modules.py:126-133).  desc as for
+ * dlio_conv3x3_bx3_fwd_ws with PH = PW = 1 and OH x OW = H x W; x1 contiguous [N][C1][H][W]; wt / wt1 from
+ * dlio_conv_bx3_prep(taps = 9 / 1, mode 1); ws as dlio_conv3x3_bx3_ws_bytes(desc). */
+int dlio_fire_expand_dgrad(const float* x, const void* wt, const float* x1, const void* wt1, int C1, const float* residual,
+                           float* y, void* ws, size_t ws_bytes, const DlioConvDesc* desc, dlio_stream_t stream);
 size_t dlio_conv3x3_bx3_prep_floats(int Cout, int Cin, int mode);
 int dlio_conv3x3_bx3_prep(const float* w, void* wt, int Cout, int Cin, int mode, dlio_stream_t stream);
 /* every split-bf16 layout of a model in one launch (DlioPrepItem as for dlio_conv2d_prep_weights_batched;

@@ -1299,3 +1299,38 @@ def test_batchnorm_small_one_launch(dev, case, residual):
     assert not ops.bn_small_ok(17, 512) and not ops.bn_small_ok(N, 300) and not ops.bn_coop_ok(1, 8192)
     with pytest.raises((ValueError, RuntimeError)):
         ops.bn_small_fwd(torch.zeros(2, 4, 10, 30, device=dev), 4, 0, 2, 4, 4, 300, set1, None, 1e-5, 0.1, prm, None, 0, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 64, 16, 8, 64), (1, 192, 48, 12, 40), (2, 384, 80, 16, 32), (1, 70, 20, 5, 132),
+                                  (16, 256, 64, 32, 64), (16, 384, 80, 16, 32), (3, 33, 24, 9, 36)])
+def test_fire_expand_pair_data_gradient_in_one_launch(dev, case):
+    """dlio_fire_expand_dgrad: dS = W3^T * dE3 + W1^T dE1 (autograd's conv2d backward of pointseg_modules.py:126-133) with
+    the expand1x1 gradient's channels as centre-tap K chunks of the split-bf16 3x3 data-gradient kernel, against fp64 and
+    against the two separate launches (1x1, then 3x3 accumulating); channel counts off the 16 / 32 tile sizes, ragged
+    H / W, the K-split launch sizes of fire_blk4 / fire_blk5, a residual"""
+    from deeplio_amd import ops
+    N, E, S, H, W = case
+    g = _g(59)
+    s = torch.randn(N, S, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    w3 = torch.randn(E, S, 3, 3, generator=g) / (S * 9) ** 0.5
+    w1 = torch.randn(E - 3, S, 1, 1, generator=g) / S ** 0.5          # (the two layers need not have equal widths here)
+    d3 = torch.randn(N, E, H, W, generator=g)
+    d1 = torch.randn(N, E - 3, H, W, generator=g)
+    res = torch.randn(N, S, H, W, generator=g)
+    (F.conv2d(s, w3.double(), None, 1, 1) * d3.double()).sum().backward()
+    g3 = s.grad.clone()
+    s.grad = None
+    (F.conv2d(s, w1.double()) * d1.double()).sum().backward()
+    ref = g3 + s.grad + res.double()
+    wt3, wt1 = ops.conv3x3_bx3_prep(w3.to(dev), 1), ops.conv1x1_bx3_prep(w1.to(dev), 1)
+    gd = ops.conv_desc(N, E, H, W, S, 3, 3, 1, 1, 1, 1, OH=H, OW=W, res_ctot=S, res_coff=0)
+    dx = torch.empty(N, S, H, W, device=dev)
+    ops.fire_expand_dgrad(d3.to(dev), wt3, d1.to(dev), wt1, dx, gd, residual=res.to(dev))
+    assert rel_err(dx, ref) < 3e-6
+    # the two launches it replaces
+    dx2 = res.to(dev).clone()
+    ops.conv1x1_bx3_fwd(d1.to(dev), wt1, None, dx2, ops.conv_desc(N, E - 3, H, W, S, 1, 1, 1, 1, 0, 0, res_ctot=S), residual=dx2) \
+        if (H * W) % 4 == 0 else dx2.add_(F.conv2d(d1.to(dev), w1.to(dev).transpose(0, 1)))
+    ops.conv3x3_bx3_fwd(d3.to(dev), wt3, None, dx2, ops.conv_desc(N, E, H, W, S, 3, 3, 1, 1, 1, 1, OH=H, OW=W, res_ctot=S), residual=dx2)
+    assert rel_err(dx, dx2) < 2e-6
