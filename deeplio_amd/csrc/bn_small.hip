@@ -387,6 +387,138 @@ __global__ __launch_bounds__(T) void bn_coop_bwd_kernel(
   }
 }
 
+// ---- the same over bf16 storage (BASELINE configs[4], deeplio_amd/mixed.py; arithmetic as mixed_bf16.hip's two-launch
+// kernels: fp32 per element, fp64 sums, one rounding to bf16 on the way out, plane averages of the STORED values):
+// a thread holds 4 x 8 bf16 = the same 32 elements per operand
+typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
+
+template <int T>
+__global__ __launch_bounds__(T) void bn16_coop_fwd_kernel(
+    const __bf16* __restrict__ x, int x_ctot, int x_coff, int N, int C, BnSet ps, float eps, float momentum,
+    float* __restrict__ mean_o, float* __restrict__ invstd_o, float* __restrict__ scale_o, const __bf16* residual, int r_ctot,
+    int r_coff, __bf16* y, int y_ctot, int y_coff, float* __restrict__ gap_out, int gap_ctot, int gap_coff, int post_relu,
+    double* part, int* sync, int P) {
+  constexpr int CH = 32 * T;                          // elements per workgroup: 1 / P of a plane
+  const int HW = CH * P, NP = N * P;
+  __shared__ double sm[2][16];
+  __shared__ double bc[512];
+  const int items = C * NP;
+  for (int it = blockIdx.x; it < items; it += gridDim.x) {
+    const int c = it / NP, np = it - c * NP, n = np / P, po = (np - n * P) * CH;
+    const __bf16* xp = x + ((size_t)n * x_ctot + x_coff + c) * HW + po;
+    cbf16x8 v[4];
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const cbf16x8*>(xp + 8 * (threadIdx.x + T * j));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float f0 = 0.f, f1 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const float e = (float)v[j][k]; f0 += e; f1 += e * e; }
+      a += f0; b += f1;
+    }
+    block_sum2_t<T>(a, b, sm);
+    coop_exchange(a, b, part, sync, C, c, np, NP, bc);
+    const double count = (double)N * HW;
+    const double m = a / count;
+    double var = b / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    const float mu = (float)m, sc = (ps.gamma ? ps.gamma[c] : 1.f) * is, be = ps.beta ? ps.beta[c] : 0.f;
+    if (threadIdx.x == 0 && np == 0) {
+      mean_o[c] = mu; invstd_o[c] = is; scale_o[c] = sc;
+      if (ps.running_mean) ps.running_mean[c] = (1.f - momentum) * ps.running_mean[c] + momentum * mu;
+      if (ps.running_var) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        ps.running_var[c] = (1.f - momentum) * ps.running_var[c] + momentum * (float)unb;
+      }
+    }
+    const __bf16* rp = residual ? residual + ((size_t)n * r_ctot + r_coff + c) * HW + po : nullptr;
+    __bf16* yp = y + ((size_t)n * y_ctot + y_coff + c) * HW + po;
+    double gs = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      cbf16x8 rv = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (rp) rv = *reinterpret_cast<const cbf16x8*>(rp + 8 * (threadIdx.x + T * j));
+      cbf16x8 o;
+      float fs = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float t = ((float)v[j][k] - mu) * sc + be;
+        if (post_relu) t = fmaxf(t, 0.f);
+        if (rp) t += (float)rv[k];
+        o[k] = (__bf16)t;
+        fs += (float)o[k];
+      }
+      *reinterpret_cast<cbf16x8*>(yp + 8 * (threadIdx.x + T * j)) = o;
+      gs += fs;
+    }
+    if (gap_out) {
+      gs = block_sum_t<T>(gs, sm[0]);
+      if (threadIdx.x == 0) gap_out[(size_t)n * gap_ctot + gap_coff + c] = (float)(gs / (double)HW);
+    }
+    coop_depart(part, sync, c, NP);
+    __syncthreads();
+  }
+}
+
+template <int T>
+__global__ __launch_bounds__(T) void bn16_coop_bwd_kernel(
+    const __bf16* __restrict__ dy, int dy_ctot, int dy_coff, const __bf16* __restrict__ x, int x_ctot, int x_coff, int N, int C,
+    BnSet ps, const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ scale,
+    __bf16* __restrict__ dx, int dx_ctot, int dx_coff, int accumulate, int post_relu, double* part, int* sync, int P) {
+  constexpr int CH = 32 * T;
+  const int HW = CH * P, NP = N * P;
+  __shared__ double sm[2][16];
+  __shared__ double bc[512];
+  const int items = C * NP;
+  for (int it = blockIdx.x; it < items; it += gridDim.x) {
+    const int c = it / NP, np = it - c * NP, n = np / P, po = (np - n * P) * CH;
+    const float mu = mean[c], is = invstd[c], sc = scale[c], be = ps.beta ? ps.beta[c] : 0.f;
+    const __bf16* gp = dy + ((size_t)n * dy_ctot + dy_coff + c) * HW + po;
+    const __bf16* xp = x + ((size_t)n * x_ctot + x_coff + c) * HW + po;
+    cbf16x8 gv[4], xv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      gv[j] = *reinterpret_cast<const cbf16x8*>(gp + 8 * (threadIdx.x + T * j));
+      xv[j] = *reinterpret_cast<const cbf16x8*>(xp + 8 * (threadIdx.x + T * j));
+    }
+    float g[4][8];
+    double sg = 0.0, sgx = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float f0 = 0.f, f1 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float xe = (float)xv[j][k];
+        float ge = (float)gv[j][k];
+        if (post_relu && !((xe - mu) * sc + be > 0.f)) ge = 0.f;
+        g[j][k] = ge;
+        f0 += ge; f1 += ge * ((xe - mu) * is);
+      }
+      sg += f0; sgx += f1;
+    }
+    block_sum2_t<T>(sg, sgx, sm);
+    coop_exchange(sg, sgx, part, sync, C, c, np, NP, bc);
+    if (threadIdx.x == 0 && np == 0) {
+      if (ps.dbeta) ps.dbeta[c] = accumulate ? ps.dbeta[c] + (float)sg : (float)sg;
+      if (ps.dgamma) ps.dgamma[c] = accumulate ? ps.dgamma[c] + (float)sgx : (float)sgx;
+    }
+    const double inv_cnt = 1.0 / ((double)N * HW);
+    const float mg = (float)(sg * inv_cnt), mgx = (float)(sgx * inv_cnt);
+    __bf16* op = dx + ((size_t)n * dx_ctot + dx_coff + c) * HW + po;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      cbf16x8 o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = (__bf16)(sc * (g[j][k] - mg - ((float)xv[j][k] - mu) * is * mgx));
+      *reinterpret_cast<cbf16x8*>(op + 8 * (threadIdx.x + T * j)) = o;
+    }
+    coop_depart(part, sync, c, NP);
+    __syncthreads();
+  }
+}
+
 // planes the cooperative kernels take: P parts of T x 8 float4 each
 int coop_t(int N, int HW, int& P, bool whole_plane = false) {
   static const int tt = getenv("DLIO_BN_COOP_T") ? atoi(getenv("DLIO_BN_COOP_T")) : 256;      // tuning knob: 256 / 512 / 1024
@@ -537,6 +669,54 @@ extern "C" int dlio_bn_coop_bwd(const float* dy, int dy_ctot, int dy_coff, const
   const int grid = coop_grid(N * P, C, T);
 #define BNC(TT) hipLaunchKernelGGL((bn_coop_bwd_kernel<8, TT>), dim3((unsigned)grid), dim3(TT), 0, s, dy, dy_ctot, dy_coff, x, x_ctot,  \
                                    x_coff, N, C, C1, s1, s2, mean, invstd, scale, dx1, dx2, accumulate, post_relu,                    \
+                                   reinterpret_cast<double*>(part), reinterpret_cast<int*>(sync), P)
+  if (T == 1024) BNC(1024); else if (T == 512) BNC(512); else BNC(256);
+#undef BNC
+  return dlio_check_launch();
+}
+
+/* bf16 storage (csrc/mixed_bf16.hip's dlio_bn_bf16_apply / dlio_bn_bf16_bwd, train mode, one layer per launch): same
+ * geometry rule in ELEMENTS (H * W a multiple of 8192 up to 65536, 2 <= N <= 64, N * parts <= 256) */
+extern "C" int dlio_bn_bf16_coop_fwd(const void* x, int N, int x_ctot, int x_coff, int C, int HW, int post_relu,
+                                     const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                                     float* running_var, float* mean, float* invstd, float* scale, const void* residual,
+                                     int r_ctot, int r_coff, void* y, int y_ctot, int y_coff, float* gap_out, int gap_ctot,
+                                     int gap_coff, void* part, void* sync, dlio_stream_t stream) {
+  if (!x || !y || !mean || !invstd || !scale || !part || !sync || C <= 0 || N <= 0 || HW <= 0) return DLIO_EINVAL;
+  int P;
+  const int T = coop_t(N, HW, P, gap_out != nullptr);
+  if (!T) return DLIO_EUNSUP;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) return DLIO_EUNSUP;
+  hipStream_t s = as_stream(stream);
+  const BnSet ps{gamma, beta, running_mean, running_var, nullptr, nullptr};
+  DlioProfScope prof(7, s, 0.0, 2.0 * N * (double)C * HW * (residual ? 3.0 : 2.0));
+  const int grid = coop_grid(N * P, C, T);
+#define BNC(TT) hipLaunchKernelGGL((bn16_coop_fwd_kernel<TT>), dim3((unsigned)grid), dim3(TT), 0, s, reinterpret_cast<const __bf16*>(x),  \
+                                   x_ctot, x_coff, N, C, ps, eps, momentum, mean, invstd, scale,                                     \
+                                   reinterpret_cast<const __bf16*>(residual), r_ctot, r_coff, reinterpret_cast<__bf16*>(y), y_ctot,  \
+                                   y_coff, gap_out, gap_ctot, gap_coff, post_relu, reinterpret_cast<double*>(part),                 \
+                                   reinterpret_cast<int*>(sync), P)
+  if (T == 1024) BNC(1024); else if (T == 512) BNC(512); else BNC(256);
+#undef BNC
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_bn_bf16_coop_bwd(const void* dy, int dy_ctot, int dy_coff, const void* x, int x_ctot, int x_coff,
+                                     const float* mean, const float* invstd, const float* scale, const float* beta, void* dx,
+                                     int dx_ctot, int dx_coff, float* dgamma, float* dbeta, int accumulate, int N, int C,
+                                     int HW, int post_relu, void* part, void* sync, dlio_stream_t stream) {
+  if (!dy || !x || !mean || !invstd || !scale || !dx || !part || !sync || C <= 0 || N <= 0 || HW <= 0) return DLIO_EINVAL;
+  int P;
+  const int T = coop_t(N, HW, P);
+  if (!T) return DLIO_EUNSUP;
+  if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx)) & 15) return DLIO_EUNSUP;
+  hipStream_t s = as_stream(stream);
+  const BnSet ps{nullptr, beta, nullptr, nullptr, dgamma, dbeta};
+  DlioProfScope prof(9, s, 0.0, 3.0 * 2.0 * N * (double)C * HW);
+  const int grid = coop_grid(N * P, C, T);
+#define BNC(TT) hipLaunchKernelGGL((bn16_coop_bwd_kernel<TT>), dim3((unsigned)grid), dim3(TT), 0, s, reinterpret_cast<const __bf16*>(dy), \
+                                   dy_ctot, dy_coff, reinterpret_cast<const __bf16*>(x), x_ctot, x_coff, N, C, ps, mean, invstd,    \
+                                   scale, reinterpret_cast<__bf16*>(dx), dx_ctot, dx_coff, accumulate, post_relu,                   \
                                    reinterpret_cast<double*>(part), reinterpret_cast<int*>(sync), P)
   if (T == 1024) BNC(1024); else if (T == 512) BNC(512); else BNC(256);
 #undef BNC

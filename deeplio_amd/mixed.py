@@ -17,6 +17,8 @@ deeplio_amd.ops / deeplio_amd.functional.
 """
 import ctypes as C
 
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -74,11 +76,33 @@ def _partials16(ws, N, C_, HW):
     return ws[:n * 8].view(torch.float64)
 
 
+# OFF by default: measured slower than the two-launch kernels on this path (1130-1205 vs 1247 frame-pairs/s: at S = 4 a
+# channel has 32-128 cooperating workgroups and half the bytes per element, the exchange no longer pays); kept for its test
+_BN_COOP16 = [os.environ.get("DLIO_BN_COOP_BF16", "0") != "0"]
+
+
+def _coop16_ok(N, HW, want_gap):
+    """the cooperative one-launch BatchNorm kernels take this geometry (no synchronised statistics: those need the partial
+    sums between two launches)"""
+    if not _BN_COOP16[0] or not ops._BN_COOP[0] or ops._SYNC_BN[0] is not None:
+        return False
+    return bool(lib.dlio_bn_coop_gap_ok(N, HW) if want_gap else lib.dlio_bn_coop_ok(N, HW))
+
+
 def bn_apply(x, x_ctot, x_coff, gamma, beta, eps, momentum, rmean, rvar, y, y_ctot, y_coff, N, C_, HW, post_relu,
              residual=None, r_ctot=0, r_coff=0, gap_out=None, gap_ctot=0, gap_coff=0, eval_prm=None):
     """train: statistics + apply -> prm [3][C] (mean, invstd, scale); eval: apply with eval_prm.  With synchronised
     statistics (GradSync.enable_sync_bn) the per-channel partial sums are all-reduced between the two launches."""
     prm = eval_prm if eval_prm is not None else torch.empty(3, C_, dtype=torch.float32, device=x.device)
+    if eval_prm is None and _coop16_ok(N, HW, gap_out is not None):
+        # one launch, every operand read once: the workgroups that hold a channel's planes in registers exchange their
+        # partial sums (csrc/bn_small.hip, the cooperative kernels over bf16 storage)
+        part, sync_ = ops._coop_ws(N, C_, x.device)
+        check(lib.dlio_bn_bf16_coop_fwd(_ptr(x), N, x_ctot, x_coff, C_, HW, int(post_relu), _ptr(gamma), _ptr(beta),
+                                        float(eps), float(momentum), _ptr(rmean), _ptr(rvar), _ptr(prm[0]), _ptr(prm[1]),
+                                        _ptr(prm[2]), _ptr(residual), r_ctot, r_coff, _ptr(y), y_ctot, y_coff, _ptr(gap_out),
+                                        gap_ctot, gap_coff, _ptr(part), _ptr(sync_), _stream()), "bn_bf16_coop_fwd")
+        return prm
     ws = _stats_ws(N, C_, HW, x.device)
 
     def call(phase, scale):
@@ -99,6 +123,13 @@ def bn_apply(x, x_ctot, x_coff, gamma, beta, eps, momentum, rmean, rvar, y, y_ct
 
 def bn_bwd(dy, dy_ctot, dy_coff, x, x_ctot, x_coff, prm, beta, dx, dx_ctot, dx_coff, N, C_, HW, post_relu,
            use_batch_stats, dgamma=None, dbeta=None, accumulate=False):
+    if use_batch_stats and _coop16_ok(N, HW, False):
+        part, sync_ = ops._coop_ws(N, C_, x.device)
+        check(lib.dlio_bn_bf16_coop_bwd(_ptr(dy), dy_ctot, dy_coff, _ptr(x), x_ctot, x_coff, _ptr(prm[0]), _ptr(prm[1]),
+                                        _ptr(prm[2]), _ptr(beta), _ptr(dx), dx_ctot, dx_coff, _ptr(dgamma), _ptr(dbeta),
+                                        int(accumulate), N, C_, HW, int(post_relu), _ptr(part), _ptr(sync_), _stream()),
+              "bn_bf16_coop_bwd")
+        return dx
     ws = _stats_ws(N, C_, HW, x.device)
 
     def call(phase, scale, local):

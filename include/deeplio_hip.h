@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 220
+#define DLIO_ABI_VERSION 221
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);           /* "gfx950" */
@@ -533,6 +533,18 @@ int dlio_bn_coop_bwd(const float* dy, int dy_ctot, int dy_coff, const float* x, 
                      const float* beta2, float* dx1, float* dx2, float* dgamma1, float* dbeta1, float* dgamma2,
                      float* dbeta2, int accumulate, int N, int C, int C1, int HW, int post_relu, void* part,
                      void* sync, dlio_stream_t stream);
+/* the cooperative one-launch kernels over bf16 storage (train mode, one layer per launch; arithmetic and rounding as
+ * dlio_bn_bf16_apply / dlio_bn_bf16_bwd, BASELINE configs[4]); geometry rule of dlio_bn_coop_ok in elements; part / sync as
+ * for dlio_bn_coop_fwd */
+int dlio_bn_bf16_coop_fwd(const void* x, int N, int x_ctot, int x_coff, int C, int HW, int post_relu, const float* gamma,
+                          const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                          float* mean, float* invstd, float* scale, const void* residual, int r_ctot, int r_coff, void* y,
+                          int y_ctot, int y_coff, float* gap_out, int gap_ctot, int gap_coff, void* part, void* sync,
+                          dlio_stream_t stream);
+int dlio_bn_bf16_coop_bwd(const void* dy, int dy_ctot, int dy_coff, const void* x, int x_ctot, int x_coff,
+                          const float* mean, const float* invstd, const float* scale, const float* beta, void* dx,
+                          int dx_ctot, int dx_coff, float* dgamma, float* dbeta, int accumulate, int N, int C, int HW,
+                          int post_relu, void* part, void* sync, dlio_stream_t stream);
 /* Train-mode BatchNorm (+ ReLU) backward behind a 3x3 / pad 1 / stride (SH, 2) max-pool (dlio_maxpool2d_fwd_aff): both
  * launches gather the gradient of the activated tensor from the pooled gradient dy_pool [N,C,OH,OW] and the arg-max map
  * while they stream x [N,C,H,W] -- the pool's own backward pass and its output are not needed.  dx contiguous;

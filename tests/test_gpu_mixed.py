@@ -108,12 +108,16 @@ def test_conv_wgrad_bf16(dev, case):
     assert rel_err(dw2, wq.grad + base.double()) < 1e-4
 
 
-@pytest.mark.parametrize("shape", [(4, 24, 8, 64), (2, 64, 16, 32), (16, 8, 4, 16), (3, 40, 2, 8)])
+@pytest.mark.parametrize("shape", [(4, 24, 8, 64), (2, 64, 16, 32), (16, 8, 4, 16), (3, 40, 2, 8),
+                                   (4, 9, 64, 128), (32, 5, 64, 256), (2, 300, 64, 512)])
 @pytest.mark.parametrize("res,gap", [(False, False), (True, True)])
 def test_batchnorm_bf16_train_eval_backward(dev, shape, res, gap):
+    """(the 64 x 128 ... 64 x 512 planes run on the cooperative one-launch kernels of csrc/bn_small.hip: one, two and four
+    workgroups per plane, 300 channels x 2 images = several trips of the persistent grid)"""
     from deeplio_amd import mixed, ops
     N, C, H, W = shape
     HW = H * W
+    mixed._BN_COOP16[0] = H * W >= 8192            # (off in the product path: slower there; see mixed._BN_COOP16)
     x = _r(shape, 10, 2.0) + 0.5
     x = x.bfloat16().float()
     gamma, beta = 1 + 0.1 * torch.randn(C, generator=_g(11)), 0.1 * torch.randn(C, generator=_g(12))
@@ -151,6 +155,7 @@ def test_batchnorm_bf16_train_eval_backward(dev, shape, res, gap):
     mixed.bn_apply(x.to(dev).bfloat16(), C, 0, gamma.to(dev), beta.to(dev), 1e-5, 0.1, None, None, ye, C, 0, N, C, HW, True,
                    eval_prm=ops.bn_eval_params(rmh, rvh, gamma.to(dev), 1e-5))
     assert rel_err(ye.float(), refe) < BF16_TOL
+    mixed._BN_COOP16[0] = False
 
 
 @pytest.mark.parametrize("shape,sh", [((2, 6, 8, 32), 1), ((3, 4, 8, 64), 2), ((1, 16, 16, 16), 2), ((2, 3, 4, 48), 1)])
