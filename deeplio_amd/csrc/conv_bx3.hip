@@ -17,6 +17,7 @@
 // Replaces nn.Conv2d forward / input-gradient for the 3x3 stride-1 layers (pointseg_modules.py:100-106
 // expand3x3, resnet.py BasicBlock, base_net.py:55-71 conv3_1 / conv4_1 / conv5_1).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -600,6 +601,280 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_alds_kernel(
     }
 }
 
+// ---- 3x3 stride 1, producer / consumer workgroups ---------------------------------------------------
+// conv3x3_bx3_alds_kernel stages a chunk's patch (gather + split: ~350 VALU per thread) BETWEEN the MFMA phases of its four
+// waves, and its prologue / epilogue are only covered by the other workgroup of the CU (MFMA busy 50 %).  Here ONE persistent
+// workgroup of eight waves per CU splits the roles: waves 0-3 do nothing but LDS reads + MFMAs (a wave = a row of the 4 x 64
+// x 32 MR tile), waves 4-7 stage the NEXT chunk -- global loads in group 0, split + LDS store of their two positions in
+// groups 1 and 2 -- into the second patch buffer and feed the weight ring (buffer_load ... lds), so VALU staging and MFMA
+// issue run side by side on every SIMD, across chunk AND tile boundaries (the producers are one chunk ahead, the first
+// chunk of the next tile included).  One barrier per weight group for all eight waves, none extra per chunk.  LDS: 2 patch
+// buffers + the two-slot ring = 112 KB.  For the long-K data gradients of fire_blk1-3 (the epilogue is small: S = 16-80
+// output channels); tile list as fire_expand's XCD-contiguous order.
+// Measured (tools/bench_dgrad3.py, N = 16): 117 / 141 / 153 / 193 us against 127 / 150 / 158 / 203 on the alds kernel, step
+// 22.45 vs 22.65 ms.  Timing ablations: the consumers ALONE (no producer work, no memory traffic) take 95 / 102 / 120 / 152
+// us = 48-60 % of the bare MFMA time -- one MFMA wave per SIMD, a barrier every three taps, LDS fragment reads behind it:
+// the loop that feeds the matrix cores, not the staging, is what is left.
+template <int MR>
+__global__ __launch_bounds__(512) void conv3x3_bx3_pc_kernel(
+    const float* __restrict__ x, const __bf16* __restrict__ wt, const float* __restrict__ bias, const float* residual, float* y,
+    DlioConvDesc d, int tiles_w, int tiles_h, int co_tiles, int total_tiles) {
+  constexpr int TWN = 2, TH = 4, TW = 64, PR = TH + 2, PC = TW + 2, NPOSP = PR * PC;
+  constexpr int NPOS = (NPOSP + 255) / 256;              // 2 patch positions per producer thread
+  constexpr int PLANE = NPOSP * 16;
+  constexpr int PBUF = 3 * PLANE;                        // bf16 per patch buffer
+  constexpr int TG = 3;
+  constexpr int AROWS = 32 * MR;
+  constexpr int AGRP = TG * 3 * AROWS * 16;
+  constexpr int AINS = TG * 3 * MR;
+  static_assert(NPOS == 2, "two positions per producer thread");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* patch0 = reinterpret_cast<__bf16*>(smem_raw);  // [2][3 planes][NPOSP][16]
+  __bf16* ring = patch0 + 2 * PBUF;                      // [2][AGRP]
+
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave >= 4;
+  const int pw = wave & 3, ptid = tid & 255;
+  const int Cin = d.Cin, Cout = d.Cout, HW = d.H * d.W;
+  const int KC = (Cin + 15) >> 4;
+
+  // ---- tile list of this workgroup
+  const int G = gridDim.x, bx = blockIdx.x & 7, bj = blockIdx.x >> 3, Gx = (G - bx + 7) >> 3;
+  const int per = (total_tiles + 7) >> 3;
+  const int base = bx * per, cnt = min(per, total_tiles - base);
+  struct Cur { int l, n, oh0, ow0, co0; bool ok; };
+  auto set_tile = [&](Cur& c) {
+    c.ok = c.l < cnt;
+    int v = base + (c.ok ? c.l : 0);
+    const int cot = v % co_tiles; v /= co_tiles;
+    const int tw = v % tiles_w; v /= tiles_w;
+    const int th = v % tiles_h;
+    c.n = v / tiles_h; c.oh0 = th * TH; c.ow0 = tw * TW; c.co0 = cot * 32 * MR;
+  };
+  Cur cur;
+  cur.l = bj;
+  set_tile(cur);
+  if (!cur.ok) return;
+
+  const size_t wplane = (size_t)Cout * 16;
+  const int nchunks_total = KC;                          // per tile
+
+  if (producer) {
+    // ================================================================ producers
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(wt), 0, (int)((size_t)9 * KC * 3 * wplane * 2), 0x00020000);
+    const int RW = (AINS - pw + 3) / 4;                  // ring instructions of this wave per group
+    auto load_agroup = [&](const Cur& c, int kc, int g, int slot) {
+#pragma unroll
+      for (int i = 0; i < (AINS + 3) / 4; ++i) {
+        const int t = i * 4 + pw;
+        if (t < AINS) {
+          const int m = t % MR, tp = t / MR, tap = g * TG + tp / 3, pl = tp - 3 * (tp / 3);
+          const unsigned awoff = ((unsigned)min(c.co0 + m * 32 + (lane >> 1), Cout - 1) * 16u + 8u * (unsigned)(lane & 1)) * 2u;
+          __bf16* dst = ring + (size_t)slot * AGRP + (size_t)t * 64 * 8;
+#if defined(__HIP_DEVICE_COMPILE__)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, awoff,
+                                                   (unsigned)((((size_t)tap * KC + kc) * 3 + pl) * wplane * 2), 0, 0);
+#else
+          (void)dst; (void)awoff; (void)tap; (void)pl;
+#endif
+        }
+      }
+    };
+    float reg[NPOS][16];
+    bool pval[NPOS];
+    int poff[NPOS];
+    const float* xn = nullptr;
+    auto tile_geometry = [&](const Cur& c) {
+#pragma unroll
+      for (int j = 0; j < NPOS; ++j) {
+        const int pos = ptid + j * 256;
+        const int r = pos / PC, cc = pos - r * PC;
+        const int ih = c.oh0 - d.PH + r, iw = c.ow0 - d.PW + cc;
+        pval[j] = pos < NPOSP && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W;
+        poff[j] = pval[j] ? ih * d.W + iw : 0;
+      }
+      xn = x + ((size_t)c.n * d.in_ctot + d.in_coff) * HW;
+    };
+    auto load_patch = [&](int kc) {                      // position-major: position 0's sixteen loads are the older ones
+#pragma unroll
+      for (int j = 0; j < NPOS; ++j)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) reg[j][c] = xn[(size_t)min(kc * 16 + c, Cin - 1) * HW + poff[j]];
+    };
+    auto store_pos = [&](__bf16* buf, int kc, int j) {
+      const int pos = ptid + j * 256;
+      if (pos < NPOSP) {
+        bf16x8 ph[2], pm[2], pl[2];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const float v = (kc * 16 + c < Cin && pval[j]) ? reg[j][c] : 0.f;
+          __bf16 h, m, l;
+          split3(v, h, m, l);
+          ph[c >> 3][c & 7] = h; pm[c >> 3][c & 7] = m; pl[c >> 3][c & 7] = l;
+        }
+        bf16x8* dst = reinterpret_cast<bf16x8*>(buf + pos * 16);
+        dst[0] = ph[0]; dst[1] = ph[1];
+        dst = reinterpret_cast<bf16x8*>(buf + PLANE + pos * 16);
+        dst[0] = pm[0]; dst[1] = pm[1];
+        dst = reinterpret_cast<bf16x8*>(buf + 2 * PLANE + pos * 16);
+        dst[0] = pl[0]; dst[1] = pl[1];
+      }
+    };
+    // prologue: first weight group, first patch
+    tile_geometry(cur);
+    load_agroup(cur, 0, 0, 0);
+    load_patch(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    store_pos(patch0, 0, 0);
+    store_pos(patch0, 0, 1);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    int q = 0, gi = 0;
+    while (cur.ok) {
+      for (int kc = 0; kc < KC; ++kc, ++q) {
+        // the chunk the producers stage while the consumers are on (cur, kc)
+        Cur nx = cur;
+        int nkc = kc + 1;
+        if (nkc == KC) { nkc = 0; nx.l += Gx; set_tile(nx); }
+        const bool have = nx.ok;
+        __bf16* nbuf = patch0 + (size_t)((q + 1) & 1) * PBUF;
+        // ---- group 0: ring(g = 1), the next chunk's patch loads
+        load_agroup(cur, kc, 1, (gi + 1) & 1);
+        if (have) {
+          if (nkc == 0) tile_geometry(nx);
+          load_patch(nkc);
+          asm volatile("s_waitcnt vmcnt(32)" ::: "memory");            // the ring pieces landed, the patch loads fly
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_barrier" ::: "memory");
+        ++gi;
+        // ---- group 1: ring(g = 2), split + store position 0
+        load_agroup(cur, kc, 2, (gi + 1) & 1);
+        if (have) {
+          if (RW == 5) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
+          else if (RW == 4) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+          else if (RW == 3) asm volatile("s_waitcnt vmcnt(19)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+          store_pos(nbuf, nkc, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        ++gi;
+        // ---- group 2: ring of the next chunk's group 0, split + store position 1
+        if (have) {
+          load_agroup(nx, nkc, 0, (gi + 1) & 1);
+          store_pos(nbuf, nkc, 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        ++gi;
+        if (nkc == 0) { cur = nx; }
+      }
+    }
+    return;
+  }
+
+  // ================================================================== consumers
+  f32x16 acc[MR][TWN];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+      for (int t = 0; t < TWN; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+  };
+  zero_acc();
+  auto read_a = [&](const __bf16* slot, int tl, bf16x8 (&a)[MR][3]) {
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        a[m][p] = *reinterpret_cast<const bf16x8*>(slot + ((tl * 3 + p) * AROWS + m * 32 + l31) * 16 + 8 * half);
+  };
+  auto compute_group = [&](const __bf16* patch, const __bf16* slot, int g) {
+    bf16x8 a[2][MR][3];
+    read_a(slot, 0, a[0]);
+#pragma unroll
+    for (int tl = 0; tl < TG; ++tl) {
+      const int tap = g * TG + tl, kh = tap / 3, kw = tap - 3 * kh;
+      if (tl + 1 < TG) read_a(slot, tl + 1, a[(tl + 1) & 1]);
+      bf16x8 b[TWN][3];
+#pragma unroll
+      for (int t = 0; t < TWN; ++t) {
+        const int pos = (wave + kh) * PC + 32 * t + l31 + kw;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          b[t][p] = *reinterpret_cast<const bf16x8*>(patch + p * PLANE + pos * 16 + 8 * half);
+      }
+      const auto& aa = a[tl & 1];
+      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+          for (int t = 0; t < TWN; ++t)
+            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[m][PA[q]], b[t][PB[q]], acc[m][t], 0, 0, 0);
+    }
+  };
+  auto epilogue = [&](const Cur& c) {
+    // D tile col = pixel (lane & 31), row = (r & 3) + 8 (r >> 2) + 4 half; DPP quad transposes -> 16-byte stores (fire_expand)
+    const int oh = c.oh0 + wave;
+    const size_t ohw = (size_t)d.OH * d.OW;
+    if (oh < d.OH) {
+      const bool o1 = (lane & 1) != 0, o2 = (lane & 2) != 0;
+      auto swz = [](float v, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, true));
+      };
+      using X1 = std::integral_constant<int, 0xB1>;
+      using X2 = std::integral_constant<int, 0x4E>;
+      const size_t pix = (size_t)oh * d.OW + c.ow0 + 4 * (l31 >> 2);
+      float* yb = y + ((size_t)c.n * d.out_ctot + d.out_coff) * ohw + pix;
+      const float* rb = residual ? residual + ((size_t)c.n * d.res_ctot + d.res_coff) * ohw + pix : nullptr;
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int t = 0; t < TWN; ++t)
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            float a0 = acc[m][t][4 * rq], a1 = acc[m][t][4 * rq + 1], a2 = acc[m][t][4 * rq + 2], a3 = acc[m][t][4 * rq + 3];
+            { const float xx = o1 ? a0 : a1, yv = swz(xx, X1{}); a0 = o1 ? yv : a0; a1 = o1 ? a1 : yv; }
+            { const float xx = o1 ? a2 : a3, yv = swz(xx, X1{}); a2 = o1 ? yv : a2; a3 = o1 ? a3 : yv; }
+            { const float xx = o2 ? a0 : a2, yv = swz(xx, X2{}); a0 = o2 ? yv : a0; a2 = o2 ? a2 : yv; }
+            { const float xx = o2 ? a1 : a3, yv = swz(xx, X2{}); a1 = o2 ? yv : a1; a3 = o2 ? a3 : yv; }
+            const int co = c.co0 + 32 * m + 8 * rq + 4 * half + (lane & 3);
+            if (co < Cout && c.ow0 + 32 * t + 4 * (l31 >> 2) < d.OW) {
+              const float bv = bias ? bias[co] : 0.f;
+              float4 o = make_float4(a0 + bv, a1 + bv, a2 + bv, a3 + bv);
+              if (rb) {
+                const float4 rv = *reinterpret_cast<const float4*>(rb + (size_t)co * ohw + 32 * t);
+                o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+              }
+              *reinterpret_cast<float4*>(yb + (size_t)co * ohw + 32 * t) = o;
+            }
+          }
+    }
+    zero_acc();
+  };
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // the producers' prologue
+  int q = 0, gi = 0;
+  while (cur.ok) {
+    for (int kc = 0; kc < KC; ++kc, ++q) {
+      const __bf16* patch = patch0 + (size_t)(q & 1) * PBUF;
+#pragma unroll
+      for (int g = 0; g < 3; ++g, ++gi) {
+        compute_group(patch, ring + (size_t)(gi & 1) * AGRP, g);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+    }
+    epilogue(cur);
+    cur.l += Gx;
+    set_tile(cur);
+  }
+  (void)nchunks_total;
+}
+
 // ---- 1x1 convolution on the same scheme, no LDS (the float4 structure of conv1x1_v4_kernel in
 // conv_fwd.hip): a wave owns 128 consecutive pixels, lane l the four pixels 4l..4l+3; per 16-channel
 // chunk a lane loads the float4 of 8 channels (8*half + j), component e of those eight is the
@@ -818,6 +1093,21 @@ int launch_bx3_alds(const float* x, const __bf16* wt, const float* bias, const f
   if (slab && !vec_out) return DLIO_EUNSUP;              // (the caller only splits when the float4 store path applies)
   hipLaunchKernelGGL((conv3x3_bx3_alds_kernel<MR, TWN>), dim3((unsigned)blocks), dim3(256), lds, s, x, wt, bias, residual, y,
                      d, tiles_w, tiles_h, co_tiles, vec_out, ksplit, slab, x1, wt1, C1);
+  return dlio_check_launch();
+}
+
+template <int MR>
+int launch_bx3_pc(const float* x, const __bf16* wt, const float* bias, const float* residual, float* y, const DlioConvDesc& d,
+                  hipStream_t s) {
+  const int tiles_w = cdiv(d.OW, 64), tiles_h = cdiv(d.OH, 4), co_tiles = cdiv(d.Cout, 32 * MR);
+  const int64_t tiles = (int64_t)d.N * tiles_h * tiles_w * co_tiles;
+  if (tiles <= 0 || tiles > 0x7fffffff) return DLIO_EINVAL;
+  constexpr size_t lds = (size_t)2 * 3 * 6 * 66 * 16 * sizeof(__bf16) + (size_t)2 * 3 * 3 * 32 * MR * 16 * sizeof(__bf16);
+  dlio_set_max_lds(reinterpret_cast<const void*>(&conv3x3_bx3_pc_kernel<MR>), (int)lds);
+  const int64_t slots = dlio_num_cus();
+  const int grid = (int)(tiles < slots ? tiles : slots);
+  hipLaunchKernelGGL((conv3x3_bx3_pc_kernel<MR>), dim3((unsigned)grid), dim3(512), lds, s, x, wt, bias, residual, y, d, tiles_w,
+                     tiles_h, co_tiles, (int)tiles);
   return dlio_check_launch();
 }
 
@@ -1077,6 +1367,17 @@ static int bx3_3x3_run(const float* x, const void* wt, const float* bias, const 
                      ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(ws)) & 15)))
     ksplit = 1;
   if (ksplit > 1) { mr = mrs; twn = twns; use_alds = true; }
+  // producer / consumer kernel: long channel loops on large maps (the data gradients of fire_blk1-3)
+  static const int pc_on = getenv("DLIO_BX3_PC") ? atoi(getenv("DLIO_BX3_PC")) : 1;
+  constexpr int pc_kc = 4;              // chunks of 16 input channels from which the producer / consumer split pays
+  if (pc_on && !x1 && ksplit == 1 && use_alds && d.PH == 1 && d.PW == 1 && d.OH == d.H && d.OW == d.W && d.OW >= 64 &&
+      (d.OW & 3) == 0 && (d.Cin + 15) / 16 >= pc_kc &&
+      ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0 &&
+      (int64_t)d.N * cdiv(d.OH, 4) * cdiv(d.OW, 64) * cdiv(d.Cout, d.Cout <= 32 ? 32 : 64) >= 2 * (int64_t)dlio_num_cus()) {
+    const int rcp = d.Cout <= 32 ? launch_bx3_pc<1>(x, w, bias, residual, y, d, s) : launch_bx3_pc<2>(x, w, bias, residual, y, d, s);
+    dlio_prof_end(3, s);
+    return rcp;
+  }
   float* slab = ksplit > 1 ? reinterpret_cast<float*>(ws) : nullptr;
 #define L3(MRV, TWV) (use_alds ? launch_bx3_alds<MRV, TWV>(x, w, bias, residual, y, d, s, ksplit, slab, x1, w1, C1) \
                                : launch_bx3<MRV, TWV>(x, w, bias, residual, y, d, s))
