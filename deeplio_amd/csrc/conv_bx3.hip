@@ -614,7 +614,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_alds_kernel(
 // Measured (tools/bench_dgrad3.py, N = 16): 117 / 141 / 153 / 193 us against 127 / 150 / 158 / 203 on the alds kernel, step
 // 22.45 vs 22.65 ms.  Timing ablations: the consumers ALONE (no producer work, no memory traffic) take 95 / 102 / 120 / 152
 // us = 48-60 % of the bare MFMA time -- one MFMA wave per SIMD, a barrier every three taps, LDS fragment reads behind it:
-// the loop that feeds the matrix cores, not the staging, is what is left.
+// the loop that feeds the matrix cores, not the staging, is what is left.  Tried on it, no gain: the barrier moved to the
+// middle of the group with a three-slot ring (129 / 147 / 156 / 194 us), a second accumulator set for the 32-channel tile
+// (118 / 139); with the LDS fragment reads removed as well the consumers take 81 / 86 / 109 / 139 us -- the MFMA issue
+// time itself at the clocks the chip holds under this load.
 template <int MR>
 __global__ __launch_bounds__(512) void conv3x3_bx3_pc_kernel(
     const float* __restrict__ x, const __bf16* __restrict__ wt, const float* __restrict__ bias, const float* residual, float* y,
