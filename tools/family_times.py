@@ -10,8 +10,7 @@ import sqlite3
 import sys
 
 FAMILIES = [
-    ("conv3x3 fwd+dgrad (split-bf16 MFMA; fused Fire expand pair)", ("conv3x3_bx3_kernel", "conv3x3_bx3_alds_kernel", "conv3x3_bf16",
-                                                                     "fire_expand_fwd_kernel")),
+    ("conv3x3 fwd+dgrad (split-bf16 MFMA; fused Fire expand pair)", ("conv3x3_bx3_", "conv3x3_bf16", "fire_expand_fwd_kernel")),
     ("stem conv fwd (fp32 MFMA)", ("conv_fwd_kernel",)),
     ("conv1x1 fwd+dgrad", ("conv1x1_",)),
     ("conv3x3 wgrad", ("wgrad3_kernel", "conv_wgrad_adirect")),

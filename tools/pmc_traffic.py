@@ -17,7 +17,7 @@ import sys
 
 FAMILIES = {
     "conv2d_fwd_mfma": ("conv_fwd_kernel",),
-    "conv3x3_bx3": ("conv3x3_bx3_kernel", "conv3x3_bx3_alds_kernel", "fire_expand_fwd_kernel"),
+    "conv3x3_bx3": ("conv3x3_bx3_", "fire_expand_fwd_kernel"),
     "conv2d_1x1": ("conv1x1_",),
     "conv2d_wgrad_mfma": ("conv_wgrad_kernel",),
     "wgrad3x3": ("wgrad3_kernel", "conv_wgrad_adirect"),
