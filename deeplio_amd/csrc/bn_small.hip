@@ -205,13 +205,20 @@ __device__ __forceinline__ void coop_exchange(double& a, double& b, double* part
   a = ta; b = tb;
 }
 
-__device__ __forceinline__ void coop_depart(double* part, int* sync, int c, int N) {
+constexpr int COOP_MAX_NP = 256;          // cooperating workgroups per channel (N * parts); the slot regions are sized for it
+
+__device__ __forceinline__ void coop_depart(double* part, int* sync, int c, int N, int gapC = 0) {
   // every partner has gathered before it departs (its loads returned before the barrier behind the exchange): the last
   // one out empties the channel's slots and clears the counter for the next launch
+  // (gapC = C when the parts of a plane exchanged their plane sums through the third slot region: emptied as well)
   if (threadIdx.x == 0) {
     const int d = __hip_atomic_fetch_add(sync + c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (d == N - 1) {
       unsigned long long* slots = reinterpret_cast<unsigned long long*>(part) + (size_t)c * N * 2;
+      if (gapC) {
+        unsigned long long* gsl = reinterpret_cast<unsigned long long*>(part) + (size_t)gapC * COOP_MAX_NP * 2 + (size_t)c * N;
+        for (int k = 0; k < N; ++k) __hip_atomic_store(gsl + k, COOP_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       for (int k = 0; k < 2 * N; ++k) __hip_atomic_store(slots + k, COOP_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(sync + c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -317,11 +324,26 @@ __global__ __launch_bounds__(T) void bn_coop_fwd_kernel(
       *reinterpret_cast<float4*>(yp + 4 * (threadIdx.x + T * j)) = make_float4(e[0], e[1], e[2], e[3]);
       gs += (double)((e[0] + e[1]) + (e[2] + e[3]));
     }
-    if (gap_out) {                                   // (P == 1; uniform: the barriers inside are taken by everyone)
+    if (gap_out) {                                   // (uniform: the barriers inside are taken by everyone)
       gs = block_sum_t<T>(gs, sm[0]);
-      if (threadIdx.x == 0) gap_out[(size_t)n * gap_ctot + gap_coff + c] = (float)(gs / (double)HW);
+      if (P == 1) {
+        if (threadIdx.x == 0) gap_out[(size_t)n * gap_ctot + gap_coff + c] = (float)(gs / (double)HW);
+      } else if (threadIdx.x < 64) {
+        // the P parts of a plane: each publishes its sum in its own slot (third slot region), the first part of the image
+        // gathers them -- lanes side by side, added in part order -- and writes the plane average
+        unsigned long long* gsl = reinterpret_cast<unsigned long long*>(part) + (size_t)C * COOP_MAX_NP * 2 + (size_t)c * NP + n * P;
+        if (threadIdx.x == 0)
+          __hip_atomic_store(gsl + (np - n * P), __builtin_bit_cast(unsigned long long, gs), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (np == n * P) {
+          double pv = 0.0;
+          if ((int)threadIdx.x < P) pv = __builtin_bit_cast(double, coop_poll(gsl + threadIdx.x, sync + C));
+          double t = 0.0;
+          for (int k = 0; k < P; ++k) t += __shfl(pv, k);
+          if (threadIdx.x == 0) gap_out[(size_t)n * gap_ctot + gap_coff + c] = (float)(t / (double)HW);
+        }
+      }
     }
-    coop_depart(part, sync, c, NP);
+    coop_depart(part, sync, c, NP, (gap_out && P > 1) ? C : 0);
     __syncthreads();                                 // bc / sm are reused by the next item
   }
 }
@@ -533,7 +555,7 @@ int coop_t(int N, int HW, int& P, bool whole_plane = false) {
   while (T > 256 && HW % (32 * T)) T >>= 1;
   if (HW % (32 * T)) return 0;
   P = HW / (32 * T);
-  return N * P <= 256 ? T : 0;
+  return N * P <= COOP_MAX_NP ? T : 0;
 }
 
 // CUs' worth of wave slots one cooperative launch may hold: two launches (the two encoder streams) must always fit the
@@ -616,7 +638,7 @@ extern "C" int dlio_bn_coop_gap_ok(int N, int HW) { int P; return coop_t(N, HW, 
 
 extern "C" size_t dlio_bn_coop_ws_bytes(int N, int C) {
   if (N <= 0 || C <= 0) return 0;
-  return (size_t)C * 256 * 2 * sizeof(double);        // (N * parts <= 256 slots pairs per channel)
+  return (size_t)C * COOP_MAX_NP * 3 * sizeof(double);   // per channel: N * parts <= 256 slot pairs + as many plane-sum slots
 }
 
 extern "C" unsigned long long dlio_bn_coop_empty(void) { return COOP_EMPTY; }
@@ -631,7 +653,7 @@ extern "C" int dlio_bn_coop_fwd(const float* x, int N, int x_ctot, int x_coff, i
   if (!x || !y || !mean || !invstd || !scale || !part || !sync || C <= 0 || C1 < 0 || C1 > C || N <= 0 || HW <= 0)
     return DLIO_EINVAL;
   int P;
-  const int T = coop_t(N, HW, P, gap_out != nullptr);
+  const int T = coop_t(N, HW, P);
   if (!T) return DLIO_EUNSUP;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) return DLIO_EUNSUP;
   hipStream_t s = as_stream(stream);

@@ -543,8 +543,9 @@ def bn_coop_set_cus(cus):
 
 
 def bn_coop_gap_ok(N, HW):
-    """the cooperative forward kernel can deliver plane averages (gap_out) for this geometry"""
-    return bn_coop_ok(N, HW) and bool(lib.dlio_bn_coop_gap_ok(N, HW))
+    """the cooperative forward kernel can deliver plane averages (gap_out) for this geometry (fp32: any it takes -- the
+    parts of a plane exchange their sums; the bf16 kernels ask dlio_bn_coop_gap_ok)"""
+    return bn_coop_ok(N, HW)
 
 
 def _coop_ws(N, C_, device):

@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 221
+#define DLIO_ABI_VERSION 222
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);           /* "gfx950" */
@@ -510,7 +510,8 @@ int dlio_bn_small_bwd(const float* dy, int dy_ctot, int dy_coff, const float* x,
  * use: a slot is its own arrival flag) and per-channel departure counters in `sync` ([C + 1] ints, zero before the first
  * use); the kernels restore both; sync[C] != 0 afterwards = a spin limit was hit, results invalid.  One launch, each element read once (dlio_bn_train_apply reads twice, dlio_bn_bwd's two launches five times
  * against three).  A plane may be cut into dlio_bn_coop_parts(N, H * W) workgroups (N * parts <= 256 slots pairs per channel;
- * with gap_out the plane stays in one workgroup: dlio_bn_coop_gap_ok).  2 <= N <= 64, H * W a multiple of 8192 up to 65536 (dlio_bn_coop_ok), else DLIO_EUNSUP.  Arguments as
+ * with gap_out the parts of a plane exchange their plane sums through a third slot region of `part`; the bf16 kernels keep
+ * the plane in one workgroup then: dlio_bn_coop_gap_ok).  2 <= N <= 64, H * W a multiple of 8192 up to 65536 (dlio_bn_coop_ok), else DLIO_EUNSUP.  Arguments as
  * dlio_bn_small_fwd / _bwd (no statistics-only mode: y required).  The launch is a persistent grid of at most ~half the
  * chip, so that two of them (two streams) can always be resident together; do not run more than two concurrently. */
 int dlio_bn_coop_ok(int N, int HW);
@@ -518,7 +519,7 @@ int dlio_bn_coop_ok(int N, int HW);
  * chip together).  Data-parallel runs lower it to leave room for the RCCL kernels that spin beside them. */
 int dlio_bn_coop_set_cus(int cus);
 int dlio_bn_coop_parts(int N, int HW);
-int dlio_bn_coop_gap_ok(int N, int HW);        /* gap_out: the plane in one workgroup, H * W in {8192, 16384, 32768} */
+int dlio_bn_coop_gap_ok(int N, int HW);        /* bf16 kernels with gap_out: the plane in one workgroup, H * W in {8192, 16384, 32768} */
 size_t dlio_bn_coop_ws_bytes(int N, int C);      /* bytes of `part` */
 unsigned long long dlio_bn_coop_empty(void);
 int dlio_bn_coop_fwd(const float* x, int N, int x_ctot, int x_coff, int C, int C1, int HW, int post_relu,
