@@ -448,6 +448,7 @@ def conv_dgrad(dy, weight, d, dx, dx_ctot, dx_coff, residual=None, r_ctot=0, r_c
 
 _CONV_BX3 = [os.environ.get("DLIO_CONV_BX3", "1") != "0"]
 _FIRE_FUSED = [os.environ.get("DLIO_FIRE_FUSED", "1") != "0"]
+_SE_FC = [os.environ.get("DLIO_SE_FC", "1") != "0"]         # the SELayer's fc pair as one launch (csrc/se_fc.hip)
 _SE_POOLED_DOT = [os.environ.get("DLIO_SE_POOLED_DOT", "1") != "0"]   # SELayer scale gradient from pooled tensors
 _BN_COOP_FWD = [True]          # cooperative kernels in the forward pass too (a module switch for ablations)
 # both expand data gradients in one launch (dlio_fire_expand_dgrad): built, tested, OFF -- the expand1x1 chunks pay the full
@@ -674,6 +675,7 @@ class FireFn(Function):
     @staticmethod
     def forward(ctx, x, sw, sb, sg, sbe, srm, srv, e1w, e1b, e1g, e1be, e1rm, e1rv, e3w, e3b, e3g,
                 e3be, e3rm, e3rv, training, momentum, eps, bypass, want_gap=False, x_aff=None, defer=False):
+        ctx.set_materialize_grads(False)     # the by-products (plane averages, affine table) get no gradient: no zero fills
         x = x.contiguous()
         N, Cin, H, W = x.shape
         S_, E1, E3 = sw.shape[0], e1w.shape[0], e3w.shape[0]
@@ -890,8 +892,11 @@ class SEPoolFn(Function):
         x = x.contiguous()
         N, C_, H, W = x.shape
         g = gap if gap is not None else ops.gap_fwd(x, N, C_, 0, C_, H * W)
-        h = ops.linear_fwd(g, w1, None, ops.ACT_RELU)
-        s = ops.linear_fwd(h, w2, None, ops.ACT_SIGMOID)
+        if _SE_FC[0] and x.is_cuda and w1.is_contiguous() and w2.is_contiguous() and ops.se_fc_ok(N, C_, w1.shape[0]):
+            h, s = ops.se_fc_fwd(g.contiguous(), w1, w2)       # both layers + activations in one launch (se_fc.hip)
+        else:
+            h = ops.linear_fwd(g, w1, None, ops.ACT_RELU)
+            s = ops.linear_fwd(h, w2, None, ops.ACT_SIGMOID)
         if pool is None:
             y, idx = ops.chan_scale_fwd(x, s), None
         else:
@@ -925,12 +930,20 @@ class SEPoolFn(Function):
             else:
                 dxs = ops.maxpool2d_bwd(dy, idx, tuple(x.shape), k, stride[0], stride[1], pad[0], pad[1])
                 dx, ds = ops.chan_scale_bwd(dxs, x, s)
-        dz2 = ops.act_bwd(ds, s, ops.ACT_SIGMOID)
         dw2, acc2, ret2 = _sink(w2, w2.shape, dy)
+        dw1, acc1, ret1 = _sink(w1, w1.shape, dy)
+        if (_SE_FC[0] and fused and dy.is_cuda and acc1 == acc2 and w1.is_contiguous() and w2.is_contiguous()
+                and ops.se_fc_ok(N, C_, w1.shape[0])):
+            # sigmoid', W2^T, relu', W1^T and the 1 / (H W) of the plane average's gradient in one launch, both weight
+            # gradients in a second one (instead of seven dense launches)
+            dgs = ops.se_fc_bwd(ds.contiguous(), s, h, g, w1, w2, dw1, dw2, acc1, 1.0 / (H * W))
+            k, stride, pad = ctx.pool
+            dx = ops.maxpool2d_bwd(dy, idx, tuple(x.shape), k, stride[0], stride[1], pad[0], pad[1], x_scale=s, x_add=dgs)
+            return dx, ret1, ret2, None, None
+        dz2 = ops.act_bwd(ds, s, ops.ACT_SIGMOID)
         ops.linear_bwd_weight(dz2, h, N, w2.shape[0], w2.shape[1], dw=dw2, want_bias=False, accumulate=acc2)
         dh = ops.linear_bwd_data(dz2, w2, N)
         dz1 = ops.act_bwd(dh, h, ops.ACT_RELU)
-        dw1, acc1, ret1 = _sink(w1, w1.shape, dy)
         ops.linear_bwd_weight(dz1, g, N, w1.shape[0], w1.shape[1], dw=dw1, want_bias=False, accumulate=acc1)
         dg = ops.linear_bwd_data(dz1, w1, N)
         if fused:

@@ -271,6 +271,7 @@ class FireFn(Function):
     @staticmethod
     def forward(ctx, x, sw, sb, sg, sbe, srm, srv, e1w, e1b, e1g, e1be, e1rm, e1rv, e3w, e3b, e3g, e3be, e3rm, e3rv,
                 training, momentum, eps, bypass, want_gap=False):
+        ctx.set_materialize_grads(False)     # the plane averages get no gradient: no zero fill in backward
         x = x.contiguous()
         N, Cin, H, W = x.shape
         S_, E1, E3 = sw.shape[0], e1w.shape[0], e3w.shape[0]

@@ -774,6 +774,33 @@ def plane_dot(a, b, div=None):
     return out
 
 
+def se_fc_ok(N, C_, R):
+    """the SELayer's two fully connected layers have the one-launch kernels for this geometry"""
+    return bool(lib.dlio_se_fc_ok(N, C_, R))
+
+
+def se_fc_fwd(g, w1, w2):
+    """g [N, C] plane averages -> (h [N, R] = relu(g w1^T), s [N, C] = sigmoid(h w2^T)) in one launch"""
+    N, C_ = g.shape
+    R = w1.shape[0]
+    h = torch.empty(N, R, dtype=torch.float32, device=g.device)
+    s = torch.empty(N, C_, dtype=torch.float32, device=g.device)
+    check(lib.dlio_se_fc_fwd(_ptr(g), _ptr(w1), _ptr(w2), _ptr(h), _ptr(s), N, C_, R, _stream()), "se_fc_fwd")
+    return h, s
+
+
+def se_fc_bwd(ds, s, h, g, w1, w2, dw1, dw2, accumulate, dg_scale=1.0):
+    """backward of se_fc_fwd in two launches: -> dg [N, C] (times dg_scale); dw1 / dw2 written or accumulated"""
+    N, C_ = g.shape
+    R = w1.shape[0]
+    dz2 = torch.empty(N, C_, dtype=torch.float32, device=g.device)
+    dz1 = torch.empty(N, R, dtype=torch.float32, device=g.device)
+    dg = torch.empty(N, C_, dtype=torch.float32, device=g.device)
+    check(lib.dlio_se_fc_bwd(_ptr(ds), _ptr(s), _ptr(h), _ptr(g), _ptr(w1), _ptr(w2), _ptr(dz2), _ptr(dz1), _ptr(dg),
+                             float(dg_scale), _ptr(dw1), _ptr(dw2), int(accumulate), N, C_, R, _stream()), "se_fc_bwd")
+    return dg
+
+
 def gap_fwd(x, N, ctot, coff, C_, HW):
     out = torch.empty(N, C_, dtype=torch.float32, device=x.device)
     check(lib.dlio_gap_fwd(_ptr(x), ctot, coff, _ptr(out), N, C_, HW, _stream()), "gap_fwd")

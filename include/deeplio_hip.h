@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 222
+#define DLIO_ABI_VERSION 223
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);           /* "gfx950" */
@@ -312,6 +312,17 @@ int dlio_maxpool2d_bwd(const float* dy, const uint8_t* idx, const float* x_scale
  * gradient behind a max-pool from POOLED tensors -- with y = maxpool(x * s), s > 0: d loss / d s = sum dy * y / s
  * (pointseg_modules.py:203-221 + the MaxPool2d behind it; autograd's mul / max_pool2d backward) */
 int dlio_plane_dot(const float* a, const float* b, const float* div, float* out, int planes, int HW, dlio_stream_t stream);
+/* The two bias-free fully connected layers of an SELayer (pointseg_modules.py:207-212, 217-219: Linear(C, R) -> ReLU ->
+ * Linear(R, C) -> Sigmoid on the [N, C] plane averages g) in one launch: h [N][R] = relu(g w1^T), s [N][C] = sigmoid(h w2^T);
+ * w1 [R][C], w2 [C][R] row-major (nn.Linear.weight).  C <= 1024, R <= 512, both multiples of 4 (dlio_se_fc_ok), else
+ * DLIO_EUNSUP.  Backward in two launches: dz2 = ds * s (1 - s), dz1 = (dz2 w2) [h > 0], dg = dg_scale * dz1 w1 (dz2 [N][C],
+ * dz1 [N][R] are scratch outputs); dw1 [R][C] (+)= dz1^T g, dw2 [C][R] (+)= dz2^T h (accumulate != 0: added to what is there). */
+int dlio_se_fc_ok(int N, int C, int R);
+int dlio_se_fc_fwd(const float* g, const float* w1, const float* w2, float* h, float* s, int N, int C, int R,
+                   dlio_stream_t stream);
+int dlio_se_fc_bwd(const float* ds, const float* s, const float* h, const float* g, const float* w1, const float* w2,
+                   float* dz2, float* dz1, float* dg, float dg_scale, float* dw1, float* dw2, int accumulate, int N, int C,
+                   int R, dlio_stream_t stream);
 /* ds[n][c] = sum_hw scatter(dy) * x  without materialising scatter(dy) (fast-path shapes only,
  * DLIO_EUNSUP otherwise) */
 int dlio_maxpool2d_bwd_dot(const float* dy, const uint8_t* idx, const float* x, float* ds, int N,

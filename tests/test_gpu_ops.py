@@ -1334,3 +1334,34 @@ def test_fire_expand_pair_data_gradient_in_one_launch(dev, case):
         if (H * W) % 4 == 0 else dx2.add_(F.conv2d(d1.to(dev), w1.to(dev).transpose(0, 1)))
     ops.conv3x3_bx3_fwd(d3.to(dev), wt3, None, dx2, ops.conv_desc(N, E, H, W, S, 3, 3, 1, 1, 1, 1, OH=H, OW=W, res_ctot=S), residual=dx2)
     assert rel_err(dx, dx2) < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(16, 128, 64), (16, 256, 128), (16, 512, 256), (3, 36, 20), (1, 1024, 512), (5, 8, 4)])
+def test_selayer_fc_pair_one_launch(dev, case):
+    """dlio_se_fc_fwd / _bwd: the SELayer's Linear(C, R) -> ReLU -> Linear(R, C) -> Sigmoid (pointseg_modules.py:207-219,
+    no biases) and autograd's backward of it -- sigmoid', W2^T, relu', W1^T, both weight gradients, written and accumulated,
+    the plane average's 1 / (H W) folded in -- against fp64; the PSEncoder's three widths, widths off every tile size, the
+    size limits, one image"""
+    from deeplio_amd import ops
+    N, C_, R = case
+    assert ops.se_fc_ok(N, C_, R) and not ops.se_fc_ok(N, 1028, 512) and not ops.se_fc_ok(N, 30, 16)
+    g = _g(61)
+    x = torch.randn(N, C_, generator=g, dtype=torch.float64, requires_grad=True)
+    w1 = (torch.randn(R, C_, generator=g) / C_ ** 0.5).double().requires_grad_(True)
+    w2 = (torch.randn(C_, R, generator=g) / R ** 0.5).double().requires_grad_(True)
+    ds = torch.randn(N, C_, generator=g)
+    h64 = torch.relu(x @ w1.t())
+    s64 = torch.sigmoid(h64 @ w2.t())
+    s64.backward(ds.double())
+    d = lambda t: t.detach().float().to(dev)
+    h, s = ops.se_fc_fwd(d(x), d(w1), d(w2))
+    assert rel_err(h, h64.detach()) < 1e-6 and rel_err(s, s64.detach()) < 1e-6
+    dw1, dw2 = torch.full((R, C_), 7.0, device=dev), torch.full((C_, R), 7.0, device=dev)
+    dg = ops.se_fc_bwd(ds.to(dev), s, h, d(x), d(w1), d(w2), dw1, dw2, False, 0.25)
+    assert rel_err(dg, 0.25 * x.grad) < 2e-6
+    assert rel_err(dw1, w1.grad) < 2e-6 and rel_err(dw2, w2.grad) < 2e-6
+    ops.se_fc_bwd(ds.to(dev), s, h, d(x), d(w1), d(w2), dw1, dw2, True)
+    assert rel_err(dw1, 2 * w1.grad) < 2e-6 and rel_err(dw2, 2 * w2.grad) < 2e-6
+    with pytest.raises((ValueError, RuntimeError)):
+        ops.se_fc_fwd(torch.randn(2, 30, device=dev), torch.randn(16, 30, device=dev), torch.randn(30, 16, device=dev))

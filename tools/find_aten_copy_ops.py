@@ -19,4 +19,4 @@ for e in prof.events():
     if e.name in ("aten::copy_", "aten::clone", "aten::fill_", "aten::zero_", "aten::add_", "aten::contiguous") :
         st = [f for f in (e.stack or []) if "deeplio_amd" in f or "bench.py" in f or "autograd" in f]
         cnt[(e.name, st[0] if st else "?", str(e.input_shapes)[:60])] += 1
-for k, v in cnt.most_common(25): print(v, k)
+for k, v in cnt.most_common(60): print(v, k)
