@@ -105,6 +105,9 @@ SIGNATURES = {
     "dlio_maxpool2d_bwd": (_i, [_p, _p, _p, _p, _p] + [_i] * 11 + [_p]),
     "dlio_maxpool2d_bwd_dot": (_i, [_p, _p, _p, _p] + [_i] * 11 + [_p]),
     "dlio_plane_dot": (_i, [_p, _p, _p, _p, _i, _i, _p]),
+    "dlio_pair_fuse_fc_ws_bytes": (_sz, [_i, _i, _i]),
+    "dlio_pair_fuse_fc_fwd": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _i, _i, _p, _p, _p, _sz, _p, _p]),
+    "dlio_pair_fuse_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "dlio_se_fc_ok": (_i, [_i, _i, _i]),
     "dlio_se_fc_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "dlio_se_fc_bwd": (_i, [_p] * 9 + [_f, _p, _p, _i, _i, _i, _i, _p]),

@@ -448,6 +448,7 @@ def conv_dgrad(dy, weight, d, dx, dx_ctot, dx_coff, residual=None, r_ctot=0, r_c
 
 _CONV_BX3 = [os.environ.get("DLIO_CONV_BX3", "1") != "0"]
 _FIRE_FUSED = [os.environ.get("DLIO_FIRE_FUSED", "1") != "0"]
+_PAIR_FUSE = [os.environ.get("DLIO_PAIR_FUSE", "1") != "0"]   # gap + add / sub + fc1 + act of the lidar head as one launch
 _SE_FC = [os.environ.get("DLIO_SE_FC", "1") != "0"]         # the SELayer's fc pair as one launch (csrc/se_fc.hip)
 _SE_POOLED_DOT = [os.environ.get("DLIO_SE_POOLED_DOT", "1") != "0"]   # SELayer scale gradient from pooled tensors
 _BN_COOP_FWD = [True]          # cooperative kernels in the forward pass too (a module switch for ablations)
@@ -1005,6 +1006,40 @@ class LinearFn(Function):
         ops.linear_bwd_weight(dz, x, M, w.shape[0], w.shape[1], dw=dw, db=db, want_bias=b is not None,
                               accumulate=acc_w)
         return dx, ret_w, ret_b, None
+
+
+class PairFuseFcFn(Function):
+    """pair_fuse_fc: act(fc1(gap(a) (+|-) gap(b))) of the two encoder outputs (lidar_feat_nets.py:84-94, :131-141) as one
+    launch (csrc/pair_fuse.hip); backward: activation, weight gradient, data gradient, one broadcast launch for both maps"""
+
+    @staticmethod
+    def forward(ctx, a, b, mode, w, bias, act):
+        a, b = a.contiguous(), b.contiguous()
+        feat, y = ops.pair_fuse_fc_fwd(a, b, mode, w, bias, act)
+        ctx.save_for_backward(feat, w, y, bias)
+        ctx.cfg = (mode, act, tuple(a.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        feat, w, y, bias = ctx.saved_tensors
+        mode, act, shape = ctx.cfg
+        dy = dy.contiguous()
+        M = feat.shape[0]
+        dz = ops.act_bwd(dy, y, act) if act else dy
+        dw, acc_w, ret_w = _sink(w, w.shape, dy)
+        db = ret_b = None
+        if bias is not None:
+            db, acc_b, ret_b = _sink(bias, bias.shape, dy)
+            if acc_b != acc_w:
+                dw, acc_w, ret_w = _new(tuple(w.shape), dy), False, None
+                db, ret_b = _new(tuple(bias.shape), dy), None
+                ret_w, ret_b = dw, db
+        ops.linear_bwd_weight(dz, feat, M, w.shape[0], w.shape[1], dw=dw, db=db, want_bias=bias is not None, accumulate=acc_w)
+        da = dbm = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            da, dbm = ops.pair_fuse_bwd(ops.linear_bwd_data(dz, w, M), shape, mode)
+        return (da if ctx.needs_input_grad[0] else None, dbm if ctx.needs_input_grad[1] else None, None, ret_w, ret_b, None)
 
 
 class BinaryFn(Function):

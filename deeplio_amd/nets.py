@@ -455,28 +455,40 @@ class BaseLidarFeatNet(BaseNet):
                             fa = next(ga)
                         except StopIteration:
                             ga = None
-                if fb.dim() == 4:
+                fused = self._fused_head(fa, fb)
+                if fb.dim() == 4 and not fused:
                     with Fh.on_stream(self._side):
                         fb = _gap(fb)
             else:
                 with Fh.on_stream(self._side):
                     fb = self.encoder2(xb)
-                    if fb.dim() == 4:
-                        fb = _gap(fb)
                 fa = self.encoder1(xa)
-            if fa.dim() == 4:
+                fused = self._fused_head(fa, fb)
+                if fb.dim() == 4 and not fused:
+                    with Fh.on_stream(self._side):
+                        fb = _gap(fb)
+            if fa.dim() == 4 and not fused:
                 fa = _gap(fa)
             main.wait_stream(self._side)
             fb.record_stream(main)
         else:
             fa, fb = self.encoder1(xa), self.encoder2(xb)
-            if fa.dim() == 4:
+            if fa.dim() == 4 and not self._fused_head(fa, fb):
                 fa, fb = _gap(fa), _gap(fb)
         return fa, fb, (b, s)
+
+    def _fused_head(self, fa, fb):
+        """the encoder outputs go to head() as maps: plane averages, add / sub, fc1 and its activation are one launch
+        (functional.PairFuseFcFn) -- fp32 maps, fusion 'add' / 'sub', the dropout behind fc1"""
+        return (Fh._PAIR_FUSE[0] and fa.dim() == 4 and fa.is_cuda and fa.dtype == torch.float32 and fb.dtype == torch.float32
+                and self.fusion in ('add', 'sub') and not self.drop_before_fc and fa.shape == fb.shape)
 
     def head(self, fa, fb, bs):
         """fusion of the two encoder features, fc1, dropout (the part behind the encoders: small, serial)"""
         b, s = bs
+        if fa.dim() == 4:       # maps (see _fused_head)
+            y = Fh.PairFuseFcFn.apply(fa, fb, 0 if self.fusion == 'add' else 1, self.fc1.weight, self.fc1.bias, self.act)
+            return Fh.dropout(y, self.p, self.training).view(b, s, -1)
         if self.fusion == 'cat':
             y = Fh.Cat2Fn.apply(fa, fb)
         else:

@@ -774,6 +774,36 @@ def plane_dot(a, b, div=None):
     return out
 
 
+_PAIR_WS = {}
+
+
+def pair_fuse_fc_fwd(a, b, mode, w, bias, act):
+    """feat = gap(a) (+|-) gap(b) [N, C]; y = act(feat w^T + bias) [N, F] in one launch (a, b contiguous [N, C, H, W])"""
+    N, C_, H, W = a.shape
+    F_ = w.shape[0]
+    key = (a.device.index if a.device.index is not None else torch._C._cuda_getDevice(), raw_stream())
+    need = lib.dlio_pair_fuse_fc_ws_bytes(N, C_, F_)
+    e = _PAIR_WS.get(key)
+    if e is None or e[0].numel() < need or e[1].numel() < N:
+        e = (torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=a.device),
+             torch.zeros(max(N, 256), dtype=torch.int32, device=a.device))       # counters: zero once, the kernel restores them
+        _PAIR_WS[key] = e
+    feat = torch.empty(N, C_, dtype=torch.float32, device=a.device)
+    y = torch.empty(N, F_, dtype=torch.float32, device=a.device)
+    check(lib.dlio_pair_fuse_fc_fwd(_ptr(a), _ptr(b), N, C_, H * W, int(mode), _ptr(w), _ptr(bias), F_, int(act), _ptr(feat),
+                                    _ptr(y), _ptr(e[0]), e[0].numel(), _ptr(e[1]), _stream()), "pair_fuse_fc_fwd")
+    return feat, y
+
+
+def pair_fuse_bwd(df, shape, mode):
+    """df [N, C] -> (da, db) [N, C, H, W]: the gradient of the two plane averages and the add / sub in one launch"""
+    N, C_, H, W = shape
+    da = torch.empty(shape, dtype=torch.float32, device=df.device)
+    db = torch.empty(shape, dtype=torch.float32, device=df.device)
+    check(lib.dlio_pair_fuse_bwd(_ptr(df), _ptr(da), _ptr(db), N, C_, H * W, int(mode), _stream()), "pair_fuse_bwd")
+    return da, db
+
+
 def se_fc_ok(N, C_, R):
     """the SELayer's two fully connected layers have the one-launch kernels for this geometry"""
     return bool(lib.dlio_se_fc_ok(N, C_, R))

@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 223
+#define DLIO_ABI_VERSION 224
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);           /* "gfx950" */
@@ -312,6 +312,18 @@ int dlio_maxpool2d_bwd(const float* dy, const uint8_t* idx, const float* x_scale
  * gradient behind a max-pool from POOLED tensors -- with y = maxpool(x * s), s > 0: d loss / d s = sum dy * y / s
  * (pointseg_modules.py:203-221 + the MaxPool2d behind it; autograd's mul / max_pool2d backward) */
 int dlio_plane_dot(const float* a, const float* b, const float* div, float* out, int planes, int HW, dlio_stream_t stream);
+/* pair_fuse_fc -- the head of the siamese lidar feature nets (lidar_feat_nets.py:84-94, :131-141) in one launch:
+ * feat [N][C] = mean_hw a[n][c] (+ mode 0 | - mode 1) mean_hw b[n][c]; y [N][F] = act(feat w^T + bias) (w [F][C] = nn.Linear.weight,
+ * bias nullable, act as dlio_linear_fwd: 0 none, 1 relu, 2 leaky 0.01, 3 sigmoid, 4 tanh).  a, b contiguous [N][C][HW].
+ * ws: dlio_pair_fuse_fc_ws_bytes() bytes of scratch; counters: N ints, ZERO before the first use, restored by the kernel
+ * (the workgroup that arrives last at an image's counter adds the per-channel-block partial products in block order).
+ * dlio_pair_fuse_bwd: da [N][C][HW] = df [N][C] / HW broadcast, db = (+|-) the same -- autograd's backward of the two
+ * adaptive_avg_pool2d and the add / sub. */
+size_t dlio_pair_fuse_fc_ws_bytes(int N, int C, int F);
+int dlio_pair_fuse_fc_fwd(const float* a, const float* b, int N, int C, int HW, int mode, const float* w, const float* bias,
+                          int F, int act, float* feat, float* y, void* ws, size_t ws_bytes, int* counters,
+                          dlio_stream_t stream);
+int dlio_pair_fuse_bwd(const float* df, float* da, float* db, int N, int C, int HW, int mode, dlio_stream_t stream);
 /* The two bias-free fully connected layers of an SELayer (pointseg_modules.py:207-212, 217-219: Linear(C, R) -> ReLU ->
  * Linear(R, C) -> Sigmoid on the [N, C] plane averages g) in one launch: h [N][R] = relu(g w1^T), s [N][C] = sigmoid(h w2^T);
  * w1 [R][C], w2 [C][R] row-major (nn.Linear.weight).  C <= 1024, R <= 512, both multiples of 4 (dlio_se_fc_ok), else

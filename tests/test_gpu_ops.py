@@ -1365,3 +1365,32 @@ def test_selayer_fc_pair_one_launch(dev, case):
     assert rel_err(dw1, 2 * w1.grad) < 2e-6 and rel_err(dw2, 2 * w2.grad) < 2e-6
     with pytest.raises((ValueError, RuntimeError)):
         ops.se_fc_fwd(torch.randn(2, 30, device=dev), torch.randn(16, 30, device=dev), torch.randn(30, 16, device=dev))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(16, 768, 16, 32, 128, 0, 1), (3, 70, 5, 7, 130, 1, 2), (2, 1024, 4, 16, 300, 1, 0), (1, 5, 2, 2, 3, 0, 3)])
+def test_pair_fuse_fc_one_launch(dev, case):
+    """dlio_pair_fuse_fc_fwd / dlio_pair_fuse_bwd: act(fc1(avgpool(enc1) (+|-) avgpool(enc2))) of lidar_feat_nets.py:84-94 /
+    :131-141 and autograd's backward of it (functional.PairFuseFcFn) against fp64: the headline head, channel counts off the
+    32-channel blocks, H * W not a multiple of 4, more features than a workgroup has threads, every activation; run twice on
+    the same scratch (the arrival counters restore themselves)"""
+    from deeplio_amd import functional as Fh
+    N, C_, H, W, F_, mode, act = case
+    g = _g(67)
+    a = torch.randn(N, C_, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(N, C_, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(F_, C_, generator=g) / C_ ** 0.5).double().requires_grad_(True)
+    bias = torch.randn(F_, generator=g).double().requires_grad_(True)
+    dy = torch.randn(N, F_, generator=g)
+    fa, fb = a.mean((2, 3)), b.mean((2, 3))
+    z = F.linear(fa + fb if mode == 0 else fa - fb, w, bias)
+    y64 = [z, torch.relu(z), F.leaky_relu(z, 0.01), torch.sigmoid(z)][act]
+    y64.backward(dy.double())
+    for rep in range(2):
+        ad, bd = a.detach().float().to(dev).requires_grad_(True), b.detach().float().to(dev).requires_grad_(True)
+        wd, bsd = w.detach().float().to(dev).requires_grad_(True), bias.detach().float().to(dev).requires_grad_(True)
+        y = Fh.PairFuseFcFn.apply(ad, bd, mode, wd, bsd, act)
+        assert rel_err(y, y64.detach()) < 2e-6
+        y.backward(dy.to(dev))
+        assert rel_err(ad.grad, a.grad) < 2e-6 and rel_err(bd.grad, b.grad) < 2e-6
+        assert rel_err(wd.grad, w.grad) < 2e-6 and rel_err(bsd.grad, bias.grad) < 2e-6
