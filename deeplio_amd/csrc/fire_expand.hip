@@ -144,11 +144,14 @@ __global__ __launch_bounds__(256) void bn_split16_kernel(
 // (HW_ID / XCC_ID + atomics): 113 us.
 // Epilogue without LDS: the four registers r & 3 = 0..3 of a lane quad (four neighbouring pixels) are transposed with two
 // DPP butterfly stages, one 16-byte store per four accumulator registers.
-template <int TWN>
+// STATS: the workgroup also leaves the sum and the sum of squares of every output channel over its tile in
+// stats[workgroup][2][128] (expand1x1 channels co0..co0+63, then expand3x3's): the BatchNorm statistics of an apply-on-load
+// block without a pass over the concat buffer (fire_stats_finalize_kernel adds the tiles in index order, in fp64).
+template <int TWN, bool STATS = false>
 __global__ __launch_bounds__(256, 2) void fire_expand_fwd_kernel(
     const __bf16* __restrict__ planes, const __bf16* __restrict__ w3t, const __bf16* __restrict__ w1t,
     const float* __restrict__ bias3, const float* __restrict__ bias1, float* __restrict__ y, int N, int KC, int H, int W,
-    int E, int y_ctot, int y_coff, int tiles_w, int tiles_h, int co_tiles) {
+    int E, int y_ctot, int y_coff, int tiles_w, int tiles_h, int co_tiles, float* __restrict__ stats = nullptr) {
   constexpr int MR = 2;
   constexpr int TH = 4, TW = 32 * TWN, PR = TH + 2, PC = TW + 2, NPOSP = PR * PC;
   constexpr int PLANE = NPOSP * 16;                      // bf16 per patch plane
@@ -311,7 +314,17 @@ __global__ __launch_bounds__(256, 2) void fire_expand_fwd_kernel(
   // quad holds channel 8 (r >> 2) + 4 half + j of the quad's four pixels.  expand1x1 -> channels [y_coff, y_coff + E),
   // expand3x3 -> [y_coff + E, y_coff + 2 E)
   const int oh = oh0 + wave;
-  if (oh >= H) return;
+  if (!STATS && oh >= H) return;
+  const bool row_ok = oh < H;
+  float st1[2][MR][4], st2[2][MR][4];              // STATS: per (layer, channel tile, register quad) = per channel of this lane
+  if constexpr (STATS) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) st1[a][m][q] = st2[a][m][q] = 0.f;
+  }
   const size_t hw = (size_t)H * W;
   float* yb = y + ((size_t)n * y_ctot + y_coff) * hw + (size_t)oh * W + ow0 + 4 * (l31 >> 2);
   const bool o1 = (lane & 1) != 0, o2 = (lane & 2) != 0;
@@ -336,27 +349,100 @@ __global__ __launch_bounds__(256, 2) void fire_expand_fwd_kernel(
           { const float x = o2 ? a0 : a2, yv = swz(x, X2{}); a0 = o2 ? yv : a0; a2 = o2 ? a2 : yv; }
           { const float x = o2 ? a1 : a3, yv = swz(x, X2{}); a1 = o2 ? yv : a1; a3 = o2 ? a3 : yv; }
           const int co = co0 + 32 * m + 8 * rq + 4 * half + (lane & 3);
-          if (co < E && ow0 + 32 * t + 4 * (l31 >> 2) < W) {
+          if (row_ok && co < E && ow0 + 32 * t + 4 * (l31 >> 2) < W) {
             const float bv = bias ? bias[co] : 0.f;
-            *reinterpret_cast<float4*>(yb + ((size_t)(set == 0 ? 0 : E) + co) * hw + 32 * t) =
-                make_float4(a0 + bv, a1 + bv, a2 + bv, a3 + bv);
+            a0 += bv; a1 += bv; a2 += bv; a3 += bv;
+            *reinterpret_cast<float4*>(yb + ((size_t)(set == 0 ? 0 : E) + co) * hw + 32 * t) = make_float4(a0, a1, a2, a3);
+            if constexpr (STATS) {
+              st1[set][m][rq] += (a0 + a1) + (a2 + a3);
+              st2[set][m][rq] += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
           }
         }
+  }
+  if constexpr (STATS) {
+    // the eight lanes 4 j + (lane & 3) of a half hold the same channel: add them (xor 4, 8, 16), the four waves (rows)
+    // through LDS (the patch is no longer read: every wave is past the last group's barrier), one 1 KB row per workgroup
+    float* sl = reinterpret_cast<float*>(smem_raw);          // [4 waves][2][128]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float u = st1[a][m][q], v = st2[a][m][q];
+#pragma unroll
+          for (int o = 4; o <= 16; o <<= 1) { u += __shfl_xor(u, o, 64); v += __shfl_xor(v, o, 64); }
+          if ((l31 >> 2) == 0) {
+            const int ch = a * 64 + 32 * m + 8 * q + 4 * half + (lane & 3);
+            sl[(wave * 2 + 0) * 128 + ch] = u;
+            sl[(wave * 2 + 1) * 128 + ch] = v;
+          }
+        }
+    __syncthreads();
+    const int which = tid >> 7, ch = tid & 127;              // 256 threads = 2 x 128
+    const float tot = (sl[(0 * 2 + which) * 128 + ch] + sl[(1 * 2 + which) * 128 + ch]) +
+                      (sl[(2 * 2 + which) * 128 + ch] + sl[(3 * 2 + which) * 128 + ch]);
+    const size_t wg = ((size_t)(n * tiles_h + th) * tiles_w + tw) * co_tiles + cot;
+    stats[wg * 256 + tid] = tot;
+  }
+}
+
+// mean / invstd / scale / shift (+ running statistics) of the 2 E channels of a Fire block's concat buffer from the tile
+// sums fire_expand_fwd_kernel<.., true> left: one workgroup per channel, tiles added in index order (fp64)
+__global__ __launch_bounds__(256) void fire_stats_finalize_kernel(
+    const float* __restrict__ stats, int tiles, int co_tiles, int E, double count, float eps, float momentum,
+    const float* __restrict__ gamma1, const float* __restrict__ beta1, float* running_mean1, float* running_var1,
+    const float* __restrict__ gamma3, const float* __restrict__ beta3, float* running_mean3, float* running_var3,
+    float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
+  __shared__ double sm[2][16];
+  const int c = blockIdx.x, set = c / E, cl = c - set * E, cot = cl >> 6, ch = set * 64 + (cl & 63);
+  double a = 0.0, b = 0.0;
+  for (int t = threadIdx.x; t < tiles; t += 256) {
+    const float* p = stats + ((size_t)t * co_tiles + cot) * 256 + ch;
+    a += (double)p[0];
+    b += (double)p[128];
+  }
+  a = block_sum_d(a, sm[0]);
+  b = block_sum_d(b, sm[1]);
+  if (threadIdx.x != 0) return;
+  const double m = a / count;
+  double var = b / count - m * m;
+  if (var < 0.0) var = 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  const float* gamma = set == 0 ? gamma1 : gamma3;
+  const float* beta = set == 0 ? beta1 : beta3;
+  float* rm = set == 0 ? running_mean1 : running_mean3;
+  float* rv = set == 0 ? running_var1 : running_var3;
+  mean[c] = (float)m;
+  invstd[c] = is;
+  scale[c] = (gamma ? gamma[cl] : 1.f) * is;
+  if (shift) shift[c] = beta ? beta[cl] : 0.f;
+  if (rm) rm[cl] = (1.f - momentum) * rm[cl] + momentum * (float)m;
+  if (rv) {
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    rv[cl] = (1.f - momentum) * rv[cl] + momentum * (float)unb;
   }
 }
 
 template <int TWN>
 int launch_fire_fwd(const __bf16* planes, const __bf16* w3t, const __bf16* w1t, const float* bias3, const float* bias1,
-                    float* y, int N, int KC, int H, int W, int E, int y_ctot, int y_coff, hipStream_t s) {
+                    float* y, int N, int KC, int H, int W, int E, int y_ctot, int y_coff, hipStream_t s, float* stats = nullptr) {
   constexpr int TH = 4, TW = 32 * TWN;
   const int tiles_w = cdiv(W, TW), tiles_h = cdiv(H, TH), co_tiles = cdiv(E, 64);
   const int64_t blocks = (int64_t)N * tiles_h * tiles_w * co_tiles;
   if (blocks <= 0 || blocks > 0x7fffffff) return DLIO_EINVAL;
   constexpr int PINS = (3 * (TH + 2) * (TW + 2) * 2 + 63) / 64;
   constexpr size_t lds = (size_t)PINS * 1024 + (size_t)2 * 2 * 3 * 64 * 16 * sizeof(__bf16);
+  if (stats) {
+    dlio_set_max_lds(reinterpret_cast<const void*>(&fire_expand_fwd_kernel<TWN, true>), (int)lds);
+    hipLaunchKernelGGL((fire_expand_fwd_kernel<TWN, true>), dim3((unsigned)blocks), dim3(256), lds, s, planes, w3t, w1t, bias3,
+                       bias1, y, N, KC, H, W, E, y_ctot, y_coff, tiles_w, tiles_h, co_tiles, stats);
+    return dlio_check_launch();
+  }
   dlio_set_max_lds(reinterpret_cast<const void*>(&fire_expand_fwd_kernel<TWN>), (int)lds);
   hipLaunchKernelGGL((fire_expand_fwd_kernel<TWN>), dim3((unsigned)blocks), dim3(256), lds, s, planes, w3t, w1t, bias3, bias1,
-                     y, N, KC, H, W, E, y_ctot, y_coff, tiles_w, tiles_h, co_tiles);
+                     y, N, KC, H, W, E, y_ctot, y_coff, tiles_w, tiles_h, co_tiles, (float*)nullptr);
   return dlio_check_launch();
 }
 
@@ -420,4 +506,51 @@ extern "C" int dlio_fire_expand_fwd(const void* planes, const void* w3t, const v
   const __bf16* w1 = reinterpret_cast<const __bf16*>(w1t);
   return W > 32 ? launch_fire_fwd<2>(pl, w3, w1, bias3, bias1, y, N, KC, H, W, E, y_ctot, y_coff, s)
                 : launch_fire_fwd<1>(pl, w3, w1, bias3, bias1, y, N, KC, H, W, E, y_ctot, y_coff, s);
+}
+
+static void fire_tiles(int N, int H, int W, int E, int& tiles, int& co_tiles) {
+  const int TW = W > 32 ? 64 : 32;
+  tiles = N * cdiv(H, 4) * cdiv(W, TW);
+  co_tiles = cdiv(E, 64);
+}
+
+extern "C" size_t dlio_fire_expand_stats_ws_bytes(int N, int H, int W, int E) {
+  if (N <= 0 || H <= 0 || W <= 0 || E <= 0) return 0;
+  int tiles, co_tiles;
+  fire_tiles(N, H, W, E, tiles, co_tiles);
+  return (size_t)tiles * co_tiles * 256 * sizeof(float);
+}
+
+extern "C" int dlio_fire_expand_fwd_stats(const void* planes, const void* w3t, const void* w1t, const float* bias3,
+                                          const float* bias1, float* y, int N, int S, int H, int W, int E, int y_ctot,
+                                          int y_coff, const float* gamma1, const float* beta1, float* running_mean1,
+                                          float* running_var1, const float* gamma3, const float* beta3, float* running_mean3,
+                                          float* running_var3, float eps, float momentum, float* mean, float* invstd,
+                                          float* scale, float* shift, void* ws, size_t ws_bytes, dlio_stream_t stream) {
+  if (!planes || !w3t || !w1t || !y || !mean || !invstd || !scale || !ws || N <= 0 || S <= 0 || H <= 0 || W <= 0 || E <= 0 ||
+      y_ctot < y_coff + 2 * E || y_coff < 0)
+    return DLIO_EINVAL;
+  const int KC = (S + 15) / 16;
+  if ((W & 3) || (reinterpret_cast<uintptr_t>(y) & 15) || (reinterpret_cast<uintptr_t>(planes) & 15)) return DLIO_EUNSUP;
+  if (dlio_fire_planes_bytes(N, S, H, W) >= 0x7fffffffull || (size_t)9 * KC * 3 * E * 32 >= 0x7fffffffull) return DLIO_EUNSUP;
+  if (ws_bytes < dlio_fire_expand_stats_ws_bytes(N, H, W, E)) return DLIO_EWS;
+  hipStream_t s = as_stream(stream);
+  const double P = (double)N * H * W;
+  const __bf16* pl = reinterpret_cast<const __bf16*>(planes);
+  const __bf16* w3 = reinterpret_cast<const __bf16*>(w3t);
+  const __bf16* w1 = reinterpret_cast<const __bf16*>(w1t);
+  float* st = reinterpret_cast<float*>(ws);
+  int rc;
+  {
+    DlioProfScope prof(3, s, 2.0 * P * E * (double)S * 10, 4.0 * P * 2 * E + 6.0 * P * KC * 16);
+    rc = W > 32 ? launch_fire_fwd<2>(pl, w3, w1, bias3, bias1, y, N, KC, H, W, E, y_ctot, y_coff, s, st)
+                : launch_fire_fwd<1>(pl, w3, w1, bias3, bias1, y, N, KC, H, W, E, y_ctot, y_coff, s, st);
+  }
+  if (rc) return rc;
+  int tiles, co_tiles;
+  fire_tiles(N, H, W, E, tiles, co_tiles);
+  hipLaunchKernelGGL(fire_stats_finalize_kernel, dim3((unsigned)(2 * E)), dim3(256), 0, s, st, tiles, co_tiles, E, P, eps, momentum,
+                     gamma1, beta1, running_mean1, running_var1, gamma3, beta3, running_mean3, running_var3, mean, invstd,
+                     scale, shift);
+  return dlio_check_launch();
 }

@@ -448,6 +448,7 @@ def conv_dgrad(dy, weight, d, dx, dx_ctot, dx_coff, residual=None, r_ctot=0, r_c
 
 _CONV_BX3 = [os.environ.get("DLIO_CONV_BX3", "1") != "0"]
 _FIRE_FUSED = [os.environ.get("DLIO_FIRE_FUSED", "1") != "0"]
+_FIRE_STATS = [os.environ.get("DLIO_FIRE_STATS", "1") != "0"]   # apply-on-load blocks: BatchNorm statistics from the expand launch
 _PAIR_FUSE = [os.environ.get("DLIO_PAIR_FUSE", "1") != "0"]   # gap + add / sub + fc1 + act of the lidar head as one launch
 _SE_FC = [os.environ.get("DLIO_SE_FC", "1") != "0"]         # the SELayer's fc pair as one launch (csrc/se_fc.hip)
 _SE_POOLED_DOT = [os.environ.get("DLIO_SE_POOLED_DOT", "1") != "0"]   # SELayer scale gradient from pooled tensors
@@ -692,7 +693,16 @@ class FireFn(Function):
                                   in_aff=x_aff, split_into=planes)
         raw_e = _new((N, CE, H, W), x)
         res = x if bypass else None
-        if fused:
+        # an apply-on-load block takes its BatchNorm statistics out of the expand launch's epilogue (tile sums + one small
+        # finalising launch) instead of a pass over the concat buffer
+        epi = fused and defer and training and _FIRE_STATS[0] and ops._SYNC_BN[0] is None
+        if epi:
+            aff, inv = _new((3, CE), x), _new((CE,), x)
+            ops.fire_expand_fwd_stats(planes, ops.conv_bx3_prepped(e3w, 0), ops.conv_bx3_prepped(e1w, 0), e3b, e1b, raw_e,
+                                      N, S_, H, W, E1, CE, 0, (e1g, e1be, e1rm, e1rv), (e3g, e3be, e3rm, e3rv), eps, momentum,
+                                      aff[0], inv, aff[1], aff[2])
+            del planes
+        elif fused:
             ops.fire_expand_fwd(planes, ops.conv_bx3_prepped(e3w, 0), ops.conv_bx3_prepped(e1w, 0), e3b, e1b, raw_e,
                                 N, S_, H, W, E1, CE, 0)
             del planes
@@ -706,6 +716,17 @@ class FireFn(Function):
                 and (not want_gap or ops.bn_coop_gap_ok(N, H * W)))
         small = training and _BN_SMALL[0] and x.is_cuda and (coop or ops.bn_small_ok(N, H * W))
         bn_fwd = ops.bn_coop_fwd if coop else ops.bn_small_fwd
+        if epi:
+            d_1, _ = _CBR.forward(act_s, S_, 0, S_, H, W, e1w, e1b, e1g, e1be, e1rm, e1rv, (1, 1), (0, 0), training,
+                                  momentum, eps, False, True, raw_e, CE, 0, None, CE, 0, N, conv_done=True, skip_bn=True)
+            d_3, _ = _CBR.forward(act_s, S_, 0, S_, H, W, e3w, e3b, e3g, e3be, e3rm, e3rv, (1, 1), (1, 1), training,
+                                  momentum, eps, False, True, raw_e, CE, E1, None, CE, E1, N, conv_done=True, skip_bn=True)
+            ctx.save_for_backward(x, sw, sbe, e1w, e1be, e3w, e3be, raw_s, act_s, raw_e, prm_s, aff, inv[:E1], inv[E1:],
+                                  sb, sg, e1b, e1g, e3b, e3g, x_aff)
+            ctx.cfg = (d_s, d_1, d_3, training, bypass, True)
+            ctx.small_prm = (aff[0], inv, aff[1])
+            ctx.mark_non_differentiable(aff)
+            return raw_e, aff
         if small:
             # fire_blk4 / fire_blk5: the two expand BatchNorms as ONE launch that reads the concat buffer once
             d_1, _ = _CBR.forward(act_s, S_, 0, S_, H, W, e1w, e1b, e1g, e1be, e1rm, e1rv, (1, 1), (0, 0), training,

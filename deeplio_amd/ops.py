@@ -632,6 +632,20 @@ def fire_expand_fwd(planes, w3t, w1t, bias3, bias1, y, N, S, H, W, E, y_ctot, y_
     return y
 
 
+def fire_expand_fwd_stats(planes, w3t, w1t, bias3, bias1, y, N, S, H, W, E, y_ctot, y_coff, set1, set3, eps, momentum,
+                          mean, invstd, scale, shift):
+    """fire_expand_fwd + the train-mode BatchNorm statistics of both expand layers from the launch's own tile sums
+    (set = (gamma, beta, running_mean, running_var)); mean / invstd / scale / shift: rows of 2 E floats"""
+    nbytes = lib.dlio_fire_expand_stats_ws_bytes(N, H, W, E)
+    ws = workspace(nbytes, y.device, slot=5)
+    check(lib.dlio_fire_expand_fwd_stats(_ptr(planes), _ptr(w3t), _ptr(w1t), _ptr(bias3), _ptr(bias1), _ptr(y), N, S, H, W, E,
+                                         y_ctot, y_coff, _ptr(set1[0]), _ptr(set1[1]), _ptr(set1[2]), _ptr(set1[3]),
+                                         _ptr(set3[0]), _ptr(set3[1]), _ptr(set3[2]), _ptr(set3[3]), float(eps),
+                                         float(momentum), _ptr(mean), _ptr(invstd), _ptr(scale), _ptr(shift), _ptr(ws),
+                                         ws.numel(), _stream()), "fire_expand_fwd_stats")
+    return y
+
+
 def bn_bwd_fused(dy, dy_ctot, dy_coff, x, x_ctot, x_coff, prm, beta, dx, dx_ctot, dx_coff, N, C_, HW,
                  pre_relu, post_relu, use_batch_stats, dgamma=None, dbeta=None, accumulate=False):
     """BN backward (reductions + dx, dgamma, dbeta) in two launches (SyncBN: partials all-reduced in

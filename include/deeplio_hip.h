@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 224
+#define DLIO_ABI_VERSION 225
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);           /* "gfx950" */
@@ -207,6 +207,17 @@ int dlio_bn_split16(const float* x, int N, int x_ctot, int x_coff, int C, int H,
                     void* planes, void* ws, size_t ws_bytes, int mode, double count_scale, dlio_stream_t stream);
 int dlio_fire_expand_fwd(const void* planes, const void* w3t, const void* w1t, const float* bias3, const float* bias1,
                          float* y, int N, int S, int H, int W, int E, int y_ctot, int y_coff, dlio_stream_t stream);
+/* The same launch that also leaves per-tile channel sums, + one small launch that turns them into the train-mode BatchNorm
+ * statistics of BOTH expand layers (mean / invstd / scale = gamma * invstd / shift = beta over the 2 E channels of the concat
+ * buffer, running statistics updated with `momentum`): an apply-on-load block (functional.FireFn(defer=True)) needs no pass
+ * over the concat buffer for its statistics.  ws: dlio_fire_expand_stats_ws_bytes() bytes. */
+size_t dlio_fire_expand_stats_ws_bytes(int N, int H, int W, int E);
+int dlio_fire_expand_fwd_stats(const void* planes, const void* w3t, const void* w1t, const float* bias3, const float* bias1,
+                               float* y, int N, int S, int H, int W, int E, int y_ctot, int y_coff, const float* gamma1,
+                               const float* beta1, float* running_mean1, float* running_var1, const float* gamma3,
+                               const float* beta3, float* running_mean3, float* running_var3, float eps, float momentum,
+                               float* mean, float* invstd, float* scale, float* shift, void* ws, size_t ws_bytes,
+                               dlio_stream_t stream);
 /* dst [planes][HU][WU] = src [planes][OH][OW] with SH-1 / SW-1 zeros inserted between rows /
  * columns (and zero tail rows/columns up to HU, WU): turns the data gradient of a strided
  * convolution into dlio_conv2d_fwd with stride 1 on the data-gradient weight layout

@@ -1218,6 +1218,32 @@ def test_fire_expand_pair_fused_matches_fp64(dev, case, training):
     assert rel_err(yb[:, 1:1 + E], ref1) < 3e-6 and rel_err(yb[:, 1 + E:1 + 2 * E], ref3) < 3e-6
     assert float(yb[:, :1].abs().max()) == 0 and float(yb[:, 1 + 2 * E:].abs().max()) == 0
     assert torch.equal(ya, yb)
+    if training:
+        # the same launch leaving tile sums + the finalising launch: BatchNorm statistics of both expand layers (what an
+        # apply-on-load block needs) without a pass over the concat buffer; same output tensor
+        yc = torch.zeros(N, 2 * E + 3, H, W, device=dev)
+        g1, be1 = torch.rand(E, generator=g).to(dev) + 0.5, torch.randn(E, generator=g).to(dev)
+        g3, be3 = torch.rand(E, generator=g).to(dev) + 0.5, torch.randn(E, generator=g).to(dev)
+        r1, v1, r3, v3 = (torch.randn(E, generator=g).to(dev), torch.rand(E, generator=g).to(dev) + 0.5,
+                          torch.randn(E, generator=g).to(dev), torch.rand(E, generator=g).to(dev) + 0.5)
+        r1o, v1o, r3o, v3o = r1.clone(), v1.clone(), r3.clone(), v3.clone()
+        aff, inv = torch.empty(3, 2 * E, device=dev), torch.empty(2 * E, device=dev)
+        for rep in range(2):        # (twice on the same scratch)
+            ops.fire_expand_fwd_stats(planes, w3t, w1t, b3.to(dev), b1.to(dev), yc, N, S, H, W, E, 2 * E + 3, 1, (g1, be1, r1, v1),
+                                      (g3, be3, r3, v3), 1e-5, 0.1, aff[0], inv, aff[1], aff[2])
+            if rep == 0:
+                r1a, v1a = r1.clone(), v1.clone()
+        assert torch.equal(yc, yb)
+        yd = yb[:, 1:1 + 2 * E].double()
+        mu64, var64 = yd.mean((0, 2, 3)), yd.var((0, 2, 3), unbiased=False)
+        is64 = 1.0 / torch.sqrt(var64 + 1e-5)
+        assert rel_err(aff[0], mu64) < 2e-6 and rel_err(inv, is64) < 2e-6
+        assert rel_err(aff[1], torch.cat([g1, g3]).double().cpu() * is64.cpu()) < 2e-6
+        assert torch.equal(aff[2], torch.cat([be1, be3]))
+        cnt = N * H * W
+        assert rel_err(r1a, 0.9 * r1o.double() + 0.1 * mu64[:E].to(dev)) < 2e-6
+        assert rel_err(v1a, 0.9 * v1o.double() + 0.1 * var64[:E].to(dev) * cnt / (cnt - 1)) < 2e-6
+        assert rel_err(r3, 0.81 * r3o.double() + 0.19 * mu64[E:].to(dev)) < 2e-6
     # the planes hold the exact three-way split: hi + mid + lo == activated value, zero border
     KC = (S + 15) // 16
     pv = planes.view(torch.bfloat16).view(N, KC, 3, H + 2, W + 2, 16).float().sum(2)      # [N][KC][H+2][W+2][16]
