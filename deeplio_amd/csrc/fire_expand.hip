@@ -549,6 +549,7 @@ extern "C" int dlio_fire_expand_fwd_stats(const void* planes, const void* w3t, c
   if (rc) return rc;
   int tiles, co_tiles;
   fire_tiles(N, H, W, E, tiles, co_tiles);
+  DlioProfScope prof(6, s, 0.0, (double)tiles * co_tiles * 256 * sizeof(float));       // (a BatchNorm statistics launch)
   hipLaunchKernelGGL(fire_stats_finalize_kernel, dim3((unsigned)(2 * E)), dim3(256), 0, s, st, tiles, co_tiles, E, P, eps, momentum,
                      gamma1, beta1, running_mean1, running_var1, gamma3, beta3, running_mean3, running_var3, mean, invstd,
                      scale, shift);

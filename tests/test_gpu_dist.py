@@ -82,7 +82,7 @@ def _single_process(dev, pin=True):
     from deeplio_amd import functional as Fh
     from deeplio_amd.trainer import TrainStep
     saved = list(Fh._BX3_1X1_MIN)
-    saved_small = Fh._BN_SMALL[0]
+    saved_small, saved_stats = Fh._BN_SMALL[0], Fh._FIRE_STATS[0]
     if pin:
         Fh._BX3_1X1_MIN[:] = [int(v) for v in SAME_KERNELS.split(",")]
     else:
@@ -90,6 +90,7 @@ def _single_process(dev, pin=True):
         # BatchNorm kernels, so the single process is compared on them too (the one-launch kernels of bn_small.hip give the
         # same statistics to 1e-7, which the ReLU masks amplify to 1e-3 in the encoder gradients like any other rounding)
         Fh._BN_SMALL[0] = False
+        Fh._FIRE_STATS[0] = False           # (and the statistics pass instead of the expand launch's tile sums)
     try:
         ts = TrainStep(make_cfg(), SHAPE, dev, GB)
         gc.fill_state(ts.model, seed=77)
@@ -98,7 +99,7 @@ def _single_process(dev, pin=True):
         torch.cuda.synchronize()
     finally:
         Fh._BX3_1X1_MIN[:] = saved
-        Fh._BN_SMALL[0] = saved_small
+        Fh._BN_SMALL[0], Fh._FIRE_STATS[0] = saved_small, saved_stats
     bufs = {k: v.detach().cpu() for k, v in ts.model.named_buffers() if k.endswith("running_mean") or k.endswith("running_var")}
     return float(loss), ts.optimizer.grad.cpu().clone(), bufs, ts
 

@@ -16,7 +16,7 @@ FAMILIES = [
     ("conv3x3 wgrad", ("wgrad3_kernel", "conv_wgrad_adirect")),
     ("conv1x1 wgrad", ("wgrad1x1_",)),
     ("other wgrad + slab reduce", ("conv_wgrad_kernel", "wgrad_reduce_kernel")),
-    ("BN fwd statistics", ("chan_reduce_kernel<0", "bn16_reduce_kernel<0")),
+    ("BN fwd statistics", ("chan_reduce_kernel<0", "bn16_reduce_kernel<0", "fire_stats_finalize", "chan_stats_finalize")),
     ("BN fwd apply", ("bn_plane_apply_kernel", "bn_apply_kernel", "bn16_plane_apply", "bn_split16_kernel")),
     ("BN fwd, one launch (statistics + apply, one read)", ("bn_coop_fwd_kernel", "bn_small_fwd_kernel")),
     ("BN bwd, one launch (reductions + apply, one read)", ("bn_coop_bwd_kernel", "bn_small_bwd_kernel")),
