@@ -40,6 +40,13 @@ static inline int ew_grid(int64_t work_items, int block) {
 // output-channel tiles of one pixel tile, adjacent halo tiles) so that they share input -- land on eight different
 // L2s and every one of them fetches the shared input from HBM again.  With v = (b % 8) * (n / 8) + b / 8 an XCD
 // works through a contiguous range of virtual indices, in order.
+// Timing experiment only (tools/variant_lib.py build ... -DDLIO_SPLIT_Q0=3): start the six-product sequence of the
+// split-bf16 kernels at product 3, i.e. run (mid,hi) (hi,mid) (hi,hi) = a TWO-piece split with three MFMAs per product and no
+// fragment reads of the third plane -- the instruction mix a two-piece fp16 split would have (open items).
+// The product build uses 0.
+#ifndef DLIO_SPLIT_Q0
+#define DLIO_SPLIT_Q0 0
+#endif
 #ifndef DLIO_XCD_SWIZZLE
 #define DLIO_XCD_SWIZZLE 1
 #endif

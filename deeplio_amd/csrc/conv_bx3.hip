@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
       // six products, smallest first; consecutive MFMAs go to different accumulators
       constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-      for (int q = 0; q < 6; ++q)
+      for (int q = DLIO_SPLIT_Q0; q < 6; ++q)
 #pragma unroll
         for (int m = 0; m < MR; ++m)
 #pragma unroll
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_alds_kernel(
       const auto& aa = a[tl & 1];
       constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-      for (int q = 0; q < 6; ++q)
+      for (int q = DLIO_SPLIT_Q0; q < 6; ++q)
 #pragma unroll
         for (int m = 0; m < MR; ++m)
 #pragma unroll
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_alds_kernel(
     }
     constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-    for (int q = 0; q < 6; ++q)
+    for (int q = DLIO_SPLIT_Q0; q < 6; ++q)
 #pragma unroll
       for (int m = 0; m < MR; ++m)
 #pragma unroll
@@ -813,7 +813,7 @@ __global__ __launch_bounds__(512) void conv3x3_bx3_pc_kernel(
       const auto& aa = a[tl & 1];
       constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-      for (int q = 0; q < 6; ++q)
+      for (int q = DLIO_SPLIT_Q0; q < 6; ++q)
 #pragma unroll
         for (int m = 0; m < MR; ++m)
 #pragma unroll
@@ -992,7 +992,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bx3_kernel(
         bb[0][j] = h; bb[1][j] = m; bb[2][j] = l;
       }
 #pragma unroll
-      for (int q = 0; q < 6; ++q)
+      for (int q = DLIO_SPLIT_Q0; q < 6; ++q)
 #pragma unroll
         for (int m = 0; m < MR; ++m)
           acc[m][e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s % AB][m][PA[q]], bb[PB[q]], acc[m][e], 0, 0, 0);

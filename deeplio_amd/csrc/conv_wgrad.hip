@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256, (BX3 && AFF) ? 1 : 2) void wgrad1x1_direct_ker
           wg_split8(v, bh[t], bm[t], bl[t]);
         }
 #pragma unroll
-        for (int term = 0; term < 6; ++term)
+        for (int term = DLIO_SPLIT_Q0; term < 6; ++term)
 #pragma unroll
           for (int m = 0; m < MR; ++m)
 #pragma unroll
@@ -949,7 +949,7 @@ __global__ __launch_bounds__(256, GK == 16 ? 4 : 2) void gemm_nt_bx3_kernel(cons
           b[t][p] = *reinterpret_cast<const wg_bf16x8*>(base + OPER + p * PLANE + (64 * wn + 32 * t + l31) * GLDK + kk + 8 * half);
       constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};     // smallest products first
 #pragma unroll
-      for (int q = 0; q < 6; ++q)
+      for (int q = DLIO_SPLIT_Q0; q < 6; ++q)
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll

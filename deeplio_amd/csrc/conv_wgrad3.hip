@@ -85,7 +85,7 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsign
 }
 
 // six products, smallest first: (lo,hi) (mid,mid) (hi,lo) (mid,hi) (hi,mid) (hi,hi)   [A plane, B plane]
-__device__ constexpr int TA_[6] = {2, 1, 0, 1, 0, 0}, TB_[6] = {0, 1, 2, 0, 1, 0};
+__device__ constexpr int TA_[9] = {2, 1, 0, 1, 0, 0, 0, 0, 0}, TB_[9] = {0, 1, 2, 0, 1, 0, 0, 0, 0};
 
 template <int MR, int NTB, bool NAT>
 struct W3Cfg {
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const float* __restrict_
   };
 
   // six products, smallest first: (lo,hi) (mid,mid) (hi,lo) (mid,hi) (hi,mid) (hi,hi)   [A plane, B plane]
-  constexpr int NTERM = NAT ? 1 : 6;
+  constexpr int NTERM = NAT ? 1 : 6 - DLIO_SPLIT_Q0;      // (DLIO_SPLIT_Q0: common.h, 0 in the product build)
   constexpr int NS = 2 * NTB;                            // steps of a tile: (k-block q, B tile t)
   constexpr int UH = NTB * NTERM;                        // work units (= groups of 3 MR MFMAs) per k-block half
 
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const float* __restrict_
       static_for<0, NTERM>([&](auto term_) {
         constexpr int term = decltype(term_)::value;
         const AQ& f = q == 0 ? a0 : a1;
-        constexpr int pa = NAT ? 0 : TA_[term];
+        constexpr int pa = NAT ? 0 : TA_[term + DLIO_SPLIT_Q0];
         static_for<0, 3>([&](auto kx_) {
           constexpr int kx = decltype(kx_)::value;
 #pragma unroll
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const float* __restrict_
             const unsigned* src = kx == 2 ? f.e[pa][m] : kx == 0 ? f.c[pa][m] : f.o[pa][m];
             const u32x4 av = {src[0], src[1], src[2], src[3]};
             if constexpr (!(W3_ABL & 8))
-              acc[m][t][kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), b.v[NAT ? 0 : TB_[term]],
+              acc[m][t][kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), b.v[NAT ? 0 : TB_[term + DLIO_SPLIT_Q0]],
                                                                     acc[m][t][kx], 0, 0, 0);
           }
         });

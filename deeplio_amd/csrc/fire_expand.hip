@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void fire_expand_fwd_kernel(
   constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
   auto mfma_slot = [&](f32x16 (&acc)[MR][TWN], const bf16x8 (&a)[MR][3], const bf16x8 (&b)[TWN][3]) {
 #pragma unroll
-    for (int q = 0; q < 6; ++q)
+    for (int q = DLIO_SPLIT_Q0; q < 6; ++q)
 #pragma unroll
       for (int m = 0; m < MR; ++m)
 #pragma unroll
