@@ -62,10 +62,13 @@ SIGNATURES = {
     "dlio_fire_planes_bytes": (_sz, [_i, _i, _i, _i]),
     "dlio_bn_split16": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _sz,
                              _i, _d, _p]),
-    "dlio_fire_expand_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "dlio_fire_expand_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "dlio_conv_h2_prep_floats": (_sz, [_i, _i, _i, _i]),
+    "dlio_conv_h2_prep": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "dlio_conv_h2_prep_batched": (_i, [_p, _i, _i64, _p]),
     "dlio_fire_expand_stats_ws_bytes": (_sz, [_i, _i, _i, _i]),
     "dlio_fire_expand_fwd_stats": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i] + [_p] * 8 + [_f, _f, _p, _p, _p, _p,
-                                        _p, _sz, _p]),
+                                        _p, _sz, _i, _p]),
     "dlio_bn_small_ok": (_i, [_i, _i]),
     "dlio_bn_small_fwd": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p,
                                _p, _i, _i, _p, _p, _p, _p, _i, _i, _p, _i, _i, _p]),

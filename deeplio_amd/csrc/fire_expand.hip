@@ -39,10 +39,32 @@ __global__ __launch_bounds__(256) void bn_split16_kernel(
     const float* __restrict__ x, int x_ctot, int x_coff, const double* __restrict__ part, int splits, double count,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum, float* running_mean,
     float* running_var, float* mean_io, float* invstd_o, float* scale_io, float* y, int y_ctot, int y_coff,
-    __bf16* __restrict__ planes, int N, int C, int H, int W, int post_relu) {
+    __bf16* __restrict__ planes, int N, int C, int H, int W, int post_relu, int h2) {
   __shared__ float tab[16][4];              // mean, scale, beta
+  __shared__ float wmax[4];
   const int kc = blockIdx.y, n = blockIdx.z, KC = gridDim.y;
   const int tid = threadIdx.x;
+  // h2 (train mode): two fp16 pieces of x * 2^k instead of three bf16 pieces of x.  2^k from a bound that needs no pass:
+  // with batch statistics |x - mean| / sqrt(var + eps) <= sqrt(count) for every element, so |BN(x)| <= |beta| + |gamma|
+  // sqrt(count); the bound is mapped to 2^14 (fp16 max 65504).  It overshoots the true maximum by ~2^7: elements down to 1e-3
+  // of the maximum keep 2^-22 relative accuracy, smaller ones an absolute error of 2^-32 of the maximum.
+  float hs = 1.f;
+  if (h2) {
+    float b = 0.f;
+    const float rc = sqrtf((float)count);
+    for (int c = tid; c < C; c += 256) b = fmaxf(b, fabsf(beta ? beta[c] : 0.f) + fabsf(gamma ? gamma[c] : 1.f) * rc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) b = fmaxf(b, __shfl_xor(b, o, 64));
+    if ((tid & 63) == 0) wmax[tid >> 6] = b;
+    __syncthreads();
+    b = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    hs = (b > 0.f && b < 3.0e38f) ? exp2f(floorf(log2f(16384.f / b))) : 1.f;
+    if (tid == 0 && blockIdx.x == 0 && kc == 0 && n == 0) {
+      // the inverse scale travels behind the planes
+      float* tail = reinterpret_cast<float*>(planes + (size_t)N * KC * 2 * ((size_t)(H + 2) * (W + 2) * 16));
+      tail[0] = 1.f / hs;
+    }
+  }
   {
     const int cl = tid >> 4, sub = tid & 15, c = kc * 16 + cl;       // 16 threads per channel
     float mu = 0.f, sc = 0.f, be = 0.f;
@@ -79,7 +101,7 @@ __global__ __launch_bounds__(256) void bn_split16_kernel(
   const int HW = H * W, lane = tid & 63, l31 = lane & 31, half = lane >> 5, wave = tid >> 6;
   const int WP = W + 2;
   const size_t pstride = (size_t)(H + 2) * WP * 16;                    // bf16 per plane
-  __bf16* pb = planes + ((size_t)n * KC + kc) * 3 * pstride + 8 * half;
+  __bf16* pb = planes + ((size_t)n * KC + kc) * (h2 ? 2 : 3) * pstride + 8 * half;
   const float* xb = x + ((size_t)n * x_ctot + x_coff + kc * 16 + 8 * half) * HW;
   float* yb = y ? y + ((size_t)n * y_ctot + y_coff + kc * 16 + 8 * half) * HW : nullptr;
   const int p0 = (blockIdx.x * 4 + wave) * (32 * SPLIT_U) + l31;
@@ -106,21 +128,28 @@ __global__ __launch_bounds__(256) void bn_split16_kernel(
         if (post_relu) t = fmaxf(t, 0.f);
         if (yb) yb[(size_t)c * HW + p] = t;
       }
-      __bf16 hh, mm, ll;
-      split3(t, hh, mm, ll);
-      ph[c] = hh; pm[c] = mm; pl[c] = ll;
+      if (h2) {
+        const float ts = t * hs;
+        const _Float16 hh = (_Float16)ts;
+        const _Float16 ll = (_Float16)(ts - (float)hh);
+        ph[c] = __builtin_bit_cast(__bf16, hh); pm[c] = __builtin_bit_cast(__bf16, ll);
+      } else {
+        __bf16 hh, mm, ll;
+        split3(t, hh, mm, ll);
+        ph[c] = hh; pm[c] = mm; pl[c] = ll;
+      }
     }
     __bf16* d = pb + ((size_t)(h + 1) * WP + (w + 1)) * 16;
     *reinterpret_cast<bf16x8*>(d) = ph;
     *reinterpret_cast<bf16x8*>(d + pstride) = pm;
-    *reinterpret_cast<bf16x8*>(d + 2 * pstride) = pl;
+    if (!h2) *reinterpret_cast<bf16x8*>(d + 2 * pstride) = pl;
     // zero border (the 3x3 padding), this lane's channel half: columns 0 / W + 1 beside its row, rows 0 / H + 1 above /
     // below its column, the corners with the edge columns
     auto zero_at = [&](int r, int c) {
       __bf16* z = pb + ((size_t)r * WP + c) * 16;
       *reinterpret_cast<bf16x8*>(z) = z8;
       *reinterpret_cast<bf16x8*>(z + pstride) = z8;
-      *reinterpret_cast<bf16x8*>(z + 2 * pstride) = z8;
+      if (!h2) *reinterpret_cast<bf16x8*>(z + 2 * pstride) = z8;
     };
     const bool left = w == 0, right = w == W - 1;
     if (left) zero_at(h + 1, 0);
@@ -147,22 +176,29 @@ __global__ __launch_bounds__(256) void bn_split16_kernel(
 // STATS: the workgroup also leaves the sum and the sum of squares of every output channel over its tile in
 // stats[workgroup][2][128] (expand1x1 channels co0..co0+63, then expand3x3's): the BatchNorm statistics of an apply-on-load
 // block without a pass over the concat buffer (fire_stats_finalize_kernel adds the tiles in index order, in fp64).
-template <int TWN, bool STATS = false>
+// H2: the planes and the weights are TWO fp16 pieces of x 2^k (bn_split16_kernel h2, prep_h2_*): three
+// v_mfma_f32_32x32x16_f16 per product (lh, hl, hh) instead of six bf16 ones, two planes through LDS instead of three; the
+// epilogue multiplies by the two inverse scales (powers of two: exact).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int TWN, bool STATS = false, bool H2 = false>
 __global__ __launch_bounds__(256, 2) void fire_expand_fwd_kernel(
     const __bf16* __restrict__ planes, const __bf16* __restrict__ w3t, const __bf16* __restrict__ w1t,
     const float* __restrict__ bias3, const float* __restrict__ bias1, float* __restrict__ y, int N, int KC, int H, int W,
-    int E, int y_ctot, int y_coff, int tiles_w, int tiles_h, int co_tiles, float* __restrict__ stats = nullptr) {
+    int E, int y_ctot, int y_coff, int tiles_w, int tiles_h, int co_tiles, float* __restrict__ stats = nullptr,
+    const float* __restrict__ inv_a = nullptr, const float* __restrict__ inv_w3 = nullptr,
+    const float* __restrict__ inv_w1 = nullptr) {
   constexpr int MR = 2;
+  constexpr int NPL = H2 ? 2 : 3;                        // planes (pieces) per operand
   constexpr int TH = 4, TW = 32 * TWN, PR = TH + 2, PC = TW + 2, NPOSP = PR * PC;
   constexpr int PLANE = NPOSP * 16;                      // bf16 per patch plane
   constexpr int PP = NPOSP * 2;                          // 16-byte pieces per plane
-  constexpr int PINS = (3 * PP + 63) / 64;               // wave instructions per patch
+  constexpr int PINS = (NPL * PP + 63) / 64;             // wave instructions per patch
   constexpr int PPER = (PINS + 3) / 4;                   // per wave
   constexpr int PATCH_B = PINS * 1024;                   // bytes (padded to whole instructions)
   constexpr int AROWS = 32 * MR;
   constexpr int TG = 2;                                  // tap slots per weight group
-  constexpr int AGRP = TG * 3 * AROWS * 16;              // bf16 per ring slot: [slot][plane][row][16 k]
-  constexpr int AINS = TG * 3 * MR;                      // wave instructions per group
+  constexpr int AGRP = TG * NPL * AROWS * 16;            // bf16 per ring slot: [slot][plane][row][16 k]
+  constexpr int AINS = TG * NPL * MR;                    // wave instructions per group
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* patch = reinterpret_cast<__bf16*>(smem_raw);   // [3 planes][NPOSP][16]
   __bf16* ring = reinterpret_cast<__bf16*>(smem_raw + PATCH_B);   // [2][AGRP]
@@ -177,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void fire_expand_fwd_kernel(
   const int co0 = cot * 32 * MR, oh0 = th * TH, ow0 = tw * TW;
   const int WP = W + 2;
   const unsigned pstride_b = (unsigned)(H + 2) * (unsigned)WP * 32u;          // bytes per plane
-  const size_t planes_b = (size_t)N * KC * 3 * pstride_b;
+  const size_t planes_b = (size_t)N * KC * NPL * pstride_b;
 
   // ---- patch: piece q = plane * PP + r * (2 PC) + cc lands at LDS byte 16 q; its global byte offset within the chunk
   const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(planes), 0, (int)planes_b, 0x00020000);
@@ -186,11 +222,11 @@ __global__ __launch_bounds__(256, 2) void fire_expand_fwd_kernel(
   for (int i = 0; i < PPER; ++i) {
     const int q = (i * 4 + wave) * 64 + lane;
     const int pl = q / PP, rem = q - pl * PP, r = rem / (2 * PC), cc = rem - r * (2 * PC);
-    pvoff[i] = q < 3 * PP ? (unsigned)pl * pstride_b + (unsigned)(r * WP) * 32u + (unsigned)cc * 16u : 0xfffffff0u;
+    pvoff[i] = q < NPL * PP ? (unsigned)pl * pstride_b + (unsigned)(r * WP) * 32u + (unsigned)cc * 16u : 0xfffffff0u;
   }
   const unsigned tile_b = (unsigned)(oh0 * WP + ow0) * 32u;
   auto load_patch = [&](int kc) {
-    const unsigned so = (unsigned)((n * KC + kc) * 3) * pstride_b + tile_b;
+    const unsigned so = (unsigned)((n * KC + kc) * NPL) * pstride_b + tile_b;
 #pragma unroll
     for (int i = 0; i < PPER; ++i) {
       const int t = i * 4 + wave;
@@ -208,9 +244,9 @@ __global__ __launch_bounds__(256, 2) void fire_expand_fwd_kernel(
   // ---- weight groups
   const size_t wplane = (size_t)E * 16;
   const __amdgpu_buffer_rsrc_t w3rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<__bf16*>(w3t), 0, (int)((size_t)9 * KC * 3 * wplane * 2), 0x00020000);
+      const_cast<__bf16*>(w3t), 0, (int)((size_t)9 * KC * NPL * wplane * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t w1rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<__bf16*>(w1t), 0, (int)((size_t)KC * 3 * wplane * 2), 0x00020000);
+      const_cast<__bf16*>(w1t), 0, (int)((size_t)KC * NPL * wplane * 2), 0x00020000);
   unsigned awoff[MR];
 #pragma unroll
   for (int m = 0; m < MR; ++m) awoff[m] = ((unsigned)min(co0 + m * 32 + (lane >> 1), E - 1) * 16u + 8u * (unsigned)(lane & 1)) * 2u;
@@ -219,16 +255,16 @@ __global__ __launch_bounds__(256, 2) void fire_expand_fwd_kernel(
     for (int i = 0; i < (AINS + 3) / 4; ++i) {
       const int t = i * 4 + wave;                        // instruction t = (j * 3 + plane) * MR + m
       if (t < AINS) {
-        const int m = t % MR, tp = t / MR, j = tp / 3, pl = tp - 3 * j;
+        const int m = t % MR, tp = t / MR, j = tp / NPL, pl = tp - NPL * j;
         const int s = g * TG + j;                        // tap slot 0..9; 5 = expand1x1
         __bf16* dst = ring + (size_t)slot * AGRP + (size_t)t * 64 * 8;
 #if defined(__HIP_DEVICE_COMPILE__)
         if (s == 5)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(w1rsrc, (__attribute__((address_space(3))) void*)dst, 16, awoff[m],
-                                                   (unsigned)(((size_t)kc * 3 + pl) * wplane * 2), 0, 0);
+                                                   (unsigned)(((size_t)kc * NPL + pl) * wplane * 2), 0, 0);
         else
           __builtin_amdgcn_raw_ptr_buffer_load_lds(w3rsrc, (__attribute__((address_space(3))) void*)dst, 16, awoff[m],
-                                                   (unsigned)((((size_t)(s < 5 ? s : s - 1) * KC + kc) * 3 + pl) * wplane * 2), 0, 0);
+                                                   (unsigned)((((size_t)(s < 5 ? s : s - 1) * KC + kc) * NPL + pl) * wplane * 2), 0, 0);
 #else
         (void)dst; (void)m; (void)pl; (void)s;
 #endif
@@ -243,34 +279,46 @@ __global__ __launch_bounds__(256, 2) void fire_expand_fwd_kernel(
     for (int t = 0; t < TWN; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc3[m][t][r] = 0.f; acc1[m][t][r] = 0.f; }
-  auto read_a = [&](const __bf16* slot, int j, bf16x8 (&a)[MR][3]) {
+  auto read_a = [&](const __bf16* slot, int j, bf16x8 (&a)[MR][NPL]) {
 #pragma unroll
     for (int m = 0; m < MR; ++m)
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
-        a[m][p] = *reinterpret_cast<const bf16x8*>(slot + ((j * 3 + p) * AROWS + m * 32 + l31) * 16 + 8 * half);
+      for (int p = 0; p < NPL; ++p)
+        a[m][p] = *reinterpret_cast<const bf16x8*>(slot + ((j * NPL + p) * AROWS + m * 32 + l31) * 16 + 8 * half);
   };
-  auto read_b = [&](int tap, bf16x8 (&b)[TWN][3]) {
+  auto read_b = [&](int tap, bf16x8 (&b)[TWN][NPL]) {
     const int kh = tap / 3, kw = tap - 3 * kh;
 #pragma unroll
     for (int t = 0; t < TWN; ++t) {
       const int pos = (wave + kh) * PC + 32 * t + l31 + kw;
 #pragma unroll
-      for (int p = 0; p < 3; ++p) b[t][p] = *reinterpret_cast<const bf16x8*>(patch + p * PLANE + pos * 16 + 8 * half);
+      for (int p = 0; p < NPL; ++p) b[t][p] = *reinterpret_cast<const bf16x8*>(patch + p * PLANE + pos * 16 + 8 * half);
     }
   };
   constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
-  auto mfma_slot = [&](f32x16 (&acc)[MR][TWN], const bf16x8 (&a)[MR][3], const bf16x8 (&b)[TWN][3]) {
+  auto mfma_slot = [&](f32x16 (&acc)[MR][TWN], const bf16x8 (&a)[MR][NPL], const bf16x8 (&b)[TWN][NPL]) {
+    if constexpr (H2) {
+      constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0};              // (lo, hi) (hi, lo) (hi, hi): smallest first
 #pragma unroll
-    for (int q = DLIO_SPLIT_Q0; q < 6; ++q)
+      for (int q = 0; q < 3; ++q)
 #pragma unroll
-      for (int m = 0; m < MR; ++m)
+        for (int m = 0; m < MR; ++m)
 #pragma unroll
-        for (int t = 0; t < TWN; ++t)
-          acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][PA[q]], b[t][PB[q]], acc[m][t], 0, 0, 0);
+          for (int t = 0; t < TWN; ++t)
+            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[m][HA[q]]),
+                                                               __builtin_bit_cast(f16x8, b[t][HB[q]]), acc[m][t], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int q = DLIO_SPLIT_Q0; q < 6; ++q)
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+          for (int t = 0; t < TWN; ++t)
+            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][PA[q]], b[t][PB[q]], acc[m][t], 0, 0, 0);
+    }
   };
   auto compute_group = [&](const __bf16* slot, int g) {
-    bf16x8 a[2][MR][3], b[TWN][3];
+    bf16x8 a[2][MR][NPL], b[TWN][NPL];
     read_a(slot, 0, a[0]);
     read_a(slot, 1, a[1]);
     const int s0 = g * TG;
@@ -333,6 +381,8 @@ __global__ __launch_bounds__(256, 2) void fire_expand_fwd_kernel(
   };
   using X1 = std::integral_constant<int, 0xB1>;         // quad_perm [1, 0, 3, 2]
   using X2 = std::integral_constant<int, 0x4E>;         // quad_perm [2, 3, 0, 1]
+  float isc[2] = {1.f, 1.f};
+  if constexpr (H2) { const float ia = inv_a[0]; isc[0] = ia * inv_w1[0]; isc[1] = ia * inv_w3[0]; }
 #pragma unroll
   for (int set = 0; set < 2; ++set) {
     const float* bias = set == 0 ? bias1 : bias3;
@@ -351,6 +401,7 @@ __global__ __launch_bounds__(256, 2) void fire_expand_fwd_kernel(
           const int co = co0 + 32 * m + 8 * rq + 4 * half + (lane & 3);
           if (row_ok && co < E && ow0 + 32 * t + 4 * (l31 >> 2) < W) {
             const float bv = bias ? bias[co] : 0.f;
+            if constexpr (H2) { a0 *= isc[set]; a1 *= isc[set]; a2 *= isc[set]; a3 *= isc[set]; }
             a0 += bv; a1 += bv; a2 += bv; a3 += bv;
             *reinterpret_cast<float4*>(yb + ((size_t)(set == 0 ? 0 : E) + co) * hw + 32 * t) = make_float4(a0, a1, a2, a3);
             if constexpr (STATS) {
@@ -425,25 +476,89 @@ __global__ __launch_bounds__(256) void fire_stats_finalize_kernel(
   }
 }
 
-template <int TWN>
-int launch_fire_fwd(const __bf16* planes, const __bf16* w3t, const __bf16* w1t, const float* bias3, const float* bias1,
-                    float* y, int N, int KC, int H, int W, int E, int y_ctot, int y_coff, hipStream_t s, float* stats = nullptr) {
-  constexpr int TH = 4, TW = 32 * TWN;
+template <int TWN, bool STATS, bool H2>
+int launch_fire_fwd_t(const __bf16* planes, const __bf16* w3t, const __bf16* w1t, const float* bias3, const float* bias1,
+                      float* y, int N, int KC, int H, int W, int E, int y_ctot, int y_coff, hipStream_t s, float* stats) {
+  constexpr int TH = 4, TW = 32 * TWN, NPL = H2 ? 2 : 3;
   const int tiles_w = cdiv(W, TW), tiles_h = cdiv(H, TH), co_tiles = cdiv(E, 64);
   const int64_t blocks = (int64_t)N * tiles_h * tiles_w * co_tiles;
   if (blocks <= 0 || blocks > 0x7fffffff) return DLIO_EINVAL;
-  constexpr int PINS = (3 * (TH + 2) * (TW + 2) * 2 + 63) / 64;
-  constexpr size_t lds = (size_t)PINS * 1024 + (size_t)2 * 2 * 3 * 64 * 16 * sizeof(__bf16);
-  if (stats) {
-    dlio_set_max_lds(reinterpret_cast<const void*>(&fire_expand_fwd_kernel<TWN, true>), (int)lds);
-    hipLaunchKernelGGL((fire_expand_fwd_kernel<TWN, true>), dim3((unsigned)blocks), dim3(256), lds, s, planes, w3t, w1t, bias3,
-                       bias1, y, N, KC, H, W, E, y_ctot, y_coff, tiles_w, tiles_h, co_tiles, stats);
-    return dlio_check_launch();
-  }
-  dlio_set_max_lds(reinterpret_cast<const void*>(&fire_expand_fwd_kernel<TWN>), (int)lds);
-  hipLaunchKernelGGL((fire_expand_fwd_kernel<TWN>), dim3((unsigned)blocks), dim3(256), lds, s, planes, w3t, w1t, bias3, bias1,
-                     y, N, KC, H, W, E, y_ctot, y_coff, tiles_w, tiles_h, co_tiles, (float*)nullptr);
+  constexpr int PINS = (NPL * (TH + 2) * (TW + 2) * 2 + 63) / 64;
+  constexpr size_t lds_k = (size_t)PINS * 1024 + (size_t)2 * 2 * NPL * 64 * 16 * sizeof(__bf16);
+  constexpr size_t lds = (STATS && lds_k < 4096) ? 4096 : lds_k;      // (the statistics epilogue uses 4 KB of it)
+  // two-piece format: the inverse scales sit behind the planes / the weight layouts
+  const float* inv_a = H2 ? reinterpret_cast<const float*>(planes + (size_t)N * KC * 2 * ((size_t)(H + 2) * (W + 2) * 16)) : nullptr;
+  const float* inv_w3 = H2 ? reinterpret_cast<const float*>(w3t) + (size_t)9 * KC * E * 16 : nullptr;
+  const float* inv_w1 = H2 ? reinterpret_cast<const float*>(w1t) + (size_t)KC * E * 16 : nullptr;
+  dlio_set_max_lds(reinterpret_cast<const void*>(&fire_expand_fwd_kernel<TWN, STATS, H2>), (int)lds);
+  hipLaunchKernelGGL((fire_expand_fwd_kernel<TWN, STATS, H2>), dim3((unsigned)blocks), dim3(256), lds, s, planes, w3t, w1t, bias3,
+                     bias1, y, N, KC, H, W, E, y_ctot, y_coff, tiles_w, tiles_h, co_tiles, stats, inv_a, inv_w3, inv_w1);
   return dlio_check_launch();
+}
+
+template <int TWN>
+int launch_fire_fwd(const __bf16* planes, const __bf16* w3t, const __bf16* w1t, const float* bias3, const float* bias1,
+                    float* y, int N, int KC, int H, int W, int E, int y_ctot, int y_coff, hipStream_t s, float* stats = nullptr,
+                    int fmt = 0) {
+#define FIRE_GO(ST, HH) launch_fire_fwd_t<TWN, ST, HH>(planes, w3t, w1t, bias3, bias1, y, N, KC, H, W, E, y_ctot, y_coff, s, stats)
+  if (fmt) return stats ? FIRE_GO(true, true) : FIRE_GO(false, true);
+  return stats ? FIRE_GO(true, false) : FIRE_GO(false, false);
+#undef FIRE_GO
+}
+
+// ---- weights as two fp16 pieces of w * 2^k: layout [tap][chunk][2][n][16] (the split-bf16 layout with two planes), behind
+// it { 2^-k, 2^k } as floats.  2^k maps the tensor's largest magnitude into [2^13, 2^14].
+__global__ __launch_bounds__(256) void prep_h2_amax_kernel(const DlioPrepItem* __restrict__ items, DlioPrepItem single) {
+  __shared__ float wm[4];
+  const DlioPrepItem it = items ? items[blockIdx.x] : single;
+  const int64_t n = (int64_t)it.Cout * it.Cin * it.taps;
+  float b = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 256) b = fmaxf(b, fabsf(it.w[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) b = fmaxf(b, __shfl_xor(b, o, 64));
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = b;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    b = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    const float sc = (b > 0.f && b < 3.0e38f) ? exp2f(floorf(log2f(16384.f / b))) : 1.f;
+    const int K = it.mode == 0 ? it.Cin : it.Cout, Nn = it.mode == 0 ? it.Cout : it.Cin;
+    float* tail = it.wt + (size_t)it.taps * ((K + 15) >> 4) * Nn * 16;
+    tail[0] = 1.f / sc;
+    tail[1] = sc;
+  }
+}
+
+__global__ void prep_h2_kernel(const DlioPrepItem* __restrict__ items, int n_items, int64_t total, DlioPrepItem single) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int lo = 0, hi = n_items - 1;                 // last item with start <= i
+    while (items && lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (items[mid].start <= i) lo = mid; else hi = mid - 1;
+    }
+    const DlioPrepItem it = items ? items[lo] : single;
+    const int64_t e = i - it.start;
+    const int K = it.mode == 0 ? it.Cin : it.Cout, Nn = it.mode == 0 ? it.Cout : it.Cin;
+    const int KC = (K + 15) >> 4;
+    const int kk = (int)(e & 15);
+    int64_t t = e >> 4;
+    const int n = (int)(t % Nn); t /= Nn;
+    const int kc = (int)(t % KC);
+    const int tap = (int)(t / KC);
+    const int k = kc * 16 + kk;
+    float v = 0.f;
+    if (k < K) {
+      if (it.mode == 0) v = it.w[((int64_t)n * it.Cin + k) * it.taps + tap];
+      else v = it.w[((int64_t)k * it.Cin + n) * it.taps + (it.taps - 1 - tap)];
+    }
+    const float sc = it.wt[(size_t)it.taps * KC * Nn * 16 + 1];
+    const float vs = v * sc;
+    const _Float16 h = (_Float16)vs;
+    const _Float16 l = (_Float16)(vs - (float)h);
+    _Float16* wt = reinterpret_cast<_Float16*>(it.wt);
+    const int64_t base = (((int64_t)tap * KC + kc) * 2) * Nn * 16 + (int64_t)n * 16 + kk;
+    wt[base] = h;
+    wt[base + (int64_t)Nn * 16] = l;
+  }
 }
 
 }  // namespace
@@ -460,8 +575,12 @@ extern "C" int dlio_bn_split16(const float* x, int N, int x_ctot, int x_coff, in
                                dlio_stream_t stream) {
   // mode 0: train, statistics + apply; 1: train, statistics partials only (-> ws); 2: train, apply from the partials in
   // ws; 3: eval (mean / scale are inputs, ws unused)
+  // + 16: the planes as TWO fp16 pieces of x 2^k with 2^-k behind them (train modes only: the bound on |BN(x)| that gives
+  // 2^k needs batch statistics)
+  const int h2 = (mode & 16) ? 1 : 0;
+  mode &= ~16;
   if (!x || !planes || !mean || !scale || N <= 0 || C <= 0 || H <= 0 || W <= 0 || mode < 0 || mode > 3 ||
-      !(count_scale >= 1.0))
+      !(count_scale >= 1.0) || (h2 && (mode == 3 || mode == 1)))
     return DLIO_EINVAL;
   if ((W & 3) || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(planes)) & 15))
     return DLIO_EUNSUP;
@@ -486,14 +605,41 @@ extern "C" int dlio_bn_split16(const float* x, int N, int x_ctot, int x_coff, in
   hipLaunchKernelGGL(bn_split16_kernel, grid, dim3(256), 0, s, x, x_ctot, x_coff,
                      mode == 3 ? (const double*)nullptr : reinterpret_cast<const double*>(ws), splits,
                      (double)N * HW * count_scale, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale,
-                     y, y_ctot, y_coff, reinterpret_cast<__bf16*>(planes), N, C, H, W, post_relu);
+                     y, y_ctot, y_coff, reinterpret_cast<__bf16*>(planes), N, C, H, W, post_relu, h2);
+  return dlio_check_launch();
+}
+
+extern "C" size_t dlio_conv_h2_prep_floats(int Cout, int Cin, int taps, int mode) {
+  if (Cout <= 0 || Cin <= 0 || taps <= 0 || (mode != 0 && mode != 1)) return 0;
+  const int K = mode == 0 ? Cin : Cout, Nn = mode == 0 ? Cout : Cin;
+  return (size_t)taps * ((K + 15) >> 4) * Nn * 16 + 4;      // two fp16 planes = one float per element, + the scales
+}
+
+extern "C" int dlio_conv_h2_prep(const float* w, void* wt, int Cout, int Cin, int taps, int mode, dlio_stream_t stream) {
+  if (!w || !wt || Cout <= 0 || Cin <= 0 || taps <= 0 || (mode != 0 && mode != 1)) return DLIO_EINVAL;
+  const int K = mode == 0 ? Cin : Cout, Nn = mode == 0 ? Cout : Cin;
+  const int64_t total = (int64_t)taps * ((K + 15) >> 4) * Nn * 16;
+  const DlioPrepItem one{w, reinterpret_cast<float*>(wt), Cout, Cin, taps, mode, 0};
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(prep_h2_amax_kernel, dim3(1), dim3(256), 0, s, (const DlioPrepItem*)nullptr, one);
+  hipLaunchKernelGGL(prep_h2_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, s, (const DlioPrepItem*)nullptr, 1, total, one);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_conv_h2_prep_batched(const DlioPrepItem* items_dev, int n_items, int64_t total, dlio_stream_t stream) {
+  if (!items_dev || n_items <= 0 || total <= 0) return DLIO_EINVAL;
+  hipStream_t s = as_stream(stream);
+  const DlioPrepItem none{nullptr, nullptr, 0, 0, 0, 0, 0};
+  hipLaunchKernelGGL(prep_h2_amax_kernel, dim3((unsigned)n_items), dim3(256), 0, s, items_dev, none);
+  hipLaunchKernelGGL(prep_h2_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, s, items_dev, n_items, total, none);
   return dlio_check_launch();
 }
 
 extern "C" int dlio_fire_expand_fwd(const void* planes, const void* w3t, const void* w1t, const float* bias3,
                                     const float* bias1, float* y, int N, int S, int H, int W, int E, int y_ctot,
-                                    int y_coff, dlio_stream_t stream) {
-  if (!planes || !w3t || !w1t || !y || N <= 0 || S <= 0 || H <= 0 || W <= 0 || E <= 0 || y_ctot < y_coff + 2 * E || y_coff < 0)
+                                    int y_coff, int planes_fmt, dlio_stream_t stream) {
+  if (!planes || !w3t || !w1t || !y || N <= 0 || S <= 0 || H <= 0 || W <= 0 || E <= 0 || y_ctot < y_coff + 2 * E || y_coff < 0 ||
+      planes_fmt < 0 || planes_fmt > 1)
     return DLIO_EINVAL;
   const int KC = (S + 15) / 16;
   if ((W & 3) || (reinterpret_cast<uintptr_t>(y) & 15) || (reinterpret_cast<uintptr_t>(planes) & 15)) return DLIO_EUNSUP;
@@ -504,8 +650,8 @@ extern "C" int dlio_fire_expand_fwd(const void* planes, const void* w3t, const v
   const __bf16* pl = reinterpret_cast<const __bf16*>(planes);
   const __bf16* w3 = reinterpret_cast<const __bf16*>(w3t);
   const __bf16* w1 = reinterpret_cast<const __bf16*>(w1t);
-  return W > 32 ? launch_fire_fwd<2>(pl, w3, w1, bias3, bias1, y, N, KC, H, W, E, y_ctot, y_coff, s)
-                : launch_fire_fwd<1>(pl, w3, w1, bias3, bias1, y, N, KC, H, W, E, y_ctot, y_coff, s);
+  return W > 32 ? launch_fire_fwd<2>(pl, w3, w1, bias3, bias1, y, N, KC, H, W, E, y_ctot, y_coff, s, nullptr, planes_fmt)
+                : launch_fire_fwd<1>(pl, w3, w1, bias3, bias1, y, N, KC, H, W, E, y_ctot, y_coff, s, nullptr, planes_fmt);
 }
 
 static void fire_tiles(int N, int H, int W, int E, int& tiles, int& co_tiles) {
@@ -526,9 +672,10 @@ extern "C" int dlio_fire_expand_fwd_stats(const void* planes, const void* w3t, c
                                           int y_coff, const float* gamma1, const float* beta1, float* running_mean1,
                                           float* running_var1, const float* gamma3, const float* beta3, float* running_mean3,
                                           float* running_var3, float eps, float momentum, float* mean, float* invstd,
-                                          float* scale, float* shift, void* ws, size_t ws_bytes, dlio_stream_t stream) {
+                                          float* scale, float* shift, void* ws, size_t ws_bytes, int planes_fmt,
+                                          dlio_stream_t stream) {
   if (!planes || !w3t || !w1t || !y || !mean || !invstd || !scale || !ws || N <= 0 || S <= 0 || H <= 0 || W <= 0 || E <= 0 ||
-      y_ctot < y_coff + 2 * E || y_coff < 0)
+      y_ctot < y_coff + 2 * E || y_coff < 0 || planes_fmt < 0 || planes_fmt > 1)
     return DLIO_EINVAL;
   const int KC = (S + 15) / 16;
   if ((W & 3) || (reinterpret_cast<uintptr_t>(y) & 15) || (reinterpret_cast<uintptr_t>(planes) & 15)) return DLIO_EUNSUP;
@@ -543,8 +690,8 @@ extern "C" int dlio_fire_expand_fwd_stats(const void* planes, const void* w3t, c
   int rc;
   {
     DlioProfScope prof(3, s, 2.0 * P * E * (double)S * 10, 4.0 * P * 2 * E + 6.0 * P * KC * 16);
-    rc = W > 32 ? launch_fire_fwd<2>(pl, w3, w1, bias3, bias1, y, N, KC, H, W, E, y_ctot, y_coff, s, st)
-                : launch_fire_fwd<1>(pl, w3, w1, bias3, bias1, y, N, KC, H, W, E, y_ctot, y_coff, s, st);
+    rc = W > 32 ? launch_fire_fwd<2>(pl, w3, w1, bias3, bias1, y, N, KC, H, W, E, y_ctot, y_coff, s, st, planes_fmt)
+                : launch_fire_fwd<1>(pl, w3, w1, bias3, bias1, y, N, KC, H, W, E, y_ctot, y_coff, s, st, planes_fmt);
   }
   if (rc) return rc;
   int tiles, co_tiles;

@@ -301,7 +301,7 @@ class _CBR:
         if split_into is not None:
             # the squeeze BatchNorm of a fused Fire block: activated tensor + its three-piece bf16 planes in one pass
             prm = ops.bn_split16(raw, raw_ctot, raw_coff, gamma, beta, eps, momentum, rmean, rvar, out, out_ctot, out_coff,
-                                 split_into, N, Cout, d.OH, d.OW, training, post_relu)
+                                 split_into[0], N, Cout, d.OH, d.OW, training, post_relu, fmt=split_into[1])
             return d, prm
         if stats_into is not None:
             prm = ops.bn_train_stats(raw, N, raw_ctot, raw_coff, Cout, OHW, pre_relu, gamma, eps, momentum, rmean, rvar,
@@ -448,6 +448,7 @@ def conv_dgrad(dy, weight, d, dx, dx_ctot, dx_coff, residual=None, r_ctot=0, r_c
 
 _CONV_BX3 = [os.environ.get("DLIO_CONV_BX3", "1") != "0"]
 _FIRE_FUSED = [os.environ.get("DLIO_FIRE_FUSED", "1") != "0"]
+_FIRE_H2 = [os.environ.get("DLIO_FIRE_H2", "1") != "0"]         # fused Fire forward on two fp16 pieces (training)
 _FIRE_STATS = [os.environ.get("DLIO_FIRE_STATS", "1") != "0"]   # apply-on-load blocks: BatchNorm statistics from the expand launch
 _PAIR_FUSE = [os.environ.get("DLIO_PAIR_FUSE", "1") != "0"]   # gap + add / sub + fc1 + act of the lidar head as one launch
 _SE_FC = [os.environ.get("DLIO_SE_FC", "1") != "0"]         # the SELayer's fc pair as one launch (csrc/se_fc.hip)
@@ -688,23 +689,26 @@ class FireFn(Function):
         fused = (_FIRE_FUSED[0] and x.is_cuda and E1 == E3 and W % 4 == 0 and _CONV_BX3[0]
                  and tuple(e3w.shape[2:]) == (3, 3) and tuple(e1w.shape[2:]) == (1, 1))
         planes = ops.fire_planes(N, S_, H, W, x.device) if fused else None
+        # training: the planes and the expand weights as two fp16 pieces (three MFMAs per product instead of six)
+        h2 = 1 if (fused and training and _FIRE_H2[0] and ops._SYNC_BN[0] is None) else 0
         d_s, prm_s = _CBR.forward(x, Cin, 0, Cin, H, W, sw, sb, sg, sbe, srm, srv, (1, 1), (0, 0),
                                   training, momentum, eps, False, True, raw_s, S_, 0, act_s, S_, 0, N,
-                                  in_aff=x_aff, split_into=planes)
+                                  in_aff=x_aff, split_into=(planes, h2) if fused else None)
         raw_e = _new((N, CE, H, W), x)
         res = x if bypass else None
         # an apply-on-load block takes its BatchNorm statistics out of the expand launch's epilogue (tile sums + one small
         # finalising launch) instead of a pass over the concat buffer
         epi = fused and defer and training and _FIRE_STATS[0] and ops._SYNC_BN[0] is None
+        if fused:
+            w3p, w1p = ((ops.conv_h2_prepped(e3w), ops.conv_h2_prepped(e1w)) if h2
+                        else (ops.conv_bx3_prepped(e3w, 0), ops.conv_bx3_prepped(e1w, 0)))
         if epi:
             aff, inv = _new((3, CE), x), _new((CE,), x)
-            ops.fire_expand_fwd_stats(planes, ops.conv_bx3_prepped(e3w, 0), ops.conv_bx3_prepped(e1w, 0), e3b, e1b, raw_e,
-                                      N, S_, H, W, E1, CE, 0, (e1g, e1be, e1rm, e1rv), (e3g, e3be, e3rm, e3rv), eps, momentum,
-                                      aff[0], inv, aff[1], aff[2])
+            ops.fire_expand_fwd_stats(planes, w3p, w1p, e3b, e1b, raw_e, N, S_, H, W, E1, CE, 0, (e1g, e1be, e1rm, e1rv),
+                                      (e3g, e3be, e3rm, e3rv), eps, momentum, aff[0], inv, aff[1], aff[2], fmt=h2)
             del planes
         elif fused:
-            ops.fire_expand_fwd(planes, ops.conv_bx3_prepped(e3w, 0), ops.conv_bx3_prepped(e1w, 0), e3b, e1b, raw_e,
-                                N, S_, H, W, E1, CE, 0)
+            ops.fire_expand_fwd(planes, w3p, w1p, e3b, e1b, raw_e, N, S_, H, W, E1, CE, 0, fmt=h2)
             del planes
         # both expand data gradients in one launch (backward): the layouts are fetched here, where the weights are the
         # long-lived Parameters the cache knows

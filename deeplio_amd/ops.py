@@ -105,7 +105,8 @@ class _PrepItemC(_ct.Structure):
 class _PrepCache:
     """mode 0 / 1: fp32-MFMA layouts (forward / data gradient) of any conv weight; mode 2 / 3: the
     split-bf16 layouts (conv_bx3.hip) of 3x3 / 1x1 weights, forward / data gradient; mode 4 / 5: the
-    native bf16 layouts of the mixed-precision path (conv_bf16.hip)"""
+    native bf16 layouts of the mixed-precision path (conv_bf16.hip); mode 6 / 7: two fp16 pieces of w 2^k + the scales
+    (fire_expand.hip)"""
 
     def __init__(self):
         self.epoch = 0
@@ -117,6 +118,8 @@ class _PrepCache:
     @staticmethod
     def _floats(w, mode):
         Cout, Cin, KH, KW = w.shape
+        if mode >= 6:
+            return lib.dlio_conv_h2_prep_floats(Cout, Cin, KH * KW, mode - 6)
         if mode >= 4:
             return (lib.dlio_conv_bf16_prep_elems(Cout, Cin, KH * KW, mode - 4) + 1) // 2     # bf16 in fp32 storage
         if mode >= 2:
@@ -128,7 +131,7 @@ class _PrepCache:
         """index-space size of one item in its family's batched kernel"""
         Cout, Cin, KH, KW = w.shape
         if mode >= 2:
-            K, Nn = (Cin, Cout) if mode in (2, 4) else (Cout, Cin)
+            K, Nn = (Cin, Cout) if mode in (2, 4, 6) else (Cout, Cin)
             return KH * KW * ((K + 15) // 16) * Nn * 16
         return lib.dlio_conv2d_prep_weight_floats(Cout, Cin, KH, KW, mode)
 
@@ -149,7 +152,10 @@ class _PrepCache:
                 self._refresh_all(dev, cur)
             if e["epoch"] != self.epoch or e["version"] != w._version:     # newly registered / batching off
                 Cout, Cin, KH, KW = w.shape
-                if mode >= 4:
+                if mode >= 6:
+                    check(lib.dlio_conv_h2_prep(_ptr(w), _ptr(e["out"]), Cout, Cin, KH * KW, mode - 6, _stream()),
+                          "conv_h2_prep")
+                elif mode >= 4:
                     check(lib.dlio_conv_bf16_prep(_ptr(w), _ptr(e["out"]), Cout, Cin, KH * KW, mode - 4, _stream()),
                           "conv_bf16_prep")
                 elif mode >= 2:
@@ -192,7 +198,8 @@ class _PrepCache:
         done = []
         for family, fn, name in ((0, lib.dlio_conv2d_prep_weights_batched, "conv2d_prep_weights_batched"),
                                  (1, lib.dlio_conv3x3_bx3_prep_batched, "conv3x3_bx3_prep_batched"),
-                                 (2, lib.dlio_conv_bf16_prep_batched, "conv_bf16_prep_batched")):
+                                 (2, lib.dlio_conv_bf16_prep_batched, "conv_bf16_prep_batched"),
+                                 (3, lib.dlio_conv_h2_prep_batched, "conv_h2_prep_batched")):
             t = self._table(dev, family)
             if t is None:
                 continue
@@ -256,6 +263,12 @@ def conv_bx3_prepped(w, mode):
 
 
 conv3x3_bx3_prepped = conv_bx3_prepped
+
+
+def conv_h2_prepped(w, mode=0):
+    """cached two-piece fp16 layout of a 3x3 or 1x1 weight (dlio_conv_h2_prep; the fused Fire forward's planes_fmt 1)"""
+    _chk(w)
+    return _PREP.get(w, mode + 6)
 
 
 def conv1x1_bx3_prep(w, mode, out=None):
@@ -597,9 +610,11 @@ def fire_planes(N, S, H, W, device):
 
 
 def bn_split16(x, x_ctot, x_coff, gamma, beta, eps, momentum, running_mean, running_var, y, y_ctot, y_coff, planes,
-               N, C_, H, W, training, post_relu=True):
+               N, C_, H, W, training, post_relu=True, fmt=0):
     """the squeeze BatchNorm (+ ReLU) of a Fire block: activated fp32 tensor y (or None) + the split planes -> prm [3][C]
     (train: batch statistics, SyncBN-aware like bn_train_apply; eval: running statistics)"""
+    if fmt and (not training or _SYNC_BN[0] is not None):
+        raise ValueError("the two-piece planes exist in train mode with local batch statistics only")
     if not training:
         prm = bn_eval_params(running_mean, running_var, gamma, eps)
         check(lib.dlio_bn_split16(_ptr(x), N, x_ctot, x_coff, C_, H, W, int(post_relu), _ptr(gamma), _ptr(beta),
@@ -613,7 +628,7 @@ def bn_split16(x, x_ctot, x_coff, gamma, beta, eps, momentum, running_mean, runn
         check(lib.dlio_bn_split16(_ptr(x), N, x_ctot, x_coff, C_, H, W, int(post_relu), _ptr(gamma), _ptr(beta),
                                   float(eps), float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(prm[0]),
                                   _ptr(prm[1]), _ptr(prm[2]), _ptr(y), y_ctot, y_coff, _ptr(planes), _ptr(ws), ws.numel(),
-                                  mode, float(scale), _stream()), "bn_split16")
+                                  mode + (16 if fmt else 0), float(scale), _stream()), "bn_split16")
     sync = _SYNC_BN[0]
     if sync is None:
         call(0, 1.0)
@@ -624,16 +639,17 @@ def bn_split16(x, x_ctot, x_coff, gamma, beta, eps, momentum, running_mean, runn
     return prm
 
 
-def fire_expand_fwd(planes, w3t, w1t, bias3, bias1, y, N, S, H, W, E, y_ctot, y_coff):
+def fire_expand_fwd(planes, w3t, w1t, bias3, bias1, y, N, S, H, W, E, y_ctot, y_coff, fmt=0):
     """y[:, y_coff : y_coff + E] = expand1x1, y[:, y_coff + E : y_coff + 2 E] = expand3x3 of the split squeeze
-    activation (w3t / w1t = conv_bx3_prepped(w, 0) of the two layers)"""
+    activation (w3t / w1t = conv_bx3_prepped(w, 0) of the two layers; fmt 1: two-piece planes (bn_split16 fmt=1) and
+    conv_h2_prepped weights)"""
     check(lib.dlio_fire_expand_fwd(_ptr(planes), _ptr(w3t), _ptr(w1t), _ptr(bias3), _ptr(bias1), _ptr(y), N, S, H, W, E,
-                                   y_ctot, y_coff, _stream()), "fire_expand_fwd")
+                                   y_ctot, y_coff, int(fmt), _stream()), "fire_expand_fwd")
     return y
 
 
 def fire_expand_fwd_stats(planes, w3t, w1t, bias3, bias1, y, N, S, H, W, E, y_ctot, y_coff, set1, set3, eps, momentum,
-                          mean, invstd, scale, shift):
+                          mean, invstd, scale, shift, fmt=0):
     """fire_expand_fwd + the train-mode BatchNorm statistics of both expand layers from the launch's own tile sums
     (set = (gamma, beta, running_mean, running_var)); mean / invstd / scale / shift: rows of 2 E floats"""
     nbytes = lib.dlio_fire_expand_stats_ws_bytes(N, H, W, E)
@@ -642,7 +658,7 @@ def fire_expand_fwd_stats(planes, w3t, w1t, bias3, bias1, y, N, S, H, W, E, y_ct
                                          y_ctot, y_coff, _ptr(set1[0]), _ptr(set1[1]), _ptr(set1[2]), _ptr(set1[3]),
                                          _ptr(set3[0]), _ptr(set3[1]), _ptr(set3[2]), _ptr(set3[3]), float(eps),
                                          float(momentum), _ptr(mean), _ptr(invstd), _ptr(scale), _ptr(shift), _ptr(ws),
-                                         ws.numel(), _stream()), "fire_expand_fwd_stats")
+                                         ws.numel(), int(fmt), _stream()), "fire_expand_fwd_stats")
     return y
 
 

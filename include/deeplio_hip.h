@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 225
+#define DLIO_ABI_VERSION 226
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);           /* "gfx950" */
@@ -206,7 +206,16 @@ int dlio_bn_split16(const float* x, int N, int x_ctot, int x_coff, int C, int H,
                     float* running_var, float* mean, float* invstd, float* scale, float* y, int y_ctot, int y_coff,
                     void* planes, void* ws, size_t ws_bytes, int mode, double count_scale, dlio_stream_t stream);
 int dlio_fire_expand_fwd(const void* planes, const void* w3t, const void* w1t, const float* bias3, const float* bias1,
-                         float* y, int N, int S, int H, int W, int E, int y_ctot, int y_coff, dlio_stream_t stream);
+                         float* y, int N, int S, int H, int W, int E, int y_ctot, int y_coff, int planes_fmt,
+                         dlio_stream_t stream);
+/* planes_fmt 1 -- the two-piece format: planes written by dlio_bn_split16 with mode + 16 (train modes 0 / 2 only: two fp16
+ * pieces of x 2^k per value, [N][ceil(S/16)][2][H + 2][W + 2][16], 2^-k as a float behind them; same allocation size) and
+ * weights from dlio_conv_h2_prep (mode 0; two fp16 pieces of w 2^j, [tap][chunk][2][n][16], then { 2^-j, 2^j }): three
+ * v_mfma_f32_32x32x16_f16 per product instead of six bf16 ones, error ~1e-7 of the result.  2^k comes from
+ * |BN(x)| <= |beta| + |gamma| sqrt(N H W), which holds for batch statistics; 2^j from the weight tensor's largest magnitude. */
+size_t dlio_conv_h2_prep_floats(int Cout, int Cin, int taps, int mode);
+int dlio_conv_h2_prep(const float* w, void* wt, int Cout, int Cin, int taps, int mode, dlio_stream_t stream);
+int dlio_conv_h2_prep_batched(const DlioPrepItem* items_dev, int n_items, int64_t total, dlio_stream_t stream);
 /* The same launch that also leaves per-tile channel sums, + one small launch that turns them into the train-mode BatchNorm
  * statistics of BOTH expand layers (mean / invstd / scale = gamma * invstd / shift = beta over the 2 E channels of the concat
  * buffer, running statistics updated with `momentum`): an apply-on-load block (functional.FireFn(defer=True)) needs no pass
@@ -217,7 +226,7 @@ int dlio_fire_expand_fwd_stats(const void* planes, const void* w3t, const void* 
                                const float* beta1, float* running_mean1, float* running_var1, const float* gamma3,
                                const float* beta3, float* running_mean3, float* running_var3, float eps, float momentum,
                                float* mean, float* invstd, float* scale, float* shift, void* ws, size_t ws_bytes,
-                               dlio_stream_t stream);
+                               int planes_fmt, dlio_stream_t stream);
 /* dst [planes][HU][WU] = src [planes][OH][OW] with SH-1 / SW-1 zeros inserted between rows /
  * columns (and zero tail rows/columns up to HU, WU): turns the data gradient of a strided
  * convolution into dlio_conv2d_fwd with stride 1 on the data-gradient weight layout

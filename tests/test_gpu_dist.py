@@ -82,7 +82,7 @@ def _single_process(dev, pin=True):
     from deeplio_amd import functional as Fh
     from deeplio_amd.trainer import TrainStep
     saved = list(Fh._BX3_1X1_MIN)
-    saved_small, saved_stats = Fh._BN_SMALL[0], Fh._FIRE_STATS[0]
+    saved_small, saved_stats, saved_h2 = Fh._BN_SMALL[0], Fh._FIRE_STATS[0], Fh._FIRE_H2[0]
     if pin:
         Fh._BX3_1X1_MIN[:] = [int(v) for v in SAME_KERNELS.split(",")]
     else:
@@ -91,6 +91,7 @@ def _single_process(dev, pin=True):
         # same statistics to 1e-7, which the ReLU masks amplify to 1e-3 in the encoder gradients like any other rounding)
         Fh._BN_SMALL[0] = False
         Fh._FIRE_STATS[0] = False           # (and the statistics pass instead of the expand launch's tile sums)
+        Fh._FIRE_H2[0] = False              # (and the three-piece planes: the two-piece ones need local batch statistics)
     try:
         ts = TrainStep(make_cfg(), SHAPE, dev, GB)
         gc.fill_state(ts.model, seed=77)
@@ -99,7 +100,7 @@ def _single_process(dev, pin=True):
         torch.cuda.synchronize()
     finally:
         Fh._BX3_1X1_MIN[:] = saved
-        Fh._BN_SMALL[0], Fh._FIRE_STATS[0] = saved_small, saved_stats
+        Fh._BN_SMALL[0], Fh._FIRE_STATS[0], Fh._FIRE_H2[0] = saved_small, saved_stats, saved_h2
     bufs = {k: v.detach().cpu() for k, v in ts.model.named_buffers() if k.endswith("running_mean") or k.endswith("running_var")}
     return float(loss), ts.optimizer.grad.cpu().clone(), bufs, ts
 

@@ -1244,6 +1244,31 @@ def test_fire_expand_pair_fused_matches_fp64(dev, case, training):
         assert rel_err(r1a, 0.9 * r1o.double() + 0.1 * mu64[:E].to(dev)) < 2e-6
         assert rel_err(v1a, 0.9 * v1o.double() + 0.1 * var64[:E].to(dev) * cnt / (cnt - 1)) < 2e-6
         assert rel_err(r3, 0.81 * r3o.double() + 0.19 * mu64[E:].to(dev)) < 2e-6
+        # the two-piece format (planes_fmt 1): planes and weights as two fp16 pieces of x 2^k, three MFMAs per product;
+        # the same activated tensor and statistics, the expand outputs to the same distance from fp64
+        act_h = torch.empty(N, S, H, W, device=dev)
+        planes_h = ops.fire_planes(N, S, H, W, dev)
+        planes_h.fill_(0x7f)
+        rmh, rvh = rm.to(dev), rv.to(dev)
+        prm_h = ops.bn_split16(rawd, S + 3, 2, gd, bd, 1e-5, 0.1, rmh, rvh, act_h, S, 0, planes_h, N, S, H, W, True, fmt=1)
+        assert torch.equal(act_h, act_b) and torch.equal(prm_h, prm_b) and torch.equal(rmh, rm2)
+        w3d, w1d = w3.to(dev), w1.to(dev)
+        w3h, w1h = ops.conv_h2_prepped(w3d), ops.conv_h2_prepped(w1d)
+        yh = torch.zeros(N, 2 * E + 3, H, W, device=dev)
+        ops.fire_expand_fwd(planes_h, w3h, w1h, b3.to(dev), b1.to(dev), yh, N, S, H, W, E, 2 * E + 3, 1, fmt=1)
+        e1h, e3h = rel_err(yh[:, 1:1 + E], ref1), rel_err(yh[:, 1 + E:1 + 2 * E], ref3)
+        print("two-piece fp16: expand1x1 %.2e expand3x3 %.2e (three-piece bf16: %.2e %.2e)" % (
+            e1h, e3h, rel_err(yb[:, 1:1 + E], ref1), rel_err(yb[:, 1 + E:1 + 2 * E], ref3)))
+        assert e1h < 3e-6 and e3h < 3e-6
+        assert float(yh[:, :1].abs().max()) == 0 and float(yh[:, 1 + 2 * E:].abs().max()) == 0
+        yh2 = torch.zeros_like(yh)
+        ops.fire_expand_fwd_stats(planes_h, w3h, w1h, b3.to(dev), b1.to(dev), yh2, N, S, H, W, E, 2 * E + 3, 1, (g1, be1, r1, v1),
+                                  (g3, be3, r3, v3), 1e-5, 0.1, aff[0], inv, aff[1], aff[2], fmt=1)
+        assert torch.equal(yh2, yh)
+        ydh = yh[:, 1:1 + 2 * E].double()
+        assert rel_err(aff[0], ydh.mean((0, 2, 3))) < 2e-6
+        with pytest.raises((ValueError, RuntimeError)):
+            ops.bn_split16(rawd, S + 3, 2, gd, bd, 1e-5, 0.1, rmh, rvh, act_h, S, 0, planes_h, N, S, H, W, False, fmt=1)
     # the planes hold the exact three-way split: hi + mid + lo == activated value, zero border
     KC = (S + 15) // 16
     pv = planes.view(torch.bfloat16).view(N, KC, 3, H + 2, W + 2, 16).float().sum(2)      # [N][KC][H+2][W+2][16]
