@@ -57,6 +57,8 @@ SIGNATURES = {
     "dlio_conv3x3_bx3_prep": (_i, [_p, _p, _i, _i, _i, _p]),
     "dlio_conv3x3_bx3_prep_batched": (_i, [_p, _i, _i64, _p]),
     "dlio_conv3x3_bx3_fwd": (_i, [_p, _p, _p, _p, _p, _cd, _p]),
+    "dlio_conv3x3_h2_ok": (_i, [_cd]),
+    "dlio_conv3x3_h2_fwd": (_i, [_p, _p, _p, _p, _p, _p, _cd, _p]),
     "dlio_conv3x3_bx3_ws_bytes": (_sz, [_cd]),
     "dlio_conv3x3_bx3_fwd_ws": (_i, [_p, _p, _p, _p, _p, _p, _sz, _cd, _p]),
     "dlio_fire_planes_bytes": (_sz, [_i, _i, _i, _i]),
@@ -87,7 +89,7 @@ SIGNATURES = {
     "dlio_bn_coop_fwd": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p,
                               _p, _i, _i, _p, _p, _p, _p, _i, _i, _p, _i, _i, _p, _p, _p]),
     "dlio_bn_coop_bwd": (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i,
-                              _p, _p, _p]),
+                              _p, _p, _p, _p]),
     "dlio_zero_upsample2d": (_i, [_p, _p, _i64, _i, _i, _i, _i, _i, _i, _p]),
     "dlio_phase_interleave2d": (_i, [_p, _i, _i, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     "dlio_conv2d_dgrad_strided": (_i, [_p, _p, _p, _cd, _p]),

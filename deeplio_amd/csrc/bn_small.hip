@@ -353,12 +353,13 @@ __global__ __launch_bounds__(T) void bn_coop_bwd_kernel(
     const float* __restrict__ dy, int dy_ctot, int dy_coff, const float* __restrict__ x, int x_ctot, int x_coff, int N, int C,
     int C1, BnSet s1, BnSet s2, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ scale, float* __restrict__ dx1, float* __restrict__ dx2, int accumulate, int post_relu,
-    double* part, int* sync, int P) {
+    double* part, int* sync, int P, float* amax_out) {
   constexpr int CH = 4 * V * T;                       // floats per workgroup: 1 / P of a plane
   const int HW = CH * P, NP = N * P;
   __shared__ double sm[2][16];
   __shared__ double bc[512];
   const int items = C * NP;
+  float amax = 0.f;                                   // largest |dx| this thread wrote (amax_out: for the two-piece split kernels)
   for (int it = blockIdx.x; it < items; it += gridDim.x) {
     const int c = it / NP, np = it - c * NP, n = np / P, po = (np - n * P) * CH;
     const BnSet& ps = c < C1 ? s1 : s2;
@@ -403,9 +404,15 @@ __global__ __launch_bounds__(T) void bn_coop_bwd_kernel(
       o.x = sc * (g[j].x - mg - xh[j].x * mgx); o.y = sc * (g[j].y - mg - xh[j].y * mgx);
       o.z = sc * (g[j].z - mg - xh[j].z * mgx); o.w = sc * (g[j].w - mg - xh[j].w * mgx);
       *reinterpret_cast<float4*>(op + 4 * (threadIdx.x + T * j)) = o;
+      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
     }
     coop_depart(part, sync, c, NP);
     __syncthreads();
+  }
+  if (amax_out) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax_out), __float_as_uint(amax));
   }
 }
 
@@ -674,7 +681,7 @@ extern "C" int dlio_bn_coop_bwd(const float* dy, int dy_ctot, int dy_coff, const
                                 const float* mean, const float* invstd, const float* scale, const float* beta1,
                                 const float* beta2, float* dx1, float* dx2, float* dgamma1, float* dbeta1, float* dgamma2,
                                 float* dbeta2, int accumulate, int N, int C, int C1, int HW, int post_relu, void* part,
-                                void* sync, dlio_stream_t stream) {
+                                void* sync, float* amax_out, dlio_stream_t stream) {
   if (!dy || !x || !mean || !invstd || !scale || !part || !sync || C <= 0 || C1 < 0 || C1 > C || N <= 0 || HW <= 0)
     return DLIO_EINVAL;
   if ((C1 > 0 && !dx1) || (C1 < C && !dx2)) return DLIO_EINVAL;
@@ -691,7 +698,7 @@ extern "C" int dlio_bn_coop_bwd(const float* dy, int dy_ctot, int dy_coff, const
   const int grid = coop_grid(N * P, C, T);
 #define BNC(TT) hipLaunchKernelGGL((bn_coop_bwd_kernel<8, TT>), dim3((unsigned)grid), dim3(TT), 0, s, dy, dy_ctot, dy_coff, x, x_ctot,  \
                                    x_coff, N, C, C1, s1, s2, mean, invstd, scale, dx1, dx2, accumulate, post_relu,                    \
-                                   reinterpret_cast<double*>(part), reinterpret_cast<int*>(sync), P)
+                                   reinterpret_cast<double*>(part), reinterpret_cast<int*>(sync), P, amax_out)
   if (T == 1024) BNC(1024); else if (T == 512) BNC(512); else BNC(256);
 #undef BNC
   return dlio_check_launch();

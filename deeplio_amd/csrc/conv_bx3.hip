@@ -618,18 +618,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_alds_kernel(
 // middle of the group with a three-slot ring (129 / 147 / 156 / 194 us), a second accumulator set for the 32-channel tile
 // (118 / 139); with the LDS fragment reads removed as well the consumers take 81 / 86 / 109 / 139 us -- the MFMA issue
 // time itself at the clocks the chip holds under this load.
-template <int MR>
+// H2: the operand as TWO fp16 pieces of x 2^k (2^k from the tensor's largest magnitude, *amax_x, left by the kernel that
+// produced x), weights from dlio_conv_h2_prep (two fp16 pieces, { 2^-j, 2^j } behind them): three v_mfma_f32_32x32x16_f16
+// per product, two planes through LDS, 7 VALU per value in the split instead of 11; the epilogue multiplies by 2^-k 2^-j.
+typedef _Float16 pc_f16x8 __attribute__((ext_vector_type(8)));
+template <int MR, bool H2 = false>
 __global__ __launch_bounds__(512) void conv3x3_bx3_pc_kernel(
     const float* __restrict__ x, const __bf16* __restrict__ wt, const float* __restrict__ bias, const float* residual, float* y,
-    DlioConvDesc d, int tiles_w, int tiles_h, int co_tiles, int total_tiles) {
+    DlioConvDesc d, int tiles_w, int tiles_h, int co_tiles, int total_tiles, const float* __restrict__ amax_x = nullptr) {
+  constexpr int NPL = H2 ? 2 : 3;
   constexpr int TWN = 2, TH = 4, TW = 64, PR = TH + 2, PC = TW + 2, NPOSP = PR * PC;
   constexpr int NPOS = (NPOSP + 255) / 256;              // 2 patch positions per producer thread
   constexpr int PLANE = NPOSP * 16;
-  constexpr int PBUF = 3 * PLANE;                        // bf16 per patch buffer
+  constexpr int PBUF = NPL * PLANE;                      // bf16 per patch buffer
   constexpr int TG = 3;
   constexpr int AROWS = 32 * MR;
-  constexpr int AGRP = TG * 3 * AROWS * 16;
-  constexpr int AINS = TG * 3 * MR;
+  constexpr int AGRP = TG * NPL * AROWS * 16;
+  constexpr int AINS = TG * NPL * MR;
   static_assert(NPOS == 2, "two positions per producer thread");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* patch0 = reinterpret_cast<__bf16*>(smem_raw);  // [2][3 planes][NPOSP][16]
@@ -662,23 +667,28 @@ __global__ __launch_bounds__(512) void conv3x3_bx3_pc_kernel(
 
   const size_t wplane = (size_t)Cout * 16;
   const int nchunks_total = KC;                          // per tile
+  float xs = 1.f;                                        // H2: 2^k of the operand
+  if constexpr (H2) {
+    const float am = amax_x[0];
+    xs = (am > 0.f && am < 3.0e38f) ? exp2f(floorf(log2f(16384.f / am))) : 1.f;
+  }
 
   if (producer) {
     // ================================================================ producers
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<__bf16*>(wt), 0, (int)((size_t)9 * KC * 3 * wplane * 2), 0x00020000);
+        const_cast<__bf16*>(wt), 0, (int)((size_t)9 * KC * NPL * wplane * 2), 0x00020000);
     const int RW = (AINS - pw + 3) / 4;                  // ring instructions of this wave per group
     auto load_agroup = [&](const Cur& c, int kc, int g, int slot) {
 #pragma unroll
       for (int i = 0; i < (AINS + 3) / 4; ++i) {
         const int t = i * 4 + pw;
         if (t < AINS) {
-          const int m = t % MR, tp = t / MR, tap = g * TG + tp / 3, pl = tp - 3 * (tp / 3);
+          const int m = t % MR, tp = t / MR, tap = g * TG + tp / NPL, pl = tp - NPL * (tp / NPL);
           const unsigned awoff = ((unsigned)min(c.co0 + m * 32 + (lane >> 1), Cout - 1) * 16u + 8u * (unsigned)(lane & 1)) * 2u;
           __bf16* dst = ring + (size_t)slot * AGRP + (size_t)t * 64 * 8;
 #if defined(__HIP_DEVICE_COMPILE__)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, awoff,
-                                                   (unsigned)((((size_t)tap * KC + kc) * 3 + pl) * wplane * 2), 0, 0);
+                                                   (unsigned)((((size_t)tap * KC + kc) * NPL + pl) * wplane * 2), 0, 0);
 #else
           (void)dst; (void)awoff; (void)tap; (void)pl;
 #endif
@@ -713,16 +723,25 @@ __global__ __launch_bounds__(512) void conv3x3_bx3_pc_kernel(
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
           const float v = (kc * 16 + c < Cin && pval[j]) ? reg[j][c] : 0.f;
-          __bf16 h, m, l;
-          split3(v, h, m, l);
-          ph[c >> 3][c & 7] = h; pm[c >> 3][c & 7] = m; pl[c >> 3][c & 7] = l;
+          if constexpr (H2) {
+            const float vs = v * xs;
+            const _Float16 h = (_Float16)vs;
+            const _Float16 l = (_Float16)(vs - (float)h);
+            ph[c >> 3][c & 7] = __builtin_bit_cast(__bf16, h); pm[c >> 3][c & 7] = __builtin_bit_cast(__bf16, l);
+          } else {
+            __bf16 h, m, l;
+            split3(v, h, m, l);
+            ph[c >> 3][c & 7] = h; pm[c >> 3][c & 7] = m; pl[c >> 3][c & 7] = l;
+          }
         }
         bf16x8* dst = reinterpret_cast<bf16x8*>(buf + pos * 16);
         dst[0] = ph[0]; dst[1] = ph[1];
         dst = reinterpret_cast<bf16x8*>(buf + PLANE + pos * 16);
         dst[0] = pm[0]; dst[1] = pm[1];
-        dst = reinterpret_cast<bf16x8*>(buf + 2 * PLANE + pos * 16);
-        dst[0] = pl[0]; dst[1] = pl[1];
+        if constexpr (!H2) {
+          dst = reinterpret_cast<bf16x8*>(buf + 2 * PLANE + pos * 16);
+          dst[0] = pl[0]; dst[1] = pl[1];
+        }
       }
     };
     // prologue: first weight group, first patch
@@ -759,7 +778,8 @@ __global__ __launch_bounds__(512) void conv3x3_bx3_pc_kernel(
           if (RW == 5) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
           else if (RW == 4) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
           else if (RW == 3) asm volatile("s_waitcnt vmcnt(19)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+          else if (RW == 2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
           store_pos(nbuf, nkc, 0);
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -788,39 +808,53 @@ __global__ __launch_bounds__(512) void conv3x3_bx3_pc_kernel(
         for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
   };
   zero_acc();
-  auto read_a = [&](const __bf16* slot, int tl, bf16x8 (&a)[MR][3]) {
+  auto read_a = [&](const __bf16* slot, int tl, bf16x8 (&a)[MR][NPL]) {
 #pragma unroll
     for (int m = 0; m < MR; ++m)
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
-        a[m][p] = *reinterpret_cast<const bf16x8*>(slot + ((tl * 3 + p) * AROWS + m * 32 + l31) * 16 + 8 * half);
+      for (int p = 0; p < NPL; ++p)
+        a[m][p] = *reinterpret_cast<const bf16x8*>(slot + ((tl * NPL + p) * AROWS + m * 32 + l31) * 16 + 8 * half);
   };
   auto compute_group = [&](const __bf16* patch, const __bf16* slot, int g) {
-    bf16x8 a[2][MR][3];
+    bf16x8 a[2][MR][NPL];
     read_a(slot, 0, a[0]);
 #pragma unroll
     for (int tl = 0; tl < TG; ++tl) {
       const int tap = g * TG + tl, kh = tap / 3, kw = tap - 3 * kh;
       if (tl + 1 < TG) read_a(slot, tl + 1, a[(tl + 1) & 1]);
-      bf16x8 b[TWN][3];
+      bf16x8 b[TWN][NPL];
 #pragma unroll
       for (int t = 0; t < TWN; ++t) {
         const int pos = (wave + kh) * PC + 32 * t + l31 + kw;
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NPL; ++p)
           b[t][p] = *reinterpret_cast<const bf16x8*>(patch + p * PLANE + pos * 16 + 8 * half);
       }
       const auto& aa = a[tl & 1];
-      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+      if constexpr (H2) {
+        constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0};            // (lo, hi) (hi, lo) (hi, hi)
 #pragma unroll
-      for (int q = DLIO_SPLIT_Q0; q < 6; ++q)
+        for (int q = 0; q < 3; ++q)
 #pragma unroll
-        for (int m = 0; m < MR; ++m)
+          for (int m = 0; m < MR; ++m)
 #pragma unroll
-          for (int t = 0; t < TWN; ++t)
-            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[m][PA[q]], b[t][PB[q]], acc[m][t], 0, 0, 0);
+            for (int t = 0; t < TWN; ++t)
+              acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pc_f16x8, aa[m][HA[q]]),
+                                                                 __builtin_bit_cast(pc_f16x8, b[t][HB[q]]), acc[m][t], 0, 0, 0);
+      } else {
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int q = DLIO_SPLIT_Q0; q < 6; ++q)
+#pragma unroll
+          for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int t = 0; t < TWN; ++t)
+              acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[m][PA[q]], b[t][PB[q]], acc[m][t], 0, 0, 0);
+      }
     }
   };
+  float isc = 1.f;
+  if constexpr (H2) isc = (1.f / xs) * reinterpret_cast<const float*>(wt)[(size_t)9 * KC * Cout * 16];
   auto epilogue = [&](const Cur& c) {
     // D tile col = pixel (lane & 31), row = (r & 3) + 8 (r >> 2) + 4 half; DPP quad transposes -> 16-byte stores (fire_expand)
     const int oh = c.oh0 + wave;
@@ -849,6 +883,7 @@ __global__ __launch_bounds__(512) void conv3x3_bx3_pc_kernel(
             const int co = c.co0 + 32 * m + 8 * rq + 4 * half + (lane & 3);
             if (co < Cout && c.ow0 + 32 * t + 4 * (l31 >> 2) < d.OW) {
               const float bv = bias ? bias[co] : 0.f;
+              if constexpr (H2) { a0 *= isc; a1 *= isc; a2 *= isc; a3 *= isc; }
               float4 o = make_float4(a0 + bv, a1 + bv, a2 + bv, a3 + bv);
               if (rb) {
                 const float4 rv = *reinterpret_cast<const float4*>(rb + (size_t)co * ohw + 32 * t);
@@ -1099,18 +1134,19 @@ int launch_bx3_alds(const float* x, const __bf16* wt, const float* bias, const f
   return dlio_check_launch();
 }
 
-template <int MR>
+template <int MR, bool H2 = false>
 int launch_bx3_pc(const float* x, const __bf16* wt, const float* bias, const float* residual, float* y, const DlioConvDesc& d,
-                  hipStream_t s) {
+                  hipStream_t s, const float* amax_x = nullptr) {
   const int tiles_w = cdiv(d.OW, 64), tiles_h = cdiv(d.OH, 4), co_tiles = cdiv(d.Cout, 32 * MR);
   const int64_t tiles = (int64_t)d.N * tiles_h * tiles_w * co_tiles;
   if (tiles <= 0 || tiles > 0x7fffffff) return DLIO_EINVAL;
-  constexpr size_t lds = (size_t)2 * 3 * 6 * 66 * 16 * sizeof(__bf16) + (size_t)2 * 3 * 3 * 32 * MR * 16 * sizeof(__bf16);
-  dlio_set_max_lds(reinterpret_cast<const void*>(&conv3x3_bx3_pc_kernel<MR>), (int)lds);
+  constexpr int NPL = H2 ? 2 : 3;
+  constexpr size_t lds = (size_t)2 * NPL * 6 * 66 * 16 * sizeof(__bf16) + (size_t)2 * 3 * NPL * 32 * MR * 16 * sizeof(__bf16);
+  dlio_set_max_lds(reinterpret_cast<const void*>(&conv3x3_bx3_pc_kernel<MR, H2>), (int)lds);
   const int64_t slots = dlio_num_cus();
   const int grid = (int)(tiles < slots ? tiles : slots);
-  hipLaunchKernelGGL((conv3x3_bx3_pc_kernel<MR>), dim3((unsigned)grid), dim3(512), lds, s, x, wt, bias, residual, y, d, tiles_w,
-                     tiles_h, co_tiles, (int)tiles);
+  hipLaunchKernelGGL((conv3x3_bx3_pc_kernel<MR, H2>), dim3((unsigned)grid), dim3(512), lds, s, x, wt, bias, residual, y, d, tiles_w,
+                     tiles_h, co_tiles, (int)tiles, amax_x);
   return dlio_check_launch();
 }
 
@@ -1339,6 +1375,35 @@ extern "C" int dlio_fire_expand_dgrad(const float* x, const void* wt, const floa
   return bx3_3x3_run(x, wt, nullptr, residual, y, ws, ws_bytes, dp, stream, x1, wt1, C1);
 }
 
+// geometry the producer / consumer kernel takes: long channel loops on large maps (the data gradients of fire_blk1-3)
+static bool bx3_pc_geom_ok(const DlioConvDesc& d) {
+  constexpr int pc_kc = 4;              // chunks of 16 input channels from which the producer / consumer split pays
+  return d.KH == 3 && d.KW == 3 && d.SH == 1 && d.SW == 1 && d.PH == 1 && d.PW == 1 && d.OH == d.H && d.OW == d.W && d.OW >= 64 &&
+         (d.OW & 3) == 0 && (d.Cin + 15) / 16 >= pc_kc && (size_t)9 * ((d.Cin + 15) / 16) * 3 * d.Cout * 32 < 0x7fffffffull &&
+         (int64_t)d.N * cdiv(d.OH, 4) * cdiv(d.OW, 64) * cdiv(d.Cout, d.Cout <= 32 ? 32 : 64) >= 2 * (int64_t)dlio_num_cus();
+}
+
+/* the same convolution on the two-piece fp16 split (conv3x3_bx3_pc_kernel<MR, true>): x fp32 with *amax_x = its largest
+ * magnitude (left on the device by the kernel that produced x), wt from dlio_conv_h2_prep.  Only the launch sizes of the
+ * producer / consumer kernel (dlio_conv3x3_h2_ok), DLIO_EUNSUP otherwise. */
+extern "C" int dlio_conv3x3_h2_ok(const DlioConvDesc* dp) {
+  return dp && dp->N > 0 && dp->Cin > 0 && dp->Cout > 0 && bx3_pc_geom_ok(*dp) && bx3_3x3_ksplit(*dp) == 1;
+}
+
+extern "C" int dlio_conv3x3_h2_fwd(const float* x, const float* amax_x, const void* wt, const float* bias, const float* residual,
+                                   float* y, const DlioConvDesc* dp, dlio_stream_t stream) {
+  if (!x || !amax_x || !wt || !y || !dp) return DLIO_EINVAL;
+  const DlioConvDesc& d = *dp;
+  if (!dlio_conv3x3_h2_ok(dp) || ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15)) return DLIO_EUNSUP;
+  hipStream_t s = as_stream(stream);
+  const double flops = 2.0 * d.N * (double)d.OH * d.OW * d.Cout * (double)d.Cin * 9;
+  const double bytes = 4.0 * d.N * ((double)d.Cin * d.H * d.W + (double)d.Cout * d.OH * d.OW * (residual ? 2.0 : 1.0));
+  DlioProfScope prof(3, s, flops, bytes);
+  const __bf16* w = reinterpret_cast<const __bf16*>(wt);
+  return d.Cout <= 32 ? launch_bx3_pc<1, true>(x, w, bias, residual, y, d, s, amax_x)
+                      : launch_bx3_pc<2, true>(x, w, bias, residual, y, d, s, amax_x);
+}
+
 static int bx3_3x3_run(const float* x, const void* wt, const float* bias, const float* residual, float* y, void* ws,
                        size_t ws_bytes, const DlioConvDesc* dp, dlio_stream_t stream, const float* x1, const void* wt1, int C1) {
   if (!x || !wt || !y || !dp) return DLIO_EINVAL;
@@ -1372,11 +1437,8 @@ static int bx3_3x3_run(const float* x, const void* wt, const float* bias, const 
   if (ksplit > 1) { mr = mrs; twn = twns; use_alds = true; }
   // producer / consumer kernel: long channel loops on large maps (the data gradients of fire_blk1-3)
   static const int pc_on = getenv("DLIO_BX3_PC") ? atoi(getenv("DLIO_BX3_PC")) : 1;
-  constexpr int pc_kc = 4;              // chunks of 16 input channels from which the producer / consumer split pays
-  if (pc_on && !x1 && ksplit == 1 && use_alds && d.PH == 1 && d.PW == 1 && d.OH == d.H && d.OW == d.W && d.OW >= 64 &&
-      (d.OW & 3) == 0 && (d.Cin + 15) / 16 >= pc_kc &&
-      ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0 &&
-      (int64_t)d.N * cdiv(d.OH, 4) * cdiv(d.OW, 64) * cdiv(d.Cout, d.Cout <= 32 ? 32 : 64) >= 2 * (int64_t)dlio_num_cus()) {
+  if (pc_on && !x1 && ksplit == 1 && use_alds && bx3_pc_geom_ok(d) &&
+      ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0) {
     const int rcp = d.Cout <= 32 ? launch_bx3_pc<1>(x, w, bias, residual, y, d, s) : launch_bx3_pc<2>(x, w, bias, residual, y, d, s);
     dlio_prof_end(3, s);
     return rcp;

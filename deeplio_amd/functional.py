@@ -267,6 +267,12 @@ class _CBR:
         if (training and need_dx and _use_bx3(N, Cout, Cin, KH, KW, stride, H, W)
                 and (KH == 3 or (pad[0] == 0 and pad[1] == 0))):
             d.wbx3_1 = ops.conv_bx3_prepped(weight, 1)          # data-gradient direction: roles swapped
+            if KH == 3 and _DGRAD_H2[0] and tuple(stride) == (1, 1):
+                # ... and as two fp16 pieces where the data gradient runs on the two-piece kernel (it needs the largest
+                # magnitude of its operand: conv_dgrad's `amax`, else the three-piece layout above is used)
+                g = ops.conv_desc(N, Cout, d.OH, d.OW, Cin, 3, 3, 1, 1, 2 - d.PH, 2 - d.PW, OH=H, OW=W)
+                if ops.conv3x3_h2_ok(g):
+                    d.wh2_1 = ops.conv_h2_prepped(weight, 1)
         if training:
             # data-gradient layouts for backward: fetched here, where `weight` is the long-lived
             # Parameter (the cache identifies weights by object; backward only sees unpacked copies)
@@ -343,7 +349,7 @@ class _CBR:
     @staticmethod
     def backward(dy, dy_ctot, dy_coff, x, d, weight, bias, gamma, prm, beta, raw, training, pre_relu,
                  post_relu, draw, need_dx, dx=None, dx_ctot=0, dx_coff=0, dx_residual=None,
-                 dxr_ctot=0, dxr_coff=0, dx_accumulate=False, in_aff=None, pooled=None, bn_grads=None):
+                 dxr_ctot=0, dxr_coff=0, dx_accumulate=False, in_aff=None, pooled=None, bn_grads=None, amax=None):
         """dy: grad wrt the activated output (slice).  draw: scratch [N,Cout,OH,OW] (contiguous).
         Returns (dweight, dbias, dgamma, dbeta); writes dx (slice) if need_dx:
         dx = dgrad (+ dx_residual) (+ previous dx when dx_accumulate)."""
@@ -400,19 +406,24 @@ class _CBR:
                     *(in_aff if in_aff is not None else ()))
         if need_dx:
             conv_dgrad(draw, weight, d, dx, dx_ctot, dx_coff, dx_residual, dxr_ctot, dxr_coff,
-                       dx_accumulate)
+                       dx_accumulate, amax=amax)
         return ret_w, ret_bias, ret_g, ret_b
 
 
 def conv_dgrad(dy, weight, d, dx, dx_ctot, dx_coff, residual=None, r_ctot=0, r_coff=0,
-               accumulate=False):
+               accumulate=False, amax=None):
     """dy: contiguous [N,Cout,OH,OW] -> dx channel slice.  Stride-1 convs reuse the MFMA
-    forward kernel with tap-reversed, transposed weights."""
+    forward kernel with tap-reversed, transposed weights.  amax: one-float tensor with max |dy| from dy's producer."""
     N, Cin, Cout = d.N, d.Cin, d.Cout
     if accumulate:
         residual, r_ctot, r_coff = dx, dx_ctot, dx_coff
     wb = getattr(d, "wbx3_1", None) if (d.SH == 1 and d.SW == 1) else None
-    if wb is not None and d.KH == 1:
+    wh = getattr(d, "wh2_1", None) if amax is not None else None
+    if wh is not None and d.KH == 3:
+        g = ops.conv_desc(N, Cout, d.OH, d.OW, Cin, 3, 3, 1, 1, 2 - d.PH, 2 - d.PW, OH=d.H, OW=d.W, in_ctot=Cout,
+                          in_coff=0, out_ctot=dx_ctot, out_coff=dx_coff, res_ctot=r_ctot, res_coff=r_coff)
+        ops.conv3x3_h2_fwd(dy, amax, wh, None, dx, g, residual=residual)
+    elif wb is not None and d.KH == 1:
         g = ops.conv_desc(N, Cout, d.OH, d.OW, Cin, 1, 1, 1, 1, 0, 0, OH=d.H, OW=d.W, in_ctot=Cout,
                           in_coff=0, out_ctot=dx_ctot, out_coff=dx_coff, res_ctot=r_ctot, res_coff=r_coff)
         ops.conv1x1_bx3_fwd(dy, wb, None, dx, g, residual=residual)
@@ -448,6 +459,7 @@ def conv_dgrad(dy, weight, d, dx, dx_ctot, dx_coff, residual=None, r_ctot=0, r_c
 
 _CONV_BX3 = [os.environ.get("DLIO_CONV_BX3", "1") != "0"]
 _FIRE_FUSED = [os.environ.get("DLIO_FIRE_FUSED", "1") != "0"]
+_DGRAD_H2 = [os.environ.get("DLIO_DGRAD_H2", "1") != "0"]       # 3x3 data gradients of fire_blk1-3 on two fp16 pieces
 _FIRE_H2 = [os.environ.get("DLIO_FIRE_H2", "1") != "0"]         # fused Fire forward on two fp16 pieces (training)
 _FIRE_STATS = [os.environ.get("DLIO_FIRE_STATS", "1") != "0"]   # apply-on-load blocks: BatchNorm statistics from the expand launch
 _PAIR_FUSE = [os.environ.get("DLIO_PAIR_FUSE", "1") != "0"]   # gap + add / sub + fc1 + act of the lidar head as one launch
@@ -817,7 +829,7 @@ class FireFn(Function):
         CE = E1 + E3
         dact_s = _new((N, S_, H, W), x)
         draw1 = _new((N, E1, H, W), x)
-        bg1 = bg3 = None
+        bg1 = bg3 = amax3 = None
         small_prm = getattr(ctx, "small_prm", None)
         bcoop = ops.bn_coop_ok(N, H * W)
         if small_prm is not None and training and dout.is_cuda and (bcoop or ops.bn_small_ok(N, H * W)):
@@ -827,9 +839,14 @@ class FireFn(Function):
             if len({k[1] for k in sk}) > 1:          # one accumulate flag serves the four outputs
                 fresh = [_new((E1 if i < 2 else E3,), dout) for i in range(4)]
                 sk = [(t, False, t) for t in fresh]
-            (ops.bn_coop_bwd if bcoop else ops.bn_small_bwd)(dout, CE, 0, raw_e, CE, 0, small_prm, e1be, e3be, draw1, draw3,
-                                                             sk[0][0], sk[1][0], sk[2][0], sk[3][0], sk[0][1], N, CE, E1,
-                                                             H * W, True)
+            if bcoop:
+                # (the 3x3 data gradient on the two-piece kernel takes its scale from the largest |draw|)
+                amax3 = ops.amax_slot(dout.device) if getattr(d_3, "wh2_1", None) is not None else None
+                ops.bn_coop_bwd(dout, CE, 0, raw_e, CE, 0, small_prm, e1be, e3be, draw1, draw3, sk[0][0], sk[1][0], sk[2][0],
+                                sk[3][0], sk[0][1], N, CE, E1, H * W, True, amax_out=amax3)
+            else:
+                ops.bn_small_bwd(dout, CE, 0, raw_e, CE, 0, small_prm, e1be, e3be, draw1, draw3, sk[0][0], sk[1][0], sk[2][0],
+                                 sk[3][0], sk[0][1], N, CE, E1, H * W, True)
             bg1, bg3 = (sk[0][2], sk[1][2]), (sk[2][2], sk[3][2])
         wdg = getattr(ctx, "wdg", None)
         g1 = _CBR.backward(dout, CE, 0, act_s, d_1, e1w, e1b, e1g, prm_1, e1be, raw_e, training, False,
@@ -837,7 +854,7 @@ class FireFn(Function):
         if bg3 is None:
             draw3 = _new((N, E3, H, W), x)
         g3 = _CBR.backward(dout, CE, E1, act_s, d_3, e3w, e3b, e3g, prm_3, e3be, raw_e, training, False,
-                           True, draw3, wdg is None, dact_s, S_, 0, dx_accumulate=True, bn_grads=bg3)
+                           True, draw3, wdg is None, dact_s, S_, 0, dx_accumulate=True, bn_grads=bg3, amax=amax3)
         if wdg is not None:
             # dS = W3^T * dE3 + W1^T dE1 in one launch: the expand1x1 gradient's channels are centre-tap chunks of the 3x3
             # data-gradient kernel (no second launch, no accumulate pass over dS)

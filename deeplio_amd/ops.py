@@ -592,11 +592,47 @@ def bn_coop_fwd(x, x_ctot, x_coff, N, C_, C1, HW, set1, set2, eps, momentum, prm
 
 
 def bn_coop_bwd(dy, dy_ctot, dy_coff, x, x_ctot, x_coff, prm, beta1, beta2, dx1, dx2, dg1, db1, dg2, db2, accumulate, N,
-                C_, C1, HW, post_relu=True):
+                C_, C1, HW, post_relu=True, amax_out=None):
+    """amax_out: a zeroed one-float tensor (amax_slot) that receives max |dx| (for the two-piece split kernels)"""
     part, sync = _coop_ws(N, C_, x.device)
     check(lib.dlio_bn_coop_bwd(_ptr(dy), dy_ctot, dy_coff, _ptr(x), x_ctot, x_coff, _ptr(prm[0]), _ptr(prm[1]), _ptr(prm[2]),
                                _ptr(beta1), _ptr(beta2), _ptr(dx1), _ptr(dx2), _ptr(dg1), _ptr(db1), _ptr(dg2), _ptr(db2),
-                               int(accumulate), N, C_, C1, HW, int(post_relu), _ptr(part), _ptr(sync), _stream()), "bn_coop_bwd")
+                               int(accumulate), N, C_, C1, HW, int(post_relu), _ptr(part), _ptr(sync), _ptr(amax_out),
+                               _stream()), "bn_coop_bwd")
+
+
+_AMAX = {}
+_AMAX_N = 2048
+
+
+def amax_slot(device):
+    """a zeroed float on the device for a kernel's largest output magnitude.  Slots come from a ring of two halves; the
+    half about to be handed out is zeroed with one fill when the allocation enters it -- the other half's slots are at least
+    _AMAX_N / 2 allocations old by then (a training step takes ~30 and joins all its streams at the optimizer)"""
+    key = device.index if device.index is not None else torch._C._cuda_getDevice()
+    e = _AMAX.get(key)
+    if e is None:
+        e = _AMAX[key] = [torch.zeros(_AMAX_N, dtype=torch.float32, device=device), 0]
+    buf, i = e
+    half = _AMAX_N // 2
+    if i % half == 0 and i >= half:                # (the first pass over the first half is the allocation's own zeros)
+        buf[(i % _AMAX_N):(i % _AMAX_N) + half].zero_()
+    e[1] = i + 1
+    j = i % _AMAX_N
+    return buf[j:j + 1]
+
+
+def conv3x3_h2_ok(desc):
+    """the two-piece 3x3 kernel takes this launch (the producer / consumer kernel's sizes)"""
+    return bool(lib.dlio_conv3x3_h2_ok(C.byref(desc)))
+
+
+def conv3x3_h2_fwd(x, amax_x, wt, bias, y, desc, residual=None):
+    """conv3x3_bx3_fwd on the two-piece fp16 split: amax_x = one-float tensor with max |x| (amax_slot filled by the producer
+    of x), wt = conv_h2_prepped(w, mode)"""
+    check(lib.dlio_conv3x3_h2_fwd(_ptr(x), _ptr(amax_x), _ptr(wt), _ptr(bias), _ptr(residual), _ptr(y), C.byref(desc),
+                                  _stream()), "conv3x3_h2_fwd")
+    return y
 
 
 def bn_coop_errors():

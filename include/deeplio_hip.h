@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 226
+#define DLIO_ABI_VERSION 227
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);           /* "gfx950" */
@@ -185,6 +185,13 @@ int dlio_conv3x3_bx3_prep_batched(const DlioPrepItem* items_dev, int n_items, in
                                   dlio_stream_t stream);
 int dlio_conv3x3_bx3_fwd(const float* x, const void* wt, const float* bias, const float* residual,
                          float* y, const DlioConvDesc* desc, dlio_stream_t stream);
+/* the same convolution on a TWO-piece fp16 split of x 2^k (three MFMAs per product instead of six): *amax_x = the
+ * largest magnitude in x (on the device, from the kernel that produced x: dlio_bn_coop_bwd's amax_out), wt from
+ * dlio_conv_h2_prep(taps 9).  Only the launch sizes of the producer / consumer kernel (the 3x3 data gradients of
+ * fire_blk1-3: dlio_conv3x3_h2_ok), DLIO_EUNSUP otherwise. */
+int dlio_conv3x3_h2_ok(const DlioConvDesc* desc);
+int dlio_conv3x3_h2_fwd(const float* x, const float* amax_x, const void* wt, const float* bias, const float* residual,
+                        float* y, const DlioConvDesc* desc, dlio_stream_t stream);
 
 /* ---- Fire expand pair as one launch (csrc/fire_expand.hip) ----------------------------------------------------------
  * Replaces  torch.cat([self.expand1x1(s), self.expand3x3(s)], 1)  of Fire.forward (pointseg_modules.py:126-133; the
@@ -576,7 +583,9 @@ int dlio_bn_coop_bwd(const float* dy, int dy_ctot, int dy_coff, const float* x, 
                      const float* mean, const float* invstd, const float* scale, const float* beta1,
                      const float* beta2, float* dx1, float* dx2, float* dgamma1, float* dbeta1, float* dgamma2,
                      float* dbeta2, int accumulate, int N, int C, int C1, int HW, int post_relu, void* part,
-                     void* sync, dlio_stream_t stream);
+                     void* sync, float* amax_out, dlio_stream_t stream);
+/* (amax_out, nullable: one float on the device, ZERO before the launch; afterwards max |dx1|, |dx2| -- what the two-piece
+ *  split kernels take their power-of-two scale from, dlio_conv3x3_h2_fwd) */
 /* the cooperative one-launch kernels over bf16 storage (train mode, one layer per launch; arithmetic and rounding as
  * dlio_bn_bf16_apply / dlio_bn_bf16_bwd, BASELINE configs[4]); geometry rule of dlio_bn_coop_ok in elements; part / sync as
  * for dlio_bn_coop_fwd */

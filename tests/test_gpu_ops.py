@@ -1341,9 +1341,12 @@ def test_batchnorm_small_one_launch(dev, case, residual):
     dx1 = torch.empty(N, c1, H, W, device=dev)
     dx2 = torch.empty(N, C - c1, H, W, device=dev) if c1 < C else None
     dg, db = torch.ones(C, device=dev), torch.ones(C, device=dev)
+    am = ops.amax_slot(dev) if coop else None
     bwd(d(dyw), C + 2, 1, d(xw), C + 3, 2, prm, set1[1], None if set2 is None else set2[1], dx1, dx2,
-        dg[:c1], db[:c1], dg[c1:] if c1 < C else None, db[c1:] if c1 < C else None, True, N, C, c1, HW, True)
+        dg[:c1], db[:c1], dg[c1:] if c1 < C else None, db[c1:] if c1 < C else None, True, N, C, c1, HW, True,
+        **(dict(amax_out=am) if coop else {}))
     dx = dx1 if dx2 is None else torch.cat([dx1, dx2], 1)
+    assert am is None or float(am) == float(dx.abs().max())        # (what the two-piece split kernels scale by)
     assert rel_err(dx, x64.grad) < 2e-6
     assert rel_err(dg - 1, g64.grad) < 2e-6 and rel_err(db - 1, b64.grad) < 2e-6
     assert ops.bn_coop_errors() == 0
@@ -1445,3 +1448,40 @@ def test_pair_fuse_fc_one_launch(dev, case):
         y.backward(dy.to(dev))
         assert rel_err(ad.grad, a.grad) < 2e-6 and rel_err(bd.grad, b.grad) < 2e-6
         assert rel_err(wd.grad, w.grad) < 2e-6 and rel_err(bsd.grad, bias.grad) < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 64, 16, 64, 1024, 1e-5), (2, 128, 32, 64, 1024, 3.0), (1, 192, 48, 64, 2048, 1e-3)])
+def test_conv3x3_two_piece_fp16_data_gradient(dev, case):
+    """dlio_conv3x3_h2_fwd (conv3x3_bx3_pc_kernel<MR, true>): the 3x3 data-gradient direction with the operand as two fp16
+    pieces of x 2^k, k from the operand's largest magnitude, against fp64 (computed on the device) and against the three-piece
+    bf16 kernel; operands at gradient / activation magnitudes with 1e4 outliers and 8 decades of dynamic range; a residual;
+    launch sizes of the producer / consumer kernel only"""
+    from deeplio_amd import ops
+    N, Cin, Cout, H, W, mag = case
+    g = _g(71)
+    x = torch.randn(N, Cin, H, W, generator=g) * mag * torch.exp(torch.rand(N, Cin, H, W, generator=g) * 18 - 16)
+    x[0, :3, 5, 7] *= 1e4
+    w = torch.randn(Cin, Cout, 3, 3, generator=g) / (Cin * 9) ** 0.5          # [conv Cout = Cin here][conv Cin = Cout]: mode 1
+    res = torch.randn(N, Cout, H, W, generator=g) * mag
+    xd, wd, rd = x.to(dev), w.to(dev), res.to(dev)
+    ref = F.conv_transpose2d(xd.double(), wd.double(), padding=1) + rd.double()
+    d = ops.conv_desc(N, Cin, H, W, Cout, 3, 3, 1, 1, 1, 1, OH=H, OW=W, res_ctot=Cout)
+    assert ops.conv3x3_h2_ok(d)
+    assert not ops.conv3x3_h2_ok(ops.conv_desc(N, Cin, 8, 64, Cout, 3, 3, 1, 1, 1, 1, OH=8, OW=64))
+    amax = ops.amax_slot(dev)
+    amax.copy_(xd.abs().max().reshape(1))
+    y = torch.empty(N, Cout, H, W, device=dev)
+    ops.conv3x3_h2_fwd(xd, amax, ops.conv_h2_prepped(wd, 1), None, y, d, residual=rd)
+    y3 = torch.empty_like(y)
+    ops.conv3x3_bx3_fwd(xd, ops.conv_bx3_prepped(wd, 1), None, y3, d, residual=rd)
+    e2, e3 = rel_err(y, ref), rel_err(y3, ref)
+    print("two-piece fp16 %.2e, three-piece bf16 %.2e" % (e2, e3))
+    assert e2 < 3e-6 and e3 < 3e-6
+    # an amax that is 2^9 too large (a loose bound) still gives fp32-level results; zero input
+    amax.mul_(512.0)
+    ops.conv3x3_h2_fwd(xd, amax, ops.conv_h2_prepped(wd, 1), None, y, d, residual=rd)
+    assert rel_err(y, ref) < 3e-6
+    amax.zero_()
+    ops.conv3x3_h2_fwd(torch.zeros_like(xd), amax, ops.conv_h2_prepped(wd, 1), None, y, d, residual=rd)
+    assert torch.equal(y, rd)
