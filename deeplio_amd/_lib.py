@@ -63,7 +63,7 @@ SIGNATURES = {
     "dlio_conv3x3_bx3_fwd_ws": (_i, [_p, _p, _p, _p, _p, _p, _sz, _cd, _p]),
     "dlio_fire_planes_bytes": (_sz, [_i, _i, _i, _i]),
     "dlio_bn_split16": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _sz,
-                             _i, _d, _p]),
+                             _i, _d, _p, _p]),
     "dlio_fire_expand_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dlio_conv_h2_prep_floats": (_sz, [_i, _i, _i, _i]),
     "dlio_conv_h2_prep": (_i, [_p, _p, _i, _i, _i, _i, _p]),
@@ -95,6 +95,8 @@ SIGNATURES = {
     "dlio_conv2d_dgrad_strided": (_i, [_p, _p, _p, _cd, _p]),
     "dlio_conv2d_wgrad_ws_bytes": (_sz, [_cd]),
     "dlio_conv2d_wgrad": (_i, [_p, _p, _p, _p, _p, _p, _p, _sz, _i, _cd, _p]),
+    "dlio_conv3x3_wgrad_h2_ok": (_i, [_cd]),
+    "dlio_conv3x3_wgrad_h2": (_i, [_p, _p, _p, _p, _p, _p, _sz, _i, _cd, _p]),
     "dlio_chan_stats_ws_bytes": (_sz, [_i, _i, _i]),
     "dlio_chan_stats": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "dlio_bn_finalize": (_i, [_p, _p, _i, _d, _p, _f, _f, _p, _p, _p, _p, _p, _p]),

@@ -1114,6 +1114,32 @@ extern "C" size_t dlio_conv2d_wgrad_ws_bytes(const DlioConvDesc* d) {
   return need;
 }
 
+/* 3x3 stride-1 pad-1 weight gradient on the two-piece fp16 split (wgrad3_kernel<.., H2>): amax_x / amax_dy = device
+ * floats with the operands' largest magnitudes (or bounds on them), left by the kernels that produced the tensors. */
+extern "C" int dlio_conv3x3_wgrad_h2_ok(const DlioConvDesc* dp) {
+  DlioWgrad3Plan p3;
+  return dp && dp->N > 0 && dp->Cin > 0 && dp->Cout > 0 && dlio_wgrad3_plan(*dp, 4, p3);
+}
+
+extern "C" int dlio_conv3x3_wgrad_h2(const float* x, const float* amax_x, const float* dy, const float* amax_dy, float* dw,
+                                     void* ws, size_t ws_bytes, int accumulate, const DlioConvDesc* dp, dlio_stream_t stream) {
+  if (!x || !amax_x || !dy || !amax_dy || !dw || !dp || !ws) return DLIO_EINVAL;
+  const DlioConvDesc& d = *dp;
+  DlioWgrad3Plan p3;
+  if (!dlio_conv3x3_wgrad_h2_ok(dp) || !dlio_wgrad3_plan(d, 4, p3)) return DLIO_EUNSUP;
+  if (ws_bytes < p3.ws_bytes) return DLIO_EWS;
+  hipStream_t s = as_stream(stream);
+  const double flops = 2.0 * d.N * (double)d.OH * d.OW * d.Cout * (double)d.Cin * 9;
+  const double bytes = 4.0 * d.N * ((double)d.Cin * d.H * d.W + (double)d.Cout * d.OH * d.OW);
+  DlioProfScope prof(4, s, flops, bytes);
+  float* wsp = reinterpret_cast<float*>(ws);
+  int rc = dlio_wgrad3_launch(x, dy, wsp, d, p3, 4, s, amax_x, amax_dy);
+  if (rc) return rc;
+  const int64_t n = (int64_t)d.Cout * d.Cin * 9;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(n, 64)), dim3(256), 0, s, wsp, dw, n, p3.splits, accumulate);
+  return dlio_check_launch();
+}
+
 extern "C" int dlio_conv2d_wgrad(const float* x, const float* dy, float* dw,
                                  const float* in_mean, const float* in_scale,
                                  const float* in_shift, void* ws, size_t ws_bytes, int accumulate,

@@ -27,6 +27,10 @@
 // NAT (mixed-precision path, BASELINE configs[4]): x / dy are bf16 in memory -- one plane, one MFMA per product,
 // no split at all; the aligned pairs a lane loads ARE O, E is the funnel shift.
 //
+// H2 (two-piece fp16 split): both operands as TWO fp16 pieces of x 2^k (2^k from the tensor's largest magnitude or
+// a bound on it, left on the device by the kernel that produced the tensor): three v_mfma_f32_32x32x16_f16 per product, two
+// planes through LDS, 8 VALU per pair in the split instead of 11; the slab write multiplies by the two inverse scales.
+//
 // Replaces the weight-gradient half of nn.Conv2d backward for pointseg_modules.py:103 (expand3x3),
 // resnet.py BasicBlock conv3x3, base_net.py:55-71 conv3_1 / conv4_1 / conv5_1.
 #include "common.h"
@@ -36,6 +40,8 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
@@ -84,13 +90,29 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsign
   l = cvt_pk(ra - as_f(m << 16), rb - as_f(m & 0xffff0000u));
 }
 
+// two fp16 pieces of (a s, b s), packed pairs: a s = h + l up to 2^-22 of the piece's magnitude (s a power of two: exact)
+__device__ __forceinline__ void split_pair_h2(float a, float b, float s, unsigned& h, unsigned& l) {
+  const float as = a * s, bs = b * s;
+  const f16x2 hv = {(_Float16)as, (_Float16)bs};
+  h = __builtin_bit_cast(unsigned, hv);
+  const f16x2 lv = {(_Float16)(as - (float)hv[0]), (_Float16)(bs - (float)hv[1])};
+  l = __builtin_bit_cast(unsigned, lv);
+}
+// 2^k that maps a tensor's largest magnitude (or a bound on it) to 2^14 (fp16 max 65504); 1 for an all-zero / non-finite one
+__device__ __forceinline__ float h2_scale(float am) {
+  return (am > 0.f && am < 3.0e38f) ? exp2f(floorf(log2f(16384.f / am))) : 1.f;
+}
+// two-piece products, smallest first: (lo,hi) (hi,lo) (hi,hi)
+__device__ constexpr int HA_[3] = {1, 0, 0}, HB_[3] = {0, 1, 0};
+
 // six products, smallest first: (lo,hi) (mid,mid) (hi,lo) (mid,hi) (hi,mid) (hi,hi)   [A plane, B plane]
 __device__ constexpr int TA_[9] = {2, 1, 0, 1, 0, 0, 0, 0, 0}, TB_[9] = {0, 1, 2, 0, 1, 0, 0, 0, 0};
 
-template <int MR, int NTB, bool NAT>
+template <int MR, int NTB, bool NAT, bool H2 = false>
 struct W3Cfg {
+  static_assert(!(NAT && H2), "one format");
   static constexpr int TH = 4, TW = 32;
-  static constexpr int NP = NAT ? 1 : 3;                 // bf16 planes
+  static constexpr int NP = NAT ? 1 : H2 ? 2 : 3;        // 16-bit planes
   static constexpr int G = (2 * NTB) / 3;                // 16-channel groups per chunk
   static constexpr int CKC = 16 * G;
   static constexpr int CS = 20;                          // dwords per (row, channel): 16 + 4 pad -> odd number of 16-B slots
@@ -105,11 +127,15 @@ struct W3Cfg {
   static constexpr int NXI = (XITEMS + 255) / 256;       // per thread
 };
 
-template <int MR, int NTB, bool NAT>
+template <int MR, int NTB, bool NAT, bool H2 = false>
 __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                         float* __restrict__ wsp, DlioConvDesc d, int co_tiles,
-                                                        int ci_chunks, int splits, int tiles_w, int tiles_h) {
-  using C = W3Cfg<MR, NTB, NAT>;
+                                                        int ci_chunks, int splits, int tiles_w, int tiles_h,
+                                                        const float* __restrict__ amax_x = nullptr,
+                                                        const float* __restrict__ amax_dy = nullptr) {
+  using C = W3Cfg<MR, NTB, NAT, H2>;
+  float xs = 1.f, ys = 1.f;                              // H2: the operands' 2^k
+  if constexpr (H2) { xs = h2_scale(amax_x[0]); ys = h2_scale(amax_dy[0]); }
   constexpr int NP = C::NP;
   constexpr unsigned EB = NAT ? 2u : 4u;
   extern __shared__ __attribute__((aligned(16))) unsigned smem[];
@@ -201,6 +227,14 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const float* __restrict_
     const bool ok = !(C::XITEMS % 256 != 0 && RPI * i + xr0 >= C::TH + 2);
     if constexpr (NAT) {
       if (hp == 0 && ok) *reinterpret_cast<u32x4*>(p) = rx.v[i];
+    } else if constexpr (H2) {
+      unsigned h, l;
+      split_pair_h2(as_f(rx.v[i][2 * hp]), as_f(rx.v[i][2 * hp + 1]), xs, h, l);
+      if (hp == 0) { xt[0] = h; xt[1] = l; }
+      else if (ok) {
+        *reinterpret_cast<u32x2*>(p) = u32x2{xt[0], h};
+        *reinterpret_cast<u32x2*>(p + C::PS) = u32x2{xt[1], l};
+      }
     } else {
       unsigned h, m, l;
       split_pair(as_f(rx.v[i][2 * hp]), as_f(rx.v[i][2 * hp + 1]), h, m, l);
@@ -217,6 +251,12 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const float* __restrict_
     unsigned* p = buf + xlds0 + RPI * i * C::RS;
     if constexpr (NAT) {
       *reinterpret_cast<u32x4*>(p) = rx.v[i];
+    } else if constexpr (H2) {
+      unsigned h0, l0, h1, l1;
+      split_pair_h2(as_f(rx.v[i][0]), as_f(rx.v[i][1]), xs, h0, l0);
+      split_pair_h2(as_f(rx.v[i][2]), as_f(rx.v[i][3]), xs, h1, l1);
+      *reinterpret_cast<u32x2*>(p) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(p + C::PS) = u32x2{l0, l1};
     } else {
       const float v0 = as_f(rx.v[i][0]), v1 = as_f(rx.v[i][1]), v2 = as_f(rx.v[i][2]), v3 = as_f(rx.v[i][3]);
       unsigned h0, m0, l0, h1, m1, l1;
@@ -277,7 +317,8 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const float* __restrict_
       } else {
         const float lo = k == 0 ? as_f(a.hl[m]) : as_f(a.v[m][(k - 1) >> 2][(k - 1) & 3]);
         const float hi = k == 16 ? as_f(a.hr[m]) : as_f(a.v[m][k >> 2][k & 3]);
-        split_pair(lo, hi, f.e[0][m][j], f.e[1][m][j], f.e[2][m][j]);
+        if constexpr (H2) split_pair_h2(lo, hi, ys, f.e[0][m][j], f.e[1][m][j]);
+        else split_pair(lo, hi, f.e[0][m][j], f.e[1][m][j], f.e[2][m][j]);
       }
     }
   };
@@ -292,7 +333,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const float* __restrict_
   };
 
   // six products, smallest first: (lo,hi) (mid,mid) (hi,lo) (mid,hi) (hi,mid) (hi,hi)   [A plane, B plane]
-  constexpr int NTERM = NAT ? 1 : 6 - DLIO_SPLIT_Q0;      // (DLIO_SPLIT_Q0: common.h, 0 in the product build)
+  constexpr int NTERM = NAT ? 1 : H2 ? 3 : 6 - DLIO_SPLIT_Q0;      // (DLIO_SPLIT_Q0: common.h, 0 in the product build)
   constexpr int NS = 2 * NTB;                            // steps of a tile: (k-block q, B tile t)
   constexpr int UH = NTB * NTERM;                        // work units (= groups of 3 MR MFMAs) per k-block half
 
@@ -386,16 +427,21 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const float* __restrict_
       static_for<0, NTERM>([&](auto term_) {
         constexpr int term = decltype(term_)::value;
         const AQ& f = q == 0 ? a0 : a1;
-        constexpr int pa = NAT ? 0 : TA_[term + DLIO_SPLIT_Q0];
+        constexpr int pa = NAT ? 0 : H2 ? HA_[term] : TA_[term + DLIO_SPLIT_Q0];
+        constexpr int pb = NAT ? 0 : H2 ? HB_[term] : TB_[term + DLIO_SPLIT_Q0];
         static_for<0, 3>([&](auto kx_) {
           constexpr int kx = decltype(kx_)::value;
 #pragma unroll
           for (int m = 0; m < MR; ++m) {
             const unsigned* src = kx == 2 ? f.e[pa][m] : kx == 0 ? f.c[pa][m] : f.o[pa][m];
             const u32x4 av = {src[0], src[1], src[2], src[3]};
-            if constexpr (!(W3_ABL & 8))
-              acc[m][t][kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), b.v[NAT ? 0 : TB_[term + DLIO_SPLIT_Q0]],
-                                                                    acc[m][t][kx], 0, 0, 0);
+            if constexpr (W3_ABL & 8) {
+            } else if constexpr (H2) {
+              acc[m][t][kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, b.v[pb]),
+                                                                   acc[m][t][kx], 0, 0, 0);
+            } else {
+              acc[m][t][kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), b.v[pb], acc[m][t][kx], 0, 0, 0);
+            }
           }
         });
         // the items of this unit (normally one; the bf16 variant has fewer units than items)
@@ -469,6 +515,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const float* __restrict_
   const size_t row_len = (size_t)d.Cin * 9;
   float* out = wsp + (size_t)split * d.Cout * row_len;
   const int nch = min(C::CKC, d.Cin - c0);
+  const float isc = (1.f / xs) * (1.f / ys);             // H2: powers of two (1 otherwise)
   for (int idx = tid; idx < 32 * MR * nch * 9; idx += 256) {
     const int tap = idx % 9;
     const int ch = (idx / 9) % nch;
@@ -481,18 +528,19 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const float* __restrict_
     const int hf = (row >> 2) & 1, r = (row & 3) + 4 * (row >> 3);
     const int i = ((((m * NTB + t) * 3 + kx) * 4 + (r >> 2)) * 64 + hf * 32 + bl) * 4 + (r & 3);
     out[(size_t)(co0 + col) * row_len + (size_t)(c0 + ch) * 9 + tap] =
-        red[i] + red[C::RED + i];
+        H2 ? (red[i] + red[C::RED + i]) * isc : red[i] + red[C::RED + i];
   }
 }
 
-template <int MR, int NTB, bool NAT>
-int launch_w3(const void* x, const void* dy, float* wsp, const DlioConvDesc& d, const DlioWgrad3Plan& p, hipStream_t s) {
-  using C = W3Cfg<MR, NTB, NAT>;
-  auto k = wgrad3_kernel<MR, NTB, NAT>;
+template <int MR, int NTB, bool NAT, bool H2 = false>
+int launch_w3(const void* x, const void* dy, float* wsp, const DlioConvDesc& d, const DlioWgrad3Plan& p, hipStream_t s,
+              const float* amax_x = nullptr, const float* amax_dy = nullptr) {
+  using C = W3Cfg<MR, NTB, NAT, H2>;
+  auto k = wgrad3_kernel<MR, NTB, NAT, H2>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
   hipLaunchKernelGGL(k, dim3(p.co_tiles * p.ci_chunks * p.splits), dim3(256), C::LDS_BYTES, s,
                      reinterpret_cast<const float*>(x), reinterpret_cast<const float*>(dy), wsp, d, p.co_tiles,
-                     p.ci_chunks, p.splits, p.tiles_w, p.tiles_h);
+                     p.ci_chunks, p.splits, p.tiles_w, p.tiles_h, amax_x, amax_dy);
   return dlio_check_launch();
 }
 
@@ -532,8 +580,13 @@ bool dlio_wgrad3_plan(const DlioConvDesc& d, int elem_bytes, DlioWgrad3Plan& p) 
 }
 
 int dlio_wgrad3_launch(const void* x, const void* dy, float* wsp, const DlioConvDesc& d, const DlioWgrad3Plan& p,
-                       int elem_bytes, hipStream_t s) {
+                       int elem_bytes, hipStream_t s, const float* amax_x, const float* amax_dy) {
   if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) != 0) return DLIO_EUNSUP;
+  if (amax_x || amax_dy) {                               // two-piece fp16 split: fp32 operands with their largest magnitudes
+    if (elem_bytes != 4 || !amax_x || !amax_dy) return DLIO_EINVAL;
+    if (p.ntb == 2) return launch_w3<1, 2, false, true>(x, dy, wsp, d, p, s, amax_x, amax_dy);
+    return launch_w3<1, 3, false, true>(x, dy, wsp, d, p, s, amax_x, amax_dy);
+  }
   if (elem_bytes == 4) {
     if (p.ntb == 2) return launch_w3<1, 2, false>(x, dy, wsp, d, p, s);
     return launch_w3<1, 3, false>(x, dy, wsp, d, p, s);

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void bn_split16_kernel(
     const float* __restrict__ x, int x_ctot, int x_coff, const double* __restrict__ part, int splits, double count,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum, float* running_mean,
     float* running_var, float* mean_io, float* invstd_o, float* scale_io, float* y, int y_ctot, int y_coff,
-    __bf16* __restrict__ planes, int N, int C, int H, int W, int post_relu, int h2) {
+    __bf16* __restrict__ planes, int N, int C, int H, int W, int post_relu, int h2, float* __restrict__ bound_out) {
   __shared__ float tab[16][4];              // mean, scale, beta
   __shared__ float wmax[4];
   const int kc = blockIdx.y, n = blockIdx.z, KC = gridDim.y;
@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256) void bn_split16_kernel(
       // the inverse scale travels behind the planes
       float* tail = reinterpret_cast<float*>(planes + (size_t)N * KC * 2 * ((size_t)(H + 2) * (W + 2) * 16));
       tail[0] = 1.f / hs;
+      if (bound_out) bound_out[0] = b;                  // for later consumers of y on the two-piece kernels (weight gradient)
     }
   }
   {
@@ -572,7 +573,7 @@ extern "C" int dlio_bn_split16(const float* x, int N, int x_ctot, int x_coff, in
                                const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                                float* running_var, float* mean, float* invstd, float* scale, float* y, int y_ctot,
                                int y_coff, void* planes, void* ws, size_t ws_bytes, int mode, double count_scale,
-                               dlio_stream_t stream) {
+                               float* bound_out, dlio_stream_t stream) {
   // mode 0: train, statistics + apply; 1: train, statistics partials only (-> ws); 2: train, apply from the partials in
   // ws; 3: eval (mean / scale are inputs, ws unused)
   // + 16: the planes as TWO fp16 pieces of x 2^k with 2^-k behind them (train modes only: the bound on |BN(x)| that gives
@@ -605,7 +606,7 @@ extern "C" int dlio_bn_split16(const float* x, int N, int x_ctot, int x_coff, in
   hipLaunchKernelGGL(bn_split16_kernel, grid, dim3(256), 0, s, x, x_ctot, x_coff,
                      mode == 3 ? (const double*)nullptr : reinterpret_cast<const double*>(ws), splits,
                      (double)N * HW * count_scale, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale,
-                     y, y_ctot, y_coff, reinterpret_cast<__bf16*>(planes), N, C, H, W, post_relu, h2);
+                     y, y_ctot, y_coff, reinterpret_cast<__bf16*>(planes), N, C, H, W, post_relu, h2, h2 ? bound_out : nullptr);
   return dlio_check_launch();
 }
 

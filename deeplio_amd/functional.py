@@ -306,8 +306,11 @@ class _CBR:
             return d, None
         if split_into is not None:
             # the squeeze BatchNorm of a fused Fire block: activated tensor + its three-piece bf16 planes in one pass
+            # (two-piece format: the bound on |out| its scale came from stays on the device for the expand3x3 weight gradient)
+            d.out_bound = _new((1,), raw) if (split_into[1] and _WGRAD_H2[0]) else None
             prm = ops.bn_split16(raw, raw_ctot, raw_coff, gamma, beta, eps, momentum, rmean, rvar, out, out_ctot, out_coff,
-                                 split_into[0], N, Cout, d.OH, d.OW, training, post_relu, fmt=split_into[1])
+                                 split_into[0], N, Cout, d.OH, d.OW, training, post_relu, fmt=split_into[1],
+                                 bound_out=d.out_bound)
             return d, prm
         if stats_into is not None:
             prm = ops.bn_train_stats(raw, N, raw_ctot, raw_coff, Cout, OHW, pre_relu, gamma, eps, momentum, rmean, rvar,
@@ -349,8 +352,11 @@ class _CBR:
     @staticmethod
     def backward(dy, dy_ctot, dy_coff, x, d, weight, bias, gamma, prm, beta, raw, training, pre_relu,
                  post_relu, draw, need_dx, dx=None, dx_ctot=0, dx_coff=0, dx_residual=None,
-                 dxr_ctot=0, dxr_coff=0, dx_accumulate=False, in_aff=None, pooled=None, bn_grads=None, amax=None):
+                 dxr_ctot=0, dxr_coff=0, dx_accumulate=False, in_aff=None, pooled=None, bn_grads=None, amax=None,
+                 x_bound=None):
         """dy: grad wrt the activated output (slice).  draw: scratch [N,Cout,OH,OW] (contiguous).
+        amax: one-float tensor with the largest |draw| (from the BatchNorm backward that wrote it), x_bound: one with a bound
+        on |x| -- with both, the 3x3 weight gradient and data gradient run on the two-piece fp16 split.
         Returns (dweight, dbias, dgamma, dbeta); writes dx (slice) if need_dx:
         dx = dgrad (+ dx_residual) (+ previous dx when dx_accumulate)."""
         N, Cout, OHW = d.N, d.Cout, d.OH * d.OW
@@ -394,7 +400,13 @@ class _CBR:
                            OW=d.OW, in_ctot=d.in_ctot, in_coff=d.in_coff, out_ctot=Cout, out_coff=0,
                            in_relu=1 if in_aff is not None else 0)
         ws = _wgrad_stream(dy) if acc_w else None
-        if ws is None:
+        wg_h2 = (amax is not None and x_bound is not None and in_aff is None and _WGRAD_H2[0] and d.KH == 3
+                 and ops.conv3x3_wgrad_h2_ok(dd))
+        if wg_h2 and ws is None:
+            ops.conv3x3_wgrad_h2(x, x_bound, draw, amax, dw, dd, accumulate=acc_w)
+        elif wg_h2:
+            _forked(ws, lambda: ops.conv3x3_wgrad_h2(x, x_bound, draw, amax, dw, dd, accumulate=True), draw, x, amax, x_bound)
+        elif ws is None:
             ops.conv2d_wgrad(x, draw, dw, dd, in_aff=in_aff, accumulate=acc_w)
         else:
             # the weight gradient goes straight into the flat gradient buffer and nothing on the
@@ -461,6 +473,7 @@ _CONV_BX3 = [os.environ.get("DLIO_CONV_BX3", "1") != "0"]
 _FIRE_FUSED = [os.environ.get("DLIO_FIRE_FUSED", "1") != "0"]
 _DGRAD_H2 = [os.environ.get("DLIO_DGRAD_H2", "1") != "0"]       # 3x3 data gradients of fire_blk1-3 on two fp16 pieces
 _FIRE_H2 = [os.environ.get("DLIO_FIRE_H2", "1") != "0"]         # fused Fire forward on two fp16 pieces (training)
+_WGRAD_H2 = [os.environ.get("DLIO_WGRAD_H2", "1") != "0"]       # expand3x3 weight gradients of fire_blk1-3 on two fp16 pieces
 _FIRE_STATS = [os.environ.get("DLIO_FIRE_STATS", "1") != "0"]   # apply-on-load blocks: BatchNorm statistics from the expand launch
 _PAIR_FUSE = [os.environ.get("DLIO_PAIR_FUSE", "1") != "0"]   # gap + add / sub + fc1 + act of the lidar head as one launch
 _SE_FC = [os.environ.get("DLIO_SE_FC", "1") != "0"]         # the SELayer's fc pair as one launch (csrc/se_fc.hip)
@@ -841,7 +854,8 @@ class FireFn(Function):
                 sk = [(t, False, t) for t in fresh]
             if bcoop:
                 # (the 3x3 data gradient on the two-piece kernel takes its scale from the largest |draw|)
-                amax3 = ops.amax_slot(dout.device) if getattr(d_3, "wh2_1", None) is not None else None
+                amax3 = (ops.amax_slot(dout.device) if (getattr(d_3, "wh2_1", None) is not None
+                                                         or getattr(d_s, "out_bound", None) is not None) else None)
                 ops.bn_coop_bwd(dout, CE, 0, raw_e, CE, 0, small_prm, e1be, e3be, draw1, draw3, sk[0][0], sk[1][0], sk[2][0],
                                 sk[3][0], sk[0][1], N, CE, E1, H * W, True, amax_out=amax3)
             else:
@@ -854,7 +868,8 @@ class FireFn(Function):
         if bg3 is None:
             draw3 = _new((N, E3, H, W), x)
         g3 = _CBR.backward(dout, CE, E1, act_s, d_3, e3w, e3b, e3g, prm_3, e3be, raw_e, training, False,
-                           True, draw3, wdg is None, dact_s, S_, 0, dx_accumulate=True, bn_grads=bg3, amax=amax3)
+                           True, draw3, wdg is None, dact_s, S_, 0, dx_accumulate=True, bn_grads=bg3, amax=amax3,
+                           x_bound=getattr(d_s, "out_bound", None))
         if wdg is not None:
             # dS = W3^T * dE3 + W1^T dE1 in one launch: the expand1x1 gradient's channels are centre-tap chunks of the 3x3
             # data-gradient kernel (no second launch, no accumulate pass over dS)

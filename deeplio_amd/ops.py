@@ -424,6 +424,20 @@ def conv2d_wgrad(x, dy, dw, desc, in_aff=None, accumulate=False):
     return dw
 
 
+def conv3x3_wgrad_h2_ok(desc):
+    return bool(lib.dlio_conv3x3_wgrad_h2_ok(C.byref(desc)))
+
+
+def conv3x3_wgrad_h2(x, amax_x, dy, amax_dy, dw, desc, accumulate=False):
+    """3x3 stride-1 weight gradient on the two-piece fp16 split; amax_x / amax_dy: one-float device tensors with the
+    operands' largest magnitudes or bounds on them (bn_split16 bound_out, bn_coop_bwd amax_out)"""
+    nbytes = lib.dlio_conv2d_wgrad_ws_bytes(C.byref(desc))
+    ws = workspace(nbytes, x.device)
+    check(lib.dlio_conv3x3_wgrad_h2(_ptr(x), _ptr(amax_x), _ptr(dy), _ptr(amax_dy), _ptr(dw), _ptr(ws), ws.numel(),
+                                    int(accumulate), C.byref(desc), _stream()), "conv3x3_wgrad_h2")
+    return dw
+
+
 # ----------------------------------------------------------------------------- batch norm
 def _stats_ws(N, C_, HW, device):
     nbytes = lib.dlio_chan_stats_ws_bytes(N, C_, HW)
@@ -646,16 +660,17 @@ def fire_planes(N, S, H, W, device):
 
 
 def bn_split16(x, x_ctot, x_coff, gamma, beta, eps, momentum, running_mean, running_var, y, y_ctot, y_coff, planes,
-               N, C_, H, W, training, post_relu=True, fmt=0):
+               N, C_, H, W, training, post_relu=True, fmt=0, bound_out=None):
     """the squeeze BatchNorm (+ ReLU) of a Fire block: activated fp32 tensor y (or None) + the split planes -> prm [3][C]
-    (train: batch statistics, SyncBN-aware like bn_train_apply; eval: running statistics)"""
+    (train: batch statistics, SyncBN-aware like bn_train_apply; eval: running statistics).  bound_out (fmt 1): a one-float
+    tensor that receives the bound on |y| the two-piece scale was taken from"""
     if fmt and (not training or _SYNC_BN[0] is not None):
         raise ValueError("the two-piece planes exist in train mode with local batch statistics only")
     if not training:
         prm = bn_eval_params(running_mean, running_var, gamma, eps)
         check(lib.dlio_bn_split16(_ptr(x), N, x_ctot, x_coff, C_, H, W, int(post_relu), _ptr(gamma), _ptr(beta),
                                   float(eps), float(momentum), None, None, _ptr(prm[0]), _ptr(prm[1]), _ptr(prm[2]),
-                                  _ptr(y), y_ctot, y_coff, _ptr(planes), None, 0, 3, 1.0, _stream()), "bn_split16")
+                                  _ptr(y), y_ctot, y_coff, _ptr(planes), None, 0, 3, 1.0, None, _stream()), "bn_split16")
         return prm
     prm = torch.empty(3, C_, dtype=torch.float32, device=x.device)
     ws = _stats_ws(N, C_, H * W, x.device)
@@ -664,7 +679,8 @@ def bn_split16(x, x_ctot, x_coff, gamma, beta, eps, momentum, running_mean, runn
         check(lib.dlio_bn_split16(_ptr(x), N, x_ctot, x_coff, C_, H, W, int(post_relu), _ptr(gamma), _ptr(beta),
                                   float(eps), float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(prm[0]),
                                   _ptr(prm[1]), _ptr(prm[2]), _ptr(y), y_ctot, y_coff, _ptr(planes), _ptr(ws), ws.numel(),
-                                  mode + (16 if fmt else 0), float(scale), _stream()), "bn_split16")
+                                  mode + (16 if fmt else 0), float(scale), _ptr(bound_out) if fmt else None, _stream()),
+              "bn_split16")
     sync = _SYNC_BN[0]
     if sync is None:
         call(0, 1.0)

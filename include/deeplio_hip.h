@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 227
+#define DLIO_ABI_VERSION 228
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);           /* "gfx950" */
@@ -211,7 +211,8 @@ size_t dlio_fire_planes_bytes(int N, int S, int H, int W);
 int dlio_bn_split16(const float* x, int N, int x_ctot, int x_coff, int C, int H, int W, int post_relu,
                     const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                     float* running_var, float* mean, float* invstd, float* scale, float* y, int y_ctot, int y_coff,
-                    void* planes, void* ws, size_t ws_bytes, int mode, double count_scale, dlio_stream_t stream);
+                    void* planes, void* ws, size_t ws_bytes, int mode, double count_scale, float* bound_out,
+                    dlio_stream_t stream);
 int dlio_fire_expand_fwd(const void* planes, const void* w3t, const void* w1t, const float* bias3, const float* bias1,
                          float* y, int N, int S, int H, int W, int E, int y_ctot, int y_coff, int planes_fmt,
                          dlio_stream_t stream);
@@ -219,7 +220,8 @@ int dlio_fire_expand_fwd(const void* planes, const void* w3t, const void* w1t, c
  * pieces of x 2^k per value, [N][ceil(S/16)][2][H + 2][W + 2][16], 2^-k as a float behind them; same allocation size) and
  * weights from dlio_conv_h2_prep (mode 0; two fp16 pieces of w 2^j, [tap][chunk][2][n][16], then { 2^-j, 2^j }): three
  * v_mfma_f32_32x32x16_f16 per product instead of six bf16 ones, error ~1e-7 of the result.  2^k comes from
- * |BN(x)| <= |beta| + |gamma| sqrt(N H W), which holds for batch statistics; 2^j from the weight tensor's largest magnitude. */
+ * |BN(x)| <= |beta| + |gamma| sqrt(N H W), which holds for batch statistics (bound_out, nullable: that bound as a device
+ * float, for later two-piece consumers of y -- dlio_conv3x3_wgrad_h2); 2^j from the weight tensor's largest magnitude. */
 size_t dlio_conv_h2_prep_floats(int Cout, int Cin, int taps, int mode);
 int dlio_conv_h2_prep(const float* w, void* wt, int Cout, int Cin, int taps, int mode, dlio_stream_t stream);
 int dlio_conv_h2_prep_batched(const DlioPrepItem* items_dev, int n_items, int64_t total, dlio_stream_t stream);
@@ -262,6 +264,13 @@ int dlio_conv2d_wgrad(const float* x, const float* dy, float* dw,
                       const float* in_mean, const float* in_scale, const float* in_shift,
                       void* ws, size_t ws_bytes, int accumulate, const DlioConvDesc* d,
                       dlio_stream_t stream);
+/* the 3x3 stride-1 pad-1 weight gradient (pointseg_modules.py:103 expand3x3 in backward) on the two-piece fp16 split: both
+ * operands as two fp16 pieces of x 2^k, three v_mfma_f32_32x32x16_f16 per product instead of six bf16 ones.
+ * amax_x / amax_dy: device floats with the largest magnitude of x / dy or a bound on it (dlio_bn_split16 bound_out,
+ * dlio_bn_coop_bwd amax_out); ws as dlio_conv2d_wgrad_ws_bytes(d).  DLIO_EUNSUP where dlio_conv3x3_wgrad_h2_ok(d) is 0. */
+int dlio_conv3x3_wgrad_h2_ok(const DlioConvDesc* d);
+int dlio_conv3x3_wgrad_h2(const float* x, const float* amax_x, const float* dy, const float* amax_dy, float* dw, void* ws,
+                          size_t ws_bytes, int accumulate, const DlioConvDesc* d, dlio_stream_t stream);
 
 /* ---- per-channel reductions / batch norm --------------------------------
  * replaces nn.BatchNorm2d (train + eval) at pointseg_net.py:19,

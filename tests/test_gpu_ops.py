@@ -1485,3 +1485,41 @@ def test_conv3x3_two_piece_fp16_data_gradient(dev, case):
     amax.zero_()
     ops.conv3x3_h2_fwd(torch.zeros_like(xd), amax, ops.conv_h2_prepped(wd, 1), None, y, d, residual=rd)
     assert torch.equal(y, rd)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 16, 64, 64, 512, 1e-5, 0), (2, 32, 128, 32, 256, 3.0, 1), (3, 48, 192, 13, 68, 1e-3, 0),
+                                  (1, 40, 70, 16, 128, 1.0, 1)])
+def test_conv3x3_two_piece_fp16_weight_gradient(dev, case):
+    """dlio_conv3x3_wgrad_h2 (wgrad3_kernel<.., H2>): the 3x3 weight gradient with both operands as two fp16 pieces of
+    x 2^k, against fp64 (computed on the device) and against the three-piece bf16 kernel; x at activation magnitudes (ReLU
+    zeros, a loose bound as the squeeze BatchNorm leaves it), dy at gradient magnitudes with 1e4 outliers and 8 decades of
+    dynamic range; channel slices, ragged channel / tile counts, accumulation"""
+    from deeplio_amd import ops
+    N, Cin, Cout, H, W, mag, acc = case
+    g = _g(73)
+    x = torch.relu(torch.randn(N, Cin + 3, H, W, generator=g))
+    dy = torch.randn(N, Cout, H, W, generator=g) * mag * torch.exp(torch.rand(N, Cout, H, W, generator=g) * 18 - 16)
+    dy[0, :3, 5, 7] *= 1e4
+    xd, dyd = x.to(dev), dy.to(dev)
+    x64, dy64 = xd[:, 2:2 + Cin].double(), dyd.double()
+    ref = torch.nn.grad.conv2d_weight(x64, (Cout, Cin, 3, 3), dy64, padding=1)
+    d = ops.conv_desc(N, Cin, H, W, Cout, 3, 3, 1, 1, 1, 1, OH=H, OW=W, in_ctot=Cin + 3, in_coff=2)
+    assert ops.conv3x3_wgrad_h2_ok(d)
+    assert not ops.conv3x3_wgrad_h2_ok(ops.conv_desc(N, Cin, H, W, Cout, 3, 3, 2, 2, 1, 1))
+    bound = (xd.abs().max() * 100.0).reshape(1)          # a bound 2^6.6 above the largest magnitude
+    amax = dyd.abs().max().reshape(1)
+    base = torch.randn(Cout, Cin, 3, 3, generator=g).to(dev) if acc else None
+    dw = base.clone() if acc else torch.empty(Cout, Cin, 3, 3, device=dev)
+    ops.conv3x3_wgrad_h2(xd, bound, dyd, amax, dw, d, accumulate=bool(acc))
+    dw3 = base.clone() if acc else torch.empty_like(dw)
+    ops.conv2d_wgrad(xd, dyd, dw3, d, accumulate=bool(acc))
+    if acc:
+        ref = ref + base.double()
+    e2, e3 = rel_err(dw, ref), rel_err(dw3, ref)
+    print("two-piece fp16 %.2e, three-piece bf16 %.2e" % (e2, e3))
+    assert e2 < 3e-6 and e3 < 3e-6
+    # all-zero gradient (amax 0): scale 1, exact zeros
+    dw0 = torch.full_like(dw, 7.0)
+    ops.conv3x3_wgrad_h2(xd, bound, torch.zeros_like(dyd), torch.zeros(1, device=dev), dw0, d)
+    assert torch.equal(dw0, torch.zeros_like(dw0))

@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """3x3 stride-1 weight gradient at the six PointSeg expand3x3 shapes of the headline step (N = 16): us per launch,
 fp32-equivalent TFLOP/s, fraction of the split-bf16 ceiling (2516.8 / 6 = 419.5 TF/s), operand bytes / time.
-   python tools/bench_wgrad3.py [bf16]"""
+   python tools/bench_wgrad3.py [bf16 | h2]      (h2: the two-piece fp16 split, dlio_conv3x3_wgrad_h2)"""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from deeplio_amd import ops
 dev = torch.device("cuda:0")
 N = 16
 bf16 = len(sys.argv) > 1 and sys.argv[1] == "bf16"
+h2 = len(sys.argv) > 1 and sys.argv[1] == "h2"
 if bf16:
     from deeplio_amd import mixed
 def timeit(fn, iters=20):
@@ -28,7 +29,10 @@ for name, ci, co, H, W in shapes:
     d = ops.conv_desc(N, ci, H, W, co, 3, 3, 1, 1, 1, 1)
     fl = 2.0 * N * H * W * ci * co * 9
     by = (2.0 if bf16 else 4.0) * N * H * W * (ci + co)
-    if bf16:
+    if h2:
+        ax, ay = x.abs().max().reshape(1), dy.abs().max().reshape(1)
+        us = timeit(lambda: ops.conv3x3_wgrad_h2(x, ax, dy, ay, dw, d))
+    elif bf16:
         us = timeit(lambda: mixed.conv_wgrad(x, dy, dw, d))
     else:
         us = timeit(lambda: ops.conv2d_wgrad(x, dy, dw, d))
