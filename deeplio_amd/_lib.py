@@ -58,6 +58,7 @@ SIGNATURES = {
     "dlio_conv3x3_bx3_prep_batched": (_i, [_p, _i, _i64, _p]),
     "dlio_conv3x3_bx3_fwd": (_i, [_p, _p, _p, _p, _p, _cd, _p]),
     "dlio_conv3x3_h2_ok": (_i, [_cd]),
+    "dlio_conv1x1_h2_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _sz, _cd, _p]),
     "dlio_conv3x3_h2_fwd": (_i, [_p, _p, _p, _p, _p, _p, _cd, _p]),
     "dlio_conv3x3_bx3_ws_bytes": (_sz, [_cd]),
     "dlio_conv3x3_bx3_fwd_ws": (_i, [_p, _p, _p, _p, _p, _p, _sz, _cd, _p]),

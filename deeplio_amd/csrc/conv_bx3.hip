@@ -923,11 +923,17 @@ __global__ __launch_bounds__(512) void conv3x3_bx3_pc_kernel(
 // (+ ReLU when d.in_relu) is formed right before the split.  The three constants per input channel sit in LDS
 // ([ci][4] floats, zero rows behind Cin so that padded channels stay 0); a lane reads the row of each of its eight
 // channels with one ds_read_b128.
-template <int MR, bool AFF>
+// H2: x as two fp16 pieces of x 2^k (k from *amax_x, the operand's largest magnitude or a bound on it), weights from
+// dlio_conv_h2_prep (taps 1): three v_mfma_f32_32x32x16_f16 per product, 7 VALU per value in the split instead of 11; the
+// stores multiply by 2^-k 2^-j.
+template <int MR, bool AFF, bool H2 = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_bx3_kernel(
     const float* __restrict__ x, const __bf16* __restrict__ wt, const float* __restrict__ bias,
     const float* __restrict__ in_mean, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
-    const float* residual, float* y, DlioConvDesc d, int pix_blocks, int co_tiles, int ksplit, float* __restrict__ slab) {
+    const float* residual, float* y, DlioConvDesc d, int pix_blocks, int co_tiles, int ksplit, float* __restrict__ slab,
+    const float* __restrict__ amax_x = nullptr) {
+  static_assert(!(AFF && H2), "the two-piece variant has no apply-on-load input");
+  constexpr int NPL = H2 ? 2 : 3;
   extern __shared__ __attribute__((aligned(16))) float aff_tab[];      // AFF: [KC * 16][4]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
   int bid = xcd_block_index();
@@ -970,7 +976,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bx3_kernel(
   const unsigned voff = ((unsigned)pc + 8u * (unsigned)half * (unsigned)P) * 4u;   // (lanes past P read pixel 0 and store nothing)
   const size_t wplane = (size_t)Cout * 16;
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(wt), 0,
-                                                                         (int)((size_t)KC * 3 * wplane * 2), 0x00020000);
+                                                                         (int)((size_t)KC * NPL * wplane * 2), 0x00020000);
+  float xs = 1.f, isc = 1.f;                                                // H2: 2^k of the operand, 2^-k 2^-j
+  if constexpr (H2) {
+    const float am = amax_x[0];
+    xs = (am > 0.f && am < 3.0e38f) ? exp2f(floorf(log2f(16384.f / am))) : 1.f;
+    isc = (1.f / xs) * reinterpret_cast<const float*>(wt)[(size_t)KC * Cout * 16];
+  }
   unsigned woff[MR];
 #pragma unroll
   for (int m = 0; m < MR; ++m) woff[m] = ((unsigned)min(co0 + m * 32 + l31, Cout - 1) * 16u + 8u * (unsigned)half) * 2u;
@@ -979,15 +991,15 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bx3_kernel(
   // tiles -- refilled right behind the MFMAs that used them -- so that the kernel fits two waves per SIMD
   constexpr int AB = MR == 2 ? 1 : 2;
   float4 v[2][8];
-  bf16x8 a[AB][MR][3];
+  bf16x8 a[AB][MR][NPL];
   auto load_a = [&](int kc, int s) {
 #pragma unroll
     for (int m = 0; m < MR; ++m)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
+      for (int pl = 0; pl < NPL; ++pl)
         if constexpr (BX3_ABLATE & 16) opaque(a[s % AB][m][pl]);
         else a[s % AB][m][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-            wrsrc, woff[m], (unsigned)(kc * 3 + pl) * (unsigned)wplane * 2u, 0));
+            wrsrc, woff[m], (unsigned)(kc * NPL + pl) * (unsigned)wplane * 2u, 0));
   };
   auto load_chunk = [&](int kc, int s) {
     if (AB == 2) load_a(kc, s);
@@ -1018,6 +1030,22 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bx3_kernel(
     s &= 1;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
+      if constexpr (H2) {
+        pc_f16x8 bh, bl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xv = (e == 0 ? v[s][j].x : (e == 1 ? v[s][j].y : (e == 2 ? v[s][j].z : v[s][j].w))) * xs;
+          bh[j] = (_Float16)xv;
+          bl[j] = (_Float16)(xv - (float)bh[j]);
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q)            // (lo, hi) (hi, lo) (hi, hi)
+#pragma unroll
+          for (int m = 0; m < MR; ++m)
+            acc[m][e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pc_f16x8, a[s % AB][m][q == 0 ? 1 : 0]),
+                                                               q == 1 ? bl : bh, acc[m][e], 0, 0, 0);
+        continue;
+      }
       bf16x8 bb[3];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -1030,7 +1058,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bx3_kernel(
       for (int q = DLIO_SPLIT_Q0; q < 6; ++q)
 #pragma unroll
         for (int m = 0; m < MR; ++m)
-          acc[m][e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s % AB][m][PA[q]], bb[PB[q]], acc[m][e], 0, 0, 0);
+          acc[m][e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s % AB][m][PA[q] % NPL], bb[PB[q]], acc[m][e], 0, 0, 0);
     }
   };
   const int kper = slab ? (KC + ksplit - 1) / ksplit : KC;
@@ -1054,7 +1082,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bx3_kernel(
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (co < Cout)
-          *reinterpret_cast<float4*>(sb + (size_t)co * P) = make_float4(acc[m][0][r], acc[m][1][r], acc[m][2][r], acc[m][3][r]);
+          *reinterpret_cast<float4*>(sb + (size_t)co * P) =
+              make_float4(acc[m][0][r] * isc, acc[m][1][r] * isc, acc[m][2][r] * isc, acc[m][3][r] * isc);
       }
     return;
   }
@@ -1078,7 +1107,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bx3_kernel(
       const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       if (co < Cout) {
         const float bv = bias ? bias[co] : 0.f;
-        float4 o = make_float4(acc[m][0][r] + bv, acc[m][1][r] + bv, acc[m][2][r] + bv, acc[m][3][r] + bv);
+        float4 o = H2 ? make_float4(acc[m][0][r] * isc + bv, acc[m][1][r] * isc + bv, acc[m][2][r] * isc + bv, acc[m][3][r] * isc + bv)
+                      : make_float4(acc[m][0][r] + bv, acc[m][1][r] + bv, acc[m][2][r] + bv, acc[m][3][r] + bv);
         if (rb) { o.x += rv[r].x; o.y += rv[r].y; o.z += rv[r].z; o.w += rv[r].w; }
         *reinterpret_cast<float4*>(yb + (size_t)co * plane) = o;
       }
@@ -1254,10 +1284,28 @@ extern "C" size_t dlio_conv1x1_bx3_ws_bytes(const DlioConvDesc* dp) {
   return ks < 2 ? 0 : (size_t)ks * dp->N * dp->Cout * dp->H * dp->W * sizeof(float);
 }
 
+static int bx3_1x1_run(const float* x, const void* wt, const float* bias, const float* in_mean, const float* in_scale,
+                       const float* in_shift, const float* residual, float* y, void* ws, size_t ws_bytes,
+                       const DlioConvDesc* dp, dlio_stream_t stream, const float* amax_x);
+
 extern "C" int dlio_conv1x1_bx3_fwd_ws(const float* x, const void* wt, const float* bias, const float* in_mean,
                                        const float* in_scale, const float* in_shift, const float* residual,
                                        float* y, void* ws, size_t ws_bytes, const DlioConvDesc* dp,
                                        dlio_stream_t stream) {
+  return bx3_1x1_run(x, wt, bias, in_mean, in_scale, in_shift, residual, y, ws, ws_bytes, dp, stream, nullptr);
+}
+
+/* the same 1x1 convolution on the two-piece fp16 split (conv1x1_bx3_kernel<MR, false, true>): *amax_x = the largest magnitude
+ * of x or a bound on it, wt from dlio_conv_h2_prep (taps 1); no apply-on-load input */
+extern "C" int dlio_conv1x1_h2_fwd(const float* x, const float* amax_x, const void* wt, const float* bias, const float* residual,
+                                   float* y, void* ws, size_t ws_bytes, const DlioConvDesc* dp, dlio_stream_t stream) {
+  if (!amax_x) return DLIO_EINVAL;
+  return bx3_1x1_run(x, wt, bias, nullptr, nullptr, nullptr, residual, y, ws, ws_bytes, dp, stream, amax_x);
+}
+
+static int bx3_1x1_run(const float* x, const void* wt, const float* bias, const float* in_mean, const float* in_scale,
+                       const float* in_shift, const float* residual, float* y, void* ws, size_t ws_bytes,
+                       const DlioConvDesc* dp, dlio_stream_t stream, const float* amax_x) {
   if (!x || !wt || !y || !dp) return DLIO_EINVAL;
   if (in_scale && (!in_mean || !in_shift)) return DLIO_EINVAL;
   const DlioConvDesc& d = *dp;
@@ -1283,10 +1331,12 @@ extern "C" int dlio_conv1x1_bx3_fwd_ws(const float* x, const void* wt, const flo
   float* slab = ksplit > 1 ? reinterpret_cast<float*>(ws) : nullptr;
   const int64_t blocks = (int64_t)d.N * pix_blocks * co_tiles * ksplit;
   const __bf16* w = reinterpret_cast<const __bf16*>(wt);
-#define BX1(MRV, AFFV) hipLaunchKernelGGL((conv1x1_bx3_kernel<MRV, AFFV>), dim3((unsigned)blocks), dim3(256), lds, s, x, w, bias, \
-                                          in_mean, in_scale, in_shift, residual, y, d, pix_blocks, co_tiles, ksplit, slab)
-  if (mr == 1) { if (in_scale) BX1(1, true); else BX1(1, false); }
-  else { if (in_scale) BX1(2, true); else BX1(2, false); }
+#define BX1(MRV, AFFV, H2V) hipLaunchKernelGGL((conv1x1_bx3_kernel<MRV, AFFV, H2V>), dim3((unsigned)blocks), dim3(256), lds, s, x, w, \
+                                               bias, in_mean, in_scale, in_shift, residual, y, d, pix_blocks, co_tiles, ksplit, slab, \
+                                               amax_x)
+  if (amax_x) { if (mr == 1) BX1(1, false, true); else BX1(2, false, true); }
+  else if (mr == 1) { if (in_scale) BX1(1, true, false); else BX1(1, false, false); }
+  else { if (in_scale) BX1(2, true, false); else BX1(2, false, false); }
 #undef BX1
   int rc = dlio_check_launch();
   if (!rc && slab) {

@@ -366,6 +366,9 @@ __device__ __forceinline__ void wg_split8(const float (&v)[8], wg_bf16x8& h, wg_
 // AFF: the X operand is the BatchNorm+ReLU of what is stored, x' = max(0, (x - mean[ci]) * scale[ci] + shift[ci])
 // (apply-on-load: the producer's activated output is never materialised); a lane owns one channel, so
 // the three constants are per-lane registers and the transform is 2 VALU per loaded value.
+#ifndef W1_COAL_PROBE
+#define W1_COAL_PROBE 0
+#endif
 template <int MR, int NT, bool BX3 = false, bool NAT = false, bool AFF = false>
 __global__ __launch_bounds__(256, (BX3 && AFF) ? 1 : 2) void wgrad1x1_direct_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ wsp,
@@ -443,15 +446,27 @@ __global__ __launch_bounds__(256, (BX3 && AFF) ? 1 : 2) void wgrad1x1_direct_ker
     for (int m = 0; m < MR; ++m)
       if (va[m]) {
 #pragma unroll
-        for (int q = 0; q < (NAT ? 2 : 4); ++q)
+        for (int q = 0; q < (NAT ? 2 : 4); ++q) {
+#if W1_COAL_PROBE     // timing only (WRONG results): a quad of lanes reads 64 contiguous bytes of one row, 16 rows per instruction
+          const unsigned po = (unsigned)(((size_t)d.out_coff + min(co0 + m * 32 + (lane >> 2) + 16 * (q & 1), d.Cout - 1)) * hw * ES) + (lane & 3) * 16u + 64u * (q >> 1);
+          a[m][q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, po, (unsigned)n * a_img + o, 0));
+#else
           a[m][q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff[m], (unsigned)n * a_img + o + 16u * q, 0));
+#endif
+        }
       }
 #pragma unroll
     for (int t = 0; t < NT; ++t)
       if (vb[t]) {
 #pragma unroll
-        for (int q = 0; q < (NAT ? 2 : 4); ++q)
+        for (int q = 0; q < (NAT ? 2 : 4); ++q) {
+#if W1_COAL_PROBE
+          const unsigned po = (unsigned)(((size_t)d.in_coff + min(c0 + t * 32 + (lane >> 2) + 16 * (q & 1), d.Cin - 1)) * hw * ES) + (lane & 3) * 16u + 64u * (q >> 1);
+          b[t][q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(brsrc, po, (unsigned)n * b_img + o, 0));
+#else
           b[t][q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(brsrc, boff[t], (unsigned)n * b_img + o + 16u * q, 0));
+#endif
+        }
       }
   };
   const bool relu_in = d.in_relu != 0;

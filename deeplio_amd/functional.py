@@ -267,6 +267,9 @@ class _CBR:
         if (training and need_dx and _use_bx3(N, Cout, Cin, KH, KW, stride, H, W)
                 and (KH == 3 or (pad[0] == 0 and pad[1] == 0))):
             d.wbx3_1 = ops.conv_bx3_prepped(weight, 1)          # data-gradient direction: roles swapped
+            if KH == 1 and _DGRAD1_H2[0] and ops.bn_coop_ok(N, d.OH * d.OW) and ops._SYNC_BN[0] is None:
+                # 1x1 data gradients behind a cooperative BatchNorm backward (which leaves the largest |dy|): two fp16 pieces
+                d.wh2_1 = ops.conv_h2_prepped(weight, 1)
             if KH == 3 and _DGRAD_H2[0] and tuple(stride) == (1, 1):
                 # ... and as two fp16 pieces where the data gradient runs on the two-piece kernel (it needs the largest
                 # magnitude of its operand: conv_dgrad's `amax`, else the three-piece layout above is used)
@@ -372,8 +375,10 @@ class _CBR:
         if bn_grads is not None:
             pass
         elif (training and _BN_SMALL[0] and not pre_relu and dy.is_cuda and ops.bn_coop_ok(N, OHW) and pooled is None):
+            if amax is None and need_dx and getattr(d, "wh2_1", None) is not None:
+                amax = ops.amax_slot(dy.device)          # the data gradient runs on two fp16 pieces: it wants the largest |draw|
             ops.bn_coop_bwd(dy, dy_ctot, dy_coff, raw, d.out_ctot, d.out_coff, prm, beta, None, draw, None, dgamma, dbeta,
-                            None, None, acc_g, N, Cout, Cout, OHW, post_relu)
+                            None, None, acc_g, N, Cout, Cout, OHW, post_relu, amax_out=amax)
         elif (training and _BN_SMALL[0] and not pre_relu and dy.is_cuda and ops.bn_small_ok(N, OHW) and pooled is None):
             ops.bn_small_bwd(dy, dy_ctot, dy_coff, raw, d.out_ctot, d.out_coff, prm, beta, None, draw, None, dgamma, dbeta,
                              None, None, acc_g, N, Cout, Cout, OHW, post_relu)
@@ -435,6 +440,10 @@ def conv_dgrad(dy, weight, d, dx, dx_ctot, dx_coff, residual=None, r_ctot=0, r_c
         g = ops.conv_desc(N, Cout, d.OH, d.OW, Cin, 3, 3, 1, 1, 2 - d.PH, 2 - d.PW, OH=d.H, OW=d.W, in_ctot=Cout,
                           in_coff=0, out_ctot=dx_ctot, out_coff=dx_coff, res_ctot=r_ctot, res_coff=r_coff)
         ops.conv3x3_h2_fwd(dy, amax, wh, None, dx, g, residual=residual)
+    elif wh is not None and d.KH == 1 and wb is not None:
+        g = ops.conv_desc(N, Cout, d.OH, d.OW, Cin, 1, 1, 1, 1, 0, 0, OH=d.H, OW=d.W, in_ctot=Cout,
+                          in_coff=0, out_ctot=dx_ctot, out_coff=dx_coff, res_ctot=r_ctot, res_coff=r_coff)
+        ops.conv1x1_h2_fwd(dy, amax, wh, None, dx, g, residual=residual)
     elif wb is not None and d.KH == 1:
         g = ops.conv_desc(N, Cout, d.OH, d.OW, Cin, 1, 1, 1, 1, 0, 0, OH=d.H, OW=d.W, in_ctot=Cout,
                           in_coff=0, out_ctot=dx_ctot, out_coff=dx_coff, res_ctot=r_ctot, res_coff=r_coff)
@@ -473,6 +482,7 @@ _CONV_BX3 = [os.environ.get("DLIO_CONV_BX3", "1") != "0"]
 _FIRE_FUSED = [os.environ.get("DLIO_FIRE_FUSED", "1") != "0"]
 _DGRAD_H2 = [os.environ.get("DLIO_DGRAD_H2", "1") != "0"]       # 3x3 data gradients of fire_blk1-3 on two fp16 pieces
 _FIRE_H2 = [os.environ.get("DLIO_FIRE_H2", "1") != "0"]         # fused Fire forward on two fp16 pieces (training)
+_DGRAD1_H2 = [os.environ.get("DLIO_DGRAD1_H2", "1") != "0"]     # squeeze / expand1x1 data gradients of fire_blk1-3 likewise
 _WGRAD_H2 = [os.environ.get("DLIO_WGRAD_H2", "1") != "0"]       # expand3x3 weight gradients of fire_blk1-3 on two fp16 pieces
 _FIRE_STATS = [os.environ.get("DLIO_FIRE_STATS", "1") != "0"]   # apply-on-load blocks: BatchNorm statistics from the expand launch
 _PAIR_FUSE = [os.environ.get("DLIO_PAIR_FUSE", "1") != "0"]   # gap + add / sub + fc1 + act of the lidar head as one launch
@@ -855,6 +865,7 @@ class FireFn(Function):
             if bcoop:
                 # (the 3x3 data gradient on the two-piece kernel takes its scale from the largest |draw|)
                 amax3 = (ops.amax_slot(dout.device) if (getattr(d_3, "wh2_1", None) is not None
+                                                         or getattr(d_1, "wh2_1", None) is not None
                                                          or getattr(d_s, "out_bound", None) is not None) else None)
                 ops.bn_coop_bwd(dout, CE, 0, raw_e, CE, 0, small_prm, e1be, e3be, draw1, draw3, sk[0][0], sk[1][0], sk[2][0],
                                 sk[3][0], sk[0][1], N, CE, E1, H * W, True, amax_out=amax3)
@@ -864,7 +875,7 @@ class FireFn(Function):
             bg1, bg3 = (sk[0][2], sk[1][2]), (sk[2][2], sk[3][2])
         wdg = getattr(ctx, "wdg", None)
         g1 = _CBR.backward(dout, CE, 0, act_s, d_1, e1w, e1b, e1g, prm_1, e1be, raw_e, training, False,
-                           True, draw1, wdg is None, dact_s, S_, 0, bn_grads=bg1)
+                           True, draw1, wdg is None, dact_s, S_, 0, bn_grads=bg1, amax=amax3)
         if bg3 is None:
             draw3 = _new((N, E3, H, W), x)
         g3 = _CBR.backward(dout, CE, E1, act_s, d_3, e3w, e3b, e3g, prm_3, e3be, raw_e, training, False,

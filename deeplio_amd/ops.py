@@ -295,6 +295,16 @@ def conv1x1_bx3_fwd(x, wt, bias, y, desc, residual=None, in_aff=None):
     return y
 
 
+def conv1x1_h2_fwd(x, amax_x, wt, bias, y, desc, residual=None):
+    """the 1x1 convolution on the two-piece fp16 split: amax_x = one-float tensor with the largest |x| (or a bound), wt =
+    conv_h2_prepped(w, mode)"""
+    nbytes = lib.dlio_conv1x1_bx3_ws_bytes(C.byref(desc))
+    ws = workspace(nbytes, x.device, slot=4) if nbytes else None
+    check(lib.dlio_conv1x1_h2_fwd(_ptr(x), _ptr(amax_x), _ptr(wt), _ptr(bias), _ptr(residual), _ptr(y), _ptr(ws),
+                                  ws.numel() if ws is not None else 0, C.byref(desc), _stream()), "conv1x1_h2_fwd")
+    return y
+
+
 def conv3x3_bx3_fwd(x, wt, bias, y, desc, residual=None):
     nbytes = lib.dlio_conv3x3_bx3_ws_bytes(C.byref(desc))
     ws = workspace(nbytes, x.device, slot=4) if nbytes else None       # K split over workgroups (small feature maps)

@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 228
+#define DLIO_ABI_VERSION 229
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);           /* "gfx950" */
@@ -190,6 +190,10 @@ int dlio_conv3x3_bx3_fwd(const float* x, const void* wt, const float* bias, cons
  * dlio_conv_h2_prep(taps 9).  Only the launch sizes of the producer / consumer kernel (the 3x3 data gradients of
  * fire_blk1-3: dlio_conv3x3_h2_ok), DLIO_EUNSUP otherwise. */
 int dlio_conv3x3_h2_ok(const DlioConvDesc* desc);
+/* the 1x1 stride-1 convolution of dlio_conv1x1_bx3_fwd_ws on the same two-piece split (the squeeze / expand1x1 data
+ * gradients, pointseg_modules.py:96,101 in backward): wt from dlio_conv_h2_prep(taps 1); ws as dlio_conv1x1_bx3_ws_bytes. */
+int dlio_conv1x1_h2_fwd(const float* x, const float* amax_x, const void* wt, const float* bias, const float* residual,
+                        float* y, void* ws, size_t ws_bytes, const DlioConvDesc* desc, dlio_stream_t stream);
 int dlio_conv3x3_h2_fwd(const float* x, const float* amax_x, const void* wt, const float* bias, const float* residual,
                         float* y, const DlioConvDesc* desc, dlio_stream_t stream);
 

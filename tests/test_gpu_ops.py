@@ -1523,3 +1523,36 @@ def test_conv3x3_two_piece_fp16_weight_gradient(dev, case):
     dw0 = torch.full_like(dw, 7.0)
     ops.conv3x3_wgrad_h2(xd, bound, torch.zeros_like(dyd), torch.zeros(1, device=dev), dw0, d)
     assert torch.equal(dw0, torch.zeros_like(dw0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 64, 16, 64, 512, 1e-5, 1), (2, 16, 128, 64, 512, 3.0, 1), (2, 48, 384, 64, 128, 1e-3, 0),
+                                  (4, 200, 40, 12, 36, 1.0, 1), (16, 384, 80, 16, 32, 1e-2, 0)])
+def test_conv1x1_two_piece_fp16_data_gradient(dev, case):
+    """dlio_conv1x1_h2_fwd (conv1x1_bx3_kernel<MR, false, true>): the 1x1 data-gradient direction with the operand as two
+    fp16 pieces of x 2^k against fp64 (on the device) and the three-piece bf16 kernel; gradient magnitudes with 1e4 outliers
+    and 8 decades of dynamic range, channel slices + residual, narrowing / widening / ragged shapes, the K-split launch"""
+    from deeplio_amd import ops
+    N, Cin, Cout, H, W, mag, use_res = case
+    g = _g(79)
+    x = torch.randn(N, Cin, H, W, generator=g) * mag * torch.exp(torch.rand(N, Cin, H, W, generator=g) * 18 - 16)
+    x[0, :3, 5, 7] *= 1e4
+    w = torch.randn(Cin, Cout, 1, 1, generator=g) / Cin ** 0.5                # [conv Cout = Cin here][conv Cin = Cout]: mode 1
+    res = torch.randn(N, Cout + 2, H, W, generator=g) * mag
+    xd, wd, rd = x.to(dev), w.to(dev), res.to(dev)
+    ref = F.conv_transpose2d(xd.double(), wd.double())
+    if use_res:
+        ref = ref + rd[:, 1:1 + Cout].double()
+    d = ops.conv_desc(N, Cin, H, W, Cout, 1, 1, 1, 1, 0, 0, OH=H, OW=W, out_ctot=Cout + 2, out_coff=1, res_ctot=Cout + 2,
+                      res_coff=1)
+    amax = xd.abs().max().reshape(1)
+    y = torch.zeros(N, Cout + 2, H, W, device=dev)
+    ops.conv1x1_h2_fwd(xd, amax, ops.conv_h2_prepped(wd, 1), None, y, d, residual=rd if use_res else None)
+    y3 = torch.zeros_like(y)
+    ops.conv1x1_bx3_fwd(xd, ops.conv_bx3_prepped(wd, 1), None, y3, d, residual=rd if use_res else None)
+    e2, e3 = rel_err(y[:, 1:1 + Cout], ref), rel_err(y3[:, 1:1 + Cout], ref)
+    print("two-piece fp16 %.2e, three-piece bf16 %.2e" % (e2, e3))
+    assert e2 < 3e-6 and e3 < 3e-6
+    assert float(y[:, 0].abs().max()) == 0.0 and float(y[:, -1].abs().max()) == 0.0
+    ops.conv1x1_h2_fwd(xd, amax * 512.0, ops.conv_h2_prepped(wd, 1), None, y, d, residual=rd if use_res else None)
+    assert rel_err(y[:, 1:1 + Cout], ref) < 3e-6
