@@ -622,6 +622,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_alds_kernel(
 // produced x), weights from dlio_conv_h2_prep (two fp16 pieces, { 2^-j, 2^j } behind them): three v_mfma_f32_32x32x16_f16
 // per product, two planes through LDS, 7 VALU per value in the split instead of 11; the epilogue multiplies by 2^-k 2^-j.
 typedef _Float16 pc_f16x8 __attribute__((ext_vector_type(8)));
+// Measured and not kept (two-piece format): a whole-chunk weight ring (two slots of nine taps), the ring loads of chunk i + 1
+// and the patch loads of chunk i + 2 (second register set) issued at the start of step i, one barrier per chunk -- 90.6 /
+// 84.8 / 87.3 / 112.6 us against 92.6-96.1 / 84.9-88.3 / 87.0-87.5 / 112.5-113.4: the chunk time (~3 us) is not a chain of
+// exposed load latencies; the step was 0.1 ms slower with it.
 template <int MR, bool H2 = false>
 __global__ __launch_bounds__(512) void conv3x3_bx3_pc_kernel(
     const float* __restrict__ x, const __bf16* __restrict__ wt, const float* __restrict__ bias, const float* residual, float* y,
@@ -630,6 +634,7 @@ __global__ __launch_bounds__(512) void conv3x3_bx3_pc_kernel(
   constexpr int TWN = 2, TH = 4, TW = 64, PR = TH + 2, PC = TW + 2, NPOSP = PR * PC;
   constexpr int NPOS = (NPOSP + 255) / 256;              // 2 patch positions per producer thread
   constexpr int PLANE = NPOSP * 16;
+  constexpr int HPL = NPOSP * 8;                         // one channel half of a plane
   constexpr int PBUF = NPL * PLANE;                      // bf16 per patch buffer
   constexpr int TG = 3;
   constexpr int AROWS = 32 * MR;
@@ -684,7 +689,9 @@ __global__ __launch_bounds__(512) void conv3x3_bx3_pc_kernel(
         const int t = i * 4 + pw;
         if (t < AINS) {
           const int m = t % MR, tp = t / MR, tap = g * TG + tp / NPL, pl = tp - NPL * (tp / NPL);
-          const unsigned awoff = ((unsigned)min(c.co0 + m * 32 + (lane >> 1), Cout - 1) * 16u + 8u * (unsigned)(lane & 1)) * 2u;
+          // LDS image of a (tap, plane, m) block: [half][32 rows][8] -- a 16-byte stride between the lanes of a ds_read_b128
+          // lane group (the [row][16] image put lanes l and l + 8 of a group on the same banks: every fragment read 2-way)
+          const unsigned awoff = ((unsigned)min(c.co0 + m * 32 + l31, Cout - 1) * 16u + 8u * (unsigned)half) * 2u;
           __bf16* dst = ring + (size_t)slot * AGRP + (size_t)t * 64 * 8;
 #if defined(__HIP_DEVICE_COMPILE__)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, awoff,
@@ -695,34 +702,53 @@ __global__ __launch_bounds__(512) void conv3x3_bx3_pc_kernel(
         }
       }
     };
+    // The gather: a buffer descriptor over the image's Cin planes, ONE 32-bit lane offset per position (beyond num_records
+    // for a position outside the image or the patch: such loads return 0 -- no select per value) and a scalar offset per
+    // channel row (64-bit lane addresses + two selects per value were 100 of the producers' ~220 instructions per chunk,
+    // and the producers are what the narrow layers wait for: 1100 issue cycles against 430 of MFMAs at blk1)
     float reg[NPOS][16];
-    bool pval[NPOS];
-    int poff[NPOS];
-    const float* xn = nullptr;
+    unsigned pvoff[NPOS];
+    constexpr unsigned OOB = 0xffffff00u;
+    const unsigned HW4 = (unsigned)HW * 4u;               // (Cin HW 4 < 4 GB: bx3_pc_geom_ok)
+    __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, 0, 0x00020000);
     auto tile_geometry = [&](const Cur& c) {
 #pragma unroll
       for (int j = 0; j < NPOS; ++j) {
         const int pos = ptid + j * 256;
         const int r = pos / PC, cc = pos - r * PC;
         const int ih = c.oh0 - d.PH + r, iw = c.ow0 - d.PW + cc;
-        pval[j] = pos < NPOSP && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W;
-        poff[j] = pval[j] ? ih * d.W + iw : 0;
+        const bool pv = pos < NPOSP && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W;
+        pvoff[j] = pv ? (unsigned)(ih * d.W + iw) * 4u : OOB;
       }
-      xn = x + ((size_t)c.n * d.in_ctot + d.in_coff) * HW;
+      xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + ((size_t)c.n * d.in_ctot + d.in_coff) * HW), 0,
+                                                (int)((unsigned)Cin * HW4), 0x00020000);
     };
-    auto load_patch = [&](int kc) {                      // position-major: position 0's sixteen loads are the older ones
+    auto load_patch_into = [&](float (&reg)[NPOS][16], int kc) {   // position-major: position 0's sixteen loads are the older ones
+      if (kc * 16 + 16 <= Cin) {
 #pragma unroll
-      for (int j = 0; j < NPOS; ++j)
+        for (int j = 0; j < NPOS; ++j)
 #pragma unroll
-        for (int c = 0; c < 16; ++c) reg[j][c] = xn[(size_t)min(kc * 16 + c, Cin - 1) * HW + poff[j]];
+          for (int c = 0; c < 16; ++c)
+            reg[j][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, pvoff[j], (unsigned)(kc * 16 + c) * HW4, 0));
+      } else {                                           // the ragged last chunk: rows behind Cin read 0 as well
+#pragma unroll
+        for (int j = 0; j < NPOS; ++j)
+#pragma unroll
+          for (int c = 0; c < 16; ++c) {
+            const int ch = kc * 16 + c;
+            reg[j][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, ch < Cin ? pvoff[j] : OOB,
+                                                                                       (unsigned)min(ch, Cin - 1) * HW4, 0));
+          }
+      }
     };
-    auto store_pos = [&](__bf16* buf, int kc, int j) {
+    auto load_patch = [&](int kc) { load_patch_into(reg, kc); };
+    auto store_pos_from = [&](const float (&reg)[NPOS][16], __bf16* buf, int j) {
       const int pos = ptid + j * 256;
       if (pos < NPOSP) {
         bf16x8 ph[2], pm[2], pl[2];
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-          const float v = (kc * 16 + c < Cin && pval[j]) ? reg[j][c] : 0.f;
+          const float v = reg[j][c];
           if constexpr (H2) {
             const float vs = v * xs;
             const _Float16 h = (_Float16)vs;
@@ -734,16 +760,18 @@ __global__ __launch_bounds__(512) void conv3x3_bx3_pc_kernel(
             ph[c >> 3][c & 7] = h; pm[c >> 3][c & 7] = m; pl[c >> 3][c & 7] = l;
           }
         }
-        bf16x8* dst = reinterpret_cast<bf16x8*>(buf + pos * 16);
-        dst[0] = ph[0]; dst[1] = ph[1];
-        dst = reinterpret_cast<bf16x8*>(buf + PLANE + pos * 16);
-        dst[0] = pm[0]; dst[1] = pm[1];
+        // plane image [half][position][8 channels]: 16-byte lane stride for the fragment reads AND for these stores
+        *reinterpret_cast<bf16x8*>(buf + pos * 8) = ph[0];
+        *reinterpret_cast<bf16x8*>(buf + HPL + pos * 8) = ph[1];
+        *reinterpret_cast<bf16x8*>(buf + PLANE + pos * 8) = pm[0];
+        *reinterpret_cast<bf16x8*>(buf + PLANE + HPL + pos * 8) = pm[1];
         if constexpr (!H2) {
-          dst = reinterpret_cast<bf16x8*>(buf + 2 * PLANE + pos * 16);
-          dst[0] = pl[0]; dst[1] = pl[1];
+          *reinterpret_cast<bf16x8*>(buf + 2 * PLANE + pos * 8) = pl[0];
+          *reinterpret_cast<bf16x8*>(buf + 2 * PLANE + HPL + pos * 8) = pl[1];
         }
       }
     };
+    auto store_pos = [&](__bf16* buf, int, int j) { store_pos_from(reg, buf, j); };
     // prologue: first weight group, first patch
     tile_geometry(cur);
     load_agroup(cur, 0, 0, 0);
@@ -813,7 +841,7 @@ __global__ __launch_bounds__(512) void conv3x3_bx3_pc_kernel(
     for (int m = 0; m < MR; ++m)
 #pragma unroll
       for (int p = 0; p < NPL; ++p)
-        a[m][p] = *reinterpret_cast<const bf16x8*>(slot + ((tl * NPL + p) * AROWS + m * 32 + l31) * 16 + 8 * half);
+        a[m][p] = *reinterpret_cast<const bf16x8*>(slot + ((tl * NPL + p) * MR + m) * 512 + half * 256 + l31 * 8);
   };
   auto compute_group = [&](const __bf16* patch, const __bf16* slot, int g) {
     bf16x8 a[2][MR][NPL];
@@ -828,7 +856,7 @@ __global__ __launch_bounds__(512) void conv3x3_bx3_pc_kernel(
         const int pos = (wave + kh) * PC + 32 * t + l31 + kw;
 #pragma unroll
         for (int p = 0; p < NPL; ++p)
-          b[t][p] = *reinterpret_cast<const bf16x8*>(patch + p * PLANE + pos * 16 + 8 * half);
+          b[t][p] = *reinterpret_cast<const bf16x8*>(patch + p * PLANE + half * HPL + pos * 8);
       }
       const auto& aa = a[tl & 1];
       if constexpr (H2) {
@@ -1430,6 +1458,7 @@ static bool bx3_pc_geom_ok(const DlioConvDesc& d) {
   constexpr int pc_kc = 4;              // chunks of 16 input channels from which the producer / consumer split pays
   return d.KH == 3 && d.KW == 3 && d.SH == 1 && d.SW == 1 && d.PH == 1 && d.PW == 1 && d.OH == d.H && d.OW == d.W && d.OW >= 64 &&
          (d.OW & 3) == 0 && (d.Cin + 15) / 16 >= pc_kc && (size_t)9 * ((d.Cin + 15) / 16) * 3 * d.Cout * 32 < 0x7fffffffull &&
+         (size_t)d.Cin * d.H * d.W * 4 < 0xffffff00ull &&
          (int64_t)d.N * cdiv(d.OH, 4) * cdiv(d.OW, 64) * cdiv(d.Cout, d.Cout <= 32 ? 32 : 64) >= 2 * (int64_t)dlio_num_cus();
 }
 
