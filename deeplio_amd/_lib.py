@@ -91,6 +91,9 @@ SIGNATURES = {
                               _p, _i, _i, _p, _p, _p, _p, _i, _i, _p, _i, _i, _p, _p, _p]),
     "dlio_bn_coop_bwd": (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i,
                               _p, _p, _p, _p]),
+    "dlio_bn_coop_pool_ok": (_i, [_i, _i, _i, _i]),
+    "dlio_bn_coop_bwd_pool": (_i, [_p, _i, _i, _p, _p, _p, _p, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                   _p, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     "dlio_zero_upsample2d": (_i, [_p, _p, _i64, _i, _i, _i, _i, _i, _i, _p]),
     "dlio_phase_interleave2d": (_i, [_p, _i, _i, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     "dlio_conv2d_dgrad_strided": (_i, [_p, _p, _p, _cd, _p]),

@@ -9,6 +9,7 @@
 // channels [0, C1) take the first parameter set, [C1, C) the second), so a Fire block's two expand BatchNorms are one launch.
 // Accumulation: per float4 in fp32, across float4 / lanes / waves in fp64 (as bn.hip), fixed order.
 #include "common.h"
+#include "pool_strip.h"
 
 namespace {
 
@@ -348,30 +349,62 @@ __global__ __launch_bounds__(T) void bn_coop_fwd_kernel(
   }
 }
 
-template <int V, int T>
+// POOL (1 / 2 = the pool's row stride): the gradient of the BatchNorm output is not stored -- the block ends in an SELayer + 3x3 /
+// stride (SH, 2) / padding 1 max-pool (pointseg_net.py:27-46) and dy = xs[n, c] * route(dyp, idx) + xadd[n, c] (+ dy when given: the
+// part of the gradient that IS stored) is formed while loading: pool3_strip routes the POOLED gradient through the arg-max map
+// for a strip of 8 rows x 4 columns, so a thread holds such a strip (T / (W / 4) strips of W / 4 threads per part of a plane)
+// instead of 8 float4 at a T float4 stride.  Saves writing the full-resolution gradient and reading it back (twice: the
+// bypass residual of the squeeze data gradient goes the same way into the previous block's launch).
+struct CoopPool { const float* dyp; const uint8_t* idx; const float* xs; const float* xadd; int W, OH, OW; };
+
+template <int V, int T, int POOL = 0>
 __global__ __launch_bounds__(T) void bn_coop_bwd_kernel(
     const float* __restrict__ dy, int dy_ctot, int dy_coff, const float* __restrict__ x, int x_ctot, int x_coff, int N, int C,
     int C1, BnSet s1, BnSet s2, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ scale, float* __restrict__ dx1, float* __restrict__ dx2, int accumulate, int post_relu,
-    double* part, int* sync, int P, float* amax_out) {
+    double* part, int* sync, int P, float* amax_out, CoopPool pl = CoopPool{}) {
+  static_assert(!POOL || V == PR, "a thread holds one pool strip");
   constexpr int CH = 4 * V * T;                       // floats per workgroup: 1 / P of a plane
   const int HW = CH * P, NP = N * P;
   __shared__ double sm[2][16];
   __shared__ double bc[512];
   const int items = C * NP;
   float amax = 0.f;                                   // largest |dx| this thread wrote (amax_out: for the two-piece split kernels)
+  // element j of this thread inside a part: float offset e0 + j * estride
+  int e0 = 4 * threadIdx.x, estride = 4 * T, pb = 0, prow = 0;
+  if constexpr (POOL != 0) {
+    const int W4 = pl.W >> 2;
+    pb = threadIdx.x % W4; prow = (threadIdx.x / W4) * V;
+    e0 = prow * pl.W + 4 * pb; estride = pl.W;
+  }
   for (int it = blockIdx.x; it < items; it += gridDim.x) {
     const int c = it / NP, np = it - c * NP, n = np / P, po = (np - n * P) * CH;
     const BnSet& ps = c < C1 ? s1 : s2;
     const int cl = c < C1 ? c : c - C1;
     const float mu = mean[c], is = invstd[c], sc = scale[c], be = ps.beta ? ps.beta[cl] : 0.f;
-    const float* gp = dy + ((size_t)n * dy_ctot + dy_coff + c) * HW + po;
+    const float* gp = dy ? dy + ((size_t)n * dy_ctot + dy_coff + c) * HW + po : nullptr;
     const float* xp = x + ((size_t)n * x_ctot + x_coff + c) * HW + po;
     float4 g[V], xh[V];
+    if constexpr (POOL != 0) {
+      const size_t plane = (size_t)n * C + c;           // (the pooled tensors hold exactly these C channels)
+      float G[PR][4];
+      pool3_strip<POOL>(pl.dyp + plane * pl.OH * pl.OW, pl.idx + plane * pl.OH * pl.OW, po / pl.W + prow, pb, pl.OH, pl.OW, G);
+      const float ps_ = pl.xs ? pl.xs[plane] : 1.f, pa = pl.xadd ? pl.xadd[plane] : 0.f;
 #pragma unroll
-    for (int j = 0; j < V; ++j) {
-      g[j] = *reinterpret_cast<const float4*>(gp + 4 * (threadIdx.x + T * j));
-      xh[j] = *reinterpret_cast<const float4*>(xp + 4 * (threadIdx.x + T * j));
+      for (int j = 0; j < V; ++j) {
+        g[j] = make_float4(G[j][0] * ps_ + pa, G[j][1] * ps_ + pa, G[j][2] * ps_ + pa, G[j][3] * ps_ + pa);
+        if (gp) {
+          const float4 a = *reinterpret_cast<const float4*>(gp + e0 + estride * j);
+          g[j].x += a.x; g[j].y += a.y; g[j].z += a.z; g[j].w += a.w;
+        }
+        xh[j] = *reinterpret_cast<const float4*>(xp + e0 + estride * j);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        g[j] = *reinterpret_cast<const float4*>(gp + e0 + estride * j);
+        xh[j] = *reinterpret_cast<const float4*>(xp + e0 + estride * j);
+      }
     }
     double sg = 0.0, sgx = 0.0;
 #pragma unroll
@@ -403,7 +436,7 @@ __global__ __launch_bounds__(T) void bn_coop_bwd_kernel(
       float4 o;
       o.x = sc * (g[j].x - mg - xh[j].x * mgx); o.y = sc * (g[j].y - mg - xh[j].y * mgx);
       o.z = sc * (g[j].z - mg - xh[j].z * mgx); o.w = sc * (g[j].w - mg - xh[j].w * mgx);
-      *reinterpret_cast<float4*>(op + 4 * (threadIdx.x + T * j)) = o;
+      *reinterpret_cast<float4*>(op + e0 + estride * j) = o;
       amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
     }
     coop_depart(part, sync, c, NP);
@@ -700,6 +733,50 @@ extern "C" int dlio_bn_coop_bwd(const float* dy, int dy_ctot, int dy_coff, const
                                    x_coff, N, C, C1, s1, s2, mean, invstd, scale, dx1, dx2, accumulate, post_relu,                    \
                                    reinterpret_cast<double*>(part), reinterpret_cast<int*>(sync), P, amax_out)
   if (T == 1024) BNC(1024); else if (T == 512) BNC(512); else BNC(256);
+#undef BNC
+  return dlio_check_launch();
+}
+
+/* dlio_bn_coop_bwd with the gradient of the BatchNorm output routed out of a max-pool's POOLED gradient while it loads
+ * (bn_coop_bwd_kernel<.., POOL>): dy nullable (the stored part of the gradient, added), dy_pooled / idx [N][C][OH][OW] (idx: the
+ * tap 0-8 of dlio_maxpool2d_fwd), x_scale / x_add [N][C] nullable. */
+extern "C" int dlio_bn_coop_pool_ok(int N, int H, int W, int SH) {
+  int P;
+  const int T = coop_t(N, H * W, P);
+  if (!T || (SH != 1 && SH != 2) || W < 8 || (W & 3) || (H & 7)) return 0;
+  const int W4 = W >> 2;
+  // a part of a plane = T / W4 strips of 8 rows: whole strips, whole rows
+  return T % W4 == 0 && (SH == 1 || (H & 1) == 0);
+}
+
+extern "C" int dlio_bn_coop_bwd_pool(const float* dy, int dy_ctot, int dy_coff, const float* dy_pooled, const unsigned char* idx,
+                                     const float* x_scale, const float* x_add, int H, int W, int SH, const float* x, int x_ctot,
+                                     int x_coff, const float* mean, const float* invstd, const float* scale, const float* beta1,
+                                     const float* beta2, float* dx1, float* dx2, float* dgamma1, float* dbeta1, float* dgamma2,
+                                     float* dbeta2, int accumulate, int N, int C, int C1, int post_relu, void* part, void* sync,
+                                     float* amax_out, dlio_stream_t stream) {
+  if (!dy_pooled || !idx || !x || !mean || !invstd || !scale || !part || !sync || C <= 0 || C1 < 0 || C1 > C || N <= 0 || H <= 0 ||
+      W <= 0)
+    return DLIO_EINVAL;
+  if ((C1 > 0 && !dx1) || (C1 < C && !dx2)) return DLIO_EINVAL;
+  if (!dlio_bn_coop_pool_ok(N, H, W, SH)) return DLIO_EUNSUP;
+  const int HW = H * W;
+  int P;
+  const int T = coop_t(N, HW, P);
+  if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx1) |
+       reinterpret_cast<uintptr_t>(dx2)) & 15)
+    return DLIO_EUNSUP;
+  const int OH = (H + 2 - 3) / SH + 1, OW = W / 2;
+  if ((reinterpret_cast<uintptr_t>(dy_pooled) & 7) || (OW & 1)) return DLIO_EUNSUP;      // float2 / 2-byte reads of the pooled rows
+  hipStream_t s = as_stream(stream);
+  const BnSet s1{nullptr, beta1, nullptr, nullptr, dgamma1, dbeta1};
+  const BnSet s2{nullptr, beta2, nullptr, nullptr, dgamma2, dbeta2};
+  const CoopPool pl{dy_pooled, idx, x_scale, x_add, W, OH, OW};
+  DlioProfScope prof(9, s, 0.0, 4.0 * N * (double)C * HW * (dy ? 3.0 : 2.0) + 5.0 * N * (double)C * OH * OW);
+  const int grid = coop_grid(N * P, C, T);
+#define BNC(TT, PL) hipLaunchKernelGGL((bn_coop_bwd_kernel<8, TT, PL>), dim3((unsigned)grid), dim3(TT), 0, s, dy, dy_ctot, dy_coff, x,                                         x_ctot, x_coff, N, C, C1, s1, s2, mean, invstd, scale, dx1, dx2, accumulate, post_relu,                                               reinterpret_cast<double*>(part), reinterpret_cast<int*>(sync), P, amax_out, pl)
+  if (SH == 1) { if (T == 1024) BNC(1024, 1); else if (T == 512) BNC(512, 1); else BNC(256, 1); }
+  else { if (T == 1024) BNC(1024, 2); else if (T == 512) BNC(512, 2); else BNC(256, 2); }
 #undef BNC
   return dlio_check_launch();
 }

@@ -625,6 +625,22 @@ def bn_coop_bwd(dy, dy_ctot, dy_coff, x, x_ctot, x_coff, prm, beta1, beta2, dx1,
                                _stream()), "bn_coop_bwd")
 
 
+def bn_coop_pool_ok(N, H, W, SH):
+    return bool(lib.dlio_bn_coop_pool_ok(N, H, W, SH))
+
+
+def bn_coop_bwd_pool(dy, dy_ctot, dy_coff, pool, x, x_ctot, x_coff, prm, beta1, beta2, dx1, dx2, dg1, db1, dg2, db2,
+                     accumulate, N, C_, C1, H, W, post_relu=True, amax_out=None):
+    """bn_coop_bwd whose upstream gradient is x_scale * route(dy_pooled, idx) + x_add (+ dy, or None): pool = (dy_pooled, idx,
+    x_scale, x_add, SH) from the SELayer + max-pool behind the block (the full-resolution gradient is never written)"""
+    dyp, idx, xs, xa, SH = pool
+    part, sync = _coop_ws(N, C_, x.device)
+    check(lib.dlio_bn_coop_bwd_pool(_ptr(dy), dy_ctot, dy_coff, _ptr(dyp), _ptr(idx), _ptr(xs), _ptr(xa), H, W, SH, _ptr(x),
+                                    x_ctot, x_coff, _ptr(prm[0]), _ptr(prm[1]), _ptr(prm[2]), _ptr(beta1), _ptr(beta2),
+                                    _ptr(dx1), _ptr(dx2), _ptr(dg1), _ptr(db1), _ptr(dg2), _ptr(db2), int(accumulate), N, C_,
+                                    C1, int(post_relu), _ptr(part), _ptr(sync), _ptr(amax_out), _stream()), "bn_coop_bwd_pool")
+
+
 _AMAX = {}
 _AMAX_N = 2048
 

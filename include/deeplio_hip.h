@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 229
+#define DLIO_ABI_VERSION 230
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);           /* "gfx950" */
@@ -599,6 +599,19 @@ int dlio_bn_coop_bwd(const float* dy, int dy_ctot, int dy_coff, const float* x, 
                      void* sync, float* amax_out, dlio_stream_t stream);
 /* (amax_out, nullable: one float on the device, ZERO before the launch; afterwards max |dx1|, |dx2| -- what the two-piece
  *  split kernels take their power-of-two scale from, dlio_conv3x3_h2_fwd) */
+/* The same launch behind an SELayer + MaxPool2d(3, stride (SH, 2), padding 1) (the end of a PSEncoder block,
+ * pointseg_net.py:27-46; SELayer pointseg_modules.py:216-221): the gradient of the BatchNorm output is not stored but
+ * formed while loading, x_scale[n, c] * route(dy_pooled through idx) + x_add[n, c] (+ dy, nullable: the part of the gradient
+ * that is stored) -- what dlio_maxpool2d_bwd(x_scale, x_add) would have written, at a quarter of the traffic.  dy_pooled /
+ * idx: [N][C][OH][OW] (C = all channels of this launch), x_scale / x_add [N][C] nullable.  dlio_bn_coop_pool_ok(N, H, W, SH):
+ * the geometry rule (dlio_bn_coop_ok + a part of a plane is whole 8-row strips). */
+int dlio_bn_coop_pool_ok(int N, int H, int W, int SH);
+int dlio_bn_coop_bwd_pool(const float* dy, int dy_ctot, int dy_coff, const float* dy_pooled, const unsigned char* idx,
+                          const float* x_scale, const float* x_add, int H, int W, int SH, const float* x, int x_ctot,
+                          int x_coff, const float* mean, const float* invstd, const float* scale, const float* beta1,
+                          const float* beta2, float* dx1, float* dx2, float* dgamma1, float* dbeta1, float* dgamma2,
+                          float* dbeta2, int accumulate, int N, int C, int C1, int post_relu, void* part, void* sync,
+                          float* amax_out, dlio_stream_t stream);
 /* the cooperative one-launch kernels over bf16 storage (train mode, one layer per launch; arithmetic and rounding as
  * dlio_bn_bf16_apply / dlio_bn_bf16_bwd, BASELINE configs[4]); geometry rule of dlio_bn_coop_ok in elements; part / sync as
  * for dlio_bn_coop_fwd */

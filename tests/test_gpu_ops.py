@@ -1556,3 +1556,57 @@ def test_conv1x1_two_piece_fp16_data_gradient(dev, case):
     assert float(y[:, 0].abs().max()) == 0.0 and float(y[:, -1].abs().max()) == 0.0
     ops.conv1x1_h2_fwd(xd, amax * 512.0, ops.conv_h2_prepped(wd, 1), None, y, d, residual=rd if use_res else None)
     assert rel_err(y[:, 1:1 + Cout], ref) < 3e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(16, 12, 5, 64, 512, 1, False), (4, 40, 17, 64, 128, 2, True), (16, 9, 4, 64, 256, 1, True),
+                                  (2, 300, 0, 64, 512, 1, False), (3, 7, 7, 128, 128, 2, False)])
+def test_batchnorm_backward_with_the_pool_gradient_routed_on_load(dev, case):
+    """dlio_bn_coop_bwd_pool: the cooperative BatchNorm backward whose upstream gradient is x_scale * route(dy_pooled, idx) +
+    x_add (+ a stored part) formed while loading, against dlio_maxpool2d_bwd (which writes that gradient, bit for bit the same
+    values) followed by dlio_bn_coop_bwd: the data gradient agrees to summation order (1e-6), the largest magnitude and the
+    parameter gradients likewise; both pool row strides, planes in 1 / 2 / 4 parts, two parameter sets, several trips of
+    the persistent grid, accumulate"""
+    from deeplio_amd import ops
+    N, C, C1, H, W, SH, stored = case
+    g = _g(83)
+    HW = H * W
+    assert ops.bn_coop_ok(N, HW) and ops.bn_coop_pool_ok(N, H, W, SH)
+    assert not ops.bn_coop_pool_ok(N, H, W, 3) and not ops.bn_coop_pool_ok(1, H, W, SH)
+    d = lambda t: t.to(dev)
+    xw = d(torch.randn(N, C + 3, H, W, generator=g) * 1.7 + 0.3)
+    act = d(torch.randn(N, C, H, W, generator=g))
+    s = d(torch.rand(N, C, generator=g) * 0.9 + 0.05)
+    xadd = d(torch.randn(N, C, generator=g) * 1e-3)
+    yp, idx = ops.maxpool2d_fwd(act, 3, SH, 2, 1, 1, False, x_scale=s)
+    dyp = d(torch.randn(*yp.shape, generator=g))
+    extra = d(torch.randn(N, C + 2, H, W, generator=g)) if stored else None
+    gam, bet = d(torch.rand(C, generator=g) + 0.5), d(torch.randn(C, generator=g) * 0.3)
+    c1 = C1 if C1 else C
+    set1 = (gam[:c1], bet[:c1], None, None)
+    set2 = (gam[c1:], bet[c1:], None, None) if c1 < C else None
+    prm = torch.empty(3, C, device=dev)
+    y = torch.empty(N, C, H, W, device=dev)
+    ops.bn_coop_fwd(xw, C + 3, 2, N, C, c1, HW, set1, set2, 1e-5, 0.1, prm, y, C, 0, True)
+    # reference: the full-resolution gradient written, then the plain launch
+    full = ops.maxpool2d_bwd(dyp, idx, (N, C, H, W), 3, SH, 2, 1, 1, x_scale=s, x_add=xadd)
+    if stored:
+        full = full + extra[:, 1:1 + C]
+    def run(fn):
+        dx1 = torch.empty(N, c1, H, W, device=dev)
+        dx2 = torch.empty(N, C - c1, H, W, device=dev) if c1 < C else None
+        dg, db = torch.ones(C, device=dev), torch.ones(C, device=dev)
+        am = ops.amax_slot(dev)
+        fn(dx1, dx2, dg, db, am)
+        return (dx1 if dx2 is None else torch.cat([dx1, dx2], 1)), dg, db, am.clone()
+    ref = run(lambda dx1, dx2, dg, db, am: ops.bn_coop_bwd(
+        full, C, 0, xw, C + 3, 2, prm, set1[1], None if set2 is None else set2[1], dx1, dx2, dg[:c1], db[:c1],
+        dg[c1:] if c1 < C else None, db[c1:] if c1 < C else None, True, N, C, c1, HW, True, amax_out=am))
+    got = run(lambda dx1, dx2, dg, db, am: ops.bn_coop_bwd_pool(
+        extra, C + 2, 1, (dyp, idx, s, xadd, SH), xw, C + 3, 2, prm, set1[1], None if set2 is None else set2[1], dx1, dx2,
+        dg[:c1], db[:c1], dg[c1:] if c1 < C else None, db[c1:] if c1 < C else None, True, N, C, c1, H, W, True, amax_out=am))
+    assert rel_err(got[0], ref[0]) < 1e-6
+    # (sums of 1e5-1e6 signed fp32 terms taken in a different order)
+    assert rel_err(got[1], ref[1]) < 5e-6 and rel_err(got[2], ref[2]) < 5e-6
+    assert abs(float(got[3]) - float(ref[3])) <= 1e-6 * float(ref[3])
+    assert ops.bn_coop_errors() == 0
