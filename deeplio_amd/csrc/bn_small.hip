@@ -9,7 +9,6 @@
 // channels [0, C1) take the first parameter set, [C1, C) the second), so a Fire block's two expand BatchNorms are one launch.
 // Accumulation: per float4 in fp32, across float4 / lanes / waves in fp64 (as bn.hip), fixed order.
 #include "common.h"
-#include "pool_strip.h"
 
 namespace {
 
@@ -352,10 +351,61 @@ __global__ __launch_bounds__(T) void bn_coop_fwd_kernel(
 // POOL (1 / 2 = the pool's row stride): the gradient of the BatchNorm output is not stored -- the block ends in an SELayer + 3x3 /
 // stride (SH, 2) / padding 1 max-pool (pointseg_net.py:27-46) and dy = xs[n, c] * route(dyp, idx) + xadd[n, c] (+ dy when given: the
 // part of the gradient that IS stored) is formed while loading: pool3_strip routes the POOLED gradient through the arg-max map
-// for a strip of 8 rows x 4 columns, so a thread holds such a strip (T / (W / 4) strips of W / 4 threads per part of a plane)
-// instead of 8 float4 at a T float4 stride.  Saves writing the full-resolution gradient and reading it back (twice: the
+// for a strip of 4 rows x 8 columns (pool3_strip8), so a thread holds such a strip (T / (W / 8) strips of W / 8 threads per part of
+// a plane) instead of 8 float4 at a T float4 stride.  Saves writing the full-resolution gradient and reading it back (twice: the
 // bypass residual of the squeeze data gradient goes the same way into the previous block's launch).
 struct CoopPool { const float* dyp; const uint8_t* idx; const float* xs; const float* xadd; int W, OH, OW; };
+
+// routed gradient of a strip of 4 input rows x 8 input columns (columns 8 b .. 8 b + 7 = pooled columns 4 b .. 4 b + 3, + the
+// kx = 0 tap of pooled column 4 b + 4, which the NEXT lane holds: one shuffle instead of two more loads; the threads of a row
+// are W / 8 <= 64 consecutive lanes, so the last thread of a row -- no such column -- is also the only one whose neighbour sits
+// elsewhere).  Per pooled row ONE 16-byte load + ONE 4-byte load (pool3_strip: 4 loads of 8 / 4 / 2 / 1 bytes per row for half
+// the columns).  Forward: out(oh, ow) = max over (ky, kx) of in(oh SH - 1 + ky, 2 ow - 1 + kx), idx = 3 ky + kx: an even input
+// column 2 m receives from (ow = m, kx = 1), an odd one 2 m + 1 from (m, kx = 2) and (m + 1, kx = 0).
+template <int SH>
+__device__ __forceinline__ void pool3_strip8(const float* __restrict__ dyp, const uint8_t* __restrict__ ip, int r0, int b,
+                                             bool row_end, int OH, int OW, float (&G)[4][8]) {
+  constexpr int NJ = SH == 1 ? 6 : 3;                  // pooled rows whose windows meet input rows r0 .. r0 + 3
+  const int oh0 = SH == 1 ? r0 - 1 : r0 / 2;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) G[r][c] = 0.f;
+  float4 v[NJ];
+  unsigned k[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {                        // loads first, unconditional (row clamped)
+    const int oh = min(max(oh0 + j, 0), OH - 1);
+    const size_t ro = (size_t)oh * OW + 4 * b;
+    v[j] = *reinterpret_cast<const float4*>(dyp + ro);
+    k[j] = *reinterpret_cast<const unsigned*>(ip + ro);
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const bool rv = (unsigned)(oh0 + j) < (unsigned)OH;
+    const float hv = __shfl_down(v[j].x, 1, 64);       // pooled column 4 b + 4
+    const unsigned hk = __shfl_down(k[j], 1, 64) & 0xffu;
+    const float val[5] = {rv ? v[j].x : 0.f, rv ? v[j].y : 0.f, rv ? v[j].z : 0.f, rv ? v[j].w : 0.f, (rv && !row_end) ? hv : 0.f};
+    const unsigned kk[5] = {k[j] & 0xffu, (k[j] >> 8) & 0xffu, (k[j] >> 16) & 0xffu, k[j] >> 24, hk};
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const unsigned ky = kk[c] >= 6u ? 2u : (kk[c] >= 3u ? 1u : 0u), kx = kk[c] - 3u * ky;
+#pragma unroll
+      for (int kyv = 0; kyv < 3; ++kyv) {
+        const int rr = SH == 1 ? j + kyv - 2 : 2 * j - 1 + kyv;      // input row inside the strip (compile time)
+        if (rr < 0 || rr >= 4) continue;
+        const float t = ky == (unsigned)kyv ? val[c] : 0.f;
+        if (c < 4) {
+          G[rr][2 * c] += kx == 1u ? t : 0.f;
+          G[rr][2 * c + 1] += kx == 2u ? t : 0.f;
+          if (c > 0) G[rr][2 * c - 1] += kx == 0u ? t : 0.f;
+        } else {
+          G[rr][7] += kx == 0u ? t : 0.f;
+        }
+      }
+    }
+  }
+}
 
 template <int V, int T, int POOL = 0>
 __global__ __launch_bounds__(T) void bn_coop_bwd_kernel(
@@ -363,20 +413,23 @@ __global__ __launch_bounds__(T) void bn_coop_bwd_kernel(
     int C1, BnSet s1, BnSet s2, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ scale, float* __restrict__ dx1, float* __restrict__ dx2, int accumulate, int post_relu,
     double* part, int* sync, int P, float* amax_out, CoopPool pl = CoopPool{}) {
-  static_assert(!POOL || V == PR, "a thread holds one pool strip");
+  static_assert(!POOL || V == 8, "a thread holds one 4 x 8 pool strip");
   constexpr int CH = 4 * V * T;                       // floats per workgroup: 1 / P of a plane
   const int HW = CH * P, NP = N * P;
   __shared__ double sm[2][16];
   __shared__ double bc[512];
   const int items = C * NP;
   float amax = 0.f;                                   // largest |dx| this thread wrote (amax_out: for the two-piece split kernels)
-  // element j of this thread inside a part: float offset e0 + j * estride
-  int e0 = 4 * threadIdx.x, estride = 4 * T, pb = 0, prow = 0;
-  if constexpr (POOL != 0) {
-    const int W4 = pl.W >> 2;
-    pb = threadIdx.x % W4; prow = (threadIdx.x / W4) * V;
-    e0 = prow * pl.W + 4 * pb; estride = pl.W;
+  // element j of this thread inside a part: float offset EO(j)
+  int e0 = 4 * threadIdx.x, pb = 0, prow = 0, pw = 0;
+  bool prow_end = false;
+  if constexpr (POOL != 0) {                          // a strip of 4 rows x 8 columns: j = 2 row + column half
+    const int W8 = pl.W >> 3;
+    pb = threadIdx.x % W8; prow = (threadIdx.x / W8) * 4; pw = pl.W;
+    prow_end = pb == W8 - 1;
+    e0 = prow * pl.W + 8 * pb;
   }
+  auto EO = [&](int j) { return POOL != 0 ? e0 + (j >> 1) * pw + 4 * (j & 1) : e0 + 4 * T * j; };
   for (int it = blockIdx.x; it < items; it += gridDim.x) {
     const int c = it / NP, np = it - c * NP, n = np / P, po = (np - n * P) * CH;
     const BnSet& ps = c < C1 ? s1 : s2;
@@ -387,23 +440,28 @@ __global__ __launch_bounds__(T) void bn_coop_bwd_kernel(
     float4 g[V], xh[V];
     if constexpr (POOL != 0) {
       const size_t plane = (size_t)n * C + c;           // (the pooled tensors hold exactly these C channels)
-      float G[PR][4];
-      pool3_strip<POOL>(pl.dyp + plane * pl.OH * pl.OW, pl.idx + plane * pl.OH * pl.OW, po / pl.W + prow, pb, pl.OH, pl.OW, G);
+      float4 st[V];
+      if (gp) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) st[j] = *reinterpret_cast<const float4*>(gp + EO(j));
+      }
+#pragma unroll
+      for (int j = 0; j < V; ++j) xh[j] = *reinterpret_cast<const float4*>(xp + EO(j));
+      float G[4][8];
+      pool3_strip8<POOL>(pl.dyp + plane * pl.OH * pl.OW, pl.idx + plane * pl.OH * pl.OW, po / pl.W + prow, pb, prow_end, pl.OH,
+                         pl.OW, G);
       const float ps_ = pl.xs ? pl.xs[plane] : 1.f, pa = pl.xadd ? pl.xadd[plane] : 0.f;
 #pragma unroll
       for (int j = 0; j < V; ++j) {
-        g[j] = make_float4(G[j][0] * ps_ + pa, G[j][1] * ps_ + pa, G[j][2] * ps_ + pa, G[j][3] * ps_ + pa);
-        if (gp) {
-          const float4 a = *reinterpret_cast<const float4*>(gp + e0 + estride * j);
-          g[j].x += a.x; g[j].y += a.y; g[j].z += a.z; g[j].w += a.w;
-        }
-        xh[j] = *reinterpret_cast<const float4*>(xp + e0 + estride * j);
+        const int r = j >> 1, c = 4 * (j & 1);
+        g[j] = make_float4(G[r][c] * ps_ + pa, G[r][c + 1] * ps_ + pa, G[r][c + 2] * ps_ + pa, G[r][c + 3] * ps_ + pa);
+        if (gp) { g[j].x += st[j].x; g[j].y += st[j].y; g[j].z += st[j].z; g[j].w += st[j].w; }
       }
     } else {
 #pragma unroll
       for (int j = 0; j < V; ++j) {
-        g[j] = *reinterpret_cast<const float4*>(gp + e0 + estride * j);
-        xh[j] = *reinterpret_cast<const float4*>(xp + e0 + estride * j);
+        g[j] = *reinterpret_cast<const float4*>(gp + EO(j));
+        xh[j] = *reinterpret_cast<const float4*>(xp + EO(j));
       }
     }
     double sg = 0.0, sgx = 0.0;
@@ -436,7 +494,7 @@ __global__ __launch_bounds__(T) void bn_coop_bwd_kernel(
       float4 o;
       o.x = sc * (g[j].x - mg - xh[j].x * mgx); o.y = sc * (g[j].y - mg - xh[j].y * mgx);
       o.z = sc * (g[j].z - mg - xh[j].z * mgx); o.w = sc * (g[j].w - mg - xh[j].w * mgx);
-      *reinterpret_cast<float4*>(op + e0 + estride * j) = o;
+      *reinterpret_cast<float4*>(op + EO(j)) = o;
       amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
     }
     coop_depart(part, sync, c, NP);
@@ -743,10 +801,10 @@ extern "C" int dlio_bn_coop_bwd(const float* dy, int dy_ctot, int dy_coff, const
 extern "C" int dlio_bn_coop_pool_ok(int N, int H, int W, int SH) {
   int P;
   const int T = coop_t(N, H * W, P);
-  if (!T || (SH != 1 && SH != 2) || W < 8 || (W & 3) || (H & 7)) return 0;
-  const int W4 = W >> 2;
-  // a part of a plane = T / W4 strips of 8 rows: whole strips, whole rows
-  return T % W4 == 0 && (SH == 1 || (H & 1) == 0);
+  if (!T || (SH != 1 && SH != 2) || W < 16 || (W & 15) || (H & 3)) return 0;
+  const int W8 = W >> 3;
+  // a part of a plane = T / W8 strips of 4 rows x W columns; the W8 threads of a row inside one wave (the halo shuffle)
+  return T % W8 == 0 && W8 <= 64 && 64 % W8 == 0;
 }
 
 extern "C" int dlio_bn_coop_bwd_pool(const float* dy, int dy_ctot, int dy_coff, const float* dy_pooled, const unsigned char* idx,
@@ -767,7 +825,8 @@ extern "C" int dlio_bn_coop_bwd_pool(const float* dy, int dy_ctot, int dy_coff, 
        reinterpret_cast<uintptr_t>(dx2)) & 15)
     return DLIO_EUNSUP;
   const int OH = (H + 2 - 3) / SH + 1, OW = W / 2;
-  if ((reinterpret_cast<uintptr_t>(dy_pooled) & 7) || (OW & 1)) return DLIO_EUNSUP;      // float2 / 2-byte reads of the pooled rows
+  if ((reinterpret_cast<uintptr_t>(dy_pooled) & 15) || (reinterpret_cast<uintptr_t>(idx) & 3) || (OW & 3))
+    return DLIO_EUNSUP;                                 // 16-byte / 4-byte reads of the pooled rows
   hipStream_t s = as_stream(stream);
   const BnSet s1{nullptr, beta1, nullptr, nullptr, dgamma1, dbeta1};
   const BnSet s2{nullptr, beta2, nullptr, nullptr, dgamma2, dbeta2};

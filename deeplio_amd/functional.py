@@ -87,12 +87,39 @@ def aux_stream(device, name):
 def join_aux_streams():
     """current stream waits for everything issued so far on every auxiliary stream of its device"""
     _JOIN_PENDING[0] = False
+    if _LAZY:
+        _LAZY.clear()
+        raise RuntimeError("a lazy pool gradient was not consumed (functional._LAZY): DLIO_LAZY_POOL_GRAD=0 turns the scheme off")
     if not _AUX or not torch.cuda.is_available():
         return
     cur = torch.cuda.current_stream()
     for (idx, _), s in list(_AUX.items()):
         if idx == cur.device.index and s != cur:
             cur.wait_stream(s)
+
+
+# Lazy pool gradients: behind the last Fire block of fire_blk1-3 sits SELayer + MaxPool (pointseg_net.py:27-46).  Its backward
+# does not write the full-resolution gradient: it hands an UNINITIALISED tensor to autograd and leaves (pooled gradient, arg-max
+# map, SE scale, SE-branch constant, pool row stride, stored) under the tensor's address.  The Fire block's cooperative
+# BatchNorm backward routes the pooled gradient while it loads (dlio_bn_coop_bwd_pool); a bypass block passes the entry on with
+# its squeeze data gradient (stored = True: that tensor then holds the rest of the sum) to the block in front of it.  Whoever
+# cannot take an entry materialises it (lazy_materialize); an entry left over at the end of backward is an error.
+_LAZY = {}
+_LAZY_POOL = [os.environ.get("DLIO_LAZY_POOL_GRAD", "1") != "0"]
+
+
+def lazy_materialize(t):
+    """t: a gradient tensor that may be lazy -> t holds the complete gradient"""
+    e = _LAZY.pop(t.data_ptr(), None)
+    if e is None:
+        return t
+    dyp, idx, xs, xadd, sh, stored = e
+    if stored:
+        full = ops.maxpool2d_bwd(dyp, idx, tuple(t.shape), 3, sh, 2, 1, 1, x_scale=xs, x_add=xadd)
+        ops.ew_binary(t, full, 0, out=t)
+    else:
+        ops.maxpool2d_bwd(dyp, idx, tuple(t.shape), 3, sh, 2, 1, 1, x_scale=xs, x_add=xadd, out=t)
+    return t
 
 
 _NO_JOIN = [False]      # set while a hipGraph records a backward pass (a captured stream must not wait for outside work)
@@ -714,6 +741,7 @@ class FireFn(Function):
     def forward(ctx, x, sw, sb, sg, sbe, srm, srv, e1w, e1b, e1g, e1be, e1rm, e1rv, e3w, e3b, e3g,
                 e3be, e3rm, e3rv, training, momentum, eps, bypass, want_gap=False, x_aff=None, defer=False):
         ctx.set_materialize_grads(False)     # the by-products (plane averages, affine table) get no gradient: no zero fills
+        ctx.x_lazy_ok = getattr(x, "_dlio_lazy_ok", False)      # (the producer of x takes a lazy gradient: see _LAZY)
         x = x.contiguous()
         N, Cin, H, W = x.shape
         S_, E1, E3 = sw.shape[0], e1w.shape[0], e3w.shape[0]
@@ -751,6 +779,8 @@ class FireFn(Function):
                if (training and _FIRE_FUSED_DGRAD[0] and _CONV_BX3[0] and x.is_cuda and tuple(e3w.shape[2:]) == (3, 3)
                    and tuple(e1w.shape[2:]) == (1, 1)) else None)
         ctx.wdg = wdg
+        lazy_ok = (_LAZY_POOL[0] and training and x.is_cuda and _BN_SMALL[0] and ops._SYNC_BN[0] is None and wdg is None
+                   and ops.bn_coop_ok(N, H * W))
         coop = (training and _BN_SMALL[0] and _BN_COOP_FWD[0] and x.is_cuda and not defer and ops.bn_coop_ok(N, H * W)
                 and (not want_gap or ops.bn_coop_gap_ok(N, H * W)))
         small = training and _BN_SMALL[0] and x.is_cuda and (coop or ops.bn_small_ok(N, H * W))
@@ -765,6 +795,7 @@ class FireFn(Function):
             ctx.cfg = (d_s, d_1, d_3, training, bypass, True)
             ctx.small_prm = (aff[0], inv, aff[1])
             ctx.mark_non_differentiable(aff)
+            raw_e._dlio_lazy_ok = lazy_ok
             return raw_e, aff
         if small:
             # fire_blk4 / fire_blk5: the two expand BatchNorms as ONE launch that reads the concat buffer once
@@ -782,6 +813,7 @@ class FireFn(Function):
                 ctx.cfg = (d_s, d_1, d_3, training, bypass, True)
                 ctx.small_prm = (aff[0], inv, aff[1])
                 ctx.mark_non_differentiable(aff)
+                raw_e._dlio_lazy_ok = lazy_ok
                 return raw_e, aff
             out = _new((N, CE, H, W), x)
             gap = _new((N, CE), x) if want_gap else None
@@ -792,6 +824,7 @@ class FireFn(Function):
                                   sb, sg, e1b, e1g, e3b, e3g, x_aff)
             ctx.cfg = (d_s, d_1, d_3, training, bypass, False)
             ctx.small_prm = (prm[0], prm[1], prm[2])
+            out._dlio_lazy_ok = lazy_ok and small
             if not want_gap:
                 return out
             ctx.mark_non_differentiable(gap)
@@ -812,6 +845,7 @@ class FireFn(Function):
                                   sb, sg, e1b, e1g, e3b, e3g, x_aff)
             ctx.cfg = (d_s, d_1, d_3, training, bypass, True)
             ctx.mark_non_differentiable(aff)
+            raw_e._dlio_lazy_ok = lazy_ok
             return raw_e, aff
         out = _new((N, CE, H, W), x)
         # plane averages of the block output for the SELayer behind it: a by-product of the BN
@@ -846,15 +880,26 @@ class FireFn(Function):
         else:
             (x, sw, sbe, e1w, e1be, e3w, e3be, raw_s, act_s, raw_e, prm_s, prm_1, prm_3, sb, sg, e1b, e1g,
              e3b, e3g, x_aff) = ctx.saved_tensors
-        dout = dout.contiguous()
         N, Cin, H, W = x.shape
         S_, E1, E3 = sw.shape[0], e1w.shape[0], e3w.shape[0]
         CE = E1 + E3
+        small_prm = getattr(ctx, "small_prm", None)
+        bcoop = ops.bn_coop_ok(N, H * W)
+        # a lazy gradient (_LAZY): routed out of the pooled gradient by the cooperative BatchNorm backward; a bypass block hands
+        # the entry on with its squeeze data gradient -- when neither is possible here the tensor is completed first
+        lazy = _LAZY.get(dout.data_ptr())
+        if lazy is not None:
+            takes = (small_prm is not None and training and bcoop and ops.bn_coop_pool_ok(N, H, W, lazy[4])
+                     and (not bypass or getattr(ctx, "x_lazy_ok", False)))
+            if takes:
+                del _LAZY[dout.data_ptr()]
+            else:
+                lazy_materialize(dout)
+                lazy = None
+        dout = dout.contiguous()
         dact_s = _new((N, S_, H, W), x)
         draw1 = _new((N, E1, H, W), x)
         bg1 = bg3 = amax3 = None
-        small_prm = getattr(ctx, "small_prm", None)
-        bcoop = ops.bn_coop_ok(N, H * W)
         if small_prm is not None and training and dout.is_cuda and (bcoop or ops.bn_small_ok(N, H * W)):
             # both expand BatchNorms' backward in one launch (dout and the raw concat buffer read once)
             draw3 = _new((N, E3, H, W), x)
@@ -867,8 +912,13 @@ class FireFn(Function):
                 amax3 = (ops.amax_slot(dout.device) if (getattr(d_3, "wh2_1", None) is not None
                                                          or getattr(d_1, "wh2_1", None) is not None
                                                          or getattr(d_s, "out_bound", None) is not None) else None)
-                ops.bn_coop_bwd(dout, CE, 0, raw_e, CE, 0, small_prm, e1be, e3be, draw1, draw3, sk[0][0], sk[1][0], sk[2][0],
-                                sk[3][0], sk[0][1], N, CE, E1, H * W, True, amax_out=amax3)
+                if lazy is not None:
+                    ops.bn_coop_bwd_pool(dout if lazy[5] else None, CE, 0, lazy[:5], raw_e, CE, 0, small_prm, e1be, e3be, draw1,
+                                         draw3, sk[0][0], sk[1][0], sk[2][0], sk[3][0], sk[0][1], N, CE, E1, H, W, True,
+                                         amax_out=amax3)
+                else:
+                    ops.bn_coop_bwd(dout, CE, 0, raw_e, CE, 0, small_prm, e1be, e3be, draw1, draw3, sk[0][0], sk[1][0],
+                                    sk[2][0], sk[3][0], sk[0][1], N, CE, E1, H * W, True, amax_out=amax3)
             else:
                 ops.bn_small_bwd(dout, CE, 0, raw_e, CE, 0, small_prm, e1be, e3be, draw1, draw3, sk[0][0], sk[1][0], sk[2][0],
                                  sk[3][0], sk[0][1], N, CE, E1, H * W, True)
@@ -890,8 +940,12 @@ class FireFn(Function):
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty_like(x) if need_dx else None
         draw_s = _new((N, S_, H, W), x)
+        # the bypass gradient: a lazy one travels on with dx (stored part: dout itself when it holds one)
+        res = (dout if (bypass and (lazy is None or lazy[5])) else None)
         gs = _CBR.backward(dact_s, S_, 0, x, d_s, sw, sb, sg, prm_s, sbe, raw_s, training, False, True,
-                           draw_s, need_dx, dx, Cin, 0, dout if bypass else None, CE, 0, in_aff=x_aff)
+                           draw_s, need_dx, dx, Cin, 0, res, CE, 0, in_aff=x_aff)
+        if lazy is not None and bypass and need_dx:
+            _LAZY[dx.data_ptr()] = lazy[:5] + (True,)
         return (dx, gs[0], gs[1], gs[2], gs[3], None, None, g1[0], g1[1], g1[2], g1[3], None, None,
                 g3[0], g3[1], g3[2], g3[3], None, None, None, None, None, None, None, None, None)
 
@@ -974,6 +1028,9 @@ class SEPoolFn(Function):
         # (the pooled output is kept: the scale gradient is sum dy * y / s over POOLED planes, see backward)
         ctx.save_for_backward(x, w1, w2, g, h, s, idx, y if (pool is not None and _SE_POOLED_DOT[0]) else None)
         ctx.pool = pool
+        # the producer of x (a Fire block on the cooperative BatchNorm path) routes the pooled gradient itself: _LAZY
+        ctx.lazy_ok = (pool is not None and getattr(x, "_dlio_lazy_ok", False) and tuple(pool[0:1]) == (3,)
+                       and tuple(pool[1])[1] == 2 and tuple(pool[2]) == (1, 1) and ops.bn_coop_pool_ok(N, H, W, pool[1][0]))
         return y
 
     @staticmethod
@@ -1007,6 +1064,10 @@ class SEPoolFn(Function):
             # gradients in a second one (instead of seven dense launches)
             dgs = ops.se_fc_bwd(ds.contiguous(), s, h, g, w1, w2, dw1, dw2, acc1, 1.0 / (H * W))
             k, stride, pad = ctx.pool
+            if getattr(ctx, "lazy_ok", False) and _LAZY_POOL[0] and ops._SYNC_BN[0] is None:
+                dx = torch.empty_like(x)                  # NOT written here: the Fire block's BatchNorm backward routes dy itself
+                _LAZY[dx.data_ptr()] = (dy, idx, s, dgs, stride[0], False)
+                return dx, ret1, ret2, None, None
             dx = ops.maxpool2d_bwd(dy, idx, tuple(x.shape), k, stride[0], stride[1], pad[0], pad[1], x_scale=s, x_add=dgs)
             return dx, ret1, ret2, None, None
         dz2 = ops.act_bwd(ds, s, ops.ACT_SIGMOID)

@@ -850,10 +850,10 @@ def maxpool2d_fwd_aff(x, aff, k, sh, sw, ph, pw):
     return y, idx
 
 
-def maxpool2d_bwd(dy, idx, in_shape, k, sh, sw, ph, pw, x_scale=None, x_add=None):
+def maxpool2d_bwd(dy, idx, in_shape, k, sh, sw, ph, pw, x_scale=None, x_add=None, out=None):
     N, C_, H, W = in_shape
     OH, OW = dy.shape[2], dy.shape[3]
-    dx = torch.empty(N, C_, H, W, dtype=torch.float32, device=dy.device)
+    dx = out if out is not None else torch.empty(N, C_, H, W, dtype=torch.float32, device=dy.device)
     check(lib.dlio_maxpool2d_bwd(_ptr(dy), _ptr(idx), _ptr(x_scale), _ptr(x_add), _ptr(dx), N, C_, H, W,
                                  OH, OW, k, sh, sw, ph, pw, _stream()), "maxpool2d_bwd")
     return dx

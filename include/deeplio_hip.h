@@ -604,7 +604,7 @@ int dlio_bn_coop_bwd(const float* dy, int dy_ctot, int dy_coff, const float* x, 
  * formed while loading, x_scale[n, c] * route(dy_pooled through idx) + x_add[n, c] (+ dy, nullable: the part of the gradient
  * that is stored) -- what dlio_maxpool2d_bwd(x_scale, x_add) would have written, at a quarter of the traffic.  dy_pooled /
  * idx: [N][C][OH][OW] (C = all channels of this launch), x_scale / x_add [N][C] nullable.  dlio_bn_coop_pool_ok(N, H, W, SH):
- * the geometry rule (dlio_bn_coop_ok + a part of a plane is whole 8-row strips). */
+ * the geometry rule (dlio_bn_coop_ok, W a multiple of 16 with W / 8 dividing 64 and the workgroup size). */
 int dlio_bn_coop_pool_ok(int N, int H, int W, int SH);
 int dlio_bn_coop_bwd_pool(const float* dy, int dy_ctot, int dy_coff, const float* dy_pooled, const unsigned char* idx,
                           const float* x_scale, const float* x_add, int H, int W, int SH, const float* x, int x_ctot,

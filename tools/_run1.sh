@@ -1,2 +1,2 @@
 cd /root/repo
-timeout 600 python -m pytest tests/test_gpu_ops.py -q -x -k "pool_gradient_routed or batchnorm_small_one_launch" 2>&1 | tail -15
+bash tools/rep_ab.sh DLIO_LAZY_POOL_GRAD=0 2>&1 | tee gpurun_out/ab_lazy_pool2.txt
