@@ -578,7 +578,7 @@ int dlio_bn_small_bwd(const float* dy, int dy_ctot, int dy_coff, const float* x,
  * dlio_bn_small_fwd / _bwd (no statistics-only mode: y required).  The launch is a persistent grid of at most ~half the
  * chip, so that two of them (two streams) can always be resident together; do not run more than two concurrently. */
 int dlio_bn_coop_ok(int N, int HW);
-/* CUs' worth of wave slots one cooperative launch may occupy (default 120 of 256; at most 128: two launches must fit the
+/* CUs' worth of wave slots one cooperative launch may occupy (default 104 of 256; at most 128: two launches must fit the
  * chip together).  Data-parallel runs lower it to leave room for the RCCL kernels that spin beside them. */
 int dlio_bn_coop_set_cus(int cus);
 int dlio_bn_coop_parts(int N, int HW);
