@@ -76,7 +76,7 @@ SIGNATURES = {
     "dlio_bn_small_fwd": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p,
                                _p, _i, _i, _p, _p, _p, _p, _i, _i, _p, _i, _i, _p]),
     "dlio_bn_small_bwd": (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i,
-                               _p]),
+                               _p, _p]),
     "dlio_bn_coop_ok": (_i, [_i, _i]),
     "dlio_bn_bf16_coop_fwd": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _i, _i, _p, _i, _i,
                                    _p, _i, _i, _p, _p, _p]),

@@ -106,9 +106,12 @@ template <int V>
 __global__ __launch_bounds__(1024) void bn_small_bwd_kernel(
     const float* __restrict__ dy, int dy_ctot, int dy_coff, const float* __restrict__ x, int x_ctot, int x_coff, int N, int C,
     int C1, BnSet s1, BnSet s2, const float* __restrict__ mean, const float* __restrict__ invstd,
-    const float* __restrict__ scale, float* __restrict__ dx1, float* __restrict__ dx2, int accumulate, int post_relu) {
+    const float* __restrict__ scale, float* __restrict__ dx1, float* __restrict__ dx2, int accumulate, int post_relu,
+    float* __restrict__ amax_out) {
   constexpr int HW = 256 * V;
   __shared__ double sm[2][16];
+  __shared__ unsigned wg_amax;
+  if (threadIdx.x == 0) wg_amax = 0u;                 // (block16_sum's barriers order this before the atomics below)
   const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const BnSet& ps = c < C1 ? s1 : s2;
   const int cl = c < C1 ? c : c - C1;
@@ -144,17 +147,28 @@ __global__ __launch_bounds__(1024) void bn_small_bwd_kernel(
     if (ps.dbeta) ps.dbeta[cl] = accumulate ? ps.dbeta[cl] + (float)sg : (float)sg;
     if (ps.dgamma) ps.dgamma[cl] = accumulate ? ps.dgamma[cl] + (float)sgx : (float)sgx;
   }
-  if (!have) return;
   const double inv_cnt = 1.0 / ((double)N * HW);
   const float mg = (float)(sg * inv_cnt), mgx = (float)(sgx * inv_cnt);
   float* op = c < C1 ? dx1 + ((size_t)wave * C1 + c) * HW : dx2 + ((size_t)wave * (C - C1) + cl) * HW;
+  float amax = 0.f;
 #pragma unroll
   for (int j = 0; j < V; ++j) {
+    if (!have) break;
     float4 o;
     o.x = sc * (g[j].x - mg - xh[j].x * mgx); o.y = sc * (g[j].y - mg - xh[j].y * mgx);
     o.z = sc * (g[j].z - mg - xh[j].z * mgx); o.w = sc * (g[j].w - mg - xh[j].w * mgx);
     *reinterpret_cast<float4*>(op + 4 * (lane + 64 * j)) = o;
+    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
   }
+  if (amax_out) {                                     // largest |dx| (for the two-piece split kernels, as bn_coop_bwd_kernel)
+    // ONE atomic per workgroup: the 16 waves x C workgroups of a launch on one address (12 k serialised atomics at fire_blk5)
+    // cost 0.7 ms per step
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if (lane == 0) atomicMax(&wg_amax, __float_as_uint(amax));
+  }
+  __syncthreads();
+  if (amax_out && threadIdx.x == 0 && wg_amax) atomicMax(reinterpret_cast<unsigned*>(amax_out), wg_amax);
 }
 
 // ---- the same for LARGE feature maps: a channel spread over N cooperating workgroups ---------------------------------
@@ -500,10 +514,15 @@ __global__ __launch_bounds__(T) void bn_coop_bwd_kernel(
     coop_depart(part, sync, c, NP);
     __syncthreads();
   }
-  if (amax_out) {
+  if (amax_out) {                                     // one atomic per workgroup (same-address atomics serialise)
+    __shared__ unsigned wg_amax;
+    if (threadIdx.x == 0) wg_amax = 0u;
+    __syncthreads();
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
-    if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax_out), __float_as_uint(amax));
+    if ((threadIdx.x & 63) == 0) atomicMax(&wg_amax, __float_as_uint(amax));
+    __syncthreads();
+    if (threadIdx.x == 0 && wg_amax) atomicMax(reinterpret_cast<unsigned*>(amax_out), wg_amax);
   }
 }
 
@@ -705,7 +724,7 @@ extern "C" int dlio_bn_small_bwd(const float* dy, int dy_ctot, int dy_coff, cons
                                  const float* mean, const float* invstd, const float* scale, const float* beta1,
                                  const float* beta2, float* dx1, float* dx2, float* dgamma1, float* dbeta1, float* dgamma2,
                                  float* dbeta2, int accumulate, int N, int C, int C1, int HW, int post_relu,
-                                 dlio_stream_t stream) {
+                                 float* amax_out, dlio_stream_t stream) {
   if (!dy || !x || !mean || !invstd || !scale || C <= 0 || C1 < 0 || C1 > C || N <= 0 || HW <= 0) return DLIO_EINVAL;
   if ((C1 > 0 && !dx1) || (C1 < C && !dx2)) return DLIO_EINVAL;
   const int v = small_v(N, HW);
@@ -718,7 +737,7 @@ extern "C" int dlio_bn_small_bwd(const float* dy, int dy_ctot, int dy_coff, cons
   const BnSet s2{nullptr, beta2, nullptr, nullptr, dgamma2, dbeta2};
   DlioProfScope prof(9, s, 0.0, 3.0 * 4.0 * N * (double)C * HW);
 #define BNS(VV) hipLaunchKernelGGL(bn_small_bwd_kernel<VV>, dim3((unsigned)C), dim3(1024), 0, s, dy, dy_ctot, dy_coff, x, x_ctot, x_coff, \
-                                   N, C, C1, s1, s2, mean, invstd, scale, dx1, dx2, accumulate, post_relu)
+                                   N, C, C1, s1, s2, mean, invstd, scale, dx1, dx2, accumulate, post_relu, amax_out)
   if (v == 1) BNS(1); else if (v == 2) BNS(2); else if (v == 4) BNS(4); else BNS(8);
 #undef BNS
   return dlio_check_launch();

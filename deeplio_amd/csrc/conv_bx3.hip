@@ -1454,19 +1454,21 @@ extern "C" int dlio_fire_expand_dgrad(const float* x, const void* wt, const floa
 }
 
 // geometry the producer / consumer kernel takes: long channel loops on large maps (the data gradients of fire_blk1-3)
-static bool bx3_pc_geom_ok(const DlioConvDesc& d) {
+// (min_half_cus: tiles >= this x CUs / 2.  The three-piece kernel needs two tiles per CU to beat the alds kernel; the two-piece
+//  one wins from half a tile per CU on -- fire_blk4's 256 -> 64 @32x64: 51.6 us against 73.7 on the alds kernel, three-piece 80.7)
+static bool bx3_pc_geom_ok(const DlioConvDesc& d, int pc_min_half_cus = 4) {
   constexpr int pc_kc = 4;              // chunks of 16 input channels from which the producer / consumer split pays
   return d.KH == 3 && d.KW == 3 && d.SH == 1 && d.SW == 1 && d.PH == 1 && d.PW == 1 && d.OH == d.H && d.OW == d.W && d.OW >= 64 &&
          (d.OW & 3) == 0 && (d.Cin + 15) / 16 >= pc_kc && (size_t)9 * ((d.Cin + 15) / 16) * 3 * d.Cout * 32 < 0x7fffffffull &&
          (size_t)d.Cin * d.H * d.W * 4 < 0xffffff00ull &&
-         (int64_t)d.N * cdiv(d.OH, 4) * cdiv(d.OW, 64) * cdiv(d.Cout, d.Cout <= 32 ? 32 : 64) >= 2 * (int64_t)dlio_num_cus();
+         (int64_t)d.N * cdiv(d.OH, 4) * cdiv(d.OW, 64) * cdiv(d.Cout, d.Cout <= 32 ? 32 : 64) * 2 >= pc_min_half_cus * (int64_t)dlio_num_cus();
 }
 
 /* the same convolution on the two-piece fp16 split (conv3x3_bx3_pc_kernel<MR, true>): x fp32 with *amax_x = its largest
  * magnitude (left on the device by the kernel that produced x), wt from dlio_conv_h2_prep.  Only the launch sizes of the
  * producer / consumer kernel (dlio_conv3x3_h2_ok), DLIO_EUNSUP otherwise. */
 extern "C" int dlio_conv3x3_h2_ok(const DlioConvDesc* dp) {
-  return dp && dp->N > 0 && dp->Cin > 0 && dp->Cout > 0 && bx3_pc_geom_ok(*dp) && bx3_3x3_ksplit(*dp) == 1;
+  return dp && dp->N > 0 && dp->Cin > 0 && dp->Cout > 0 && bx3_pc_geom_ok(*dp, 1);
 }
 
 extern "C" int dlio_conv3x3_h2_fwd(const float* x, const float* amax_x, const void* wt, const float* bias, const float* residual,

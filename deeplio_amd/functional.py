@@ -294,8 +294,9 @@ class _CBR:
         if (training and need_dx and _use_bx3(N, Cout, Cin, KH, KW, stride, H, W)
                 and (KH == 3 or (pad[0] == 0 and pad[1] == 0))):
             d.wbx3_1 = ops.conv_bx3_prepped(weight, 1)          # data-gradient direction: roles swapped
-            if KH == 1 and _DGRAD1_H2[0] and ops.bn_coop_ok(N, d.OH * d.OW) and ops._SYNC_BN[0] is None:
-                # 1x1 data gradients behind a cooperative BatchNorm backward (which leaves the largest |dy|): two fp16 pieces
+            if (KH == 1 and _DGRAD1_H2[0] and ops._SYNC_BN[0] is None
+                    and (ops.bn_coop_ok(N, d.OH * d.OW) or (_SMALL_H2[0] and ops.bn_small_ok(N, d.OH * d.OW)))):
+                # 1x1 data gradients behind a one-launch BatchNorm backward (which leaves the largest |dy|): two fp16 pieces
                 d.wh2_1 = ops.conv_h2_prepped(weight, 1)
             if KH == 3 and _DGRAD_H2[0] and tuple(stride) == (1, 1):
                 # ... and as two fp16 pieces where the data gradient runs on the two-piece kernel (it needs the largest
@@ -407,8 +408,10 @@ class _CBR:
             ops.bn_coop_bwd(dy, dy_ctot, dy_coff, raw, d.out_ctot, d.out_coff, prm, beta, None, draw, None, dgamma, dbeta,
                             None, None, acc_g, N, Cout, Cout, OHW, post_relu, amax_out=amax)
         elif (training and _BN_SMALL[0] and not pre_relu and dy.is_cuda and ops.bn_small_ok(N, OHW) and pooled is None):
+            if amax is None and need_dx and _SMALL_H2[0] and getattr(d, "wh2_1", None) is not None:
+                amax = ops.amax_slot(dy.device)
             ops.bn_small_bwd(dy, dy_ctot, dy_coff, raw, d.out_ctot, d.out_coff, prm, beta, None, draw, None, dgamma, dbeta,
-                             None, None, acc_g, N, Cout, Cout, OHW, post_relu)
+                             None, None, acc_g, N, Cout, Cout, OHW, post_relu, amax_out=amax)
         elif pooled is not None:
             # dy is the POOLED gradient: (arg-max map, pool row stride) -- the BatchNorm passes gather the gradient of the
             # activated tensor themselves (dlio_bn_bwd_pool), the pool's backward pass is not run
@@ -510,6 +513,7 @@ _FIRE_FUSED = [os.environ.get("DLIO_FIRE_FUSED", "1") != "0"]
 _DGRAD_H2 = [os.environ.get("DLIO_DGRAD_H2", "1") != "0"]       # 3x3 data gradients of fire_blk1-3 on two fp16 pieces
 _FIRE_H2 = [os.environ.get("DLIO_FIRE_H2", "1") != "0"]         # fused Fire forward on two fp16 pieces (training)
 _DGRAD1_H2 = [os.environ.get("DLIO_DGRAD1_H2", "1") != "0"]     # squeeze / expand1x1 data gradients of fire_blk1-3 likewise
+_SMALL_H2 = [os.environ.get("DLIO_SMALL_H2", "1") != "0"]       # ... and of fire_blk4 / blk5 (scale from dlio_bn_small_bwd's amax_out)
 _WGRAD_H2 = [os.environ.get("DLIO_WGRAD_H2", "1") != "0"]       # expand3x3 weight gradients of fire_blk1-3 on two fp16 pieces
 _FIRE_STATS = [os.environ.get("DLIO_FIRE_STATS", "1") != "0"]   # apply-on-load blocks: BatchNorm statistics from the expand launch
 _PAIR_FUSE = [os.environ.get("DLIO_PAIR_FUSE", "1") != "0"]   # gap + add / sub + fc1 + act of the lidar head as one launch
@@ -907,11 +911,13 @@ class FireFn(Function):
             if len({k[1] for k in sk}) > 1:          # one accumulate flag serves the four outputs
                 fresh = [_new((E1 if i < 2 else E3,), dout) for i in range(4)]
                 sk = [(t, False, t) for t in fresh]
+            # (the data / weight gradients on the two-piece kernels take their scale from the largest |draw|)
+            amax3 = (ops.amax_slot(dout.device) if (getattr(d_3, "wh2_1", None) is not None
+                                                     or getattr(d_1, "wh2_1", None) is not None
+                                                     or getattr(d_s, "out_bound", None) is not None) else None)
+            if not bcoop and not _SMALL_H2[0]:
+                amax3 = None
             if bcoop:
-                # (the 3x3 data gradient on the two-piece kernel takes its scale from the largest |draw|)
-                amax3 = (ops.amax_slot(dout.device) if (getattr(d_3, "wh2_1", None) is not None
-                                                         or getattr(d_1, "wh2_1", None) is not None
-                                                         or getattr(d_s, "out_bound", None) is not None) else None)
                 if lazy is not None:
                     ops.bn_coop_bwd_pool(dout if lazy[5] else None, CE, 0, lazy[:5], raw_e, CE, 0, small_prm, e1be, e3be, draw1,
                                          draw3, sk[0][0], sk[1][0], sk[2][0], sk[3][0], sk[0][1], N, CE, E1, H, W, True,
@@ -921,7 +927,7 @@ class FireFn(Function):
                                     sk[2][0], sk[3][0], sk[0][1], N, CE, E1, H * W, True, amax_out=amax3)
             else:
                 ops.bn_small_bwd(dout, CE, 0, raw_e, CE, 0, small_prm, e1be, e3be, draw1, draw3, sk[0][0], sk[1][0], sk[2][0],
-                                 sk[3][0], sk[0][1], N, CE, E1, H * W, True)
+                                 sk[3][0], sk[0][1], N, CE, E1, H * W, True, amax_out=amax3)
             bg1, bg3 = (sk[0][2], sk[1][2]), (sk[2][2], sk[3][2])
         wdg = getattr(ctx, "wdg", None)
         g1 = _CBR.backward(dout, CE, 0, act_s, d_1, e1w, e1b, e1g, prm_1, e1be, raw_e, training, False,

@@ -559,10 +559,11 @@ def bn_small_fwd(x, x_ctot, x_coff, N, C_, C1, HW, set1, set2, eps, momentum, pr
 
 
 def bn_small_bwd(dy, dy_ctot, dy_coff, x, x_ctot, x_coff, prm, beta1, beta2, dx1, dx2, dg1, db1, dg2, db2, accumulate, N,
-                 C_, C1, HW, post_relu=True):
+                 C_, C1, HW, post_relu=True, amax_out=None):
+    """amax_out: a zeroed one-float tensor (amax_slot) that receives max |dx| (for the two-piece split kernels)"""
     check(lib.dlio_bn_small_bwd(_ptr(dy), dy_ctot, dy_coff, _ptr(x), x_ctot, x_coff, _ptr(prm[0]), _ptr(prm[1]), _ptr(prm[2]),
                                 _ptr(beta1), _ptr(beta2), _ptr(dx1), _ptr(dx2), _ptr(dg1), _ptr(db1), _ptr(dg2), _ptr(db2),
-                                int(accumulate), N, C_, C1, HW, int(post_relu), _stream()), "bn_small_bwd")
+                                int(accumulate), N, C_, C1, HW, int(post_relu), _ptr(amax_out), _stream()), "bn_small_bwd")
 
 
 _COOP_WS = {}

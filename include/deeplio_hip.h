@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 230
+#define DLIO_ABI_VERSION 231
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);           /* "gfx950" */
@@ -567,7 +567,7 @@ int dlio_bn_small_bwd(const float* dy, int dy_ctot, int dy_coff, const float* x,
                       const float* mean, const float* invstd, const float* scale, const float* beta1,
                       const float* beta2, float* dx1, float* dx2, float* dgamma1, float* dbeta1, float* dgamma2,
                       float* dbeta2, int accumulate, int N, int C, int C1, int HW, int post_relu,
-                      dlio_stream_t stream);
+                      float* amax_out, dlio_stream_t stream);
 /* The same for LARGE feature maps (fire_blk1-3: 32-128 KB per (n, c) plane): the N workgroups that hold a channel's planes
  * in registers exchange partial sums through `part` ([C][N][2] 64-bit slots, every one holding dlio_bn_coop_empty() before the first
  * use: a slot is its own arrival flag) and per-channel departure counters in `sync` ([C + 1] ints, zero before the first

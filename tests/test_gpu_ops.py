@@ -1341,10 +1341,9 @@ def test_batchnorm_small_one_launch(dev, case, residual):
     dx1 = torch.empty(N, c1, H, W, device=dev)
     dx2 = torch.empty(N, C - c1, H, W, device=dev) if c1 < C else None
     dg, db = torch.ones(C, device=dev), torch.ones(C, device=dev)
-    am = ops.amax_slot(dev) if coop else None
+    am = ops.amax_slot(dev)
     bwd(d(dyw), C + 2, 1, d(xw), C + 3, 2, prm, set1[1], None if set2 is None else set2[1], dx1, dx2,
-        dg[:c1], db[:c1], dg[c1:] if c1 < C else None, db[c1:] if c1 < C else None, True, N, C, c1, HW, True,
-        **(dict(amax_out=am) if coop else {}))
+        dg[:c1], db[:c1], dg[c1:] if c1 < C else None, db[c1:] if c1 < C else None, True, N, C, c1, HW, True, amax_out=am)
     dx = dx1 if dx2 is None else torch.cat([dx1, dx2], 1)
     assert am is None or float(am) == float(dx.abs().max())        # (what the two-piece split kernels scale by)
     assert rel_err(dx, x64.grad) < 2e-6
