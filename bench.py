@@ -267,6 +267,10 @@ def main():
         # mixed precision: 75 FLOP/B fused is far below the bf16 ridge (315) -> priced in bytes
         "conv_bf16": ((11,), "hbm", PEAK_HBM_GBS, "native-bf16 convolutions (forward, data and weight gradient; HBM-bound)"),
     }
+    if not (args.lidar == "lidar-feat-pointseg" and args.dtype == "f32"):
+        # FlowNet / ResNet / Simple-1 have no layer on the two-piece kernels (nor has the bf16 path): three-piece ceiling
+        for k in ("conv3x3_bx3", "wgrad3x3"):
+            FAMILIES[k] = FAMILIES[k][:2] + (PEAK_BX3_TFLOPS,) + FAMILIES[k][3:]
     SUBKIND = {6: "forward statistics", 7: "forward apply", 8: "backward reductions", 9: "backward apply"}
     ALL_KINDS = sorted(k for f in FAMILIES.values() for k in f[0])
 
@@ -378,6 +382,9 @@ def main():
                                   "launches of fire_blk1-3); the three-piece bf16 launches that remain (small maps, stems: "
                                   "6 MFMAs, ceiling 419.5) are priced against the same, higher ceiling")
                 out["frac_of_three_piece_ceiling"] = round(a / PEAK_BX3_TFLOPS, 4)
+                out["frac_of_fp32_mfma_peak"] = round(a / PEAK_F32_MFMA_TFLOPS, 4)
+            elif peak == PEAK_BX3_TFLOPS:
+                out["peak_is"] = "bf16 dense MFMA peak 2516.8 TF/s / 6 MFMAs per fp32 product (three-piece bf16 split)"
                 out["frac_of_fp32_mfma_peak"] = round(a / PEAK_F32_MFMA_TFLOPS, 4)
             if name == "batchnorm":
                 out["bytes_are"] = ("what the launches move by construction: the one-launch kernels (csrc/bn_small.hip: a "

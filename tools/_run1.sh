@@ -1,3 +1,8 @@
-cd /root/repo
-timeout 900 python -m pytest tests/test_gpu_ops.py -q -x -k "batchnorm_small_one_launch or pool_gradient_routed" 2>&1 | tail -3
-bash tools/rep_ab.sh DLIO_SMALL_H2=0 2>&1 | tee gpurun_out/ab_small_h2.txt
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
+bash $R/tools/collect_profiles.sh r04 > $O/collect.log 2>&1
+cd $R
+python bench.py --lidar lidar-feat-flownet --batch 4 --no-cpu-baseline > $O/r04_bench_flownet.json 2> $O/fl.err
+python bench.py --lidar lidar-feat-resnet --batch 4 --no-cpu-baseline > $O/r04_bench_resnet.json 2> $O/rs.err
+python tools/block_times.py > $O/r04_block_times.txt 2>&1
+bash tools/pmc_mfma.sh r04 > /dev/null 2>&1
+tail -3 $O/collect.log; tail -c 600 $O/r04_bench_default.json; ls -la $O | grep r04_ | head -30

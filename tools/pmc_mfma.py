@@ -20,6 +20,26 @@ import re
 import sqlite3
 import sys
 
+def rate_label(k, util):
+    """MFMA rate the utilisation stands for: fp32 MFMA 157.3 TF/s; three-piece bf16 split 2516.8 / 6 = 419.5 fp32-equivalent;
+    two-piece fp16 split 2516.8 / 3 = 838.9 (the `..., true>` instantiations of the 3x3 / 1x1 split kernels)"""
+    m = re.search(r"<(.*)>", k)
+    a = [t.strip() for t in m.group(1).split(",")] if m else []
+    name = k.split("<")[0]
+    h2 = ((name.endswith("conv3x3_bx3_pc_kernel") and a[1:2] == ["true"]) or (name.endswith("fire_expand_fwd_kernel") and a[2:3] == ["true"])
+          or (name.endswith("wgrad3_kernel") and a[3:4] == ["true"]) or (name.endswith("conv1x1_bx3_kernel") and a[2:3] == ["true"]))
+    if h2:
+        return "%.1f (fp32-equivalent: util x 838.9, two-piece)" % (util * 8.389)
+    nat = (name.endswith("wgrad3_kernel") and a[2:3] == ["true"]) or (name.endswith("wgrad1x1_direct_kernel") and a[3:4] == ["true"]) or "bf16" in name
+    if nat:
+        return "%.1f (bf16 MFMA: util x 2516.8)" % (util * 25.168)
+    bx3 = ("bx3" in name or name.endswith("fire_expand_fwd_kernel") or name.endswith("wgrad3_kernel")
+           or (name.endswith("wgrad1x1_direct_kernel") and a[2:3] == ["true"]))
+    if bx3:
+        return "%.1f (fp32-equivalent: util x 419.5, three-piece)" % (util * 4.195)
+    return "%.1f" % (util * 1.573)
+
+
 
 def main(db, out):
     cur = sqlite3.connect(db).cursor()
@@ -53,7 +73,7 @@ def main(db, out):
         f.write("| kernel | launches | GPU-active cycles (M) | MfmaUtil %% | on duration x 2.4 GHz %% | = TFLOP/s incl. padding | WAIT_ANY %% | WAIT_INST_ANY %% | ACTIVE_INST %% |\n".replace("%%", "%"))
         f.write("|---|---|---|---|---|---|---|---|---|\n")
         for act, k, n, util, util_d, wa, wi, ai in lines:
-            tf = "%.1f (fp32-equivalent: util x 419.5)" % (util * 4.195) if ("bx3" in k or ("wgrad3_kernel" in k and k.rstrip().endswith("false>")) or ("wgrad1x1_direct" in k and k.rstrip().endswith("true>"))) else "%.1f" % (util * 1.573)
+            tf = rate_label(k, util)
             f.write("| `%s` | %d | %.1f | %.1f | %.1f | %s | %.0f | %.0f | %.0f |\n" % (k[:70], n, act / 1e6, util, util_d, tf, wa, wi, ai))
         f.write("\nAll kernels of the pass: MFMA busy %.1f %% of GPU-active cycles (MFMA kernels only: %.1f %%).\n"
                 % (100.0 * tot_busy / (tot_act * 1024), 100.0 * tot_busy / (sum(l[0] for l in lines) * 1024)))
