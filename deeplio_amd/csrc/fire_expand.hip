@@ -509,18 +509,32 @@ int launch_fire_fwd(const __bf16* planes, const __bf16* w3t, const __bf16* w1t, 
 
 // ---- weights as two fp16 pieces of w * 2^k: layout [tap][chunk][2][n][16] (the split-bf16 layout with two planes), behind
 // it { 2^-k, 2^k } as floats.  2^k maps the tensor's largest magnitude into [2^13, 2^14].
-__global__ __launch_bounds__(256) void prep_h2_amax_kernel(const DlioPrepItem* __restrict__ items, DlioPrepItem single) {
-  __shared__ float wm[4];
+// (one workgroup per weight tensor; 1024 threads x 16-byte loads: with 256 threads and scalar loads the largest tensor -- 147 k
+//  elements, 576 dependent trips -- took 163 us at the head of EVERY step, in front of both encoders' first kernel)
+__global__ __launch_bounds__(1024) void prep_h2_amax_kernel(const DlioPrepItem* __restrict__ items, DlioPrepItem single) {
+  __shared__ float wm[16];
   const DlioPrepItem it = items ? items[blockIdx.x] : single;
   const int64_t n = (int64_t)it.Cout * it.Cin * it.taps;
   float b = 0.f;
-  for (int64_t i = threadIdx.x; i < n; i += 256) b = fmaxf(b, fabsf(it.w[i]));
+  if ((reinterpret_cast<uintptr_t>(it.w) & 15) == 0) {
+    const float4* w4 = reinterpret_cast<const float4*>(it.w);
+    const int64_t n4 = n >> 2;
+    for (int64_t i = threadIdx.x; i < n4; i += 1024) {
+      const float4 v = w4[i];
+      b = fmaxf(b, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 1024) b = fmaxf(b, fabsf(it.w[i]));
+  } else {
+    for (int64_t i = threadIdx.x; i < n; i += 1024) b = fmaxf(b, fabsf(it.w[i]));
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) b = fmaxf(b, __shfl_xor(b, o, 64));
   if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = b;
   __syncthreads();
   if (threadIdx.x == 0) {
-    b = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    b = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) b = fmaxf(b, wm[i]);
     const float sc = (b > 0.f && b < 3.0e38f) ? exp2f(floorf(log2f(16384.f / b))) : 1.f;
     const int K = it.mode == 0 ? it.Cin : it.Cout, Nn = it.mode == 0 ? it.Cout : it.Cin;
     float* tail = it.wt + (size_t)it.taps * ((K + 15) >> 4) * Nn * 16;
@@ -622,7 +636,7 @@ extern "C" int dlio_conv_h2_prep(const float* w, void* wt, int Cout, int Cin, in
   const int64_t total = (int64_t)taps * ((K + 15) >> 4) * Nn * 16;
   const DlioPrepItem one{w, reinterpret_cast<float*>(wt), Cout, Cin, taps, mode, 0};
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(prep_h2_amax_kernel, dim3(1), dim3(256), 0, s, (const DlioPrepItem*)nullptr, one);
+  hipLaunchKernelGGL(prep_h2_amax_kernel, dim3(1), dim3(1024), 0, s, (const DlioPrepItem*)nullptr, one);
   hipLaunchKernelGGL(prep_h2_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, s, (const DlioPrepItem*)nullptr, 1, total, one);
   return dlio_check_launch();
 }
@@ -631,7 +645,7 @@ extern "C" int dlio_conv_h2_prep_batched(const DlioPrepItem* items_dev, int n_it
   if (!items_dev || n_items <= 0 || total <= 0) return DLIO_EINVAL;
   hipStream_t s = as_stream(stream);
   const DlioPrepItem none{nullptr, nullptr, 0, 0, 0, 0, 0};
-  hipLaunchKernelGGL(prep_h2_amax_kernel, dim3((unsigned)n_items), dim3(256), 0, s, items_dev, none);
+  hipLaunchKernelGGL(prep_h2_amax_kernel, dim3((unsigned)n_items), dim3(1024), 0, s, items_dev, none);
   hipLaunchKernelGGL(prep_h2_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, s, items_dev, n_items, total, none);
   return dlio_check_launch();
 }
