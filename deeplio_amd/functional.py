@@ -293,17 +293,22 @@ class _CBR:
             wt = ops.conv2d_prepped(weight, 0)
         if (training and need_dx and _use_bx3(N, Cout, Cin, KH, KW, stride, H, W)
                 and (KH == 3 or (pad[0] == 0 and pad[1] == 0))):
-            d.wbx3_1 = ops.conv_bx3_prepped(weight, 1)          # data-gradient direction: roles swapped
-            if (KH == 1 and _DGRAD1_H2[0] and ops._SYNC_BN[0] is None
+            if (KH == 1 and _DGRAD1_H2[0] and ops._SYNC_BN[0] is None and not pre_relu and _BN_SMALL[0]
                     and (ops.bn_coop_ok(N, d.OH * d.OW) or (_SMALL_H2[0] and ops.bn_small_ok(N, d.OH * d.OW)))):
                 # 1x1 data gradients behind a one-launch BatchNorm backward (which leaves the largest |dy|): two fp16 pieces
                 d.wh2_1 = ops.conv_h2_prepped(weight, 1)
-            if KH == 3 and _DGRAD_H2[0] and tuple(stride) == (1, 1):
+            if KH == 3 and _DGRAD_H2[0] and tuple(stride) == (1, 1) and ops._SYNC_BN[0] is None and not pre_relu and _BN_SMALL[0]:
                 # ... and as two fp16 pieces where the data gradient runs on the two-piece kernel (it needs the largest
                 # magnitude of its operand: conv_dgrad's `amax`, else the three-piece layout above is used)
                 g = ops.conv_desc(N, Cout, d.OH, d.OW, Cin, 3, 3, 1, 1, 2 - d.PH, 2 - d.PW, OH=H, OW=W)
                 if ops.conv3x3_h2_ok(g):
                     d.wh2_1 = ops.conv_h2_prepped(weight, 1)
+            # the three-piece layout of the data-gradient direction (roles swapped) only where no two-piece one exists: every
+            # registered layout is rebuilt at the head of each step, in front of both encoders (conv_dgrad fetches it on demand
+            # should the producer of dy not have left a magnitude)
+            d.bx3_1_ok = True
+            if getattr(d, "wh2_1", None) is None:
+                d.wbx3_1 = ops.conv_bx3_prepped(weight, 1)
         if training:
             # data-gradient layouts for backward: fetched here, where `weight` is the long-lived
             # Parameter (the cache identifies weights by object; backward only sees unpacked copies)
@@ -312,7 +317,7 @@ class _CBR:
                 plan = _phase_plan(d)
             # the fp32 layout only where conv_dgrad will run the fp32-MFMA kernel on it (every registered layout is
             # rebuilt once per optimizer step: the split-bf16 layers' fp32 copies were a third of that launch)
-            if need_dx and getattr(d, "wbx3_1", None) is None and plan is None:
+            if need_dx and getattr(d, "wbx3_1", None) is None and not getattr(d, "bx3_1_ok", False) and plan is None:
                 d.wt2 = ops.conv2d_prepped(weight, 1)
             if plan is not None:               # tap-subset layouts of the phase-decomposed data gradient
                 d.wt_ph = {(it[0], it[1]): (ops.conv_bx3_prepped_phase(weight, d.SH, d.SW, it[0], it[1])
@@ -466,11 +471,13 @@ def conv_dgrad(dy, weight, d, dx, dx_ctot, dx_coff, residual=None, r_ctot=0, r_c
         residual, r_ctot, r_coff = dx, dx_ctot, dx_coff
     wb = getattr(d, "wbx3_1", None) if (d.SH == 1 and d.SW == 1) else None
     wh = getattr(d, "wh2_1", None) if amax is not None else None
+    if wh is None and wb is None and getattr(d, "bx3_1_ok", False) and d.SH == 1 and d.SW == 1:
+        wb = ops.conv_bx3_prepped(weight, 1)             # (a two-piece layer whose operand came without its magnitude)
     if wh is not None and d.KH == 3:
         g = ops.conv_desc(N, Cout, d.OH, d.OW, Cin, 3, 3, 1, 1, 2 - d.PH, 2 - d.PW, OH=d.H, OW=d.W, in_ctot=Cout,
                           in_coff=0, out_ctot=dx_ctot, out_coff=dx_coff, res_ctot=r_ctot, res_coff=r_coff)
         ops.conv3x3_h2_fwd(dy, amax, wh, None, dx, g, residual=residual)
-    elif wh is not None and d.KH == 1 and wb is not None:
+    elif wh is not None and d.KH == 1:
         g = ops.conv_desc(N, Cout, d.OH, d.OW, Cin, 1, 1, 1, 1, 0, 0, OH=d.H, OW=d.W, in_ctot=Cout,
                           in_coff=0, out_ctot=dx_ctot, out_coff=dx_coff, res_ctot=r_ctot, res_coff=r_coff)
         ops.conv1x1_h2_fwd(dy, amax, wh, None, dx, g, residual=residual)

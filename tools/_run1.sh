@@ -1,8 +1,3 @@
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
-bash $R/tools/collect_profiles.sh r04 > $O/collect.log 2>&1
-cd $R
-python bench.py --lidar lidar-feat-flownet --batch 4 --no-cpu-baseline > $O/r04_bench_flownet.json 2> $O/fl.err
-python bench.py --lidar lidar-feat-resnet --batch 4 --no-cpu-baseline > $O/r04_bench_resnet.json 2> $O/rs.err
-python tools/block_times.py > $O/r04_block_times.txt 2>&1
-bash tools/pmc_mfma.sh r04 > /dev/null 2>&1
-tail -c 300 $O/r04_bench_default.json
+cd /root/repo
+run() { env "$@" python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-isolated 2>/dev/null | tail -1 | python -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])"; }
+for i in 1 2 3 4 5; do echo "pruned $(run X=1)  keep $(run DLIO_KEEP_BX3_DGRAD=1)"; done
