@@ -77,12 +77,16 @@ SIGNATURES = {
                                _p, _i, _i, _p, _p, _p, _p, _i, _i, _p, _i, _i, _p]),
     "dlio_bn_small_bwd": (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i,
                                _p, _p]),
+    "dlio_bn_aff_apply": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _i, _i, _p, _i, _i, _p]),
+    "dlio_bn_aff_pool_ok": (_i, [_i, _i, _i]),
+    "dlio_bn_aff_pool_fwd": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "dlio_bn_coop_ok": (_i, [_i, _i]),
     "dlio_bn_bf16_coop_fwd": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _i, _i, _p, _i, _i,
                                    _p, _i, _i, _p, _p, _p]),
     "dlio_bn_bf16_coop_bwd": (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p,
                                    _p]),
     "dlio_bn_coop_set_cus": (_i, [_i]),
+    "dlio_bn_coop_set_mode": (_i, [_i]),
     "dlio_bn_coop_parts": (_i, [_i, _i]),
     "dlio_bn_coop_gap_ok": (_i, [_i, _i]),
     "dlio_bn_coop_ws_bytes": (_sz, [_i, _i]),

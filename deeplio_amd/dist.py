@@ -63,11 +63,8 @@ class GradSync:
         self._tail_work = None
         self._timing = None          # (start events, end events) of all_reduce_grads when measure_exposed(True)
         if self.world > 1 and flat_grad.is_cuda:
-            # the cooperative BatchNorm kernels spin for their partners: with RCCL's own persistent kernels beside them two
-            # of them must still fit the chip together (csrc/bn_small.hip)
-            from . import ops
-            # (gloo = the dry run with ranks SHARING a device: four such launches may meet on it)
-            ops.bn_coop_set_cus(88 if dist.get_backend() == "nccl" else 48)
+            # (the cooperative BatchNorm launches need no co-residency with RCCL's persistent kernels: ticket dispenser,
+            #  csrc/bn_small.hip; their default grid leaves 3 / 8 of the chip's wave slots alone)
 
     def enable_sync_bn(self, on=True):
         """synchronised BatchNorm statistics: the per-channel partial sums of every train-mode BN

@@ -87,9 +87,6 @@ def aux_stream(device, name):
 def join_aux_streams():
     """current stream waits for everything issued so far on every auxiliary stream of its device"""
     _JOIN_PENDING[0] = False
-    if _LAZY:
-        _LAZY.clear()
-        raise RuntimeError("a lazy pool gradient was not consumed (functional._LAZY): DLIO_LAZY_POOL_GRAD=0 turns the scheme off")
     if not _AUX or not torch.cuda.is_available():
         return
     cur = torch.cuda.current_stream()
@@ -106,20 +103,85 @@ def join_aux_streams():
 # cannot take an entry materialises it (lazy_materialize); an entry left over at the end of backward is an error.
 _LAZY = {}
 _LAZY_POOL = [os.environ.get("DLIO_LAZY_POOL_GRAD", "1") != "0"]
+_LAZY_CB = [False]
 
 
-def lazy_materialize(t):
-    """t: a gradient tensor that may be lazy -> t holds the complete gradient"""
-    e = _LAZY.pop(t.data_ptr(), None)
+class _LazyGrad:
+    """what stands behind a gradient tensor that was handed to autograd unwritten: `tensor` (held, so that its address cannot
+    be handed out again while the entry lives), the pooled gradient / arg-max map / SE scale / SE-branch constant / pool row
+    stride it is formed from, `stored` (the tensor already holds a part of the sum), `token` (the identity of the Fire block
+    whose backward is to consume it: FireFn.forward hangs the same object on its output), `full` (shape of the gradient)"""
+    __slots__ = ("tensor", "dyp", "idx", "xs", "xadd", "sh", "stored", "token", "full")
+
+    def __init__(self, tensor, dyp, idx, xs, xadd, sh, stored, token, full):
+        self.tensor, self.dyp, self.idx, self.xs, self.xadd, self.sh = tensor, dyp, idx, xs, xadd, sh
+        self.stored, self.token, self.full = stored, token, tuple(full)
+
+    def pool(self):
+        return (self.dyp, self.idx, self.xs, self.xadd, self.sh)
+
+
+def lazy_clear():
+    """forget every pending lazy gradient (start of a training step, error paths)"""
+    _LAZY.clear()
+    _LAZY_CB[0] = False
+
+
+def _lazy_end_of_pass():
+    _LAZY_CB[0] = False
+    if _LAZY:
+        n = len(_LAZY)
+        _LAZY.clear()
+        raise RuntimeError("%d lazy pool gradient(s) were not consumed by the Fire block they were meant for (functional._LAZY): "
+                           "the backward pass did not reach it, or its gradient was taken directly -- DLIO_LAZY_POOL_GRAD=0 "
+                           "turns the scheme off" % n)
+
+
+def _lazy_put(entry):
+    """register an unwritten gradient; the pass that created it checks at its end that somebody consumed it"""
+    _LAZY[entry.tensor.data_ptr()] = entry
+    if not _LAZY_CB[0]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_lazy_end_of_pass)
+            _LAZY_CB[0] = True
+        except RuntimeError:            # not inside an engine pass (a direct call in a test)
+            pass
+
+
+def _lazy_take(dout, token):
+    """the entry behind dout if it is the one addressed to `token`; raises when the gradient of a block that expects a lazy
+    entry arrives altered (a second consumer of the block's output, a tensor hook, retain_grad: autograd then sums the
+    unwritten tensor into a new one)"""
+    e = _LAZY.get(dout.data_ptr())
+    if e is not None and (e.token is not token or token is None or tuple(e.tensor.shape) != tuple(dout.shape)):
+        e = None
+    if e is None and token is not None and any(v.token is token for v in _LAZY.values()):
+        lazy_clear()
+        raise RuntimeError("the lazy pool gradient addressed to this Fire block arrived altered: its output has a second "
+                           "consumer, a tensor hook or retain_grad -- DLIO_LAZY_POOL_GRAD=0 turns the scheme off")
+    return e
+
+
+def lazy_materialize(t, entry=None):
+    """t: a gradient tensor that may be lazy -> a tensor that holds the complete gradient (t itself when it has the
+    gradient's shape; a new one when t stands for a gradient formed entirely from pooled tensors)"""
+    e = entry if entry is not None else _LAZY.get(t.data_ptr())
     if e is None:
         return t
-    dyp, idx, xs, xadd, sh, stored = e
-    if stored:
-        full = ops.maxpool2d_bwd(dyp, idx, tuple(t.shape), 3, sh, 2, 1, 1, x_scale=xs, x_add=xadd)
+    _LAZY.pop(e.tensor.data_ptr(), None)
+    same = tuple(t.shape) == e.full
+    if e.stored:
+        full = ops.maxpool2d_bwd(e.dyp, e.idx, e.full, 3, e.sh, 2, 1, 1, x_scale=e.xs, x_add=e.xadd)
         ops.ew_binary(t, full, 0, out=t)
-    else:
-        ops.maxpool2d_bwd(dyp, idx, tuple(t.shape), 3, sh, 2, 1, 1, x_scale=xs, x_add=xadd, out=t)
-    return t
+        return t
+    return ops.maxpool2d_bwd(e.dyp, e.idx, e.full, 3, e.sh, 2, 1, 1, x_scale=e.xs, x_add=e.xadd, out=t if same else None)
+
+
+def _mark_lazy(ctx, out, ok):
+    """FireFn.forward: `out` may receive a lazy gradient (the block's cooperative BatchNorm backward routes it)"""
+    tok = object() if ok else None
+    ctx.lazy_token = tok
+    out._dlio_lazy_token = tok
 
 
 _NO_JOIN = [False]      # set while a hipGraph records a backward pass (a captured stream must not wait for outside work)
@@ -523,6 +585,24 @@ _DGRAD1_H2 = [os.environ.get("DLIO_DGRAD1_H2", "1") != "0"]     # squeeze / expa
 _SMALL_H2 = [os.environ.get("DLIO_SMALL_H2", "1") != "0"]       # ... and of fire_blk4 / blk5 (scale from dlio_bn_small_bwd's amax_out)
 _WGRAD_H2 = [os.environ.get("DLIO_WGRAD_H2", "1") != "0"]       # expand3x3 weight gradients of fire_blk1-3 on two fp16 pieces
 _FIRE_STATS = [os.environ.get("DLIO_FIRE_STATS", "1") != "0"]   # apply-on-load blocks: BatchNorm statistics from the expand launch
+# ... and for the blocks on large planes that write their output: statistics from the expand launch + a streaming apply
+# (0: the cooperative one-launch BatchNorm forward of round 4)
+_FIRE_STREAM = [os.environ.get("DLIO_FIRE_STREAM", "1") != "0"]
+# the block in front of SELayer + MaxPool pools while it applies its BatchNorm: its output is never written (0: written, pooled by SEPoolFn)
+_POOL_FUSE = [os.environ.get("DLIO_POOL_FUSE", "1") != "0"]
+
+
+def _pool_row_stride(pool):
+    """row stride of a (k, stride, pad) max-pool the fused kernels take (3 x 3, stride (1 | 2, 2), padding 1), else 0"""
+    if pool is None:
+        return 0
+    k, stride, pad = pool
+    k = k if isinstance(k, (tuple, list)) else (k, k)
+    stride = stride if isinstance(stride, (tuple, list)) else (stride, stride)
+    pad = pad if isinstance(pad, (tuple, list)) else (pad, pad)
+    if tuple(k) == (3, 3) and tuple(pad) == (1, 1) and stride[1] == 2 and stride[0] in (1, 2):
+        return int(stride[0])
+    return 0
 _PAIR_FUSE = [os.environ.get("DLIO_PAIR_FUSE", "1") != "0"]   # gap + add / sub + fc1 + act of the lidar head as one launch
 _SE_FC = [os.environ.get("DLIO_SE_FC", "1") != "0"]         # the SELayer's fc pair as one launch (csrc/se_fc.hip)
 _SE_POOLED_DOT = [os.environ.get("DLIO_SE_POOLED_DOT", "1") != "0"]   # SELayer scale gradient from pooled tensors
@@ -750,9 +830,14 @@ class FireFn(Function):
 
     @staticmethod
     def forward(ctx, x, sw, sb, sg, sbe, srm, srv, e1w, e1b, e1g, e1be, e1rm, e1rv, e3w, e3b, e3g,
-                e3be, e3rm, e3rv, training, momentum, eps, bypass, want_gap=False, x_aff=None, defer=False):
+                e3be, e3rm, e3rv, training, momentum, eps, bypass, want_gap=False, x_aff=None, defer=False, pool=None):
+        """pool (k, stride, pad): the block is followed by SELayer + MaxPool2d(pool) and NOTHING else reads its output
+        (pointseg_net.py:27-46) -- where the streaming path applies the block returns (pooled maximum of its output, plane
+        averages, arg-max map) instead of the output (see the `poolfuse` branch)"""
         ctx.set_materialize_grads(False)     # the by-products (plane averages, affine table) get no gradient: no zero fills
-        ctx.x_lazy_ok = getattr(x, "_dlio_lazy_ok", False)      # (the producer of x takes a lazy gradient: see _LAZY)
+        ctx.x_token = getattr(x, "_dlio_lazy_token", None)      # (the producer of x takes a lazy gradient: see _LAZY)
+        ctx.lazy_token = None
+        ctx.poolfuse = None
         x = x.contiguous()
         N, Cin, H, W = x.shape
         S_, E1, E3 = sw.shape[0], e1w.shape[0], e3w.shape[0]
@@ -772,7 +857,12 @@ class FireFn(Function):
         res = x if bypass else None
         # an apply-on-load block takes its BatchNorm statistics out of the expand launch's epilogue (tile sums + one small
         # finalising launch) instead of a pass over the concat buffer
-        epi = fused and defer and training and _FIRE_STATS[0] and ops._SYNC_BN[0] is None
+        # ... and so does a block on LARGE planes that writes its output (bypass blocks, the block in front of SELayer + pool):
+        # with the statistics known its BatchNorm + ReLU (+ residual) is a streaming apply -- round 4 ran the cooperative
+        # one-launch kernel here, whose workgroups spin for each other's partial sums
+        stream_bn = (fused and not defer and training and _FIRE_STATS[0] and _FIRE_STREAM[0] and ops._SYNC_BN[0] is None
+                     and _BN_SMALL[0] and ops.bn_coop_ok(N, H * W))
+        epi = fused and training and _FIRE_STATS[0] and ops._SYNC_BN[0] is None and (defer or stream_bn)
         if fused:
             w3p, w1p = ((ops.conv_h2_prepped(e3w), ops.conv_h2_prepped(e1w)) if h2
                         else (ops.conv_bx3_prepped(e3w, 0), ops.conv_bx3_prepped(e1w, 0)))
@@ -805,9 +895,32 @@ class FireFn(Function):
                                   sb, sg, e1b, e1g, e3b, e3g, x_aff)
             ctx.cfg = (d_s, d_1, d_3, training, bypass, True)
             ctx.small_prm = (aff[0], inv, aff[1])
-            ctx.mark_non_differentiable(aff)
-            raw_e._dlio_lazy_ok = lazy_ok
-            return raw_e, aff
+            if defer:
+                ctx.mark_non_differentiable(aff)
+                _mark_lazy(ctx, raw_e, lazy_ok)
+                return raw_e, aff
+            raff = x_aff if bypass else None
+            sh = _pool_row_stride(pool)
+            if (want_gap and sh and lazy_ok and _POOL_FUSE[0] and ops.bn_coop_pool_ok(N, H, W, sh)
+                    and ops.bn_aff_pool_ok(H, W, sh)):
+                # poolfuse: BatchNorm + ReLU + bypass + the max-pool behind the SELayer in one pass; the block's output is
+                # never written (its gradient arrives as a lazy entry formed from the POOLED gradient: SEPoolFn.backward)
+                pr, idx, gap = ops.bn_aff_pool_fwd(raw_e, CE, 0, N, CE, H, W, sh, aff, residual=res, r_ctot=Cin, r_coff=0,
+                                                   r_aff=raff)
+                ctx.poolfuse = (sh, (N, CE, H, W))
+                ctx.mark_non_differentiable(gap, idx)
+                _mark_lazy(ctx, pr, True)
+                pr._dlio_pooled = (idx, H, W)
+                return pr, gap, idx
+            out = _new((N, CE, H, W), x)
+            gap = _new((N, CE), x) if want_gap else None
+            ops.bn_aff_apply(raw_e, CE, 0, N, CE, H * W, aff, out, CE, 0, residual=res, r_ctot=Cin, r_coff=0, r_aff=raff,
+                             gap_out=gap, gap_ctot=CE, gap_coff=0)
+            _mark_lazy(ctx, out, lazy_ok)
+            if not want_gap:
+                return out
+            ctx.mark_non_differentiable(gap)
+            return out, gap
         if small:
             # fire_blk4 / fire_blk5: the two expand BatchNorms as ONE launch that reads the concat buffer once
             d_1, _ = _CBR.forward(act_s, S_, 0, S_, H, W, e1w, e1b, e1g, e1be, e1rm, e1rv, (1, 1), (0, 0), training,
@@ -824,7 +937,7 @@ class FireFn(Function):
                 ctx.cfg = (d_s, d_1, d_3, training, bypass, True)
                 ctx.small_prm = (aff[0], inv, aff[1])
                 ctx.mark_non_differentiable(aff)
-                raw_e._dlio_lazy_ok = lazy_ok
+                _mark_lazy(ctx, raw_e, lazy_ok)
                 return raw_e, aff
             out = _new((N, CE, H, W), x)
             gap = _new((N, CE), x) if want_gap else None
@@ -835,7 +948,7 @@ class FireFn(Function):
                                   sb, sg, e1b, e1g, e3b, e3g, x_aff)
             ctx.cfg = (d_s, d_1, d_3, training, bypass, False)
             ctx.small_prm = (prm[0], prm[1], prm[2])
-            out._dlio_lazy_ok = lazy_ok and small
+            _mark_lazy(ctx, out, lazy_ok and small)
             if not want_gap:
                 return out
             ctx.mark_non_differentiable(gap)
@@ -856,7 +969,7 @@ class FireFn(Function):
                                   sb, sg, e1b, e1g, e3b, e3g, x_aff)
             ctx.cfg = (d_s, d_1, d_3, training, bypass, True)
             ctx.mark_non_differentiable(aff)
-            raw_e._dlio_lazy_ok = lazy_ok
+            _mark_lazy(ctx, raw_e, lazy_ok)
             return raw_e, aff
         out = _new((N, CE, H, W), x)
         # plane averages of the block output for the SELayer behind it: a by-product of the BN
@@ -898,14 +1011,18 @@ class FireFn(Function):
         bcoop = ops.bn_coop_ok(N, H * W)
         # a lazy gradient (_LAZY): routed out of the pooled gradient by the cooperative BatchNorm backward; a bypass block hands
         # the entry on with its squeeze data gradient -- when neither is possible here the tensor is completed first
-        lazy = _LAZY.get(dout.data_ptr())
+        lazy = _lazy_take(dout, getattr(ctx, "lazy_token", None))
+        poolfuse = getattr(ctx, "poolfuse", None)
+        if poolfuse is not None and lazy is None:
+            raise RuntimeError("a Fire block that pooled its own output (poolfuse) received a gradient that did not come from the "
+                               "SELayer + MaxPool node behind it")
         if lazy is not None:
-            takes = (small_prm is not None and training and bcoop and ops.bn_coop_pool_ok(N, H, W, lazy[4])
-                     and (not bypass or getattr(ctx, "x_lazy_ok", False)))
+            takes = (small_prm is not None and training and bcoop and ops.bn_coop_pool_ok(N, H, W, lazy.sh)
+                     and (not bypass or getattr(ctx, "x_token", None) is not None))
             if takes:
                 del _LAZY[dout.data_ptr()]
             else:
-                lazy_materialize(dout)
+                dout = lazy_materialize(dout, lazy)
                 lazy = None
         dout = dout.contiguous()
         dact_s = _new((N, S_, H, W), x)
@@ -926,7 +1043,7 @@ class FireFn(Function):
                 amax3 = None
             if bcoop:
                 if lazy is not None:
-                    ops.bn_coop_bwd_pool(dout if lazy[5] else None, CE, 0, lazy[:5], raw_e, CE, 0, small_prm, e1be, e3be, draw1,
+                    ops.bn_coop_bwd_pool(dout if lazy.stored else None, CE, 0, lazy.pool(), raw_e, CE, 0, small_prm, e1be, e3be, draw1,
                                          draw3, sk[0][0], sk[1][0], sk[2][0], sk[3][0], sk[0][1], N, CE, E1, H, W, True,
                                          amax_out=amax3)
                 else:
@@ -954,13 +1071,15 @@ class FireFn(Function):
         dx = torch.empty_like(x) if need_dx else None
         draw_s = _new((N, S_, H, W), x)
         # the bypass gradient: a lazy one travels on with dx (stored part: dout itself when it holds one)
-        res = (dout if (bypass and (lazy is None or lazy[5])) else None)
+        res = (dout if (bypass and (lazy is None or lazy.stored)) else None)
         gs = _CBR.backward(dact_s, S_, 0, x, d_s, sw, sb, sg, prm_s, sbe, raw_s, training, False, True,
                            draw_s, need_dx, dx, Cin, 0, res, CE, 0, in_aff=x_aff)
         if lazy is not None and bypass and need_dx:
-            _LAZY[dx.data_ptr()] = lazy[:5] + (True,)
+            # the bypass part of this block's input gradient stays unwritten: the entry travels on with dx (which holds the
+            # squeeze data gradient) to the block in front
+            _lazy_put(_LazyGrad(dx, lazy.dyp, lazy.idx, lazy.xs, lazy.xadd, lazy.sh, True, ctx.x_token, lazy.full))
         return (dx, gs[0], gs[1], gs[2], gs[3], None, None, g1[0], g1[1], g1[2], g1[3], None, None,
-                g3[0], g3[1], g3[2], g3[3], None, None, None, None, None, None, None, None, None)
+                g3[0], g3[1], g3[2], g3[3], None, None, None, None, None, None, None, None, None, None)
 
 
 class ConvAddFn(Function):
@@ -1021,42 +1140,61 @@ class MaxPoolFn(Function):
 class SEPoolFn(Function):
     """SELayer (pointseg_modules.py:216-221) fused with the MaxPool2d that always follows it in
     PSEncoder (pointseg_net.py:27-46): the channel re-weighting is applied while pooling, so the
-    scaled full-resolution tensor is never written.  pool=None gives the plain SELayer."""
+    scaled full-resolution tensor is never written.  pool=None gives the plain SELayer.
+    pooled = (arg-max map, H, W): x is already the POOLED maximum of the block output (FireFn's poolfuse branch; the scale
+    s = sigmoid(..) > 0 commutes with the maximum) -- the forward is the fc pair + one pass over the pooled tensor."""
 
     @staticmethod
-    def forward(ctx, x, w1, w2, pool, gap=None):
+    def forward(ctx, x, w1, w2, pool, gap=None, pooled=None):
+        tok = getattr(x, "_dlio_lazy_token", None)
+        plain = x._backward_hooks is None and not x.retains_grad      # (hooks / retain_grad would see the unwritten tensor)
         x = x.contiguous()
-        N, C_, H, W = x.shape
+        if pooled is not None:
+            idx, H, W = pooled
+            N, C_ = x.shape[0], x.shape[1]
+            if gap is None or pool is None or tok is None or not plain:
+                raise ValueError("a pre-pooled SELayer input needs the plane averages, the pool geometry and an untouched "
+                                 "producer output (no hooks / retain_grad)")
+        else:
+            N, C_, H, W = x.shape
         g = gap if gap is not None else ops.gap_fwd(x, N, C_, 0, C_, H * W)
         if _SE_FC[0] and x.is_cuda and w1.is_contiguous() and w2.is_contiguous() and ops.se_fc_ok(N, C_, w1.shape[0]):
             h, s = ops.se_fc_fwd(g.contiguous(), w1, w2)       # both layers + activations in one launch (se_fc.hip)
         else:
             h = ops.linear_fwd(g, w1, None, ops.ACT_RELU)
             s = ops.linear_fwd(h, w2, None, ops.ACT_SIGMOID)
-        if pool is None:
+        if pooled is not None:
+            y = ops.chan_scale_fwd(x, s)
+        elif pool is None:
             y, idx = ops.chan_scale_fwd(x, s), None
         else:
             k, stride, pad = pool
             y, idx = ops.maxpool2d_fwd(x, k, stride[0], stride[1], pad[0], pad[1], False, x_scale=s)
         # (the pooled output is kept: the scale gradient is sum dy * y / s over POOLED planes, see backward)
-        ctx.save_for_backward(x, w1, w2, g, h, s, idx, y if (pool is not None and _SE_POOLED_DOT[0]) else None)
+        keep_y = pooled is not None or (pool is not None and _SE_POOLED_DOT[0])
+        ctx.save_for_backward(None if pooled is not None else x, w1, w2, g, h, s, idx, y if keep_y else None)
         ctx.pool = pool
+        ctx.shape = (N, C_, H, W)
+        ctx.pre_pooled = pooled is not None
+        ctx.lazy_token = tok
         # the producer of x (a Fire block on the cooperative BatchNorm path) routes the pooled gradient itself: _LAZY
-        ctx.lazy_ok = (pool is not None and getattr(x, "_dlio_lazy_ok", False) and tuple(pool[0:1]) == (3,)
-                       and tuple(pool[1])[1] == 2 and tuple(pool[2]) == (1, 1) and ops.bn_coop_pool_ok(N, H, W, pool[1][0]))
+        ctx.lazy_ok = (pooled is not None or
+                       (pool is not None and tok is not None and plain and _pool_row_stride(pool) != 0
+                        and ops.bn_coop_pool_ok(N, H, W, pool[1][0])))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w1, w2, g, h, s, idx, y = ctx.saved_tensors
-        N, C_, H, W = x.shape
+        N, C_, H, W = ctx.shape
         dy = dy.contiguous()
+        pre = ctx.pre_pooled
         fused = False
         if ctx.pool is None:
             dx, ds = ops.chan_scale_bwd(dy, x, s)
         else:
             k, stride, pad = ctx.pool
-            fused = ops.pool_fast_path(H, W, dy.shape[2], dy.shape[3], k, stride[0], stride[1], pad[0], pad[1])
+            fused = pre or ops.pool_fast_path(H, W, dy.shape[2], dy.shape[3], k, stride[0], stride[1], pad[0], pad[1])
             if fused:
                 # two passes over the full-resolution tensor instead of six: ds from (dy, idx, x) with
                 # the pooled gradient recomputed on the fly; dx written once at the end
@@ -1076,26 +1214,26 @@ class SEPoolFn(Function):
             # sigmoid', W2^T, relu', W1^T and the 1 / (H W) of the plane average's gradient in one launch, both weight
             # gradients in a second one (instead of seven dense launches)
             dgs = ops.se_fc_bwd(ds.contiguous(), s, h, g, w1, w2, dw1, dw2, acc1, 1.0 / (H * W))
-            k, stride, pad = ctx.pool
-            if getattr(ctx, "lazy_ok", False) and _LAZY_POOL[0] and ops._SYNC_BN[0] is None:
-                dx = torch.empty_like(x)                  # NOT written here: the Fire block's BatchNorm backward routes dy itself
-                _LAZY[dx.data_ptr()] = (dy, idx, s, dgs, stride[0], False)
-                return dx, ret1, ret2, None, None
-            dx = ops.maxpool2d_bwd(dy, idx, tuple(x.shape), k, stride[0], stride[1], pad[0], pad[1], x_scale=s, x_add=dgs)
-            return dx, ret1, ret2, None, None
-        dz2 = ops.act_bwd(ds, s, ops.ACT_SIGMOID)
-        ops.linear_bwd_weight(dz2, h, N, w2.shape[0], w2.shape[1], dw=dw2, want_bias=False, accumulate=acc2)
-        dh = ops.linear_bwd_data(dz2, w2, N)
-        dz1 = ops.act_bwd(dh, h, ops.ACT_RELU)
-        ops.linear_bwd_weight(dz1, g, N, w1.shape[0], w1.shape[1], dw=dw1, want_bias=False, accumulate=acc1)
-        dg = ops.linear_bwd_data(dz1, w1, N)
-        if fused:
-            k, stride, pad = ctx.pool
-            dx = ops.maxpool2d_bwd(dy, idx, tuple(x.shape), k, stride[0], stride[1], pad[0], pad[1],
-                                   x_scale=s, x_add=ops.ew_scale(dg, 1.0 / (H * W)))
         else:
-            ops.gap_bwd(dg, dx, N, C_, H * W, accumulate=True)
-        return dx, ret1, ret2, None, None
+            dz2 = ops.act_bwd(ds, s, ops.ACT_SIGMOID)
+            ops.linear_bwd_weight(dz2, h, N, w2.shape[0], w2.shape[1], dw=dw2, want_bias=False, accumulate=acc2)
+            dh = ops.linear_bwd_data(dz2, w2, N)
+            dz1 = ops.act_bwd(dh, h, ops.ACT_RELU)
+            ops.linear_bwd_weight(dz1, g, N, w1.shape[0], w1.shape[1], dw=dw1, want_bias=False, accumulate=acc1)
+            dg = ops.linear_bwd_data(dz1, w1, N)
+            if not fused:
+                ops.gap_bwd(dg, dx, N, C_, H * W, accumulate=True)
+                return dx, ret1, ret2, None, None, None
+            dgs = ops.ew_scale(dg, 1.0 / (H * W))
+        k, stride, pad = ctx.pool
+        if pre or (getattr(ctx, "lazy_ok", False) and _LAZY_POOL[0] and ops._SYNC_BN[0] is None):
+            # NOT written here: the Fire block's BatchNorm backward routes dy itself.  pre-pooled input: the tensor handed
+            # back has the pooled shape (it stands for the gradient of the block output, which was never stored either)
+            dx = torch.empty(dy.shape if pre else (N, C_, H, W), dtype=torch.float32, device=dy.device)
+            _lazy_put(_LazyGrad(dx, dy, idx, s, dgs, stride[0], False, ctx.lazy_token, (N, C_, H, W)))
+            return dx, ret1, ret2, None, None, None
+        dx = ops.maxpool2d_bwd(dy, idx, (N, C_, H, W), k, stride[0], stride[1], pad[0], pad[1], x_scale=s, x_add=dgs)
+        return dx, ret1, ret2, None, None, None
 
 
 class GapFn(Function):

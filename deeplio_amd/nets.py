@@ -113,9 +113,11 @@ class Fire(nn.Module):
             self.upsample = nn.Conv2d(inplanes, expand1x1_planes + expand3x3_planes, 1)
         self.residual = bypass == "simple" and same
 
-    def forward(self, x, want_gap=False, defer=False):
+    def forward(self, x, want_gap=False, defer=False, pool=None):
         """want_gap: also return the [N, C] plane averages of the output (for a following SELayer).
-        x may be a (raw, aff) pair from a deferring block (functional.FireFn); defer: return such a pair."""
+        x may be a (raw, aff) pair from a deferring block (functional.FireFn); defer: return such a pair.
+        pool (k, stride, pad): SELayer + MaxPool2d(pool) are the ONLY readers of this block's output -- the block may then
+        return (pooled maximum, plane averages, arg-max map) instead (functional.FireFn, poolfuse)."""
         tr = self.training
         s, sb, e1, e1b, e3, e3b = (self.squeeze, self.squeeze_bn, self.expand1x1, self.expand1x1_bn,
                                    self.expand3x3, self.expand3x3_bn)
@@ -135,7 +137,7 @@ class Fire(nn.Module):
         if bf16:
             out = mixed.FireFn.apply(*args)
         else:
-            out = Fh.FireFn.apply(*args, x_aff, defer)
+            out = Fh.FireFn.apply(*args, x_aff, defer, pool if up is None else None)
         if up is None:
             return out
         out = Fh.ConvAddFn.apply(x, up.weight, up.bias, out)      # out + upsample(identity), :136-138
@@ -156,12 +158,12 @@ class SELayer(nn.Module):
         self.fc = nn.Sequential(nn.Linear(in_features, in_features // reduction, bias=False), nn.ReLU(),
                                 nn.Linear(in_features // reduction, in_features, bias=False), nn.Sigmoid())
 
-    def forward(self, x, pool=None, gap=None):
+    def forward(self, x, pool=None, gap=None, pooled=None):
         if x.dtype == torch.bfloat16:
             if pool is None:
                 raise ValueError("the bf16 SELayer exists fused with the max-pool behind it only (as PSEncoder uses it)")
             return mixed.SEPoolFn.apply(x, self.fc[0].weight, self.fc[2].weight, pool, gap)
-        return Fh.SEPoolFn.apply(x, self.fc[0].weight, self.fc[2].weight, pool, gap)
+        return Fh.SEPoolFn.apply(x, self.fc[0].weight, self.fc[2].weight, pool, gap, pooled)
 
 
 class MaxPool(nn.Module):
@@ -238,18 +240,23 @@ class PSEncoder(BaseNet):
         for name, *_ in PS_BLOCKS:
             mods = list(getattr(self, name))
             i = 0
-            gap = None
+            gap = pooled = None
             while i < len(mods):
                 m = mods[i]
                 if isinstance(m, SELayer) and i + 1 < len(mods) and isinstance(mods[i + 1], MaxPool):
                     p = mods[i + 1]
-                    x = m(x, (p.k, p.stride, p.pad), gap)
+                    x = m(x, (p.k, p.stride, p.pad), gap, pooled)
                     i += 2
                 elif isinstance(m, SELayer):
                     x = m(x, None, gap)
                     i += 1
                 elif isinstance(m, Fire) and i + 1 < len(mods) and isinstance(mods[i + 1], SELayer):
-                    x, gap = m(x, want_gap=True)       # the SELayer's squeeze comes out of the BN apply
+                    # the SELayer's squeeze comes out of the BN apply; with the pool behind it the block may pool its own
+                    # output (its only readers are these two modules)
+                    p = mods[i + 2] if (i + 2 < len(mods) and isinstance(mods[i + 2], MaxPool) and not mods[i + 2].ceil_mode) else None
+                    r = m(x, want_gap=True, pool=(p.k, p.stride, p.pad) if (p is not None and self.precision == 'fp32') else None)
+                    x, gap = r[0], r[1]
+                    pooled = getattr(x, "_dlio_pooled", None) if len(r) == 3 else None
                     i += 1
                 elif (isinstance(m, Fire) and i + 1 < len(mods) and isinstance(mods[i + 1], Fire) and _APPLY_ON_LOAD
                       and m.can_defer() and getattr(mods[i + 1], "upsample", None) is None

@@ -566,6 +566,35 @@ def bn_small_bwd(dy, dy_ctot, dy_coff, x, x_ctot, x_coff, prm, beta1, beta2, dx1
                                 int(accumulate), N, C_, C1, HW, int(post_relu), _ptr(amax_out), _stream()), "bn_small_bwd")
 
 
+def bn_aff_apply(x, x_ctot, x_coff, N, C_, HW, aff, y, y_ctot, y_coff, residual=None, r_ctot=0, r_coff=0, r_aff=None,
+                 gap_out=None, gap_ctot=0, gap_coff=0):
+    """streaming BatchNorm + ReLU (+ residual, itself apply-on-load with r_aff) from known statistics: aff = (mean, scale,
+    shift) rows over the C_ channels (csrc/bn_stream.hip)"""
+    ra = r_aff if r_aff is not None else (None, None, None)
+    check(lib.dlio_bn_aff_apply(_ptr(x), N, x_ctot, x_coff, C_, HW, _ptr(aff[0]), _ptr(aff[1]), _ptr(aff[2]), _ptr(residual),
+                                r_ctot, r_coff, _ptr(ra[0]), _ptr(ra[1]), _ptr(ra[2]), _ptr(y), y_ctot, y_coff, _ptr(gap_out),
+                                gap_ctot, gap_coff, _stream()), "bn_aff_apply")
+    return y
+
+
+def bn_aff_pool_ok(H, W, SH):
+    return bool(lib.dlio_bn_aff_pool_ok(H, W, SH))
+
+
+def bn_aff_pool_fwd(x, x_ctot, x_coff, N, C_, H, W, SH, aff, residual=None, r_ctot=0, r_coff=0, r_aff=None, want_gap=True):
+    """BatchNorm + ReLU (+ residual) + MaxPool2d(3, (SH, 2), 1) without the full-resolution output -> (pooled maximum,
+    arg-max codes, plane averages of the un-pooled output); the SELayer's scale is applied to the POOLED tensor afterwards"""
+    OH, OW = (H + 2 - 3) // SH + 1, W // 2
+    yp = torch.empty(N, C_, OH, OW, dtype=torch.float32, device=x.device)
+    idx = torch.empty(N, C_, OH, OW, dtype=torch.uint8, device=x.device)
+    gap = torch.empty(N, C_, dtype=torch.float32, device=x.device) if want_gap else None
+    ra = r_aff if r_aff is not None else (None, None, None)
+    check(lib.dlio_bn_aff_pool_fwd(_ptr(x), N, x_ctot, x_coff, C_, H, W, SH, _ptr(aff[0]), _ptr(aff[1]), _ptr(aff[2]),
+                                   _ptr(residual), r_ctot, r_coff, _ptr(ra[0]), _ptr(ra[1]), _ptr(ra[2]), _ptr(yp), _ptr(idx),
+                                   _ptr(gap), C_, 0, _stream()), "bn_aff_pool_fwd")
+    return yp, idx, gap
+
+
 _COOP_WS = {}
 _BN_COOP = [os.environ.get("DLIO_BN_COOP", "1") != "0"]
 
@@ -576,8 +605,14 @@ def bn_coop_ok(N, HW):
 
 
 def bn_coop_set_cus(cus):
-    """wave-slot budget of one cooperative BatchNorm launch in CUs (0 = default); see dlio_bn_coop_set_cus"""
+    """CUs a cooperative BatchNorm launch sizes its grid for (0 = default); see dlio_bn_coop_set_cus"""
     check(lib.dlio_bn_coop_set_cus(int(cus)), "bn_coop_set_cus")
+
+
+def bn_coop_set_mode(oneshot):
+    """2: persistent workgroups, one item at a time (default); 1: one item per workgroup; 0: persistent, software-pipelined
+    workgroups; -1: the default again (see dlio_bn_coop_set_mode)"""
+    check(lib.dlio_bn_coop_set_mode(int(oneshot)), "bn_coop_set_mode")
 
 
 def bn_coop_gap_ok(N, HW):
@@ -591,7 +626,7 @@ def _coop_ws(N, C_, device):
     initialised when allocated (slots = the library's "empty" pattern, counters = 0; the kernels restore both)"""
     key = (device.index if device.index is not None else torch._C._cuda_getDevice(), raw_stream())
     e = _COOP_WS.get(key)
-    need_p, need_s = lib.dlio_bn_coop_ws_bytes(N, C_) // 8, C_ + 1
+    need_p, need_s = lib.dlio_bn_coop_ws_bytes(N, C_) // 8, C_ + 4
     if e is None or e[0].numel() < need_p or e[1].numel() < need_s:
         empty = lib.dlio_bn_coop_empty()
         e = (torch.full((max(need_p, 1 << 15),), empty - (1 << 64) if empty >= (1 << 63) else empty, dtype=torch.int64,
@@ -647,10 +682,13 @@ _AMAX_N = 2048
 
 
 def amax_slot(device):
-    """a zeroed float on the device for a kernel's largest output magnitude.  Slots come from a ring of two halves; the
-    half about to be handed out is zeroed with one fill when the allocation enters it -- the other half's slots are at least
-    _AMAX_N / 2 allocations old by then (a training step takes ~30 and joins all its streams at the optimizer)"""
-    key = device.index if device.index is not None else torch._C._cuda_getDevice()
+    """a zeroed float on the device for a kernel's largest output magnitude.  Slots come from a ring of two halves, ONE RING
+    PER (device, stream): the half about to be handed out is zeroed with one fill on the allocating stream when the
+    allocation enters it, i.e. ordered in front of the producer that will write the slot (a ring shared by all streams had
+    its fill race with the other encoder's producer).  The other half's slots are _AMAX_N / 2 allocations of this stream
+    old by then; their last readers (the weight-gradient companion stream) were forked long before -- a training step takes
+    ~15 slots per stream and joins all its streams at the optimizer."""
+    key = (device.index if device.index is not None else torch._C._cuda_getDevice(), raw_stream())
     e = _AMAX.get(key)
     if e is None:
         e = _AMAX[key] = [torch.zeros(_AMAX_N, dtype=torch.float32, device=device), 0]
@@ -677,8 +715,35 @@ def conv3x3_h2_fwd(x, amax_x, wt, bias, y, desc, residual=None):
 
 
 def bn_coop_errors():
-    """number of cooperative BatchNorm launches that hit their spin limit (0 = none)"""
-    return sum(int(e[1][:].ne(0).sum().item() > 0) for e in _COOP_WS.values())
+    """number of cooperative BatchNorm workspaces whose launches hit the spin limit (0 = none); synchronises"""
+    return sum(int(e[1][0].item() != 0) for e in _COOP_WS.values())
+
+
+def bn_coop_check(fallback=True):
+    """-> True when every cooperative BatchNorm launch so far found its partners.  Otherwise (a spin limit was hit: results
+    of those launches are invalid) the workspaces are re-initialised and, with fallback, the cooperative kernels are
+    switched off for the rest of the process -- the two-launch kernels of bn.hip take over.  Synchronises (one 4-byte read
+    per workspace): call it where the caller synchronises anyway (TrainStep.check)."""
+    bad = bn_coop_errors()
+    if not bad:
+        return True
+    torch.cuda.synchronize()
+    if os.environ.get("DLIO_BN_COOP_DEBUG"):
+        for k, (part, sync) in _COOP_WS.items():
+            e = lib.dlio_bn_coop_empty()
+            e = e - (1 << 64) if e >= (1 << 63) else e
+            print("[bn_coop] workspace", k, "header", sync[:4].tolist(), "nonzero counters", sync[4:].nonzero().flatten().tolist()[:8],
+                  "non-empty slots", (part != e).nonzero().flatten().tolist()[:16], flush=True)
+    empty = lib.dlio_bn_coop_empty()
+    for part, sync in _COOP_WS.values():
+        part.fill_(empty - (1 << 64) if empty >= (1 << 63) else empty)
+        sync.zero_()
+    if fallback:
+        _BN_COOP[0] = False
+        import warnings
+        warnings.warn("deeplio_amd: a cooperative BatchNorm launch did not find its partner workgroups (%d workspace(s)); "
+                      "falling back to the two-launch BatchNorm kernels" % bad, RuntimeWarning)
+    return False
 
 
 def fire_planes(N, S, H, W, device):

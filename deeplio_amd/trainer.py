@@ -124,6 +124,7 @@ class TrainStep:
     def step(self, imgs, normals, imus, gts_f2f, gts_f2g):
         self._steps += 1
         self._manage_gc()
+        Fh.lazy_clear()            # (entries a failed backward pass may have left behind)
         loss = self._tail(self.model.forward_features([[imgs, normals], imus]), gts_f2f, gts_f2g)
         self.optimizer.zero_grad()
         loss.backward()
@@ -140,4 +141,10 @@ class TrainStep:
             raise ValueError("pred_f2f: non-finite model output")
         if f[1] & 1:
             raise ValueError("Det error: chained rotation with det != 1")
+        if self.device.type == "cuda" and not ops.bn_coop_check():
+            # (the cooperative BatchNorm launches spin for partner workgroups; a launch that did not find them within its
+            #  bound leaves wrong statistics behind.  bn_coop_check has re-initialised the scratch and switched to the
+            #  two-launch kernels: the caller restores its last good state and carries on)
+            raise RuntimeError("a cooperative BatchNorm launch hit its spin limit: the steps since the last check() are "
+                               "invalid; the two-launch BatchNorm kernels are used from here on")
         return f

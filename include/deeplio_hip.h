@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 231
+#define DLIO_ABI_VERSION 232
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);           /* "gfx950" */
@@ -568,19 +568,30 @@ int dlio_bn_small_bwd(const float* dy, int dy_ctot, int dy_coff, const float* x,
                       const float* beta2, float* dx1, float* dx2, float* dgamma1, float* dbeta1, float* dgamma2,
                       float* dbeta2, int accumulate, int N, int C, int C1, int HW, int post_relu,
                       float* amax_out, dlio_stream_t stream);
-/* The same for LARGE feature maps (fire_blk1-3: 32-128 KB per (n, c) plane): the N workgroups that hold a channel's planes
- * in registers exchange partial sums through `part` ([C][N][2] 64-bit slots, every one holding dlio_bn_coop_empty() before the first
- * use: a slot is its own arrival flag) and per-channel departure counters in `sync` ([C + 1] ints, zero before the first
- * use); the kernels restore both; sync[C] != 0 afterwards = a spin limit was hit, results invalid.  One launch, each element read once (dlio_bn_train_apply reads twice, dlio_bn_bwd's two launches five times
- * against three).  A plane may be cut into dlio_bn_coop_parts(N, H * W) workgroups (N * parts <= 256 slots pairs per channel;
+/* The same for LARGE feature maps (fire_blk1-3: 32-128 KB per (n, c) plane): the N * parts workgroups that hold a channel's
+ * planes in registers exchange partial sums through `part` ([C][N * parts][2] 64-bit slots, every one holding
+ * dlio_bn_coop_empty() before the first use: a slot is its own arrival flag) and `sync` ([C + 4] ints, zero before the first
+ * use: [0] error flag, [1] ticket dispenser, [2] workgroups that have left, [4 + c] departures of channel c); the kernels
+ * restore everything but the error flag; sync[0] != 0 afterwards = a spin limit was hit, results invalid (re-initialise both
+ * buffers).  One launch, each element read once (dlio_bn_train_apply reads twice, dlio_bn_bwd's two launches five times
+ * against three).  A plane may be cut into dlio_bn_coop_parts(N, H * W) workgroups (N * parts <= 256 slot pairs per channel;
  * with gap_out the parts of a plane exchange their plane sums through a third slot region of `part`; the bf16 kernels keep
- * the plane in one workgroup then: dlio_bn_coop_gap_ok).  2 <= N <= 64, H * W a multiple of 8192 up to 65536 (dlio_bn_coop_ok), else DLIO_EUNSUP.  Arguments as
- * dlio_bn_small_fwd / _bwd (no statistics-only mode: y required).  The launch is a persistent grid of at most ~half the
- * chip, so that two of them (two streams) can always be resident together; do not run more than two concurrently. */
+ * the plane in one workgroup then: dlio_bn_coop_gap_ok).  2 <= N <= 64, H * W a multiple of 8192 up to 65536
+ * (dlio_bn_coop_ok), else DLIO_EUNSUP.  Arguments as dlio_bn_small_fwd / _bwd (no statistics-only mode: y required).
+ * Items are handed out in order by the ticket dispenser and a workgroup loads its next item under the exchange of the
+ * current one; progress needs N * parts workgroups of a launch resident at a time (checked against the occupancy query for
+ * two concurrent launches, else DLIO_EUNSUP), not the whole grid: any number of launches may be in flight. */
 int dlio_bn_coop_ok(int N, int HW);
-/* CUs' worth of wave slots one cooperative launch may occupy (default 104 of 256; at most 128: two launches must fit the
- * chip together).  Data-parallel runs lower it to leave room for the RCCL kernels that spin beside them. */
+/* CUs a cooperative launch sizes its grid for (0 = the default, 5 / 8 of the chip; the grid is CUs x the occupancy query's
+ * workgroups per CU).  A cap, not a correctness condition.  cus < 0 (tests): exactly -cus workgroups per launch, whatever the geometry --
+ * fewer than half the cooperating workgroups of a channel cannot make progress and end in the error flag. */
 int dlio_bn_coop_set_cus(int cus);
+/* 2 (default): persistent workgroups (grid as above), one item at a time, the next ticket drawn when the item is done;
+ * 1: one item per workgroup, the grid covers the items (measured: beside other streams' launches the dispatcher can starve
+ * the not yet started partners for > 100 ms -- the spin limit fires; kept for experiments); 0: persistent workgroups that
+ * load their next item under the exchange of the current one (twice the registers); -1: back to the default (environment
+ * DLIO_BN_COOP_MODE). */
+int dlio_bn_coop_set_mode(int oneshot);
 int dlio_bn_coop_parts(int N, int HW);
 int dlio_bn_coop_gap_ok(int N, int HW);        /* bf16 kernels with gap_out: the plane in one workgroup, H * W in {8192, 16384, 32768} */
 size_t dlio_bn_coop_ws_bytes(int N, int C);      /* bytes of `part` */
@@ -612,6 +623,26 @@ int dlio_bn_coop_bwd_pool(const float* dy, int dy_ctot, int dy_coff, const float
                           const float* beta2, float* dx1, float* dx2, float* dgamma1, float* dbeta1, float* dgamma2,
                           float* dbeta2, int accumulate, int N, int C, int C1, int post_relu, void* part, void* sync,
                           float* amax_out, dlio_stream_t stream);
+/* Train-mode BatchNorm2d + ReLU (+ bypass residual) as a streaming apply for layers whose statistics are known before the
+ * pass (dlio_fire_expand_fwd_stats leaves mean / scale / shift rows over the concat buffer's channels; pointseg_modules.py:
+ * 100-106,126-133): y = max(0, (x - mean[c]) * scale[c] + shift[c]) + r, r = residual as stored, or -- r_scale given: the
+ * residual is a deferred block's raw output -- max(0, (r - r_mean) * r_scale + r_shift) with rows indexed by r_coff + c.
+ * gap_out (nullable): plane averages of y, [N][gap_ctot] at gap_coff.  H * W a multiple of 4, 16-byte aligned tensors. */
+int dlio_bn_aff_apply(const float* x, int N, int x_ctot, int x_coff, int C, int HW, const float* mean,
+                      const float* scale, const float* shift, const float* residual, int r_ctot, int r_coff,
+                      const float* r_mean, const float* r_scale, const float* r_shift, float* y, int y_ctot,
+                      int y_coff, float* gap_out, int gap_ctot, int gap_coff, dlio_stream_t stream);
+/* The same followed by MaxPool2d(3, stride (SH, 2), padding 1) WITHOUT writing y (a Fire block in front of SELayer + MaxPool,
+ * pointseg_net.py:27-46; SELayer pointseg_modules.py:207-221: its scale s = sigmoid(..) > 0, so maxpool(s * y) = s *
+ * maxpool(y) with the same arg-max): y_pooled [N][C][OH][OW] = the pooled maximum of y (to be scaled by the caller:
+ * dlio_chan_scale_fwd), idx = the tap codes of dlio_maxpool2d_fwd (bit-identical to pooling the materialised y), gap_out
+ * (nullable) = plane averages of y.  SH in {1, 2}, W a multiple of 4, H even for SH = 2 (dlio_bn_aff_pool_ok). */
+int dlio_bn_aff_pool_ok(int H, int W, int SH);
+int dlio_bn_aff_pool_fwd(const float* x, int N, int x_ctot, int x_coff, int C, int H, int W, int SH,
+                         const float* mean, const float* scale, const float* shift, const float* residual,
+                         int r_ctot, int r_coff, const float* r_mean, const float* r_scale, const float* r_shift,
+                         float* y_pooled, unsigned char* idx, float* gap_out, int gap_ctot, int gap_coff,
+                         dlio_stream_t stream);
 /* the cooperative one-launch kernels over bf16 storage (train mode, one layer per launch; arithmetic and rounding as
  * dlio_bn_bf16_apply / dlio_bn_bf16_bwd, BASELINE configs[4]); geometry rule of dlio_bn_coop_ok in elements; part / sync as
  * for dlio_bn_coop_fwd */

@@ -296,3 +296,129 @@ def test_stem_pool_apply_on_load(dev):
     for other in res[:2]:
         for a, r in zip(other, res[2]):
             assert rel_err(a, r.double()) < 2e-5
+
+
+# ------------------------------------------------------------------------------ lazy pool gradients (functional._LAZY)
+def _fire_se_pool(dev, bypass_first=False, sh=1, seed=5):
+    """Fire -> Fire(bypass) -> SELayer -> MaxPool2d(3, (sh, 2), 1) as PSEncoder wires a stage (pointseg_net.py:27-46), at a
+    geometry the cooperative BatchNorm kernels take (N = 2, 32 x 256 planes)"""
+    from deeplio_amd import nets
+    torch.manual_seed(seed)
+    f0 = nets.Fire(32, 16, 16, 16, bypass="simple" if bypass_first else None).to(dev)
+    f1 = nets.Fire(32, 16, 16, 16, bypass="simple").to(dev)
+    se = nets.SELayer(32, reduction=2).to(dev)
+    for m in (f0, f1, se):
+        m.train()
+    x = torch.randn(2, 32, 32, 256, device=dev)
+    return f0, f1, se, (3, (sh, 2), (1, 1)), x
+
+
+def _run_stage(f0, f1, se, pool, x, poolfuse=True, lazy=True, hook=None):
+    from deeplio_amd import functional as Fh
+    for m in (f0, f1, se):
+        m.zero_grad()
+    Fh.lazy_clear()
+    old = (Fh._POOL_FUSE[0], Fh._LAZY_POOL[0])
+    Fh._POOL_FUSE[0], Fh._LAZY_POOL[0] = poolfuse, lazy
+    try:
+        xi = x.clone().requires_grad_(True)
+        a = f0(xi, defer=f0.can_defer())
+        r = f1(a, want_gap=True, pool=pool)
+        if hook is not None:
+            hook(r[0])
+        y = se(r[0], pool, r[1], getattr(r[0], "_dlio_pooled", None) if len(r) == 3 else None)
+        w = torch.linspace(-1, 1, y.numel(), device=y.device).view_as(y)
+        (y * w).sum().backward()
+        grads = [xi.grad.clone()] + [p.grad.clone() for m in (f0, f1, se) for p in m.parameters()]
+        return y.detach().clone(), grads, len(r) == 3
+    finally:
+        Fh._POOL_FUSE[0], Fh._LAZY_POOL[0] = old
+
+
+@pytest.mark.parametrize("sh", [1, 2])
+def test_fire_stage_pooling_its_own_output_equals_the_unfused_stage(dev, sh):
+    """a PSEncoder stage end (Fire -> Fire(bypass) -> SELayer -> MaxPool, pointseg_net.py:27-46) three ways: the block pools
+    while it applies its BatchNorm and never writes its output (poolfuse; its gradient arrives as a lazy entry formed from
+    the pooled gradient), lazy pool gradients over the written output, and everything materialised: same forward values bit
+    for bit, gradients to summation order"""
+    from deeplio_amd import functional as Fh
+    f0, f1, se, pool, x = _fire_se_pool(dev, sh=sh)
+    y_a, g_a, fused_a = _run_stage(f0, f1, se, pool, x, poolfuse=True, lazy=True)
+    y_b, g_b, fused_b = _run_stage(f0, f1, se, pool, x, poolfuse=False, lazy=True)
+    y_c, g_c, fused_c = _run_stage(f0, f1, se, pool, x, poolfuse=False, lazy=False)
+    assert fused_a and not fused_b and not fused_c and not Fh._LAZY
+    assert torch.equal(y_a, y_b) and torch.equal(y_b, y_c)
+    for ga, gb, gc_ in zip(g_a, g_b, g_c):
+        assert rel_err(ga, gc_) < 5e-6 and rel_err(gb, gc_) < 5e-6
+
+
+def test_lazy_pool_gradient_refuses_what_would_read_the_unwritten_tensor(dev):
+    """the hazards of handing autograd an unwritten gradient: retain_grad / a tensor hook on the block output
+    -> the SELayer + pool node writes the gradient itself (same numbers); a pre-pooled input with a hook is refused at
+    forward; a second consumer of the block output -> the Fire block raises when its gradient arrives altered; the
+    gradient of the block output taken directly -> the pass raises at its end; nothing stays behind in the registry"""
+    from deeplio_amd import functional as Fh
+    f0, f1, se, pool, x = _fire_se_pool(dev)
+    y_ref, g_ref, _ = _run_stage(f0, f1, se, pool, x, poolfuse=False, lazy=False)
+    # retain_grad on the written output: not lazy, same gradients, and the retained gradient is the real one
+    kept = []
+    y1, g1, _ = _run_stage(f0, f1, se, pool, x, poolfuse=False, lazy=True, hook=lambda t: (t.retain_grad(), kept.append(t)))
+    assert torch.equal(y1, y_ref) and all(rel_err(a, b) < 5e-6 for a, b in zip(g1, g_ref)) and not Fh._LAZY
+    assert kept[0].grad is not None and torch.isfinite(kept[0].grad).all() and float(kept[0].grad.abs().max()) > 0
+    # a hook on a pre-pooled output: refused where it is consumed
+    with pytest.raises(ValueError):
+        _run_stage(f0, f1, se, pool, x, poolfuse=True, lazy=True, hook=lambda t: t.register_hook(lambda g: g))
+    Fh.lazy_clear()
+    # second consumer of the block output
+    Fh._POOL_FUSE[0] = False
+    try:
+        xi = x.clone().requires_grad_(True)
+        out, gap = f1(f0(xi, defer=f0.can_defer()), want_gap=True, pool=pool)
+        y = se(out, pool, gap)
+        with pytest.raises(RuntimeError, match="second consumer|altered"):
+            (y.sum() + out.sum()).backward()
+        assert not Fh._LAZY
+        # the gradient of the block output itself: nobody consumes the entry -> the pass raises at its end
+        xi = x.clone().requires_grad_(True)
+        out, gap = f1(f0(xi, defer=f0.can_defer()), want_gap=True, pool=pool)
+        y = se(out, pool, gap)
+        with pytest.raises(RuntimeError, match="not consumed"):
+            torch.autograd.grad(y.sum(), out)
+        assert not Fh._LAZY
+    finally:
+        Fh._POOL_FUSE[0] = True
+    # ... and the next ordinary step is unaffected
+    y2, g2, _ = _run_stage(f0, f1, se, pool, x, poolfuse=True, lazy=True)
+    assert torch.equal(y2, y_ref) and all(rel_err(a, b) < 5e-6 for a, b in zip(g2, g_ref))
+
+
+def test_lazy_pool_gradient_is_materialised_where_nobody_can_route_it(dev):
+    """lazy_materialize: a Fire block with a bypass whose input does NOT come from a block that takes a lazy entry (here: a
+    plain tensor) completes the gradient itself -- written output and pre-pooled output alike"""
+    from deeplio_amd import functional as Fh
+    from deeplio_amd import nets
+    torch.manual_seed(9)
+    f1 = nets.Fire(32, 16, 16, 16, bypass="simple").to(dev).train()
+    se = nets.SELayer(32, reduction=2).to(dev).train()
+    pool = (3, (1, 2), (1, 1))
+    x = torch.randn(2, 32, 32, 256, device=dev)
+
+    def run(poolfuse, lazy):
+        Fh.lazy_clear()
+        for m in (f1, se):
+            m.zero_grad()
+        old = (Fh._POOL_FUSE[0], Fh._LAZY_POOL[0])
+        Fh._POOL_FUSE[0], Fh._LAZY_POOL[0] = poolfuse, lazy
+        try:
+            xi = x.clone().requires_grad_(True)
+            r = f1(xi, want_gap=True, pool=pool)
+            y = se(r[0], pool, r[1], getattr(r[0], "_dlio_pooled", None) if len(r) == 3 else None)
+            (y * y).sum().backward()
+            return [xi.grad.clone()] + [p.grad.clone() for m in (f1, se) for p in m.parameters()], len(r) == 3
+        finally:
+            Fh._POOL_FUSE[0], Fh._LAZY_POOL[0] = old
+    ref, _ = run(False, False)
+    for pf in (False, True):
+        got, fused = run(pf, True)
+        assert fused == pf and not Fh._LAZY
+        assert all(rel_err(a, b) < 5e-6 for a, b in zip(got, ref))

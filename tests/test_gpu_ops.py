@@ -1609,3 +1609,187 @@ def test_batchnorm_backward_with_the_pool_gradient_routed_on_load(dev, case):
     assert rel_err(got[1], ref[1]) < 5e-6 and rel_err(got[2], ref[2]) < 5e-6
     assert abs(float(got[3]) - float(ref[3])) <= 1e-6 * float(ref[3])
     assert ops.bn_coop_errors() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,grid", [(2, 0), (2, -16), (2, -40), (1, 0), (0, 0), (0, -8), (0, -16), (0, -40)])
+def test_cooperative_batchnorm_ticket_protocol_corner_cases(dev, mode, grid):
+    """csrc/bn_small.hip, round 5: items are handed out in order by a ticket counter.  mode 2 (default): persistent workgroups,
+    one item at a time; mode 1: one item per workgroup; mode 0: persistent, a workgroup loads its NEXT item under the exchange
+    of the current one.  grid 0: the occupancy-sized grid; grid < 0 (test hook of dlio_bn_coop_set_cus): exactly that many
+    workgroups -- with N * parts = 16 cooperating workgroups per channel, 8 pipelined workgroups hold TWO items of a channel
+    each (the 'publish both before waiting' path), 16 hold one each, 40 leave a ragged tail; forward (+ residual + plane
+    averages over 2 parts) and backward against torch in fp64, several launches on one workspace"""
+    from deeplio_amd import ops
+    N, C, C1, H, W = 8, 11, 4, 128, 128           # H * W = 16384 -> 2 parts of 8192 floats: 16 partners per channel
+    g = _g(91)
+    HW = H * W
+    assert ops.bn_coop_ok(N, HW) and lib_parts(N, HW) == 2
+    x = torch.randn(N, C, H, W, generator=g) * 1.3 - 0.2
+    res = torch.randn(N, C, H, W, generator=g)
+    dy = torch.randn(N, C, H, W, generator=g)
+    gam, bet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    x64 = x.double().requires_grad_(True)
+    g64, b64 = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    y64 = torch.relu(F.batch_norm(x64, None, None, g64, b64, True, 0.1, 1e-5)) + res.double()
+    y64.backward(dy.double())
+    d = lambda t: t.to(dev)
+    xd, rd, dyd, gd, bd = d(x), d(res), d(dy), d(gam), d(bet)
+    set1, set2 = (gd[:C1], bd[:C1], None, None), (gd[C1:], bd[C1:], None, None)
+    ops.bn_coop_set_mode(mode)
+    ops.bn_coop_set_cus(grid)
+    try:
+        for _ in range(3):
+            prm = torch.empty(3, C, device=dev)
+            y = torch.empty(N, C, H, W, device=dev)
+            gap = torch.empty(N, C, device=dev)
+            ops.bn_coop_fwd(xd, C, 0, N, C, C1, HW, set1, set2, 1e-5, 0.1, prm, y, C, 0, True, residual=rd, r_ctot=C, r_coff=0,
+                            gap_out=gap, gap_ctot=C, gap_coff=0)
+            dx1, dx2 = torch.empty(N, C1, H, W, device=dev), torch.empty(N, C - C1, H, W, device=dev)
+            dg, db = torch.empty(C, device=dev), torch.empty(C, device=dev)
+            am = ops.amax_slot(dev)
+            ops.bn_coop_bwd(dyd, C, 0, xd, C, 0, prm, bd[:C1], bd[C1:], dx1, dx2, dg[:C1], db[:C1], dg[C1:], db[C1:], False, N, C,
+                            C1, HW, True, amax_out=am)
+            dx = torch.cat([dx1, dx2], 1)
+            assert rel_err(y, y64.detach()) < 1e-6 and rel_err(gap, y64.detach().mean((2, 3))) < 1e-6
+            assert rel_err(dx, x64.grad) < 2e-6 and float(am) == float(dx.abs().max())
+            assert rel_err(dg, g64.grad) < 2e-6 and rel_err(db, b64.grad) < 2e-6
+        assert ops.bn_coop_errors() == 0
+    finally:
+        ops.bn_coop_set_cus(0)
+        ops.bn_coop_set_mode(-1)
+
+
+def lib_parts(N, HW):
+    from deeplio_amd import _lib
+    return int(_lib.lib.dlio_bn_coop_parts(N, HW))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("oneshot", [2, 1, 0])
+def test_cooperative_batchnorm_launches_on_several_streams_at_once(dev, oneshot):
+    """four streams issue cooperative BatchNorm launches of different geometry back to back (round 4 allowed two at a
+    time and capped each at 104 CUs; the ticket dispenser needs no co-residency of whole grids): every result equals the one
+    the same launch gives alone, bit for bit (fixed summation order), no spin limit hit"""
+    from deeplio_amd import ops
+    g = _g(92)
+    cases = [(16, 24, 64, 512), (16, 40, 64, 256), (8, 64, 64, 128), (16, 32, 64, 128)]
+    ops.bn_coop_set_mode(oneshot)
+    work = []
+    for N, C, H, W in cases:
+        x = (torch.randn(N, C, H, W, generator=g) * 1.1 + 0.1).to(dev)
+        dy = torch.randn(N, C, H, W, generator=g).to(dev)
+        gam, bet = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.3).to(dev)
+        work.append((N, C, H * W, x, dy, gam, bet))
+
+    def run(item, reps):
+        N, C, HW, x, dy, gam, bet = item
+        outs = []
+        for _ in range(reps):
+            prm = torch.empty(3, C, device=dev)
+            y = torch.empty_like(x)
+            ops.bn_coop_fwd(x, C, 0, N, C, C, HW, (gam, bet, None, None), None, 1e-5, 0.1, prm, y, C, 0, True)
+            dx = torch.empty_like(x)
+            dg, db = torch.empty(C, device=dev), torch.empty(C, device=dev)
+            ops.bn_coop_bwd(dy, C, 0, x, C, 0, prm, bet, None, dx, None, dg, db, None, None, False, N, C, C, HW, True)
+            outs = [y, dx, dg, db, prm]
+        return outs
+    alone = [run(it, 1) for it in work]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev) for _ in work]
+    together = []
+    for it, s in zip(work, streams):
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            together.append(run(it, 6))
+    for s in streams:
+        torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    ops.bn_coop_set_mode(-1)
+    for a, b in zip(alone, together):
+        for ta, tb in zip(a, b):
+            assert torch.equal(ta, tb)
+    assert ops.bn_coop_errors() == 0
+
+
+@pytest.mark.gpu
+def test_cooperative_batchnorm_spin_limit_sets_the_flag_and_the_host_falls_back(dev):
+    """a launch that cannot make progress (ONE workgroup for four cooperating ones: test hook) ends -- bounded spin -- with
+    the error flag set; ops.bn_coop_check() reports it, re-initialises the workspace and switches the cooperative kernels
+    off; switched on again the same workspace gives correct results"""
+    import warnings
+    from deeplio_amd import ops
+    N, C, HW = 4, 1, 8192
+    g = _g(93)
+    x = (torch.randn(N, C, 64, 128, generator=g)).to(dev)
+    gam, bet = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    prm = torch.empty(3, C, device=dev)
+    y = torch.empty_like(x)
+    assert ops.bn_coop_check()
+    ops.bn_coop_set_mode(0)
+    ops.bn_coop_set_cus(-1)
+    try:
+        ops.bn_coop_fwd(x, C, 0, N, C, C, HW, (gam, bet, None, None), None, 1e-5, 0.1, prm, y, C, 0, True)
+        torch.cuda.synchronize()
+    finally:
+        ops.bn_coop_set_cus(0)
+        ops.bn_coop_set_mode(-1)
+    assert ops.bn_coop_errors() == 1
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert not ops.bn_coop_check()
+    assert w and "falling back" in str(w[0].message)
+    try:
+        assert not ops.bn_coop_ok(N, HW) and ops.bn_coop_errors() == 0
+    finally:
+        ops._BN_COOP[0] = True
+    ops.bn_coop_fwd(x, C, 0, N, C, C, HW, (gam, bet, None, None), None, 1e-5, 0.1, prm, y, C, 0, True)
+    ref = torch.relu(F.batch_norm(x.double(), None, None, gam.double(), bet.double(), True, 0.1, 1e-5))
+    assert rel_err(y, ref) < 1e-6 and ops.bn_coop_check()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(16, 12, 64, 512, 1, True, True), (4, 40, 64, 128, 2, True, False), (3, 7, 10, 36, 1, False, False),
+                                  (2, 9, 12, 20, 2, True, True), (16, 6, 64, 256, 1, True, False), (2, 5, 32, 64, 2, False, False)])
+def test_streaming_batchnorm_apply_and_pool_without_the_full_resolution_output(dev, case):
+    """csrc/bn_stream.hip: BatchNorm + ReLU (+ bypass residual, itself apply-on-load) from KNOWN statistics as a streaming
+    apply (dlio_bn_aff_apply: against fp64, plane averages included) and the same fused with the MaxPool2d(3, (SH, 2), 1)
+    behind the SELayer (dlio_bn_aff_pool_fwd; pointseg_net.py:27-46): pooled maximum and arg-max codes BIT-IDENTICAL to
+    dlio_maxpool2d_fwd over the materialised output, plane averages equal to the materialised ones; scaling the pooled
+    maximum by s > 0 equals pooling the scaled tensor (what SEPoolFn does on the pre-pooled input)"""
+    from deeplio_amd import ops
+    N, C, H, W, SH, with_res, r_aff = case
+    g = _g(97)
+    d = lambda t: t.to(dev)
+    xw = d(torch.randn(N, C + 3, H, W, generator=g) * 1.7 + 0.3)
+    res = d(torch.randn(N, C + 1, H, W, generator=g)) if with_res else None
+    aff = d(torch.stack([torch.randn(C, generator=g) * 0.2, torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3]))
+    raff = d(torch.stack([torch.randn(C + 1, generator=g) * 0.2, torch.rand(C + 1, generator=g) + 0.5,
+                          torch.randn(C + 1, generator=g) * 0.3])) if r_aff else None
+    x64 = xw[:, 2:2 + C].double()
+    y64 = torch.relu((x64 - aff[0].double()[None, :, None, None]) * aff[1].double()[None, :, None, None] + aff[2].double()[None, :, None, None])
+    if with_res:
+        r64 = res[:, 1:].double()
+        if r_aff:
+            r64 = torch.relu((r64 - raff[0, 1:].double()[None, :, None, None]) * raff[1, 1:].double()[None, :, None, None]
+                             + raff[2, 1:].double()[None, :, None, None])
+        y64 = y64 + r64
+    y = torch.zeros(N, C + 2, H, W, device=dev)
+    gap = torch.zeros(N, C + 1, device=dev)
+    ops.bn_aff_apply(xw, C + 3, 2, N, C, H * W, aff, y, C + 2, 1, residual=res, r_ctot=C + 1, r_coff=1,
+                     r_aff=(raff[0], raff[1], raff[2]) if r_aff else None, gap_out=gap, gap_ctot=C + 1, gap_coff=1)
+    assert rel_err(y[:, 1:1 + C], y64) < 1e-6 and float(y[:, 0].abs().max()) == 0 and float(y[:, 1 + C:].abs().max()) == 0
+    assert rel_err(gap[:, 1:], y64.mean((2, 3))) < 1e-6
+    y2 = torch.empty(N, C, H, W, device=dev)              # (no plane averages: planes cut into chunks)
+    ops.bn_aff_apply(xw, C + 3, 2, N, C, H * W, aff, y2, C, 0, residual=res, r_ctot=C + 1, r_coff=1,
+                     r_aff=(raff[0], raff[1], raff[2]) if r_aff else None)
+    assert torch.equal(y2, y[:, 1:1 + C])
+    assert ops.bn_aff_pool_ok(H, W, SH) and not ops.bn_aff_pool_ok(H, W, 3) and not ops.bn_aff_pool_ok(H, 6, SH)
+    yp, idx, gp = ops.bn_aff_pool_fwd(xw, C + 3, 2, N, C, H, W, SH, aff, residual=res, r_ctot=C + 1, r_coff=1,
+                                      r_aff=(raff[0], raff[1], raff[2]) if r_aff else None)
+    ref_y, ref_i = ops.maxpool2d_fwd(y2, 3, SH, 2, 1, 1, False)
+    assert torch.equal(yp, ref_y) and torch.equal(idx, ref_i)
+    assert rel_err(gp, y64.mean((2, 3))) < 1e-6
+    s = d(torch.rand(N, C, generator=g) * 0.9 + 0.05)
+    ys, is_ = ops.maxpool2d_fwd(y2, 3, SH, 2, 1, 1, False, x_scale=s)
+    assert torch.equal(is_, idx) and torch.equal(ops.chan_scale_fwd(yp, s), ys)

@@ -24,7 +24,7 @@ def timeit(fn, reps=20):
     return a.elapsed_time(b) / reps * 1e3
 
 
-print("%-6s | %9s %9s | %9s %9s | GB/s one-launch fwd, bwd" % ("layer", "fwd 2x2", "fwd one", "bwd 2x2", "bwd one"))
+print("%-6s | %9s %9s %9s %9s | %9s %9s %9s | GB/s one-launch fwd, stream, bwd, bwd+pool" % ("layer", "fwd 2x2", "fwd one", "stream", "str+pool", "bwd 2x2", "bwd one", "bwd pool"))
 for name, E, H, W in LAYERS:
     CE, HW = 2 * E, H * W
     raw = torch.randn(N, CE, H, W, device=dev)
@@ -53,6 +53,21 @@ for name, E, H, W in LAYERS:
     t_bo = timeit(b_old)
     t_bn = timeit(lambda: one_b(dy, CE, 0, raw, CE, 0, prm, b[:E], b[E:], d1, d3, dg[:E], db[:E], dg[E:], db[E:], False, N, CE, E, HW, True))
     tb = 4.0 * N * CE * HW
-    print("%-6s | %9.1f %9.1f | %9.1f %9.1f | %6.0f %6.0f   %s" % (name, t_fo, t_fn, t_bo, t_bn, 3 * tb / t_fn / 1e3, 3 * tb / t_bn / 1e3,
-                                                                "coop" if coop else "small"))
+    # round 5: statistics known (expand epilogue) -> streaming apply; the same + the pool behind the SELayer; backward with
+    # the pooled gradient routed on load
+    aff = torch.stack([torch.zeros(CE, device=dev), g, b])
+    t_st = timeit(lambda: ops.bn_aff_apply(raw, CE, 0, N, CE, HW, aff, out, CE, 0, residual=res, r_ctot=CE, r_coff=0))
+    SH = 2 if name.startswith("blk3") else 1
+    t_sp = t_bp = float("nan")
+    if coop and ops.bn_coop_pool_ok(N, H, W, SH):
+        t_sp = timeit(lambda: ops.bn_aff_pool_fwd(raw, CE, 0, N, CE, H, W, SH, aff, residual=res, r_ctot=CE, r_coff=0))
+        yp, idx = ops.maxpool2d_fwd(out, 3, SH, 2, 1, 1, False)
+        dyp = torch.randn_like(yp)
+        xs, xa = torch.rand(N, CE, device=dev) + 0.1, torch.randn(N, CE, device=dev) * 1e-3
+        t_bp = timeit(lambda: ops.bn_coop_bwd_pool(None, CE, 0, (dyp, idx, xs, xa, SH), raw, CE, 0, prm, b[:E], b[E:], d1, d3, dg[:E],
+                                                   db[:E], dg[E:], db[E:], False, N, CE, E, H, W, True))
+    pb = tb * 2 + 5.0 * N * CE * HW / (2 * SH)
+    print("%-6s | %9.1f %9.1f %9.1f %9.1f | %9.1f %9.1f %9.1f | %6.0f %6.0f %6.0f %6.0f  %s" % (
+        name, t_fo, t_fn, t_st, t_sp, t_bo, t_bn, t_bp, 3 * tb / t_fn / 1e3, 3 * tb / t_st / 1e3, 3 * tb / t_bn / 1e3, pb / t_bp / 1e3,
+        "coop" if coop else "small"))
 print("coop errors:", ops.bn_coop_errors())
