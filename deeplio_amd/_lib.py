@@ -33,6 +33,7 @@ SIGNATURES = {
     "dlio_version": (_i, []),
     "dlio_abi_hash": (C.c_uint32, []),
     "dlio_arch": (C.c_char_p, []),
+    "dlio_build_probes": (_i, []),
     "dlio_strerror": (C.c_char_p, [_i]),
     "dlio_last_hip_error_string": (C.c_char_p, []),
     "dlio_prof_enable": (_i, [_i]),
@@ -220,6 +221,12 @@ def _load():
         raise ImportError("deeplio_amd: %s was built from a different include/deeplio_hip.h (library ABI %d / "
                           "%08x, header %d / %08x) -- rebuild with `python -m deeplio_amd.build`"
                           % (LIB_PATH, lib.dlio_version(), lib.dlio_abi_hash(), abi_version(), abi_hash()))
+    # ... and neither must a library built with a timing probe (kernels that skip work on purpose: tools/variant_lib.py)
+    probes = lib.dlio_build_probes()
+    if probes and os.environ.get("DLIO_ALLOW_PROBES", "0") != "1":
+        raise ImportError("deeplio_amd: %s was built with timing-probe macros (mask %d: DLIO_SPLIT_Q0 / BX3_ABLATE / "
+                          "W1_COAL_PROBE) and computes wrong results -- rebuild with `python -m deeplio_amd.build --force` "
+                          "(DLIO_ALLOW_PROBES=1 loads it for a timing experiment)" % (LIB_PATH, probes))
     return lib
 
 

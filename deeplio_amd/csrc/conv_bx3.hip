@@ -1612,3 +1612,6 @@ extern "C" int dlio_conv_bx3_fwd_taps(const float* x, const void* wt, const floa
   dlio_prof_end(3, s);
   return rc;
 }
+
+// timing probes compiled into this file (bit 0: DLIO_SPLIT_Q0, bit 1: BX3_ABLATE); 0 in the product build, checked at load (dlio_build_probes)
+int dlio_probe_bx3() { return ((DLIO_SPLIT_Q0) != 0 ? 1 : 0) | ((BX3_ABLATE) != 0 ? 2 : 0); }

@@ -1297,3 +1297,6 @@ extern "C" int dlio_conv2d_wgrad(const float* x, const float* dy, float* dw,
   dlio_prof_end(pkind, s);
   return rc;
 }
+
+// timing probes compiled into this file (bit 0: DLIO_SPLIT_Q0, bit 2: W1_COAL_PROBE); 0 in the product build, checked at load (dlio_build_probes)
+int dlio_probe_wgrad() { return ((DLIO_SPLIT_Q0) != 0 ? 1 : 0) | ((W1_COAL_PROBE) != 0 ? 4 : 0); }

@@ -594,3 +594,6 @@ int dlio_wgrad3_launch(const void* x, const void* dy, float* wsp, const DlioConv
   if (p.ntb == 2) return launch_w3<1, 2, true>(x, dy, wsp, d, p, s);
   return launch_w3<1, 3, true>(x, dy, wsp, d, p, s);
 }
+
+// timing probes compiled into this file (bit 0: DLIO_SPLIT_Q0); 0 in the product build, checked at load (dlio_build_probes)
+int dlio_probe_wgrad3() { return ((DLIO_SPLIT_Q0) != 0 ? 1 : 0); }

@@ -717,3 +717,6 @@ extern "C" int dlio_fire_expand_fwd_stats(const void* planes, const void* w3t, c
                      scale, shift);
   return dlio_check_launch();
 }
+
+// timing probes compiled into this file (bit 0: DLIO_SPLIT_Q0); 0 in the product build, checked at load (dlio_build_probes)
+int dlio_probe_fire() { return ((DLIO_SPLIT_Q0) != 0 ? 1 : 0); }

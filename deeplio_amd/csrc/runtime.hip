@@ -127,6 +127,16 @@ void dlio_set_max_lds(const void* kernel, int bytes) {
   if (dev >= 0) done.insert({dev, kernel});
 }
 
+// Timing probes (-DDLIO_SPLIT_Q0, -DBX3_ABLATE, -DW1_COAL_PROBE: tools/variant_lib.py, tools/bx3_ablate.py) build kernels that
+// compute WRONG results on purpose; the product build sets none of them and the Python side refuses a library that has any.
+int dlio_probe_bx3();
+int dlio_probe_wgrad();
+int dlio_probe_wgrad3();
+int dlio_probe_fire();
+extern "C" int dlio_build_probes(void) {
+  return ((DLIO_SPLIT_Q0) != 0 ? 1 : 0) | dlio_probe_bx3() | dlio_probe_wgrad() | dlio_probe_wgrad3() | dlio_probe_fire();
+}
+
 extern "C" const char* dlio_arch(void) { return "gfx950"; }
 extern "C" const char* dlio_strerror(int code) {
   switch (code) {

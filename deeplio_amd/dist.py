@@ -62,9 +62,8 @@ class GradSync:
         self.tail_lo = None          # element offset where the early bucket starts
         self._tail_work = None
         self._timing = None          # (start events, end events) of all_reduce_grads when measure_exposed(True)
-        if self.world > 1 and flat_grad.is_cuda:
-            # (the cooperative BatchNorm launches need no co-residency with RCCL's persistent kernels: ticket dispenser,
-            #  csrc/bn_small.hip; their default grid leaves 3 / 8 of the chip's wave slots alone)
+        # (the cooperative BatchNorm launches need no co-residency with RCCL's persistent kernels -- ticket dispenser,
+        #  csrc/bn_small.hip -- and their default grid leaves 3 / 8 of the chip's wave slots alone: nothing to set up here)
 
     def enable_sync_bn(self, on=True):
         """synchronised BatchNorm statistics: the per-channel partial sums of every train-mode BN
@@ -134,12 +133,13 @@ class GradSync:
 
     def all_reduce_grads(self):
         if self.world > 1:
-            if self._timing is not None:
+            timed = self._timing is not None and len(self._timing[0]) < 4096      # (a bounded sample: a long run must not grow the lists)
+            if timed:
                 e = torch.cuda.Event(enable_timing=True)
                 e.record()
                 self._timing[0].append(e)
             self._all_reduce_grads()
-            if self._timing is not None:
+            if timed:
                 e = torch.cuda.Event(enable_timing=True)
                 e.record()
                 self._timing[1].append(e)

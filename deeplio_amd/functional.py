@@ -359,7 +359,8 @@ class _CBR:
                     and (ops.bn_coop_ok(N, d.OH * d.OW) or (_SMALL_H2[0] and ops.bn_small_ok(N, d.OH * d.OW)))):
                 # 1x1 data gradients behind a one-launch BatchNorm backward (which leaves the largest |dy|): two fp16 pieces
                 d.wh2_1 = ops.conv_h2_prepped(weight, 1)
-            if KH == 3 and _DGRAD_H2[0] and tuple(stride) == (1, 1) and ops._SYNC_BN[0] is None and not pre_relu and _BN_SMALL[0]:
+            if (KH == 3 and _DGRAD_H2[0] and tuple(stride) == (1, 1) and ops._SYNC_BN[0] is None and not pre_relu and _BN_SMALL[0]
+                    and (ops.bn_coop_ok(N, d.OH * d.OW) or (_SMALL_H2[0] and ops.bn_small_ok(N, d.OH * d.OW)))):
                 # ... and as two fp16 pieces where the data gradient runs on the two-piece kernel (it needs the largest
                 # magnitude of its operand: conv_dgrad's `amax`, else the three-piece layout above is used)
                 g = ops.conv_desc(N, Cout, d.OH, d.OW, Cin, 3, 3, 1, 1, 2 - d.PH, 2 - d.PW, OH=H, OW=W)

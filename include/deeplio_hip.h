@@ -45,7 +45,10 @@ typedef void* dlio_stream_t;
 #define DLIO_ABI_VERSION 232
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
-const char* dlio_arch(void);           /* "gfx950" */
+const char* dlio_arch(void);
+/* != 0: the library was built with a TIMING PROBE macro (kernels that skip work and give wrong results: DLIO_SPLIT_Q0 bit 0,
+ * BX3_ABLATE bit 1, W1_COAL_PROBE bit 2); the host side refuses such a library unless DLIO_ALLOW_PROBES=1 */
+int dlio_build_probes(void);           /* "gfx950" */
 const char* dlio_strerror(int code);
 /* hipGetErrorString of the HIP error behind the last DLIO_ELAUNCH in this thread */
 const char* dlio_last_hip_error_string(void);

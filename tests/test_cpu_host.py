@@ -399,6 +399,32 @@ def test_stale_library_is_rejected_at_import(tmp_path):
     assert "REJECTED" in r.stdout and "different include/deeplio_hip.h" in r.stdout, r.stdout + r.stderr
 
 
+def test_library_built_with_a_timing_probe_is_rejected_at_import():
+    """the product library carries no timing probe (-DDLIO_SPLIT_Q0 / -DBX3_ABLATE / -DW1_COAL_PROBE build kernels that skip
+    work and give wrong results: tools/variant_lib.py); a library that reports one is refused at import unless
+    DLIO_ALLOW_PROBES=1"""
+    from deeplio_amd import _lib
+    assert _lib.lib.dlio_build_probes() == 0
+    code = ("import ctypes, deeplio_amd._lib as L\n")
+    # simulate a probe build: patch the table's loader so that the probe query answers 1
+    code = ("import ctypes as C\n"
+            "real = C.CDLL\n"
+            "class Fake:\n"
+            "    def __init__(self, path): self._l = real(path)\n"
+            "    def __getattr__(self, n):\n"
+            "        if n == 'dlio_build_probes':\n"
+            "            f = lambda: 1\n"
+            "            return type('F', (), {'__call__': staticmethod(f), 'restype': None, 'argtypes': None})()\n"
+            "        return getattr(self._l, n)\n"
+            "C.CDLL = Fake\n"
+            "try:\n    import deeplio_amd._lib\nexcept ImportError as e:\n    print('REJECTED', e)\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+    assert "REJECTED" in r.stdout and "timing-probe" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True,
+                       env=dict(os.environ, DLIO_ALLOW_PROBES="1"))
+    assert "REJECTED" not in r.stdout, r.stdout + r.stderr
+
+
 def test_oracle_geodesic_rotation_terms_known_answers():
     """the geodesic rotation terms (BASELINE configs[4]; definition in include/deeplio_hip.h): angle
     between rotations about one axis = difference of the angles; invariant to quaternion sign, scale

@@ -334,15 +334,19 @@ def test_headline_shape_eval_forward_vs_oracle(dev):
     assert rel_err(pos, opos) < TOL and rel_err(ori, oori) < TOL, (rel_err(pos, opos), rel_err(ori, oori))
 
 
-def test_headline_shape_train_forward_vs_oracle(dev):
-    """same geometry, train mode (batch statistics over B*S = 2 images of 64x2048), dropout off: forward
-    outputs and loss against the CPU oracle <= 1e-4"""
-    from deeplio_amd import losses, misc, nets
+@pytest.mark.parametrize("B", [1, 8])
+def test_headline_shape_train_forward_vs_oracle(dev, B):
+    """same geometry, train mode (batch statistics over B*S images of 64x2048), dropout off: forward outputs, loss AND the
+    running statistics of every BatchNorm against the CPU oracle <= 1e-4.  B = 8 is the launch size bench.py times
+    (N = 16 images per encoder): there the one-launch BatchNorm of the small maps runs 16 waves, the cooperative kernels cut
+    planes into parts, the Fire block in front of SELayer + pool pools its own output and the K-split heuristics take their
+    other branches (trainer.py:238-266 of the reference is what is matched)"""
+    from deeplio_amd import losses, misc, nets, ops
     from deeplio_amd.config import make_config
     from oracle import model as om
     from oracle import se3 as ose3
     cfg = make_config(seq=2, overrides=gc.NO_DROP)
-    misc.build_config_container(cfg, types.SimpleNamespace(device=str(dev), batch_size=1))
+    misc.build_config_container(cfg, types.SimpleNamespace(device=str(dev), batch_size=B))
     model = nets.get_model((5, 64, 2048), cfg, dev)
     gc.fill_state(model, seed=1000)
     model.train()
@@ -351,7 +355,7 @@ def test_headline_shape_train_forward_vs_oracle(dev):
     gc.fill_state(omodel, seed=1000)
     omodel.train()
     ocrit = om.get_loss_function(cfg)
-    batch = gc.make_batch(7, 1, 2, 5, 64, 2048, 50)
+    batch = gc.make_batch(7, B, 2, 5, 64, 2048, 50)
     pt, pw, pp, pq, loss = hip_step_forward(model, crit, tuple(t.to(dev) for t in batch))
     with torch.no_grad():
         a, b = omodel([[batch[0], batch[1]], batch[2]])
@@ -360,6 +364,16 @@ def test_headline_shape_train_forward_vs_oracle(dev):
                       batch[4][:, 1:3, 3:7])
     assert rel_err(pt, a) < TOL and rel_err(pw, b) < TOL, (rel_err(pt, a), rel_err(pw, b))
     assert rel_err(loss, oloss) < TOL
+    # running statistics: every BatchNorm of both encoders saw the same batch statistics
+    osd, worst = omodel.state_dict(), (0.0, None)
+    n = 0
+    for k, v in model.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            e = rel_err(v, osd[k])
+            worst = max(worst, (e, k))
+            n += 1
+    assert n >= 2 * 2 * (1 + 3 * 12) and worst[0] < TOL, worst
+    assert ops.bn_coop_errors() == 0
 
 
 def test_lidar_fusion_cat_resnet_vs_oracle(dev):
@@ -566,7 +580,11 @@ def test_reference_iteration_protocol_on_hip_objects(dev, tmp_path, loss_type):
     omodel.train()
     ocrit = om.get_loss_function(cfg)
     oopt = torch.optim.Adam([{'params': omodel.parameters()}, {'params': ocrit.parameters()}], lr=1e-3, weight_decay=1e-4)
-    bounds = [1e-4, 4e-3, 5e-2]          # new batch per iteration: the chaotic envelope of test_adam_trajectory, a little wider
+    from deeplio_amd import functional as Fh
+    h2 = any(sw[0] for sw in (Fh._FIRE_H2, Fh._DGRAD_H2, Fh._DGRAD1_H2, Fh._WGRAD_H2, Fh._SMALL_H2))
+    # new batch per iteration: the chaotic envelope of test_adam_trajectory, a little wider; the wider iteration-1 bound only
+    # with the two-piece fp16 kernels on (fp32-level in norm, not per element: the sign-like first Adam step amplifies it)
+    bounds = [1e-4, 4e-3 if h2 else 2e-3, 5e-2]
     # (iteration 1 sits at 1e-3 ... 2.5e-3 depending on which fp32-accurate kernel the tiny layers run on: the first Adam
     #  step is sign-like, see test_adam_trajectory)
     for it in range(3):
@@ -772,9 +790,11 @@ def _pinned_encoder_forward(enc, ename, dec):
     return fwd
 
 
-def test_headline_encoder_gradients_with_the_decisions_pinned(dev):
+@pytest.mark.parametrize("B", [1, 4])
+def test_headline_encoder_gradients_with_the_decisions_pinned(dev, B):
     """The envelope of test_headline_shape_gradients_vs_oracle turned into a test of the kernels: at the headline geometry
-    (64x2048x5, B = 1, S = 2, train mode) the fp64 oracle is run with the ReLU masks and max-pool arg-max maps THE HIP
+    (64x2048x5, B = 1 and B = 4 -- N = 8 images per encoder: planes cut into parts, the routing of the timed launch size --,
+    S = 2, train mode) the fp64 oracle is run with the ReLU masks and max-pool arg-max maps THE HIP
     FORWARD USED (read off its tape: raw convolution outputs + BatchNorm parameters through the library's own backward
     mask, the uint8 arg-max maps) instead of deciding them itself.  With the decisions equal, the 1e-2 disagreement of any
     two fp32 evaluations of this network is gone and `loss.backward()` of the HIP path (trainer.py:263-281) must match the
@@ -784,12 +804,12 @@ def test_headline_encoder_gradients_with_the_decisions_pinned(dev):
     from oracle import model as om
     from oracle import se3 as ose3
     cfg = make_config(seq=2, overrides=gc.NO_DROP)
-    misc.build_config_container(cfg, types.SimpleNamespace(device=str(dev), batch_size=1))
+    misc.build_config_container(cfg, types.SimpleNamespace(device=str(dev), batch_size=B))
     model = nets.get_model((5, 64, 2048), cfg, dev)
     gc.fill_state(model, seed=1000)
     model.train()
     crit = losses.get_loss_function(cfg, dev)
-    batch = gc.make_batch(7, 1, 2, 5, 64, 2048, 50)
+    batch = gc.make_batch(7, B, 2, 5, 64, 2048, 50)
     *_, loss = hip_step_forward(model, crit, tuple(t.to(dev) for t in batch))
     dec = _hip_decisions(model, loss)
     assert len(dec) == 2 * (12 + 1 + 4), sorted(dec)            # per encoder: 12 Fire blocks, the stem, 4 SELayer + pool

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """GPU time of each PointSeg block of encoder 1 inside the LIVE overlapped training step (steady state: steps issued back to
 back, no sync in between, no profiler): hipEvents at the block boundaries of the forward pass (the yields of
-PSEncoder.forward_steps) and, through tensor hooks on the block outputs, of the backward pass.
+PSEncoder.forward_steps) and, through pre-hooks on the nodes that produced the block outputs (tensor hooks would switch the
+lazy pool gradients off: functional._LAZY), of the backward pass.
 usage: python tools/block_times.py"""
 import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -35,8 +36,8 @@ def fs_w(x):
         if on[0] and i < len(names):
             ev("fwd " + names[i])
             t = y[0] if isinstance(y, tuple) else y
-            if torch.is_tensor(t) and t.requires_grad:
-                t.register_hook(lambda g, n=names[i]: ev("bwd: gradient of the output of " + n))
+            if torch.is_tensor(t) and t.requires_grad and t.grad_fn is not None:
+                t.grad_fn.register_prehook(lambda g, n=names[i]: ev("bwd: gradient of the output of " + n))
         yield y
 
 
