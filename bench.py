@@ -73,6 +73,7 @@ def cpu_parity_probe(cfg, C, H, W, T, S, sample_B, device):
     different generators): the relative difference of the two losses -- the timed path checked against the checker at a
     launch size of its own, inside the run that produced the number."""
     import copy
+    from deeplio_amd.trainer import TrainStep
     from oracle import model as om
     from oracle import se3 as ose3
     cfg0 = copy.deepcopy(cfg)

@@ -75,7 +75,7 @@ SIGNATURES = {
                                         _p, _sz, _i, _p]),
     "dlio_bn_small_ok": (_i, [_i, _i]),
     "dlio_bn_small_fwd": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p,
-                               _p, _i, _i, _p, _p, _p, _p, _i, _i, _p, _i, _i, _p]),
+                               _p, _i, _i, _p, _p, _p, _p, _i, _i, _p, _i, _i, _p, _p]),
     "dlio_bn_small_bwd": (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i,
                                _p, _p]),
     "dlio_bn_aff_apply": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _i, _i, _p, _i, _i, _p]),
@@ -93,7 +93,7 @@ SIGNATURES = {
     "dlio_bn_coop_ws_bytes": (_sz, [_i, _i]),
     "dlio_bn_coop_empty": (C.c_uint64, []),
     "dlio_bn_coop_fwd": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p,
-                              _p, _i, _i, _p, _p, _p, _p, _i, _i, _p, _i, _i, _p, _p, _p]),
+                              _p, _i, _i, _p, _p, _p, _p, _i, _i, _p, _i, _i, _p, _p, _p, _p]),
     "dlio_bn_coop_bwd": (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i,
                               _p, _p, _p, _p]),
     "dlio_bn_coop_pool_ok": (_i, [_i, _i, _i, _i]),
@@ -139,7 +139,7 @@ SIGNATURES = {
     "dlio_linear_bwd_data_ws_bytes": (_sz, [_i, _i, _i]),
     "dlio_linear_bwd_data": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "dlio_linear_bwd_weight": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _p]),
-    "dlio_ew_binary": (_i, [_p, _p, _p, _i64, _i, _p]),
+    "dlio_ew_binary": (_i, [_p, _p, _p, _i64, _i, _p, _p]),
     "dlio_seg_sum_fwd": (_i, [_p, _p, _i, _i, _i, _p]),
     "dlio_seg_sum_bwd": (_i, [_p, _p, _i, _i, _i, _p]),
     "dlio_ew_scale": (_i, [_p, _f, _p, _i64, _p]),
@@ -168,9 +168,9 @@ SIGNATURES = {
     "dlio_gt_relative": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "dlio_chan_stats_splits": (_i, [_i, _i, _i]),
     "dlio_bn_train_apply": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _i, _i,
-                                 _p, _i, _i, _p, _i, _i, _p, _sz, _i, _d, _p, _p, _p, _p]),
+                                 _p, _i, _i, _p, _i, _i, _p, _sz, _i, _d, _p, _p, _p, _p, _p]),
     "dlio_bn_bwd": (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i,
-                         _p, _sz, _i, _d, _p, _p]),
+                         _p, _sz, _i, _d, _p, _p, _p]),
     "dlio_scan_project_ws_bytes": (_sz, [_i, _i]),
     "dlio_scan_project": (_i, [_p, _p, _i, _i, _i, _d, _d, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "dlio_scan_normals": (_i, [_p, _p, _p, _i, _i, _p]),

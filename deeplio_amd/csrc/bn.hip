@@ -334,8 +334,11 @@ __global__ __launch_bounds__(256) void bn_plane_apply_kernel(
     float* scale_o, const float* residual, int r_ctot, int r_coff, float* y, int y_ctot, int y_coff,
     int N, int C, int HW, int pre_relu, int post_relu, int chunks, int chunk_len,
     float* __restrict__ gap_out, int gap_ctot, int gap_coff, const float* __restrict__ r_mean = nullptr,
-    const float* __restrict__ r_scale = nullptr, const float* __restrict__ r_shift = nullptr) {
+    const float* __restrict__ r_scale = nullptr, const float* __restrict__ r_shift = nullptr,
+    float* __restrict__ amax_out = nullptr) {
   __shared__ double sm[2][16];
+  __shared__ unsigned s_amax;
+  float amax = 0.f;                    // largest |y| this thread wrote (amax_out: the next layer's two-piece operand scale)
   const int chunk = blockIdx.x % chunks;
   const int pl = blockIdx.x / chunks;
   const int n = pl / C, c = pl - n * C;
@@ -387,6 +390,7 @@ __global__ __launch_bounds__(256) void bn_plane_apply_kernel(
         }
         *reinterpret_cast<float4*>(yp + ((size_t)(i + u * 256) << 2)) = make_float4(e[0], e[1], e[2], e[3]);
         gs += (double)((e[0] + e[1]) + (e[2] + e[3]));
+        amax = amax4(amax, e[0], e[1], e[2], e[3]);
       }
     }
   }
@@ -407,6 +411,7 @@ __global__ __launch_bounds__(256) void bn_plane_apply_kernel(
       }
       *reinterpret_cast<float4*>(yp + ((size_t)i << 2)) = make_float4(e[0], e[1], e[2], e[3]);
       gs += (double)((e[0] + e[1]) + (e[2] + e[3]));
+      amax = amax4(amax, e[0], e[1], e[2], e[3]);
     } else {
       float xx = xp[i];
       if (pre_relu) xx = fmaxf(xx, 0.f);
@@ -415,12 +420,14 @@ __global__ __launch_bounds__(256) void bn_plane_apply_kernel(
       if (rp) o += raff ? fmaxf((rp[i] - rmu) * rsc + rsh, 0.f) : rp[i];
       yp[i] = o;
       gs += o;
+      amax = fmaxf(amax, fabsf(o));
     }
   }
   if (gap_out) {                       // chunks == 1 whenever gap_out is set
     const double r = block_sum_d(gs, sm[0]);
     if (threadIdx.x == 0) gap_out[(size_t)n * gap_ctot + gap_coff + c] = (float)(r / (double)HW);
   }
+  if (amax_out) block_amax_commit(amax, amax_out, &s_amax);
 }
 
 template <bool VEC, int UN = 1>
@@ -430,8 +437,11 @@ __global__ __launch_bounds__(256) void bn_plane_bwd_kernel(
     const float* __restrict__ scale, const float* __restrict__ beta, const double* __restrict__ part,
     const double* __restrict__ lpart, double inv_cnt,
     int splits, float* dx, int dx_ctot, int dx_coff, float* dgamma, float* dbeta, int accumulate,
-    int N, int C, int HW, int pre_relu, int post_relu, int use_batch_stats, int chunks, int chunk_len) {
+    int N, int C, int HW, int pre_relu, int post_relu, int use_batch_stats, int chunks, int chunk_len,
+    float* __restrict__ amax_out = nullptr) {
   __shared__ double sm[2][16];
+  __shared__ unsigned s_amax;
+  float amax = 0.f;                    // largest |dx| this thread wrote (amax_out: the data gradient's two-piece operand scale)
   const int chunk = blockIdx.x % chunks;
   const int pl = blockIdx.x / chunks;
   const int n = pl / C, c = pl - n * C;
@@ -481,6 +491,7 @@ __global__ __launch_bounds__(256) void bn_plane_bwd_kernel(
           ge[k] = o;
         }
         *reinterpret_cast<float4*>(op + ((size_t)(i + u * 256) << 2)) = make_float4(ge[0], ge[1], ge[2], ge[3]);
+        amax = amax4(amax, ge[0], ge[1], ge[2], ge[3]);
       }
     }
   }
@@ -505,9 +516,10 @@ __global__ __launch_bounds__(256) void bn_plane_bwd_kernel(
       if (pre_relu && !(xraw > 0.f)) o = 0.f;
       ge[k] = o;
     }
-    if (VEC) *reinterpret_cast<float4*>(op + ((size_t)i << 2)) = make_float4(ge[0], ge[1], ge[2], ge[3]);
-    else op[i] = ge[0];
+    if (VEC) { *reinterpret_cast<float4*>(op + ((size_t)i << 2)) = make_float4(ge[0], ge[1], ge[2], ge[3]); amax = amax4(amax, ge[0], ge[1], ge[2], ge[3]); }
+    else { op[i] = ge[0]; amax = fmaxf(amax, fabsf(ge[0])); }
   }
+  if (amax_out) block_amax_commit(amax, amax_out, &s_amax);
 }
 
 // chunks per plane: one when planes alone fill the chip (or the plane average is wanted), else
@@ -967,7 +979,7 @@ extern "C" int dlio_bn_train_apply(const float* x, int N, int x_ctot, int x_coff
                                    float* gap_out, int gap_ctot, int gap_coff, void* ws,
                                    size_t ws_bytes, int phase, double count_scale,
                                    const float* r_mean, const float* r_scale, const float* r_shift,
-                                   dlio_stream_t stream) {
+                                   float* amax_out, dlio_stream_t stream) {
   if (!x || !y || !mean || !invstd || !scale || N <= 0 || C <= 0 || HW <= 0 || !ws || phase < 0 ||
       phase > 2 || !(count_scale >= 1.0))
     return DLIO_EINVAL;
@@ -999,17 +1011,17 @@ extern "C" int dlio_bn_train_apply(const float* x, int N, int x_ctot, int x_coff
     hipLaunchKernelGGL((bn_plane_apply_kernel<true, 4>), grid, dim3(256), 0, s, x, x_ctot, x_coff, part, splits,
                        (double)N * HW * count_scale, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
                        scale, residual, r_ctot, r_coff, y, y_ctot, y_coff, N, C, HW, pre_relu, post_relu,
-                       chunks, chunk_len, gap_out, gap_ctot, gap_coff, r_mean, r_scale, r_shift);
+                       chunks, chunk_len, gap_out, gap_ctot, gap_coff, r_mean, r_scale, r_shift, amax_out);
   else if (vec)
     hipLaunchKernelGGL(bn_plane_apply_kernel<true>, grid, dim3(256), 0, s, x, x_ctot, x_coff, part, splits,
                        (double)N * HW * count_scale, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
                        scale, residual, r_ctot, r_coff, y, y_ctot, y_coff, N, C, HW, pre_relu, post_relu,
-                       chunks, chunk_len, gap_out, gap_ctot, gap_coff, r_mean, r_scale, r_shift);
+                       chunks, chunk_len, gap_out, gap_ctot, gap_coff, r_mean, r_scale, r_shift, amax_out);
   else
     hipLaunchKernelGGL(bn_plane_apply_kernel<false>, grid, dim3(256), 0, s, x, x_ctot, x_coff, part, splits,
                        (double)N * HW * count_scale, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
                        scale, residual, r_ctot, r_coff, y, y_ctot, y_coff, N, C, HW, pre_relu, post_relu,
-                       chunks, chunk_len, gap_out, gap_ctot, gap_coff, r_mean, r_scale, r_shift);
+                       chunks, chunk_len, gap_out, gap_ctot, gap_coff, r_mean, r_scale, r_shift, amax_out);
   return dlio_check_launch();
 }
 
@@ -1018,7 +1030,7 @@ extern "C" int dlio_bn_bwd(const float* dy, int dy_ctot, int dy_coff, const floa
                            const float* beta, float* dx, int dx_ctot, int dx_coff, float* dgamma,
                            float* dbeta, int accumulate, int N, int C, int HW, int pre_relu,
                            int post_relu, int use_batch_stats, void* ws, size_t ws_bytes, int phase,
-                           double count_scale, const void* local_ws, dlio_stream_t stream) {
+                           double count_scale, const void* local_ws, float* amax_out, dlio_stream_t stream) {
   if (!dy || !x || !mean || !invstd || !scale || !dx || N <= 0 || C <= 0 || HW <= 0 || !ws ||
       phase < 0 || phase > 2 || !(count_scale >= 1.0))
     return DLIO_EINVAL;
@@ -1052,16 +1064,16 @@ extern "C" int dlio_bn_bwd(const float* dy, int dy_ctot, int dy_coff, const floa
     hipLaunchKernelGGL((bn_plane_bwd_kernel<true, 2>), grid, dim3(256), 0, s, dy, dy_ctot, dy_coff, x, x_ctot,
                        x_coff, mean, invstd, scale, beta, part, lpart, inv_cnt, splits, dx, dx_ctot, dx_coff,
                        dgamma, dbeta, accumulate, N, C, HW, pre_relu, post_relu, use_batch_stats, chunks,
-                       chunk_len);
+                       chunk_len, amax_out);
   else if (vec)
     hipLaunchKernelGGL(bn_plane_bwd_kernel<true>, grid, dim3(256), 0, s, dy, dy_ctot, dy_coff, x, x_ctot,
                        x_coff, mean, invstd, scale, beta, part, lpart, inv_cnt, splits, dx, dx_ctot, dx_coff,
                        dgamma, dbeta, accumulate, N, C, HW, pre_relu, post_relu, use_batch_stats, chunks,
-                       chunk_len);
+                       chunk_len, amax_out);
   else
     hipLaunchKernelGGL(bn_plane_bwd_kernel<false>, grid, dim3(256), 0, s, dy, dy_ctot, dy_coff, x, x_ctot,
                        x_coff, mean, invstd, scale, beta, part, lpart, inv_cnt, splits, dx, dx_ctot, dx_coff,
                        dgamma, dbeta, accumulate, N, C, HW, pre_relu, post_relu, use_batch_stats, chunks,
-                       chunk_len);
+                       chunk_len, amax_out);
   return dlio_check_launch();
 }

@@ -41,9 +41,10 @@ __global__ __launch_bounds__(1024) void bn_small_fwd_kernel(
     float* __restrict__ mean_o, float* __restrict__ invstd_o, float* __restrict__ scale_o, float* __restrict__ shift_o,
     const float* residual, int r_ctot, int r_coff, const float* __restrict__ r_mean, const float* __restrict__ r_scale,
     const float* __restrict__ r_shift, float* y, int y_ctot, int y_coff, float* __restrict__ gap_out, int gap_ctot,
-    int gap_coff, int post_relu) {
+    int gap_coff, int post_relu, float* __restrict__ amax_out = nullptr) {
   constexpr int HW = 256 * V;
   __shared__ double sm[2][16];
+  __shared__ unsigned s_amax;
   const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const BnSet& ps = c < C1 ? s1 : s2;
   const int cl = c < C1 ? c : c - C1;
@@ -75,7 +76,9 @@ __global__ __launch_bounds__(1024) void bn_small_fwd_kernel(
       ps.running_var[cl] = (1.f - momentum) * ps.running_var[cl] + momentum * (float)unb;
     }
   }
-  if (!y || !have) return;                          // statistics only (apply-on-load consumers)
+  if (!y) return;                                   // statistics only (apply-on-load consumers)
+  float amax = 0.f;
+  if (have) {
   const float* rp = residual ? residual + ((size_t)wave * r_ctot + r_coff + c) * HW : nullptr;
   const bool raff = rp && r_scale;
   const float rmu = raff ? r_mean[r_coff + c] : 0.f, rsc = raff ? r_scale[r_coff + c] : 1.f, rsh = raff ? r_shift[r_coff + c] : 0.f;
@@ -96,11 +99,14 @@ __global__ __launch_bounds__(1024) void bn_small_fwd_kernel(
     }
     *reinterpret_cast<float4*>(yp + 4 * (lane + 64 * j)) = make_float4(e[0], e[1], e[2], e[3]);
     gs += (double)((e[0] + e[1]) + (e[2] + e[3]));
+    amax = amax4(amax, e[0], e[1], e[2], e[3]);
   }
   if (gap_out) {                                     // plane average of the OUTPUT (the SELayer behind the block): a wave = a plane
     gs = wave_sum_d(gs);
     if (lane == 0) gap_out[(size_t)wave * gap_ctot + gap_coff + c] = (float)(gs / (double)HW);
   }
+  }
+  if (amax_out) block_amax_commit(amax, amax_out, &s_amax);      // (every wave: the images a workgroup does not have add 0)
 }
 
 // dx = scale * (g - mean(g) - xhat * mean(g * xhat)), g = dy where the activated output was > 0 (post_relu);
@@ -323,12 +329,12 @@ __device__ __forceinline__ void block_sum2_t(double& a, double& b, double (*sm)[
 }
 
 template <int V, int T, bool PIPE = true>
-__global__ __launch_bounds__(T) void bn_coop_fwd_kernel(
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu((T == 256 && !PIPE) ? 3 : 2, (T == 256 && !PIPE) ? 3 : 4))) void bn_coop_fwd_kernel(
     const float* __restrict__ x, int x_ctot, int x_coff, int N, int C, int C1, BnSet s1, BnSet s2, float eps, float momentum,
     float* __restrict__ mean_o, float* __restrict__ invstd_o, float* __restrict__ scale_o, const float* residual, int r_ctot,
     int r_coff, const float* __restrict__ r_mean, const float* __restrict__ r_scale, const float* __restrict__ r_shift,
     float* y, int y_ctot, int y_coff, float* __restrict__ gap_out, int gap_ctot, int gap_coff, int post_relu,
-    double* part, int* sync, int P, int loop = 1) {
+    double* part, int* sync, int P, int loop = 1, float* __restrict__ amax_out = nullptr) {
   // PIPE: persistent workgroups, the next item's loads in flight under the exchange.  !PIPE: one item at a time -- loop = 0:
   // one item per workgroup (grid = items), loop = 1: persistent, the next ticket drawn when the item is done
   constexpr int CH = 4 * V * T;                       // floats per workgroup: 1 / P of a plane
@@ -353,8 +359,9 @@ __global__ __launch_bounds__(T) void bn_coop_fwd_kernel(
     }
     block_sum2_t<T>(a, b, sm);
   };
-  int it = 0;
-  bool prepub = false;
+  int it = 0, tk_next = 0;
+  bool prepub = false, early = false;
+  float amax = 0.f;                                   // largest |y| this thread wrote (amax_out)
   float4 v[V], vn[V];
   if constexpr (PIPE) {
     it = coop_draw_sync(sync, &s_tk);
@@ -365,7 +372,9 @@ __global__ __launch_bounds__(T) void bn_coop_fwd_kernel(
       if (it >= items) break;
       coop_draw(sync, &s_tk);                         // (read behind the barriers of the reduction)
     } else {
-      it = coop_draw_sync(sync, &s_tk);
+      // (loop mode: the next ticket was drawn while the previous item was applied and stored -- behind its exchange, where
+      //  holding it cannot make anybody wait -- and published to the workgroup by the barrier that ended that item)
+      it = early ? s_tk : coop_draw_sync(sync, &s_tk);
       if (it >= items) break;
       issue(it, v);
     }
@@ -392,6 +401,7 @@ __global__ __launch_bounds__(T) void bn_coop_fwd_kernel(
       if (threadIdx.x == 0) coop_publish(a2, b2, part, c, nxt - c * NP, NP);
     }
     coop_gather(a, b, part, sync, c, NP, bc);
+    if (!PIPE && loop && threadIdx.x == 0) tk_next = __hip_atomic_fetch_add(sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const double count = (double)N * HW;
     const double m = a / count;
     double var = b / count - m * m;
@@ -424,6 +434,7 @@ __global__ __launch_bounds__(T) void bn_coop_fwd_kernel(
       }
       *reinterpret_cast<float4*>(yp + 4 * (threadIdx.x + T * j)) = make_float4(e[0], e[1], e[2], e[3]);
       gs += (double)((e[0] + e[1]) + (e[2] + e[3]));
+      amax = amax4(amax, e[0], e[1], e[2], e[3]);
     }
     if (gap_out) {                                   // (uniform: the barriers inside are taken by everyone)
       gs = block_sum_t<T>(gs, sm[0]);
@@ -446,6 +457,7 @@ __global__ __launch_bounds__(T) void bn_coop_fwd_kernel(
       }
     }
     coop_depart(part, sync, c, NP, (gap_out && P > 1) ? C : 0, C, !PIPE && !loop);
+    if (!PIPE && loop) { if (threadIdx.x == 0) s_tk = tk_next; early = true; }
     __syncthreads();                                 // bc / sm / s_tk are reused by the next item
     if (have) {
 #pragma unroll
@@ -456,6 +468,10 @@ __global__ __launch_bounds__(T) void bn_coop_fwd_kernel(
     if (!PIPE && !loop) break;                       // one item per workgroup
   }
   if (PIPE || loop) coop_leave(sync);
+  if (amax_out) {
+    __shared__ unsigned s_amax;
+    block_amax_commit(amax, amax_out, &s_amax);
+  }
 }
 
 // POOL (1 / 2 = the pool's row stride): the gradient of the BatchNorm output is not stored -- the block ends in an SELayer + 3x3 /
@@ -533,7 +549,7 @@ template <int V, int POOL> struct CoopBwdRaw {
 };
 
 template <int V, int T, int POOL = 0, bool PIPE = true>
-__global__ __launch_bounds__(T) void bn_coop_bwd_kernel(
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu((T == 256 && !PIPE) ? 3 : 2, (T == 256 && !PIPE) ? 3 : 4))) void bn_coop_bwd_kernel(
     const float* __restrict__ dy, int dy_ctot, int dy_coff, const float* __restrict__ x, int x_ctot, int x_coff, int N, int C,
     int C1, BnSet s1, BnSet s2, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ scale, float* __restrict__ dx1, float* __restrict__ dx2, int accumulate, int post_relu,
@@ -610,8 +626,8 @@ __global__ __launch_bounds__(T) void bn_coop_bwd_kernel(
       sg += f0; sgx += f1;
     }
   };
-  int it = 0;
-  bool prepub = false;
+  int it = 0, tk_next = 0;
+  bool prepub = false, early = false;
   Raw raw;
   if constexpr (PIPE) {
     it = coop_draw_sync(sync, &s_tk);
@@ -622,7 +638,7 @@ __global__ __launch_bounds__(T) void bn_coop_bwd_kernel(
       if (it >= items) break;
       coop_draw(sync, &s_tk);                         // (read behind the barriers of the reduction)
     } else {
-      it = coop_draw_sync(sync, &s_tk);
+      it = early ? s_tk : coop_draw_sync(sync, &s_tk);      // (see bn_coop_fwd_kernel)
       if (it >= items) break;
       issue(it, raw);
     }
@@ -646,6 +662,7 @@ __global__ __launch_bounds__(T) void bn_coop_bwd_kernel(
       if (threadIdx.x == 0) coop_publish(s2a, s2b, part, c, nxt - c * NP, NP);
     }
     coop_gather(sg, sgx, part, sync, c, NP, bc);
+    if (!PIPE && loop && threadIdx.x == 0) tk_next = __hip_atomic_fetch_add(sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x == 0 && np == 0) {
       if (ps.dbeta) ps.dbeta[cl] = accumulate ? ps.dbeta[cl] + (float)sg : (float)sg;
       if (ps.dgamma) ps.dgamma[cl] = accumulate ? ps.dgamma[cl] + (float)sgx : (float)sgx;
@@ -663,6 +680,7 @@ __global__ __launch_bounds__(T) void bn_coop_bwd_kernel(
       amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
     }
     coop_depart(part, sync, c, NP, 0, C, !PIPE && !loop);
+    if (!PIPE && loop) { if (threadIdx.x == 0) s_tk = tk_next; early = true; }
     __syncthreads();                                  // bc / sm / s_tk are reused by the next item
     it = nxt;
     prepub = same;
@@ -896,7 +914,7 @@ extern "C" int dlio_bn_small_fwd(const float* x, int N, int x_ctot, int x_coff, 
                                  float eps, float momentum, float* mean, float* invstd, float* scale, float* shift_out,
                                  const float* residual, int r_ctot, int r_coff, const float* r_mean, const float* r_scale,
                                  const float* r_shift, float* y, int y_ctot, int y_coff, float* gap_out, int gap_ctot,
-                                 int gap_coff, dlio_stream_t stream) {
+                                 int gap_coff, float* amax_out, dlio_stream_t stream) {
   if (!x || !mean || !invstd || !scale || C <= 0 || C1 < 0 || C1 > C || N <= 0 || HW <= 0) return DLIO_EINVAL;
   const int v = small_v(N, HW);
   if (!v) return DLIO_EUNSUP;
@@ -907,7 +925,7 @@ extern "C" int dlio_bn_small_fwd(const float* x, int N, int x_ctot, int x_coff, 
   DlioProfScope prof(7, s, 0.0, 4.0 * N * (double)C * HW * (y ? (residual ? 3.0 : 2.0) : 1.0));
 #define BNS(VV) hipLaunchKernelGGL(bn_small_fwd_kernel<VV>, dim3((unsigned)C), dim3(1024), 0, s, x, x_ctot, x_coff, N, C1, s1, s2, eps, \
                                    momentum, mean, invstd, scale, shift_out, residual, r_ctot, r_coff, r_mean, r_scale, r_shift, y,     \
-                                   y_ctot, y_coff, gap_out, gap_ctot, gap_coff, post_relu)
+                                   y_ctot, y_coff, gap_out, gap_ctot, gap_coff, post_relu, amax_out)
   if (v == 1) BNS(1); else if (v == 2) BNS(2); else if (v == 4) BNS(4); else BNS(8);
 #undef BNS
   return dlio_check_launch();
@@ -964,7 +982,7 @@ extern "C" int dlio_bn_coop_fwd(const float* x, int N, int x_ctot, int x_coff, i
                                 float eps, float momentum, float* mean, float* invstd, float* scale,
                                 const float* residual, int r_ctot, int r_coff, const float* r_mean, const float* r_scale,
                                 const float* r_shift, float* y, int y_ctot, int y_coff, float* gap_out, int gap_ctot,
-                                int gap_coff, void* part, void* sync, dlio_stream_t stream) {
+                                int gap_coff, void* part, void* sync, float* amax_out, dlio_stream_t stream) {
   if (!x || !y || !mean || !invstd || !scale || !part || !sync || C <= 0 || C1 < 0 || C1 > C || N <= 0 || HW <= 0)
     return DLIO_EINVAL;
   int P;
@@ -979,7 +997,7 @@ extern "C" int dlio_bn_coop_fwd(const float* x, int N, int x_ctot, int x_coff, i
 #define BNC(TT, PP) do { grid = coop_grid(reinterpret_cast<const void*>(&bn_coop_fwd_kernel<8, TT, PP>), N * P, C, TT, !PP); if (grid > 0) hipLaunchKernelGGL((bn_coop_fwd_kernel<8, TT, PP>), dim3((unsigned)grid), dim3(TT), 0, s, x, x_ctot, x_coff, N, C, C1, s1, s2, \
                                    eps, momentum, mean, invstd, scale, residual, r_ctot, r_coff, r_mean, r_scale, r_shift, y, y_ctot,     \
                                    y_coff, gap_out, gap_ctot, gap_coff, post_relu, reinterpret_cast<double*>(part),                      \
-                                   reinterpret_cast<int*>(sync), P, coop_mode() == 2 ? 1 : 0); } while (0)
+                                   reinterpret_cast<int*>(sync), P, coop_mode() == 2 ? 1 : 0, amax_out); } while (0)
   if (coop_oneshot()) { if (T == 512) BNC(512, false); else BNC(256, false); }
   else { if (T == 512) BNC(512, true); else BNC(256, true); }
 #undef BNC

@@ -85,6 +85,26 @@ __device__ __forceinline__ double block_sum_d(double v, double* smem /* >= 16 do
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// largest magnitude a workgroup produced -> *amax_out (one device float, zero before the launch: the operand scale of the
+// two-piece fp16 kernels).  Every thread of the workgroup calls this (barriers inside); at most ONE global atomic per workgroup,
+// and only when it would raise the value (same-address atomics serialise at ~13 ns each: thousands of workgroups).
+__device__ __forceinline__ void block_amax_commit(float amax, float* amax_out, unsigned* s_wg /* one unsigned in LDS */) {
+  if (threadIdx.x == 0) *s_wg = 0u;
+  __syncthreads();
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(s_wg, __float_as_uint(amax));
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned w = *s_wg;
+    if (w > __hip_atomic_load(reinterpret_cast<unsigned*>(amax_out), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(reinterpret_cast<unsigned*>(amax_out), w);
+  }
+}
+__device__ __forceinline__ float amax4(float m, float a, float b, float c, float d) {
+  return fmaxf(m, fmaxf(fmaxf(fabsf(a), fabsf(b)), fmaxf(fabsf(c), fabsf(d))));
+}
+
 // compute units of the current device (cached; 256 on MI355X, also the answer without a device
 // so that workspace queries work on a build host)
 int dlio_num_cus();

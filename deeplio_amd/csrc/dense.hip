@@ -437,6 +437,36 @@ __global__ void ew_binary_kernel(const float* __restrict__ a, const float* __res
   }
 }
 
+// the same on float4 with four loads in flight per operand and (optionally) the largest |y| written: the tail of a
+// BasicBlock, relu(out + identity) over 16-268 MB tensors, whose consumer is a two-piece fp16 3x3 convolution
+__global__ __launch_bounds__(256) void ew_binary_v4_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                           float4* __restrict__ y, int64_t n4, int op, float* __restrict__ amax_out) {
+  constexpr int UN = 4;
+  __shared__ unsigned s_amax;
+  float amax = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += UN * stride) {
+    float4 u[UN], v[UN];
+#pragma unroll
+    for (int k = 0; k < UN; ++k) {
+      const int64_t j = i + k * stride < n4 ? i + k * stride : n4 - 1;
+      u[k] = a[j]; v[k] = b[j];
+    }
+#pragma unroll
+    for (int k = 0; k < UN; ++k) {
+      if (i + k * stride >= n4) continue;
+      const float ue[4] = {u[k].x, u[k].y, u[k].z, u[k].w}, ve[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        o[e] = op == 0 ? ue[e] + ve[e] : (op == 1 ? ue[e] - ve[e] : (op == 2 ? ue[e] * ve[e] : fmaxf(ue[e] + ve[e], 0.f)));
+      y[i + k * stride] = make_float4(o[0], o[1], o[2], o[3]);
+      amax = amax4(amax, o[0], o[1], o[2], o[3]);
+    }
+  }
+  if (amax_out) block_amax_commit(amax, amax_out, &s_amax);
+}
+
 // y[g][c] = sum_r x[g][r][c]   /   dx[g][r][c] = dy[g][c]
 __global__ void seg_sum_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int groups,
                                    int rows, int cols) {
@@ -769,11 +799,18 @@ extern "C" int dlio_linear_bwd_weight(const float* dz, int lddz, const float* x,
   return rc;
 }
 
-extern "C" int dlio_ew_binary(const float* a, const float* b, float* y, int64_t n, int op,
+extern "C" int dlio_ew_binary(const float* a, const float* b, float* y, int64_t n, int op, float* amax_out,
                               dlio_stream_t stream) {
   if (!a || !b || !y || n <= 0 || op < 0 || op > 3) return DLIO_EINVAL;
-  hipLaunchKernelGGL(ew_binary_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, as_stream(stream), a,
-                     b, y, n, op);
+  const bool v4 = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+  if (amax_out && !v4) return DLIO_EUNSUP;
+  if (v4 && (n >= 4096 || amax_out))
+    hipLaunchKernelGGL(ew_binary_v4_kernel, dim3(ew_grid(n / 16, 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(b), reinterpret_cast<float4*>(y), n / 4,
+                       op, amax_out);
+  else
+    hipLaunchKernelGGL(ew_binary_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, as_stream(stream), a,
+                       b, y, n, op);
   return dlio_check_launch();
 }
 

@@ -611,7 +611,7 @@ extern "C" int dlio_bn_split16(const float* x, int N, int x_ctot, int x_coff, in
       // statistics partials by the BatchNorm path's own reduction (dlio_bn_train_apply phase 1)
       const int rc = dlio_bn_train_apply(x, N, x_ctot, x_coff, C, HW, 0, post_relu, gamma, beta, eps, momentum, running_mean,
                                          running_var, mean, invstd, scale, nullptr, 0, 0, y ? y : const_cast<float*>(x), y_ctot,
-                                         y_coff, nullptr, 0, 0, ws, ws_bytes, 1, count_scale, nullptr, nullptr, nullptr, stream);
+                                         y_coff, nullptr, 0, 0, ws, ws_bytes, 1, count_scale, nullptr, nullptr, nullptr, nullptr, stream);
       if (rc || mode == 1) return rc;
     }
   }

@@ -332,11 +332,14 @@ class _CBR:
                 training, momentum, eps, pre_relu, post_relu, raw, raw_ctot, raw_coff, out, out_ctot,
                 out_coff, N, residual=None, r_ctot=0, r_coff=0, gap=None, gap_ctot=0, gap_coff=0,
                 need_dx=True, in_aff=None, r_aff=None, stats_into=None, shift_into=None, conv_done=False,
-                split_into=None, skip_bn=False):
+                split_into=None, skip_bn=False, x_amax=None, want_amax=False):
         """in_aff (mean, scale, shift rows over the x_ctot input channels): x is stored BEFORE its producer's
         BatchNorm + ReLU and activated while the convolution loads it; r_aff: the same for the residual;
         stats_into (three [Cout] tensors): train-mode statistics only -- the activated output is not
-        written, the consumers apply (mean, scale, beta) on load (apply-on-load, HISTORY 11)."""
+        written, the consumers apply (mean, scale, beta) on load (apply-on-load, HISTORY 11).
+        x_amax (one-float tensor: the largest |x|, left by x's producer): a 3x3 stride-1 layer runs its forward -- and in
+        backward its weight gradient -- on the two-piece fp16 split; want_amax: the BatchNorm launch that writes `out` leaves
+        its largest magnitude in d.out_amax (for the next layer)."""
         Cout, _, KH, KW = weight.shape
         d = ops.conv_desc(N, Cin, H, W, Cout, KH, KW, stride[0], stride[1], pad[0], pad[1],
                           in_ctot=x_ctot, in_coff=x_coff, out_ctot=raw_ctot, out_coff=raw_coff,
@@ -349,7 +352,14 @@ class _CBR:
                 and (((KH, KW) == (3, 5) and tuple(stride) == (1, 2) and (not need_dx or _CONV_BX3_3X5[0]))
                      or ((KH, KW) == (3, 3) and tuple(stride) == (2, 2) and _CONV_BX3_3X5[0] and Cin >= 16)))
         bx3 = bx3 or stem
-        if bx3:
+        # FlowNet / ResNet / any plain conv + BN layer: 3x3 stride-1 forward on two fp16 pieces when the producer of x left its
+        # largest magnitude (three MFMAs per product instead of six)
+        h2f = (bx3 and not stem and KH == 3 and training and x_amax is not None and in_aff is None and not conv_done
+               and _CONV_H2_FWD[0] and ops._SYNC_BN[0] is None and x.is_cuda and ops.conv3x3_h2_ok(d))
+        d.x_amax = x_amax if h2f else None
+        if h2f:
+            wt = ops.conv_h2_prepped(weight, 0)
+        elif bx3:
             wt = ops.conv_bx3_prepped(weight, 0)
         else:
             wt = ops.conv2d_prepped(weight, 0)
@@ -360,7 +370,9 @@ class _CBR:
                 # 1x1 data gradients behind a one-launch BatchNorm backward (which leaves the largest |dy|): two fp16 pieces
                 d.wh2_1 = ops.conv_h2_prepped(weight, 1)
             if (KH == 3 and _DGRAD_H2[0] and tuple(stride) == (1, 1) and ops._SYNC_BN[0] is None and not pre_relu and _BN_SMALL[0]
-                    and (ops.bn_coop_ok(N, d.OH * d.OW) or (_SMALL_H2[0] and ops.bn_small_ok(N, d.OH * d.OW)))):
+                    and (ops.bn_coop_ok(N, d.OH * d.OW) or (_SMALL_H2[0] and ops.bn_small_ok(N, d.OH * d.OW))
+                         or (_CONV_H2_FWD[0] and want_amax))):
+                # (want_amax: a plain conv + BN layer -- its two-launch BatchNorm backward leaves the largest |dy| as well)
                 # ... and as two fp16 pieces where the data gradient runs on the two-piece kernel (it needs the largest
                 # magnitude of its operand: conv_dgrad's `amax`, else the three-piece layout above is used)
                 g = ops.conv_desc(N, Cout, d.OH, d.OW, Cin, 3, 3, 1, 1, 2 - d.PH, 2 - d.PW, OH=H, OW=W)
@@ -389,6 +401,8 @@ class _CBR:
                            for it in plan if it is not None}
         if conv_done:
             pass                 # raw already holds this layer's output (fused Fire expand pair, dlio_fire_expand_fwd)
+        elif h2f:
+            ops.conv3x3_h2_fwd(x, x_amax, wt, bias, raw, d)
         elif stem:
             ops.conv3x5s2_bx3_fwd(x, wt, bias, raw, d)
         elif bx3 and KH == 1:
@@ -419,22 +433,25 @@ class _CBR:
                 and (gap is None or ops.bn_coop_gap_ok(N, OHW))):
             # large planes: the N workgroups holding a channel in registers exchange their partial sums (one launch, one read)
             prm = torch.empty(3, Cout, dtype=torch.float32, device=raw.device)
+            d.out_amax = ops.amax_slot_kept(raw.device) if want_amax else None
             ops.bn_coop_fwd(raw, raw_ctot, raw_coff, N, Cout, Cout, OHW, (gamma, beta, rmean, rvar), None, eps, momentum,
                             prm, out, out_ctot, out_coff, post_relu, residual=residual, r_ctot=r_ctot, r_coff=r_coff,
-                            r_aff=r_aff, gap_out=gap, gap_ctot=gap_ctot, gap_coff=gap_coff)
+                            r_aff=r_aff, gap_out=gap, gap_ctot=gap_ctot, gap_coff=gap_coff, amax_out=d.out_amax)
             return d, prm
         if (training and _BN_SMALL[0] and not pre_relu and raw.is_cuda and ops.bn_small_ok(N, OHW) and stats_into is None):
             # small feature maps: statistics + apply in ONE launch, the tensor read once (bn_small.hip)
             prm = torch.empty(3, Cout, dtype=torch.float32, device=raw.device)
+            d.out_amax = ops.amax_slot_kept(raw.device) if (want_amax and out is not None) else None
             ops.bn_small_fwd(raw, raw_ctot, raw_coff, N, Cout, Cout, OHW, (gamma, beta, rmean, rvar), None, eps, momentum,
                              prm, out, out_ctot, out_coff, post_relu, residual=residual, r_ctot=r_ctot, r_coff=r_coff,
-                             r_aff=r_aff, gap_out=gap, gap_ctot=gap_ctot, gap_coff=gap_coff)
+                             r_aff=r_aff, gap_out=gap, gap_ctot=gap_ctot, gap_coff=gap_coff, amax_out=d.out_amax)
             return d, prm
         if training and _PLANE_BN[0]:
             # statistics + finalise + apply (+ the plane averages an SELayer wants) in 2 launches
+            d.out_amax = ops.amax_slot_kept(raw.device) if (want_amax and raw.is_cuda) else None
             prm = ops.bn_train_apply(raw, raw_ctot, raw_coff, gamma, beta, eps, momentum, rmean, rvar, out,
                                      out_ctot, out_coff, N, Cout, OHW, pre_relu, post_relu, residual, r_ctot,
-                                     r_coff, gap, gap_ctot, gap_coff, r_aff=r_aff)
+                                     r_coff, gap, gap_ctot, gap_coff, r_aff=r_aff, amax_out=d.out_amax)
             return d, prm
         if r_aff is not None:
             raise RuntimeError("a residual that is stored before its BatchNorm + ReLU (apply-on-load) needs the plane-"
@@ -471,12 +488,12 @@ class _CBR:
         if bn_grads is not None:
             pass
         elif (training and _BN_SMALL[0] and not pre_relu and dy.is_cuda and ops.bn_coop_ok(N, OHW) and pooled is None):
-            if amax is None and need_dx and getattr(d, "wh2_1", None) is not None:
-                amax = ops.amax_slot(dy.device)          # the data gradient runs on two fp16 pieces: it wants the largest |draw|
+            if amax is None and ((need_dx and getattr(d, "wh2_1", None) is not None) or getattr(d, "x_amax", None) is not None):
+                amax = ops.amax_slot(dy.device)          # the data / weight gradient runs on two fp16 pieces: it wants the largest |draw|
             ops.bn_coop_bwd(dy, dy_ctot, dy_coff, raw, d.out_ctot, d.out_coff, prm, beta, None, draw, None, dgamma, dbeta,
                             None, None, acc_g, N, Cout, Cout, OHW, post_relu, amax_out=amax)
         elif (training and _BN_SMALL[0] and not pre_relu and dy.is_cuda and ops.bn_small_ok(N, OHW) and pooled is None):
-            if amax is None and need_dx and _SMALL_H2[0] and getattr(d, "wh2_1", None) is not None:
+            if amax is None and _SMALL_H2[0] and ((need_dx and getattr(d, "wh2_1", None) is not None) or getattr(d, "x_amax", None) is not None):
                 amax = ops.amax_slot(dy.device)
             ops.bn_small_bwd(dy, dy_ctot, dy_coff, raw, d.out_ctot, d.out_coff, prm, beta, None, draw, None, dgamma, dbeta,
                              None, None, acc_g, N, Cout, Cout, OHW, post_relu, amax_out=amax)
@@ -484,10 +501,14 @@ class _CBR:
             # dy is the POOLED gradient: (arg-max map, pool row stride) -- the BatchNorm passes gather the gradient of the
             # activated tensor themselves (dlio_bn_bwd_pool), the pool's backward pass is not run
             ops.bn_bwd_pool(dy, pooled[0], raw, prm, beta, draw, pooled[1], dgamma, dbeta, accumulate=acc_g)
+        elif _PLANE_BN[0]:
+            if amax is None and dy.is_cuda and training and (getattr(d, "wh2_1", None) is not None or getattr(d, "x_amax", None) is not None):
+                amax = ops.amax_slot(dy.device)          # the data / weight gradient runs on two fp16 pieces
+            ops.bn_bwd_fused(dy, dy_ctot, dy_coff, raw, d.out_ctot, d.out_coff, prm, beta, draw, Cout, 0, N,
+                             Cout, OHW, pre_relu, post_relu, training, dgamma, dbeta, accumulate=acc_g, amax_out=amax)
         else:
-            (ops.bn_bwd_fused if _PLANE_BN[0] else ops.bn_bwd)(
-                dy, dy_ctot, dy_coff, raw, d.out_ctot, d.out_coff, prm, beta, draw, Cout, 0, N,
-                Cout, OHW, pre_relu, post_relu, training, dgamma, dbeta, accumulate=acc_g)
+            ops.bn_bwd(dy, dy_ctot, dy_coff, raw, d.out_ctot, d.out_coff, prm, beta, draw, Cout, 0, N,
+                       Cout, OHW, pre_relu, post_relu, training, dgamma, dbeta, accumulate=acc_g)
         ret_bias = None
         if bias is not None:
             dbias, acc, ret_bias = _sink(bias, (Cout,), dy)
@@ -503,6 +524,8 @@ class _CBR:
                            OW=d.OW, in_ctot=d.in_ctot, in_coff=d.in_coff, out_ctot=Cout, out_coff=0,
                            in_relu=1 if in_aff is not None else 0)
         ws = _wgrad_stream(dy) if acc_w else None
+        if x_bound is None:
+            x_bound = getattr(d, "x_amax", None)          # (a two-piece forward: the weight gradient takes the same scale)
         wg_h2 = (amax is not None and x_bound is not None and in_aff is None and _WGRAD_H2[0] and d.KH == 3
                  and ops.conv3x3_wgrad_h2_ok(dd))
         if wg_h2 and ws is None:
@@ -585,6 +608,9 @@ _FIRE_H2 = [os.environ.get("DLIO_FIRE_H2", "1") != "0"]         # fused Fire for
 _DGRAD1_H2 = [os.environ.get("DLIO_DGRAD1_H2", "1") != "0"]     # squeeze / expand1x1 data gradients of fire_blk1-3 likewise
 _SMALL_H2 = [os.environ.get("DLIO_SMALL_H2", "1") != "0"]       # ... and of fire_blk4 / blk5 (scale from dlio_bn_small_bwd's amax_out)
 _WGRAD_H2 = [os.environ.get("DLIO_WGRAD_H2", "1") != "0"]       # expand3x3 weight gradients of fire_blk1-3 on two fp16 pieces
+# plain conv + BN layers (FlowNet, ResNet): 3x3 stride-1 forward + weight gradient on two fp16 pieces, scale from the producer's
+# BatchNorm launch; data gradients likewise behind the two-launch BatchNorm backward (0: three-piece bf16 as in round 4)
+_CONV_H2_FWD = [os.environ.get("DLIO_CONV_H2_FWD", "1") != "0"]
 _FIRE_STATS = [os.environ.get("DLIO_FIRE_STATS", "1") != "0"]   # apply-on-load blocks: BatchNorm statistics from the expand launch
 # ... and for the blocks on large planes that write their output: statistics from the expand launch + a streaming apply
 # (0: the cooperative one-launch BatchNorm forward of round 4)
@@ -754,13 +780,16 @@ class ConvBnAct(Function):
         Cout, _, KH, KW = weight.shape
         OH = (H + 2 * pad[0] - KH) // stride[0] + 1
         OW = (W + 2 * pad[1] - KW) // stride[1] + 1
+        x_amax = getattr(x, "_dlio_amax", None)
         raw = _new((N, Cout, OH, OW), x)
         out = _new((N, Cout, OH, OW), x)
         d, prm = _CBR.forward(x, Cin, 0, Cin, H, W, weight, bias, gamma, beta, rmean, rvar, stride,
                               pad, training, momentum, eps, pre_relu, post_relu, raw, Cout, 0, out,
-                              Cout, 0, N, need_dx=ctx.needs_input_grad[0])
+                              Cout, 0, N, need_dx=ctx.needs_input_grad[0], x_amax=x_amax,
+                              want_amax=training and x.is_cuda and _CONV_H2_FWD[0] and ops._SYNC_BN[0] is None)
         ctx.save_for_backward(x, weight, beta, raw, prm, gamma, bias)
         ctx.cfg = (d, training, pre_relu, post_relu)
+        out._dlio_amax = getattr(d, "out_amax", None)        # (the largest |out|: the next layer's two-piece operand scale)
         return out
 
     @staticmethod
@@ -1124,10 +1153,12 @@ class ConvAddFn(Function):
 class MaxPoolFn(Function):
     @staticmethod
     def forward(ctx, x, k, stride, pad, ceil_mode):
+        amax = getattr(x, "_dlio_amax", None)
         x = x.contiguous()
         y, idx = ops.maxpool2d_fwd(x, k, stride[0], stride[1], pad[0], pad[1], ceil_mode)
         ctx.save_for_backward(idx)
         ctx.cfg = (tuple(x.shape), k, stride, pad)
+        y._dlio_amax = amax                 # (max |pool(x)| <= max |x|: still a valid operand scale)
         return y
 
     @staticmethod
@@ -1329,7 +1360,11 @@ class BinaryFn(Function):
     @staticmethod
     def forward(ctx, a, b, op):
         a, b = a.contiguous(), b.contiguous()
-        y = ops.ew_binary(a, b, op)
+        # relu(a + b), the BasicBlock tail: its consumer is a 3x3 convolution -- leave the largest magnitude for it
+        slot = (ops.amax_slot_kept(a.device) if (op == 3 and a.is_cuda and _CONV_H2_FWD[0] and a.numel() % 4 == 0
+                                                   and any(ctx.needs_input_grad[:2]) and ops._SYNC_BN[0] is None) else None)
+        y = ops.ew_binary(a, b, op, amax_out=slot)
+        y._dlio_amax = slot
         ctx.op = op
         if op == 2:
             ctx.save_for_backward(a, b)

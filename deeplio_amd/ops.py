@@ -511,9 +511,9 @@ def _partials_view(ws, N, C_, HW):
 
 def bn_train_apply(x, x_ctot, x_coff, gamma, beta, eps, momentum, running_mean, running_var, y, y_ctot,
                    y_coff, N, C_, HW, pre_relu, post_relu, residual=None, r_ctot=0, r_coff=0,
-                   gap_out=None, gap_ctot=0, gap_coff=0, r_aff=None):
+                   gap_out=None, gap_ctot=0, gap_coff=0, r_aff=None, amax_out=None):
     """train-mode BN forward (statistics + apply) in two launches -> prm [3][C]; with SyncBN the
-    partial sums are all-reduced between the two launches"""
+    partial sums are all-reduced between the two launches.  amax_out: a zeroed one-float tensor that receives max |y|"""
     prm = torch.empty(3, C_, dtype=torch.float32, device=x.device)
     ws = _stats_ws(N, C_, HW, x.device)
 
@@ -525,7 +525,8 @@ def bn_train_apply(x, x_ctot, x_coff, gamma, beta, eps, momentum, running_mean, 
                                       gap_ctot, gap_coff, _ptr(ws), ws.numel(), phase, float(scale),
                                       _ptr(r_aff[0]) if r_aff is not None else None,
                                       _ptr(r_aff[1]) if r_aff is not None else None,
-                                      _ptr(r_aff[2]) if r_aff is not None else None, _stream()),
+                                      _ptr(r_aff[2]) if r_aff is not None else None, _ptr(amax_out) if phase != 1 else None,
+                                      _stream()),
               "bn_train_apply")
     sync = _SYNC_BN[0]
     if sync is None:
@@ -544,7 +545,8 @@ def bn_small_ok(N, HW):
 
 
 def bn_small_fwd(x, x_ctot, x_coff, N, C_, C1, HW, set1, set2, eps, momentum, prm, y, y_ctot, y_coff, post_relu=True,
-                 shift_out=None, residual=None, r_ctot=0, r_coff=0, r_aff=None, gap_out=None, gap_ctot=0, gap_coff=0):
+                 shift_out=None, residual=None, r_ctot=0, r_coff=0, r_aff=None, gap_out=None, gap_ctot=0, gap_coff=0,
+                 amax_out=None):
     """train-mode BatchNorm (+ ReLU, + residual) of a small feature map in one launch; set1 / set2 = (gamma, beta,
     running_mean, running_var) of the channels [0, C1) / [C1, C_) (set2 None: one layer); prm = (mean, invstd, scale)
     rows of C_ floats; y None: statistics only"""
@@ -554,7 +556,8 @@ def bn_small_fwd(x, x_ctot, x_coff, N, C_, C1, HW, set1, set2, eps, momentum, pr
                                 float(momentum), _ptr(prm[0]), _ptr(prm[1]), _ptr(prm[2]), _ptr(shift_out), _ptr(residual),
                                 r_ctot, r_coff, _ptr(r_aff[0]) if r_aff is not None else None,
                                 _ptr(r_aff[1]) if r_aff is not None else None, _ptr(r_aff[2]) if r_aff is not None else None,
-                                _ptr(y), y_ctot, y_coff, _ptr(gap_out), gap_ctot, gap_coff, _stream()), "bn_small_fwd")
+                                _ptr(y), y_ctot, y_coff, _ptr(gap_out), gap_ctot, gap_coff, _ptr(amax_out), _stream()),
+          "bn_small_fwd")
     return prm
 
 
@@ -637,7 +640,7 @@ def _coop_ws(N, C_, device):
 
 
 def bn_coop_fwd(x, x_ctot, x_coff, N, C_, C1, HW, set1, set2, eps, momentum, prm, y, y_ctot, y_coff, post_relu=True,
-                residual=None, r_ctot=0, r_coff=0, r_aff=None, gap_out=None, gap_ctot=0, gap_coff=0):
+                residual=None, r_ctot=0, r_coff=0, r_aff=None, gap_out=None, gap_ctot=0, gap_coff=0, amax_out=None):
     """bn_small_fwd for large planes (N cooperating workgroups per channel)"""
     g2 = set2 if set2 is not None else (None, None, None, None)
     part, sync = _coop_ws(N, C_, x.device)
@@ -646,7 +649,8 @@ def bn_coop_fwd(x, x_ctot, x_coff, N, C_, C1, HW, set1, set2, eps, momentum, prm
                                float(momentum), _ptr(prm[0]), _ptr(prm[1]), _ptr(prm[2]), _ptr(residual),
                                r_ctot, r_coff, _ptr(r_aff[0]) if r_aff is not None else None,
                                _ptr(r_aff[1]) if r_aff is not None else None, _ptr(r_aff[2]) if r_aff is not None else None,
-                               _ptr(y), y_ctot, y_coff, _ptr(gap_out), gap_ctot, gap_coff, _ptr(part), _ptr(sync), _stream()),
+                               _ptr(y), y_ctot, y_coff, _ptr(gap_out), gap_ctot, gap_coff, _ptr(part), _ptr(sync),
+                               _ptr(amax_out), _stream()),
           "bn_coop_fwd")
     return prm
 
@@ -698,6 +702,27 @@ def amax_slot(device):
         buf[(i % _AMAX_N):(i % _AMAX_N) + half].zero_()
     e[1] = i + 1
     j = i % _AMAX_N
+    return buf[j:j + 1]
+
+
+_AMAX_KEEP = {}
+
+
+def amax_slot_kept(device):
+    """amax_slot for a value that is read again in the backward pass (the operand scale of a two-piece forward convolution,
+    reused by its weight gradient): a ring of its own, four times as long -- a slot is zeroed again >= 4096 allocations of
+    its stream later, hundreds of training steps"""
+    key = (device.index if device.index is not None else torch._C._cuda_getDevice(), raw_stream())
+    e = _AMAX_KEEP.get(key)
+    n = 4 * _AMAX_N
+    if e is None:
+        e = _AMAX_KEEP[key] = [torch.zeros(n, dtype=torch.float32, device=device), 0]
+    buf, i = e
+    half = n // 2
+    if i % half == 0 and i >= half:
+        buf[(i % n):(i % n) + half].zero_()
+    e[1] = i + 1
+    j = i % n
     return buf[j:j + 1]
 
 
@@ -807,16 +832,17 @@ def fire_expand_fwd_stats(planes, w3t, w1t, bias3, bias1, y, N, S, H, W, E, y_ct
 
 
 def bn_bwd_fused(dy, dy_ctot, dy_coff, x, x_ctot, x_coff, prm, beta, dx, dx_ctot, dx_coff, N, C_, HW,
-                 pre_relu, post_relu, use_batch_stats, dgamma=None, dbeta=None, accumulate=False):
+                 pre_relu, post_relu, use_batch_stats, dgamma=None, dbeta=None, accumulate=False, amax_out=None):
     """BN backward (reductions + dx, dgamma, dbeta) in two launches (SyncBN: partials all-reduced in
-    between, dgamma / dbeta from the local copy)"""
+    between, dgamma / dbeta from the local copy).  amax_out: a zeroed one-float tensor that receives max |dx|"""
     ws = _stats_ws(N, C_, HW, x.device)
 
     def call(phase, scale, local):
         check(lib.dlio_bn_bwd(_ptr(dy), dy_ctot, dy_coff, _ptr(x), x_ctot, x_coff, _ptr(prm[0]), _ptr(prm[1]),
                               _ptr(prm[2]), _ptr(beta), _ptr(dx), dx_ctot, dx_coff, _ptr(dgamma), _ptr(dbeta),
                               int(accumulate), N, C_, HW, int(pre_relu), int(post_relu), int(use_batch_stats),
-                              _ptr(ws), ws.numel(), phase, float(scale), _ptr(local), _stream()), "bn_bwd")
+                              _ptr(ws), ws.numel(), phase, float(scale), _ptr(local),
+                              _ptr(amax_out) if phase != 1 else None, _stream()), "bn_bwd")
     sync = _SYNC_BN[0]
     if sync is None or not use_batch_stats:
         call(0, 1.0, None)
@@ -1085,10 +1111,11 @@ def linear_bwd_weight(dz, x, M, N_, K, dw=None, db=None, want_bias=True, lddz=No
     return dw, db
 
 
-def ew_binary(a, b, op, out=None):
+def ew_binary(a, b, op, out=None, amax_out=None):
+    """amax_out: a zeroed one-float tensor that receives max |out| (tensors of a multiple of four elements, 16-byte aligned)"""
     if out is None:
         out = torch.empty_like(a)
-    check(lib.dlio_ew_binary(_ptr(a), _ptr(b), _ptr(out), a.numel(), op, _stream()), "ew_binary")
+    check(lib.dlio_ew_binary(_ptr(a), _ptr(b), _ptr(out), a.numel(), op, _ptr(amax_out), _stream()), "ew_binary")
     return out
 
 

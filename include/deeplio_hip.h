@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 232
+#define DLIO_ABI_VERSION 233
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);
@@ -421,7 +421,7 @@ int dlio_linear_bwd_weight(const float* dz, int lddz, const float* x, int ldx, f
 
 /* ---- elementwise helpers ---------------------------------------------- */
 /* op: 0 a+b, 1 a-b, 2 a*b, 3 relu(a+b) (BasicBlock tail) */
-int dlio_ew_binary(const float* a, const float* b, float* y, int64_t n, int op,
+int dlio_ew_binary(const float* a, const float* b, float* y, int64_t n, int op, float* amax_out,
                    dlio_stream_t stream);
 /* torch.sum(y, dim=0) per IMU window (imu_feat_nets.py:49): y[g][c] = sum_r x[g][r][c];
  * backward broadcasts dy over r */
@@ -541,6 +541,9 @@ int dlio_gt_relative(const float* gts, const int32_t* combinations, float* f2f, 
  * convolution output and is activated on load, residual' = max(0, (r - r_mean) * r_scale + r_shift)
  * (apply-on-load: the producing Fire block's BatchNorm+ReLU output is never written). */
 int dlio_chan_stats_splits(int N, int C, int HW);
+/* amax_out (nullable; also on dlio_bn_small_fwd / dlio_bn_coop_fwd / dlio_bn_bwd / dlio_ew_binary): one device float, ZERO
+ * before the launch, that receives the largest |y| written -- the operand scale of a two-piece fp16 consumer
+ * (dlio_conv3x3_h2_fwd, dlio_conv3x3_wgrad_h2) without a pass of its own. */
 int dlio_bn_train_apply(const float* x, int N, int x_ctot, int x_coff, int C, int HW, int pre_relu,
                         int post_relu, const float* gamma, const float* beta, float eps,
                         float momentum, float* running_mean, float* running_var, float* mean,
@@ -548,7 +551,7 @@ int dlio_bn_train_apply(const float* x, int N, int x_ctot, int x_coff, int C, in
                         float* y, int y_ctot, int y_coff, float* gap_out, int gap_ctot, int gap_coff,
                         void* ws, size_t ws_bytes, int phase, double count_scale,
                         const float* r_mean, const float* r_scale, const float* r_shift,
-                        dlio_stream_t stream);
+                        float* amax_out, dlio_stream_t stream);
 /* Train-mode BatchNorm2d (+ ReLU, + residual) of SMALL feature maps in ONE launch (csrc/bn_small.hip; the BatchNorm2d of
  * pointseg_modules.py:98-106 in fire_blk4 / fire_blk5): N <= 16 images, H * W in {256, 512, 1024, 2048} (dlio_bn_small_ok),
  * 16-byte aligned planes; DLIO_EUNSUP otherwise (use dlio_bn_train_apply / dlio_bn_bwd).  One workgroup holds a channel
@@ -565,7 +568,7 @@ int dlio_bn_small_fwd(const float* x, int N, int x_ctot, int x_coff, int C, int 
                       float eps, float momentum, float* mean, float* invstd, float* scale, float* shift_out,
                       const float* residual, int r_ctot, int r_coff, const float* r_mean, const float* r_scale,
                       const float* r_shift, float* y, int y_ctot, int y_coff, float* gap_out, int gap_ctot,
-                      int gap_coff, dlio_stream_t stream);
+                      int gap_coff, float* amax_out, dlio_stream_t stream);
 int dlio_bn_small_bwd(const float* dy, int dy_ctot, int dy_coff, const float* x, int x_ctot, int x_coff,
                       const float* mean, const float* invstd, const float* scale, const float* beta1,
                       const float* beta2, float* dx1, float* dx2, float* dgamma1, float* dbeta1, float* dgamma2,
@@ -605,7 +608,7 @@ int dlio_bn_coop_fwd(const float* x, int N, int x_ctot, int x_coff, int C, int C
                      float eps, float momentum, float* mean, float* invstd, float* scale,
                      const float* residual, int r_ctot, int r_coff, const float* r_mean, const float* r_scale,
                      const float* r_shift, float* y, int y_ctot, int y_coff, float* gap_out, int gap_ctot,
-                     int gap_coff, void* part, void* sync, dlio_stream_t stream);
+                     int gap_coff, void* part, void* sync, float* amax_out, dlio_stream_t stream);
 int dlio_bn_coop_bwd(const float* dy, int dy_ctot, int dy_coff, const float* x, int x_ctot, int x_coff,
                      const float* mean, const float* invstd, const float* scale, const float* beta1,
                      const float* beta2, float* dx1, float* dx2, float* dgamma1, float* dbeta1, float* dgamma2,
@@ -678,7 +681,7 @@ int dlio_bn_bwd(const float* dy, int dy_ctot, int dy_coff, const float* x, int x
                 float* dx, int dx_ctot, int dx_coff, float* dgamma, float* dbeta, int accumulate,
                 int N, int C, int HW, int pre_relu, int post_relu, int use_batch_stats, void* ws,
                 size_t ws_bytes, int phase, double count_scale, const void* local_ws,
-                dlio_stream_t stream);
+                float* amax_out, dlio_stream_t stream);
 
 /* ---- lidar scan -> range image (the data step in front of the path) --------
  * LaserScan.do_range_projection (deeplio/common/laserscan.py:122-185): per point

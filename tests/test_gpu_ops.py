@@ -1793,3 +1793,40 @@ def test_streaming_batchnorm_apply_and_pool_without_the_full_resolution_output(d
     s = d(torch.rand(N, C, generator=g) * 0.9 + 0.05)
     ys, is_ = ops.maxpool2d_fwd(y2, 3, SH, 2, 1, 1, False, x_scale=s)
     assert torch.equal(is_, idx) and torch.equal(ops.chan_scale_fwd(yp, s), ys)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(8, 12, 32, 128), (2, 5, 64, 128), (16, 6, 16, 64), (3, 7, 9, 20)])
+def test_batchnorm_and_block_tail_leave_the_largest_magnitude_they_write(dev, case):
+    """amax_out of the launches that produce an operand of a two-piece fp16 convolution (round 5: FlowNet / ResNet layers): the
+    BatchNorm forward kernels (two-launch, one-launch small / cooperative), the two-launch BatchNorm backward and the
+    BasicBlock tail relu(a + b) leave max |output| -- exactly -- in a zeroed device float, with the outputs unchanged"""
+    from deeplio_amd import ops
+    N, C, H, W = case
+    HW = H * W
+    g = _g(101)
+    d = lambda t: t.to(dev)
+    x, res, dy = d(torch.randn(N, C, H, W, generator=g) * 1.7 + 0.3), d(torch.randn(N, C, H, W, generator=g)), d(torch.randn(N, C, H, W, generator=g))
+    gam, bet = d(torch.rand(C, generator=g) + 0.5), d(torch.randn(C, generator=g) * 0.3)
+
+    def check(fn):
+        y0, y1, am = torch.empty_like(x), torch.empty_like(x), ops.amax_slot_kept(dev)
+        fn(y0, None)
+        fn(y1, am)
+        assert torch.equal(y0, y1) and float(am) == float(y1.abs().max()) > 0
+        return y1
+    prm_box = []
+    def plane(y, am):
+        prm_box[:] = [ops.bn_train_apply(x, C, 0, gam, bet, 1e-5, 0.1, None, None, y, C, 0, N, C, HW, False, False, res, C, 0, amax_out=am)]
+    check(plane)
+    prm = prm_box[0]
+    if ops.bn_small_ok(N, HW):
+        check(lambda y, am: ops.bn_small_fwd(x, C, 0, N, C, C, HW, (gam, bet, None, None), None, 1e-5, 0.1, torch.empty(3, C, device=dev), y, C, 0,
+                                             True, residual=res, r_ctot=C, r_coff=0, amax_out=am))
+    if ops.bn_coop_ok(N, HW):
+        check(lambda y, am: ops.bn_coop_fwd(x, C, 0, N, C, C, HW, (gam, bet, None, None), None, 1e-5, 0.1, torch.empty(3, C, device=dev), y, C, 0,
+                                            True, residual=res, r_ctot=C, r_coff=0, amax_out=am))
+    check(lambda y, am: ops.bn_bwd_fused(dy, C, 0, x, C, 0, (prm[0], prm[1], prm[2]), bet, y, C, 0, N, C, HW, False, True, True, amax_out=am))
+    if x.numel() % 4 == 0:
+        check(lambda y, am: ops.ew_binary(x, res, 3, out=y, amax_out=am))
+    assert ops.bn_coop_errors() == 0

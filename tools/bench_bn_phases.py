@@ -37,7 +37,7 @@ for name, E, H, W in LAYERS:
     def phase(ph, r=None):
         check(lib.dlio_bn_train_apply(_ptr(raw), N, CE, 0, CE, HW, 0, 1, _ptr(g), _ptr(b), 1e-5, 0.1, _ptr(rm), _ptr(rv), _ptr(prm[0]),
                                       _ptr(prm[1]), _ptr(prm[2]), _ptr(r), CE, 0, _ptr(out), CE, 0, None, 0, 0, _ptr(ws), ws.numel(),
-                                      ph, 1.0, None, None, None, _stream()), "x")
+                                      ph, 1.0, None, None, None, None, _stream()), "x")
     t_c = timeit(lambda: ops.bn_coop_fwd(raw, CE, 0, N, CE, E, HW, s1, s2, 1e-5, 0.1, prm, out, CE, 0, True))
     t_g = timeit(lambda: ops.bn_coop_fwd(raw, CE, 0, N, CE, E, HW, s1, s2, 1e-5, 0.1, prm, out, CE, 0, True, gap_out=gap, gap_ctot=CE))
     t_1 = timeit(lambda: phase(1))

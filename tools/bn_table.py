@@ -56,12 +56,12 @@ for name, C, ctot, H, W in shapes:
     def fwd(phase):
         ops.check(lib.dlio_bn_train_apply(_ptr(x), N, ctot, 0, C, HW, 0, 1, _ptr(g), _ptr(b), 1e-5, 0.1, _ptr(rm), _ptr(rv),
                                           _ptr(prm[0]), _ptr(prm[1]), _ptr(prm[2]), None, 0, 0, _ptr(y), ctot, 0, None, 0, 0,
-                                          _ptr(ws), ws.numel(), phase, 1.0, _stream()), "fwd")
+                                          _ptr(ws), ws.numel(), phase, 1.0, None, None, None, None, _stream()), "fwd")
 
     def bwd(phase):
         ops.check(lib.dlio_bn_bwd(_ptr(dy), ctot, 0, _ptr(x), ctot, 0, _ptr(prm[0]), _ptr(prm[1]), _ptr(prm[2]), _ptr(b),
                                   _ptr(dx), ctot, 0, _ptr(dg), _ptr(db), 0, N, C, HW, 0, 1, 1, _ptr(ws), ws.numel(), phase, 1.0,
-                                  None, _stream()), "bwd")
+                                  None, None, _stream()), "bwd")
     ts = [timeit(lambda: fwd(1)), timeit(lambda: fwd(2)), timeit(lambda: bwd(1)), timeit(lambda: bwd(2))]
     byt = 4.0 * N * C * HW
     passes = [1, 2, 2, 3]
