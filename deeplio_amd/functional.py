@@ -367,6 +367,7 @@ class _CBR:
                 and (KH == 3 or (pad[0] == 0 and pad[1] == 0))):
             if (KH == 1 and _DGRAD1_H2[0] and ops._SYNC_BN[0] is None and not pre_relu and _BN_SMALL[0]
                     and (ops.bn_coop_ok(N, d.OH * d.OW) or (_SMALL_H2[0] and ops.bn_small_ok(N, d.OH * d.OW)))):
+                # (with a cooperative geometry below _BN_COOP_MIN_BYTES the two-launch backward runs: it leaves amax as well)
                 # 1x1 data gradients behind a one-launch BatchNorm backward (which leaves the largest |dy|): two fp16 pieces
                 d.wh2_1 = ops.conv_h2_prepped(weight, 1)
             if (KH == 3 and _DGRAD_H2[0] and tuple(stride) == (1, 1) and ops._SYNC_BN[0] is None and not pre_relu and _BN_SMALL[0]
@@ -430,7 +431,7 @@ class _CBR:
                                      prm=stats_into, beta=beta, shift_out=shift_into)
             return d, prm
         if (training and _BN_SMALL[0] and _BN_COOP_FWD[0] and not pre_relu and raw.is_cuda and out is not None and ops.bn_coop_ok(N, OHW)
-                and (gap is None or ops.bn_coop_gap_ok(N, OHW))):
+                and (gap is None or ops.bn_coop_gap_ok(N, OHW)) and _coop_pays(N, Cout, OHW)):
             # large planes: the N workgroups holding a channel in registers exchange their partial sums (one launch, one read)
             prm = torch.empty(3, Cout, dtype=torch.float32, device=raw.device)
             d.out_amax = ops.amax_slot_kept(raw.device) if want_amax else None
@@ -487,7 +488,8 @@ class _CBR:
                 ret_g, ret_b = dgamma, dbeta
         if bn_grads is not None:
             pass
-        elif (training and _BN_SMALL[0] and not pre_relu and dy.is_cuda and ops.bn_coop_ok(N, OHW) and pooled is None):
+        elif (training and _BN_SMALL[0] and not pre_relu and dy.is_cuda and ops.bn_coop_ok(N, OHW) and pooled is None
+              and _coop_pays(N, Cout, OHW)):
             if amax is None and ((need_dx and getattr(d, "wh2_1", None) is not None) or getattr(d, "x_amax", None) is not None):
                 amax = ops.amax_slot(dy.device)          # the data / weight gradient runs on two fp16 pieces: it wants the largest |draw|
             ops.bn_coop_bwd(dy, dy_ctot, dy_coff, raw, d.out_ctot, d.out_coff, prm, beta, None, draw, None, dgamma, dbeta,
@@ -617,6 +619,18 @@ _FIRE_STATS = [os.environ.get("DLIO_FIRE_STATS", "1") != "0"]   # apply-on-load 
 _FIRE_STREAM = [os.environ.get("DLIO_FIRE_STREAM", "1") != "0"]
 # the block in front of SELayer + MaxPool pools while it applies its BatchNorm: its output is never written (0: written, pooled by SEPoolFn)
 _POOL_FUSE = [os.environ.get("DLIO_POOL_FUSE", "1") != "0"]
+
+
+# the cooperative one-launch BatchNorm kernels pay from this many bytes per operand on: below it (the squeeze layers: 8-34 MB) the
+# second read of the two-launch kernels comes out of the L2 / Infinity Cache and they are faster than an exchange between
+# workgroups (tools/bench_bn_squeeze.py: 26-31 us against 32-48)
+# ... alone; inside the five-stream step the two choices are equal within the run-to-run noise (19.1-19.4 ms either way), so the
+# default keeps the launch count down: 0 = cooperative wherever the geometry allows
+_BN_COOP_MIN_BYTES = [int(os.environ.get("DLIO_BN_COOP_MIN_MB", "0")) << 20]
+
+
+def _coop_pays(N, C, HW):
+    return 4 * N * C * HW >= _BN_COOP_MIN_BYTES[0]
 
 
 def _pool_row_stride(pool):
