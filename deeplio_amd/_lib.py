@@ -51,6 +51,8 @@ SIGNATURES = {
     "dlio_conv1x1_bx3_fwd_aff": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _cd, _p]),
     "dlio_conv3x5s2_bx3_fwd": (_i, [_p, _p, _p, _p, _p, _cd, _p]),
     "dlio_conv_bx3_fwd_taps": (_i, [_p, _p, _p, _p, _p, _cd, _p]),
+    "dlio_conv_h2_fwd_strided": (_i, [_p, _p, _p, _p, _p, _p, _cd, _p]),
+    "dlio_conv_h2_fwd_taps": (_i, [_p, _p, _p, _p, _p, _p, _cd, _p]),
     "dlio_conv1x1_bx3_ws_bytes": (_sz, [_cd]),
     "dlio_conv1x1_bx3_fwd_ws": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _cd, _p]),
     "dlio_fire_expand_dgrad": (_i, [_p, _p, _p, _p, _i, _p, _p, _p, _sz, _cd, _p]),

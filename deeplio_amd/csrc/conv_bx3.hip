@@ -33,6 +33,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef BX3_STEM_PF
 #define BX3_STEM_PF 4      // weight-fragment prefetch distance (taps) of the 15-tap stem: 12 MFMAs per tap cover less latency
 #endif
+typedef _Float16 pc_f16x8 __attribute__((ext_vector_type(8)));
 template <class T>
 __device__ __forceinline__ void opaque(T& v) { asm volatile("" : "=v"(v)); }
 
@@ -106,17 +107,21 @@ __global__ void prep_bx3_batched_kernel(const DlioPrepItem* __restrict__ items, 
 
 // KH x KW taps, row stride 1, column stride SW (3x3 / 1: Fire expand3x3 & co; 3x5 / 2: the PointSeg stem,
 // pointseg_net.py:18-20): output column c of a tile reads patch columns SW * c + kw.
-template <int MR, int TWN, int KH = 3, int KW = 3, int SW = 1, int SH = 1>
+// H2 (two-piece fp16 split, as conv3x3_bx3_pc_kernel<MR, true>): x as two fp16 pieces of x 2^k (k from *amax_x, left by the
+// producer of x), weights from dlio_conv_h2_prep: two planes through LDS, three v_mfma_f32_32x32x16_f16 per product; the
+// stores multiply by the two inverse scales.  FlowNet conv2-6 / ResNet stage heads and the phases of their data gradients.
+template <int MR, int TWN, int KH = 3, int KW = 3, int SW = 1, int SH = 1, bool H2 = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
     const float* __restrict__ x, const __bf16* __restrict__ wt, const float* __restrict__ bias,
     const float* residual, float* y, DlioConvDesc d, int tiles_w, int tiles_h, int co_tiles, int patch_at,
-    int vec_out) {
+    int vec_out, const float* __restrict__ amax_x = nullptr) {
+  constexpr int NPL = H2 ? 2 : 3;                        // 16-bit planes per operand
   constexpr int TH = 4, TW = 32 * TWN, NT = KH * KW;
   constexpr int PR = SH * (TH - 1) + KH, PC = SW * (TW - 1) + KW, NPOSP = PR * PC;
   constexpr int NPOS = (NPOSP + 255) / 256;              // patch positions per thread
   constexpr int PLANE = NPOSP * 16;                      // bf16 per plane
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);    // [2 buffers][3 planes][NPOSP][16]
+  __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);    // [2 buffers][NPL planes][NPOSP][16]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
   int bid = xcd_block_index();
@@ -127,6 +132,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
   const int co0 = cot * 32 * MR, oh0 = th * TH, ow0 = tw * TW;
   const int Cin = d.Cin, Cout = d.Cout, HW = d.H * d.W;
   const int KC = (Cin + 15) >> 4;
+  float xs = 1.f, isc = 1.f;                             // H2: 2^k of the operand, 2^-k 2^-j
+  if constexpr (H2) {
+    const float am = amax_x[0];
+    xs = (am > 0.f && am < 3.0e38f) ? exp2f(floorf(log2f(16384.f / am))) : 1.f;
+    isc = (1.f / xs) * reinterpret_cast<const float*>(wt)[(size_t)NT * KC * Cout * 16];
+  }
 
   // ---- staging: a thread owns NPOS patch positions for all 16 channels of a chunk
   bool pval[NPOS];
@@ -172,16 +183,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
         bf16x8 ph[2], pm[2], pl[2];
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-          __bf16 h, m, l;
-          split3(reg[j][c], h, m, l);
-          ph[c >> 3][c & 7] = h; pm[c >> 3][c & 7] = m; pl[c >> 3][c & 7] = l;
+          if constexpr (H2) {
+            const float xv = reg[j][c] * xs;
+            const _Float16 hh = (_Float16)xv;
+            const _Float16 ll = (_Float16)(xv - (float)hh);
+            ph[c >> 3][c & 7] = __builtin_bit_cast(__bf16, hh); pm[c >> 3][c & 7] = __builtin_bit_cast(__bf16, ll);
+          } else {
+            __bf16 h, m, l;
+            split3(reg[j][c], h, m, l);
+            ph[c >> 3][c & 7] = h; pm[c >> 3][c & 7] = m; pl[c >> 3][c & 7] = l;
+          }
         }
         bf16x8* dst = reinterpret_cast<bf16x8*>(buf + pos * 16);
         dst[0] = ph[0]; dst[1] = ph[1];
         dst = reinterpret_cast<bf16x8*>(buf + PLANE + pos * 16);
         dst[0] = pm[0]; dst[1] = pm[1];
-        dst = reinterpret_cast<bf16x8*>(buf + 2 * PLANE + pos * 16);
-        dst[0] = pl[0]; dst[1] = pl[1];
+        if constexpr (!H2) {
+          dst = reinterpret_cast<bf16x8*>(buf + 2 * PLANE + pos * 16);
+          dst[0] = pl[0]; dst[1] = pl[1];
+        }
       }
     }
   };
@@ -191,12 +211,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
 #pragma unroll
   for (int m = 0; m < MR; ++m) nrow[m] = min(co0 + 32 * m + l31, Cout - 1);
   const size_t wplane = (size_t)Cout * 16;
-  auto load_a = [&](int tap, int kc, bf16x8 (&a)[MR][3]) {
-    const __bf16* base = wt + (((size_t)tap * KC + kc) * 3) * wplane + 8 * half;
+  auto load_a = [&](int tap, int kc, bf16x8 (&a)[MR][NPL]) {
+    const __bf16* base = wt + (((size_t)tap * KC + kc) * NPL) * wplane + 8 * half;
 #pragma unroll
     for (int m = 0; m < MR; ++m)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
+      for (int p = 0; p < NPL; ++p) {
         if constexpr (BX3_ABLATE & 4) opaque(a[m][p]);
         else a[m][p] = *reinterpret_cast<const bf16x8*>(base + p * wplane + (size_t)nrow[m] * 16);
       }
@@ -214,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
   // per wave; one tap ahead does not hide an L2 miss when only a few waves share the SIMD)
   constexpr int PF = (KW == 5 ? BX3_STEM_PF : 2), RING = PF + 1;
   auto compute = [&](const __bf16* buf, int kc, bool prefetch) {
-    bf16x8 a[RING][MR][3];
+    bf16x8 a[RING][MR][NPL];
     if (patch_at < 0 && prefetch) load_chunk(kc + 1);
 #pragma unroll
     for (int p = 0; p < PF; ++p) load_a(p, kc, a[p]);
@@ -229,27 +249,39 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
       //  -- with one hoisted test, or sched_barrier(0) fences instead, the compiler's own order is
       //  15-25 % slower on the long-K layers: 64->256 data gradient 193 -> 237-242 us)
       if (tap == patch_at && prefetch) load_chunk(kc + 1);
-      bf16x8 b[TWN][3];
+      bf16x8 b[TWN][NPL];
 #pragma unroll
       for (int t = 0; t < TWN; ++t) {
         const int pos = SW == 2 ? (wave * SH + kh) * PC + (kw & 1) * PCH + (32 * t + l31) + (kw >> 1)
                                 : (wave * SH + kh) * PC + 32 * t + l31 + kw;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NPL; ++p) {
           if constexpr (BX3_ABLATE & 8) opaque(b[t][p]);
           else b[t][p] = *reinterpret_cast<const bf16x8*>(buf + p * PLANE + pos * 16 + 8 * half);
         }
       }
       const auto& aa = a[tap % RING];
-      // six products, smallest first; consecutive MFMAs go to different accumulators
-      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+      if constexpr (H2) {
+        constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0};              // (lo, hi) (hi, lo) (hi, hi): smallest first
 #pragma unroll
-      for (int q = DLIO_SPLIT_Q0; q < 6; ++q)
+        for (int q = 0; q < 3; ++q)
 #pragma unroll
-        for (int m = 0; m < MR; ++m)
+          for (int m = 0; m < MR; ++m)
 #pragma unroll
-          for (int t = 0; t < TWN; ++t)
-            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[m][PA[q]], b[t][PB[q]], acc[m][t], 0, 0, 0);
+            for (int t = 0; t < TWN; ++t)
+              acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pc_f16x8, aa[m][HA[q]]),
+                                                                 __builtin_bit_cast(pc_f16x8, b[t][HB[q]]), acc[m][t], 0, 0, 0);
+      } else {
+        // six products, smallest first; consecutive MFMAs go to different accumulators
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int q = DLIO_SPLIT_Q0; q < 6; ++q)
+#pragma unroll
+          for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int t = 0; t < TWN; ++t)
+              acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[m][PA[q] % NPL], b[t][PB[q] % NPL], acc[m][t], 0, 0, 0);
+      }
     }
   };
 
@@ -258,8 +290,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
   store_chunk(smem, 0);
   __syncthreads();
   for (int kc = 0; kc < KC; ++kc) {
-    const __bf16* cur = smem + (size_t)(kc & 1) * 3 * PLANE;
-    __bf16* nxt = smem + (size_t)((kc + 1) & 1) * 3 * PLANE;
+    const __bf16* cur = smem + (size_t)(kc & 1) * NPL * PLANE;
+    __bf16* nxt = smem + (size_t)((kc + 1) & 1) * NPL * PLANE;
     compute(cur, kc, kc + 1 < KC);
     if constexpr (!(BX3_ABLATE & 1)) { if (kc + 1 < KC) store_chunk(nxt, kc + 1); }
     __syncthreads();
@@ -284,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
       for (int t = 0; t < TWN; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          wbuf[(32 * m + (r & 3) + 8 * (r >> 2) + 4 * half) * TWP + 32 * t + l31] = acc[m][t][r];
+          wbuf[(32 * m + (r & 3) + 8 * (r >> 2) + 4 * half) * TWP + 32 * t + l31] = H2 ? acc[m][t][r] * isc : acc[m][t][r];
     // (each wave reads back only what it wrote itself: no barrier)
     constexpr int Q = TW / 4;                   // float4 per channel row
     float* yrow = y + ((size_t)n * d.out_ctot + d.out_coff) * ohw + (size_t)oh * d.OW + ow0;
@@ -315,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (co >= Cout) continue;
-        float v = acc[m][t][r];
+        float v = H2 ? acc[m][t][r] * isc : acc[m][t][r];
         if (bias) v += bias[co];
         const size_t pix = (size_t)oh * d.OW + ow;
         if (residual) v += residual[((size_t)n * d.res_ctot + d.res_coff + co) * ohw + pix];
@@ -621,7 +653,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_alds_kernel(
 // H2: the operand as TWO fp16 pieces of x 2^k (2^k from the tensor's largest magnitude, *amax_x, left by the kernel that
 // produced x), weights from dlio_conv_h2_prep (two fp16 pieces, { 2^-j, 2^j } behind them): three v_mfma_f32_32x32x16_f16
 // per product, two planes through LDS, 7 VALU per value in the split instead of 11; the epilogue multiplies by 2^-k 2^-j.
-typedef _Float16 pc_f16x8 __attribute__((ext_vector_type(8)));
 // Measured and not kept (two-piece format): a whole-chunk weight ring (two slots of nine taps), the ring loads of chunk i + 1
 // and the patch loads of chunk i + 2 (second register set) issued at the start of step i, one barrier per chunk -- 90.6 /
 // 84.8 / 87.3 / 112.6 us against 92.6-96.1 / 84.9-88.3 / 87.0-87.5 / 112.5-113.4: the chunk time (~3 us) is not a chain of
@@ -1208,17 +1239,17 @@ int launch_bx3_pc(const float* x, const __bf16* wt, const float* bias, const flo
   return dlio_check_launch();
 }
 
-template <int MR, int TWN, int KH = 3, int KW = 3, int SW = 1, int SH = 1>
+template <int MR, int TWN, int KH = 3, int KW = 3, int SW = 1, int SH = 1, bool H2 = false>
 int launch_bx3(const float* x, const __bf16* wt, const float* bias, const float* residual, float* y,
-               const DlioConvDesc& d, hipStream_t s) {
+               const DlioConvDesc& d, hipStream_t s, const float* amax_x = nullptr) {
   constexpr int TH = 4, TW = 32 * TWN;
-  constexpr size_t BUF = (size_t)3 * (SH * (TH - 1) + KH) * (SW * (TW - 1) + KW) * 16 * sizeof(__bf16);
+  constexpr size_t BUF = (size_t)(H2 ? 2 : 3) * (SH * (TH - 1) + KH) * (SW * (TW - 1) + KW) * 16 * sizeof(__bf16);
   const int tiles_w = cdiv(d.OW, TW), tiles_h = cdiv(d.OH, TH), co_tiles = cdiv(d.Cout, 32 * MR);
   const int64_t blocks = (int64_t)d.N * tiles_h * tiles_w * co_tiles;
   if (blocks <= 0 || blocks > 0x7fffffff) return DLIO_EINVAL;
   // one patch buffer is enough for a single-chunk layer (<= 16 input channels: the stem) -- twice the workgroups per CU
   const size_t lds = (size_t)(d.Cin <= 16 ? 1 : 2) * BUF;
-  dlio_set_max_lds(reinterpret_cast<const void*>(&conv3x3_bx3_kernel<MR, TWN, KH, KW, SW, SH>), (int)(2 * BUF));
+  dlio_set_max_lds(reinterpret_cast<const void*>(&conv3x3_bx3_kernel<MR, TWN, KH, KW, SW, SH, H2>), (int)(2 * BUF));
   // when the next chunk's patch loads are issued: behind the first three taps' weight fragments for
   // long channel loops (loads return in order -- fragments queued behind 16-32 patch loads stall
   // their MFMAs for an HBM round trip: blk4 / blk5 data gradients 100 -> 67 us, 125 -> 60 us), ahead of
@@ -1231,8 +1262,8 @@ int launch_bx3(const float* x, const __bf16* wt, const float* bias, const float*
   const int vec_out = vec_on && (d.OW & 3) == 0 && (((size_t)d.OH * d.OW) & 3) == 0 &&
                       ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0 &&
                       (size_t)4 * 32 * MR * (TWN == 1 ? TW + 4 : TW + 8) * sizeof(float) <= lds;
-  hipLaunchKernelGGL((conv3x3_bx3_kernel<MR, TWN, KH, KW, SW, SH>), dim3((unsigned)blocks), dim3(256), lds, s, x, wt, bias, residual, y,
-                     d, tiles_w, tiles_h, co_tiles, patch_at, vec_out);
+  hipLaunchKernelGGL((conv3x3_bx3_kernel<MR, TWN, KH, KW, SW, SH, H2>), dim3((unsigned)blocks), dim3(256), lds, s, x, wt, bias, residual, y,
+                     d, tiles_w, tiles_h, co_tiles, patch_at, vec_out, amax_x);
   return dlio_check_launch();
 }
 
@@ -1609,6 +1640,60 @@ extern "C" int dlio_conv_bx3_fwd_taps(const float* x, const void* wt, const floa
   else BX3_TAPS(1, 2)
   else BX3_TAPS(1, 1)
 #undef BX3_TAPS
+  dlio_prof_end(3, s);
+  return rc;
+}
+
+/* The strided / small-tap-window launches above on the two-piece fp16 split (conv3x3_bx3_kernel<.., H2>): *amax_x = the largest
+ * magnitude of x (left on the device by its producer), wt from dlio_conv_h2_prep(taps = KH * KW, mode).  Layers with more than
+ * 32 output channels (else DLIO_EUNSUP: the three-piece launch takes them). */
+extern "C" int dlio_conv_h2_fwd_strided(const float* x, const float* amax_x, const void* wt, const float* bias,
+                                        const float* residual, float* y, const DlioConvDesc* dp, dlio_stream_t stream) {
+  if (!x || !amax_x || !wt || !y || !dp) return DLIO_EINVAL;
+  const DlioConvDesc& d = *dp;
+  const bool s35 = d.KH == 3 && d.KW == 5 && d.SH == 1 && d.SW == 2;
+  const bool s33 = d.KH == 3 && d.KW == 3 && d.SH == 2 && d.SW == 2;
+  if ((!s35 && !s33) || d.Cout <= 32) return DLIO_EUNSUP;
+  if (d.N <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.H <= 0 || d.W <= 0 || d.PH < 0 || d.PW < 0) return DLIO_EINVAL;
+  if (d.OH != (d.H + 2 * d.PH - d.KH) / d.SH + 1 || d.OW != (d.W + 2 * d.PW - d.KW) / d.SW + 1 || d.OH < 1 || d.OW < 1)
+    return DLIO_EINVAL;
+  hipStream_t s = as_stream(stream);
+  const double flops = 2.0 * d.N * (double)d.OH * d.OW * d.Cout * (double)d.Cin * d.KH * d.KW;
+  const double bytes = 4.0 * d.N * ((double)d.Cin * d.H * d.W + (double)d.Cout * d.OH * d.OW * (residual ? 2.0 : 1.0));
+  dlio_prof_begin(3, s, flops, bytes);
+  const __bf16* w = reinterpret_cast<const __bf16*>(wt);
+  const int rc = s33 ? launch_bx3<2, 1, 3, 3, 2, 2, true>(x, w, bias, residual, y, d, s, amax_x)
+                     : launch_bx3<2, 1, 3, 5, 2, 1, true>(x, w, bias, residual, y, d, s, amax_x);
+  dlio_prof_end(3, s);
+  return rc;
+}
+
+extern "C" int dlio_conv_h2_fwd_taps(const float* x, const float* amax_x, const void* wt, const float* bias,
+                                     const float* residual, float* y, const DlioConvDesc* dp, dlio_stream_t stream) {
+  if (!x || !amax_x || !wt || !y || !dp) return DLIO_EINVAL;
+  const DlioConvDesc& d = *dp;
+  if (d.SH != 1 || d.SW != 1) return DLIO_EUNSUP;
+  if (d.N <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.H <= 0 || d.W <= 0 || d.PH < 0 || d.PW < 0 || d.OH < 1 || d.OW < 1)
+    return DLIO_EINVAL;
+  if (d.OH > d.H + 2 * d.PH || d.OW > d.W + 2 * d.PW) return DLIO_EINVAL;
+  hipStream_t s = as_stream(stream);
+  const double flops = 2.0 * d.N * (double)d.OH * d.OW * d.Cout * (double)d.Cin * d.KH * d.KW;
+  const double bytes = 4.0 * d.N * ((double)d.Cin * d.H * d.W + (double)d.Cout * d.OH * d.OW * (residual ? 2.0 : 1.0));
+  const __bf16* w = reinterpret_cast<const __bf16*>(wt);
+  const bool wide = d.OW >= 48;
+  int rc = DLIO_EUNSUP;
+  dlio_prof_begin(3, s, flops, bytes);
+#define H2_TAPS(kh, kw)                                                                         \
+  if (d.KH == kh && d.KW == kw)                                                                 \
+    rc = wide ? launch_bx3<2, 2, kh, kw, 1, 1, true>(x, w, bias, residual, y, d, s, amax_x)     \
+              : launch_bx3<2, 1, kh, kw, 1, 1, true>(x, w, bias, residual, y, d, s, amax_x);
+  H2_TAPS(3, 3)
+  else H2_TAPS(3, 2)
+  else H2_TAPS(2, 2)
+  else H2_TAPS(2, 1)
+  else H2_TAPS(1, 2)
+  else H2_TAPS(1, 1)
+#undef H2_TAPS
   dlio_prof_end(3, s);
   return rc;
 }

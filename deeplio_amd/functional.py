@@ -356,8 +356,11 @@ class _CBR:
         # largest magnitude (three MFMAs per product instead of six)
         h2f = (bx3 and not stem and KH == 3 and training and x_amax is not None and in_aff is None and not conv_done
                and _CONV_H2_FWD[0] and ops._SYNC_BN[0] is None and x.is_cuda and ops.conv3x3_h2_ok(d))
+        # ... and the strided layers the split kernel takes (FlowNet conv2-6, ResNet's stage heads): the same with two pieces
+        h2s = (stem and training and x_amax is not None and _CONV_H2_FWD[0] and ops._SYNC_BN[0] is None and x.is_cuda
+               and Cout > 32 and not conv_done)
         d.x_amax = x_amax if h2f else None
-        if h2f:
+        if h2f or h2s:
             wt = ops.conv_h2_prepped(weight, 0)
         elif bx3:
             wt = ops.conv_bx3_prepped(weight, 0)
@@ -396,7 +399,11 @@ class _CBR:
             if need_dx and getattr(d, "wbx3_1", None) is None and not getattr(d, "bx3_1_ok", False) and plan is None:
                 d.wt2 = ops.conv2d_prepped(weight, 1)
             if plan is not None:               # tap-subset layouts of the phase-decomposed data gradient
-                d.wt_ph = {(it[0], it[1]): (ops.conv_bx3_prepped_phase(weight, d.SH, d.SW, it[0], it[1])
+                # (two fp16 pieces where the BatchNorm backward of this layer leaves the largest |dy|: any plain layer in
+                #  training, see _CBR.backward)
+                d.ph_h2 = (_CONV_H2_FWD[0] and want_amax and ops._SYNC_BN[0] is None and not pre_relu and Cin > 32)
+                d.wt_ph = {(it[0], it[1]): ((ops.conv_h2_prepped_phase if d.ph_h2 else ops.conv_bx3_prepped_phase)(
+                                                weight, d.SH, d.SW, it[0], it[1])
                                             if _phase_on_bx3(d, it[2], it[3]) else
                                             ops.conv2d_prepped_phase(weight, d.SH, d.SW, it[0], it[1]))
                            for it in plan if it is not None}
@@ -404,6 +411,8 @@ class _CBR:
             pass                 # raw already holds this layer's output (fused Fire expand pair, dlio_fire_expand_fwd)
         elif h2f:
             ops.conv3x3_h2_fwd(x, x_amax, wt, bias, raw, d)
+        elif h2s:
+            ops.conv_h2_strided_fwd(x, x_amax, wt, bias, raw, d)
         elif stem:
             ops.conv3x5s2_bx3_fwd(x, wt, bias, raw, d)
         elif bx3 and KH == 1:
@@ -490,12 +499,14 @@ class _CBR:
             pass
         elif (training and _BN_SMALL[0] and not pre_relu and dy.is_cuda and ops.bn_coop_ok(N, OHW) and pooled is None
               and _coop_pays(N, Cout, OHW)):
-            if amax is None and ((need_dx and getattr(d, "wh2_1", None) is not None) or getattr(d, "x_amax", None) is not None):
+            if amax is None and ((need_dx and (getattr(d, "wh2_1", None) is not None or getattr(d, "ph_h2", False)))
+                                 or getattr(d, "x_amax", None) is not None):
                 amax = ops.amax_slot(dy.device)          # the data / weight gradient runs on two fp16 pieces: it wants the largest |draw|
             ops.bn_coop_bwd(dy, dy_ctot, dy_coff, raw, d.out_ctot, d.out_coff, prm, beta, None, draw, None, dgamma, dbeta,
                             None, None, acc_g, N, Cout, Cout, OHW, post_relu, amax_out=amax)
         elif (training and _BN_SMALL[0] and not pre_relu and dy.is_cuda and ops.bn_small_ok(N, OHW) and pooled is None):
-            if amax is None and _SMALL_H2[0] and ((need_dx and getattr(d, "wh2_1", None) is not None) or getattr(d, "x_amax", None) is not None):
+            if amax is None and _SMALL_H2[0] and ((need_dx and (getattr(d, "wh2_1", None) is not None or getattr(d, "ph_h2", False)))
+                                                  or getattr(d, "x_amax", None) is not None):
                 amax = ops.amax_slot(dy.device)
             ops.bn_small_bwd(dy, dy_ctot, dy_coff, raw, d.out_ctot, d.out_coff, prm, beta, None, draw, None, dgamma, dbeta,
                              None, None, acc_g, N, Cout, Cout, OHW, post_relu, amax_out=amax)
@@ -504,7 +515,8 @@ class _CBR:
             # activated tensor themselves (dlio_bn_bwd_pool), the pool's backward pass is not run
             ops.bn_bwd_pool(dy, pooled[0], raw, prm, beta, draw, pooled[1], dgamma, dbeta, accumulate=acc_g)
         elif _PLANE_BN[0]:
-            if amax is None and dy.is_cuda and training and (getattr(d, "wh2_1", None) is not None or getattr(d, "x_amax", None) is not None):
+            if amax is None and dy.is_cuda and training and (getattr(d, "wh2_1", None) is not None or getattr(d, "x_amax", None) is not None
+                                                              or getattr(d, "ph_h2", False)):
                 amax = ops.amax_slot(dy.device)          # the data / weight gradient runs on two fp16 pieces
             ops.bn_bwd_fused(dy, dy_ctot, dy_coff, raw, d.out_ctot, d.out_coff, prm, beta, draw, Cout, 0, N,
                              Cout, OHW, pre_relu, post_relu, training, dgamma, dbeta, accumulate=acc_g, amax_out=amax)
@@ -588,7 +600,7 @@ def conv_dgrad(dy, weight, d, dx, dx_ctot, dx_coff, residual=None, r_ctot=0, r_c
     else:
         # strided conv: insert the stride's zeros into dy and run the stride-1 MFMA kernel on it
         # (SH*SW x the minimal MFMA work, still ~50x faster than a scalar gather)
-        if _DGRAD_PHASES[0] and _dgrad_phases(dy, weight, d, dx, dx_ctot, dx_coff, residual, r_ctot, r_coff):
+        if _DGRAD_PHASES[0] and _dgrad_phases(dy, weight, d, dx, dx_ctot, dx_coff, residual, r_ctot, r_coff, amax=amax):
             return dx
         HU = (d.OH - 1) * d.SH + 1 + (d.H + 2 * d.PH - d.KH) % d.SH
         WU = (d.OW - 1) * d.SW + 1 + (d.W + 2 * d.PW - d.KW) % d.SW
@@ -751,7 +763,7 @@ def _phase_plan(d):
     return plan
 
 
-def _dgrad_phases(dy, weight, d, dx, dx_ctot, dx_coff, residual, r_ctot, r_coff):
+def _dgrad_phases(dy, weight, d, dx, dx_ctot, dx_coff, residual, r_ctot, r_coff, amax=None):
     """strided data gradient as SH*SW stride-1 convolutions of dy, one per input phase, woven
     together by dlio_phase_interleave2d: no MFMA work on inserted zeros (the zero-upsample route
     does SH*SW x the minimum).  Returns False when the plan does not exist."""
@@ -767,13 +779,18 @@ def _dgrad_phases(dy, weight, d, dx, dx_ctot, dx_coff, residual, r_ctot, r_coff)
             continue
         rh, rw, Mh, Mw, pt, pl, Hp, Wp = item
         bx3 = _phase_on_bx3(d, Mh, Mw)
+        ph_h2 = bx3 and getattr(d, "ph_h2", False)          # (the stash then holds two-piece layouts)
+        h2 = ph_h2 and amax is not None and stash is not None
         wt = stash.get((rh, rw)) if stash else None
-        if wt is None:                      # direct call (no forward ran on this descriptor)
+        if wt is None or (ph_h2 and not h2):
+            # direct call (no forward ran on this descriptor) / a two-piece layout whose operand came without its magnitude
             wt = (ops.conv_bx3_prepped_phase if bx3 else ops.conv2d_prepped_phase)(weight, d.SH, d.SW, rh, rw, cache=False)
         out = _new((N, Cin, Hp, Wp), dy)
         g = ops.conv_desc(N, Cout, d.OH, d.OW, Cin, Mh, Mw, 1, 1, pt, pl, OH=Hp, OW=Wp, in_ctot=Cout, in_coff=0,
                           out_ctot=Cin, out_coff=0)
-        if bx3:
+        if h2:
+            ops.conv_h2_taps_fwd(dy, amax, wt, None, out, g)
+        elif bx3:
             ops.conv_bx3_taps_fwd(dy, wt, None, out, g)
         else:
             ops.conv2d_fwd(dy, wt, None, out, g)

@@ -400,6 +400,47 @@ def conv_bx3_prepped_phase(w, SH, SW, rh, rw, cache=True):
     return out
 
 
+def conv_h2_prepped_phase(w, SH, SW, rh, rw, cache=True):
+    """two-piece fp16 data-gradient (mode 1) layout of w[:, :, rh::SH, rw::SW] (dlio_conv_h2_fwd_taps)"""
+    Cout, Cin, KH, KW = w.shape
+    Mh, Mw = len(range(rh, KH, SH)), len(range(rw, KW, SW))
+    nfl = lib.dlio_conv_h2_prep_floats(Cout, Cin, Mh * Mw, 1)
+    e = None
+    if cache:
+        key = ("h2", w.data_ptr(), tuple(w.shape), SH, SW, rh, rw)
+        e = _PHASE_W.get(key)
+        if e is None or e["ref"]() is not w:
+            e = _PHASE_W[key] = dict(ref=_weakref.ref(w), epoch=-1, version=-1,
+                                     out=torch.empty(nfl, dtype=torch.float32, device=w.device))
+            for k in [k for k, v in _PHASE_W.items() if v["ref"]() is None]:
+                del _PHASE_W[k]
+        if e["epoch"] == _PREP.epoch and e["version"] == w._version:
+            return e["out"]
+        out = e["out"]
+    else:
+        out = torch.empty(nfl, dtype=torch.float32, device=w.device)
+    sub = w.detach()[:, :, rh::SH, rw::SW].contiguous()
+    check(lib.dlio_conv_h2_prep(_ptr(sub), _ptr(out), Cout, Cin, Mh * Mw, 1, _stream()), "conv_h2_prep")
+    sub.record_stream(torch.cuda.current_stream())
+    if e is not None:
+        e.update(epoch=_PREP.epoch, version=w._version)
+    return out
+
+
+def conv_h2_strided_fwd(x, amax_x, wt, bias, y, desc, residual=None):
+    """3x5 stride (1, 2) / 3x3 stride (2, 2) forward on the two-piece fp16 split (more than 32 output channels)"""
+    check(lib.dlio_conv_h2_fwd_strided(_ptr(x), _ptr(amax_x), _ptr(wt), _ptr(bias), _ptr(residual), _ptr(y), C.byref(desc),
+                                       _stream()), "conv_h2_fwd_strided")
+    return y
+
+
+def conv_h2_taps_fwd(x, amax_x, wt, bias, y, desc, residual=None):
+    """conv_bx3_taps_fwd on the two-piece fp16 split"""
+    check(lib.dlio_conv_h2_fwd_taps(_ptr(x), _ptr(amax_x), _ptr(wt), _ptr(bias), _ptr(residual), _ptr(y), C.byref(desc),
+                                    _stream()), "conv_h2_fwd_taps")
+    return y
+
+
 def conv_bx3_taps_fwd(x, wt, bias, y, desc, residual=None):
     """stride-1 convolution with a small tap window and an explicit output extent on the split-bf16 kernel"""
     check(lib.dlio_conv_bx3_fwd_taps(_ptr(x), _ptr(wt), _ptr(bias), _ptr(residual), _ptr(y), C.byref(desc), _stream()),

@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 233
+#define DLIO_ABI_VERSION 234
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);
@@ -153,6 +153,14 @@ int dlio_conv1x1_bx3_fwd_aff(const float* x, const void* wt, const float* bias, 
  * DLIO_EUNSUP for other tap windows or strides (use dlio_conv2d_fwd). */
 int dlio_conv_bx3_fwd_taps(const float* x, const void* wt, const float* bias, const float* residual, float* y,
                            const DlioConvDesc* desc, dlio_stream_t stream);
+/* dlio_conv3x5s2_bx3_fwd / dlio_conv_bx3_fwd_taps on the two-piece fp16 split: *amax_x = the largest |x| (one device float
+ * left by the producer of x: amax_out of the BatchNorm launches), wt from dlio_conv_h2_prep(taps = KH * KW, mode); layers with
+ * more than 32 output channels, else DLIO_EUNSUP.  FlowNet conv2-6 (lidar_feat_nets.py:248-257), ResNet's strided stage heads
+ * (resnet.py:27-47) and the phases of their data gradients. */
+int dlio_conv_h2_fwd_strided(const float* x, const float* amax_x, const void* wt, const float* bias,
+                             const float* residual, float* y, const DlioConvDesc* d, dlio_stream_t stream);
+int dlio_conv_h2_fwd_taps(const float* x, const float* amax_x, const void* wt, const float* bias,
+                          const float* residual, float* y, const DlioConvDesc* d, dlio_stream_t stream);
 /* the split-bf16 kernel on strided layers, forward: 3x5 taps with stride (1, 2) (the PointSeg stem, pointseg_net.py:18-20;
  * FlowNet conv2 / conv3) and 3x3 taps with stride (2, 2) (FlowNet conv4-6, lidar_feat_nets.py:252-257; ResNet layer2-4,
  * resnet.py:27-47); weights from dlio_conv_bx3_prep(taps = KH * KW, mode 0); DLIO_EUNSUP for anything else */

@@ -1830,3 +1830,57 @@ def test_batchnorm_and_block_tail_leave_the_largest_magnitude_they_write(dev, ca
     if x.numel() % 4 == 0:
         check(lambda y, am: ops.ew_binary(x, res, 3, out=y, amax_out=am))
     assert ops.bn_coop_errors() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 64, 128, 16, 70, 3, 5, 1, 2, 1, 2), (2, 128, 256, 12, 40, 3, 3, 2, 2, 1, 1), (1, 40, 70, 9, 33, 3, 3, 2, 2, 1, 1),
+                                  (3, 48, 64, 8, 64, 3, 5, 1, 2, 1, 2)])
+@pytest.mark.parametrize("scale", [1e-4, 3.0])
+def test_strided_conv_two_piece_fp16_forward(dev, case, scale):
+    """dlio_conv_h2_fwd_strided (conv3x3_bx3_kernel<.., H2>): the 3x5 stride (1, 2) and 3x3 stride (2, 2) forward launches of
+    FlowNet conv2-6 / ResNet's stage heads (lidar_feat_nets.py:248-257, resnet.py:27-47) on two fp16 pieces of x 2^k, k from
+    the operand's largest magnitude: against fp64 at the three-piece kernel's level, operands at activation and gradient
+    magnitudes with a 1e3 outlier, bias, and an amax that is a loose bound (x 300)"""
+    from deeplio_amd import ops
+    N, Cin, Cout, H, W, KH, KW, SH, SW, PH, PW = case
+    g = _g(111)
+    x = torch.randn(N, Cin, H, W, generator=g) * scale
+    x[0, 0, 0, 0] = 1e3 * scale
+    w = torch.randn(Cout, Cin, KH, KW, generator=g) / math.sqrt(Cin * KH * KW)
+    b = torch.randn(Cout, generator=g) * 0.1 * scale
+    ref = F.conv2d(x.double(), w.double(), b.double(), (SH, SW), (PH, PW))
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+    d = ops.conv_desc(N, Cin, H, W, Cout, KH, KW, SH, SW, PH, PW)
+    wt = ops.conv_h2_prepped(wd, 0)
+    for loose in (1.0, 300.0):
+        am = (xd.abs().max() * loose).reshape(1).contiguous()
+        y = torch.empty(N, Cout, d.OH, d.OW, device=dev)
+        ops.conv_h2_strided_fwd(xd, am, wt, bd, y, d)
+        assert rel_err(y, ref) < 2e-6, (loose, rel_err(y, ref))
+    y3 = torch.empty_like(y)
+    ops.conv3x5s2_bx3_fwd(xd, ops.conv_bx3_prepped(wd, 0), bd, y3, d)
+    assert rel_err(y, y3) < 3e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,extra", [((3, 3), (2, 1)), ((2, 2), (1, 1)), ((3, 2), (0, 1)), ((1, 2), (0, 1)), ((2, 1), (1, 0)), ((1, 1), (0, 0))])
+def test_conv_taps_two_piece_fp16_with_explicit_output_extent(dev, k, extra):
+    """dlio_conv_h2_fwd_taps: the stride-1 phases of a strided layer's data gradient (functional._dgrad_phases) on two fp16
+    pieces: small tap windows, asymmetric padding by output extent, narrow and wide tiles, against fp64"""
+    from deeplio_amd import ops
+    g = _g(112)
+    KH, KW = k
+    for (N, Cin, Cout, H, W) in ((2, 128, 64, 9, 37), (1, 70, 96, 6, 70)):
+        pt, pl = KH - 1, KW - 1
+        OH, OW = H + pt - extra[0], W + pl - extra[1]
+        x = torch.randn(N, Cin, H, W, generator=g) * 1e-4
+        w = torch.randn(Cout, Cin, KH, KW, generator=g) / math.sqrt(Cin * KH * KW)
+        xp = F.pad(x.double(), (pl, KW, pt, KH))
+        ref = F.conv2d(xp, w.double())[:, :, :OH, :OW]
+        xd, wd = x.to(dev), w.to(dev)
+        d = ops.conv_desc(N, Cin, H, W, Cout, KH, KW, 1, 1, pt, pl, OH=OH, OW=OW)
+        wt = torch.empty(ops.lib.dlio_conv_h2_prep_floats(Cout, Cin, KH * KW, 0), dtype=torch.float32, device=dev)
+        ops.check(ops.lib.dlio_conv_h2_prep(ops._ptr(wd), ops._ptr(wt), Cout, Cin, KH * KW, 0, ops._stream()), "prep")
+        y = torch.empty(N, Cout, OH, OW, device=dev)
+        ops.conv_h2_taps_fwd(xd, xd.abs().max().reshape(1).contiguous(), wt, None, y, d)
+        assert rel_err(y, ref) < 2e-6, rel_err(y, ref)
