@@ -437,11 +437,13 @@ def main():
             if name == "batchnorm":
                 out["bytes_are"] = ("what the launches move by construction: the one-launch kernels (csrc/bn_small.hip: a "
                                     "channel's planes held in registers, partial sums exchanged between workgroups) read "
-                                    "every operand once -- forward 2-3 passes over the conv output (read, residual, write; "
-                                    "listed under 'forward apply'), backward 3 (dy, x, dx; under 'backward apply'); the "
-                                    "two-launch kernels that remain (statistics of apply-on-load layers, the stem behind "
-                                    "its pool) 1 + 2-3 and 2 + 3; SURVEY 8(d)'s fused minimum counts 0 bytes for BatchNorm, "
-                                    "i.e. all of this is overhead relative to it")
+                                    "every operand once -- backward 3 passes (dy, x, dx; under 'backward apply'), forward on "
+                                    "the small maps 2-3 (read, residual, write; under 'forward apply'); the expand layers of "
+                                    "fire_blk1-3 take their statistics from the convolution's epilogue and apply in ONE streaming "
+                                    "pass (csrc/bn_stream.hip: read, residual, write -- or, in front of SELayer + pool, write only "
+                                    "the pooled tensor); the two-launch kernels that remain (squeeze layers, the stem behind its "
+                                    "pool) 1 + 2-3 and 2 + 3; SURVEY 8(d)'s fused minimum counts 0 bytes for BatchNorm, i.e. all "
+                                    "of this is overhead relative to it")
                 if "sub" in v:
                     out["kernels"] = {k: {"GB/s": round(rate(sv, "hbm"), 1), "ms_per_step": round(sv["ms"] / steps, 3),
                                           "launches_per_step": sv["launches"] / steps} for k, sv in v["sub"].items()}
@@ -450,7 +452,7 @@ def main():
         # PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction of
         # the guide applied): collected by tools/pmc_traffic.py, committed under profiles/
         pmc = None
-        for fn in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for fn in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             path = os.path.join(ROOT, "profiles", fn)
             if os.path.exists(path) and B == 8 and S == 2 and headline:
                 with open(path) as f:

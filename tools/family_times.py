@@ -18,6 +18,7 @@ FAMILIES = [
     ("other wgrad + slab reduce", ("conv_wgrad_kernel", "wgrad_reduce_kernel")),
     ("BN fwd statistics", ("chan_reduce_kernel<0", "bn16_reduce_kernel<0", "fire_stats_finalize", "chan_stats_finalize")),
     ("BN fwd apply", ("bn_plane_apply_kernel", "bn_apply_kernel", "bn16_plane_apply", "bn_split16_kernel")),
+    ("BN fwd streaming apply (statistics from the conv epilogue; + max-pool)", ("bn_aff_apply_kernel", "bn_aff_pool_kernel")),
     ("BN fwd, one launch (statistics + apply, one read)", ("bn_coop_fwd_kernel", "bn_small_fwd_kernel")),
     ("BN bwd, one launch (reductions + apply, one read)", ("bn_coop_bwd_kernel", "bn_small_bwd_kernel")),
     ("BN bwd reduce", ("chan_reduce_kernel<1", "chan_reduce_kernel<2", "bn16_reduce_kernel<1")),

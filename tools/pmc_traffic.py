@@ -23,7 +23,7 @@ FAMILIES = {
     "wgrad3x3": ("wgrad3_kernel", "conv_wgrad_adirect"),
     "wgrad1x1": ("wgrad1x1_direct",),
     "wgrad_reduce": ("wgrad_reduce",),
-    "batchnorm": ("chan_reduce", "chan_stats", "bn_apply", "bn_bwd", "bn_plane", "bn_coop_", "bn_small_", "bn_split16", "bn_pool_", "fire_stats_finalize"),
+    "batchnorm": ("chan_reduce", "chan_stats", "bn_apply", "bn_bwd", "bn_plane", "bn_coop_", "bn_small_", "bn_split16", "bn_pool_", "fire_stats_finalize", "bn_aff_"),
     "pool_se": ("maxpool", "gap_", "chan_scale", "pool3", "plane_dot"),
 }
 
