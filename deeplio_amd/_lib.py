@@ -141,6 +141,7 @@ SIGNATURES = {
     "dlio_linear_bwd_data_ws_bytes": (_sz, [_i, _i, _i]),
     "dlio_linear_bwd_data": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "dlio_linear_bwd_weight": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _p]),
+    "dlio_abs_max": (_i, [_p, _i64, _p, _p]),
     "dlio_ew_binary": (_i, [_p, _p, _p, _i64, _i, _p, _p]),
     "dlio_seg_sum_fwd": (_i, [_p, _p, _i, _i, _i, _p]),
     "dlio_seg_sum_bwd": (_i, [_p, _p, _i, _i, _i, _p]),

@@ -830,6 +830,34 @@ extern "C" int dlio_seg_sum_bwd(const float* dy, float* dx, int groups, int rows
   return dlio_check_launch();
 }
 
+// largest |x| of a tensor -> *amax_out (zero before the launch): the operand scale of a two-piece fp16 consumer whose input
+// has no producer kernel to leave it (the stem's range images)
+__global__ __launch_bounds__(256) void abs_max_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ amax_out) {
+  __shared__ unsigned s_amax;
+  float amax = 0.f;
+  const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * blockDim.x;
+  const bool al = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+  if (al) {
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += 4 * stride) {
+      float4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = x4[i + k * stride < n4 ? i + k * stride : n4 - 1];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) amax = amax4(amax, v[k].x, v[k].y, v[k].z, v[k].w);
+    }
+  }
+  for (int64_t i = (al ? (n4 << 2) : 0) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride)
+    amax = fmaxf(amax, fabsf(x[i]));
+  block_amax_commit(amax, amax_out, &s_amax);
+}
+
+extern "C" int dlio_abs_max(const float* x, int64_t n, float* amax_out, dlio_stream_t stream) {
+  if (!x || !amax_out || n <= 0) return DLIO_EINVAL;
+  hipLaunchKernelGGL(abs_max_kernel, dim3(ew_grid(n / 16 + 1, 256)), dim3(256), 0, as_stream(stream), x, n, amax_out);
+  return dlio_check_launch();
+}
+
 extern "C" int dlio_ew_scale(const float* a, float alpha, float* y, int64_t n,
                              dlio_stream_t stream) {
   if (!a || !y || n <= 0) return DLIO_EINVAL;

@@ -1152,6 +1152,14 @@ def linear_bwd_weight(dz, x, M, N_, K, dw=None, db=None, want_bias=True, lddz=No
     return dw, db
 
 
+def abs_max(x, keep=True):
+    """-> a one-float tensor with max |x| (x contiguous): the operand scale of a two-piece convolution over a tensor that
+    comes without one"""
+    slot = amax_slot_kept(x.device) if keep else amax_slot(x.device)
+    check(lib.dlio_abs_max(_ptr(x), x.numel(), _ptr(slot), _stream()), "abs_max")
+    return slot
+
+
 def ew_binary(a, b, op, out=None, amax_out=None):
     """amax_out: a zeroed one-float tensor that receives max |out| (tensors of a multiple of four elements, 16-byte aligned)"""
     if out is None:

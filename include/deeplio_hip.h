@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 234
+#define DLIO_ABI_VERSION 235
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);
@@ -429,6 +429,9 @@ int dlio_linear_bwd_weight(const float* dz, int lddz, const float* x, int ldx, f
 
 /* ---- elementwise helpers ---------------------------------------------- */
 /* op: 0 a+b, 1 a-b, 2 a*b, 3 relu(a+b) (BasicBlock tail) */
+/* *amax_out (zero before the launch) = max |x|: the operand scale of a two-piece fp16 convolution for a tensor no kernel of
+ * ours produced (the stem's input images) */
+int dlio_abs_max(const float* x, int64_t n, float* amax_out, dlio_stream_t stream);
 int dlio_ew_binary(const float* a, const float* b, float* y, int64_t n, int op, float* amax_out,
                    dlio_stream_t stream);
 /* torch.sum(y, dim=0) per IMU window (imu_feat_nets.py:49): y[g][c] = sum_r x[g][r][c];

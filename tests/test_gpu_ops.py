@@ -1884,3 +1884,16 @@ def test_conv_taps_two_piece_fp16_with_explicit_output_extent(dev, k, extra):
         y = torch.empty(N, Cout, OH, OW, device=dev)
         ops.conv_h2_taps_fwd(xd, xd.abs().max().reshape(1).contiguous(), wt, None, y, d)
         assert rel_err(y, ref) < 2e-6, rel_err(y, ref)
+
+
+@pytest.mark.gpu
+def test_abs_max_of_a_tensor(dev):
+    """dlio_abs_max: the operand scale of a two-piece convolution for a tensor that comes without one (exact, any length,
+    unaligned views)"""
+    from deeplio_amd import ops
+    g = _g(121)
+    for n in (1, 5, 4096, 1 << 20, (1 << 20) + 3):
+        x = torch.randn(n + 1, generator=g).to(dev)
+        for v in (x[:n], x[1:]):
+            v = v if v.is_contiguous() else v.contiguous()
+            assert float(ops.abs_max(v)) == float(v.abs().max())
