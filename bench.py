@@ -173,12 +173,17 @@ _WGRAD_FORK_DEFAULT = True
 
 def set_overlap(model, on):
     from deeplio_amd import functional as Fh
+    from deeplio_amd import ops
     global _WGRAD_FORK_DEFAULT
     if not on:
         _WGRAD_FORK_DEFAULT = Fh._WGRAD_FORK[0]
         Fh.set_wgrad_stream(False)
+        # one stream: a cooperative BatchNorm launch has the chip to itself -- its grid is sized for all of it (the default
+        # 5 / 8 leaves room for the neighbours' kernels of the five-stream step; DLIO_BN_COOP_CUS overrides both)
+        ops.bn_coop_set_cus(1 << 20)
     else:
         Fh.set_wgrad_stream(_WGRAD_FORK_DEFAULT)
+        ops.bn_coop_set_cus(0)
     for m in model.modules():
         if hasattr(m, "two_streams"):
             m.two_streams = on

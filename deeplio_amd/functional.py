@@ -253,7 +253,7 @@ class DeferredBranchFn(Function):
         _want_join()
         return None, None, None
 
-    LATE = False
+    LATE = os.environ.get("DLIO_IMU_BWD_LATE", "0") != "0"
     _PENDING = []
 
     @staticmethod

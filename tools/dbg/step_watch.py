@@ -29,4 +29,4 @@ for i in range(0, n, every):
         print("step", i, "%.2f ms" % dt, "loss %.6f" % float(loss), "errors", err, [e[1][:4].tolist() for e in ops._COOP_WS.values()], flush=True)
     if err:
         ops.bn_coop_check(fallback=False)
-print("avg %.3f ms/step  chunks with errors %d" % (tot / max(cnt, 1), nerr))
+print("avg %.3f ms/step  chunks with errors %d  peak memory %.2f GB" % (tot / max(cnt, 1), nerr, torch.cuda.max_memory_allocated() / 1e9))
