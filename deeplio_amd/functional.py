@@ -253,7 +253,7 @@ class DeferredBranchFn(Function):
         _want_join()
         return None, None, None
 
-    LATE = os.environ.get("DLIO_IMU_BWD_LATE", "0") != "0"
+    LATE = False                # (round 5 re-measured: 19.8 against 19.2 ms per step with the branch issued last)
     _PENDING = []
 
     @staticmethod
@@ -638,7 +638,7 @@ _POOL_FUSE = [os.environ.get("DLIO_POOL_FUSE", "1") != "0"]
 # workgroups (tools/bench_bn_squeeze.py: 26-31 us against 32-48)
 # ... alone; inside the five-stream step the two choices are equal within the run-to-run noise (19.1-19.4 ms either way), so the
 # default keeps the launch count down: 0 = cooperative wherever the geometry allows
-_BN_COOP_MIN_BYTES = [int(os.environ.get("DLIO_BN_COOP_MIN_MB", "0")) << 20]
+_BN_COOP_MIN_BYTES = [0]            # (a module switch for tools / ablations: bytes per operand)
 
 
 def _coop_pays(N, C, HW):
