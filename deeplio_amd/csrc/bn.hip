@@ -719,7 +719,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_strip(
         const float gg = ((xe[k] - mu) * sc + be > 0.f) ? G[q][k] : 0.f;
         oe[k] = sc * (gg - mg - xh * mgx);
       }
-      *reinterpret_cast<float4*>(dx + ((size_t)pl * H + ih0 + q) * W + 4 * b) = make_float4(oe[0], oe[1], oe[2], oe[3]);
+      st4<32>(dx + ((size_t)pl * H + ih0 + q) * W + 4 * b, make_float4(oe[0], oe[1], oe[2], oe[3]));
     }
   }
 }

@@ -432,7 +432,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu((T == 256 && 
         if (raff) re[k] = fmaxf((re[k] - rmu) * rsc + rsh, 0.f);
         e[k] = o + re[k];
       }
-      *reinterpret_cast<float4*>(yp + 4 * (threadIdx.x + T * j)) = make_float4(e[0], e[1], e[2], e[3]);
+      st4<16>(yp + 4 * (threadIdx.x + T * j), make_float4(e[0], e[1], e[2], e[3]));
       gs += (double)((e[0] + e[1]) + (e[2] + e[3]));
       amax = amax4(amax, e[0], e[1], e[2], e[3]);
     }
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu((T == 256 && 
       float4 o;
       o.x = sc * (g[j].x - mg - xh[j].x * mgx); o.y = sc * (g[j].y - mg - xh[j].y * mgx);
       o.z = sc * (g[j].z - mg - xh[j].z * mgx); o.w = sc * (g[j].w - mg - xh[j].w * mgx);
-      *reinterpret_cast<float4*>(op + EO(j)) = o;
+      st4<8>(op + EO(j), o);
       amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
     }
     coop_depart(part, sync, c, NP, 0, C, !PIPE && !loop);

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void bn_aff_apply_kernel(
         if (raff) re[k] = act1(re[k], rmu, rsc, rsh);
         e[k] = o + re[k];
       }
-      yp[i + u * 256] = make_float4(e[0], e[1], e[2], e[3]);
+      st4<16>(reinterpret_cast<float*>(yp + i + u * 256), make_float4(e[0], e[1], e[2], e[3]));
       gs += (double)((e[0] + e[1]) + (e[2] + e[3]));
     }
   }

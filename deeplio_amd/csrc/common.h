@@ -101,6 +101,20 @@ __device__ __forceinline__ void block_amax_commit(float amax, float* amax_out, u
       atomicMax(reinterpret_cast<unsigned*>(amax_out), w);
   }
 }
+// Streaming (non-temporal) 16-byte store for outputs no later launch finds in L2 anyway (activations of 100+ MB):
+// DLIO_NT_SITES is a bit set of the kernels that use it (A/B by tools/variant_lib.py), 0 = plain stores everywhere.
+#ifndef DLIO_NT_SITES
+#define DLIO_NT_SITES 59
+#endif
+template <int SITE>
+__device__ __forceinline__ void st4(float* p, float4 v) {
+  if constexpr ((DLIO_NT_SITES & SITE) != 0) {
+    f32x4 o = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(p));
+  } else {
+    *reinterpret_cast<float4*>(p) = v;
+  }
+}
 __device__ __forceinline__ float amax4(float m, float a, float b, float c, float d) {
   return fmaxf(m, fmaxf(fmaxf(fabsf(a), fabsf(b)), fmaxf(fabsf(c), fabsf(d))));
 }

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
         const float4 rv = *reinterpret_cast<const float4*>(rrow + (size_t)co * ohw + 4 * q);
         v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
       }
-      *reinterpret_cast<float4*>(yrow + (size_t)co * ohw + 4 * q) = v;
+      st4<4>(yrow + (size_t)co * ohw + 4 * q, v);
     }
     return;
   }
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bx3_alds_kernel(
         const float4 rv = *reinterpret_cast<const float4*>(rrow + (size_t)co * ohw + 4 * q);
         v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
       }
-      *reinterpret_cast<float4*>(yrow + (size_t)co * ohw + 4 * q) = v;
+      st4<4>(yrow + (size_t)co * ohw + 4 * q, v);
     }
     return;
   }
@@ -948,7 +948,7 @@ __global__ __launch_bounds__(512) void conv3x3_bx3_pc_kernel(
                 const float4 rv = *reinterpret_cast<const float4*>(rb + (size_t)co * ohw + 32 * t);
                 o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
               }
-              *reinterpret_cast<float4*>(yb + (size_t)co * ohw + 32 * t) = o;
+              st4<4>(yb + (size_t)co * ohw + 32 * t, o);
             }
           }
     }
@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bx3_kernel(
         float4 o = H2 ? make_float4(acc[m][0][r] * isc + bv, acc[m][1][r] * isc + bv, acc[m][2][r] * isc + bv, acc[m][3][r] * isc + bv)
                       : make_float4(acc[m][0][r] + bv, acc[m][1][r] + bv, acc[m][2][r] + bv, acc[m][3][r] + bv);
         if (rb) { o.x += rv[r].x; o.y += rv[r].y; o.z += rv[r].z; o.w += rv[r].w; }
-        *reinterpret_cast<float4*>(yb + (size_t)co * plane) = o;
+        st4<2>(yb + (size_t)co * plane, o);
       }
     }
   }

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void fire_expand_fwd_kernel(
             const float bv = bias ? bias[co] : 0.f;
             if constexpr (H2) { a0 *= isc[set]; a1 *= isc[set]; a2 *= isc[set]; a3 *= isc[set]; }
             a0 += bv; a1 += bv; a2 += bv; a3 += bv;
-            *reinterpret_cast<float4*>(yb + ((size_t)(set == 0 ? 0 : E) + co) * hw + 32 * t) = make_float4(a0, a1, a2, a3);
+            st4<1>(yb + ((size_t)(set == 0 ? 0 : E) + co) * hw + 32 * t, make_float4(a0, a1, a2, a3));
             if constexpr (STATS) {
               st1[set][m][rq] += (a0 + a1) + (a2 + a3);
               st2[set][m][rq] += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);

@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void maxpool3_bwd_strip(const float* __restric
       float4 o = make_float4(G[r][0], G[r][1], G[r][2], G[r][3]);
       if (xs) { o.x *= s; o.y *= s; o.z *= s; o.w *= s; }
       if (xadd) { o.x += a; o.y += a; o.z += a; o.w += a; }
-      *reinterpret_cast<float4*>(dx + ((size_t)pl * H + ih0 + r) * W + 4 * b) = o;
+      st4<32>(dx + ((size_t)pl * H + ih0 + r) * W + 4 * b, o);
     }
   }
 }
