@@ -35,6 +35,7 @@ SIGNATURES = {
     "dlio_arch": (C.c_char_p, []),
     "dlio_build_probes": (_i, []),
     "dlio_strerror": (C.c_char_p, [_i]),
+    "dlio_streams_share_queue": (_i, [_p, _p, C.POINTER(_i)]),
     "dlio_last_hip_error_string": (C.c_char_p, []),
     "dlio_prof_enable": (_i, [_i]),
     "dlio_prof_sample": (_i, [_i]),

@@ -137,6 +137,52 @@ extern "C" int dlio_build_probes(void) {
   return ((DLIO_SPLIT_Q0) != 0 ? 1 : 0) | dlio_probe_bx3() | dlio_probe_wgrad() | dlio_probe_wgrad3() | dlio_probe_fire();
 }
 
+// ---- which HIP streams share a hardware queue -----------------------------------------------------------------------
+// The runtime serves all streams of a process from a small pool of hardware queues (4 by default); two streams on one queue run
+// their launches strictly one after the other.  The training step keeps four heavy streams (two encoders, their
+// weight-gradient companions) that must not share: +2 ms per step when any two of them do.  Which queue a stream gets
+// depends on what the process created before, so the host side probes it: a short launch on b, issued behind a spinning one on
+// a, finishes early exactly when the two streams have different queues.
+__global__ void spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+extern "C" int dlio_streams_share_queue(dlio_stream_t a, dlio_stream_t b, int* shared) {
+  if (!shared) return DLIO_EINVAL;
+  hipStream_t sa = as_stream(a), sb = as_stream(b);
+  if (sa == sb) { *shared = 1; return DLIO_OK; }
+  int dev = 0, khz = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) {
+    (void)hipGetLastError();
+    khz = 100000;
+  }
+  const long long long_ticks = (long long)khz * 150 / 1000, short_ticks = (long long)khz / 1000;     // 150 us, 1 us
+  hipEvent_t e0, ea, eb;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&ea) != hipSuccess || hipEventCreate(&eb) != hipSuccess)
+    return DLIO_ELAUNCH;
+  int votes = 0, rc = DLIO_OK;
+  for (int rep = 0; rep < 3 && rc == DLIO_OK; ++rep) {      // (rep 0 = warm-up: the first launch on a stream is slow)
+    (void)hipStreamSynchronize(sa);
+    (void)hipStreamSynchronize(sb);
+    (void)hipEventRecord(e0, sa);
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, sa, long_ticks);
+    (void)hipEventRecord(ea, sa);
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, sb, short_ticks);
+    (void)hipEventRecord(eb, sb);
+    rc = dlio_check_launch();
+    if (hipStreamSynchronize(sa) != hipSuccess || hipStreamSynchronize(sb) != hipSuccess) rc = DLIO_ELAUNCH;
+    float ta = 0.f, tb = 0.f;
+    if (rc == DLIO_OK && (hipEventElapsedTime(&ta, e0, ea) != hipSuccess || hipEventElapsedTime(&tb, e0, eb) != hipSuccess))
+      rc = DLIO_ELAUNCH;
+    if (rep > 0 && tb > 0.5f * ta) ++votes;
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
+  *shared = votes == 2;
+  return rc;
+}
+
 extern "C" const char* dlio_arch(void) { return "gfx950"; }
 extern "C" const char* dlio_strerror(int code) {
   switch (code) {

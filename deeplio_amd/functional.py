@@ -84,6 +84,69 @@ def aux_stream(device, name):
     return s
 
 
+_ASSIGNED = set()
+
+
+def assign_streams(device, force=False):
+    """Create the step's auxiliary streams so that its four HEAVY streams -- the current one (first encoder), 'encoder2' and
+    their two weight-gradient companions -- are served by four different hardware queues.  The HIP runtime hands a new stream
+    the least used of its (4) hardware queues, i.e. the outcome depends on every stream the process created before (RCCL's,
+    another library's, a test's): two heavy streams on one queue run one after the other and the step takes 20.9-21.3 instead
+    of 19.0 ms (DESIGN 3).  Candidates come from torch's stream pool and are sorted by queue with dlio_streams_share_queue;
+    the three light streams (IMU branch, reverse directions of the two bidirectional RNNs) each get a stream on the queue of a
+    heavy one that is idle while they run.  Once per device (TrainStep.__init__ calls it); DLIO_ASSIGN_STREAMS=0 leaves the
+    streams to their order of first use."""
+    if not (torch.cuda.is_available() and device.type == "cuda"):
+        return None
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if (idx in _ASSIGNED and not force) or os.environ.get("DLIO_ASSIGN_STREAMS", "1") == "0":
+        return None
+    _ASSIGNED.add(idx)
+    main = torch.cuda.current_stream(idx)
+    if not force and any(k[0] == idx for k in _AUX):
+        return None                  # somebody has run on this device already: leave its streams alone
+    for k in [k for k in _AUX if k[0] == idx]:
+        del _AUX[k]
+    cands, used = [], set()
+
+    def cand(j):
+        while len(cands) <= j:
+            cands.append(torch.cuda.Stream(device=idx))
+        return cands[j]
+
+    def pick(avoid, prefer=None, limit=12):
+        """an unused candidate that shares no queue with `avoid` (and the queue of `prefer`, if given)"""
+        for j in range(limit):
+            if j in used:
+                continue
+            c = cand(j)
+            if any(ops.streams_share_queue(h, c) for h in avoid):
+                continue
+            if prefer is not None and not ops.streams_share_queue(prefer, c):
+                continue
+            used.add(j)
+            return c
+        return None
+
+    def any_unused():
+        j = next(j for j in range(64) if j not in used)
+        used.add(j)
+        return cand(j)
+
+    heavy = [main]
+    for _ in range(3):
+        heavy.append(pick(heavy) or any_unused())        # (fewer than four queues: GPU_MAX_HW_QUEUES < 4)
+    enc2, wg0, wg2 = heavy[1:]
+    imu = pick([main, enc2], prefer=wg2) or pick([main, enc2]) or any_unused()
+    rd_imu = pick([main, enc2, imu], prefer=wg0) or pick([main, imu]) or any_unused()
+    rd_main = pick([main, wg0, wg2], prefer=enc2) or pick([main]) or any_unused()
+    table = {"encoder2": enc2, "wgrad@%x" % main.cuda_stream: wg0, "wgrad@%x" % enc2.cuda_stream: wg2, "imu": imu,
+             "rnndir@%x" % imu.cuda_stream: rd_imu, "rnndir@%x" % main.cuda_stream: rd_main}
+    for name, st in table.items():
+        _AUX[(idx, name)] = st
+    return table
+
+
 def join_aux_streams():
     """current stream waits for everything issued so far on every auxiliary stream of its device"""
     _JOIN_PENDING[0] = False

@@ -28,6 +28,13 @@ def raw_stream():
     return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
+def streams_share_queue(a, b):
+    """True when torch streams a and b are served by one hardware queue (dlio_streams_share_queue; synchronises both)"""
+    out = C.c_int(0)
+    check(lib.dlio_streams_share_queue(C.c_void_p(a.cuda_stream), C.c_void_p(b.cuda_stream), C.byref(out)), "streams_share_queue")
+    return bool(out.value)
+
+
 def _stream():
     return C.c_void_p(raw_stream())
 

@@ -27,6 +27,7 @@ class TrainStep:
         self.args = types.SimpleNamespace(device=str(device), batch_size=batch_size, lr=lr,
                                           weight_decay=weight_decay, momentum=momentum)
         build_config_container(cfg, self.args)
+        Fh.assign_streams(self.device)              # the heavy streams of the step on hardware queues of their own
         self.model = get_model(input_shape, cfg, self.device)
         self.criterion = get_loss_function(cfg, self.device)
         self.optimizer = create_optimizer([{'params': self.model.parameters()},

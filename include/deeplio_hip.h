@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 235
+#define DLIO_ABI_VERSION 236
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);
@@ -50,6 +50,11 @@ const char* dlio_arch(void);
  * BX3_ABLATE bit 1, W1_COAL_PROBE bit 2); the host side refuses such a library unless DLIO_ALLOW_PROBES=1 */
 int dlio_build_probes(void);           /* "gfx950" */
 const char* dlio_strerror(int code);
+/* shared[0] = 1 when HIP streams a and b are served by the same hardware queue (their launches then never overlap), found
+ * by timing: a 1 us launch on b issued behind a 150 us spin on a.  Synchronises both streams.  The host side uses it to
+ * put the step's four heavy streams (the two siamese encoders of LidarPointSegFeat, lidar_feat_nets.py:62-118, and their
+ * weight-gradient companions) on four different queues whatever the process created before (deeplio_amd.functional.assign_streams). */
+int dlio_streams_share_queue(dlio_stream_t a, dlio_stream_t b, int* shared);
 /* hipGetErrorString of the HIP error behind the last DLIO_ELAUNCH in this thread */
 const char* dlio_last_hip_error_string(void);
 

@@ -422,3 +422,37 @@ def test_lazy_pool_gradient_is_materialised_where_nobody_can_route_it(dev):
         got, fused = run(pf, True)
         assert fused == pf and not Fh._LAZY
         assert all(rel_err(a, b) < 5e-6 for a, b in zip(got, ref))
+
+
+def test_assign_streams_puts_the_heavy_streams_on_queues_of_their_own(dev):
+    """functional.assign_streams: whatever streams the process created before (here: three more), the current stream, the
+    second encoder's and the two weight-gradient companions end up on four different hardware queues (two of them on one
+    queue cost 2 ms of a 19 ms step: the runtime hands a new stream the least used of its 4 queues); the probe itself
+    (dlio_streams_share_queue) says 'shared' for a stream and itself and for the light streams and their partners"""
+    from deeplio_amd import functional as Fh, ops
+    if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 4:
+        pytest.skip("fewer than four hardware queues configured")
+    saved, assigned = dict(Fh._AUX), set(Fh._ASSIGNED)
+    try:
+        extra = [torch.cuda.Stream(device=dev) for _ in range(3)]
+        for s in extra:
+            with torch.cuda.stream(s):
+                torch.zeros(1, device=dev)
+        t = Fh.assign_streams(dev, force=True)
+        main = torch.cuda.current_stream(dev)
+        assert ops.streams_share_queue(main, main)
+        enc2 = t["encoder2"]
+        heavy = [main, enc2, t["wgrad@%x" % main.cuda_stream], t["wgrad@%x" % enc2.cuda_stream]]
+        for i in range(4):
+            for j in range(i + 1, 4):
+                assert not ops.streams_share_queue(heavy[i], heavy[j]), (i, j)
+        imu = t["imu"]
+        light = [imu, t["rnndir@%x" % imu.cuda_stream], t["rnndir@%x" % main.cuda_stream]]
+        assert len({s.cuda_stream for s in heavy + light}) == 7
+        assert not ops.streams_share_queue(imu, main) and not ops.streams_share_queue(imu, enc2)
+        assert not ops.streams_share_queue(light[1], imu)
+        # a second call leaves the table alone
+        assert Fh.assign_streams(dev) is None and Fh._AUX[(dev.index or 0, "encoder2")] is enc2
+    finally:
+        Fh._AUX.clear(); Fh._AUX.update(saved)
+        Fh._ASSIGNED.clear(); Fh._ASSIGNED.update(assigned)

@@ -8,6 +8,10 @@ from deeplio_amd.trainer import TrainStep
 dev = torch.device("cuda:0")
 C, H, W, T, S, B = 5, 64, 2048, 50, 2, 8
 cfg = make_config(lidar="lidar-feat-pointseg", imu="imu-feat-rnn", fusion="fusion-layer-soft", odom="odom-feat-rnn", seq=S)
+_dummies = [torch.cuda.Stream(device=dev) for _ in range(int(os.environ.get("WATCH_DUMMY_STREAMS", "0")))]   # rotates the stream -> hardware queue mapping
+for _s in _dummies:
+    with torch.cuda.stream(_s):
+        torch.zeros(1, device=dev)
 torch.manual_seed(20260928)
 ts = TrainStep(cfg, (C, H, W), dev, B)
 batch = bench.synth_batch(1234, B, S, C, H, W, T, dev)
