@@ -1,5 +1,5 @@
 import os, sys, time, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from deeplio_amd import ops
 dev = torch.device("cuda:0")
 N = 16

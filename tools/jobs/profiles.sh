@@ -1,3 +1,6 @@
+#!/bin/bash
+# GPU job: every profile under profiles/r<NN>_* (kernel stats serial + overlapped, families, PMC traffic / MFMA, block times,
+# BatchNorm table, FlowNet / ResNet lines).   gpurun --timeout 3600 -- "bash tools/jobs/profiles.sh"  then copy gpurun_out/r05_* to profiles/
 cd /root/repo; export GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 bash tools/collect_profiles.sh r05 > gpurun_out/collect.log 2>&1
 bash tools/pmc_mfma.sh r05 > /dev/null 2>&1

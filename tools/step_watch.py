@@ -1,6 +1,6 @@
-"""per-step time + cooperative BatchNorm error flag, step by step (usage: env ... python tools/dbg/step_watch.py [steps])"""
+"""per-step time + cooperative BatchNorm error flag, step by step (usage: env ... python tools/step_watch.py [steps])"""
 import os, sys, time, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import bench
 from deeplio_amd import ops
 from deeplio_amd.config import make_config

@@ -1,6 +1,6 @@
 """order in which the auxiliary streams of one training step are created (it decides which streams share a hardware queue)"""
 import os, sys, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import bench
 from deeplio_amd import functional as Fh, ops
 from deeplio_amd.config import make_config
