@@ -416,6 +416,85 @@ def test_model_bf16_training_tracks_fp32(dev):
     assert set(g16) == set(g32)
 
 
+def test_model_bf16_full_size_train_steps(dev):
+    """BASELINE configs[4] at its own geometry -- 64 x 2048 x 5, T = 50, seq_len 4, geodesic rotation loss, bf16 encoders,
+    full-size RNNs, Adam -- with per-GPU batch 2 (8 frame pairs, 16 images per encoder; the bench line runs batch 8): the
+    launch sizes at which the bf16 kernels take their large-plane branches (statistics splits, pool strips, weight-gradient
+    slabs).  Envelope: the poses and the loss of the first step against the fp32 ORACLE on the same weights and batch within
+    MODEL_TOL; properties: three optimizer steps next to the fp32 HIP run at the same seeds stay within 10 % of its losses
+    (which at this initialisation and lr 1e-3 go up before they come down), every gradient is fp32 and finite, the running statistics of the first step (same weights) are within MODEL_TOL of the fp32 run's."""
+    from deeplio_amd import losses, misc, nets
+    from deeplio_amd.config import make_config
+    from deeplio_amd.optimizer import create_optimizer
+    from deeplio_amd.se3 import se3_to_SE3
+    from oracle import model as om
+    from oracle import se3 as ose3
+    B, S, C, H, W, T = 2, 4, 5, 64, 2048, 50
+    batch = gc.make_batch(2100, B, S, C, H, W, T)
+    dbatch = tuple(t.to(dev) for t in batch)
+
+    def cfg_of(prec):
+        ov = dict(gc.NO_DROP)
+        ov['lidar-feat-pointseg/precision'] = prec
+        cfg = make_config(lidar="lidar-feat-pointseg", imu="imu-feat-rnn", fusion="fusion-layer-soft", odom="odom-feat-rnn",
+                          seq=S, overrides=ov)
+        cfg['losses']['rotation'] = 'geodesic'
+        return cfg
+
+    def loss_of(crit, pt, pw, pp, pq, f2f, f2g):
+        return crit(pt, pw, pp[:, 1:3], pq[:, 1:3], f2f[:, :, 0:3], f2f[:, :, 3:], f2g[:, 1:3, 0:3], f2g[:, 1:3, 3:7])
+
+    args = types.SimpleNamespace(lr=1e-3, weight_decay=1e-4, momentum=0.9)
+    traj = {}
+    for prec in ("bf16", "fp32"):
+        cfg = cfg_of(prec)
+        misc.build_config_container(cfg, types.SimpleNamespace(device=str(dev), batch_size=B))
+        model = nets.get_model((C, H, W), cfg, dev)
+        gc.fill_state(model, seed=1000)
+        crit = losses.get_loss_function(cfg, dev)
+        model.train()
+        opt = create_optimizer([{'params': model.parameters()}, {'params': crit.parameters()}], cfg, args)
+        ls, first = [], None
+        for it in range(3):
+            pt, pw = model([[dbatch[0], dbatch[1]], dbatch[2]])
+            pp, pq = se3_to_SE3(pt, pw)
+            loss = loss_of(crit, pt, pw, pp, pq, dbatch[3], dbatch[4])
+            opt.zero_grad()
+            loss.backward()
+            if it == 0:
+                first = (pt.detach().cpu(), pw.detach().cpu())
+                stats = {k: v.detach().cpu().double() for k, v in model.state_dict().items() if "running_" in k}
+                assert all(p.grad.dtype == torch.float32 and bool(torch.isfinite(p.grad).all())
+                           for p in model.parameters() if p.grad is not None)
+            opt.step()
+            ls.append(float(loss.item()))
+        traj[prec] = (ls, first, stats)
+        del model, crit, opt
+        torch.cuda.empty_cache()
+    cfg = cfg_of('fp32')
+    omodel = om.get_model((C, H, W), cfg)
+    gc.fill_state(omodel, seed=1000)
+    omodel.train()
+    ocrit = om.get_loss_function(cfg)
+    with torch.no_grad():
+        a, b = omodel([[batch[0], batch[1]], batch[2]])
+        p2, q2 = ose3.se3_to_SE3(a, b)
+        oloss = float(loss_of(ocrit, a, b, p2, q2, batch[3], batch[4]).item())
+    (l16, f16, s16), (l32, f32, s32) = traj["bf16"], traj["fp32"]
+    print("full-size configs[4]: losses bf16", l16, "fp32", l32, "oracle step 0", oloss,
+          "| poses vs oracle: bf16 %.2e / %.2e, fp32 %.2e / %.2e" % (rel_err(f16[0], a), rel_err(f16[1], b),
+                                                                     rel_err(f32[0], a), rel_err(f32[1], b)))
+    assert rel_err(f32[0], a) < 1e-4 and rel_err(f32[1], b) < 1e-4 and abs(l32[0] - oloss) <= 1e-4 * abs(oloss)
+    assert rel_err(f16[0], a) < MODEL_TOL and rel_err(f16[1], b) < MODEL_TOL
+    assert abs(l16[0] - oloss) <= MODEL_TOL * abs(oloss)
+    assert all(np.isfinite(l16))
+    for a16, a32 in zip(l16, l32):
+        assert abs(a16 - a32) <= 0.1 * abs(a32), (l16, l32)
+    worst = max((rel_err(s16[k], s32[k]), k) for k in s32)
+    print("running statistics bf16 vs fp32 after the first step: worst %.2e (%s)" % worst)
+    assert worst[0] < MODEL_TOL
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(4, 24, 8, 64), (4, 16, 16, 32)])
 def test_bf16_batchnorm_synchronised_statistics_equal_the_whole_batch(dev, shape):
