@@ -168,6 +168,10 @@ SIGNATURES = {
                                _p, _p]),
     "dlio_pose_loss_bwd": (_i, [C.POINTER(_p), C.POINTER(_p), C.POINTER(C.c_int32), _p, _p, _f, _i,
                                _p, _p, C.POINTER(_p), _p, _p, _p]),
+    "dlio_pose_tail_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _f, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "dlio_pose_tail_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _f, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p,
+                               _p, _p, _i, _p]),
+    "dlio_pose_tail_ws_floats": (_sz, [_i, _i, _i, _i]),
     "dlio_pair_stack": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dlio_gt_relative": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "dlio_chan_stats_splits": (_i, [_i, _i, _i]),

@@ -219,17 +219,19 @@ __global__ void so3_project_bwd_kernel(const float* __restrict__ R, const float*
 __global__ void se3_chain_fwd_kernel(const float* __restrict__ t, const float* __restrict__ w,
                                      float* __restrict__ p, float* __restrict__ q,
                                      float* __restrict__ R_all, int32_t* status, int B, int S,
-                                     int order) {
+                                     int order, int32_t* nonfinite = nullptr) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   M3 P;
 #pragma unroll
   for (int i = 0; i < 9; ++i) P.m[i] = (i % 4 == 0) ? 1.f : 0.f;
   float pp[3] = {0.f, 0.f, 0.f};
-  int bad = 0;
+  int bad = 0, nf = 0;
   for (int s = 0; s < S; ++s) {
     const float* ts = t + ((size_t)b * S + s) * 3;
     const float* wv = w + ((size_t)b * S + s) * 3;
+    if (nonfinite)        // trainer.py:240-243 (torch.isnan / isinf of the model output), without a launch of its own
+      for (int i = 0; i < 3; ++i) nf |= !(fabsf(ts[i]) <= 3.402823466e38f) || !(fabsf(wv[i]) <= 3.402823466e38f);
     const M3 R = so3_exp(wv[0], wv[1], wv[2]);
     if (!close1(det3(R))) bad |= 1;
     float np[3];
@@ -259,14 +261,21 @@ __global__ void se3_chain_fwd_kernel(const float* __restrict__ t, const float* _
     for (int i = 0; i < 9; ++i) Ro[i] = P.m[i];
   }
   if (bad && status) atomicOr(status, bad);
+  if (nf) atomicOr(nonfinite, 1);
 }
 
 __global__ void se3_chain_bwd_kernel(const float* __restrict__ t, const float* __restrict__ w,
                                      const float* __restrict__ R_all, const float* __restrict__ dp,
                                      const float* __restrict__ dq, float* __restrict__ dt,
-                                     float* __restrict__ dw, int B, int S, int order) {
+                                     float* __restrict__ dw, int B, int S, int order,
+                                     int g0 = 0, int g1 = 1 << 30, const float* __restrict__ addt = nullptr,
+                                     const float* __restrict__ addw = nullptr) {
+  // g0, g1: dp / dq hold the rows g0 <= s < g1 of every batch item only ([B][g1 - g0][3 | 4]); the other rows' gradient is zero.
+  // addt, addw: added to dt, dw (the gradient the increments get from the criterion's local terms)
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
+  g1 = min(g1, S);
+  const int G = g1 - g0;
   M3 dP;
 #pragma unroll
   for (int i = 0; i < 9; ++i) dP.m[i] = 0.f;
@@ -285,8 +294,10 @@ __global__ void se3_chain_bwd_kernel(const float* __restrict__ t, const float* _
     }
     // quaternion gradient into dP
     float g[4] = {0.f, 0.f, 0.f, 0.f};
-    if (dq) {
-      const float* gq = dq + o * 4;
+    const bool in_g = s >= g0 && s < g1;
+    const size_t og = (size_t)b * G + (s - g0);
+    if (dq && in_g) {
+      const float* gq = dq + og * 4;
       if (order == 0) { g[0] = gq[0]; g[1] = gq[1]; g[2] = gq[2]; g[3] = gq[3]; }
       else { g[1] = gq[0]; g[2] = gq[1]; g[3] = gq[2]; g[0] = gq[3]; }
     }
@@ -302,13 +313,14 @@ __global__ void se3_chain_bwd_kernel(const float* __restrict__ t, const float* _
     }
     float gp[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) gp[i] = dpa[i] + (dp ? dp[o * 3 + i] : 0.f);
+    for (int i = 0; i < 3; ++i) gp[i] = dpa[i] + ((dp && in_g) ? dp[og * 3 + i] : 0.f);
     const float* ts = t + o * 3;
     const float* wv = w + o * 3;
     // p_s = Pm t_s + p_{s-1}
     float* dto = dt + o * 3;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) dto[i] = Pm.m[i] * gp[0] + Pm.m[3 + i] * gp[1] + Pm.m[6 + i] * gp[2];
+    for (int i = 0; i < 3; ++i)
+      dto[i] = Pm.m[i] * gp[0] + Pm.m[3 + i] * gp[1] + Pm.m[6 + i] * gp[2] + (addt ? addt[o * 3 + i] : 0.f);
     const M3 R = so3_exp(wv[0], wv[1], wv[2]);
     // P_s = Pm R : dPm = dP R^T + gp t^T ; dR = Pm^T dP
     M3 dPm, dR;
@@ -321,6 +333,8 @@ __global__ void se3_chain_bwd_kernel(const float* __restrict__ t, const float* _
         dR.m[i * 3 + j] = Pm.m[i] * dP.m[j] + Pm.m[3 + i] * dP.m[3 + j] + Pm.m[6 + i] * dP.m[6 + j];
       }
     so3_exp_bwd(wv[0], wv[1], wv[2], dR, dw + o * 3);
+    if (addw)
+      for (int i = 0; i < 3; ++i) dw[o * 3 + i] += addw[o * 3 + i];
     dP = dPm;
     dpa[0] = gp[0]; dpa[1] = gp[1]; dpa[2] = gp[2];
   }
@@ -388,25 +402,34 @@ __device__ __forceinline__ void so3_to_quat_bwd(const float* phi, const float* g
 }
 
 // mean over rows of theta^2; kind 1: rows of 3 (so(3) vectors), kind 3: rows of 4 (quaternions)
-__device__ __forceinline__ float geo_row(int kind, const float* pr, const float* gt, int r, float* grad) {
-  if (kind == 3) return geo_theta2(pr + (size_t)r * 4, gt + (size_t)r * 4, grad);
+__device__ __forceinline__ float geo_row(int kind, const float* pr, const float* gt, float* grad) {
+  if (kind == 3) return geo_theta2(pr, gt, grad);
   float qa[4], qb[4];
-  so3_to_quat(pr + (size_t)r * 3, qa);
-  so3_to_quat(gt + (size_t)r * 3, qb);
+  so3_to_quat(pr, qa);
+  so3_to_quat(gt, qb);
   if (!grad) return geo_theta2(qa, qb, nullptr);
   float gq[4];
   const float v = geo_theta2(qa, qb, gq);
-  so3_to_quat_bwd(pr + (size_t)r * 3, gq, grad);
+  so3_to_quat_bwd(pr, gq, grad);
   return v;
 }
 
 // ---- pose loss: single block ------------------------------------------------------
+// term i compares n[i] elements = rows of D[i] columns; row j of the term is row (j % R[i]) of batch item j / R[i]:
+// pred[i] + (j / R) pbs + (j % R) prs, gt[i] + (j / R) gbs + (j % R) grs (element strides).  The plain entry points pass
+// contiguous arrays (R = all rows, prs = grs = D); dlio_pose_tail_* read the predicted poses' rows g0..g1 and the columns of
+// gt_f2f [B][S][6] / gt_f2g [B][S][7] in place.  dpred is always contiguous [n / D][D].
 struct LossArgs {
   const float* pred[4];
   const float* gt[4];
   float* dpred[4];
   int32_t n[4];
+  int32_t D[4], R[4], pbs[4], prs[4], gbs[4], grs[4];
 };
+__device__ __forceinline__ const float* loss_row(const float* base, int j, int R, int bs, int rs) {
+  const int b = j / R;
+  return base + (size_t)b * bs + (size_t)(j - b * R) * rs;
+}
 
 __global__ __launch_bounds__(256) void pose_loss_fwd_kernel(LossArgs a, const float* sx,
                                                             const float* sq, float beta, int mode,
@@ -419,11 +442,14 @@ __global__ __launch_bounds__(256) void pose_loss_fwd_kernel(LossArgs a, const fl
     double s = 0.0;
     int cnt = a.n[i];
     if (geo && (i == 1 || i == 3)) {
-      cnt = a.n[i] / (i == 1 ? 3 : 4);
-      for (int r = threadIdx.x; r < cnt; r += 256) s += (double)geo_row(i, a.pred[i], a.gt[i], r, nullptr);
+      cnt = a.n[i] / a.D[i];
+      for (int r = threadIdx.x; r < cnt; r += 256)
+        s += (double)geo_row(i, loss_row(a.pred[i], r, a.R[i], a.pbs[i], a.prs[i]),
+                             loss_row(a.gt[i], r, a.R[i], a.gbs[i], a.grs[i]), nullptr);
     } else {
       for (int e = threadIdx.x; e < a.n[i]; e += 256) {
-        const float d = a.pred[i][e] - a.gt[i][e];
+        const int r = e / a.D[i], c = e - r * a.D[i];
+        const float d = loss_row(a.pred[i], r, a.R[i], a.pbs[i], a.prs[i])[c] - loss_row(a.gt[i], r, a.R[i], a.gbs[i], a.grs[i])[c];
         s += (double)d * d;
       }
     }
@@ -443,7 +469,7 @@ __global__ __launch_bounds__(256) void pose_loss_fwd_kernel(LossArgs a, const fl
 __global__ __launch_bounds__(256) void pose_loss_bwd_kernel(LossArgs a, const float* sx,
                                                             const float* sq, float beta, int mode,
                                                             const float* out, const float* gscale,
-                                                            float* dsx, float* dsq) {
+                                                            float* dsx, float* dsq, int acc_hyper = 0) {
   const float gs = gscale ? gscale[0] : 1.f;
   const bool geo = (mode & 2) != 0;
   mode &= 1;
@@ -453,22 +479,25 @@ __global__ __launch_bounds__(256) void pose_loss_bwd_kernel(LossArgs a, const fl
   for (int i = 0; i < 4; ++i) {
     if (a.n[i] <= 0 || !a.dpred[i]) continue;
     if (geo && (i == 1 || i == 3)) {
-      const int w = i == 1 ? 3 : 4, rows = a.n[i] / w;
+      const int w = a.D[i], rows = a.n[i] / w;
       const float coef = gs * cq / (float)rows;
       for (int r = threadIdx.x; r < rows; r += 256) {
         float g[4];
-        geo_row(i, a.pred[i], a.gt[i], r, g);
+        geo_row(i, loss_row(a.pred[i], r, a.R[i], a.pbs[i], a.prs[i]), loss_row(a.gt[i], r, a.R[i], a.gbs[i], a.grs[i]), g);
         for (int k = 0; k < w; ++k) a.dpred[i][(size_t)r * w + k] = coef * g[k];
       }
       continue;
     }
     const float coef = gs * ((i == 0 || i == 2) ? cx : cq) * 2.f / (float)a.n[i];
-    for (int e = threadIdx.x; e < a.n[i]; e += 256) a.dpred[i][e] = coef * (a.pred[i][e] - a.gt[i][e]);
+    for (int e = threadIdx.x; e < a.n[i]; e += 256) {
+      const int r = e / a.D[i], c = e - r * a.D[i];
+      a.dpred[i][e] = coef * (loss_row(a.pred[i], r, a.R[i], a.pbs[i], a.prs[i])[c] - loss_row(a.gt[i], r, a.R[i], a.gbs[i], a.grs[i])[c]);
+    }
   }
   if (threadIdx.x == 0 && mode == 0) {
     const float Lt = out[1], Lw = out[2], Lp = out[3], Lq = out[4];
-    if (dsx) dsx[0] = gs * (1.f - (Lp + Lt) * cx);
-    if (dsq) dsq[0] = gs * (1.f - (Lq + Lw) * cq);
+    if (dsx) dsx[0] = (acc_hyper ? dsx[0] : 0.f) + gs * (1.f - (Lp + Lt) * cx);
+    if (dsq) dsq[0] = (acc_hyper ? dsq[0] : 0.f) + gs * (1.f - (Lq + Lw) * cq);
   }
 }
 
@@ -511,7 +540,34 @@ static int fill_loss_args(LossArgs& a, const float* const* pred, const float* co
     a.pred[i] = pred[i];
     a.gt[i] = gt[i];
     a.dpred[i] = dpred ? dpred[i] : nullptr;
-    if (n[i] < 0 || (n[i] > 0 && (!pred[i] || !gt[i]))) return DLIO_EINVAL;
+    a.D[i] = i == 3 ? 4 : 3;
+    a.R[i] = n[i] / a.D[i] > 0 ? n[i] / a.D[i] : 1;
+    a.pbs[i] = a.gbs[i] = 0;
+    a.prs[i] = a.grs[i] = a.D[i];
+    if (n[i] < 0 || n[i] % a.D[i] || (n[i] > 0 && (!pred[i] || !gt[i]))) return DLIO_EINVAL;
+  }
+  return DLIO_OK;
+}
+
+// the criterion's operands as views (see LossArgs): increments t, w [B][S][3], chained poses p [B][S][3], q [B][S][4], rows g0..g1
+static int fill_tail_args(LossArgs& a, const float* t, const float* w, const float* p, const float* q, const float* gt_f2f,
+                          const float* gt_f2g, int B, int S, int g0, int g1, int terms, float* const* dpred) {
+  const int G = g1 - g0;
+  const float* pred[4] = {t, w, p + (size_t)g0 * 3, q + (size_t)g0 * 4};
+  const float* gt[4] = {gt_f2f, gt_f2f + 3, gt_f2g + (size_t)g0 * 7, gt_f2g + (size_t)g0 * 7 + 3};
+  for (int i = 0; i < 4; ++i) {
+    const bool local = i < 2;
+    const bool on = (terms & (local ? 1 : 2)) != 0;
+    a.D[i] = i == 3 ? 4 : 3;
+    a.R[i] = local ? S : G;
+    a.n[i] = on ? B * a.R[i] * a.D[i] : 0;
+    a.pred[i] = pred[i];
+    a.gt[i] = gt[i];
+    a.dpred[i] = (dpred && on) ? dpred[i] : nullptr;
+    a.pbs[i] = S * a.D[i];
+    a.prs[i] = a.D[i];
+    a.gbs[i] = S * (local ? 6 : 7);
+    a.grs[i] = local ? 6 : 7;
   }
   return DLIO_OK;
 }
@@ -544,4 +600,51 @@ extern "C" int dlio_pose_loss_bwd(const float* const* pred, const float* const* 
   hipLaunchKernelGGL(pose_loss_bwd_kernel, dim3(1), dim3(256), 0, as_stream(stream), a, sx, sq,
                      beta, mode, out, gscale, dsx, dsq);
   return dlio_check_launch();
+}
+
+// ---- Trainer's tail: SE(3) chain + criterion, two launches each way ------------------------------------------------------------
+extern "C" int dlio_pose_tail_fwd(const float* t, const float* w, const float* gt_f2f, const float* gt_f2g, int B, int S,
+                                  int g0, int g1, int terms, const float* sx, const float* sq, float beta, int mode,
+                                  int order, float* p, float* q, float* R_all, int32_t* status, int32_t* nonfinite,
+                                  float* out, dlio_stream_t stream) {
+  if (!t || !w || !gt_f2f || !gt_f2g || !p || !q || !R_all || !out || B <= 0 || S <= 0 || g0 < 0 || g1 > S || g0 >= g1 ||
+      terms < 1 || terms > 3 || ((mode & 1) == 0 && (!sx || !sq)) || mode < 0 || mode > 3 || (order != 0 && order != 1))
+    return DLIO_EINVAL;
+  hipLaunchKernelGGL(se3_chain_fwd_kernel, dim3(cdiv(B, 64)), dim3(64), 0, as_stream(stream), t, w, p, q, R_all, status, B, S,
+                     order, nonfinite);
+  int rc = dlio_check_launch();
+  if (rc) return rc;
+  LossArgs a;
+  fill_tail_args(a, t, w, p, q, gt_f2f, gt_f2g, B, S, g0, g1, terms, nullptr);
+  hipLaunchKernelGGL(pose_loss_fwd_kernel, dim3(1), dim3(256), 0, as_stream(stream), a, sx, sq, beta, mode, out);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_pose_tail_bwd(const float* t, const float* w, const float* gt_f2f, const float* gt_f2g, int B, int S,
+                                  int g0, int g1, int terms, const float* sx, const float* sq, float beta, int mode,
+                                  int order, const float* p, const float* q, const float* R_all, const float* out,
+                                  const float* gscale, float* ws, float* dt, float* dw, float* dsx, float* dsq,
+                                  int acc_hyper, dlio_stream_t stream) {
+  if (!t || !w || !gt_f2f || !gt_f2g || !p || !q || !R_all || !out || !ws || !dt || !dw || B <= 0 || S <= 0 || g0 < 0 ||
+      g1 > S || g0 >= g1 || terms < 1 || terms > 3 || ((mode & 1) == 0 && (!sx || !sq)) || mode < 0 || mode > 3 ||
+      (order != 0 && order != 1))
+    return DLIO_EINVAL;
+  // ws: [B][S][3] x 2 (the local terms' gradients) + [B][G][3] + [B][G][4] (the global terms'); see dlio_pose_tail_ws_floats
+  const int G = g1 - g0;
+  float* dpred[4] = {ws, ws + (size_t)B * S * 3, ws + (size_t)B * S * 6, ws + (size_t)B * S * 6 + (size_t)B * G * 3};
+  LossArgs a;
+  fill_tail_args(a, t, w, p, q, gt_f2f, gt_f2g, B, S, g0, g1, terms, dpred);
+  hipLaunchKernelGGL(pose_loss_bwd_kernel, dim3(1), dim3(256), 0, as_stream(stream), a, sx, sq, beta, mode, out, gscale, dsx,
+                     dsq, acc_hyper);
+  int rc = dlio_check_launch();
+  if (rc) return rc;
+  const bool loc = (terms & 1) != 0, glob = (terms & 2) != 0;
+  hipLaunchKernelGGL(se3_chain_bwd_kernel, dim3(cdiv(B, 64)), dim3(64), 0, as_stream(stream), t, w, R_all,
+                     glob ? dpred[2] : nullptr, glob ? dpred[3] : nullptr, dt, dw, B, S, order, g0, g1,
+                     loc ? dpred[0] : nullptr, loc ? dpred[1] : nullptr);
+  return dlio_check_launch();
+}
+
+extern "C" size_t dlio_pose_tail_ws_floats(int B, int S, int g0, int g1) {
+  return (size_t)B * S * 6 + (size_t)B * (g1 - g0) * 7;
 }

@@ -1762,6 +1762,40 @@ class SE3ChainFn(Function):
         return dt, dw, None, None
 
 
+class PoseTailFn(Function):
+    """Trainer's tail as ONE tape node: se3_to_SE3 (trainer.py:324-351) + the criterion on (f2f_t, f2f_w, f2g_p[:, g0:g1],
+    f2g_q[:, g0:g1]) against the columns of gt_f2f / gt_f2g (trainer.py:245-252) + the non-finite check of the model output
+    (trainer.py:240-243): two launches forward, two backward (SE3ChainFn + slices + PoseLossFn + the engine's accumulations
+    are 21, all on the serial chain of the step's middle).  Same kernels, same values."""
+
+    @staticmethod
+    def forward(ctx, sx, sq, beta, mode, terms, t, w, gt_f2f, gt_f2g, g0, g1, order, status, nonfinite):
+        t, w, gt_f2f, gt_f2g = t.contiguous(), w.contiguous(), gt_f2f.contiguous(), gt_f2g.contiguous()
+        out, p, q, R = ops.pose_tail_fwd(t, w, gt_f2f, gt_f2g, g0, g1, terms, sx, sq, beta, mode, order, status, nonfinite)
+        ctx.saved = (t, w, gt_f2f, gt_f2g, sx, sq, p, q, R, out)
+        ctx.cfg = (beta, mode, terms, g0, g1, order)
+        ctx.terms_out = out
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        t, w, gt_f2f, gt_f2g, sx, sq, p, q, R, out = ctx.saved
+        beta, mode, terms, g0, g1, order = ctx.cfg
+        ctx.saved = None
+        dsx = dsq = ret_x = ret_q = None
+        acc = False
+        if (mode & 1) == 0 and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            dsx, acc_x, ret_x = _sink(sx, (), t)
+            dsq, acc_q, ret_q = _sink(sq, (), t)
+            if acc_x != acc_q:
+                dsx, dsq = _new((), t), _new((), t)
+                acc_x, ret_x, ret_q = False, dsx, dsq
+            acc = acc_x
+        dt, dw = ops.pose_tail_bwd(t, w, gt_f2f, gt_f2g, g0, g1, terms, sx, sq, beta, mode, order, p, q, R, out, g.contiguous(),
+                                   dsx, dsq, acc)
+        return (ret_x, ret_q, None, None, None, dt, dw) + (None,) * 7
+
+
 class PoseLossFn(Function):
     """HWSLoss / LWSLoss forward+backward in one launch each (losses/losses.py:21-39,68-86)."""
 

@@ -1331,6 +1331,35 @@ def pose_loss_bwd(preds, gts, sx, sq, beta, mode, out, gscale):
     return dpreds, dsx, dsq
 
 
+def pose_tail_fwd(t, w, gt_f2f, gt_f2g, g0, g1, terms, sx, sq, beta, mode, order, status=None, nonfinite=None):
+    """SE(3) chain + criterion on slices read in place (dlio_pose_tail_fwd) -> out [5] (loss, Lt, Lw, Lp, Lq), p, q, R_all"""
+    for x in (t, w, gt_f2f, gt_f2g):
+        _chk(x)
+    B, S, _ = t.shape
+    assert tuple(w.shape) == (B, S, 3) and tuple(gt_f2f.shape) == (B, S, 6) and tuple(gt_f2g.shape) == (B, S, 7)
+    dev = t.device
+    p = torch.empty(B, S, 3, dtype=torch.float32, device=dev)
+    q = torch.empty(B, S, 4, dtype=torch.float32, device=dev)
+    R = torch.empty(B, S, 9, dtype=torch.float32, device=dev)
+    out = torch.empty(5, dtype=torch.float32, device=dev)
+    check(lib.dlio_pose_tail_fwd(_ptr(t), _ptr(w), _ptr(gt_f2f), _ptr(gt_f2g), B, S, g0, g1, terms, _ptr(sx), _ptr(sq),
+                                 float(beta), mode, order, _ptr(p), _ptr(q), _ptr(R), _ptr(status), _ptr(nonfinite), _ptr(out),
+                                 _stream()), "pose_tail_fwd")
+    return out, p, q, R
+
+
+def pose_tail_bwd(t, w, gt_f2f, gt_f2g, g0, g1, terms, sx, sq, beta, mode, order, p, q, R, out, gscale, dsx=None, dsq=None,
+                  acc_hyper=False):
+    """-> dt, dw [B,S,3] (dlio_pose_tail_bwd); dsx / dsq are written (added to with acc_hyper) when given"""
+    B, S, _ = t.shape
+    ws = torch.empty(lib.dlio_pose_tail_ws_floats(B, S, g0, g1), dtype=torch.float32, device=t.device)
+    dt, dw = torch.empty_like(t), torch.empty_like(w)
+    check(lib.dlio_pose_tail_bwd(_ptr(t), _ptr(w), _ptr(gt_f2f), _ptr(gt_f2g), B, S, g0, g1, terms, _ptr(sx), _ptr(sq),
+                                 float(beta), mode, order, _ptr(p), _ptr(q), _ptr(R), _ptr(out), _ptr(gscale), _ptr(ws),
+                                 _ptr(dt), _ptr(dw), _ptr(dsx), _ptr(dsq), int(acc_hyper), _stream()), "pose_tail_bwd")
+    return dt, dw
+
+
 # ----------------------------------------------------------------------------- batch prep
 def pair_stack(images, comb, c_split):
     """images [B,F,Ctot,H,W], comb int32 [S,2] (device) -> xyz [B,S,2,c_split,H,W], normals [...]"""

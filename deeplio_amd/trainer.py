@@ -33,7 +33,9 @@ class TrainStep:
         self.optimizer = create_optimizer([{'params': self.model.parameters()},
                                            {'params': self.criterion.parameters()}], cfg, self.args)
         self.max_glob_seq = max_glob_seq            # trainer.py:42
+        self.fused_tail = True                      # functional.PoseTailFn instead of se3_to_SE3 + slices + criterion
         self.flags = torch.zeros(2, dtype=torch.int32, device=self.device)   # [nonfinite, se3 status]
+        self._one = torch.ones((), dtype=torch.float32, device=self.device)
         self.grad_sync = None
         # Host-side hygiene: a step creates ~1e4 short-lived Python objects (tensors, autograd contexts), so
         # CPython's cyclic collector runs many times per step and its full collections walk every object
@@ -107,9 +109,19 @@ class TrainStep:
 
     def _tail(self, feats, gts_f2f, gts_f2g, hook=True):
         """features -> loss: the model's last layers, NaN/Inf flags, SE(3) chain, criterion"""
+        pred_f2f_t, pred_f2f_w = self.model.forward_tail(feats, grads_ready_hook=hook)
+        crit, lt = self.criterion, self.criterion.loss_Types
+        g0, g1 = 1, min(self.max_glob_seq + 1, pred_f2f_t.shape[1])
+        if (self.fused_tail and pred_f2f_t.is_cuda and g0 < g1 and (lt[0] or lt[1]) and hasattr(crit, "mode")
+                and tuple(gts_f2f.shape) == tuple(pred_f2f_t.shape[:2]) + (6,)
+                and tuple(gts_f2g.shape) == tuple(pred_f2f_t.shape[:2]) + (7,)):
+            # non-finite check, SE(3) chain and criterion as one tape node (two launches each way; same kernels as below)
+            return Fh.PoseTailFn.apply(getattr(crit, "sx", None), getattr(crit, "sq", None), float(getattr(crit, "beta", 0.)),
+                                       crit.mode | (2 if crit.rotation == 'geodesic' else 0),
+                                       (1 if lt[0] else 0) | (2 if lt[1] else 0), pred_f2f_t, pred_f2f_w, gts_f2f, gts_f2g,
+                                       g0, g1, 0, self.flags[1:2], self.flags[0:1])
         gt_f2f_t, gt_f2f_w = gts_f2f[:, :, 0:3], gts_f2f[:, :, 3:]
         gt_f2g_p, gt_f2g_q = gts_f2g[:, :, 0:3], gts_f2g[:, :, 3:7]
-        pred_f2f_t, pred_f2f_w = self.model.forward_tail(feats, grads_ready_hook=hook)
         ops.nonfinite_flag(pred_f2f_t, self.flags[0:1])        # trainer.py:240-243, no host sync
         ops.nonfinite_flag(pred_f2f_w, self.flags[0:1])
         pred_f2g_p, pred_f2g_q = se3_to_SE3(pred_f2f_t, pred_f2f_w, status=self.flags[1:2])
@@ -128,7 +140,7 @@ class TrainStep:
         Fh.lazy_clear()            # (entries a failed backward pass may have left behind)
         loss = self._tail(self.model.forward_features([[imgs, normals], imus]), gts_f2f, gts_f2g)
         self.optimizer.zero_grad()
-        loss.backward()
+        loss.backward(self._one)                   # (an explicit d loss / d loss: no fill launch per step)
         if self.grad_sync is not None:
             self.grad_sync.all_reduce_grads()
         self.optimizer.step()

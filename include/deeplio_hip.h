@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 236
+#define DLIO_ABI_VERSION 237
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);
@@ -528,6 +528,24 @@ int dlio_pose_loss_bwd(const float* const* pred, const float* const* gt, const i
                        const float* sx, const float* sq, float beta, int mode,
                        const float* out, const float* gscale, float* const* dpred,
                        float* dsx, float* dsq, dlio_stream_t stream);
+
+/* The trainer's tail -- se3_to_SE3 (trainer.py:324-351), the criterion on (f2f_t, f2f_w, f2g_p[:, g0:g1], f2g_q[:, g0:g1])
+ * against gt_f2f [B][S][6] = (t | w) and gt_f2g [B][S][7] = (p | q) (trainer.py:245-252; losses/losses.py:21-39,68-86) and the
+ * torch.isnan / isinf check of the model output (trainer.py:240-243) -- in two launches each way; the slices are read in
+ * place.  terms: bit 0 local (f2f), bit 1 global (f2g) (losses/__init__.py:10-18); mode, sx, sq, beta, out [5] as
+ * dlio_pose_loss_fwd; order, status, p, q, R_all as dlio_se3_chain_fwd; nonfinite (nullable): |= 1 on a non-finite t / w.
+ * _bwd: dt, dw = gscale * d loss / d (t, w) (local terms + the chain's backward of the global terms); dsx, dsq (HWS, nullable):
+ * acc_hyper != 0 adds to what they hold (they are views of the flat gradient buffer then).  ws: dlio_pose_tail_ws_floats. */
+int dlio_pose_tail_fwd(const float* t, const float* w, const float* gt_f2f, const float* gt_f2g, int B, int S,
+                       int g0, int g1, int terms, const float* sx, const float* sq, float beta, int mode,
+                       int order, float* p, float* q, float* R_all, int32_t* status, int32_t* nonfinite,
+                       float* out, dlio_stream_t stream);
+int dlio_pose_tail_bwd(const float* t, const float* w, const float* gt_f2f, const float* gt_f2g, int B, int S,
+                       int g0, int g1, int terms, const float* sx, const float* sq, float beta, int mode,
+                       int order, const float* p, const float* q, const float* R_all, const float* out,
+                       const float* gscale, float* ws, float* dt, float* dw, float* dsx, float* dsq,
+                       int acc_hyper, dlio_stream_t stream);
+size_t dlio_pose_tail_ws_floats(int B, int S, int g0, int g1);
 
 /* ---- batch preparation ----------------------------------------------------
  * DataCombiCreater.process (models/misc.py:24-125) on the device.

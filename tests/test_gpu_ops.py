@@ -525,6 +525,63 @@ def test_pose_loss(dev, mode):
         assert rel_err(dsx, sxr.grad) < 1e-5 and rel_err(dsq, sqr.grad) < 1e-5
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("terms", [1, 2, 3])
+def test_pose_tail_one_node_equals_chain_slices_and_criterion(dev, mode, terms):
+    """functional.PoseTailFn (dlio_pose_tail_fwd / _bwd: SE(3) chain + criterion on slices read in place + non-finite check,
+    two launches each way) against the separate nodes it replaces in TrainStep._tail -- nonfinite_flag, SE3ChainFn, the
+    [:, 1:3] slices, PoseLossFn and autograd's sums of the twice-used increments: loss, its four terms, d loss / d (t, w) and
+    d loss / d (sx, sq) BIT-identical (same kernels, same summation order), for HWS / LWS, MSE / geodesic rotation terms and
+    local / global / both; the flags fire on a NaN input"""
+    from deeplio_amd import functional as Fh, ops
+    g = _g(31 + mode)
+    B, S, g0, g1 = 5, 4, 1, 3
+    t, w = torch.randn(B, S, 3, generator=g).to(dev), (torch.randn(B, S, 3, generator=g) * 0.3).to(dev)
+    f2f, f2g = torch.randn(B, S, 6, generator=g).to(dev), torch.randn(B, S, 7, generator=g).to(dev)
+    f2g[..., 3:] /= f2g[..., 3:].norm(dim=-1, keepdim=True)
+    hws = (mode & 1) == 0
+
+    def params():
+        return (torch.tensor(0.3, device=dev, requires_grad=hws), torch.tensor(-3.0, device=dev, requires_grad=hws))
+
+    # the separate nodes
+    sx, sq = params()
+    ta, wa = t.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    flags = torch.zeros(2, dtype=torch.int32, device=dev)
+    p, q = Fh.SE3ChainFn.apply(ta, wa, 0, flags[1:2])
+    pt, pw = (ta, wa) if terms & 1 else (ta.detach(), wa.detach())
+    pp, pq = (p, q) if terms & 2 else (p.detach(), q.detach())
+    ref = Fh.PoseLossFn.apply(sx, sq, 1125., mode, bool(terms & 1), bool(terms & 2), pt, pw, pp[:, g0:g1], pq[:, g0:g1],
+                              f2f[:, :, 0:3], f2f[:, :, 3:], f2g[:, g0:g1, 0:3], f2g[:, g0:g1, 3:7])
+    (ref * 0.7).backward()
+    # one node
+    sx2, sq2 = params()
+    tb, wb = t.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    flags2 = torch.zeros(2, dtype=torch.int32, device=dev)
+    one = Fh.PoseTailFn.apply(sx2, sq2, 1125., mode, terms, tb, wb, f2f, f2g, g0, g1, 0, flags2[1:2], flags2[0:1])
+    (one * 0.7).backward()
+    assert torch.equal(one, ref) and flags2.tolist() == [0, 0]
+    assert torch.equal(tb.grad, ta.grad) and torch.equal(wb.grad, wa.grad)
+    if hws:
+        assert torch.equal(sx2.grad, sx.grad) and torch.equal(sq2.grad, sq.grad)
+    # the gradients of sx, sq go straight into .grad when it exists (and ADD to it)
+    if hws:
+        sx3, sq3 = params()
+        sx3.grad, sq3.grad = torch.full((), 2.0, device=dev), torch.full((), -1.0, device=dev)
+        tc, wc = t.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        (Fh.PoseTailFn.apply(sx3, sq3, 1125., mode, terms, tc, wc, f2f, f2g, g0, g1, 0, None, None) * 0.7).backward()
+        assert abs(float(sx3.grad) - (float(sx.grad) + 2.0)) < 1e-6 and abs(float(sq3.grad) - (float(sq.grad) - 1.0)) < 1e-6
+    # non-finite model output
+    tn = t.clone(); tn[2, 1, 0] = float("nan")
+    flags3 = torch.zeros(2, dtype=torch.int32, device=dev)
+    Fh.PoseTailFn.apply(sx2, sq2, 1125., mode, terms, tn, w, f2f, f2g, g0, g1, 0, flags3[1:2], flags3[0:1])
+    assert flags3[0].item() == 1
+    wn = w.clone(); wn[0, 3, 2] = float("inf")
+    flags3.zero_()
+    Fh.PoseTailFn.apply(sx2, sq2, 1125., mode, terms, t, wn, f2f, f2g, g0, g1, 0, flags3[1:2], flags3[0:1])
+    assert flags3[0].item() == 1
+
+
 @pytest.mark.parametrize("mode", [2, 3])
 def test_pose_loss_geodesic(dev, mode):
     """rotation terms as squared geodesic angles (mode bit 1; BASELINE configs[4]) vs the fp64 oracle,
