@@ -1065,6 +1065,29 @@ bool make_plan_3x5s2(const DlioConvDesc& d, Wg35Plan& q) {
   return true;
 }
 
+// column phases -> two 3x3 stride-1 launches -> merge (see deinterleave_cols_kernel); amax_x / amax_dy: the two-piece kernel
+// (the phases are subsets of x: its bound holds for both)
+int run_3x5s2(const float* x, const float* dy, float* dw, float* wsp, const DlioConvDesc& d, const Wg35Plan& q35,
+              int accumulate, hipStream_t s, const float* amax_x, const float* amax_dy) {
+  const size_t pf = (q35.phase_floats + 3) & ~(size_t)3, sl = (q35.p3.ws_bytes / sizeof(float) + 3) & ~(size_t)3;
+  const size_t t9 = (size_t)d.Cout * d.Cin * 9;
+  float* xe = wsp; float* xo = xe + pf; float* se = xo + pf; float* so = se + sl; float* te = so + sl; float* to = te + t9;
+  const int64_t rows = (int64_t)d.N * d.Cin * d.H;
+  const int W8 = d.W / 8;
+  hipLaunchKernelGGL(deinterleave_cols_kernel, dim3((unsigned)cdiv64(rows * W8, 256)), dim3(256), 0, s, x, xe, xo, rows, W8,
+                     (int64_t)0, d.Cin, d.in_ctot, d.in_coff, d.H);
+  int rc = dlio_check_launch();
+  if (!rc) rc = dlio_wgrad3_launch(xe, dy, se, q35.sub, q35.p3, 4, s, amax_x, amax_dy);
+  if (!rc) rc = dlio_wgrad3_launch(xo, dy, so, q35.sub, q35.p3, 4, s, amax_x, amax_dy);
+  if (rc) return rc;
+  const int64_t n9 = (int64_t)t9;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(n9, 64)), dim3(256), 0, s, se, te, n9, q35.p3.splits, 0);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(n9, 64)), dim3(256), 0, s, so, to, n9, q35.p3.splits, 0);
+  const int64_t n15 = (int64_t)d.Cout * d.Cin * 15;
+  hipLaunchKernelGGL(wgrad_merge_3x5_kernel, dim3((unsigned)cdiv64(n15, 256)), dim3(256), 0, s, te, to, dw, n15, accumulate);
+  return dlio_check_launch();
+}
+
 }  // namespace
 
 // bf16 x / dy (mixed-precision path): 3x3 stride-1 (dY-direct kernel) and 1x1 stride-1 (direct kernel),
@@ -1133,7 +1156,8 @@ extern "C" size_t dlio_conv2d_wgrad_ws_bytes(const DlioConvDesc* d) {
  * floats with the operands' largest magnitudes (or bounds on them), left by the kernels that produced the tensors. */
 extern "C" int dlio_conv3x3_wgrad_h2_ok(const DlioConvDesc* dp) {
   DlioWgrad3Plan p3;
-  return dp && dp->N > 0 && dp->Cin > 0 && dp->Cout > 0 && dlio_wgrad3_plan(*dp, 4, p3);
+  Wg35Plan q35;
+  return dp && dp->N > 0 && dp->Cin > 0 && dp->Cout > 0 && (dlio_wgrad3_plan(*dp, 4, p3) || make_plan_3x5s2(*dp, q35));
 }
 
 extern "C" int dlio_conv3x3_wgrad_h2(const float* x, const float* amax_x, const float* dy, const float* amax_dy, float* dw,
@@ -1141,9 +1165,19 @@ extern "C" int dlio_conv3x3_wgrad_h2(const float* x, const float* amax_x, const 
   if (!x || !amax_x || !dy || !amax_dy || !dw || !dp || !ws) return DLIO_EINVAL;
   const DlioConvDesc& d = *dp;
   DlioWgrad3Plan p3;
-  if (!dlio_conv3x3_wgrad_h2_ok(dp) || !dlio_wgrad3_plan(d, 4, p3)) return DLIO_EUNSUP;
-  if (ws_bytes < p3.ws_bytes) return DLIO_EWS;
+  if (!dlio_conv3x3_wgrad_h2_ok(dp)) return DLIO_EUNSUP;
   hipStream_t s = as_stream(stream);
+  if (!dlio_wgrad3_plan(d, 4, p3)) {
+    // 3x5 taps, stride (1, 2): the two column phases on the two-piece kernel (run_3x5s2)
+    Wg35Plan q35;
+    if (!make_plan_3x5s2(d, q35)) return DLIO_EUNSUP;
+    if (ws_bytes < q35.ws_bytes) return DLIO_EWS;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(ws)) & 15) return DLIO_EUNSUP;
+    DlioProfScope prof35(1, s, 2.0 * d.N * (double)d.OH * d.OW * d.Cout * (double)d.Cin * 15,
+                         4.0 * d.N * ((double)d.Cin * d.H * d.W + (double)d.Cout * d.OH * d.OW));
+    return run_3x5s2(x, dy, dw, reinterpret_cast<float*>(ws), d, q35, accumulate, s, amax_x, amax_dy);
+  }
+  if (ws_bytes < p3.ws_bytes) return DLIO_EWS;
   const double flops = 2.0 * d.N * (double)d.OH * d.OW * d.Cout * (double)d.Cin * 9;
   const double bytes = 4.0 * d.N * ((double)d.Cin * d.H * d.W + (double)d.Cout * d.OH * d.OW);
   DlioProfScope prof(4, s, flops, bytes);
@@ -1246,25 +1280,7 @@ extern "C" int dlio_conv2d_wgrad(const float* x, const float* dy, float* dw,
   Wg35Plan q35;
   if (!in_scale && make_plan_3x5s2(d, q35) && ws_bytes >= q35.ws_bytes &&
       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(ws)) & 15) == 0) {
-    // column phases -> two 3x3 stride-1 launches -> merge (see deinterleave_cols_kernel)
-    const size_t pf = (q35.phase_floats + 3) & ~(size_t)3, sl = (q35.p3.ws_bytes / sizeof(float) + 3) & ~(size_t)3;
-    const size_t t9 = (size_t)d.Cout * d.Cin * 9;
-    float* xe = wsp; float* xo = xe + pf; float* se = xo + pf; float* so = se + sl; float* te = so + sl; float* to = te + t9;
-    const int64_t rows = (int64_t)d.N * d.Cin * d.H;
-    const int W8 = d.W / 8;
-    hipLaunchKernelGGL(deinterleave_cols_kernel, dim3((unsigned)cdiv64(rows * W8, 256)), dim3(256), 0, s, x, xe, xo, rows, W8,
-                       (int64_t)0, d.Cin, d.in_ctot, d.in_coff, d.H);
-    rc = dlio_check_launch();
-    if (!rc) rc = dlio_wgrad3_launch(xe, dy, se, q35.sub, q35.p3, 4, s);
-    if (!rc) rc = dlio_wgrad3_launch(xo, dy, so, q35.sub, q35.p3, 4, s);
-    if (!rc) {
-      const int64_t n9 = (int64_t)t9;
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(n9, 64)), dim3(256), 0, s, se, te, n9, q35.p3.splits, 0);
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(n9, 64)), dim3(256), 0, s, so, to, n9, q35.p3.splits, 0);
-      const int64_t n15 = (int64_t)d.Cout * d.Cin * 15;
-      hipLaunchKernelGGL(wgrad_merge_3x5_kernel, dim3((unsigned)cdiv64(n15, 256)), dim3(256), 0, s, te, to, dw, n15, accumulate);
-      rc = dlio_check_launch();
-    }
+    rc = run_3x5s2(x, dy, dw, wsp, d, q35, accumulate, s, nullptr, nullptr);
     dlio_prof_end(pkind, s);
     return rc;
   }

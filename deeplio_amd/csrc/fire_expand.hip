@@ -509,23 +509,28 @@ int launch_fire_fwd(const __bf16* planes, const __bf16* w3t, const __bf16* w1t, 
 
 // ---- weights as two fp16 pieces of w * 2^k: layout [tap][chunk][2][n][16] (the split-bf16 layout with two planes), behind
 // it { 2^-k, 2^k } as floats.  2^k maps the tensor's largest magnitude into [2^13, 2^14].
-// (one workgroup per weight tensor; 1024 threads x 16-byte loads: with 256 threads and scalar loads the largest tensor -- 147 k
-//  elements, 576 dependent trips -- took 163 us at the head of EVERY step, in front of both encoders' first kernel)
+// (1024 threads x 16-byte loads: with 256 threads and scalar loads the largest PointSeg tensor -- 147 k elements, 576 dependent
+//  trips -- took 163 us at the head of EVERY step, in front of both encoders' first kernel.  H2_AMAX_WGS workgroups per weight
+//  tensor (grid.y): one workgroup reads at ~50 GB/s, FlowNet's conv6 -- 4.7 M elements -- took 373 us.  The partial maxima meet
+//  in tail[2] (integer atomicMax on the bits of a non-negative float: order-independent), tail[3] counts arrivals, the last
+//  workgroup writes the scales and leaves both words zero for the next launch; the host zeroes them once, at allocation.)
+constexpr int H2_AMAX_WGS = 32;
 __global__ __launch_bounds__(1024) void prep_h2_amax_kernel(const DlioPrepItem* __restrict__ items, DlioPrepItem single) {
   __shared__ float wm[16];
   const DlioPrepItem it = items ? items[blockIdx.x] : single;
   const int64_t n = (int64_t)it.Cout * it.Cin * it.taps;
+  const int64_t t0 = (int64_t)blockIdx.y * 1024 + threadIdx.x, stride = (int64_t)gridDim.y * 1024;
   float b = 0.f;
   if ((reinterpret_cast<uintptr_t>(it.w) & 15) == 0) {
     const float4* w4 = reinterpret_cast<const float4*>(it.w);
     const int64_t n4 = n >> 2;
-    for (int64_t i = threadIdx.x; i < n4; i += 1024) {
+    for (int64_t i = t0; i < n4; i += stride) {
       const float4 v = w4[i];
       b = fmaxf(b, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
     }
-    for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 1024) b = fmaxf(b, fabsf(it.w[i]));
+    for (int64_t i = (n4 << 2) + t0; i < n; i += stride) b = fmaxf(b, fabsf(it.w[i]));
   } else {
-    for (int64_t i = threadIdx.x; i < n; i += 1024) b = fmaxf(b, fabsf(it.w[i]));
+    for (int64_t i = t0; i < n; i += stride) b = fmaxf(b, fabsf(it.w[i]));
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) b = fmaxf(b, __shfl_xor(b, o, 64));
@@ -535,11 +540,22 @@ __global__ __launch_bounds__(1024) void prep_h2_amax_kernel(const DlioPrepItem* 
     b = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) b = fmaxf(b, wm[i]);
-    const float sc = (b > 0.f && b < 3.0e38f) ? exp2f(floorf(log2f(16384.f / b))) : 1.f;
     const int K = it.mode == 0 ? it.Cin : it.Cout, Nn = it.mode == 0 ? it.Cout : it.Cin;
     float* tail = it.wt + (size_t)it.taps * ((K + 15) >> 4) * Nn * 16;
-    tail[0] = 1.f / sc;
-    tail[1] = sc;
+    unsigned* tu = reinterpret_cast<unsigned*>(tail);
+    if (!(b < 3.0e38f)) b = 3.4e38f;                     // NaN / Inf anywhere: the scale falls back to 1
+    __hip_atomic_fetch_max(tu + 2, __float_as_uint(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    const unsigned arrived = __hip_atomic_fetch_add(tu + 3, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (arrived == gridDim.y - 1) {
+      __threadfence();
+      b = __uint_as_float(__hip_atomic_load(tu + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      const float sc = (b > 0.f && b < 3.0e38f) ? exp2f(floorf(log2f(16384.f / b))) : 1.f;
+      tail[0] = 1.f / sc;
+      tail[1] = sc;
+      __hip_atomic_store(tu + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(tu + 3, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -636,7 +652,9 @@ extern "C" int dlio_conv_h2_prep(const float* w, void* wt, int Cout, int Cin, in
   const int64_t total = (int64_t)taps * ((K + 15) >> 4) * Nn * 16;
   const DlioPrepItem one{w, reinterpret_cast<float*>(wt), Cout, Cin, taps, mode, 0};
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(prep_h2_amax_kernel, dim3(1), dim3(1024), 0, s, (const DlioPrepItem*)nullptr, one);
+  // (the two scratch words behind the scales must be zero: zeroed here for a layout buffer that comes from anywhere)
+  if (hipMemsetAsync(reinterpret_cast<float*>(wt) + total + 2, 0, 2 * sizeof(float), s) != hipSuccess) return DLIO_ELAUNCH;
+  hipLaunchKernelGGL(prep_h2_amax_kernel, dim3(1, H2_AMAX_WGS), dim3(1024), 0, s, (const DlioPrepItem*)nullptr, one);
   hipLaunchKernelGGL(prep_h2_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, s, (const DlioPrepItem*)nullptr, 1, total, one);
   return dlio_check_launch();
 }
@@ -645,7 +663,7 @@ extern "C" int dlio_conv_h2_prep_batched(const DlioPrepItem* items_dev, int n_it
   if (!items_dev || n_items <= 0 || total <= 0) return DLIO_EINVAL;
   hipStream_t s = as_stream(stream);
   const DlioPrepItem none{nullptr, nullptr, 0, 0, 0, 0, 0};
-  hipLaunchKernelGGL(prep_h2_amax_kernel, dim3((unsigned)n_items), dim3(1024), 0, s, items_dev, none);
+  hipLaunchKernelGGL(prep_h2_amax_kernel, dim3((unsigned)n_items, H2_AMAX_WGS), dim3(1024), 0, s, items_dev, none);
   hipLaunchKernelGGL(prep_h2_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, s, items_dev, n_items, total, none);
   return dlio_check_launch();
 }

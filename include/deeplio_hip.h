@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 237
+#define DLIO_ABI_VERSION 238
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);
@@ -242,6 +242,9 @@ int dlio_fire_expand_fwd(const void* planes, const void* w3t, const void* w1t, c
  * v_mfma_f32_32x32x16_f16 per product instead of six bf16 ones, error ~1e-7 of the result.  2^k comes from
  * |BN(x)| <= |beta| + |gamma| sqrt(N H W), which holds for batch statistics (bound_out, nullable: that bound as a device
  * float, for later two-piece consumers of y -- dlio_conv3x3_wgrad_h2); 2^j from the weight tensor's largest magnitude. */
+/* (the last two of the dlio_conv_h2_prep_floats floats are scratch of the magnitude pass -- several workgroups per tensor
+ * meet there -- and must be ZERO before dlio_conv_h2_prep_batched; dlio_conv_h2_prep zeroes them and every launch leaves
+ * them zero, so a layout that went through dlio_conv_h2_prep once can be refreshed by the batched call from then on) */
 size_t dlio_conv_h2_prep_floats(int Cout, int Cin, int taps, int mode);
 int dlio_conv_h2_prep(const float* w, void* wt, int Cout, int Cin, int taps, int mode, dlio_stream_t stream);
 int dlio_conv_h2_prep_batched(const DlioPrepItem* items_dev, int n_items, int64_t total, dlio_stream_t stream);
@@ -287,7 +290,9 @@ int dlio_conv2d_wgrad(const float* x, const float* dy, float* dw,
 /* the 3x3 stride-1 pad-1 weight gradient (pointseg_modules.py:103 expand3x3 in backward) on the two-piece fp16 split: both
  * operands as two fp16 pieces of x 2^k, three v_mfma_f32_32x32x16_f16 per product instead of six bf16 ones.
  * amax_x / amax_dy: device floats with the largest magnitude of x / dy or a bound on it (dlio_bn_split16 bound_out,
- * dlio_bn_coop_bwd amax_out); ws as dlio_conv2d_wgrad_ws_bytes(d).  DLIO_EUNSUP where dlio_conv3x3_wgrad_h2_ok(d) is 0. */
+ * dlio_bn_coop_bwd amax_out); ws as dlio_conv2d_wgrad_ws_bytes(d).  DLIO_EUNSUP where dlio_conv3x3_wgrad_h2_ok(d) is 0.
+ * Also takes the 3x5 stride-(1, 2) pad-(1, 2) layers (FlowNet conv2 / conv3, lidar_feat_nets.py:248-251): their two column
+ * phases are 3x3 stride-1 weight gradients (dlio_conv2d_wgrad does the same on three pieces). */
 int dlio_conv3x3_wgrad_h2_ok(const DlioConvDesc* d);
 int dlio_conv3x3_wgrad_h2(const float* x, const float* amax_x, const float* dy, const float* amax_dy, float* dw, void* ws,
                           size_t ws_bytes, int accumulate, const DlioConvDesc* d, dlio_stream_t stream);

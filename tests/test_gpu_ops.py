@@ -1582,6 +1582,38 @@ def test_conv3x3_two_piece_fp16_weight_gradient(dev, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 64, 128, 16, 256, 1e-4, 0), (1, 128, 256, 12, 136, 1.0, 1), (3, 32, 48, 8, 64, 1e-2, 0)])
+def test_conv3x5_stride12_two_piece_fp16_weight_gradient(dev, case):
+    """the 3x5 stride-(1, 2) pad-(1, 2) weight gradient (FlowNet conv2 / conv3, lidar_feat_nets.py:248-251) through
+    dlio_conv3x3_wgrad_h2: column phases of x, two launches of the two-piece 3x3 kernel, merge -- against fp64 (on the device)
+    and the three-piece route of dlio_conv2d_wgrad; gradient magnitudes with outliers and 8 decades of range, accumulation"""
+    from deeplio_amd import ops
+    N, Cin, Cout, H, W, mag, acc = case
+    g = _g(79)
+    x = torch.relu(torch.randn(N, Cin, H, W, generator=g))
+    OW = W // 2
+    dy = torch.randn(N, Cout, H, OW, generator=g) * mag * torch.exp(torch.rand(N, Cout, H, OW, generator=g) * 18 - 16)
+    dy[0, :3, 5, 7] *= 1e4
+    xd, dyd = x.to(dev), dy.to(dev)
+    ref = torch.nn.grad.conv2d_weight(xd.double(), (Cout, Cin, 3, 5), dyd.double(), stride=(1, 2), padding=(1, 2))
+    d = ops.conv_desc(N, Cin, H, W, Cout, 3, 5, 1, 2, 1, 2, OH=H, OW=OW)
+    assert ops.conv3x3_wgrad_h2_ok(d)
+    assert not ops.conv3x3_wgrad_h2_ok(ops.conv_desc(N, 8, H, W, Cout, 3, 5, 1, 2, 1, 2, OH=H, OW=OW))     # narrow: staged kernel
+    bound = (xd.abs().max() * 30.0).reshape(1)
+    amax = dyd.abs().max().reshape(1)
+    base = torch.randn(Cout, Cin, 3, 5, generator=g).to(dev) if acc else None
+    dw = base.clone() if acc else torch.empty(Cout, Cin, 3, 5, device=dev)
+    ops.conv3x3_wgrad_h2(xd, bound, dyd, amax, dw, d, accumulate=bool(acc))
+    dw3 = base.clone() if acc else torch.empty_like(dw)
+    ops.conv2d_wgrad(xd, dyd, dw3, d, accumulate=bool(acc))
+    if acc:
+        ref = ref + base.double()
+    e2, e3 = rel_err(dw, ref), rel_err(dw3, ref)
+    print("3x5 s(1,2): two-piece fp16 %.2e, three-piece bf16 %.2e" % (e2, e3))
+    assert e2 < 2e-6 and e3 < 2e-6
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", [(2, 64, 16, 64, 512, 1e-5, 1), (2, 16, 128, 64, 512, 3.0, 1), (2, 48, 384, 64, 128, 1e-3, 0),
                                   (4, 200, 40, 12, 36, 1.0, 1), (16, 384, 80, 16, 32, 1e-2, 0)])
 def test_conv1x1_two_piece_fp16_data_gradient(dev, case):
