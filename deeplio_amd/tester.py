@@ -17,6 +17,7 @@ import types
 import numpy as np
 import torch
 
+from . import functional as Fh
 from . import losses, misc, nets
 from .se3 import se3_to_SE3
 
@@ -109,6 +110,7 @@ class TestStep:
         cc = cc if cc is not None else misc.get_config_container()
         if cc.seq_size != 1:
             raise ValueError("Sequence size mus tbe equal 1 in test mode.")      # tester.py:40-42
+        Fh.assign_streams(self.device)              # the two encoder streams on hardware queues of their own
         self.model = nets.get_model(input_shape, cfg, self.device)
         self.criterion = losses.get_loss_function(cfg, self.device)
         self.model.eval()

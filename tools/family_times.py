@@ -32,7 +32,7 @@ FAMILIES = [
 
 def main(db, steps, out=None, note=""):
     cur = sqlite3.connect(db).cursor()
-    rows = cur.execute("select name, count(*), sum(end-start)/1e6 from kernels group by name").fetchall()
+    rows = cur.execute("select name, count(*), sum(end-start)/1e6 from kernels where name not like '%spin_kernel%' group by name").fetchall()
     fam = {n: [0, 0.0] for n, _ in FAMILIES}
     fam["everything else"] = [0, 0.0]
     for name, c, ms in rows:
