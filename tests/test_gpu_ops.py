@@ -1986,3 +1986,40 @@ def test_abs_max_of_a_tensor(dev):
         for v in (x[:n], x[1:]):
             v = v if v.is_contiguous() else v.contiguous()
             assert float(ops.abs_max(v)) == float(v.abs().max())
+
+
+@pytest.mark.gpu
+def test_two_piece_weight_layout_scales_single_and_batched(dev):
+    """the magnitude pass of the two-piece weight layouts (prep_h2_amax_kernel: 32 workgroups per tensor meet in two scratch
+    words behind the scales, the last one writes { 2^-k, 2^k } and leaves the scratch zero): scales of a 4.7 M-element tensor
+    (FlowNet conv6), a tiny one, an all-zero one and one with an Inf -- through the single call and, after an in-place update of
+    the weights, twice through the batched refresh (a scratch word that was not left zero would show in the second)"""
+    from deeplio_amd import ops
+    g = _g(91)
+    ws = [(torch.randn(1024, 512, 3, 3, generator=g) * 0.01).to(dev), torch.randn(8, 4, 1, 1, generator=g).to(dev),
+          torch.zeros(16, 16, 3, 3, device=dev), (torch.randn(64, 32, 3, 3, generator=g) * 3.0).to(dev)]
+    ws[0][513, 77, 1, 2] = -7.5
+
+    def expect(w):
+        b = float(w.abs().max())
+        return 2.0 ** math.floor(math.log2(16384.0 / b)) if (b > 0 and math.isfinite(b)) else 1.0
+
+    def scales(w):
+        lay = ops.conv_h2_prepped(w, 0)
+        return float(lay[-3]), float(lay[-4]), lay[-2:].tolist()          # 2^k, 2^-k, scratch
+
+    for w in ws:
+        sc, inv, scratch = scales(w)
+        assert sc == expect(w) and inv == 1.0 / sc and scratch == [0.0, 0.0], (tuple(w.shape), sc, expect(w), scratch)
+    for rnd in range(2):
+        with torch.no_grad():
+            ws[0].mul_(5.0)
+            ws[1].mul_(0.01)
+            ws[3].mul_(1.7)
+        ops.weights_changed()                   # next use refreshes every registered layout in one batched launch
+        for w in ws:
+            sc, inv, scratch = scales(w)
+            assert sc == expect(w) and inv == 1.0 / sc and scratch == [0.0, 0.0], (rnd, tuple(w.shape), sc, expect(w), scratch)
+    ws[3][5, 6, 0, 0] = float("inf")            # (a NaN does not take part in a maximum; the element itself stays NaN in the layout)
+    ops.weights_changed()
+    assert scales(ws[3])[0] == 1.0 and scales(ws[3])[2] == [0.0, 0.0]
