@@ -93,8 +93,22 @@ class GradSync:
         on its weight-gradient companion)"""
         if self.world > 1 and self.tail_lo is not None and self._tail_work is None:
             if self.flat_grad.is_cuda:
-                from .functional import join_wgrad_stream
+                from .functional import aux_stream, join_wgrad_stream
                 join_wgrad_stream()     # the tail's weight gradients are forked onto the companion stream
+                # Issued as a SYNCHRONOUS collective under a stream of our own: current process groups launch such a
+                # collective on the current stream, older ones on an internal stream the current one then waits for -- either
+                # way the event below marks its end, the calling (encoder) stream goes on, and in the first case the exchange
+                # sits on the hardware queue functional.assign_streams chose for it (beside a weight-gradient companion)
+                # instead of wherever the runtime puts the group's own stream (DESIGN 6).
+                cur = torch.cuda.current_stream()
+                comm = aux_stream(self.flat_grad.device, "comm")
+                comm.wait_stream(cur)
+                with torch.cuda.stream(comm):
+                    dist.all_reduce(self.flat_grad[self.tail_lo:], op=dist.ReduceOp.SUM)
+                    ev = torch.cuda.Event()
+                    ev.record(comm)
+                self._tail_work = ev
+                return
             self._tail_work = dist.all_reduce(self.flat_grad[self.tail_lo:], op=dist.ReduceOp.SUM, async_op=True)
 
     def broadcast_parameters(self, extra=()):
@@ -151,7 +165,10 @@ class GradSync:
                 join_aux_streams()      # weight gradients are produced on auxiliary HIP streams
             if self._tail_work is not None:
                 dist.all_reduce(self.flat_grad[:self.tail_lo], op=dist.ReduceOp.SUM)
-                self._tail_work.wait()
+                if isinstance(self._tail_work, torch.cuda.Event):
+                    torch.cuda.current_stream().wait_event(self._tail_work)
+                else:
+                    self._tail_work.wait()
                 self._tail_work = None
             else:
                 dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)

@@ -93,8 +93,8 @@ def assign_streams(device, force=False):
     the least used of its (4) hardware queues, i.e. the outcome depends on every stream the process created before (RCCL's,
     another library's, a test's): two heavy streams on one queue run one after the other and the step takes 20.9-21.3 instead
     of 19.0 ms (DESIGN 3).  Candidates come from torch's stream pool and are sorted by queue with dlio_streams_share_queue;
-    the three light streams (IMU branch, reverse directions of the two bidirectional RNNs) each get a stream on the queue of a
-    heavy one that is idle while they run.  Once per device (TrainStep.__init__ calls it); DLIO_ASSIGN_STREAMS=0 leaves the
+    the light streams (IMU branch, reverse directions of the two bidirectional RNNs, the data-parallel exchange) each get a
+    stream on the queue of a heavy one that is idle -- or has slack -- while they run.  Once per device (TrainStep.__init__ calls it); DLIO_ASSIGN_STREAMS=0 leaves the
     streams to their order of first use."""
     if not (torch.cuda.is_available() and device.type == "cuda"):
         return None
@@ -140,8 +140,11 @@ def assign_streams(device, force=False):
     imu = pick([main, enc2], prefer=wg2) or pick([main, enc2]) or any_unused()
     rd_imu = pick([main, enc2, imu], prefer=wg0) or pick([main, imu]) or any_unused()
     rd_main = pick([main, wg0, wg2], prefer=enc2) or pick([main]) or any_unused()
+    # data parallel: the stream the overlapped gradient all-reduce is issued on (dist.GradSync.reduce_tail_async) -- beside a
+    # weight-gradient companion, never on an encoder's queue (a collective there would hold that encoder for its ~3 ms)
+    comm = pick([main, enc2], prefer=wg0) or pick([main, enc2]) or any_unused()
     table = {"encoder2": enc2, "wgrad@%x" % main.cuda_stream: wg0, "wgrad@%x" % enc2.cuda_stream: wg2, "imu": imu,
-             "rnndir@%x" % imu.cuda_stream: rd_imu, "rnndir@%x" % main.cuda_stream: rd_main}
+             "rnndir@%x" % imu.cuda_stream: rd_imu, "rnndir@%x" % main.cuda_stream: rd_main, "comm": comm}
     for name, st in table.items():
         _AUX[(idx, name)] = st
     return table

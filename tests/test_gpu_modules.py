@@ -451,6 +451,8 @@ def test_assign_streams_puts_the_heavy_streams_on_queues_of_their_own(dev):
         assert len({s.cuda_stream for s in heavy + light}) == 7
         assert not ops.streams_share_queue(imu, main) and not ops.streams_share_queue(imu, enc2)
         assert not ops.streams_share_queue(light[1], imu)
+        comm = t["comm"]            # the data-parallel exchange: never on an encoder's queue
+        assert not ops.streams_share_queue(comm, main) and not ops.streams_share_queue(comm, enc2)
         # a second call leaves the table alone
         assert Fh.assign_streams(dev) is None and Fh._AUX[(dev.index or 0, "encoder2")] is enc2
     finally:
