@@ -102,12 +102,23 @@ def assign_streams(device, force=False):
     if (idx in _ASSIGNED and not force) or os.environ.get("DLIO_ASSIGN_STREAMS", "1") == "0":
         return None
     _ASSIGNED.add(idx)
+    with torch.cuda.device(idx):            # (the probe creates events and launches on the CURRENT device)
+        return _assign_streams_on(idx, force)
+
+
+def _assign_streams_on(idx, force):
     main = torch.cuda.current_stream(idx)
     if not force and any(k[0] == idx for k in _AUX):
         return None                  # somebody has run on this device already: leave its streams alone
     for k in [k for k in _AUX if k[0] == idx]:
         del _AUX[k]
-    cands, used = [], set()
+    cands, used, memo = [], set(), {}
+
+    def share(a, b):
+        k = (a.cuda_stream, b.cuda_stream)
+        if k not in memo:
+            memo[k] = memo[(k[1], k[0])] = ops.streams_share_queue(a, b)
+        return memo[k]
 
     def cand(j):
         while len(cands) <= j:
@@ -120,9 +131,9 @@ def assign_streams(device, force=False):
             if j in used:
                 continue
             c = cand(j)
-            if any(ops.streams_share_queue(h, c) for h in avoid):
+            if any(share(h, c) for h in avoid):
                 continue
-            if prefer is not None and not ops.streams_share_queue(prefer, c):
+            if prefer is not None and not share(prefer, c):
                 continue
             used.add(j)
             return c
