@@ -104,28 +104,159 @@ def cpu_parity_probe(cfg, C, H, W, T, S, sample_B, device):
             "probe": "train-mode forward + SE(3) chain + loss, dropout off, same weights and batch, B=%d S=%d" % (sample_B, S)}
 
 
-def cpu_baseline(cfg, C, H, W, T, S, sample_B, steps):
+def cpu_baseline(cfg, C, H, W, T, S, sample_B, steps, threads=None):
     """The oracle (CPU port of the reference's path) on this box's host cores: full training
     step on a bounded sample of the same workload."""
     from oracle import model as om
     ncores = usable_cores()
-    torch.set_num_threads(ncores)
-    model = om.get_model((C, H, W), cfg)
-    model.train()
-    crit = om.get_loss_function(cfg)
-    opt = om.create_optimizer([{'params': model.parameters()}, {'params': crit.parameters()}], cfg,
-                              lr=1e-3, weight_decay=1e-4)
-    batch = synth_batch(99, sample_B, S, C, H, W, T, "cpu")
-    om.train_step(model, crit, opt, batch)            # warm-up
+    keep = torch.get_num_threads()
+    torch.set_num_threads(min(threads, ncores) if threads else ncores)
+    try:
+        model = om.get_model((C, H, W), cfg)
+        model.train()
+        crit = om.get_loss_function(cfg)
+        opt = om.create_optimizer([{'params': model.parameters()}, {'params': crit.parameters()}], cfg,
+                                  lr=1e-3, weight_decay=1e-4)
+        batch = synth_batch(99, sample_B, S, C, H, W, T, "cpu")
+        om.train_step(model, crit, opt, batch)            # warm-up
+        per = []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            om.train_step(model, crit, opt, batch)
+            per.append(time.perf_counter() - t0)
+        dt = sum(per) / steps
+        used = torch.get_num_threads()
+    finally:
+        torch.set_num_threads(keep)
+    return {"value": round(sample_B * S / dt, 4), "unit": "frame-pairs/s", "cores": used,
+            "kind": "port",
+            "s_per_step": [round(v, 2) for v in per],
+            "sample": "oracle (torch-CPU port of the reference path), same model/loss/Adam step, "
+                      "B=%d S=%d 64x2048x%d T=%d, %d timed steps after 1 warm-up, %.2f s/step, %d threads"
+                      % (sample_B, S, C, T, steps, dt, used)}
+
+
+def make_host_batch(seed, B, S, C, H, W, T):
+    """what the reference's DataLoader hands DataCombiCreater.process (misc.py:24-63), in pinned memory (its loader runs with
+    pin_memory): images [B, S+1, 2C, H, W] (C channels per stream: xyz | normals), imus [B, S, T, 6], gts [B, S+1, 15] =
+    rows [position(3), rotation matrix(9), velocity(3)] of a random smooth trajectory"""
+    import numpy as np
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    images = torch.randn(B, S + 1, 2 * C, H, W, generator=g)
+    imus = torch.rand(B, S, T, 6, generator=g)
+    gts = torch.zeros(B, S + 1, 15)
+    rng = np.random.default_rng(seed)
+    for b in range(B):
+        R, t = np.eye(3), np.zeros(3)
+        for f in range(S + 1):
+            w = 0.01 * rng.standard_normal(3)
+            th = float(np.linalg.norm(w))
+            K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]) / max(th, 1e-12)
+            R = R @ (np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K))
+            t = t + 0.1 * rng.standard_normal(3)
+            gts[b, f] = torch.from_numpy(np.concatenate([t, R.reshape(-1), np.zeros(3)]).astype(np.float32))
+    return {'images': images.pin_memory(), 'imus': imus.pin_memory(), 'gts': gts.pin_memory()}
+
+
+def host_fed_region(ts, B, S, C, H, W, T, device, steps, warmup=2, pool=3):
+    """`steps` training steps fed from the HOST (trainer.py:213 + misc.py:24-63): every step takes a pinned host batch (a pool of
+    `pool` distinct ones, cycled) -- H2D copies and DataCombiCreater's kernels (pair gather + channel split, ground-truth
+    transform) are issued on the 'feed' stream one step AHEAD of the step that consumes them (double-buffered: while step i
+    runs, batch i+1 crosses PCIe), the step's stream waits for the batch's event.  -> seconds per step (steady state)"""
+    import numpy as np
+    from deeplio_amd import functional as Fh
+    from deeplio_amd import misc
+    comb = np.asarray([[i, i + 1] for i in range(S)])
+    feed = Fh.aux_stream(device, "feed")
+    dc = misc.DataCombiCreater(comb, device=device, c_split=C)
+    hosts = [make_host_batch(4321 + i, B, S, C, H, W, T) for i in range(pool)]
+    main = torch.cuda.current_stream()
+
+    def stage(i):
+        feed.wait_stream(main)             # (nothing of the step in flight is touched; orders the very first copy)
+        with Fh.on_stream(feed):
+            dc.process(hosts[i % pool])
+            out = (dc.res_imgs, dc.res_normals, dc.res_imu, dc.res_gt_f2f, dc.res_gt_f2g)
+            ev = torch.cuda.Event()
+            ev.record(feed)
+        return out, ev
+
+    nxt = stage(0)
+    t0 = None
+    for i in range(warmup + steps):
+        if i == warmup:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        cur, nxt = nxt, None
+        main.wait_event(cur[1])
+        for t in cur[0]:
+            t.record_stream(main)
+        nxt = stage(i + 1)                 # the next batch crosses PCIe under this step
+        ts.step(*cur[0])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    dc.check()
+    h2d = sum(v.numel() * v.element_size() for v in hosts[0].values())
+    return dt, h2d
+
+
+# BASELINE.json configs[2] / [3] / [4] at their per-GPU batch (global batch / DP degree), as short driver-run sub-lines.
+# GF / MB per frame pair: SURVEY 8(d) (forward conv FLOPs + RNN; fused-minimum bytes forward, fp32; training = 3 x).
+SUB_CONFIGS = (
+    dict(key="configs[2]", lidar="lidar-feat-flownet", imu="imu-feat-rnn", fusion="fusion-layer-cat", odom="odom-feat-rnn",
+         overrides={'imu-feat-rnn/type': 'gru'}, C=3, S=2, B=4, dtype="f32", gf=172.64 + 0.111, mb=363.0,
+         workload="BASELINE configs[2]: lidar-feat-flownet + imu-feat-rnn GRU (bi-GRU-128x2) + fusion-layer-cat + odom-feat-rnn "
+                  "bi-LSTM-1024x2, 64x2048x3, T=50, S=2, global bs=16 at DP=4 = per-GPU batch 4 (this line: one rank's share)"),
+    dict(key="configs[3]", lidar="lidar-feat-resnet", imu="imu-feat-rnn", fusion="fusion-layer-cat", odom="odom-feat-rnn",
+         overrides={'lidar-feat-resnet/fusion': 'cat'}, C=3, S=2, B=4, dtype="f32", gf=178.31 + 0.124, mb=866.0,
+         workload="BASELINE configs[3]: lidar-feat-resnet (fusion=cat, build-defined: SURVEY Q1) + imu-feat-rnn bi-LSTM-128x2 + "
+                  "fusion-layer-cat + odom-feat-rnn bi-LSTM-1024x2, 64x2048x3 (KITTI geometry, synthetic data), T=50, S=2, "
+                  "global bs=32 at DP=8 = per-GPU batch 4 (this line: one rank's share)"),
+    dict(key="configs[4]", lidar="lidar-feat-pointseg", imu="imu-feat-rnn", fusion="fusion-layer-soft", odom="odom-feat-rnn",
+         overrides={'lidar-feat-pointseg/precision': 'bf16', 'losses/rotation': 'geodesic'}, C=5, S=4, B=8, dtype="bf16",
+         gf=36.13 + 0.124, mb=957.0 / 2,
+         workload="BASELINE configs[4]: full DeepLIO (PointSeg + bi-LSTM-128x2 + fusion-layer-soft + odom-feat-rnn bi-LSTM-1024x2) "
+                  "bf16 mixed precision, geodesic pose loss (HWS), 64x2048x5, T=50, seq_len=4, global bs=64 at DP=8 = per-GPU "
+                  "batch 8 (this line: one rank's share)"),
+)
+
+
+def config_line(sc, device, steps, warmup=3):
+    """one short training-throughput line for a BASELINE config other than the headline: same TrainStep, same timing rule
+    (device syncs on both sides of `steps` steps), the whole-step roofline view on SURVEY 8(d)'s algorithmic figures"""
+    import gc as _gc
+    from deeplio_amd.config import make_config
+    from deeplio_amd.trainer import TrainStep
+    cfg = make_config(lidar=sc["lidar"], imu=sc["imu"], fusion=sc["fusion"], odom=sc["odom"], seq=sc["S"],
+                      overrides=sc["overrides"])
+    torch.manual_seed(20260928)
+    ts = TrainStep(cfg, (sc["C"], 64, 2048), device, sc["B"])
+    batch = synth_batch(1234, sc["B"], sc["S"], sc["C"], 64, 2048, 50, device)
+    for _ in range(warmup):
+        ts.step(*batch)
+    ts.check()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        om.train_step(model, crit, opt, batch)
+        loss = ts.step(*batch)
+    torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    return {"value": round(sample_B * S / dt, 4), "unit": "frame-pairs/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": "oracle (torch-CPU port of the reference path), same model/loss/Adam step, "
-                      "B=%d S=%d 64x2048x%d T=%d, %d timed steps after 1 warm-up, %.2f s/step"
-                      % (sample_B, S, C, T, steps, dt)}
+    ts.check()
+    v = sc["B"] * sc["S"] / dt
+    tf, gbs = v * 3 * sc["gf"] * 1e9 / 1e12, v * 3 * sc["mb"] * 1e6 / 1e9
+    out = {"config": sc["key"], "workload": sc["workload"], "value": round(v, 2), "unit": "frame-pairs/s",
+           "ms_per_step": round(1e3 * dt, 3), "steps": steps, "warmup": warmup, "dtype": sc["dtype"],
+           "frame_pairs_per_step": sc["B"] * sc["S"], "loss": float(loss.item()),
+           "roofline": {"step": {
+               "mfma": {"achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS if sc["dtype"] == "f32" else 2516.8,
+                        "unit": "TFLOP/s",
+                        "frac": round(tf / (PEAK_F32_MFMA_TFLOPS if sc["dtype"] == "f32" else 2516.8), 4)},
+               "hbm": {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)}}}}
+    ts.release_gc()
+    del ts, batch, loss
+    _gc.collect()
+    torch.cuda.empty_cache()
+    return out
 
 
 def self_launch(n, dry_run):
@@ -200,13 +331,25 @@ def main():
     ap.add_argument("--seq", type=int, default=None, help="frame pairs per sample (S); default 2 (4 with --dtype bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8, help="samples per CPU-baseline step (default: the timed batch itself)")
-    ap.add_argument("--cpu-steps", type=int, default=1)
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps (BASELINE.md: >= 3) after 1 warm-up")
+    ap.add_argument("--cpu8-batch", type=int, default=4,
+                    help="samples per step of the extra 8-thread CPU line (BASELINE.md section 2; 0 = skip it)")
+    ap.add_argument("--cpu8-steps", type=int, default=2)
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the short sub-lines for BASELINE configs[2] / [3] / [4] (\"configs\" in the JSON line)")
+    ap.add_argument("--config-steps", type=int, default=6, help="timed steps per sub-line (>= 5)")
+    ap.add_argument("--host-batch", action="store_true",
+                    help="time the steps HOST-FED: a fresh pinned host batch per step through DataCombiCreater on a copy "
+                         "stream, double-buffered (the default line reports this figure as well, under \"host_fed\")")
+    ap.add_argument("--host-steps", type=int, default=10, help="steps of the host-fed region of the default line (0 = skip)")
     ap.add_argument("--lidar", default="lidar-feat-pointseg", help="informational runs of the other families")
     ap.add_argument("--imu", default="imu-feat-rnn")
     ap.add_argument("--fusion", default="fusion-layer-soft")
     ap.add_argument("--odom", default="odom-feat-rnn")
     ap.add_argument("--channels", type=int, default=5, help="range-image channels per stream (C)")
-    ap.add_argument("--no-isolated", action="store_true", help="skip the non-overlapped roofline pass")
+    ap.add_argument("--no-isolated", action="store_true",
+                    help="diagnosis runs: skip the per-family roofline pre-passes AND the extras of the default line "
+                         "(host-fed region, sub-lines for configs[2] / [3] / [4])")
     ap.add_argument("--iso-steps", type=int, default=3)
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32: the headline (BASELINE configs[1]).  bf16: informational line for BASELINE configs[4] -- "
@@ -552,12 +695,28 @@ def main():
                        "bn_coop": bool(ops._BN_COOP[0])},
             "roofline": roofline,
         }
+        if world == 1 and headline and (args.host_batch or (args.host_steps > 0 and not args.no_isolated)) and not args.serial:
+            hs = args.steps if args.host_batch else args.host_steps
+            hdt, h2d = host_fed_region(ts, B, S, C, H, W, T, device, hs)
+            ts.check()
+            out["host_fed"] = {
+                "value": round(B * S / hdt, 3), "unit": "frame-pairs/s", "ms_per_step": round(1e3 * hdt, 3), "steps": hs,
+                "vs_device_resident": round((B * S / hdt) / value, 4), "h2d_bytes_per_step": h2d,
+                "what": "the same step fed from the HOST: a pinned host batch per step (pool of 3 distinct ones) -> H2D + "
+                        "DataCombiCreater (pair gather + channel split, ground-truth transform; misc.py:24-63) on a copy "
+                        "stream one step ahead (double-buffered), the step waits for the batch's event; `value` above is "
+                        "the device-resident figure the contract asks for"}
+        if world == 1 and headline and not args.no_configs and not args.no_isolated and not args.serial:
+            out["configs"] = [config_line(sc, device, max(5, args.config_steps)) for sc in SUB_CONFIGS]
         if dist_info is not None:
             # what the N > 1 line rests on: the backend and the world size read back from the process group, a collective only
             # N ranks answer correctly, the part of the gradient exchange the step waited for, the overlap switch
             out["dist"] = dist_info
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, C, H, W, T, S, args.cpu_batch, args.cpu_steps)
+            if args.cpu8_batch > 0 and usable_cores() > 8:
+                # the n = 8 thread line beside the all-cores one (comparable with SURVEY's 8-core probe)
+                out["cpu_baseline"]["threads_8"] = cpu_baseline(cfg, C, H, W, T, S, args.cpu8_batch, args.cpu8_steps, threads=8)
             out["cpu_baseline"].update(cpu_parity_probe(cfg, C, H, W, T, S, args.cpu_batch, device))
         print(json.dumps(out))
     if world > 1:

@@ -154,8 +154,12 @@ def _assign_streams_on(idx, force):
     # data parallel: the stream the overlapped gradient all-reduce is issued on (dist.GradSync.reduce_tail_async) -- beside a
     # weight-gradient companion, never on an encoder's queue (a collective there would hold that encoder for its ~3 ms)
     comm = pick([main, enc2], prefer=wg0) or pick([main, enc2]) or any_unused()
+    # host-fed training: the stream the NEXT batch's H2D copies + DataCombiCreater kernels are issued on (a barrier packet
+    # behind a ~2.5 ms PCIe copy holds its hardware queue: beside a weight-gradient companion, which is idle during the
+    # forward pass the copy runs under -- never on an encoder's queue)
+    feed = pick([main, enc2], prefer=wg0) or pick([main, enc2]) or any_unused()
     table = {"encoder2": enc2, "wgrad@%x" % main.cuda_stream: wg0, "wgrad@%x" % enc2.cuda_stream: wg2, "imu": imu,
-             "rnndir@%x" % imu.cuda_stream: rd_imu, "rnndir@%x" % main.cuda_stream: rd_main, "comm": comm}
+             "rnndir@%x" % imu.cuda_stream: rd_imu, "rnndir@%x" % main.cuda_stream: rd_main, "comm": comm, "feed": feed}
     for name, st in table.items():
         _AUX[(idx, name)] = st
     return table

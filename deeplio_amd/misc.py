@@ -85,8 +85,11 @@ class DataCombiCreater(object):
     (deeplio_amd/csrc/batchprep.hip); `untrans-images` is only processed on request
     (`with_untransformed=True`), the hot loop never reads it."""
 
-    def __init__(self, combinations, device='cpu', with_untransformed=False):
+    def __init__(self, combinations, device='cpu', with_untransformed=False, c_split=3):
+        """c_split: channels of the first stream (misc.py:66-68 hard-codes 0:3 | 3: -- xyz | normals of the KITTI path;
+        synthetic per-stream channel counts, BASELINE's "x5", pass their own)"""
         import torch
+        self.c_split = int(c_split)
         self.combinations = combinations
         self.device = torch.device(device)
         self.seq_size = get_config_container().seq_size
@@ -113,7 +116,7 @@ class DataCombiCreater(object):
 
     def process_images(self, imgs):
         from . import ops
-        return ops.pair_stack(imgs.float().contiguous(), self._comb, 3)      # misc.py:66-68: 0:3 | 3:
+        return ops.pair_stack(imgs.float().contiguous(), self._comb, self.c_split)      # misc.py:66-68: 0:3 | 3:
 
     def process_ground_turth(self, gts):
         """single-sample form of the reference API: gts [S+1, 15] -> (f2f [S,6], f2g [S,7])"""

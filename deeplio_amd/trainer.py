@@ -48,6 +48,13 @@ class TrainStep:
         self.gc_every = int(os.environ.get("DLIO_GC_EVERY", "100"))
         self._gc_armed = False
         self._steps = 0
+        # Device-side error words (non-finite output, det != 1, a cooperative BatchNorm launch at its spin limit) are
+        # polled WITHOUT a host sync: every `check_every` steps they are copied asynchronously into pinned memory and the
+        # copy issued `check_every` steps earlier (long complete) is inspected -- a bad step raises at most 2 x check_every
+        # steps later instead of training on until somebody calls check().  0 switches the polling off.
+        self.check_every = int(os.environ.get("DLIO_CHECK_EVERY", "8"))
+        self._poll_pending = None
+        self._poll_host = None
         self.model.train()
         if grad_sync is not None:
             self.set_grad_sync(grad_sync)
@@ -66,6 +73,8 @@ class TrainStep:
     def set_grad_sync(self, sync):
         """data parallel: gradient exchange in two buckets, the tail one overlapped with backward"""
         self.grad_sync = sync
+        if sync is not None and sync.world > 1 and "DLIO_CHECK_EVERY" not in os.environ:
+            self.check_every = 1          # beside RCCL's kernels the cooperative launches are least certain of their partners
         if sync is not None and sync.world > 1:
             sync.set_tail(self.tail_offset())
             self.model.tail_grads_ready = sync.reduce_tail_async if sync.tail_lo is not None else None
@@ -144,10 +153,39 @@ class TrainStep:
         if self.grad_sync is not None:
             self.grad_sync.all_reduce_grads()
         self.optimizer.step()
+        if self.check_every > 0 and self._steps % self.check_every == 0:
+            self._poll()
         return loss.detach()
+
+    def _poll(self):
+        """inspect the error words copied at the previous poll, then start the next asynchronous copy"""
+        pend = self._poll_pending
+        self._poll_pending = None
+        if pend is not None:
+            host, ev = pend
+            ev.synchronize()               # recorded check_every steps ago: complete unless the host runs that far ahead
+            h = host.tolist()
+            if h[0] or (h[1] & 1) or any(h[2:]):      # (flags[1] bit 1 only records a re-orthonormalisation: not an error)
+                self.check()               # raises (and re-initialises / falls back for the cooperative kernels)
+        if self.device.type != "cuda":
+            return
+        words = [self.flags] + [e[1][0:1] for e in ops._COOP_WS.values()]
+        n = sum(w.numel() for w in words)
+        if self._poll_host is None or self._poll_host[0].numel() < n:
+            self._poll_host = [torch.zeros(max(n, 32), dtype=torch.int32).pin_memory() for _ in range(2)]
+        self._poll_host.reverse()          # two pinned buffers, alternating: the one just inspected is the free one
+        host = self._poll_host[0][:n]
+        o = 0
+        for w in words:                    # copy engine, no kernel launch: a few 4-byte D2H copies per poll
+            host[o:o + w.numel()].copy_(w, non_blocking=True)
+            o += w.numel()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._poll_pending = (host, ev)
 
     def check(self):
         """raise like trainer.py:240-243 / :341-348 if any step since the last check went bad"""
+        self._poll_pending = None
         f = self.flags.tolist()
         self.flags.zero_()
         if f[0]:

@@ -22,7 +22,7 @@ def _run(*extra):
 
 
 def test_bench_json_contract(dev):
-    d = _run("--no-cpu-baseline", "--iso-steps", "1")
+    d = _run("--no-cpu-baseline", "--iso-steps", "1", "--no-configs", "--host-steps", "0")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in d, k
@@ -72,11 +72,38 @@ def test_bench_json_contract(dev):
 
 
 def test_bench_cpu_baseline_object(dev):
-    d = _run("--no-isolated", "--cpu-steps", "1", "--cpu-batch", "1")
+    d = _run("--no-isolated", "--cpu-steps", "2", "--cpu-batch", "1", "--cpu8-batch", "1", "--cpu8-steps", "1", "--no-configs",
+             "--host-steps", "0")
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] == "port" and c["unit"] == d["unit"] and c["cores"] >= 1 and c["value"] > 0
+    assert len(c["s_per_step"]) == 2 and "2 timed steps" in c["sample"]
+    if c["cores"] > 8:                     # the n = 8 thread line beside the all-cores one
+        c8 = c["threads_8"]
+        assert c8["cores"] == 8 and c8["kind"] == "port" and c8["value"] > 0
+    assert c["loss_rel_err_vs_oracle"] < 1e-4
+
+
+def test_bench_sub_lines_and_host_fed(dev):
+    """the default line also carries (a) short driver-run lines for BASELINE configs[2] / [3] / [4] at their per-GPU batch --
+    FlowNet + GRU + fusion-layer-cat, ResNet(cat) + bi-LSTM, bf16 PointSeg S = 4 with the geodesic loss -- and (b) the
+    host-fed figure: the same step with a pinned host batch per step through DataCombiCreater on the copy stream"""
+    d = _run("--no-cpu-baseline", "--iso-steps", "1", "--host-steps", "4", "--config-steps", "5")
+    subs = d["configs"]
+    assert [s["config"] for s in subs] == ["configs[2]", "configs[3]", "configs[4]"]
+    for s, (fp, dt, words) in zip(subs, ((8, "f32", ("lidar-feat-flownet", "GRU", "fusion-layer-cat")),
+                                         (8, "f32", ("lidar-feat-resnet", "fusion=cat", "bi-LSTM")),
+                                         (32, "bf16", ("bf16", "geodesic", "seq_len=4")))):
+        assert s["steps"] >= 5 and s["frame_pairs_per_step"] == fp and s["dtype"] == dt
+        assert all(w in s["workload"] for w in words), s["workload"]
+        assert abs(s["value"] - fp / (s["ms_per_step"] * 1e-3)) <= 1e-2 * s["value"]
+        r = s["roofline"]["step"]
+        assert 0 < r["mfma"]["frac"] < 1 and 0 < r["hbm"]["frac"] < 1
+        assert s["loss"] == s["loss"] and abs(s["loss"]) < 1e6          # finite
+    h = d["host_fed"]
+    assert h["steps"] == 4 and h["value"] > 0 and h["h2d_bytes_per_step"] > 100e6
+    assert abs(h["vs_device_resident"] - h["value"] / d["value"]) <= 1e-3
 
 
 def _run_env(env, *extra):
@@ -91,7 +118,7 @@ def _run_env(env, *extra):
 def test_bench_self_launch_one_rank(dev):
     """--gpus 1 through the launcher that `python bench.py --gpus N` uses when no torchrun set WORLD_SIZE"""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    d = _run_env(env, "--gpus", "1", "--spawn", "--no-cpu-baseline", "--no-isolated")
+    d = _run_env(env, "--gpus", "1", "--spawn", "--no-cpu-baseline", "--no-isolated", "--no-configs", "--host-steps", "0")
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "dp1"
 
 
