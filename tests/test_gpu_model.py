@@ -748,6 +748,18 @@ def _hip_decisions(model, loss):
             t = node.saved_tensors                                             # x, w1, w2, g, h, s, idx
             key = tuple(ptr[t[1].data_ptr()].split(".")[1:3]) + ("pool",)
             dec[key] = dict(idx=t[6].cpu())
+        elif name == "ConvBnActBackward":                                      # plain conv + BN (+ ReLU) layers: FlowNet, ResNet
+            t = node.saved_tensors                                             # x, weight, beta, raw, prm, gamma, bias
+            if node.cfg[3]:                                                    # post_relu
+                dec[("cbr", ptr[t[1].data_ptr()][:-len(".weight")])] = dict(mask=_relu_mask(t[3], tuple(t[4]), t[2]))
+        elif name == "MaxPoolFnBackward":                                      # (ResNet: one per encoder, behind conv1 + bn1)
+            src = node.next_functions[0][0]
+            key = ("pool", ptr[src.saved_tensors[1].data_ptr()].split(".")[1])
+            dec[key] = dict(idx=node.saved_tensors[0].cpu())
+        elif name == "BinaryFnBackward" and node.op == 3:                      # BasicBlock tail relu(bn2(conv2(.)) + identity)
+            src = node.next_functions[0][0]                                    # the bn2 node
+            blk = ptr[src.saved_tensors[1].data_ptr()][:-len(".conv2.weight")]
+            dec[("tail", blk)] = dict(mask=(node.saved_tensors[0] > 0).cpu())
     return dec
 
 
@@ -790,11 +802,24 @@ def _pinned_encoder_forward(enc, ename, dec):
     return fwd
 
 
-@pytest.mark.parametrize("B", [1, 4])
+def _mem_available_gb():
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    return int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
+
+
+@pytest.mark.parametrize("B", [1, 4, 8])
 def test_headline_encoder_gradients_with_the_decisions_pinned(dev, B):
     """The envelope of test_headline_shape_gradients_vs_oracle turned into a test of the kernels: at the headline geometry
-    (64x2048x5, B = 1 and B = 4 -- N = 8 images per encoder: planes cut into parts, the routing of the timed launch size --,
-    S = 2, train mode) the fp64 oracle is run with the ReLU masks and max-pool arg-max maps THE HIP
+    (64x2048x5, B = 1, B = 4 -- N = 8 images per encoder: planes cut into parts -- and B = 8: N = 16, THE LAUNCH bench.py times
+    (part counts of the cooperative BatchNorm kernels, K-splits and slab counts of the weight gradients are those of the timed
+    step), S = 2, train mode) the fp64 oracle (at B = 8 on a host without ~150 GB of free memory: the fp32 oracle with the same
+    pinned decisions, itself measured 7e-5 from fp64 -- the bound is then 2e-4 = both sides' distance from fp64) is run with the ReLU masks and max-pool arg-max maps THE HIP
     FORWARD USED (read off its tape: raw convolution outputs + BatchNorm parameters through the library's own backward
     mask, the uint8 arg-max maps) instead of deciding them itself.  With the decisions equal, the 1e-2 disagreement of any
     two fp32 evaluations of this network is gone and `loss.backward()` of the HIP path (trainer.py:263-281) must match the
@@ -833,7 +858,13 @@ def test_headline_encoder_gradients_with_the_decisions_pinned(dev, B):
         g = {k: p.grad.double() for k, p in m.named_parameters() if p.grad is not None}
         g["criterion.sx"], g["criterion.sq"] = c.sx.grad.double(), c.sq.grad.double()
         return float(lo.detach()), g
-    lo, g64 = pinned_oracle(torch.float64)
+    # fp64 activations of the pinned oracle: ~4.5 GB per frame pair per encoder pair (B = 4: ~40 GB; B = 8: ~75 GB + the masks)
+    ref64 = B < 8 or _mem_available_gb() > 150.0
+    if B == 8 and not ref64 and _mem_available_gb() < 60.0:
+        pytest.skip("the pinned oracle at B = 8 needs ~40 GB of host memory in fp32 (%.0f GB available)" % _mem_available_gb())
+    tol = TOL if ref64 else 2.0 * TOL
+    lo, g64 = pinned_oracle(torch.float64 if ref64 else torch.float32)
+    print("pinned oracle: %s (MemAvailable %.0f GB)" % ("fp64" if ref64 else "fp32", _mem_available_gb()))
     assert abs(float(loss.detach()) - lo) <= TOL * abs(lo)
     named = dict(model.named_parameters())
     named["criterion.sx"], named["criterion.sq"] = crit.sx, crit.sq
@@ -852,7 +883,9 @@ def test_headline_encoder_gradients_with_the_decisions_pinned(dev, B):
     for k, e in sorted(rows, key=lambda r: -r[1])[:5]:
         print("   %-64s %.2e" % (k, e))
     assert len(enc_rows) > 200
-    over = [r for r in rows if r[1] > TOL]
+    over = [r for r in rows if r[1] > tol]
+    if over and not ref64:
+        raise AssertionError("over %.0e against the fp32 pinned oracle: %r" % (tol, over))
     if over:
         # A parameter gradient that is a heavily cancelling sum (the stem's BatchNorm bias at N = 8 images: the gradient field
         # behind a BatchNorm backward has zero mean per channel, d loss / d beta sums 4 M signed terms of it) is not computable
@@ -894,3 +927,234 @@ def test_reference_arithmetic_disagrees_with_itself_across_thread_counts(dev):
     print("torch fp32, 1 thread vs 8 threads: encoder gradients rel-L2 median %.2e max %.2e | behind the encoders median %.2e "
           "max %.2e" % (np.median(enc), enc.max(), np.median(rest), rest.max()))
     assert np.median(enc) > 10 * TOL and rest.max() < 10 * TOL
+
+
+def _pinned_flownet_forward(enc, prefix, dec):
+    """FlowNetEncoder.forward of the oracle (lidar_feat_nets.py:240-267) with every ReLU replaced by the given mask"""
+    from oracle import model as om
+
+    def fwd(x):
+        for name, *_ in om.FLOWNET_LAYERS:
+            seq = getattr(enc, name)
+            x = seq[1](seq[0](x)) * dec[("cbr", "%s.%s.0" % (prefix, name))]["mask"].to(x.dtype)
+        return x.mean((2, 3))
+    return fwd
+
+
+def _pinned_resnet_forward(enc, prefix, dec):
+    """ResNetEncoder.forward of the oracle (resnet.py:94-112 + torchvision BasicBlock) with the ReLU masks of conv1 / every
+    block's first convolution / every block tail and the max-pool's arg-max map given instead of decided"""
+    def fwd(x):
+        x = enc.bn1(enc.conv1(x)) * dec[("cbr", prefix + ".conv1")]["mask"].to(x.dtype)
+        x = _pool_by_index(x, dec[("pool", prefix.split(".")[1])]["idx"], (1, 2))
+        for i in range(4):
+            for j, blk in enumerate(getattr(enc, "layer%d" % (i + 1))):
+                p = "%s.layer%d.%d" % (prefix, i + 1, j)
+                idt = x if blk.downsample is None else blk.downsample(x)
+                out = blk.bn1(blk.conv1(x)) * dec[("cbr", p + ".conv1")]["mask"].to(x.dtype)
+                out = blk.bn2(blk.conv2(out))
+                x = (out + idt) * dec[("tail", p)]["mask"].to(x.dtype)
+        return x.mean((2, 3))
+    return fwd
+
+
+@pytest.mark.parametrize("lidar,imu_type,C", [("lidar-feat-flownet", "gru", 3), ("lidar-feat-resnet", "lstm", 3)])
+def test_other_families_encoder_gradients_with_the_decisions_pinned(dev, lidar, imu_type, C):
+    """BASELINE configs[2] / configs[3] at their real geometry (64x2048, C = 3 per stream), B = 2, S = 2 (N = 4 images per
+    encoder), train mode: `loss.backward()` of the HIP path (trainer.py:263-281) against the fp64 oracle run with the ReLU
+    masks (conv + BN + ReLU layers, BasicBlock tails) and the max-pool arg-max map THE HIP FORWARD USED -- every parameter,
+    the encoders included (lidar_feat_nets.py:240-267: FlowNet's 5x7 / 3x5 strided stems, 3x3 stride-2 layers; resnet.py:14-112:
+    the 5x7 full-resolution stem, BasicBlocks with (1, 2) / (2, 2) downsampling): the phase-decomposed data gradients, the
+    tap-wise stride-2 weight gradients and the two-piece fp16 layers are held to <= 1e-4 relative L2 per parameter (a heavily
+    cancelling sum -- a BatchNorm bias behind millions of signed terms -- to three times the error of torch fp32 under the
+    same pinned decisions, as in the PointSeg test above)."""
+    from deeplio_amd import losses, misc, nets
+    from deeplio_amd.config import make_config
+    from oracle import model as om
+    from oracle import se3 as ose3
+    B = 2
+    cfg = make_config(lidar=lidar, imu="imu-feat-rnn", fusion="fusion-layer-cat", odom="odom-feat-rnn", seq=2,
+                      overrides=dict(gc.NO_DROP, **{'imu-feat-rnn/type': imu_type}))
+    misc.build_config_container(cfg, types.SimpleNamespace(device=str(dev), batch_size=B))
+    model = nets.get_model((C, 64, 2048), cfg, dev)
+    gc.fill_state(model, seed=1000)
+    model.train()
+    crit = losses.get_loss_function(cfg, dev)
+    batch = gc.make_batch(11, B, 2, C, 64, 2048, 50)
+    *_, loss = hip_step_forward(model, crit, tuple(t.to(dev) for t in batch))
+    dec = _hip_decisions(model, loss)
+    flownet = lidar == "lidar-feat-flownet"
+    assert len(dec) == (2 * 9 if flownet else 2 * (1 + 1 + 11 + 11)), sorted(dec)     # ResNet: conv1, pool, 11 x (conv1, tail)
+    loss.backward()
+    torch.cuda.synchronize()
+
+    def pinned_oracle(dtype):
+        m = om.get_model((C, 64, 2048), cfg)
+        gc.fill_state(m, seed=1000)
+        m, c = m.to(dtype).train(), om.get_loss_function(cfg).to(dtype)
+        for ename in ("encoder1", "encoder2"):
+            enc = getattr(m.lidar_feat_net, ename)
+            enc.forward = (_pinned_flownet_forward if flownet else _pinned_resnet_forward)(enc, "lidar_feat_net." + ename, dec)
+        xyz, nrm, imu, f2f, f2g = (t.to(dtype) for t in batch)
+        a, b = m([[xyz, nrm], imu])
+        p2, q2 = ose3.se3_to_SE3(a, b)
+        lo = c(a, b, p2[:, 1:3], q2[:, 1:3], f2f[:, :, 0:3], f2f[:, :, 3:], f2g[:, 1:3, 0:3], f2g[:, 1:3, 3:7])
+        lo.backward()
+        g = {k: p.grad.double() for k, p in m.named_parameters() if p.grad is not None}
+        g["criterion.sx"], g["criterion.sq"] = c.sx.grad.double(), c.sq.grad.double()
+        return float(lo.detach()), g
+    lo, g64 = pinned_oracle(torch.float64)
+    assert abs(float(loss.detach()) - lo) <= TOL * abs(lo)
+    named = dict(model.named_parameters())
+    named["criterion.sx"], named["criterion.sq"] = crit.sx, crit.sq
+    gmax = max(float(v.abs().max()) for v in g64.values())
+    rows = []
+    for k, ref in g64.items():
+        mine = named[k].grad.detach().double().cpu()
+        if float(ref.abs().max()) < 1e-5 * gmax:
+            assert float(mine.abs().max()) < 1e-4 * gmax, k
+            continue
+        rows.append((k, _l2(mine, ref)))
+    errs = np.asarray([r[1] for r in rows])
+    enc_rows = [r for r in rows if r[0].startswith("lidar_feat_net.encoder")]
+    print("%s, pinned decisions, rel-L2 vs fp64 over %d parameters (%d in the encoders): median %.2e max %.2e"
+          % (lidar, len(rows), len(enc_rows), np.median(errs), errs.max()))
+    for k, e in sorted(rows, key=lambda r: -r[1])[:5]:
+        print("   %-64s %.2e" % (k, e))
+    assert len(enc_rows) >= (2 * 9 * 3 - 4 if flownet else 100)
+    over = [r for r in rows if r[1] > TOL]
+    if over:
+        _, g32 = pinned_oracle(torch.float32)
+        for k, e in over:
+            e32 = _l2(g32[k], g64[k])
+            print("   over 1e-4: %-52s HIP %.2e | torch fp32 with the same decisions %.2e" % (k, e, e32))
+            assert e <= 3.0 * e32, (k, e, e32)
+        assert len(over) <= 6 and all(".bias" in k or "bn" in k for k, _ in over), over
+
+
+def _imu_forward_with_masks(net, masks, p):
+    """ImufeatRNN0.forward of the oracle (imu_feat_nets.py:75-83) with nn.LSTM's inter-layer dropout (drawn inside the fused
+    nn.LSTM call, not injectable) replaced by the given masks: the two layers run as two single-layer bidirectional nn.LSTMs
+    that SHARE the 2-layer module's Parameters (gradients land in the oracle model), state carried per layer from sub-sequence
+    s to s + 1 exactly as the stacked call carries it"""
+    rnn = net.rnn
+    H = rnn.hidden_size
+    dtype = rnn.weight_ih_l0.dtype
+
+    def layer(l):
+        m = torch.nn.LSTM(rnn.input_size if l == 0 else 2 * H, H, 1, bidirectional=True, batch_first=True).to(dtype)
+        for sfx in ("", "_reverse"):
+            for nm in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                setattr(m, "%s_l0%s" % (nm, sfx), getattr(rnn, "%s_l%d%s" % (nm, l, sfx)))
+        return m
+    l0, l1 = layer(0), layer(1)
+
+    def fwd(x):
+        b, s, t, n = x.shape
+        st0 = st1 = None
+        outs = []
+        for i in range(s):
+            o0, st0 = l0(x[:, i], st0)
+            o0 = o0 * masks[i].view(b, t, 2 * H).to(o0.dtype) / (1.0 - p)
+            o1, st1 = l1(o0, st1)
+            outs.append(o1.view(b, t, 2, H)[:, -1, 0, :])
+        return torch.stack(outs, 1)
+    return fwd
+
+
+def test_headline_step_with_dropout_on_and_the_masks_copied_into_the_oracle(dev):
+    """BASELINE configs[1] as bench.py times it -- dropout ON (lidar head 0.1, nn.LSTM inter-layer 0.1 in the IMU net, 0.25 in
+    front of the heads: lidar_feat_nets.py:97-99, imu_feat_nets.py:62-66, deeplio_nets.py:84-86) -- at 64x2048x5, B = 1, S = 2,
+    train mode: the masks the HIP kernels drew (Philox, deeplio_amd.functional._dropout_launch) are copied into the fp64 oracle
+    together with the encoders' ReLU / arg-max decisions; loss and EVERY parameter gradient then agree to 1e-4 -- the scaling by
+    1 / (1 - p), the mask re-use in backward and the RNN's inter-layer site included."""
+    from deeplio_amd import functional as Fh
+    from deeplio_amd import losses, misc, nets
+    from deeplio_amd.config import make_config
+    from oracle import model as om
+    from oracle import se3 as ose3
+    B = 1
+    cfg = make_config(seq=2)
+    assert cfg['deeplio']['dropout'] == 0.25 and cfg['lidar-feat-pointseg']['dropout'] == 0.1 and cfg['imu-feat-rnn']['dropout'] == 0.1
+    misc.build_config_container(cfg, types.SimpleNamespace(device=str(dev), batch_size=B))
+    model = nets.get_model((5, 64, 2048), cfg, dev)
+    gc.fill_state(model, seed=1000)
+    model.train()
+    crit = losses.get_loss_function(cfg, dev)
+    batch = gc.make_batch(7, B, 2, 5, 64, 2048, 50)
+    drawn = []
+    launch = Fh._dropout_launch
+
+    def recording(x, p):
+        y, mask = launch(x, p)
+        drawn.append((tuple(x.shape), p, mask))
+        return y, mask
+    Fh._dropout_launch = recording
+    try:
+        *_, loss = hip_step_forward(model, crit, tuple(t.to(dev) for t in batch))
+    finally:
+        Fh._dropout_launch = launch
+    # issue order (nets.DeepLIO.forward_features / forward_tail): the IMU net's S inter-layer sites, the lidar head, the heads
+    assert [(s, p) for s, p, _ in drawn] == [((B * 50, 256), 0.1)] * 2 + [((B * 2, 128), 0.1), ((B, 2, 1024), 0.25)], drawn
+    masks = [m.cpu() for _, _, m in drawn]
+    for m, (_, p, _) in zip(masks, drawn):
+        assert set(m.unique().tolist()) <= {0, 1} and abs(float(m.float().mean()) - (1 - p)) < 0.1
+    dec = _hip_decisions(model, loss)
+    loss.backward()
+    torch.cuda.synchronize()
+    m = om.get_model((5, 64, 2048), cfg)
+    gc.fill_state(m, seed=1000)
+    m, c = m.double().train(), om.get_loss_function(cfg).double()
+    for ename in ("encoder1", "encoder2"):
+        enc = getattr(m.lidar_feat_net, ename)
+        enc.forward = _pinned_encoder_forward(enc, ename, dec)
+    m.imu_feat_net.forward = _imu_forward_with_masks(m.imu_feat_net, masks[0:2], 0.1)
+    m.lidar_feat_net.drop.forward = lambda x: x * masks[2].view(x.shape).to(x.dtype) / 0.9
+    m.drop.forward = lambda x: x * masks[3].view(x.shape).to(x.dtype) / 0.75
+    xyz, nrm, imu, f2f, f2g = (t.double() for t in batch)
+    a, b = m([[xyz, nrm], imu])
+    p2, q2 = ose3.se3_to_SE3(a, b)
+    lo = c(a, b, p2[:, 1:3], q2[:, 1:3], f2f[:, :, 0:3], f2f[:, :, 3:], f2g[:, 1:3, 0:3], f2g[:, 1:3, 3:7])
+    lo.backward()
+    assert abs(float(loss.detach()) - float(lo.detach())) <= TOL * abs(float(lo.detach()))
+    g64 = {k: p.grad.double() for k, p in m.named_parameters() if p.grad is not None}
+    g64["criterion.sx"], g64["criterion.sq"] = c.sx.grad.double(), c.sq.grad.double()
+    named = dict(model.named_parameters())
+    named["criterion.sx"], named["criterion.sq"] = crit.sx, crit.sq
+    gmax = max(float(v.abs().max()) for v in g64.values())
+    rows = []
+    for k, ref in g64.items():
+        mine = named[k].grad.detach().double().cpu()
+        if float(ref.abs().max()) < 1e-5 * gmax:
+            assert float(mine.abs().max()) < 1e-4 * gmax, k
+            continue
+        rows.append((k, _l2(mine, ref)))
+    errs = np.asarray([r[1] for r in rows])
+    print("dropout on, masks + decisions pinned: rel-L2 vs fp64 over %d parameters: median %.2e max %.2e (%s)"
+          % (len(rows), np.median(errs), errs.max(), max(rows, key=lambda r: r[1])[0]))
+    assert len(rows) > 250 and errs.max() <= TOL, sorted(rows, key=lambda r: -r[1])[:5]
+
+
+def test_train_step_polls_its_error_words_without_being_asked(dev):
+    """TrainStep.step copies the device-side error words (non-finite output, det != 1, a cooperative BatchNorm launch at its
+    spin limit) into pinned memory every `check_every` steps and inspects the copy made one period earlier: a bad step raises
+    within 2 x check_every steps although nobody calls check() (trainer.py:240-243 raises in the same iteration -- with a host
+    sync per step)."""
+    from deeplio_amd.trainer import TrainStep
+    name = "pointseg_lstm_cat"
+    g = gc.MODEL_CASES[name]['geom']
+    ts = TrainStep(gc.case_cfg(name), (g['C'], g['H'], g['W']), dev, g['B'])
+    ts.check_every = 2
+    batch = tuple(t.to(dev) for t in gc.make_batch(2000, g['B'], g['S'], g['C'], g['H'], g['W'], g['T']))
+    try:
+        for _ in range(6):
+            ts.step(*batch)                       # healthy steps: the polls find nothing
+        bad = list(batch)
+        bad[0] = bad[0].clone()
+        bad[0][0, 0, 0, 0, 0, 0] = float("nan")
+        ts.step(*bad)                             # the model output of this step is non-finite
+        with pytest.raises(ValueError, match="non-finite"):
+            for _ in range(2 * ts.check_every + 1):
+                ts.step(*batch)
+    finally:
+        ts.release_gc()
