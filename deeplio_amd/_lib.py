@@ -160,6 +160,11 @@ SIGNATURES = {
                              _p]),
     "dlio_gru_seq_bwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz,
                              _p]),
+    "dlio_lstm_layer_ok": (_i, [_i, _i, _i, _i, _i]),
+    "dlio_lstm_layer_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "dlio_lstm_layer_fwd": (_i, [_p, _i] + [_p] * 8 + [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "dlio_lstm_layer_bwd": (_i, [_p, _i, _p, _i, _p, _p, _p] + [_p] * 4 + [_p] + [_p] * 8 + [_i, _p, _i, _i, _i, _i, _i, _i, _p,
+                                 _sz, _p]),
     "dlio_se3_chain_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "dlio_se3_chain_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "dlio_so3_project": (_i, [_p, _p, _p, _i, _p]),

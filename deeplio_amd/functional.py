@@ -1759,6 +1759,82 @@ class RNNFn(Function):
         return (dx, None, None, None, None, None, None) + tuple(grads)
 
 
+_LSTM_LAYER = [os.environ.get("DLIO_LSTM_LAYER", "1") != "0"]      # wide LSTMs: one launch sequence per LAYER (lstm_stream.hip)
+
+
+def lstm_stack_ok(x4, mode, H, L, D):
+    """RNNParams.run may take LstmStackFn: an LSTM over ONE sequence per sample (no state carried between sub-sequences), wide
+    enough for the weight-streaming layer kernels"""
+    if not (_LSTM_LAYER[0] and mode == "lstm" and x4.is_cuda and x4.dim() == 4 and x4.shape[1] == 1):
+        return False
+    B, _, T, I = x4.shape
+    return all(ops.lstm_layer_ok(T, B, I if l == 0 else D * H, H, D) for l in range(L))
+
+
+class LstmStackFn(Function):
+    """nn.LSTM(I -> H, L layers, D directions, batch_first) over one sequence per sample from the zero state -- the odometry
+    net (odom_feat_nets.py:61-68,72-83: 256 -> 1024, 2 layers, bidirectional, over the S axis): every layer is ONE call that
+    runs both directions and all steps (csrc/lstm_stream.hip: 2 T launches forward, 2 T + 2 backward, weights streamed in
+    K slices / N slabs at HBM rate) instead of RNNFn's per-direction, per-step dlio_linear_* + cell launches on two streams.
+    x [B, T, I] -> [B, T, D H]; inter-layer dropout as nn.LSTM (train only)."""
+
+    @staticmethod
+    def forward(ctx, x, H, L, D, p, training, *weights):
+        x = x.contiguous()
+        B, T, I = x.shape
+        rows = B * T
+        W = [[weights[(l * D + d) * 4:(l * D + d) * 4 + 4] for d in range(D)] for l in range(L)]
+        inp = x.view(rows, I)
+        saved = []
+        out = None
+        for l in range(L):
+            Il = inp.shape[1]
+            out = _new((rows, D * H), x)
+            cs, hp, gates = ops.lstm_layer_fwd(inp, Il, W[l], out, D * H, T, B, Il, H, D)
+            rec = {"inp": inp, "cs": cs, "hp": hp, "gates": gates}
+            if l + 1 < L and training and p > 0.:
+                inp, rec["mask"] = _dropout_launch(out, p)
+            else:
+                inp = out
+            saved.append(rec)
+        ctx.saved, ctx.weights = saved, weights
+        ctx.cfg = (H, L, D, p, B, T, I)
+        return out.view(B, T, D * H)
+
+    @staticmethod
+    def backward(ctx, dtop):
+        H, L, D, p, B, T, I = ctx.cfg
+        weights, saved = ctx.weights, ctx.saved
+        rows = B * T
+        dout = dtop.contiguous().view(rows, D * H)
+        grads = [None] * len(weights)
+        dx = None
+        for l in reversed(range(L)):
+            rec = saved[l]
+            Il = rec["inp"].shape[1]
+            need_dinp = l > 0 or ctx.needs_input_grad[0]
+            dinp = _new((rows, Il), dout) if need_dinp else None
+            shapes = ((4 * H, Il), (4 * H, H), (4 * H,), (4 * H,))
+            sinks = [[_sink(weights[(l * D + d) * 4 + j], shapes[j], dout) for j in range(4)] for d in range(D)]
+            acc = all(sk[1] for dd in sinks for sk in dd)
+            if not acc and any(sk[1] for dd in sinks for sk in dd):     # one accumulate flag per launch: fresh buffers for all
+                sinks = [[(_new(shapes[j], dout), False, None) for j in range(4)] for d in range(D)]
+                sinks = [[(t, False, t) for t, _, _ in dd] for dd in sinks]
+            for d in range(D):
+                for j in range(4):
+                    grads[(l * D + d) * 4 + j] = sinks[d][j][2]
+            ops.lstm_layer_bwd(dout, D * H, rec["inp"], Il, rec["hp"], rec["gates"], rec["cs"],
+                               [(weights[(l * D + d) * 4], weights[(l * D + d) * 4 + 1]) for d in range(D)],
+                               [tuple(sk[0] for sk in sinks[d]) for d in range(D)], acc, dinp, Il, T, B, Il, H, D)
+            if l > 0:
+                prev = saved[l - 1]
+                dout = ops.dropout_bwd(dinp, prev["mask"], p) if "mask" in prev else dinp
+            else:
+                dx = dinp.view(B, T, I) if dinp is not None else None
+        ctx.saved = None
+        return (dx, None, None, None, None, None) + tuple(grads)
+
+
 # =============================================================================== pose chain / loss
 class SE3ChainFn(Function):
     """Trainer.se3_to_SE3 (trainer.py:324-351): f2f increments -> f2g (p, q).  order 0 = wxyz

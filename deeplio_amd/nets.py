@@ -605,6 +605,10 @@ class RNNParams(nn.Module):
     def run(self, x4, training):
         """x4 [B, Sg, T, I] -> [B, Sg, T, D*H]"""
         D = 2 if self.bidirectional else 1
+        if Fh.lstm_stack_ok(x4, self.mode, self.hidden_size, self.num_layers, D):
+            # one sequence per sample, wide hidden state (the odometry net): one both-directions launch sequence per layer
+            return Fh.LstmStackFn.apply(x4[:, 0], self.hidden_size, self.num_layers, D, self.dropout, training,
+                                        *self.flat_weights()).unsqueeze(1)
         return Fh.RNNFn.apply(x4, self.mode, self.hidden_size, self.num_layers, D, self.dropout,
                               training, *self.flat_weights())
 

@@ -1247,6 +1247,41 @@ def lstm_seq_bwd(dhs, dhs_off, lddhs, dhT, dcT, gates, cs, c0, w_hh, dgates, dh0
                                 int(reverse), _ptr(ws), ws.numel(), _stream()), "lstm_seq_bwd")
 
 
+def lstm_layer_ok(T, B, I, H, D):
+    """the both-directions-per-launch streamed LSTM layer (csrc/lstm_stream.hip) takes this geometry"""
+    return bool(lib.dlio_lstm_layer_ok(T, B, I, H, D))
+
+
+def lstm_layer_fwd(x, ldx, w, hs, ldhs, T, B, I, H, D):
+    """one LSTM layer, D directions, T steps from the zero state.  x [B*T rows (b T + t)][ldx]; w = per direction (w_ih, w_hh,
+    b_ih, b_hh); hs [rows][ldhs] receives direction d in columns d H ..  -> (cs, hp, gates) saved for lstm_layer_bwd"""
+    rows = B * T
+    cs = torch.empty(D, rows, H, dtype=torch.float32, device=x.device)
+    hp = torch.empty(D, rows, H, dtype=torch.float32, device=x.device)
+    gates = torch.empty(D, rows, 4 * H, dtype=torch.float32, device=x.device)
+    ws = workspace(lib.dlio_lstm_layer_ws_bytes(T, B, I, H, D), x.device, slot=2)
+    w1 = w[1] if D == 2 else (None, None, None, None)
+    check(lib.dlio_lstm_layer_fwd(_ptr(x), ldx, _ptr(w[0][0]), _ptr(w[0][1]), _ptr(w[0][2]), _ptr(w[0][3]), _ptr(w1[0]),
+                                  _ptr(w1[1]), _ptr(w1[2]), _ptr(w1[3]), _ptr(hs), ldhs, _ptr(cs), _ptr(hp), _ptr(gates), T, B,
+                                  I, H, D, _ptr(ws), ws.numel(), _stream()), "lstm_layer_fwd")
+    return cs, hp, gates
+
+
+def lstm_layer_bwd(dhs, lddhs, x, ldx, hp, gates, cs, w, dws, accumulate, dx, lddx, T, B, I, H, D):
+    """w = per direction (w_ih, w_hh); dws = per direction (dw_ih, dw_hh, db_ih, db_hh) written (or accumulated into);
+    dx [rows][lddx] or None"""
+    rows = B * T
+    dgates = torch.empty(D, rows, 4 * H, dtype=torch.float32, device=x.device)
+    ws = workspace(lib.dlio_lstm_layer_ws_bytes(T, B, I, H, D), x.device, slot=2)
+    w1 = w[1] if D == 2 else (None, None)
+    g1 = dws[1] if D == 2 else (None, None, None, None)
+    check(lib.dlio_lstm_layer_bwd(_ptr(dhs), lddhs, _ptr(x), ldx, _ptr(hp), _ptr(gates), _ptr(cs), _ptr(w[0][0]), _ptr(w[0][1]),
+                                  _ptr(w1[0]), _ptr(w1[1]), _ptr(dgates), _ptr(dws[0][0]), _ptr(dws[0][1]), _ptr(dws[0][2]),
+                                  _ptr(dws[0][3]), _ptr(g1[0]), _ptr(g1[1]), _ptr(g1[2]), _ptr(g1[3]), int(accumulate),
+                                  _ptr(dx), lddx, T, B, I, H, D, _ptr(ws), ws.numel(), _stream()), "lstm_layer_bwd")
+    return dgates
+
+
 def gru_seq_fwd(gx, w_hh, b_hh, h0, hs, hs_off, ldhs, hp, gates, hT, T, B, H, rst, rsb, reverse):
     ws = _rnn_ws(T, B, H, gx.device)
     check(lib.dlio_gru_seq_fwd(_ptr(gx), _ptr(w_hh), _ptr(b_hh), _ptr(h0), _off(hs, hs_off), ldhs,

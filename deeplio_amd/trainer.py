@@ -55,6 +55,12 @@ class TrainStep:
         self.check_every = int(os.environ.get("DLIO_CHECK_EVERY", "8"))
         self._poll_pending = None
         self._poll_host = None
+        # the optimizer step over the tail bucket issued from inside backward (see _tail_ready); 0: one sweep at the end
+        self.early_tail_step = os.environ.get("DLIO_EARLY_TAIL_STEP", "1") != "0"
+        self._tail_lo = self.tail_offset()
+        if self._tail_lo is not None and (self._tail_lo <= 0 or self._tail_lo % 4):
+            self._tail_lo = None
+        self.model.tail_grads_ready = self._tail_ready
         self.model.train()
         if grad_sync is not None:
             self.set_grad_sync(grad_sync)
@@ -70,6 +76,31 @@ class TrainStep:
         index = {id(p): i for i, p in enumerate(self.optimizer.params)}
         return self.optimizer.offsets[index[id(first)]]
 
+    def _tail_ready(self):
+        """autograd hook on the fusion output's gradient: everything behind the feature nets (odometry net, heads, loss weights:
+        [tail_offset():] of the flat buffers, 87 % of the headline model) has its final gradient.  Data parallel: start that
+        bucket's all-reduce; then run the optimizer over it NOW on the 'comm' stream (beside a weight-gradient companion,
+        functional.assign_streams) -- under the encoder backward instead of at the end of the step."""
+        sync = self.grad_sync
+        dp = sync is not None and sync.world > 1
+        if dp and sync.tail_lo is not None:
+            sync.reduce_tail_async()
+        if not self.early_tail_step or self._tail_lo is None or not hasattr(self.optimizer, "step_early"):
+            return
+        if dp and not isinstance(getattr(sync, "_tail_work", None), torch.cuda.Event):
+            return                     # (the bucket is not being reduced on the comm stream: the whole step at the end)
+        if self.device.type != "cuda":
+            return
+        overlap = getattr(self.model, "side_stream", True)
+        if overlap:
+            comm = Fh.aux_stream(self.device, "comm")
+            cur = Fh.current_stream_obj()
+            Fh.join_wgrad_stream()     # (weight gradients of the tail that were forked onto the companion stream)
+            comm.wait_stream(cur)
+            self.optimizer.step_early(self._tail_lo, comm)
+        else:
+            self.optimizer.step_early(self._tail_lo, None)
+
     def set_grad_sync(self, sync):
         """data parallel: gradient exchange in two buckets, the tail one overlapped with backward"""
         self.grad_sync = sync
@@ -77,7 +108,6 @@ class TrainStep:
             self.check_every = 1          # beside RCCL's kernels the cooperative launches are least certain of their partners
         if sync is not None and sync.world > 1:
             sync.set_tail(self.tail_offset())
-            self.model.tail_grads_ready = sync.reduce_tail_async if sync.tail_lo is not None else None
 
     def _manage_gc(self):
         if self.gc_mode == "default":

@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 238
+#define DLIO_ABI_VERSION 239
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);
@@ -498,6 +498,35 @@ int dlio_gru_seq_bwd(const float* dhs, int lddhs, const float* dhT, const float*
                      const float* hp, const float* w_hh, float* dgx, float* dgh, float* dh0,
                      int T, int B, int H, int rst, int rsb, int reverse, void* ws,
                      size_t ws_bytes, dlio_stream_t stream);
+
+/* ---- streamed LSTM LAYER, both directions per launch ---------------------
+ * nn.LSTM(256 -> 1024, num_layers 2, bidirectional, batch_first) of OdomFeatRNN
+ * (odom_feat_nets.py:61-68, forward :72-83) over the S axis: one call = one layer,
+ * D = 1 | 2 directions, the whole sequence of T steps, ZERO initial state.  Rows are
+ * r(t, b) = b T + t (batch-first).  x [rows][ldx >= I]; hs [rows][ldhs >= D H]: direction d
+ * writes columns d H .. d H + H (torch's layout of a bidirectional output); saved for
+ * backward: cs, hp [D][rows][H] (c_t and the h that ENTERED step t), gates [D][rows][4H]
+ * (post-activation, order i, f, g, o).  Parameters of direction 1 may be NULL when D = 1.
+ * Geometry: B <= 8, H and I multiples of 256 (dlio_lstm_layer_ok); ws from
+ * dlio_lstm_layer_ws_bytes (the K-slice / N-slab partial sums; fixed summation order).
+ * Backward: dhs [rows][lddhs] = gradient w.r.t. hs (both directions' columns); writes
+ * dgates [D][rows][4H] (scratch the caller owns), the eight parameter gradients
+ * (accumulate != 0: added to what is there) and, unless NULL, dx [rows][lddx >= I] summed
+ * over both directions. */
+int dlio_lstm_layer_ok(int T, int B, int I, int H, int D);
+size_t dlio_lstm_layer_ws_bytes(int T, int B, int I, int H, int D);
+int dlio_lstm_layer_fwd(const float* x, int ldx, const float* w_ih0, const float* w_hh0,
+                        const float* b_ih0, const float* b_hh0, const float* w_ih1,
+                        const float* w_hh1, const float* b_ih1, const float* b_hh1, float* hs,
+                        int ldhs, float* cs, float* hp, float* gates, int T, int B, int I, int H,
+                        int D, void* ws, size_t ws_bytes, dlio_stream_t stream);
+int dlio_lstm_layer_bwd(const float* dhs, int lddhs, const float* x, int ldx, const float* hp,
+                        const float* gates, const float* cs, const float* w_ih0,
+                        const float* w_hh0, const float* w_ih1, const float* w_hh1, float* dgates,
+                        float* dw_ih0, float* dw_hh0, float* db_ih0, float* db_hh0, float* dw_ih1,
+                        float* dw_hh1, float* db_ih1, float* db_hh1, int accumulate, float* dx,
+                        int lddx, int T, int B, int I, int H, int D, void* ws, size_t ws_bytes,
+                        dlio_stream_t stream);
 
 /* ---- pose chain + loss --------------------------------------------------
  * Trainer.se3_to_SE3 (trainer.py:324-351): per batch element chain

@@ -270,6 +270,52 @@ def test_odom_rnn_fc_softfusion_imufc(dev):
     compare(nets.ImuFeatFC(fc), om.ImuFeatFC(fc, ctx), xi, dev)
 
 
+@pytest.mark.parametrize("B,S,H,bidir", [(8, 2, 1024, True), (8, 5, 512, True), (3, 3, 256, True), (4, 2, 256, False), (1, 1, 256, True)])
+def test_odom_lstm_one_launch_sequence_per_layer(dev, B, S, H, bidir):
+    """OdomFeatRNN (odom_feat_nets.py:48-86: nn.LSTM(256 -> H, 2 layers, bidirectional) over the S axis, forward half kept) on
+    functional.LstmStackFn / csrc/lstm_stream.hip -- both directions and all steps of a layer in one call, the weight-streaming
+    products cut into K slices (fp32 MFMA) / N slabs with the partial sums joined by the consumer -- against nn.LSTM in fp64:
+    output, input gradient and all 16 parameter gradients (the top layer's reverse direction: exactly zero); the
+    headline geometry (B = 8, S = 2, H = 1024), S = 5 (40 rows: three passes of the input projection), a ragged batch, one
+    direction, a single step; and against RNNFn's per-direction path on the same weights (1e-6)."""
+    from deeplio_amd import functional as Fh
+    from deeplio_amd import nets
+    from oracle import model as om
+    cfg = _ctx(dev, seq=S)
+    ctx = om.Ctx(cfg)
+    x = torch.randn(B, S, 256, generator=torch.Generator().manual_seed(17))
+    rc = {'type': 'lstm', 'hidden-size': H, 'num-layers': 2, 'bidirectional': bidir, 'dropout': 0.}
+    hip = nets.OdomFeatRNN(256, rc)
+    taken = []
+    apply_ = Fh.LstmStackFn.apply
+    Fh.LstmStackFn.apply = staticmethod(lambda *a: (taken.append(1), apply_(*a))[1])
+    try:
+        compare(hip, om.OdomFeatRNN(256, rc, ctx), x, dev, tol=2e-5)
+    finally:
+        Fh.LstmStackFn.apply = apply_
+    assert taken == [1]
+    # the same module through the per-direction path
+    grads_a = {k: p.grad.clone() for k, p in hip.named_parameters()}
+    xa = x.clone().to(dev).requires_grad_(True)
+    ya = hip(xa)
+    for p in hip.parameters():
+        p.grad = None
+    Fh._LSTM_LAYER[0] = False
+    try:
+        xb = x.clone().to(dev).requires_grad_(True)
+        yb = hip(xb)
+    finally:
+        Fh._LSTM_LAYER[0] = True
+    assert rel_err(ya, yb) < 1e-6
+    g = torch.randn(ya.shape, generator=torch.Generator().manual_seed(5)).to(dev)
+    yb.backward(g)
+    gmax = max(float(v.abs().max()) for v in grads_a.values())
+    for k, p in hip.named_parameters():
+        assert float((p.grad - grads_a[k]).abs().max()) <= 2e-6 * gmax + 1e-6 * float(grads_a[k].abs().max()), k
+    if bidir:
+        assert float(grads_a["rnn.weight_ih_l1_reverse"].abs().max()) == 0.0     # Q3: the discarded half gets no gradient
+
+
 def test_stem_pool_apply_on_load(dev):
     """PSEncoder stem + pool1 as one node: pool1 takes the maximum over max(0, BN(raw)) while it loads the stem's raw
     output (dlio_maxpool2d_fwd_aff).  Forward, input-free backward (weight / BatchNorm gradients) and the running

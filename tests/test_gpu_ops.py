@@ -2125,4 +2125,5 @@ def test_two_piece_kernels_per_channel_relative_error_over_six_decades(dev):
     order = torch.argsort(torch.arange(E) % 4, stable=True)           # output channels by the decade group they read
     report("fire expand1x1 two-piece", e1[order])
     report("fire expand3x3 two-piece", e3[order])
-    assert all(v <= 1e-4 for v in worst.values()), worst
+    print("worst per-channel rel-L2: " + ", ".join("%s %.2e" % kv for kv in worst.items()))
+    assert all(v <= 1e-4 for v in worst.values()), ", ".join("%s %.2e" % kv for kv in worst.items())
