@@ -690,6 +690,216 @@ __global__ __launch_bounds__(256) void linear_wgrad_mfma_kernel(
   }
 }
 
+// ---- the small layers of the step's serial middle as single launches ---------------------------------------------------------
+// DeepLIOFusionSoft (fusion_nets.py:64-75): cat = [a | b]; s1 = sigmoid(cat W1^T + b1), s2 = sigmoid(cat W2^T + b2);
+// out = [a s1 | b s2] -- ten launches as cat + 2 x linear + 2 x multiply + cat.  One wave per output column j (rows of the
+// stacked [W1; W2], F = Fa + Fb columns each), all R sample rows in passes of 16.
+__global__ __launch_bounds__(256) void soft_fusion_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                              const float* __restrict__ w1, const float* __restrict__ b1,
+                                                              const float* __restrict__ w2, const float* __restrict__ b2,
+                                                              float* __restrict__ out, float* __restrict__ gate, int R, int Fa,
+                                                              int Fb) {
+  const int F = Fa + Fb;
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= F) return;
+  const float* __restrict__ wr = j < Fa ? w1 + (size_t)j * F : w2 + (size_t)(j - Fa) * F;
+  const float bias = j < Fa ? (b1 ? b1[j] : 0.f) : (b2 ? b2[j - Fa] : 0.f);
+  for (int m0 = 0; m0 < R; m0 += 16) {
+    float acc[16];
+#pragma unroll
+    for (int mm = 0; mm < 16; ++mm) acc[mm] = 0.f;
+    for (int k = lane; k < F; k += 64) {
+      const float wv = wr[k];
+#pragma unroll
+      for (int mm = 0; mm < 16; ++mm) {
+        const int m = m0 + mm;
+        if (m < R) acc[mm] += wv * (k < Fa ? a[(size_t)m * Fa + k] : b[(size_t)m * Fb + (k - Fa)]);
+      }
+    }
+#pragma unroll
+    for (int mm = 0; mm < 16; ++mm) acc[mm] = wave_sum(acc[mm]);
+    if (lane < 16 && m0 + lane < R) {
+      const int m = m0 + lane;
+      float v = 0.f;
+#pragma unroll
+      for (int mm = 0; mm < 16; ++mm) v = lane == mm ? acc[mm] : v;
+      const float sg = 1.0f / (1.0f + expf(-(v + bias)));
+      const float src = j < Fa ? a[(size_t)m * Fa + j] : b[(size_t)m * Fb + (j - Fa)];
+      out[(size_t)m * F + j] = src * sg;
+      gate[(size_t)m * F + j] = sg;
+    }
+  }
+}
+
+// backward of the above: grid F / 16; workgroup g owns rows j in [16 g, 16 g + 16) of the stacked weight (their gradient:
+// dW[j][k] = sum_m dpre[m][j] cat[m][k], db[j]) and columns k in the same range of d cat (= sum_j dpre[m][j] W[j][k] +
+// dout gate); dpre = dout src gate (1 - gate) is formed by every workgroup in LDS (16 x F floats per pass of 16 samples)
+template <int FMAX>
+__global__ __launch_bounds__(256) void soft_fusion_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ a,
+                                                              const float* __restrict__ b, const float* __restrict__ gate,
+                                                              const float* __restrict__ w1, const float* __restrict__ w2,
+                                                              float* __restrict__ da, float* __restrict__ db_,
+                                                              float* __restrict__ dw1, float* __restrict__ dbias1,
+                                                              float* __restrict__ dw2, float* __restrict__ dbias2, int R, int Fa,
+                                                              int Fb, int accumulate) {
+  __shared__ float sdp[16][FMAX], scat[16][FMAX];
+  const int F = Fa + Fb;
+  const int g0 = blockIdx.x * 16;
+  const int t = threadIdx.x, jj = t >> 4, kg = t & 15;
+  constexpr int NI = FMAX / 16;
+  float acc[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) acc[i] = 0.f;
+  float bsum = 0.f;
+  for (int m0 = 0; m0 < R; m0 += 16) {
+    __syncthreads();
+    for (int i = t; i < 16 * F; i += 256) {
+      const int mm = i / F, c = i - mm * F, m = m0 + mm;
+      float dp = 0.f, cv = 0.f;
+      if (m < R) {
+        cv = c < Fa ? a[(size_t)m * Fa + c] : b[(size_t)m * Fb + (c - Fa)];
+        const float sg = gate[(size_t)m * F + c];
+        dp = dout[(size_t)m * F + c] * cv * sg * (1.f - sg);
+      }
+      sdp[mm][c] = dp;
+      scat[mm][c] = cv;
+    }
+    __syncthreads();
+    // weight-gradient rows g0 + jj
+    const int j = g0 + jj;
+    if (j < F) {
+#pragma unroll
+      for (int mm = 0; mm < 16; ++mm) {
+        const float dp = sdp[mm][j];
+        if (kg == 0) bsum += dp;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+          if (kg + 16 * i < F) acc[i] += dp * scat[mm][kg + 16 * i];
+      }
+    }
+    // d cat, columns g0 + kg, sample m0 + jj
+    const int k = g0 + kg, m = m0 + jj;
+    if (k < F && m < R) {
+      float s = 0.f;
+      for (int jx = 0; jx < F; ++jx) {
+        const float wv = jx < Fa ? w1[(size_t)jx * F + k] : w2[(size_t)(jx - Fa) * F + k];
+        s += sdp[jj][jx] * wv;
+      }
+      const float v = s + dout[(size_t)m * F + k] * gate[(size_t)m * F + k];
+      if (k < Fa) da[(size_t)m * Fa + k] = v;
+      else db_[(size_t)m * Fb + (k - Fa)] = v;
+    }
+  }
+  const int j = g0 + jj;
+  if (j < F) {
+    float* __restrict__ dwr = j < Fa ? dw1 + (size_t)j * F : dw2 + (size_t)(j - Fa) * F;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int k = kg + 16 * i;
+      if (k < F) dwr[k] = accumulate ? dwr[k] + acc[i] : acc[i];
+    }
+    if (kg == 0) {
+      float* __restrict__ p = j < Fa ? dbias1 + j : dbias2 + (j - Fa);
+      *p = accumulate ? *p + bsum : bsum;
+    }
+  }
+}
+
+// deeplio_nets.py:84-90: dropout(p) in front of the two heads fc_pos / fc_ori (Linear(K, 3) each) -- slice copy + dropout +
+// two linear launches.  One workgroup per sample row: the row (read with its own row stride: the forward half of the
+// odometry LSTM's [.., 2H] output, no slice copy) is masked into LDS, the six dot products are taken by its four waves.
+// The mask comes from the same Philox stream position a separate dropout launch over the contiguous [R, K] tensor would use.
+__global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict__ x, int ldx, uint8_t* __restrict__ mask,
+                                                        const float* __restrict__ wp, const float* __restrict__ bp,
+                                                        const float* __restrict__ wo, const float* __restrict__ bo,
+                                                        float* __restrict__ pos, float* __restrict__ ori, int R, int K, float p,
+                                                        uint64_t seed, uint64_t offset) {
+  extern __shared__ __attribute__((aligned(16))) float ys[];       // [K]
+  const int m = blockIdx.x;
+  const float inv = 1.0f / (1.0f - p);
+  const float* __restrict__ xr = x + (size_t)m * ldx;
+  for (int g = threadIdx.x; g < (K >> 2); g += 256) {
+    float4 v = *reinterpret_cast<const float4*>(xr + 4 * g);
+    if (mask) {
+      const uint64_t ctr = offset + (uint64_t)(((size_t)m * K) >> 2) + (uint64_t)g;
+      uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+      philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+      float* vv = reinterpret_cast<float*>(&v);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float u = (float)(c[j] >> 8) * (1.0f / 16777216.0f);
+        const uint8_t keep = u >= p ? 1 : 0;
+        mask[(size_t)m * K + 4 * g + j] = keep;
+        vv[j] = keep ? vv[j] * inv : 0.f;
+      }
+    }
+    *reinterpret_cast<float4*>(ys + 4 * g) = v;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = wave; c < 6; c += 4) {
+    const float* __restrict__ wr = c < 3 ? wp + (size_t)c * K : wo + (size_t)(c - 3) * K;
+    float s = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+      const float4 wv = *reinterpret_cast<const float4*>(wr + k);
+      const float4 yv = *reinterpret_cast<const float4*>(ys + k);
+      s += (wv.x * yv.x + wv.y * yv.y) + (wv.z * yv.z + wv.w * yv.w);
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+      if (c < 3) pos[m * 3 + c] = s + (bp ? bp[c] : 0.f);
+      else ori[m * 3 + (c - 3)] = s + (bo ? bo[c - 3] : 0.f);
+    }
+  }
+}
+
+// backward: thread = column k; dW[c][k] = sum_m d[m][c] y[m][k], dx[m][k] = keep / (1 - p) sum_c d[m][c] W[c][k]; the columns
+// [K, lddx) of dx (the discarded reverse half of the LSTM output) are written as zeros; biases by workgroup 0
+__global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict__ dpos, const float* __restrict__ dori,
+                                                        const float* __restrict__ x, int ldx, const uint8_t* __restrict__ mask,
+                                                        const float* __restrict__ wp, const float* __restrict__ wo,
+                                                        float* __restrict__ dx, int lddx, float* __restrict__ dwp,
+                                                        float* __restrict__ dbp, float* __restrict__ dwo, float* __restrict__ dbo,
+                                                        int R, int K, float p, int accumulate) {
+  extern __shared__ float sd[];                                    // [R][6]
+  const float inv = 1.0f / (1.0f - p);
+  for (int i = threadIdx.x; i < R * 6; i += 256) {
+    const int m = i / 6, c = i - m * 6;
+    sd[i] = c < 3 ? dpos[m * 3 + c] : dori[m * 3 + (c - 3)];
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x < 6) {
+    const int c = threadIdx.x;
+    float s = 0.f;
+    for (int m = 0; m < R; ++m) s += sd[m * 6 + c];
+    float* q = c < 3 ? (dbp ? dbp + c : nullptr) : (dbo ? dbo + (c - 3) : nullptr);
+    if (q) *q = accumulate ? *q + s : s;
+  }
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= lddx) return;
+  if (k >= K) {
+    if (dx) for (int m = 0; m < R; ++m) dx[(size_t)m * lddx + k] = 0.f;
+    return;
+  }
+  float w6[6], dw[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) { w6[c] = c < 3 ? wp[(size_t)c * K + k] : wo[(size_t)(c - 3) * K + k]; dw[c] = 0.f; }
+  for (int m = 0; m < R; ++m) {
+    const float kp = mask ? (mask[(size_t)m * K + k] ? inv : 0.f) : 1.f;
+    const float y = x[(size_t)m * ldx + k] * kp;
+    float g = 0.f;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { const float dd = sd[m * 6 + c]; dw[c] += dd * y; g += dd * w6[c]; }
+    if (dx) dx[(size_t)m * lddx + k] = g * kp;
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    float* q = c < 3 ? dwp + (size_t)c * K + k : dwo + (size_t)(c - 3) * K + k;
+    *q = accumulate ? *q + dw[c] : dw[c];
+  }
+}
+
 }  // namespace
 
 extern "C" int dlio_linear_fwd(const float* x, int ldx, const float* w, const float* b,
@@ -895,5 +1105,55 @@ extern "C" int dlio_nonfinite_flag(const float* x, int64_t n, int32_t* flag,
   if (!x || !flag || n <= 0) return DLIO_EINVAL;
   hipLaunchKernelGGL(nonfinite_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, as_stream(stream), x,
                      n, flag);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_soft_fusion_ok(int R, int Fa, int Fb) { return R > 0 && Fa > 0 && Fb > 0 && Fa + Fb <= 512; }
+
+extern "C" int dlio_soft_fusion_fwd(const float* a, const float* b, const float* w1, const float* b1, const float* w2,
+                                    const float* b2, float* out, float* gate, int R, int Fa, int Fb, dlio_stream_t stream) {
+  if (!a || !b || !w1 || !w2 || !out || !gate) return DLIO_EINVAL;
+  if (!dlio_soft_fusion_ok(R, Fa, Fb)) return DLIO_EUNSUP;
+  hipLaunchKernelGGL(soft_fusion_fwd_kernel, dim3(cdiv(Fa + Fb, 4)), dim3(256), 0, as_stream(stream), a, b, w1, b1, w2, b2, out,
+                     gate, R, Fa, Fb);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_soft_fusion_bwd(const float* dout, const float* a, const float* b, const float* gate, const float* w1,
+                                    const float* w2, float* da, float* db, float* dw1, float* dbias1, float* dw2, float* dbias2,
+                                    int R, int Fa, int Fb, int accumulate, dlio_stream_t stream) {
+  if (!dout || !a || !b || !gate || !w1 || !w2 || !da || !db || !dw1 || !dbias1 || !dw2 || !dbias2) return DLIO_EINVAL;
+  if (!dlio_soft_fusion_ok(R, Fa, Fb)) return DLIO_EUNSUP;
+  const int F = Fa + Fb;
+  if (F <= 256)
+    hipLaunchKernelGGL((soft_fusion_bwd_kernel<256>), dim3(cdiv(F, 16)), dim3(256), 0, as_stream(stream), dout, a, b, gate, w1, w2,
+                       da, db, dw1, dbias1, dw2, dbias2, R, Fa, Fb, accumulate);
+  else
+    hipLaunchKernelGGL((soft_fusion_bwd_kernel<512>), dim3(cdiv(F, 16)), dim3(256), 0, as_stream(stream), dout, a, b, gate, w1, w2,
+                       da, db, dw1, dbias1, dw2, dbias2, R, Fa, Fb, accumulate);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_heads_ok(int R, int K, int ldx) {
+  return R > 0 && R <= 1024 && K >= 4 && (K & 3) == 0 && K <= 8192 && ldx >= K && (ldx & 3) == 0;
+}
+
+extern "C" int dlio_heads_fwd(const float* x, int ldx, uint8_t* mask, const float* wp, const float* bp, const float* wo,
+                              const float* bo, float* pos, float* ori, int R, int K, float p, uint64_t seed, uint64_t offset,
+                              dlio_stream_t stream) {
+  if (!x || !wp || !wo || !pos || !ori || !(p >= 0.f && p < 1.f)) return DLIO_EINVAL;
+  if (!dlio_heads_ok(R, K, ldx) || (reinterpret_cast<uintptr_t>(x) & 15)) return DLIO_EUNSUP;
+  hipLaunchKernelGGL(heads_fwd_kernel, dim3(R), dim3(256), (size_t)K * sizeof(float), as_stream(stream), x, ldx, mask, wp, bp, wo,
+                     bo, pos, ori, R, K, p, seed, offset);
+  return dlio_check_launch();
+}
+
+extern "C" int dlio_heads_bwd(const float* dpos, const float* dori, const float* x, int ldx, const uint8_t* mask,
+                              const float* wp, const float* wo, float* dx, int lddx, float* dwp, float* dbp, float* dwo,
+                              float* dbo, int R, int K, float p, int accumulate, dlio_stream_t stream) {
+  if (!dpos || !dori || !x || !wp || !wo || !dwp || !dwo || !(p >= 0.f && p < 1.f)) return DLIO_EINVAL;
+  if (!dlio_heads_ok(R, K, ldx) || (dx && lddx < K)) return DLIO_EUNSUP;
+  hipLaunchKernelGGL(heads_bwd_kernel, dim3(cdiv(dx ? lddx : K, 256)), dim3(256), (size_t)R * 6 * sizeof(float), as_stream(stream),
+                     dpos, dori, x, ldx, mask, wp, wo, dx, dx ? lddx : K, dwp, dbp, dwo, dbo, R, K, p, accumulate);
   return dlio_check_launch();
 }

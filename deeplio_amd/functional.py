@@ -1759,6 +1759,73 @@ class RNNFn(Function):
         return (dx, None, None, None, None, None, None) + tuple(grads)
 
 
+_TAIL_FUSED = [os.environ.get("DLIO_TAIL_FUSED", "1") != "0"]      # soft fusion / dropout + heads as one launch each
+
+
+class SoftFusionFn(Function):
+    """DeepLIOFusionSoft.forward (fusion_nets.py:64-75) as one launch each way: -> (out [.., Fa + Fb], gate [.., Fa + Fb] = [s1 | s2])"""
+
+    @staticmethod
+    def forward(ctx, a, b, w1, b1, w2, b2):
+        lead = a.shape[:-1]
+        a2, b2d = a.contiguous().view(-1, a.shape[-1]), b.contiguous().view(-1, b.shape[-1])
+        out, gate = ops.soft_fusion_fwd(a2, b2d, w1, b1, w2, b2)
+        ctx.save_for_backward(a2, b2d, gate, w1, w2, b1, b2)
+        ctx.lead = lead
+        ctx.mark_non_differentiable(gate)
+        return out.view(lead + (out.shape[-1],)), gate.view(lead + (gate.shape[-1],))
+
+    @staticmethod
+    def backward(ctx, dout, _dgate):
+        a2, b2d, gate, w1, w2, b1, b2 = ctx.saved_tensors
+        dout = dout.contiguous().view(gate.shape)
+        sinks = [_sink(w1, w1.shape, dout), _sink(b1, b1.shape, dout), _sink(w2, w2.shape, dout), _sink(b2, b2.shape, dout)]
+        acc = all(sk[1] for sk in sinks)
+        if not acc and any(sk[1] for sk in sinks):
+            fresh = [_new(tuple(t.shape), dout) for t in (w1, b1, w2, b2)]
+            sinks = [(t, False, t) for t in fresh]
+        da, db = ops.soft_fusion_bwd(dout, a2, b2d, gate, w1, w2, sinks[0][0], sinks[1][0], sinks[2][0], sinks[3][0], acc)
+        return (da.view(ctx.lead + (da.shape[-1],)), db.view(ctx.lead + (db.shape[-1],)), sinks[0][2], sinks[1][2], sinks[2][2],
+                sinks[3][2])
+
+
+class HeadsFn(Function):
+    """DeepLIO.forward's end (deeplio_nets.py:84-90): dropout(p) -> fc_pos, fc_ori, as one launch each way.  x [B, S, ldx]: the
+    first K = fc_pos.in_features columns of every row are the features (the forward half of the odometry LSTM's bidirectional
+    output, read in place); its gradient comes back full width, the other columns zero."""
+
+    @staticmethod
+    def forward(ctx, x, wp, bp, wo, bo, p, training):
+        x = x.contiguous()
+        K = wp.shape[1]
+        ldx = x.shape[-1]
+        R = x.numel() // ldx
+        drop = training and p > 0.
+        off = _DROPOUT_STATE["offset"]
+        if drop:
+            _DROPOUT_STATE["offset"] = off + (R * K + 3) // 4
+        pos, ori, mask = ops.heads_fwd(x, ldx, R, K, wp, bp, wo, bo, p if drop else 0., _DROPOUT_STATE["seed"], off)
+        ctx.save_for_backward(x, wp, wo, bp, bo, mask)
+        ctx.cfg = (R, K, ldx, p if drop else 0.)
+        lead = x.shape[:-1]
+        return pos.view(lead + (3,)), ori.view(lead + (3,))
+
+    @staticmethod
+    def backward(ctx, dpos, dori):
+        x, wp, wo, bp, bo, mask = ctx.saved_tensors
+        R, K, ldx, p = ctx.cfg
+        dpos = (dpos if dpos is not None else torch.zeros(R, 3, device=x.device)).contiguous()
+        dori = (dori if dori is not None else torch.zeros(R, 3, device=x.device)).contiguous()
+        sinks = [_sink(wp, wp.shape, x), _sink(bp, bp.shape, x), _sink(wo, wo.shape, x), _sink(bo, bo.shape, x)]
+        acc = all(sk[1] for sk in sinks)
+        if not acc and any(sk[1] for sk in sinks):
+            fresh = [_new(tuple(t.shape), x) for t in (wp, bp, wo, bo)]
+            sinks = [(t, False, t) for t in fresh]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        ops.heads_bwd(dpos, dori, x, ldx, mask, wp, wo, dx, ldx, sinks[0][0], sinks[1][0], sinks[2][0], sinks[3][0], R, K, p, acc)
+        return dx, sinks[0][2], sinks[1][2], sinks[2][2], sinks[3][2], None, None
+
+
 _LSTM_LAYER = [os.environ.get("DLIO_LSTM_LAYER", "1") != "0"]      # wide LSTMs: one launch sequence per LAYER (lstm_stream.hip)
 
 

@@ -676,6 +676,15 @@ class DeepLIOFusionSoft(BaseNet):
 
     def forward(self, x):
         lidar, imu = x[0], x[1]
+        if (Fh._TAIL_FUSED[0] and lidar.is_cuda and lidar.dtype == torch.float32 and imu.dtype == torch.float32
+                and lidar.shape[:-1] == imu.shape[:-1]
+                and ops.soft_fusion_ok(lidar.numel() // lidar.shape[-1], lidar.shape[-1], imu.shape[-1])):
+            # cat + two gated linear layers + two products + cat as one launch
+            out, gate = Fh.SoftFusionFn.apply(lidar, imu, self.layers[0].weight, self.layers[0].bias, self.layers[1].weight,
+                                              self.layers[1].bias)
+            fa = lidar.shape[-1]
+            self.s1_feat, self.s2_feat = gate[..., :fa], gate[..., fa:]
+            return out
         cat = Fh.Cat2Fn.apply(lidar, imu)
         self.s1_feat = Fh.LinearFn.apply(cat, self.layers[0].weight, self.layers[0].bias, ops.ACT_SIGMOID)
         self.s2_feat = Fh.LinearFn.apply(cat, self.layers[1].weight, self.layers[1].bias, ops.ACT_SIGMOID)
@@ -723,9 +732,13 @@ class OdomFeatRNN(BaseNet):
         self.num_dir = 2 if self.bidirectional else 1
 
     def forward(self, x):
+        return self.forward_full(x)[:, :, :self.hidden_size]
+
+    def forward_full(self, x):
+        """[B, S, D H]: both directions' outputs of the top layer (the model keeps the first H columns, :82)"""
         b, s, n = x.shape
         tops = self.rnn.run(x.reshape(b, 1, s, n), self.training)   # [B, 1, S, D*H]
-        return tops[:, 0, :, :self.hidden_size]
+        return tops[:, 0]
 
     def get_output_shape(self):
         return [1, 1, self.hidden_size]
@@ -811,8 +824,20 @@ class DeepLIO(BaseNet):
                 and last.requires_grad):
             cb = self.tail_grads_ready
             last.register_hook(lambda g: cb())
+        K = self.fc_pos.in_features
+        if (Fh._TAIL_FUSED[0] and isinstance(self.odom_feat_net, OdomFeatRNN) and torch.is_tensor(last) and last.is_cuda
+                and last.dim() == 3 and self.odom_feat_net.hidden_size == K
+                and ops.heads_ok(last.shape[0] * last.shape[1], K, self.odom_feat_net.num_dir * K)):
+            # the heads read the forward half of the LSTM output in place: no slice copy, dropout + both heads one launch
+            full = self.odom_feat_net.forward_full(last)
+            return Fh.HeadsFn.apply(full, self.fc_pos.weight, self.fc_pos.bias, self.fc_ori.weight, self.fc_ori.bias,
+                                    self.p, self.training)
         if self.odom_feat_net is not None:
             last = self.odom_feat_net(last)
+        if (Fh._TAIL_FUSED[0] and torch.is_tensor(last) and last.is_cuda and last.dim() == 3 and last.shape[-1] == K
+                and last.dtype == torch.float32 and ops.heads_ok(last.shape[0] * last.shape[1], K, K)):
+            return Fh.HeadsFn.apply(last, self.fc_pos.weight, self.fc_pos.bias, self.fc_ori.weight, self.fc_ori.bias,
+                                    self.p, self.training)
         last = Fh.dropout(last, self.p, self.training)
         x_pos = Fh.LinearFn.apply(last, self.fc_pos.weight, self.fc_pos.bias, ops.ACT_NONE)
         x_ori = Fh.LinearFn.apply(last, self.fc_ori.weight, self.fc_ori.bias, ops.ACT_NONE)

@@ -1216,6 +1216,49 @@ def dropout_bwd(dy, mask, p):
     return dx
 
 
+def soft_fusion_ok(R, Fa, Fb):
+    return bool(lib.dlio_soft_fusion_ok(R, Fa, Fb))
+
+
+def soft_fusion_fwd(a, b, w1, b1, w2, b2):
+    """DeepLIOFusionSoft.forward as one launch: a [R, Fa], b [R, Fb] -> (out [R, Fa + Fb], gate [R, Fa + Fb] = [s1 | s2])"""
+    R, Fa = a.shape
+    Fb = b.shape[1]
+    out = torch.empty(R, Fa + Fb, dtype=torch.float32, device=a.device)
+    gate = torch.empty(R, Fa + Fb, dtype=torch.float32, device=a.device)
+    check(lib.dlio_soft_fusion_fwd(_ptr(a), _ptr(b), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(out), _ptr(gate), R, Fa, Fb,
+                                   _stream()), "soft_fusion_fwd")
+    return out, gate
+
+
+def soft_fusion_bwd(dout, a, b, gate, w1, w2, dw1, db1, dw2, db2, accumulate):
+    R, Fa = a.shape
+    Fb = b.shape[1]
+    da, db = torch.empty_like(a), torch.empty_like(b)
+    check(lib.dlio_soft_fusion_bwd(_ptr(dout), _ptr(a), _ptr(b), _ptr(gate), _ptr(w1), _ptr(w2), _ptr(da), _ptr(db), _ptr(dw1),
+                                   _ptr(db1), _ptr(dw2), _ptr(db2), R, Fa, Fb, int(accumulate), _stream()), "soft_fusion_bwd")
+    return da, db
+
+
+def heads_ok(R, K, ldx):
+    return bool(lib.dlio_heads_ok(R, K, ldx))
+
+
+def heads_fwd(x, ldx, R, K, wp, bp, wo, bo, p, seed, offset):
+    """dropout(p) + fc_pos + fc_ori over rows of x (row stride ldx) -> (pos [R, 3], ori [R, 3], mask [R, K] u8 | None)"""
+    pos = torch.empty(R, 3, dtype=torch.float32, device=x.device)
+    ori = torch.empty(R, 3, dtype=torch.float32, device=x.device)
+    mask = torch.empty(R, K, dtype=torch.uint8, device=x.device) if p > 0. else None
+    check(lib.dlio_heads_fwd(_ptr(x), ldx, _ptr(mask), _ptr(wp), _ptr(bp), _ptr(wo), _ptr(bo), _ptr(pos), _ptr(ori), R, K,
+                             float(p), int(seed), int(offset), _stream()), "heads_fwd")
+    return pos, ori, mask
+
+
+def heads_bwd(dpos, dori, x, ldx, mask, wp, wo, dx, lddx, dwp, dbp, dwo, dbo, R, K, p, accumulate):
+    check(lib.dlio_heads_bwd(_ptr(dpos), _ptr(dori), _ptr(x), ldx, _ptr(mask), _ptr(wp), _ptr(wo), _ptr(dx), lddx, _ptr(dwp),
+                             _ptr(dbp), _ptr(dwo), _ptr(dbo), R, K, float(p), int(accumulate), _stream()), "heads_bwd")
+
+
 def nonfinite_flag(x, flag):
     check(lib.dlio_nonfinite_flag(_ptr(x), x.numel(), _ptr(flag), _stream()), "nonfinite_flag")
 

