@@ -165,9 +165,10 @@ SIGNATURES = {
     "dlio_lstm_layer_fwd": (_i, [_p, _i] + [_p] * 8 + [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "dlio_lstm_layer_bwd": (_i, [_p, _i, _p, _i, _p, _p, _p] + [_p] * 4 + [_p] + [_p] * 8 + [_i, _p, _i, _i, _i, _i, _i, _i, _p,
                                  _sz, _p]),
+    "dlio_optim_set_max_blocks": (_i, [_i]),
     "dlio_soft_fusion_ok": (_i, [_i, _i, _i]),
-    "dlio_soft_fusion_fwd": (_i, [_p] * 8 + [_i, _i, _i, _p]),
-    "dlio_soft_fusion_bwd": (_i, [_p] * 12 + [_i, _i, _i, _i, _p]),
+    "dlio_soft_fusion_fwd": (_i, [_p, _i, _p, _i] + [_p] * 6 + [_i, _i, _i, _p]),
+    "dlio_soft_fusion_bwd": (_i, [_p, _p, _i, _p, _i] + [_p] * 9 + [_i, _i, _i, _i, _p]),
     "dlio_heads_ok": (_i, [_i, _i, _i]),
     "dlio_heads_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _u64, _u64, _p]),
     "dlio_heads_bwd": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _f, _i, _p]),

@@ -698,7 +698,7 @@ __global__ __launch_bounds__(256) void soft_fusion_fwd_kernel(const float* __res
                                                               const float* __restrict__ w1, const float* __restrict__ b1,
                                                               const float* __restrict__ w2, const float* __restrict__ b2,
                                                               float* __restrict__ out, float* __restrict__ gate, int R, int Fa,
-                                                              int Fb) {
+                                                              int Fb, int lda, int ldb) {
   const int F = Fa + Fb;
   const int lane = threadIdx.x & 63;
   const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -711,11 +711,14 @@ __global__ __launch_bounds__(256) void soft_fusion_fwd_kernel(const float* __res
     for (int mm = 0; mm < 16; ++mm) acc[mm] = 0.f;
     for (int k = lane; k < F; k += 64) {
       const float wv = wr[k];
+      // (one pointer / stride per column, rows past R re-read the last row: 16 independent loads in flight, no branch)
+      const float* __restrict__ src = k < Fa ? a + k : b + (k - Fa);
+      const int st = k < Fa ? lda : ldb;
+      float xv[16];
 #pragma unroll
-      for (int mm = 0; mm < 16; ++mm) {
-        const int m = m0 + mm;
-        if (m < R) acc[mm] += wv * (k < Fa ? a[(size_t)m * Fa + k] : b[(size_t)m * Fb + (k - Fa)]);
-      }
+      for (int mm = 0; mm < 16; ++mm) xv[mm] = src[(size_t)min(m0 + mm, R - 1) * st];
+#pragma unroll
+      for (int mm = 0; mm < 16; ++mm) acc[mm] += wv * xv[mm];
     }
 #pragma unroll
     for (int mm = 0; mm < 16; ++mm) acc[mm] = wave_sum(acc[mm]);
@@ -725,7 +728,7 @@ __global__ __launch_bounds__(256) void soft_fusion_fwd_kernel(const float* __res
 #pragma unroll
       for (int mm = 0; mm < 16; ++mm) v = lane == mm ? acc[mm] : v;
       const float sg = 1.0f / (1.0f + expf(-(v + bias)));
-      const float src = j < Fa ? a[(size_t)m * Fa + j] : b[(size_t)m * Fb + (j - Fa)];
+      const float src = j < Fa ? a[(size_t)m * lda + j] : b[(size_t)m * ldb + (j - Fa)];
       out[(size_t)m * F + j] = src * sg;
       gate[(size_t)m * F + j] = sg;
     }
@@ -742,7 +745,7 @@ __global__ __launch_bounds__(256) void soft_fusion_bwd_kernel(const float* __res
                                                               float* __restrict__ da, float* __restrict__ db_,
                                                               float* __restrict__ dw1, float* __restrict__ dbias1,
                                                               float* __restrict__ dw2, float* __restrict__ dbias2, int R, int Fa,
-                                                              int Fb, int accumulate) {
+                                                              int Fb, int lda, int ldb, int accumulate) {
   __shared__ float sdp[16][FMAX], scat[16][FMAX];
   const int F = Fa + Fb;
   const int g0 = blockIdx.x * 16;
@@ -758,7 +761,7 @@ __global__ __launch_bounds__(256) void soft_fusion_bwd_kernel(const float* __res
       const int mm = i / F, c = i - mm * F, m = m0 + mm;
       float dp = 0.f, cv = 0.f;
       if (m < R) {
-        cv = c < Fa ? a[(size_t)m * Fa + c] : b[(size_t)m * Fb + (c - Fa)];
+        cv = c < Fa ? a[(size_t)m * lda + c] : b[(size_t)m * ldb + (c - Fa)];
         const float sg = gate[(size_t)m * F + c];
         dp = dout[(size_t)m * F + c] * cv * sg * (1.f - sg);
       }
@@ -782,10 +785,18 @@ __global__ __launch_bounds__(256) void soft_fusion_bwd_kernel(const float* __res
     const int k = g0 + kg, m = m0 + jj;
     if (k < F && m < R) {
       float s = 0.f;
-      for (int jx = 0; jx < F; ++jx) {
-        const float wv = jx < Fa ? w1[(size_t)jx * F + k] : w2[(size_t)(jx - Fa) * F + k];
-        s += sdp[jj][jx] * wv;
+      int jx = 0;
+      for (; jx + 8 <= F; jx += 8) {                 // eight weight loads in flight (a column walk: 64 B per 16 lanes and row)
+        float wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int r = jx + u;
+          wv[u] = r < Fa ? w1[(size_t)r * F + k] : w2[(size_t)(r - Fa) * F + k];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += sdp[jj][jx + u] * wv[u];
       }
+      for (; jx < F; ++jx) s += sdp[jj][jx] * (jx < Fa ? w1[(size_t)jx * F + k] : w2[(size_t)(jx - Fa) * F + k]);
       const float v = s + dout[(size_t)m * F + k] * gate[(size_t)m * F + k];
       if (k < Fa) da[(size_t)m * Fa + k] = v;
       else db_[(size_t)m * Fb + (k - Fa)] = v;
@@ -1110,27 +1121,29 @@ extern "C" int dlio_nonfinite_flag(const float* x, int64_t n, int32_t* flag,
 
 extern "C" int dlio_soft_fusion_ok(int R, int Fa, int Fb) { return R > 0 && Fa > 0 && Fb > 0 && Fa + Fb <= 512; }
 
-extern "C" int dlio_soft_fusion_fwd(const float* a, const float* b, const float* w1, const float* b1, const float* w2,
-                                    const float* b2, float* out, float* gate, int R, int Fa, int Fb, dlio_stream_t stream) {
-  if (!a || !b || !w1 || !w2 || !out || !gate) return DLIO_EINVAL;
+extern "C" int dlio_soft_fusion_fwd(const float* a, int lda, const float* b, int ldb, const float* w1, const float* b1,
+                                    const float* w2, const float* b2, float* out, float* gate, int R, int Fa, int Fb,
+                                    dlio_stream_t stream) {
+  if (!a || !b || !w1 || !w2 || !out || !gate || lda < Fa || ldb < Fb) return DLIO_EINVAL;
   if (!dlio_soft_fusion_ok(R, Fa, Fb)) return DLIO_EUNSUP;
   hipLaunchKernelGGL(soft_fusion_fwd_kernel, dim3(cdiv(Fa + Fb, 4)), dim3(256), 0, as_stream(stream), a, b, w1, b1, w2, b2, out,
-                     gate, R, Fa, Fb);
+                     gate, R, Fa, Fb, lda, ldb);
   return dlio_check_launch();
 }
 
-extern "C" int dlio_soft_fusion_bwd(const float* dout, const float* a, const float* b, const float* gate, const float* w1,
-                                    const float* w2, float* da, float* db, float* dw1, float* dbias1, float* dw2, float* dbias2,
-                                    int R, int Fa, int Fb, int accumulate, dlio_stream_t stream) {
-  if (!dout || !a || !b || !gate || !w1 || !w2 || !da || !db || !dw1 || !dbias1 || !dw2 || !dbias2) return DLIO_EINVAL;
+extern "C" int dlio_soft_fusion_bwd(const float* dout, const float* a, int lda, const float* b, int ldb, const float* gate,
+                                    const float* w1, const float* w2, float* da, float* db, float* dw1, float* dbias1, float* dw2,
+                                    float* dbias2, int R, int Fa, int Fb, int accumulate, dlio_stream_t stream) {
+  if (!dout || !a || !b || !gate || !w1 || !w2 || !da || !db || !dw1 || !dbias1 || !dw2 || !dbias2 || lda < Fa || ldb < Fb)
+    return DLIO_EINVAL;
   if (!dlio_soft_fusion_ok(R, Fa, Fb)) return DLIO_EUNSUP;
   const int F = Fa + Fb;
   if (F <= 256)
     hipLaunchKernelGGL((soft_fusion_bwd_kernel<256>), dim3(cdiv(F, 16)), dim3(256), 0, as_stream(stream), dout, a, b, gate, w1, w2,
-                       da, db, dw1, dbias1, dw2, dbias2, R, Fa, Fb, accumulate);
+                       da, db, dw1, dbias1, dw2, dbias2, R, Fa, Fb, lda, ldb, accumulate);
   else
     hipLaunchKernelGGL((soft_fusion_bwd_kernel<512>), dim3(cdiv(F, 16)), dim3(256), 0, as_stream(stream), dout, a, b, gate, w1, w2,
-                       da, db, dw1, dbias1, dw2, dbias2, R, Fa, Fb, accumulate);
+                       da, db, dw1, dbias1, dw2, dbias2, R, Fa, Fb, lda, ldb, accumulate);
   return dlio_check_launch();
 }
 

@@ -24,6 +24,29 @@ namespace {
 
 __device__ __forceinline__ float sigm_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// p[0] + p[stride] + ... (n terms, in that order) with up to eight loads in flight
+__device__ __forceinline__ float sum_strided(const float* __restrict__ p, int n, size_t stride) {
+  float s = 0.f;
+  int i = 0;
+  for (; i + 8 <= n; i += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(i + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  if (i + 4 <= n) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = p[(size_t)(i + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s += v[u];
+    i += 4;
+  }
+  for (; i < n; ++i) s += p[(size_t)i * stride];
+  return s;
+}
+
 // ------------------------------------------------------------------------------------------------- y_part = x W^T (slice of K)
 // grid (ceil(N / 64), KQ, D); block 256 = 4 waves; wave w owns the 16 weight rows blockIdx.x * 64 + 16 w .. + 15 over one K slice
 // of KS * 256 columns of one direction.  The product runs on v_mfma_f32_16x16x4_f32 (exact fp32: an fmaf chain) with the
@@ -112,14 +135,10 @@ __global__ void lstm_cell_fwd2_kernel(const float* __restrict__ gxp, int KQi, co
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int n = g * H + k;
-      float s = 0.f;
-      for (int q = 0; q < KQi; ++q) s += gxp[(((size_t)d * KQi + q) * rows + row) * G + n];
-      s += bi ? bi[n] : 0.f;
-      float rsum = 0.f;
-      if (step > 0)
-        for (int q = 0; q < KQh; ++q) rsum += recp[(((size_t)d * KQh + q) * B + b) * G + n];
-      rsum += bh ? bh[n] : 0.f;
-      pre[g] = s + rsum;
+      const float* __restrict__ gp = gxp + ((size_t)d * KQi * rows + row) * G + n;
+      const float* __restrict__ rp = recp + ((size_t)d * KQh * B + b) * G + n;
+      pre[g] = (sum_strided(gp, KQi, (size_t)rows * G) + (bi ? bi[n] : 0.f)) +
+               ((step > 0 ? sum_strided(rp, KQh, (size_t)B * G) : 0.f) + (bh ? bh[n] : 0.f));
     }
     const float ig = sigm_(pre[0]), fg = sigm_(pre[1]), gg = tanhf(pre[2]), og = sigm_(pre[3]);
     const float cprev = step > 0 ? cs[((size_t)d * rows + rowp) * H + k] : 0.f;
@@ -154,11 +173,7 @@ __global__ void lstm_cell_bwd2_kernel(const float* __restrict__ dhs, int lddhs, 
     const float c = cs[dr * H + k];
     const float cp = first_fwd ? 0.f : cs[((size_t)d * rows + b * T + tp) * H + k];
     float dh = dhs ? dhs[(size_t)row * lddhs + d * H + k] : 0.f;
-    if (step > 0) {
-      float s = 0.f;
-      for (int sp = 0; sp < NS; ++sp) s += dhp[(((size_t)d * NS + sp) * B + b) * H + k];
-      dh += s;
-    }
+    if (step > 0) dh += sum_strided(dhp + ((size_t)d * NS * B + b) * H + k, NS, (size_t)B * H);
     const float tc = tanhf(c);
     const float dcin = step > 0 ? dccur[e] : 0.f;
     const float dc = fmaf(dh * og, 1.f - tc * tc, dcin);
@@ -290,20 +305,35 @@ __global__ __launch_bounds__(256) void lstm_wgrad_kernel(WgArgs a, int lddz, int
   float4 acc[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int m = 0; m < M; ++m) {
-    const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)m * s.ldx + k);
+  // (the old values of an accumulating launch are requested first: they arrive under the product)
+  float4 old[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    old[j] = (accumulate && n0 + j < N) ? *reinterpret_cast<const float4*>(s.dw + (size_t)(n0 + j) * K + k)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int nr = min(4, N - n0);
+  auto fma_row = [&](int m, const float4& xv) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float g = n0 + j < N ? dz[(size_t)m * lddz + n0 + j] : 0.f;
+      const float g = j < nr ? dz[(size_t)m * lddz + n0 + j] : 0.f;
       acc[j].x += g * xv.x; acc[j].y += g * xv.y; acc[j].z += g * xv.z; acc[j].w += g * xv.w;
     }
+  };
+  int m = 0;
+  for (; m + 4 <= M; m += 4) {
+    float4 xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xv[u] = *reinterpret_cast<const float4*>(x + (size_t)(m + u) * s.ldx + k);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fma_row(m + u, xv[u]);
   }
+  for (; m < M; ++m) fma_row(m, *reinterpret_cast<const float4*>(x + (size_t)m * s.ldx + k));
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    if (n0 + j < N) {
-      float4* p = reinterpret_cast<float4*>(s.dw + (size_t)(n0 + j) * K + k);
-      if (accumulate) { const float4 o = *p; acc[j].x += o.x; acc[j].y += o.y; acc[j].z += o.z; acc[j].w += o.w; }
-      *p = acc[j];
+    if (j < nr) {
+      float4 o = old[j];
+      o.x += acc[j].x; o.y += acc[j].y; o.z += acc[j].z; o.w += acc[j].w;
+      *reinterpret_cast<float4*>(s.dw + (size_t)(n0 + j) * K + k) = o;
     }
   }
 }

@@ -120,7 +120,23 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   if (threadIdx.x == 0) atomicAdd(out, r);
 }
 
+// workgroups an optimizer sweep may use (0: the default of every memory-bound sweep, 8 per CU).  A sweep issued from inside the
+// backward pass (FlatOptimizer.step_early: the tail bucket's update under the encoder backward) is background work: at the full
+// grid its 2048 resident workgroups starve the 3-30 us launches of the critical chain for the sweep's whole length.
+int g_max_blocks = 0;
+inline int opt_grid(int64_t items) {
+  int g = ew_grid(items, 256);
+  if (g_max_blocks > 0 && g > g_max_blocks) g = g_max_blocks;
+  return g;
+}
+
 }  // namespace
+
+extern "C" int dlio_optim_set_max_blocks(int blocks) {
+  if (blocks < 0) return DLIO_EINVAL;
+  g_max_blocks = blocks;
+  return DLIO_OK;
+}
 
 extern "C" int dlio_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr,
                               float beta1, float beta2, float eps, float weight_decay, int step,
@@ -130,7 +146,7 @@ extern "C" int dlio_adam_step(float* p, const float* g, float* m, float* v, int6
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   const float lr_over_bc1 = (float)((double)lr / bc1);
   const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-  int grid = ew_grid(cdiv64(n, 4), 256);
+  int grid = opt_grid(cdiv64(n, 4));
   hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, as_stream(stream), p, g, m, v, n,
                      lr_over_bc1, beta1, beta2, eps, weight_decay, inv_sqrt_bc2, grad_scale);
   return dlio_check_launch();
@@ -140,7 +156,7 @@ extern "C" int dlio_sgd_step(float* p, const float* g, float* buf, int64_t n, fl
                              float momentum, float weight_decay, int step, float grad_scale,
                              dlio_stream_t stream) {
   if (!p || !g || n <= 0 || step < 1 || (momentum != 0.f && !buf)) return DLIO_EINVAL;
-  hipLaunchKernelGGL(sgd_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, as_stream(stream), p, g, buf,
+  hipLaunchKernelGGL(sgd_kernel, dim3(opt_grid(n)), dim3(256), 0, as_stream(stream), p, g, buf,
                      n, lr, momentum, weight_decay, step == 1 ? 1 : 0, grad_scale);
   return dlio_check_launch();
 }
@@ -150,7 +166,7 @@ extern "C" int dlio_rmsprop_step(float* p, const float* g, float* square_avg, fl
                                  float weight_decay, float momentum, float grad_scale,
                                  dlio_stream_t stream) {
   if (!p || !g || !square_avg || n <= 0 || (momentum != 0.f && !momentum_buf)) return DLIO_EINVAL;
-  hipLaunchKernelGGL(rmsprop_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, as_stream(stream), p, g,
+  hipLaunchKernelGGL(rmsprop_kernel, dim3(opt_grid(n)), dim3(256), 0, as_stream(stream), p, g,
                      square_avg, momentum != 0.f ? momentum_buf : nullptr, grad_avg, n, lr, alpha, eps,
                      weight_decay, momentum, grad_scale);
   return dlio_check_launch();
@@ -160,7 +176,7 @@ extern "C" int dlio_adadelta_step(float* p, const float* g, float* square_avg, f
                                   int64_t n, float lr, float rho, float eps, float weight_decay,
                                   float grad_scale, dlio_stream_t stream) {
   if (!p || !g || !square_avg || !acc_delta || n <= 0) return DLIO_EINVAL;
-  hipLaunchKernelGGL(adadelta_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, as_stream(stream), p, g,
+  hipLaunchKernelGGL(adadelta_kernel, dim3(opt_grid(n)), dim3(256), 0, as_stream(stream), p, g,
                      square_avg, acc_delta, n, lr, rho, eps, weight_decay, grad_scale);
   return dlio_check_launch();
 }

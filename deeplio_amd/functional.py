@@ -1762,31 +1762,49 @@ class RNNFn(Function):
 _TAIL_FUSED = [os.environ.get("DLIO_TAIL_FUSED", "1") != "0"]      # soft fusion / dropout + heads as one launch each
 
 
+def _rows_view(t):
+    """t [..., F] -> (tensor to hand to a kernel, row stride) when its rows are F contiguous floats a uniform stride apart
+    (a contiguous tensor, or a slice like rnn_out[:, :, -1, :H]); else a contiguous copy"""
+    F_ = t.shape[-1]
+    if t.stride(-1) == 1 and t.dim() >= 2:
+        ld, ok = t.stride(-2), True
+        for i in range(t.dim() - 2):            # leading dimensions must collapse onto the row stride
+            ok = ok and t.stride(i) == t.stride(i + 1) * t.shape[i + 1]
+        if ok and ld >= F_ and ld % 4 == 0 and t.data_ptr() % 16 == 0:
+            return t, ld
+    t = t.contiguous()
+    return t, F_
+
+
 class SoftFusionFn(Function):
     """DeepLIOFusionSoft.forward (fusion_nets.py:64-75) as one launch each way: -> (out [.., Fa + Fb], gate [.., Fa + Fb] = [s1 | s2])"""
 
     @staticmethod
     def forward(ctx, a, b, w1, b1, w2, b2):
-        lead = a.shape[:-1]
-        a2, b2d = a.contiguous().view(-1, a.shape[-1]), b.contiguous().view(-1, b.shape[-1])
-        out, gate = ops.soft_fusion_fwd(a2, b2d, w1, b1, w2, b2)
-        ctx.save_for_backward(a2, b2d, gate, w1, w2, b1, b2)
-        ctx.lead = lead
+        lead = tuple(a.shape[:-1])
+        Fa, Fb = a.shape[-1], b.shape[-1]
+        R = a.numel() // Fa
+        av, lda = _rows_view(a)
+        bv, ldb = _rows_view(b)
+        out, gate = ops.soft_fusion_fwd(av, lda, bv, ldb, R, Fa, Fb, w1, b1, w2, b2)
+        ctx.save_for_backward(av, bv, gate, w1, w2, b1, b2)
+        ctx.cfg = (lead, R, Fa, Fb, lda, ldb)
         ctx.mark_non_differentiable(gate)
-        return out.view(lead + (out.shape[-1],)), gate.view(lead + (gate.shape[-1],))
+        return out.view(lead + (Fa + Fb,)), gate.view(lead + (Fa + Fb,))
 
     @staticmethod
     def backward(ctx, dout, _dgate):
-        a2, b2d, gate, w1, w2, b1, b2 = ctx.saved_tensors
+        av, bv, gate, w1, w2, b1, b2 = ctx.saved_tensors
+        lead, R, Fa, Fb, lda, ldb = ctx.cfg
         dout = dout.contiguous().view(gate.shape)
         sinks = [_sink(w1, w1.shape, dout), _sink(b1, b1.shape, dout), _sink(w2, w2.shape, dout), _sink(b2, b2.shape, dout)]
         acc = all(sk[1] for sk in sinks)
         if not acc and any(sk[1] for sk in sinks):
             fresh = [_new(tuple(t.shape), dout) for t in (w1, b1, w2, b2)]
             sinks = [(t, False, t) for t in fresh]
-        da, db = ops.soft_fusion_bwd(dout, a2, b2d, gate, w1, w2, sinks[0][0], sinks[1][0], sinks[2][0], sinks[3][0], acc)
-        return (da.view(ctx.lead + (da.shape[-1],)), db.view(ctx.lead + (db.shape[-1],)), sinks[0][2], sinks[1][2], sinks[2][2],
-                sinks[3][2])
+        da, db = ops.soft_fusion_bwd(dout, av, lda, bv, ldb, R, Fa, Fb, gate, w1, w2, sinks[0][0], sinks[1][0], sinks[2][0],
+                                     sinks[3][0], acc)
+        return (da.view(lead + (Fa,)), db.view(lead + (Fb,)), sinks[0][2], sinks[1][2], sinks[2][2], sinks[3][2])
 
 
 class HeadsFn(Function):
@@ -1843,10 +1861,14 @@ class LstmStackFn(Function):
     net (odom_feat_nets.py:61-68,72-83: 256 -> 1024, 2 layers, bidirectional, over the S axis): every layer is ONE call that
     runs both directions and all steps (csrc/lstm_stream.hip: 2 T launches forward, 2 T + 2 backward, weights streamed in
     K slices / N slabs at HBM rate) instead of RNNFn's per-direction, per-step dlio_linear_* + cell launches on two streams.
-    x [B, T, I] -> [B, T, D H]; inter-layer dropout as nn.LSTM (train only)."""
+    x [B, T, I] -> [B, T, D H]; inter-layer dropout as nn.LSTM (train only).
+    top_fwd_only: the caller keeps the forward direction of the top layer only (odom_feat_nets.py:82, SURVEY Q3: the reverse
+    half of a bidirectional top layer is discarded, its parameters get a zero gradient) -- that direction of that layer is not
+    run at all (a quarter of the net's weight traffic each way); the result is [B, T, H] and the reverse direction's
+    parameters receive no gradient (None: an all-zero gradient for the optimizer, as in the reference)."""
 
     @staticmethod
-    def forward(ctx, x, H, L, D, p, training, *weights):
+    def forward(ctx, x, H, L, D, p, training, top_fwd_only, *weights):
         x = x.contiguous()
         B, T, I = x.shape
         rows = B * T
@@ -1856,9 +1878,10 @@ class LstmStackFn(Function):
         out = None
         for l in range(L):
             Il = inp.shape[1]
-            out = _new((rows, D * H), x)
-            cs, hp, gates = ops.lstm_layer_fwd(inp, Il, W[l], out, D * H, T, B, Il, H, D)
-            rec = {"inp": inp, "cs": cs, "hp": hp, "gates": gates}
+            Dl = 1 if (top_fwd_only and l == L - 1) else D
+            out = _new((rows, Dl * H), x)
+            cs, hp, gates = ops.lstm_layer_fwd(inp, Il, W[l], out, Dl * H, T, B, Il, H, Dl)
+            rec = {"inp": inp, "cs": cs, "hp": hp, "gates": gates, "D": Dl}
             if l + 1 < L and training and p > 0.:
                 inp, rec["mask"] = _dropout_launch(out, p)
             else:
@@ -1866,40 +1889,45 @@ class LstmStackFn(Function):
             saved.append(rec)
         ctx.saved, ctx.weights = saved, weights
         ctx.cfg = (H, L, D, p, B, T, I)
-        return out.view(B, T, D * H)
+        return out.view(B, T, out.shape[1])
 
     @staticmethod
     def backward(ctx, dtop):
         H, L, D, p, B, T, I = ctx.cfg
         weights, saved = ctx.weights, ctx.saved
         rows = B * T
-        dout = dtop.contiguous().view(rows, D * H)
+        dout = dtop.contiguous().view(rows, -1)
         grads = [None] * len(weights)
         dx = None
         for l in reversed(range(L)):
             rec = saved[l]
+            Dl = rec["D"]
             Il = rec["inp"].shape[1]
             need_dinp = l > 0 or ctx.needs_input_grad[0]
             dinp = _new((rows, Il), dout) if need_dinp else None
             shapes = ((4 * H, Il), (4 * H, H), (4 * H,), (4 * H,))
-            sinks = [[_sink(weights[(l * D + d) * 4 + j], shapes[j], dout) for j in range(4)] for d in range(D)]
+            sinks = [[_sink(weights[(l * D + d) * 4 + j], shapes[j], dout) for j in range(4)] for d in range(Dl)]
             acc = all(sk[1] for dd in sinks for sk in dd)
             if not acc and any(sk[1] for dd in sinks for sk in dd):     # one accumulate flag per launch: fresh buffers for all
-                sinks = [[(_new(shapes[j], dout), False, None) for j in range(4)] for d in range(D)]
-                sinks = [[(t, False, t) for t, _, _ in dd] for dd in sinks]
-            for d in range(D):
+                sinks = [[_new(shapes[j], dout) for j in range(4)] for d in range(Dl)]
+                sinks = [[(t, False, t) for t in dd] for dd in sinks]
+            for d in range(Dl):
                 for j in range(4):
                     grads[(l * D + d) * 4 + j] = sinks[d][j][2]
-            ops.lstm_layer_bwd(dout, D * H, rec["inp"], Il, rec["hp"], rec["gates"], rec["cs"],
-                               [(weights[(l * D + d) * 4], weights[(l * D + d) * 4 + 1]) for d in range(D)],
-                               [tuple(sk[0] for sk in sinks[d]) for d in range(D)], acc, dinp, Il, T, B, Il, H, D)
+            for d in range(Dl, D):                # the direction that was not run: an all-zero gradient (a sunk .grad stays as it is)
+                for j in range(4):
+                    t, a_, r_ = _sink(weights[(l * D + d) * 4 + j], shapes[j], dout)
+                    grads[(l * D + d) * 4 + j] = None if a_ else t.zero_()
+            ops.lstm_layer_bwd(dout, Dl * H, rec["inp"], Il, rec["hp"], rec["gates"], rec["cs"],
+                               [(weights[(l * D + d) * 4], weights[(l * D + d) * 4 + 1]) for d in range(Dl)],
+                               [tuple(sk[0] for sk in sinks[d]) for d in range(Dl)], acc, dinp, Il, T, B, Il, H, Dl)
             if l > 0:
                 prev = saved[l - 1]
                 dout = ops.dropout_bwd(dinp, prev["mask"], p) if "mask" in prev else dinp
             else:
                 dx = dinp.view(B, T, I) if dinp is not None else None
         ctx.saved = None
-        return (dx, None, None, None, None, None) + tuple(grads)
+        return (dx, None, None, None, None, None, None) + tuple(grads)
 
 
 # =============================================================================== pose chain / loss

@@ -602,13 +602,14 @@ class RNNParams(nn.Module):
     def flat_weights(self):
         return [getattr(self, n) for n in self._order]
 
-    def run(self, x4, training):
-        """x4 [B, Sg, T, I] -> [B, Sg, T, D*H]"""
+    def run(self, x4, training, top_fwd_only=False):
+        """x4 [B, Sg, T, I] -> [B, Sg, T, D*H] (top_fwd_only: the caller keeps [..., :H] only -- the streamed layer path then
+        returns [B, Sg, T, H] and never runs the top layer's reverse direction; the other paths ignore the hint)"""
         D = 2 if self.bidirectional else 1
         if Fh.lstm_stack_ok(x4, self.mode, self.hidden_size, self.num_layers, D):
             # one sequence per sample, wide hidden state (the odometry net): one both-directions launch sequence per layer
             return Fh.LstmStackFn.apply(x4[:, 0], self.hidden_size, self.num_layers, D, self.dropout, training,
-                                        *self.flat_weights()).unsqueeze(1)
+                                        bool(top_fwd_only and D == 2), *self.flat_weights()).unsqueeze(1)
         return Fh.RNNFn.apply(x4, self.mode, self.hidden_size, self.num_layers, D, self.dropout,
                               training, *self.flat_weights())
 
@@ -735,9 +736,15 @@ class OdomFeatRNN(BaseNet):
         return self.forward_full(x)[:, :, :self.hidden_size]
 
     def forward_full(self, x):
-        """[B, S, D H]: both directions' outputs of the top layer (the model keeps the first H columns, :82)"""
+        """[B, S, H | D H]: the top layer's outputs whose first H columns the model keeps (:82) -- the streamed layer path
+        delivers just those, the per-direction path both directions"""
         b, s, n = x.shape
-        tops = self.rnn.run(x.reshape(b, 1, s, n), self.training)   # [B, 1, S, D*H]
+        r = self.rnn
+        D = 2 if r.bidirectional else 1
+        if Fh.lstm_stack_ok(x.unsqueeze(1), r.mode, r.hidden_size, r.num_layers, D):
+            # (no unsqueeze / select views around the node: their backward is a zero fill + a copy each)
+            return Fh.LstmStackFn.apply(x, r.hidden_size, r.num_layers, D, r.dropout, self.training, D == 2, *r.flat_weights())
+        tops = r.run(x.reshape(b, 1, s, n), self.training, top_fwd_only=True)   # [B, 1, S, H | D*H]
         return tops[:, 0]
 
     def get_output_shape(self):
@@ -826,8 +833,7 @@ class DeepLIO(BaseNet):
             last.register_hook(lambda g: cb())
         K = self.fc_pos.in_features
         if (Fh._TAIL_FUSED[0] and isinstance(self.odom_feat_net, OdomFeatRNN) and torch.is_tensor(last) and last.is_cuda
-                and last.dim() == 3 and self.odom_feat_net.hidden_size == K
-                and ops.heads_ok(last.shape[0] * last.shape[1], K, self.odom_feat_net.num_dir * K)):
+                and last.dim() == 3 and self.odom_feat_net.hidden_size == K and K % 4 == 0 and K <= 8192):
             # the heads read the forward half of the LSTM output in place: no slice copy, dropout + both heads one launch
             full = self.odom_feat_net.forward_full(last)
             return Fh.HeadsFn.apply(full, self.fc_pos.weight, self.fc_pos.bias, self.fc_ori.weight, self.fc_ori.bias,

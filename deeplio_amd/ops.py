@@ -1220,23 +1220,22 @@ def soft_fusion_ok(R, Fa, Fb):
     return bool(lib.dlio_soft_fusion_ok(R, Fa, Fb))
 
 
-def soft_fusion_fwd(a, b, w1, b1, w2, b2):
-    """DeepLIOFusionSoft.forward as one launch: a [R, Fa], b [R, Fb] -> (out [R, Fa + Fb], gate [R, Fa + Fb] = [s1 | s2])"""
-    R, Fa = a.shape
-    Fb = b.shape[1]
+def soft_fusion_fwd(a, lda, b, ldb, R, Fa, Fb, w1, b1, w2, b2):
+    """DeepLIOFusionSoft.forward as one launch: rows of a / b with strides lda / ldb -> (out [R, Fa + Fb], gate [R, Fa + Fb] =
+    [s1 | s2])"""
     out = torch.empty(R, Fa + Fb, dtype=torch.float32, device=a.device)
     gate = torch.empty(R, Fa + Fb, dtype=torch.float32, device=a.device)
-    check(lib.dlio_soft_fusion_fwd(_ptr(a), _ptr(b), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(out), _ptr(gate), R, Fa, Fb,
-                                   _stream()), "soft_fusion_fwd")
+    check(lib.dlio_soft_fusion_fwd(_ptr(a), lda, _ptr(b), ldb, _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(out), _ptr(gate), R,
+                                   Fa, Fb, _stream()), "soft_fusion_fwd")
     return out, gate
 
 
-def soft_fusion_bwd(dout, a, b, gate, w1, w2, dw1, db1, dw2, db2, accumulate):
-    R, Fa = a.shape
-    Fb = b.shape[1]
-    da, db = torch.empty_like(a), torch.empty_like(b)
-    check(lib.dlio_soft_fusion_bwd(_ptr(dout), _ptr(a), _ptr(b), _ptr(gate), _ptr(w1), _ptr(w2), _ptr(da), _ptr(db), _ptr(dw1),
-                                   _ptr(db1), _ptr(dw2), _ptr(db2), R, Fa, Fb, int(accumulate), _stream()), "soft_fusion_bwd")
+def soft_fusion_bwd(dout, a, lda, b, ldb, R, Fa, Fb, gate, w1, w2, dw1, db1, dw2, db2, accumulate):
+    da = torch.empty(R, Fa, dtype=torch.float32, device=dout.device)
+    db = torch.empty(R, Fb, dtype=torch.float32, device=dout.device)
+    check(lib.dlio_soft_fusion_bwd(_ptr(dout), _ptr(a), lda, _ptr(b), ldb, _ptr(gate), _ptr(w1), _ptr(w2), _ptr(da), _ptr(db),
+                                   _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2), R, Fa, Fb, int(accumulate), _stream()),
+          "soft_fusion_bwd")
     return da, db
 
 
@@ -1523,6 +1522,11 @@ def velo_image(proj_xyz, proj_remission, normals, proj_range, max_depth, channel
 
 
 # ----------------------------------------------------------------------------- optimizer
+def optim_set_max_blocks(blocks):
+    """workgroups the optimizer sweeps may use (0: default)"""
+    check(lib.dlio_optim_set_max_blocks(int(blocks)), "optim_set_max_blocks")
+
+
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
     weights_changed()
     check(lib.dlio_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(beta1),

@@ -3,6 +3,8 @@ MI355X: all parameters of all groups are re-homed into ONE flat fp32 buffer (gra
 second one), so the optimizer step is a single HBM-bound kernel over 41-65 M floats and the
 data-parallel gradient exchange is a single large RCCL all-reduce over xGMI
 (deeplio_amd.dist).  Weight decay is L2 added to the gradient, as torch.optim does."""
+import os
+
 import torch
 
 from . import ops
@@ -56,6 +58,7 @@ class FlatOptimizer:
         self.step_count = 0
         self.grad_scale = 1.0
         self._early = None           # (lo, event): [lo:] of this step was already updated by step_early()
+        self.early_blocks = int(os.environ.get("DLIO_EARLY_STEP_BLOCKS", "256"))
 
     def _apply(self, lo, hi, count):
         """the update rule over elements [lo:hi) of the flat buffers (one launch); `count` = this step's number"""
@@ -89,6 +92,8 @@ class FlatOptimizer:
         #  Linear / RNN parameters only -- no convolution layouts -- and a bump now would make any on-demand layout fetch of
         #  the backward pass still running rebuild every layout)
         epoch = ops._PREP.epoch
+        # background work: a small grid (one workgroup per CU) leaves the chip to the critical chain it runs beside
+        ops.optim_set_max_blocks(self.early_blocks)
         if stream is None:
             self._apply(lo, self.flat.numel(), self.step_count + 1)
             ev = torch.cuda.Event()
@@ -99,6 +104,7 @@ class FlatOptimizer:
                 self._apply(lo, self.flat.numel(), self.step_count + 1)
                 ev = torch.cuda.Event()
                 ev.record(stream)
+        ops.optim_set_max_blocks(0)
         ops._PREP.epoch = epoch
         self._early = (lo, ev)
         return True

@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 239
+#define DLIO_ABI_VERSION 240
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);
@@ -532,16 +532,17 @@ int dlio_lstm_layer_bwd(const float* dhs, int lddhs, const float* x, int ldx, co
  * DeepLIOFusionSoft.forward (fusion_nets.py:64-75): cat = [a | b] ([R][Fa], [R][Fb]);
  * s1 = sigmoid(cat W1^T + b1) ([Fa][Fa+Fb] weights), s2 = sigmoid(cat W2^T + b2);
  * out [R][Fa+Fb] = [a s1 | b s2]; gate [R][Fa+Fb] = [s1 | s2] (saved for backward, the
- * module's s1_feat / s2_feat).  Fa + Fb <= 512 (dlio_soft_fusion_ok).  Backward writes
+ * module's s1_feat / s2_feat); a / b are read with row strides lda / ldb (the IMU feature is
+ * a strided slice of the RNN output: no copy).  Fa + Fb <= 512 (dlio_soft_fusion_ok).  Backward writes
  * da, db and the four parameter gradients (accumulate != 0: added). */
 int dlio_soft_fusion_ok(int R, int Fa, int Fb);
-int dlio_soft_fusion_fwd(const float* a, const float* b, const float* w1, const float* b1,
-                         const float* w2, const float* b2, float* out, float* gate, int R,
-                         int Fa, int Fb, dlio_stream_t stream);
-int dlio_soft_fusion_bwd(const float* dout, const float* a, const float* b, const float* gate,
-                         const float* w1, const float* w2, float* da, float* db, float* dw1,
-                         float* dbias1, float* dw2, float* dbias2, int R, int Fa, int Fb,
-                         int accumulate, dlio_stream_t stream);
+int dlio_soft_fusion_fwd(const float* a, int lda, const float* b, int ldb, const float* w1,
+                         const float* b1, const float* w2, const float* b2, float* out,
+                         float* gate, int R, int Fa, int Fb, dlio_stream_t stream);
+int dlio_soft_fusion_bwd(const float* dout, const float* a, int lda, const float* b, int ldb,
+                         const float* gate, const float* w1, const float* w2, float* da,
+                         float* db, float* dw1, float* dbias1, float* dw2, float* dbias2, int R,
+                         int Fa, int Fb, int accumulate, dlio_stream_t stream);
 /* DeepLIO.forward's last lines (deeplio_nets.py:84-90): y = dropout(x, p); pos = fc_pos(y),
  * ori = fc_ori(y) (Linear(K, 3) each).  x [R][ldx >= K] is read in place (the forward half
  * of the odometry LSTM's [.., 2H] output: no slice copy); mask [R][K] u8 (NULL: no dropout)
@@ -871,6 +872,9 @@ int dlio_cast_bf16(const void* src, void* dst, int64_t n, int dir, dlio_stream_t
  * (optimizer.py:4-16) over ONE flat parameter buffer: weight decay is L2 added
  * to the gradient.  step is the 1-based step count. grad_scale multiplies g
  * first (data-parallel averaging). */
+/* workgroups the sweeps below may use (0 = default, 8 per CU): a sweep issued under the backward pass (the tail bucket's early
+ * update, FlatOptimizer.step_early) runs as background work on a small grid */
+int dlio_optim_set_max_blocks(int blocks);
 int dlio_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr,
                    float beta1, float beta2, float eps, float weight_decay, int step,
                    float grad_scale, dlio_stream_t stream);

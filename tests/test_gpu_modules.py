@@ -96,7 +96,7 @@ def compare(hip, ora, x, dev, train=True, tol=TOL, fwd=None, ofwd=None, margin=2
     for k, p in hip.named_parameters():
         if op[k].grad is None:
             continue
-        a, b = p.grad.double().cpu(), op[k].grad
+        a, b = (p.grad if p.grad is not None else torch.zeros_like(p)).double().cpu(), op[k].grad      # (None = all-zero)
         # |err| <= 1e-4 * own scale + 1e-6 * largest gradient of the module: the second term lets
         # analytically-zero gradients pass (conv bias in front of a train-mode BN is pure
         # rounding noise, ~1e-7 * gmax, in the reference's arithmetic as well)
@@ -295,7 +295,7 @@ def test_odom_lstm_one_launch_sequence_per_layer(dev, B, S, H, bidir):
         Fh.LstmStackFn.apply = apply_
     assert taken == [1]
     # the same module through the per-direction path
-    grads_a = {k: p.grad.clone() for k, p in hip.named_parameters()}
+    grads_a = {k: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for k, p in hip.named_parameters()}
     xa = x.clone().to(dev).requires_grad_(True)
     ya = hip(xa)
     for p in hip.parameters():
@@ -313,7 +313,9 @@ def test_odom_lstm_one_launch_sequence_per_layer(dev, B, S, H, bidir):
     for k, p in hip.named_parameters():
         assert float((p.grad - grads_a[k]).abs().max()) <= 2e-6 * gmax + 1e-6 * float(grads_a[k].abs().max()), k
     if bidir:
-        assert float(grads_a["rnn.weight_ih_l1_reverse"].abs().max()) == 0.0     # Q3: the discarded half gets no gradient
+        # Q3: the discarded half of the top layer gets no gradient -- the streamed path does not even run that direction
+        assert dict(hip.named_parameters())["rnn.weight_ih_l1_reverse"].grad.abs().max() == 0.0     # (per-direction path: zeros)
+        assert float(grads_a["rnn.weight_ih_l1_reverse"].abs().max()) == 0.0
 
 
 def test_stem_pool_apply_on_load(dev):
@@ -531,6 +533,16 @@ def test_soft_fusion_and_heads_one_launch_each(dev):
         out.backward(dy.to(dev))
         for h, r in zip(th, t64):
             assert rel_err(h.grad, r.grad) < 5e-6, (R, Fa, Fb, tuple(h.shape))
+    # the second feature as a strided slice of a larger tensor (the IMU net's rnn_out[:, :, -1, :H]): read in place, same values
+    big = torch.randn(4, 2, 5, 64, generator=g).to(dev)
+    a = torch.randn(4, 2, 32, generator=g).to(dev)
+    w1, b1 = (torch.randn(32, 64, generator=g) / 8).to(dev), torch.randn(32, generator=g).to(dev)
+    w2, b2 = (torch.randn(32, 64, generator=g) / 8).to(dev), torch.randn(32, generator=g).to(dev)
+    sl = big[:, :, -1, :32]
+    assert not sl.is_contiguous() and Fh._rows_view(sl)[1] == 5 * 64
+    o1, g1 = Fh.SoftFusionFn.apply(a, sl, w1, b1, w2, b2)
+    o2, g2 = Fh.SoftFusionFn.apply(a, sl.contiguous(), w1, b1, w2, b2)
+    assert torch.equal(o1, o2) and torch.equal(g1, g2) and o1.shape == (4, 2, 64)
     for R, K, ldx, p in ((16, 1024, 2048, 0.25), (40, 68, 68, 0.5), (5, 128, 256, 0.0)):
         x = torch.randn(R, ldx, generator=g)
         wp, bp = torch.randn(3, K, generator=g) / K ** 0.5, torch.randn(3, generator=g)
