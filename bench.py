@@ -603,7 +603,7 @@ def main():
         # PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction of
         # the guide applied): collected by tools/pmc_traffic.py, committed under profiles/
         pmc = None
-        for fn in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for fn in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             path = os.path.join(ROOT, "profiles", fn)
             if os.path.exists(path) and B == 8 and S == 2 and headline:
                 with open(path) as f:
@@ -695,7 +695,10 @@ def main():
                        "parallelism": "dp%d" % world, "loss": float(loss.item()),
                        # the cooperative one-launch BatchNorm kernels were in use for the whole timed region (False: a launch
                        # hit its spin limit during warm-up and the run fell back to the two-launch kernels)
-                       "bn_coop": bool(ops._BN_COOP[0])},
+                       "bn_coop": bool(ops._BN_COOP[0]),
+                       # functional.assign_streams: the step's four heavy streams found four different hardware queues (4)
+                       "stream_queues": __import__("deeplio_amd.functional", fromlist=["x"]).ASSIGN_REPORT.get(
+                           device.index if device.index is not None else 0)},
             "roofline": roofline,
         }
         if world == 1 and headline and (args.host_batch or (args.host_steps > 0 and not args.no_isolated)) and not args.serial:

@@ -85,6 +85,7 @@ def aux_stream(device, name):
 
 
 _ASSIGNED = set()
+ASSIGN_REPORT = {}          # device index -> what assign_streams found (bench.py prints it)
 
 
 def assign_streams(device, force=False):
@@ -101,9 +102,10 @@ def assign_streams(device, force=False):
     idx = device.index if device.index is not None else torch.cuda.current_device()
     if (idx in _ASSIGNED and not force) or os.environ.get("DLIO_ASSIGN_STREAMS", "1") == "0":
         return None
-    _ASSIGNED.add(idx)
     with torch.cuda.device(idx):            # (the probe creates events and launches on the CURRENT device)
-        return _assign_streams_on(idx, force)
+        table = _assign_streams_on(idx, force)
+    _ASSIGNED.add(idx)                      # (only a probe that ran to its end settles the device: an exception above leaves
+    return table                            #  the next caller free to try again)
 
 
 def _assign_streams_on(idx, force):
@@ -148,6 +150,13 @@ def _assign_streams_on(idx, force):
     for _ in range(3):
         heavy.append(pick(heavy) or any_unused())        # (fewer than four queues: GPU_MAX_HW_QUEUES < 4)
     enc2, wg0, wg2 = heavy[1:]
+    distinct = sum(1 for i, h in enumerate(heavy) if not any(share(h, g) for g in heavy[:i]))
+    ASSIGN_REPORT[idx] = {"heavy_streams_on_distinct_queues": distinct, "candidates_probed": len(cands)}
+    if distinct < 4:
+        import warnings
+        warnings.warn("deeplio_amd: the step's four heavy HIP streams share hardware queues (%d distinct found; "
+                      "GPU_MAX_HW_QUEUES=%s): two of them on one queue cost ~10 %% of the step"
+                      % (distinct, os.environ.get("GPU_MAX_HW_QUEUES", "default 4")), RuntimeWarning)
     imu = pick([main, enc2], prefer=wg2) or pick([main, enc2]) or any_unused()
     rd_imu = pick([main, enc2, imu], prefer=wg0) or pick([main, imu]) or any_unused()
     rd_main = pick([main, wg0, wg2], prefer=enc2) or pick([main]) or any_unused()
@@ -260,6 +269,9 @@ def lazy_materialize(t, entry=None):
 
 def _mark_lazy(ctx, out, ok):
     """FireFn.forward: `out` may receive a lazy gradient (the block's cooperative BatchNorm backward routes it)"""
+    # a backward pass that raised never ran its end-of-pass callback: the flag it left set would keep every later pass from
+    # registering the unconsumed-entry check again -- a forward pass is the one place no engine pass of this graph is running
+    _LAZY_CB[0] = False
     tok = object() if ok else None
     ctx.lazy_token = tok
     out._dlio_lazy_token = tok
@@ -356,6 +368,21 @@ def _wgrad_stream(like):
     if not (_WGRAD_FORK[0] and like.is_cuda):
         return None
     return aux_stream(like.device, "wgrad@%x" % ops.raw_stream())
+
+
+_PREP_SIDE = [os.environ.get("DLIO_PREP_SIDE", "1") != "0"]
+
+
+def _prep_side_stream(cur):
+    """where ops._PrepCache issues the long weight re-layout launches at the head of a step: the calling stream's weight-gradient
+    companion (idle until backward) -- the stems then queue behind the short three-piece launches only"""
+    if not (_PREP_SIDE[0] and _WGRAD_FORK[0]) or torch.cuda.is_current_stream_capturing():
+        return None
+    idx = cur.device.index if cur.device.index is not None else torch.cuda.current_device()
+    return _AUX.get((idx, "wgrad@%x" % cur.cuda_stream)) or aux_stream(cur.device, "wgrad@%x" % cur.cuda_stream)
+
+
+ops._PREP.side = _prep_side_stream
 
 
 def join_wgrad_stream():

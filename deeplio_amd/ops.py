@@ -119,8 +119,9 @@ class _PrepCache:
         self.epoch = 0
         self.entries = {}        # (device index, data_ptr, shape, mode) -> dict
         self.tables = {}         # (device index, family) -> dict(items_dev, n, total, keys)
-        self.waited = {}         # stream handle -> last refresh event it waited for
+        self.waited = {}         # (stream handle, id of a refresh event) it has waited for (cleared by every refresh)
         self.batched = True
+        self.side = None         # callable(current stream) -> a stream for the long two-piece / bf16 family launches, or None
 
     @staticmethod
     def _floats(w, mode):
@@ -151,7 +152,6 @@ class _PrepCache:
                      out=torch.empty(self._floats(w, mode), dtype=torch.float32, device=w.device))
             self.entries[key] = e
             self.tables.pop((dev, mode >> 1), None)
-        cur = None
         cur_raw = raw_stream()
         if e["epoch"] != self.epoch or e["version"] != w._version:
             cur = torch.cuda.current_stream()
@@ -172,11 +172,12 @@ class _PrepCache:
                     check(lib.dlio_conv2d_prep_weight(_ptr(w), _ptr(e["out"]), Cout, Cin, KH, KW, mode, _stream()),
                           "conv2d_prep_weight")
                 e.update(epoch=self.epoch, version=w._version, stream=cur_raw, event=None)
-        elif e["stream"] != cur_raw and e["event"] is not None:
+        if e["stream"] != cur_raw and e["event"] is not None:
             # prepped on another stream in this epoch: one wait per (stream, refresh event)
-            if self.waited.get(cur_raw) is not e["event"]:
+            wk = (cur_raw, id(e["event"]))
+            if wk not in self.waited:
                 torch.cuda.current_stream().wait_event(e["event"])
-                self.waited[cur_raw] = e["event"]
+                self.waited[wk] = True
         return e["out"]
 
     def _table(self, dev, family):
@@ -199,28 +200,47 @@ class _PrepCache:
         return t
 
     def _refresh_all(self, dev, cur):
+        """rebuild every registered layout (the optimizer changed the weights): the fp32-MFMA and three-piece families -- what
+        the stems and the first squeeze layers read -- on the calling stream; the two-piece / bf16 families (the long launches:
+        a magnitude pass + the split of every Fire and plain 3x3 weight, ~230 us at the headline shape) on `self.side(cur)`,
+        a stream that is idle at the head of a step (the caller's weight-gradient companion), so that the stems do not queue
+        behind them; every entry carries its family's event, a reader on another stream waits for it once"""
         for k in [k for k, e in self.entries.items() if e["ref"]() is None]:
             del self.entries[k]
             self.tables.pop((k[0], k[3] >> 1), None)
-        done = []
-        for family, fn, name in ((0, lib.dlio_conv2d_prep_weights_batched, "conv2d_prep_weights_batched"),
-                                 (1, lib.dlio_conv3x3_bx3_prep_batched, "conv3x3_bx3_prep_batched"),
-                                 (2, lib.dlio_conv_bf16_prep_batched, "conv_bf16_prep_batched"),
-                                 (3, lib.dlio_conv_h2_prep_batched, "conv_h2_prep_batched")):
-            t = self._table(dev, family)
-            if t is None:
+        self.waited.clear()
+        side = self.side(cur) if self.side is not None else None
+        groups = ((cur, ((0, lib.dlio_conv2d_prep_weights_batched, "conv2d_prep_weights_batched"),
+                         (1, lib.dlio_conv3x3_bx3_prep_batched, "conv3x3_bx3_prep_batched"))),
+                  (side if side is not None else cur,
+                   ((2, lib.dlio_conv_bf16_prep_batched, "conv_bf16_prep_batched"),
+                    (3, lib.dlio_conv_h2_prep_batched, "conv_h2_prep_batched"))))
+        for st, fams in groups:
+            done = []
+            other = st is not cur and st.cuda_stream != cur.cuda_stream
+            if other:
+                st.wait_stream(cur)                        # the weights are final on the calling stream
+                prev = torch._C._cuda_getCurrentStream(st.device_index)
+                torch._C._cuda_setStream(stream_id=st.stream_id, device_index=st.device_index, device_type=st.device_type)
+            try:
+                for family, fn, name in fams:
+                    t = self._table(dev, family)
+                    if t is None:
+                        continue
+                    check(fn(_ptr(t["items"]), t["n"], t["total"], _stream()), name)
+                    done += t["keys"]
+            finally:
+                if other:
+                    torch._C._cuda_setStream(stream_id=prev[0], device_index=prev[1], device_type=prev[2])
+            if not done:
                 continue
-            check(fn(_ptr(t["items"]), t["n"], t["total"], _stream()), name)
-            done += t["keys"]
-        if not done:
-            return
-        ev = torch.cuda.Event()
-        ev.record(cur)
-        for k in done:
-            e = self.entries.get(k)
-            w = e["ref"]() if e is not None else None
-            if w is not None:
-                e.update(epoch=self.epoch, version=w._version, stream=cur.cuda_stream, event=ev)
+            ev = torch.cuda.Event()
+            ev.record(st)
+            for k in done:
+                e = self.entries.get(k)
+                w = e["ref"]() if e is not None else None
+                if w is not None:
+                    e.update(epoch=self.epoch, version=w._version, stream=st.cuda_stream, event=ev)
 
 
 _PREP = _PrepCache()
