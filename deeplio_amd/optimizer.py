@@ -109,8 +109,39 @@ class FlatOptimizer:
         self._early = (lo, ev)
         return True
 
+    def set_overwritten(self, params):
+        """`params` (a contiguous run of this optimizer's parameters, in order): their gradient slots are OVERWRITTEN by their
+        producer in every backward pass (functional.LstmStackFn writes a layer's weight gradients in one launch, exactly once)
+        or never written at all (a direction that is not run: stays zero) -- zero_grad() then skips them: no fill over, and no
+        read-modify-write into, the 143 MB of the odometry LSTM's gradients.  Only for a loop that runs exactly one backward
+        pass per step (TrainStep): gradient accumulation over several passes needs the default.  None / empty: off."""
+        self._skip = None
+        for p in self.params:
+            if hasattr(p, "_dlio_grad_overwrite"):
+                del p._dlio_grad_overwrite
+        ps = list(params or [])
+        if not ps:
+            return
+        index = {id(p): i for i, p in enumerate(self.params)}
+        idx = sorted(index[id(p)] for p in ps)
+        if idx != list(range(idx[0], idx[0] + len(idx))):
+            raise ValueError("set_overwritten needs a contiguous run of parameters")
+        lo = self.offsets[idx[0]]
+        hi = self.offsets[idx[-1] + 1] if idx[-1] + 1 < len(self.offsets) else self.flat.numel()
+        self.grad[lo:hi].zero_()                 # (the slots nobody ever writes must hold zeros from now on)
+        for p in ps:
+            p._dlio_grad_overwrite = True
+        self._skip = (lo, hi)
+
     def zero_grad(self, set_to_none=False):
-        self.grad.zero_()
+        skip = getattr(self, "_skip", None)
+        if skip is None:
+            self.grad.zero_()
+        else:
+            if skip[0] > 0:
+                self.grad[:skip[0]].zero_()
+            if skip[1] < self.grad.numel():
+                self.grad[skip[1]:].zero_()
         for p, o in zip(self.params, self.offsets):   # keep .grad views attached
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)

@@ -61,6 +61,10 @@ class TrainStep:
         if self._tail_lo is not None and (self._tail_lo <= 0 or self._tail_lo % 4):
             self._tail_lo = None
         self.model.tail_grads_ready = self._tail_ready
+        # the odometry LSTM's gradient slots (143 of the 165 MB): written once per step by functional.LstmStackFn, neither
+        # zero-filled nor read back (FlatOptimizer.set_overwritten); 0: the default fill + accumulate
+        self.overwrite_lstm_grads = os.environ.get("DLIO_GRAD_OVERWRITE", "1") != "0"
+        self._set_overwritten()
         self.model.train()
         if grad_sync is not None:
             self.set_grad_sync(grad_sync)
@@ -75,6 +79,21 @@ class TrainStep:
             return None
         index = {id(p): i for i, p in enumerate(self.optimizer.params)}
         return self.optimizer.offsets[index[id(first)]]
+
+    def _set_overwritten(self):
+        from .nets import OdomFeatRNN
+        net = self.model.odom_feat_net
+        ok = (self.overwrite_lstm_grads and isinstance(net, OdomFeatRNN) and hasattr(self.optimizer, "set_overwritten")
+              and self.device.type == "cuda" and net.rnn.mode == "lstm" and Fh._LSTM_LAYER[0])
+        if ok:
+            r = net.rnn
+            D = 2 if r.bidirectional else 1
+            B = self.args.batch_size
+            S = self.model.seq_size
+            ok = (B <= 8 and all(ops.lstm_layer_ok(S, B, r.input_size if l == 0 else D * r.hidden_size, r.hidden_size, D)
+                                 for l in range(r.num_layers))
+                  and all(p.requires_grad for p in r.parameters()))
+        self.optimizer.set_overwritten(list(net.rnn.parameters()) if ok else None)
 
     def _tail_ready(self):
         """autograd hook on the fusion output's gradient: everything behind the feature nets (odometry net, heads, loss weights:

@@ -1203,3 +1203,45 @@ def test_early_tail_optimizer_step_is_bit_identical(dev, optim):
     assert la == lb and torch.equal(pa, pb)
     for k in sa:
         assert torch.equal(sa[k], sb[k]), k
+
+
+def test_lstm_gradient_slots_overwritten_instead_of_zeroed(dev):
+    """TrainStep marks the odometry LSTM's gradient slots as overwritten by their producer (FlatOptimizer.set_overwritten:
+    functional.LstmStackFn writes a layer's weight gradients in one launch, exactly once per backward pass; the discarded
+    direction's slots are never written and stay zero): zero_grad() skips them, the weight-gradient launch does not read them
+    back.  Parameters and Adam moments after three steps are BIT-identical to the zero-fill + accumulate path, also when a
+    step falls back to the per-direction RNNFn (a batch the layer kernels do not take) -- its first write then replaces the
+    stale contents (optimizer.py:4-16, trainer.py:263-266)."""
+    from deeplio_amd import functional as Fh
+    from deeplio_amd.config import make_config
+    from deeplio_amd.trainer import TrainStep
+    g = dict(B=2, S=2, C=5, H=16, W=64, T=7)
+    batch = tuple(t.to(dev) for t in gc.make_batch(2000, g['B'], g['S'], g['C'], g['H'], g['W'], g['T']))
+    res = []
+    for over, fallback_step in ((True, None), (False, None), (True, 1)):
+        cfg = make_config(seq=2, overrides=dict(gc.NO_DROP, **{'odom-feat-rnn/hidden-size': 256}))
+        os.environ["DLIO_GRAD_OVERWRITE"] = "1" if over else "0"
+        try:
+            ts = TrainStep(cfg, (g['C'], g['H'], g['W']), dev, g['B'])
+        finally:
+            os.environ.pop("DLIO_GRAD_OVERWRITE", None)
+        gc.fill_state(ts.model, seed=1000)
+        skip = getattr(ts.optimizer, "_skip", None)
+        assert (skip is not None) == over
+        if over:
+            assert skip[1] - skip[0] == sum((p.numel() + 15) // 16 * 16 for p in ts.model.odom_feat_net.rnn.parameters())
+        losses = []
+        for i in range(3):
+            Fh._LSTM_LAYER[0] = i != fallback_step
+            try:
+                losses.append(float(ts.step(*batch)))
+            finally:
+                Fh._LSTM_LAYER[0] = True
+        ts.check()
+        torch.cuda.synchronize()
+        res.append((losses, ts.optimizer.flat.clone(), ts.optimizer.exp_avg.clone(), ts.optimizer.exp_avg_sq.clone()))
+        ts.release_gc()
+    (la, pa, ma, va), (lb, pb, mb, vb), (lc, pc, mc, vc) = res
+    assert la == lb and torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    # (the fallback step computes the same gradients through other kernels: fp32-close, not bit-equal)
+    assert rel_err(pc, pa) < 1e-5 and abs(lc[2] - la[2]) <= 1e-4 * abs(la[2])
