@@ -1211,14 +1211,14 @@ def test_lstm_gradient_slots_overwritten_instead_of_zeroed(dev):
     direction's slots are never written and stay zero): zero_grad() skips them, the weight-gradient launch does not read them
     back.  Parameters and Adam moments after three steps are BIT-identical to the zero-fill + accumulate path, also when a
     step falls back to the per-direction RNNFn (a batch the layer kernels do not take) -- its first write then replaces the
-    stale contents (optimizer.py:4-16, trainer.py:263-266)."""
+    stale contents (optimizer.py:4-16, trainer.py:263-266).  Off by default (DLIO_GRAD_OVERWRITE: no measurable gain)."""
     from deeplio_amd import functional as Fh
     from deeplio_amd.config import make_config
     from deeplio_amd.trainer import TrainStep
     g = dict(B=2, S=2, C=5, H=16, W=64, T=7)
     batch = tuple(t.to(dev) for t in gc.make_batch(2000, g['B'], g['S'], g['C'], g['H'], g['W'], g['T']))
     res = []
-    for over, fallback_step in ((True, None), (False, None), (True, 1)):
+    for over, fallback_step in ((True, None), (False, None), (True, 1), (False, 1)):
         cfg = make_config(seq=2, overrides=dict(gc.NO_DROP, **{'odom-feat-rnn/hidden-size': 256}))
         os.environ["DLIO_GRAD_OVERWRITE"] = "1" if over else "0"
         try:
@@ -1241,7 +1241,8 @@ def test_lstm_gradient_slots_overwritten_instead_of_zeroed(dev):
         torch.cuda.synchronize()
         res.append((losses, ts.optimizer.flat.clone(), ts.optimizer.exp_avg.clone(), ts.optimizer.exp_avg_sq.clone()))
         ts.release_gc()
-    (la, pa, ma, va), (lb, pb, mb, vb), (lc, pc, mc, vc) = res
-    assert la == lb and torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
-    # (the fallback step computes the same gradients through other kernels: fp32-close, not bit-equal)
-    assert rel_err(pc, pa) < 1e-5 and abs(lc[2] - la[2]) <= 1e-4 * abs(la[2])
+    for (la, pa, ma, va), (lb, pb, mb, vb) in ((res[0], res[1]), (res[2], res[3])):
+        assert la == lb and torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    # (the fallback step computes the same gradients through other kernels: fp32-close losses; Adam's sign-like first updates
+    #  turn that into parameter differences of a few 1e-4)
+    assert abs(res[2][0][2] - res[0][0][2]) <= 1e-3 * abs(res[0][0][2])
