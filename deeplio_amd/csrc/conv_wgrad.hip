@@ -43,11 +43,42 @@ struct WgCfg {
   static constexpr int NDY = CO_T / 2;            // dY elements per thread
 };
 
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wg_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int wg_u32x4 __attribute__((ext_vector_type(4)));
+
+// x = hi + mid + lo in bf16 pieces (see conv_bx3.hip): eight values -> three MFMA fragments, pair by pair as in
+// conv_wgrad3.hip (v_cvt_pk_bf16_f32 rounds two values at once; a bf16 widens to fp32 by a shift / a mask of the
+// packed dword): 11 VALU per pair instead of 7 per value, the same roundings
+__device__ __forceinline__ unsigned wg_cvt_pk(float a, float b) {
+  return __builtin_bit_cast(unsigned, wg_bf16x2{(__bf16)a, (__bf16)b});
+}
+__device__ __forceinline__ float wg_as_f(unsigned u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ void wg_split8(const float (&v)[8], wg_bf16x8& h, wg_bf16x8& m, wg_bf16x8& l) {
+  unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = v[2 * j], b = v[2 * j + 1];
+    hh[j] = wg_cvt_pk(a, b);
+    const float ra = a - wg_as_f(hh[j] << 16), rb = b - wg_as_f(hh[j] & 0xffff0000u);
+    mm[j] = wg_cvt_pk(ra, rb);
+    ll[j] = wg_cvt_pk(ra - wg_as_f(mm[j] << 16), rb - wg_as_f(mm[j] & 0xffff0000u));
+  }
+  h = __builtin_bit_cast(wg_bf16x8, wg_u32x4{hh[0], hh[1], hh[2], hh[3]});
+  m = __builtin_bit_cast(wg_bf16x8, wg_u32x4{mm[0], mm[1], mm[2], mm[3]});
+  l = __builtin_bit_cast(wg_bf16x8, wg_u32x4{ll[0], ll[1], ll[2], ll[3]});
+}
+
 // Software pipeline over the block's pixel tiles: global loads of tile t+1 (dY tile and X'
 // patch) are issued into registers, the MFMAs of tile t run out of LDS stage t&1, the registers
 // are written to stage (t+1)&1, one barrier per tile.  The kernel runs one workgroup per CU
 // (160 accumulator registers), so this in-block overlap is what hides the HBM latency.
-template <int KH, int KW, int SH, int SW, int NT, int MRW, bool VEC>
+// BX3 (round 6; the PointSeg stem, 3x5 stride (1, 2), 10 input channels: 2 x 258 us at the end of the step, where nothing
+// overlaps it): the products on v_mfma_f32_32x32x16_bf16 over the exact three-piece bf16 split of both operands (six MFMAs per
+// fp32 product, conv_bx3.hip) instead of eight v_mfma_f32_32x32x2_f32 per 16 pixels: a lane reads its 8 consecutive pixels
+// of a dY row / of an X' column out of the same LDS tiles, splits them (11 VALU per pair) and issues 6 MFMAs per (m, t)
+// tile -- 120 MFMAs of 32 cycles per tile and wave instead of 160 of 64.
+template <int KH, int KW, int SH, int SW, int NT, int MRW, bool VEC, bool BX3 = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ wsp,
     const float* __restrict__ in_mean, const float* __restrict__ in_scale,
@@ -244,6 +275,40 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   // 8 steps of 2 k-pairs; the LDS operands of step s+1 are read before the MFMAs of step s
   // (register double buffer + sched_group_barrier), so LDS latency overlaps the MFMAs
   auto mfma_tile = [&](const float* buf) {
+    if constexpr (BX3) {
+      // k block ks = the wave's pixels 16 ks .. 16 ks + 15 of its tile row; lane (row l31, half): pixels 8 half .. + 7 of it
+      const float* drow8 = buf + C::XL + l31 * C::DYS + wave * 32 + half * 8;
+      const float* xrow8 = buf + (wave * SH) * C::PC + half * 8 * SW;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        wg_bf16x8 ah[C::MR], am[C::MR], al[C::MR];
+#pragma unroll
+        for (int m = 0; m < C::MR; ++m) {
+          float v[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = drow8[m * 32 * C::DYS + ks * 16 + i];
+          wg_split8(v, ah[m], am[m], al[m]);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          float v[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = xrow8[off[t] + (ks * 16 + i) * SW];
+          wg_bf16x8 bh, bm, bl;
+          wg_split8(v, bh, bm, bl);
+          // smallest products first (conv_bx3.hip): lo hi, mid mid, hi lo, mid hi, hi mid, hi hi
+#pragma unroll
+          for (int term = 0; term < 6; ++term)
+#pragma unroll
+            for (int m = 0; m < C::MR; ++m) {
+              const wg_bf16x8& av = term == 0 ? al[m] : (term == 1 || term == 3) ? am[m] : ah[m];
+              const wg_bf16x8& bw = (term == 0 || term == 3 || term == 5) ? bh : (term == 1 || term == 4) ? bm : bl;
+              acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bw, acc[m][t], 0, 0, 0);
+            }
+        }
+      }
+      return;
+    }
     const float* drow = buf + C::XL + l31 * C::DYS + wave * 32 + half;
     const float* xrow = buf + (wave * SH) * C::PC + half * SW;
     float a[2][C::MR][2], b[2][NT][2];
@@ -325,32 +390,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
 
 __device__ __forceinline__ float f4e(const float4& v, int i) {
   return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
-}
-
-typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 wg_bf16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int wg_u32x4 __attribute__((ext_vector_type(4)));
-
-// x = hi + mid + lo in bf16 pieces (see conv_bx3.hip): eight values -> three MFMA fragments, pair by pair as in
-// conv_wgrad3.hip (v_cvt_pk_bf16_f32 rounds two values at once; a bf16 widens to fp32 by a shift / a mask of the
-// packed dword): 11 VALU per pair instead of 7 per value, the same roundings
-__device__ __forceinline__ unsigned wg_cvt_pk(float a, float b) {
-  return __builtin_bit_cast(unsigned, wg_bf16x2{(__bf16)a, (__bf16)b});
-}
-__device__ __forceinline__ float wg_as_f(unsigned u) { return __builtin_bit_cast(float, u); }
-__device__ __forceinline__ void wg_split8(const float (&v)[8], wg_bf16x8& h, wg_bf16x8& m, wg_bf16x8& l) {
-  unsigned hh[4], mm[4], ll[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float a = v[2 * j], b = v[2 * j + 1];
-    hh[j] = wg_cvt_pk(a, b);
-    const float ra = a - wg_as_f(hh[j] << 16), rb = b - wg_as_f(hh[j] & 0xffff0000u);
-    mm[j] = wg_cvt_pk(ra, rb);
-    ll[j] = wg_cvt_pk(ra - wg_as_f(mm[j] << 16), rb - wg_as_f(mm[j] & 0xffff0000u));
-  }
-  h = __builtin_bit_cast(wg_bf16x8, wg_u32x4{hh[0], hh[1], hh[2], hh[3]});
-  m = __builtin_bit_cast(wg_bf16x8, wg_u32x4{mm[0], mm[1], mm[2], mm[3]});
-  l = __builtin_bit_cast(wg_bf16x8, wg_u32x4{ll[0], ll[1], ll[2], ll[3]});
 }
 
 // ---- 1x1 stride-1 weight gradient straight from global memory -------------------------------
@@ -672,8 +711,14 @@ int launch_mr(const float* x, const float* dy, float* dw, const float* in_mean,
   constexpr bool CAN_VEC = SH == 1 && SW == 1 && ((KH == 1 && KW == 1) || (KH == 3 && KW == 3));
   const bool vec = CAN_VEC && (d.OW & 3) == 0 && (d.W & 3) == 0 &&
                    ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
+  // the 3x5 stride-(1, 2) launches (the PointSeg stem; FlowNet's narrow ones): three-piece bf16 products
+  constexpr bool STEM = KH == 3 && KW == 5 && SH == 1 && SW == 2 && MRW == 2;
+  static const bool stem_bx3 = !(getenv("DLIO_WGRAD_STEM_BX3") && atoi(getenv("DLIO_WGRAD_STEM_BX3")) == 0);
   auto kern = (CAN_VEC && vec) ? conv_wgrad_kernel<KH, KW, SH, SW, NT, MRW, CAN_VEC>
                                : conv_wgrad_kernel<KH, KW, SH, SW, NT, MRW, false>;
+  if constexpr (STEM) {
+    if (stem_bx3) kern = conv_wgrad_kernel<KH, KW, SH, SW, NT, MRW, false, true>;
+  }
   hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
   const int blocks = p.co_tiles * p.ci_chunks * p.splits;

@@ -2134,3 +2134,32 @@ def test_two_piece_kernels_per_channel_relative_error_over_six_decades(dev):
     report("fire expand3x3 two-piece", e3[order], from_bound=True)
     for name, (hi, low, low_tol) in worst.items():
         assert hi <= 1e-4 and low <= low_tol, (name, hi, low, low_tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(4, 10, 64, 512, 64, 0), (2, 10, 13, 200, 64, 1), (1, 10, 8, 64, 40, 0), (2, 64, 8, 128, 128, 1)])
+def test_stem_weight_gradient_three_piece_bf16(dev, case):
+    """dlio_conv2d_wgrad for the 3x5 stride-(1, 2) pad-(1, 2) stem (pointseg_net.py:18-20: Conv2d(2C, 64, (3, 5), (1, 2), (1, 2)))
+    on conv_wgrad_kernel<3, 5, 1, 2, .., BX3>: the products on the bf16 MFMA over the exact three-piece split of both operands
+    -- against fp64 (on the device) to fp32 accuracy; gradient magnitudes with outliers and 8 decades of range, ragged tile
+    edges (H not a multiple of 4, W / 2 not of 32), fewer output channels than a tile, several input-channel chunks,
+    accumulation"""
+    from deeplio_amd import ops
+    N, Cin, H, W, Cout, acc = case
+    g = _g(83)
+    x = torch.randn(N, Cin, H, W, generator=g) * torch.exp(torch.rand(N, Cin, 1, 1, generator=g) * 6 - 3)
+    OW = (W + 4 - 5) // 2 + 1
+    dy = torch.randn(N, Cout, H, OW, generator=g) * 1e-3 * torch.exp(torch.rand(N, Cout, H, OW, generator=g) * 18 - 16)
+    dy[0, :3, 5, 7] *= 1e4
+    xd, dyd = x.to(dev), dy.to(dev)
+    ref = torch.nn.grad.conv2d_weight(xd.double(), (Cout, Cin, 3, 5), dyd.double(), stride=(1, 2), padding=(1, 2))
+    d = ops.conv_desc(N, Cin, H, W, Cout, 3, 5, 1, 2, 1, 2, OH=H, OW=OW)
+    base = torch.randn(Cout, Cin, 3, 5, generator=g).to(dev) if acc else None
+    dw = base.clone() if acc else torch.full((Cout, Cin, 3, 5), float("nan"), device=dev)
+    ops.conv2d_wgrad(xd, dyd, dw, d, accumulate=bool(acc))
+    if acc:
+        ref = ref + base.double()
+    e = rel_err(dw, ref)
+    rows = _per_channel_rel_l2(dw, ref, 0)
+    print("3x5 s(1,2) weight gradient, three-piece bf16: %.2e of the scale, worst output-channel rel-L2 %.2e" % (e, float(rows.max())))
+    assert e < 2e-6 and float(rows.max()) < 1e-5

@@ -1,0 +1,16 @@
+#!/bin/bash
+# round 6, job I: stem weight gradient on the three-piece bf16 MFMA: tests + A/B + exclusive kernel time
+cd /root/repo; mkdir -p gpurun_out
+( timeout 900 python -m pytest tests/test_gpu_ops.py -m gpu -q -x -k "stem_weight or conv_fwd_wgrad_dgrad or wgrad" -s 2>&1 | grep -v "^$" | tail -25 ) > gpurun_out/r6i_t1.log
+( timeout 1200 python -m pytest tests/test_gpu_model.py -m gpu -q -x -k "golden or headline_shape_train or adam_traj or stream_overlap" 2>&1 | tail -5 ) > gpurun_out/r6i_t2.log
+run() { env "$@" python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-isolated 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])"; }
+echo "warm       $(run X=1)" > gpurun_out/r6i_ab.txt
+for i in 1 2 3 4; do
+  echo "new        $(run X=1)"
+  echo "stem-f32   $(run DLIO_WGRAD_STEM_BX3=0)"
+done >> gpurun_out/r6i_ab.txt 2>&1
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace -d /root/repo/gpurun_out/prof_i -o pi -- python /root/repo/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-isolated --serial > /root/repo/gpurun_out/prof_i.log 2>&1
+DB=$(find /root/repo/gpurun_out/prof_i -name '*.db' | head -1)
+python /root/repo/tools/rocprof_summary.py $DB /root/repo/gpurun_out/r6i_kernel_stats_serial.md 6 "bench.py --serial"
+rm -rf /root/repo/gpurun_out/prof_i
