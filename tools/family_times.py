@@ -24,8 +24,9 @@ FAMILIES = [
     ("BN bwd reduce", ("chan_reduce_kernel<1", "chan_reduce_kernel<2", "bn16_reduce_kernel<1")),
     ("BN bwd apply", ("bn_plane_bwd_kernel", "bn_bwd_apply_kernel", "bn16_plane_bwd")),
     ("max-pool / SE scale", ("maxpool", "chan_scale", "gap_", "pool16_", "gap16_", "cast_", "plane_dot")),
-    ("linear (RNN projections, SE fc, heads)", ("linear_", "col_sum_kernel", "act_bwd_kernel", "se_fc_", "pair_fuse_")),
-    ("LSTM/GRU recurrences", ("lstm_", "gru_", "init_state")),
+    ("linear (RNN projections, SE fc, heads, soft fusion)", ("linear_", "col_sum_kernel", "act_bwd_kernel", "se_fc_", "pair_fuse_",
+                                                            "soft_fusion_", "heads_")),
+    ("LSTM/GRU recurrences (incl. the streamed layer's weight-streaming products)", ("lstm_", "gru_", "init_state", "gemv_", "slab_reduce")),
     ("optimizer + weight re-layout", ("adam_kernel", "sgd_kernel", "rmsprop", "adadelta", "prep_")),
 ]
 
