@@ -648,6 +648,8 @@ class _CBR:
         ws = _wgrad_stream(dy) if acc_w else None
         if x_bound is None:
             x_bound = getattr(d, "x_amax", None)          # (a two-piece forward: the weight gradient takes the same scale)
+            if x_bound is not None and not ops.amax_fresh(x_bound):
+                x_bound = None                            # (recycled since the forward pass: the three-piece weight gradient)
         wg_h2 = (amax is not None and x_bound is not None and in_aff is None and _WGRAD_H2[0] and d.KH == 3
                  and ops.conv3x3_wgrad_h2_ok(dd))
         if wg_h2 and ws is None:
@@ -920,6 +922,8 @@ class ConvBnAct(Function):
         OH = (H + 2 * pad[0] - KH) // stride[0] + 1
         OW = (W + 2 * pad[1] - KW) // stride[1] + 1
         x_amax = getattr(x, "_dlio_amax", None)
+        if x_amax is not None and not ops.amax_fresh(x_amax):
+            x_amax = None                 # (the producer's slot was recycled since: the three-piece kernels need no scale)
         raw = _new((N, Cout, OH, OW), x)
         out = _new((N, Cout, OH, OW), x)
         d, prm = _CBR.forward(x, Cin, 0, Cin, H, W, weight, bias, gamma, beta, rmean, rvar, stride,

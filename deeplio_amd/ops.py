@@ -791,7 +791,21 @@ def amax_slot_kept(device):
         buf[(i % n):(i % n) + half].zero_()
     e[1] = i + 1
     j = i % n
-    return buf[j:j + 1]
+    slot = buf[j:j + 1]
+    slot._dlio_gen = (key, i)          # (ring, allocation number): amax_fresh() tells a consumer whether the slot still is its own
+    return slot
+
+
+def amax_fresh(slot):
+    """a slot handed out by amax_slot_kept still holds its producer's value: the ring zeroes a slot again half a ring
+    (2 x _AMAX_N = 4096 allocations of its stream) after it was handed out -- a tensor that outlived that many allocations (many
+    train-mode forwards kept alive before their backward) must not be scaled by whatever the slot holds now.  Slots that did not
+    come from the ring (a test's own one-float tensor) count as fresh."""
+    gen = getattr(slot, "_dlio_gen", None)
+    if gen is None:
+        return True
+    e = _AMAX_KEEP.get(gen[0])
+    return e is not None and e[1] - gen[1] <= 2 * _AMAX_N
 
 
 def conv3x3_h2_ok(desc):

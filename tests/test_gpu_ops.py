@@ -2163,3 +2163,21 @@ def test_stem_weight_gradient_three_piece_bf16(dev, case):
     rows = _per_channel_rel_l2(dw, ref, 0)
     print("3x5 s(1,2) weight gradient, three-piece bf16: %.2e of the scale, worst output-channel rel-L2 %.2e" % (e, float(rows.max())))
     assert e < 2e-6 and float(rows.max()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_amax_slots_know_when_they_were_recycled(dev):
+    """ops.amax_slot_kept hands out one-float slots from a ring per (device, stream) that re-zeroes a slot 4096 allocations
+    later; a slot carries (ring, allocation number) and ops.amax_fresh tells a consumer whether its producer's value can still
+    be there -- functional._CBR falls back to the three-piece kernels (which need no scale) on a stale slot instead of
+    scaling by another layer's magnitude (ADVICE: a tensor that outlives the window)."""
+    from deeplio_amd import ops
+    s0 = ops.amax_slot_kept(dev)
+    s0.fill_(3.0)
+    assert ops.amax_fresh(s0) and ops.amax_fresh(torch.ones(1, device=dev))      # (a caller's own tensor: always fresh)
+    for _ in range(2 * ops._AMAX_N - 1):
+        ops.amax_slot_kept(dev)
+    assert ops.amax_fresh(s0) and float(s0) == 3.0            # still inside the window: untouched
+    for _ in range(3):
+        ops.amax_slot_kept(dev)
+    assert not ops.amax_fresh(s0)
