@@ -198,6 +198,10 @@ class TrainStep:
         self._steps += 1
         self._manage_gc()
         Fh.lazy_clear()            # (entries a failed backward pass may have left behind)
+        if getattr(self.optimizer, "_early", None) is not None:
+            # a pass that raised between its early tail sweep and optimizer.step(): that sweep stands (the caller restores its
+            # last good state after an error), its marker must not make THIS step skip the tail
+            self.optimizer._early = None
         loss = self._tail(self.model.forward_features([[imgs, normals], imus]), gts_f2f, gts_f2g)
         self.optimizer.zero_grad()
         loss.backward(self._one)                   # (an explicit d loss / d loss: no fill launch per step)
