@@ -370,7 +370,7 @@ def _wgrad_stream(like):
     return aux_stream(like.device, "wgrad@%x" % ops.raw_stream())
 
 
-_PREP_SIDE = [os.environ.get("DLIO_PREP_SIDE", "0") != "0"]      # measured: 18.46-18.61 ms with it, 18.29-18.60 without (round 6): off
+_PREP_SIDE = [os.environ.get("DLIO_PREP_SIDE", "0") != "0"]      # measured: median 18.63 ms with it, 18.38 without (ten alternations, round 6): off
 
 
 def _prep_side_stream(cur):

@@ -64,7 +64,7 @@ class TrainStep:
         # DLIO_GRAD_OVERWRITE=1: the odometry LSTM's gradient slots (143 of the 165 MB) are written once per step by
         # functional.LstmStackFn and neither zero-filled nor read back (FlatOptimizer.set_overwritten).  Bit-identical training
         # (test_lstm_gradient_slots_overwritten_instead_of_zeroed), 190 MB less traffic per step -- and no measurable gain
-        # (18.13-18.43 against 18.01-18.26 ms, four alternations): off by default, the plain fill + accumulate contract stays
+        # (median 18.35 against 18.38 ms, ten alternations): off by default, the plain fill + accumulate contract stays
         self.overwrite_lstm_grads = os.environ.get("DLIO_GRAD_OVERWRITE", "0") != "0"
         self._set_overwritten()
         self.model.train()
