@@ -110,8 +110,11 @@ __global__ void prep_bx3_batched_kernel(const DlioPrepItem* __restrict__ items, 
 // H2 (two-piece fp16 split, as conv3x3_bx3_pc_kernel<MR, true>): x as two fp16 pieces of x 2^k (k from *amax_x, left by the
 // producer of x), weights from dlio_conv_h2_prep: two planes through LDS, three v_mfma_f32_32x32x16_f16 per product; the
 // stores multiply by the two inverse scales.  FlowNet conv2-6 / ResNet stage heads and the phases of their data gradients.
+#ifndef BX3_STEM_OCC
+#define BX3_STEM_OCC 2      // workgroups per CU the three-piece 15-tap stem is compiled for (3 needs BX3_STEM_PF <= 1: 166 VGPRs)
+#endif
 template <int MR, int TWN, int KH = 3, int KW = 3, int SW = 1, int SH = 1, bool H2 = false>
-__global__ __launch_bounds__(256, 2) void conv3x3_bx3_kernel(
+__global__ __launch_bounds__(256, (KW == 5 && !H2) ? BX3_STEM_OCC : 2) void conv3x3_bx3_kernel(
     const float* __restrict__ x, const __bf16* __restrict__ wt, const float* __restrict__ bias,
     const float* residual, float* y, DlioConvDesc d, int tiles_w, int tiles_h, int co_tiles, int patch_at,
     int vec_out, const float* __restrict__ amax_x = nullptr) {
