@@ -34,7 +34,8 @@ def rate_label(k, util):
     if nat:
         return "%.1f (bf16 MFMA: util x 2516.8)" % (util * 25.168)
     bx3 = ("bx3" in name or name.endswith("fire_expand_fwd_kernel") or name.endswith("wgrad3_kernel")
-           or (name.endswith("wgrad1x1_direct_kernel") and a[2:3] == ["true"]))
+           or (name.endswith("wgrad1x1_direct_kernel") and a[2:3] == ["true"])
+           or (name.endswith("conv_wgrad_kernel") and a[7:8] == ["true"]))        # the stem weight gradient (round 6)
     if bx3:
         return "%.1f (fp32-equivalent: util x 419.5, three-piece)" % (util * 4.195)
     return "%.1f" % (util * 1.573)
