@@ -163,6 +163,7 @@ SIGNATURES = {
     "dlio_lstm_layer_ok": (_i, [_i, _i, _i, _i, _i]),
     "dlio_lstm_layer_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "dlio_lstm_layer_fwd": (_i, [_p, _i] + [_p] * 8 + [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "dlio_lstm_layer_wgrad": (_i, [_p, _p, _i, _p] + [_p] * 8 + [_i, _i, _i, _i, _i, _i, _p]),
     "dlio_lstm_layer_bwd": (_i, [_p, _i, _p, _i, _p, _p, _p] + [_p] * 4 + [_p] + [_p] * 8 + [_i, _p, _i, _i, _i, _i, _i, _i, _p,
                                  _sz, _p]),
     "dlio_optim_set_max_blocks": (_i, [_i]),

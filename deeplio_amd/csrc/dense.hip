@@ -817,6 +817,122 @@ __global__ __launch_bounds__(256) void soft_fusion_bwd_kernel(const float* __res
   }
 }
 
+// the same on v_mfma_f32_16x16x4_f32 (F and Fa multiples of 16): the scalar kernel above walks a 256-long dependent dot product per
+// thread (86 us beside the early optimizer sweep, ~30 alone); here a workgroup's four waves form
+//   dW[j][k]  = sum_m dpre[m][j] cat[m][k]   as 16 x 16 tiles over k with the 16 samples as the MFMA's k dimension (4 MFMAs a tile),
+//   dcat[m][k] = sum_j dpre[m][j] W[j][k]     as ONE 16 x 16 tile whose j range is cut over the four waves (F / 16 MFMAs each, the
+//                                             weight elements loaded up front), the four partial tiles summed through LDS in wave order.
+template <int FMAX>
+__global__ __launch_bounds__(256) void soft_fusion_bwd_mfma_kernel(const float* __restrict__ dout, const float* __restrict__ a,
+                                                                   const float* __restrict__ b, const float* __restrict__ gate,
+                                                                   const float* __restrict__ w1, const float* __restrict__ w2,
+                                                                   float* __restrict__ da, float* __restrict__ db_,
+                                                                   float* __restrict__ dw1, float* __restrict__ dbias1,
+                                                                   float* __restrict__ dw2, float* __restrict__ dbias2, int R,
+                                                                   int Fa, int Fb, int lda, int ldb, int accumulate) {
+  constexpr int LD = FMAX + 4;                                     // LDS row stride: the 16 rows of a fragment read on different banks
+  __shared__ float sdp[16][LD], scat[16][LD];
+  __shared__ float red[4][16][17];
+  const int F = Fa + Fb;
+  const int g0 = blockIdx.x * 16;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lq = lane >> 4;
+  constexpr int NTW = FMAX / 64;                                   // k tiles of the weight gradient per wave
+  f32x4 accw[NTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) accw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  const int ntiles = F >> 4;
+  // this wave's slice of the j range for dcat: rows [jw0, jw1) of the stacked weight, in steps of 4; column g0 + li
+  const int jper = ((F / 4 + 3) / 4) * 4;                          // per wave, a multiple of 4
+  const int jw0 = min(wave * jper, F), jw1 = min(jw0 + jper, F);
+  for (int m0 = 0; m0 < R; m0 += 16) {
+    __syncthreads();
+    for (int i = t; i < 16 * F; i += 256) {
+      const int mm = i / F, c = i - mm * F, m = m0 + mm;
+      float dp = 0.f, cv = 0.f;
+      if (m < R) {
+        cv = c < Fa ? a[(size_t)m * lda + c] : b[(size_t)m * ldb + (c - Fa)];
+        const float sg = gate[(size_t)m * F + c];
+        dp = dout[(size_t)m * F + c] * cv * sg * (1.f - sg);
+      }
+      sdp[mm][c] = dp;
+      scat[mm][c] = cv;
+    }
+    __syncthreads();
+    // ---- weight-gradient rows g0 .. g0 + 15: A[i = row j][kk = sample], B[kk = sample][n = column k]
+    {
+      float av[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) av[q] = sdp[4 * q + lq][g0 + li];
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) {
+        const int kt = wave + 4 * i;
+        if (kt < ntiles) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            accw[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], scat[4 * q + lq][16 * kt + li], accw[i], 0, 0, 0);
+        }
+      }
+      if (t < 16) {
+        float sb = 0.f;
+#pragma unroll
+        for (int mm = 0; mm < 16; ++mm) sb += sdp[mm][g0 + t];
+        bsum += sb;
+      }
+    }
+    // ---- d cat, columns g0 .. g0 + 15: A[i = sample][kk = row j], B[kk = row j][n = column]
+    {
+      f32x4 accc = {0.f, 0.f, 0.f, 0.f};
+      constexpr int CH = 16;                                        // weight elements in flight per lane
+      for (int j0 = jw0; j0 < jw1; j0 += 4 * CH) {
+        float wv[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          const int j = min(j0 + 4 * u + lq, F - 1);
+          wv[u] = j < Fa ? w1[(size_t)j * F + g0 + li] : w2[(size_t)(j - Fa) * F + g0 + li];
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          const int jb = j0 + 4 * u;
+          if (jb < jw1) accc = __builtin_amdgcn_mfma_f32_16x16x4f32(sdp[li][min(jb + lq, F - 1)], wv[u], accc, 0, 0, 0);
+        }
+      }
+      // C: column (l & 15) = k, row 4 (l >> 4) + r = sample
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][4 * lq + r][li] = accc[r];
+      __syncthreads();
+      {
+        const int mm = t >> 4, kk = t & 15, m = m0 + mm, k = g0 + kk;
+        if (m < R && k < F) {
+          const float s = ((red[0][mm][kk] + red[1][mm][kk]) + red[2][mm][kk]) + red[3][mm][kk];
+          const float v = s + dout[(size_t)m * F + k] * gate[(size_t)m * F + k];
+          if (k < Fa) da[(size_t)m * Fa + k] = v;
+          else db_[(size_t)m * Fb + (k - Fa)] = v;
+        }
+      }
+    }
+  }
+  // ---- write the weight gradient: tile column (l & 15) = k, row 4 (l >> 4) + r = j
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) {
+    const int kt = wave + 4 * i;
+    if (kt >= ntiles) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = g0 + 4 * lq + r, k = 16 * kt + li;
+      if (j < F) {
+        float* p = (j < Fa ? dw1 + (size_t)j * F : dw2 + (size_t)(j - Fa) * F) + k;
+        *p = accumulate ? *p + accw[i][r] : accw[i][r];
+      }
+    }
+  }
+  if (t < 16 && g0 + t < F) {
+    const int j = g0 + t;
+    float* p = j < Fa ? dbias1 + j : dbias2 + (j - Fa);
+    *p = accumulate ? *p + bsum : bsum;
+  }
+}
+
 // deeplio_nets.py:84-90: dropout(p) in front of the two heads fc_pos / fc_ori (Linear(K, 3) each) -- slice copy + dropout +
 // two linear launches.  One workgroup per sample row: the row (read with its own row stride: the forward half of the
 // odometry LSTM's [.., 2H] output, no slice copy) is masked into LDS, the six dot products are taken by its four waves.
@@ -1138,6 +1254,16 @@ extern "C" int dlio_soft_fusion_bwd(const float* dout, const float* a, int lda, 
     return DLIO_EINVAL;
   if (!dlio_soft_fusion_ok(R, Fa, Fb)) return DLIO_EUNSUP;
   const int F = Fa + Fb;
+  static const int mfma_on = getenv("DLIO_SOFT_FUSION_MFMA") ? atoi(getenv("DLIO_SOFT_FUSION_MFMA")) : 1;
+  if (mfma_on && (F & 15) == 0 && (Fa & 15) == 0) {
+    if (F <= 256)
+      hipLaunchKernelGGL((soft_fusion_bwd_mfma_kernel<256>), dim3(F / 16), dim3(256), 0, as_stream(stream), dout, a, b, gate, w1,
+                         w2, da, db, dw1, dbias1, dw2, dbias2, R, Fa, Fb, lda, ldb, accumulate);
+    else
+      hipLaunchKernelGGL((soft_fusion_bwd_mfma_kernel<512>), dim3(F / 16), dim3(256), 0, as_stream(stream), dout, a, b, gate, w1,
+                         w2, da, db, dw1, dbias1, dw2, dbias2, R, Fa, Fb, lda, ldb, accumulate);
+    return dlio_check_launch();
+  }
   if (F <= 256)
     hipLaunchKernelGGL((soft_fusion_bwd_kernel<256>), dim3(cdiv(F, 16)), dim3(256), 0, as_stream(stream), dout, a, b, gate, w1, w2,
                        da, db, dw1, dbias1, dw2, dbias2, R, Fa, Fb, lda, ldb, accumulate);

@@ -359,7 +359,37 @@ static void launch_gemv(hipStream_t s, const float* x0, const float* x1, int ldx
                        m0, N, K);
 }
 
+extern "C" int dlio_lstm_layer_ok(int T, int B, int I, int H, int D);
+
+static void launch_wgrad(hipStream_t s, const float* dgates, const float* x, int ldx, const float* hp, float* dw_ih0, float* dw_hh0,
+                         float* db_ih0, float* db_hh0, float* dw_ih1, float* dw_hh1, float* db_ih1, float* db_hh1, int accumulate,
+                         int T, int B, int I, int H, int D) {
+  const int rows = B * T, G = 4 * H;
+  WgArgs a;
+  for (int d = 0; d < 2; ++d) {
+    const bool on = d < D;
+    const float* dz = dgates + (size_t)(on ? d : 0) * rows * G;
+    a.s[2 * d + 0] = WgSet{dz, x, ldx, on ? I : 0, d ? dw_ih1 : dw_ih0, d ? db_ih1 : db_ih0};
+    a.s[2 * d + 1] = WgSet{dz, hp + (size_t)(on ? d : 0) * rows * H, H, on ? H : 0, d ? dw_hh1 : dw_hh0, d ? db_hh1 : db_hh0};
+  }
+  const int kmax = I > H ? I : H;
+  hipLaunchKernelGGL(lstm_wgrad_kernel, dim3(cdiv(kmax / 4, 256), G / 4, 2 * D), dim3(256), 0, s, a, G, rows, G, accumulate);
+}
+
 }  // namespace
+
+extern "C" int dlio_lstm_layer_wgrad(const float* dgates, const float* x, int ldx, const float* hp, float* dw_ih0, float* dw_hh0,
+                                     float* db_ih0, float* db_hh0, float* dw_ih1, float* dw_hh1, float* db_ih1, float* db_hh1,
+                                     int accumulate, int T, int B, int I, int H, int D, dlio_stream_t stream) {
+  if (!dgates || !x || !hp || !dw_ih0 || !dw_hh0 || (D == 2 && (!dw_ih1 || !dw_hh1))) return DLIO_EINVAL;
+  if (!dlio_lstm_layer_ok(T, B, I, H, D) || ldx < I || (ldx & 3)) return DLIO_EUNSUP;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(hp) | reinterpret_cast<uintptr_t>(dw_ih0) |
+       reinterpret_cast<uintptr_t>(dw_hh0) | reinterpret_cast<uintptr_t>(dw_ih1) | reinterpret_cast<uintptr_t>(dw_hh1)) & 15)
+    return DLIO_EUNSUP;
+  launch_wgrad(as_stream(stream), dgates, x, ldx, hp, dw_ih0, dw_hh0, db_ih0, db_hh0, dw_ih1, dw_hh1, db_ih1, db_hh1, accumulate, T,
+               B, I, H, D);
+  return dlio_check_launch();
+}
 
 extern "C" int dlio_lstm_layer_ok(int T, int B, int I, int H, int D) {
   return T >= 1 && B >= 1 && B <= 8 && (D == 1 || D == 2) && H >= 256 && H % 256 == 0 && I >= 256 && I % 256 == 0;
@@ -411,8 +441,9 @@ extern "C" int dlio_lstm_layer_bwd(const float* dhs, int lddhs, const float* x, 
                                    float* db_hh0, float* dw_ih1, float* dw_hh1, float* db_ih1, float* db_hh1, int accumulate,
                                    float* dx, int lddx, int T, int B, int I, int H, int D, void* ws, size_t ws_bytes,
                                    dlio_stream_t stream) {
-  if (!dhs || !x || !hp || !gates || !cs || !w_ih0 || !w_hh0 || !dgates || !dw_ih0 || !dw_hh0 || !ws ||
-      (D == 2 && (!w_ih1 || !w_hh1 || !dw_ih1 || !dw_hh1)))
+  const bool with_wgrad = dw_ih0 != nullptr;                       // NULL: the caller runs dlio_lstm_layer_wgrad itself (another stream)
+  if (!dhs || !x || !hp || !gates || !cs || !w_ih0 || !w_hh0 || !dgates || !ws || (D == 2 && (!w_ih1 || !w_hh1)) ||
+      (with_wgrad && (!dw_hh0 || (D == 2 && (!dw_ih1 || !dw_hh1)))))
     return DLIO_EINVAL;
   if (!dlio_lstm_layer_ok(T, B, I, H, D) || ldx < I || lddhs < D * H || (ldx & 3) || (dx && (lddx < I || (lddx & 3))))
     return DLIO_EUNSUP;
@@ -441,15 +472,8 @@ extern "C" int dlio_lstm_layer_bwd(const float* dhs, int lddhs, const float* x, 
     hipLaunchKernelGGL((gemv_t_splitn_kernel<8>), dim3(cdiv(H / 4, 64), NS, D), dim3(256), 0, s, z0, z1, T * G, w_hh0, w_hh1, dhp,
                        B, B, 0, G, H);
   }
-  WgArgs a;
-  for (int d = 0; d < 2; ++d) {
-    const bool on = d < D;
-    const float* dz = dgates + (size_t)(on ? d : 0) * rows * G;
-    a.s[2 * d + 0] = WgSet{dz, x, ldx, on ? I : 0, d ? dw_ih1 : dw_ih0, d ? db_ih1 : db_ih0};
-    a.s[2 * d + 1] = WgSet{dz, hp + (size_t)(on ? d : 0) * rows * H, H, on ? H : 0, d ? dw_hh1 : dw_hh0, d ? db_hh1 : db_hh0};
-  }
-  const int kmax = I > H ? I : H;
-  hipLaunchKernelGGL(lstm_wgrad_kernel, dim3(cdiv(kmax / 4, 256), G / 4, 2 * D), dim3(256), 0, s, a, G, rows, G, accumulate);
+  if (with_wgrad)
+    launch_wgrad(s, dgates, x, ldx, hp, dw_ih0, dw_hh0, db_ih0, db_hh0, dw_ih1, dw_hh1, db_ih1, db_hh1, accumulate, T, B, I, H, D);
   if (dx) {
     for (int m0 = 0; m0 < rows; m0 += 16) {
       const int M = rows - m0 < 16 ? rows - m0 : 16;

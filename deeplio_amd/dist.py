@@ -93,8 +93,7 @@ class GradSync:
         on its weight-gradient companion)"""
         if self.world > 1 and self.tail_lo is not None and self._tail_work is None:
             if self.flat_grad.is_cuda:
-                from .functional import aux_stream, join_wgrad_stream
-                join_wgrad_stream()     # the tail's weight gradients are forked onto the companion stream
+                from .functional import aux_stream, wgrad_stream_of
                 # Issued as a SYNCHRONOUS collective under a stream of our own: current process groups launch such a
                 # collective on the current stream, older ones on an internal stream the current one then waits for -- either
                 # way the event below marks its end, the calling (encoder) stream goes on, and in the first case the exchange
@@ -102,7 +101,10 @@ class GradSync:
                 # instead of wherever the runtime puts the group's own stream.
                 cur = torch.cuda.current_stream()
                 comm = aux_stream(self.flat_grad.device, "comm")
-                comm.wait_stream(cur)
+                ws = wgrad_stream_of(cur)
+                if ws is not None:
+                    comm.wait_stream(ws)    # the tail's weight gradients are forked onto the companion stream: the exchange
+                comm.wait_stream(cur)       # waits for them, the backward chain on `cur` does not
                 with torch.cuda.stream(comm):
                     dist.all_reduce(self.flat_grad[self.tail_lo:], op=dist.ReduceOp.SUM)
                     ev = torch.cuda.Event()

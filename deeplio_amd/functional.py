@@ -385,6 +385,12 @@ def _prep_side_stream(cur):
 ops._PREP.side = _prep_side_stream
 
 
+def wgrad_stream_of(cur):
+    """the weight-gradient companion of stream `cur`, if one exists (None: nothing was forked from it)"""
+    idx = cur.device.index if cur.device.index is not None else torch.cuda.current_device()
+    return _AUX.get((idx, "wgrad@%x" % cur.cuda_stream))
+
+
 def join_wgrad_stream():
     """current stream waits for the weight-gradient kernels forked from it so far"""
     if torch.cuda.is_available():
@@ -1877,6 +1883,7 @@ class HeadsFn(Function):
         return dx, sinks[0][2], sinks[1][2], sinks[2][2], sinks[3][2], None, None
 
 
+_LSTM_WGRAD_FORK = [os.environ.get("DLIO_LSTM_WGRAD_FORK", "1") != "0"]
 _LSTM_LAYER = [os.environ.get("DLIO_LSTM_LAYER", "1") != "0"]      # wide LSTMs: one launch sequence per LAYER (lstm_stream.hip)
 
 
@@ -1955,9 +1962,19 @@ class LstmStackFn(Function):
                 for j in range(4):
                     t, a_, r_ = _sink(weights[(l * D + d) * 4 + j], shapes[j], dout)
                     grads[(l * D + d) * 4 + j] = None if a_ else t.zero_()
-            ops.lstm_layer_bwd(dout, Dl * H, rec["inp"], Il, rec["hp"], rec["gates"], rec["cs"],
-                               [(weights[(l * D + d) * 4], weights[(l * D + d) * 4 + 1]) for d in range(Dl)],
-                               [tuple(sk[0] for sk in sinks[d]) for d in range(Dl)], acc, dinp, Il, T, B, Il, H, Dl)
+            wpairs = [(weights[(l * D + d) * 4], weights[(l * D + d) * 4 + 1]) for d in range(Dl)]
+            outs = [tuple(sk[0] for sk in sinks[d]) for d in range(Dl)]
+            ws = _wgrad_stream(dout) if (acc and _LSTM_WGRAD_FORK[0]) else None
+            if ws is None:
+                ops.lstm_layer_bwd(dout, Dl * H, rec["inp"], Il, rec["hp"], rec["gates"], rec["cs"], wpairs, outs, acc, dinp, Il,
+                                   T, B, Il, H, Dl)
+            else:
+                # the weight-gradient launch (33 / 29 us on the step's serial chain) goes straight into the flat gradient buffer and
+                # nothing on the tape waits for it: forked onto the companion stream like the convolutions' weight gradients
+                dg = ops.lstm_layer_bwd(dout, Dl * H, rec["inp"], Il, rec["hp"], rec["gates"], rec["cs"], wpairs, None, acc, dinp,
+                                        Il, T, B, Il, H, Dl)
+                inp_l, hp_l = rec["inp"], rec["hp"]
+                _forked(ws, lambda: ops.lstm_layer_wgrad(dg, inp_l, Il, hp_l, outs, True, T, B, Il, H, Dl), dg, inp_l, hp_l)
             if l > 0:
                 prev = saved[l - 1]
                 dout = ops.dropout_bwd(dinp, prev["mask"], p) if "mask" in prev else dinp

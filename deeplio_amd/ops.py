@@ -1343,13 +1343,23 @@ def lstm_layer_fwd(x, ldx, w, hs, ldhs, T, B, I, H, D):
     return cs, hp, gates
 
 
+def lstm_layer_wgrad(dgates, x, ldx, hp, dws, accumulate, T, B, I, H, D):
+    """the layer's weight + bias gradients from lstm_layer_bwd(.., dws=None)'s dgates (one launch)"""
+    g1 = dws[1] if D == 2 else (None, None, None, None)
+    check(lib.dlio_lstm_layer_wgrad(_ptr(dgates), _ptr(x), ldx, _ptr(hp), _ptr(dws[0][0]), _ptr(dws[0][1]), _ptr(dws[0][2]),
+                                    _ptr(dws[0][3]), _ptr(g1[0]), _ptr(g1[1]), _ptr(g1[2]), _ptr(g1[3]), int(accumulate), T, B, I,
+                                    H, D, _stream()), "lstm_layer_wgrad")
+
+
 def lstm_layer_bwd(dhs, lddhs, x, ldx, hp, gates, cs, w, dws, accumulate, dx, lddx, T, B, I, H, D):
-    """w = per direction (w_ih, w_hh); dws = per direction (dw_ih, dw_hh, db_ih, db_hh) written (or accumulated into);
-    dx [rows][lddx] or None"""
+    """w = per direction (w_ih, w_hh); dws = per direction (dw_ih, dw_hh, db_ih, db_hh) written (or accumulated into), or None:
+    the data path only (lstm_layer_wgrad takes the returned dgates); dx [rows][lddx] or None"""
     rows = B * T
     dgates = torch.empty(D, rows, 4 * H, dtype=torch.float32, device=x.device)
     ws = workspace(lib.dlio_lstm_layer_ws_bytes(T, B, I, H, D), x.device, slot=2)
     w1 = w[1] if D == 2 else (None, None)
+    if dws is None:
+        dws = [(None, None, None, None)] * D
     g1 = dws[1] if D == 2 else (None, None, None, None)
     check(lib.dlio_lstm_layer_bwd(_ptr(dhs), lddhs, _ptr(x), ldx, _ptr(hp), _ptr(gates), _ptr(cs), _ptr(w[0][0]), _ptr(w[0][1]),
                                   _ptr(w1[0]), _ptr(w1[1]), _ptr(dgates), _ptr(dws[0][0]), _ptr(dws[0][1]), _ptr(dws[0][2]),

@@ -57,6 +57,7 @@ class TrainStep:
         self._poll_host = None
         # the optimizer step over the tail bucket issued from inside backward (see _tail_ready); 0: one sweep at the end
         self.early_tail_step = os.environ.get("DLIO_EARLY_TAIL_STEP", "1") != "0"
+        self.zero_grad_early = os.environ.get("DLIO_ZERO_GRAD_EARLY", "1") != "0"
         self._tail_lo = self.tail_offset()
         if self._tail_lo is not None and (self._tail_lo <= 0 or self._tail_lo % 4):
             self._tail_lo = None
@@ -116,8 +117,10 @@ class TrainStep:
         if overlap:
             comm = Fh.aux_stream(self.device, "comm")
             cur = Fh.current_stream_obj()
-            Fh.join_wgrad_stream()     # (weight gradients of the tail that were forked onto the companion stream)
-            comm.wait_stream(cur)
+            ws = Fh.wgrad_stream_of(cur)
+            if ws is not None:
+                comm.wait_stream(ws)   # (the tail's weight gradients were forked onto the companion stream: the sweep waits for
+            comm.wait_stream(cur)      #  them, the chain on `cur` does not)
             self.optimizer.step_early(self._tail_lo, comm)
         else:
             self.optimizer.step_early(self._tail_lo, None)
@@ -202,8 +205,22 @@ class TrainStep:
             # a pass that raised between its early tail sweep and optimizer.step(): that sweep stands (the caller restores its
             # last good state after an error), its marker must not make THIS step skip the tail
             self.optimizer._early = None
+        zero_ev = None
+        if self.zero_grad_early and self.device.type == "cuda" and getattr(self.model, "side_stream", True):
+            # the 165 MB fill of the flat gradient buffer runs on the `comm` stream beside the forward pass (its hardware queue is
+            # idle until backward) instead of between the loss and backward(), in the step's serial middle
+            comm = Fh.aux_stream(self.device, "comm")
+            cur = Fh.current_stream_obj()
+            comm.wait_stream(cur)                  # behind the previous step's optimizer sweep
+            with Fh.on_stream(comm):
+                self.optimizer.zero_grad()
+                zero_ev = torch.cuda.Event()
+                zero_ev.record(comm)
         loss = self._tail(self.model.forward_features([[imgs, normals], imus]), gts_f2f, gts_f2g)
-        self.optimizer.zero_grad()
+        if zero_ev is None:
+            self.optimizer.zero_grad()
+        else:
+            Fh.current_stream_obj().wait_event(zero_ev)
         loss.backward(self._one)                   # (an explicit d loss / d loss: no fill launch per step)
         if self.grad_sync is not None:
             self.grad_sync.all_reduce_grads()

@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 240
+#define DLIO_ABI_VERSION 241
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);
@@ -520,6 +520,12 @@ int dlio_lstm_layer_fwd(const float* x, int ldx, const float* w_ih0, const float
                         const float* w_hh1, const float* b_ih1, const float* b_hh1, float* hs,
                         int ldhs, float* cs, float* hp, float* gates, int T, int B, int I, int H,
                         int D, void* ws, size_t ws_bytes, dlio_stream_t stream);
+/* the weight-gradient launch of dlio_lstm_layer_bwd on its own (dlio_lstm_layer_bwd with dw_ih0 == NULL skips it): nothing
+ * downstream on the tape reads these gradients, the caller may issue it on a companion stream behind the data path */
+int dlio_lstm_layer_wgrad(const float* dgates, const float* x, int ldx, const float* hp, float* dw_ih0,
+                          float* dw_hh0, float* db_ih0, float* db_hh0, float* dw_ih1, float* dw_hh1,
+                          float* db_ih1, float* db_hh1, int accumulate, int T, int B, int I, int H,
+                          int D, dlio_stream_t stream);
 int dlio_lstm_layer_bwd(const float* dhs, int lddhs, const float* x, int ldx, const float* hp,
                         const float* gates, const float* cs, const float* w_ih0,
                         const float* w_hh0, const float* w_ih1, const float* w_hh1, float* dgates,

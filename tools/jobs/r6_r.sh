@@ -1,0 +1,25 @@
+#!/bin/bash
+# round 6, job R: the serial middle again: MFMA soft-fusion backward, LSTM weight gradients forked, zero_grad beside the forward pass
+cd /root/repo; mkdir -p gpurun_out
+( timeout 1500 python -m pytest tests/test_gpu_modules.py tests/test_gpu_dist.py tests/test_tester.py -m gpu -q -x 2>&1 | tail -6 ) > gpurun_out/r6r_t1.log
+( timeout 1800 python -m pytest tests/test_gpu_model.py -m gpu -q -x -k "not pinned and not thread_counts" 2>&1 | tail -6 ) > gpurun_out/r6r_t2.log
+run() { env "$@" python bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-isolated 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'])"; }
+echo "warm $(run X=1)" > gpurun_out/r6r_ab.txt
+for i in 1 2 3 4 5 6 7 8; do
+  echo "new $(run X=1)"
+  echo "before $(run DLIO_SOFT_FUSION_MFMA=0 DLIO_LSTM_WGRAD_FORK=0 DLIO_ZERO_GRAD_EARLY=0)"
+  echo "nozero $(run DLIO_ZERO_GRAD_EARLY=0)"
+done >> gpurun_out/r6r_ab.txt 2>&1
+python - <<'P' >> gpurun_out/r6r_ab.txt
+import collections, statistics
+v = collections.defaultdict(list)
+for l in open('/root/repo/gpurun_out/r6r_ab.txt'):
+    p = l.split()
+    if len(p) == 2 and p[0] != 'warm':
+        try: v[p[0]].append(float(p[1]))
+        except ValueError: pass
+for k, x in v.items():
+    print("# %-10s n=%d median %.3f mean %.3f min %.3f max %.3f" % (k, len(x), statistics.median(x), statistics.mean(x), min(x), max(x)))
+P
+python tools/block_times.py > gpurun_out/r6r_block_times.txt 2>&1
+bash tools/prof_overlap.sh r6r
