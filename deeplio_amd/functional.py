@@ -1883,7 +1883,10 @@ class HeadsFn(Function):
         return dx, sinks[0][2], sinks[1][2], sinks[2][2], sinks[3][2], None, None
 
 
-_LSTM_WGRAD_FORK = [os.environ.get("DLIO_LSTM_WGRAD_FORK", "1") != "0"]
+# the LSTM layer's weight-gradient launch forked onto the companion stream: the serial middle gets 60 us shorter and the step
+# 0.1 ms LONGER (median 18.07 against 17.96 ms, eight alternations: the launch then shares the hardware queue with the early
+# optimizer sweep and the first convolution weight gradients) -- off
+_LSTM_WGRAD_FORK = [os.environ.get("DLIO_LSTM_WGRAD_FORK", "0") != "0"]
 _LSTM_LAYER = [os.environ.get("DLIO_LSTM_LAYER", "1") != "0"]      # wide LSTMs: one launch sequence per LAYER (lstm_stream.hip)
 
 
