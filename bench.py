@@ -158,7 +158,7 @@ def make_host_batch(seed, B, S, C, H, W, T):
     return {'images': images.pin_memory(), 'imus': imus.pin_memory(), 'gts': gts.pin_memory()}
 
 
-def host_fed_region(ts, B, S, C, H, W, T, device, steps, warmup=2, pool=3):
+def host_fed_region(ts, B, S, C, H, W, T, device, steps, warmup=4, pool=3):
     """`steps` training steps fed from the HOST (trainer.py:213 + misc.py:24-63): every step takes a pinned host batch (a pool of
     `pool` distinct ones, cycled) -- H2D copies and DataCombiCreater's kernels (pair gather + channel split, ground-truth
     transform) are issued on the 'feed' stream one step AHEAD of the step that consumes them (double-buffered: while step i
@@ -350,7 +350,7 @@ def main():
     ap.add_argument("--host-batch", action="store_true",
                     help="time the steps HOST-FED: a fresh pinned host batch per step through DataCombiCreater on a copy "
                          "stream, double-buffered (the default line reports this figure as well, under \"host_fed\")")
-    ap.add_argument("--host-steps", type=int, default=10, help="steps of the host-fed region of the default line (0 = skip)")
+    ap.add_argument("--host-steps", type=int, default=20, help="steps of the host-fed region of the default line (0 = skip)")
     ap.add_argument("--lidar", default="lidar-feat-pointseg", help="informational runs of the other families")
     ap.add_argument("--imu", default="imu-feat-rnn")
     ap.add_argument("--fusion", default="fusion-layer-soft")
