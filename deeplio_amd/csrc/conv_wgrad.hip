@@ -711,8 +711,9 @@ int launch_mr(const float* x, const float* dy, float* dw, const float* in_mean,
   constexpr bool CAN_VEC = SH == 1 && SW == 1 && ((KH == 1 && KW == 1) || (KH == 3 && KW == 3));
   const bool vec = CAN_VEC && (d.OW & 3) == 0 && (d.W & 3) == 0 &&
                    ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
-  // the 3x5 stride-(1, 2) launches (the PointSeg stem; FlowNet's narrow ones): three-piece bf16 products
-  constexpr bool STEM = KH == 3 && KW == 5 && SH == 1 && SW == 2 && MRW == 2;
+  // the multi-tap launches this staged kernel still takes -- the PointSeg stem (3x5 stride (1, 2)), the 5x7 stems and the strided
+  // / 3x5 layers of FlowNet, ResNet and Simple-1 whose operands come without a magnitude -- : three-piece bf16 products
+  constexpr bool STEM = KH * KW > 1 && !(KH == 3 && KW == 3 && SH == 1 && SW == 1) && MRW == 2;
   static const bool stem_bx3 = !(getenv("DLIO_WGRAD_STEM_BX3") && atoi(getenv("DLIO_WGRAD_STEM_BX3")) == 0);
   auto kern = (CAN_VEC && vec) ? conv_wgrad_kernel<KH, KW, SH, SW, NT, MRW, CAN_VEC>
                                : conv_wgrad_kernel<KH, KW, SH, SW, NT, MRW, false>;
