@@ -14,16 +14,19 @@ constexpr int RB = 256;  // reduction block
 
 // split the (n, hw) domain of one channel over `splits` blocks.
 // mode 0: stats (sum x', sum x'^2)    mode 1: bn backward (sum g, sum g*xh)   mode 2: sum only
-template <int MODE, int UN = 1>
+// MM (mode 0): the block also leaves the smallest and the largest value it saw in mm[c][split][2] (floats) -- the exact range of
+// a channel, from which the squeeze BatchNorm's two-piece planes take their scale (fire_expand.hip) instead of the analytic bound
+template <int MODE, int UN = 1, bool MM = false>
 __global__ __launch_bounds__(RB) void chan_reduce_kernel(
     const float* __restrict__ a, int a_ctot, int a_coff, const float* __restrict__ x, int x_ctot,
     int x_coff, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ scale, const float* __restrict__ beta, int N, int C, int HW,
-    int pre_relu, int post_relu, int splits, double* __restrict__ part) {
+    int pre_relu, int post_relu, int splits, double* __restrict__ part, float* __restrict__ mm = nullptr) {
   __shared__ double sm[2][16];
   const int c = blockIdx.x / splits;
   const int sp = blockIdx.x % splits;
   double s0 = 0.0, s1 = 0.0;
+  float vmin = 3.0e38f, vmax = -3.0e38f;
   float mu = 0.f, is = 0.f, sc = 0.f, be = 0.f;
   if (MODE == 1) { mu = mean[c]; is = invstd[c]; sc = scale[c]; be = beta ? beta[c] : 0.f; }
   const int64_t total = (int64_t)N * HW;
@@ -60,6 +63,7 @@ __global__ __launch_bounds__(RB) void chan_reduce_kernel(
         for (int k = 0; k < 4; ++k) {
           float xx = (MODE == 0 && pre_relu) ? fmaxf(ae[k], 0.f) : ae[k];
           f0 += xx; f1 += xx * xx;
+          if constexpr (MM) { vmin = fminf(vmin, xx); vmax = fmaxf(vmax, xx); }
         }
         s0 += f0; s1 += (MODE == 0) ? (double)f1 : 0.0;
       }
@@ -102,6 +106,7 @@ __global__ __launch_bounds__(RB) void chan_reduce_kernel(
         if (MODE == 0 && pre_relu) av = fmaxf(av, 0.f);
         s0 += av;
         if (MODE == 0) s1 += (double)av * av;
+        if constexpr (MM) { vmin = fminf(vmin, av); vmax = fmaxf(vmax, av); }
       }
     }
   }
@@ -110,6 +115,23 @@ __global__ __launch_bounds__(RB) void chan_reduce_kernel(
   if (threadIdx.x == 0) {
     part[((size_t)c * splits + sp) * 2 + 0] = r0;
     part[((size_t)c * splits + sp) * 2 + 1] = r1;
+  }
+  if constexpr (MM) {
+    __shared__ float smm[2][RB / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      vmin = fminf(vmin, __shfl_xor(vmin, o, 64));
+      vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { smm[0][threadIdx.x >> 6] = vmin; smm[1][threadIdx.x >> 6] = vmax; }
+    __syncthreads();
+    if (threadIdx.x == 0 && mm) {
+      float lo = smm[0][0], hi = smm[1][0];
+#pragma unroll
+      for (int w = 1; w < RB / 64; ++w) { lo = fminf(lo, smm[0][w]); hi = fmaxf(hi, smm[1][w]); }
+      mm[((size_t)c * splits + sp) * 2 + 0] = lo;
+      mm[((size_t)c * splits + sp) * 2 + 1] = hi;
+    }
   }
 }
 
@@ -753,7 +775,32 @@ extern "C" int dlio_chan_stats_splits(int N, int C, int HW) {
 
 extern "C" size_t dlio_chan_stats_ws_bytes(int N, int C, int HW) {
   if (N <= 0 || C <= 0 || HW <= 0) return 0;
-  return (size_t)C * pick_splits(N, C, HW) * 2 * sizeof(double);
+  // [C][splits][2] doubles (sum, sum of squares) + [C][splits][2] floats (min, max: dlio_bn_split16's two-piece planes)
+  return (size_t)C * pick_splits(N, C, HW) * (2 * sizeof(double) + 2 * sizeof(float));
+}
+
+// internal (fire_expand.hip): the train-mode statistics partials of dlio_bn_train_apply's first phase + the per-split range of
+// every channel behind them in the same workspace; -> the range array, or nullptr when the workspace has no room for it (the
+// plain partials are written either way)
+float* dlio_internal_stats_partials_mm(const float* x, int N, int x_ctot, int x_coff, int C, int HW, void* ws, size_t ws_bytes,
+                                       hipStream_t s, int* rc) {
+  const int splits = pick_splits(N, C, HW);
+  *rc = DLIO_OK;
+  if (ws_bytes < (size_t)C * splits * 2 * sizeof(double)) { *rc = DLIO_EWS; return nullptr; }
+  double* part = reinterpret_cast<double*>(ws);
+  float* mm = ws_bytes >= (size_t)C * splits * (2 * sizeof(double) + 2 * sizeof(float)) ? reinterpret_cast<float*>(part + (size_t)C * splits * 2)
+                                                                                     : nullptr;
+  DlioProfScope prof(6, s, 0.0, 4.0 * N * (double)C * HW);
+  if (mm)
+    hipLaunchKernelGGL((chan_reduce_kernel<0, 4, true>), dim3((unsigned)(C * splits)), dim3(RB), 0, s, x, x_ctot, x_coff,
+                       (const float*)nullptr, 0, 0, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, N, C, HW, 0, 0, splits, part, mm);
+  else
+    hipLaunchKernelGGL((chan_reduce_kernel<0, 4>), dim3((unsigned)(C * splits)), dim3(RB), 0, s, x, x_ctot, x_coff,
+                       (const float*)nullptr, 0, 0, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, N, C, HW, 0, 0, splits, part);
+  *rc = dlio_check_launch();
+  return mm;
 }
 
 static int chan_reduce(int mode, const float* a, int a_ctot, int a_coff, const float* x, int x_ctot,

@@ -13,6 +13,7 @@
 //                          patch), its weight fragments ride in the weight ring beside the centre tap's.  Both halves of
 //                          the concat buffer are written from one epilogue.
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -39,7 +40,8 @@ __global__ __launch_bounds__(256) void bn_split16_kernel(
     const float* __restrict__ x, int x_ctot, int x_coff, const double* __restrict__ part, int splits, double count,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum, float* running_mean,
     float* running_var, float* mean_io, float* invstd_o, float* scale_io, float* y, int y_ctot, int y_coff,
-    __bf16* __restrict__ planes, int N, int C, int H, int W, int post_relu, int h2, float* __restrict__ bound_out) {
+    __bf16* __restrict__ planes, int N, int C, int H, int W, int post_relu, int h2, float* __restrict__ bound_out,
+    const float* __restrict__ mm = nullptr) {
   __shared__ float tab[16][4];              // mean, scale, beta
   __shared__ float wmax[4];
   const int kc = blockIdx.y, n = blockIdx.z, KC = gridDim.y;
@@ -48,11 +50,46 @@ __global__ __launch_bounds__(256) void bn_split16_kernel(
   // with batch statistics |x - mean| / sqrt(var + eps) <= sqrt(count) for every element, so |BN(x)| <= |beta| + |gamma|
   // sqrt(count); the bound is mapped to 2^14 (fp16 max 65504).  It overshoots the true maximum by ~2^7: elements down to 1e-3
   // of the maximum keep 2^-22 relative accuracy, smaller ones an absolute error of 2^-32 of the maximum.
+  // Round 6: with the statistics partials comes the exact RANGE of every channel (mm: min / max per split, left by the
+  // statistics pass that reads the tensor anyway).  BatchNorm is monotone per channel, so the largest |BN(x)| of the tensor is
+  // max over channels of max(|BN(min)|, |BN(max)|) (behind the ReLU: max(BN(min), BN(max), 0)) -- the exact maximum instead
+  // of a bound 2^7 ... 2^9 above it: elements down to 1e-3 of the TRUE maximum keep 2^-22, channels four to five decades below
+  // the largest one keep 1e-4 relative accuracy (tests/test_gpu_ops.py: six-decade test).  Every workgroup finalises every
+  // channel's statistics for it (16 threads per channel, chunks of 16 channels; the same summation order as below).
   float hs = 1.f;
   if (h2) {
     float b = 0.f;
-    const float rc = sqrtf((float)count);
-    for (int c = tid; c < C; c += 256) b = fmaxf(b, fabsf(beta ? beta[c] : 0.f) + fabsf(gamma ? gamma[c] : 1.f) * rc);
+    if (mm && part) {
+      const int cl = tid >> 4, sub = tid & 15;
+      for (int cb = 0; cb < C; cb += 16) {
+        const int c = cb + cl;
+        if (c < C) {
+          double sa = 0.0, sq = 0.0;
+          float lo = 3.0e38f, hi = -3.0e38f;
+          for (int q = sub; q < splits; q += 16) {
+            sa += part[((size_t)c * splits + q) * 2 + 0];
+            sq += part[((size_t)c * splits + q) * 2 + 1];
+            lo = fminf(lo, mm[((size_t)c * splits + q) * 2 + 0]);
+            hi = fmaxf(hi, mm[((size_t)c * splits + q) * 2 + 1]);
+          }
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) {
+            sa += __shfl_xor(sa, o, 16); sq += __shfl_xor(sq, o, 16);
+            lo = fminf(lo, __shfl_xor(lo, o, 16)); hi = fmaxf(hi, __shfl_xor(hi, o, 16));
+          }
+          const double m = sa / count;
+          double var = sq / count - m * m;
+          if (var < 0.0) var = 0.0;
+          const float is = (float)(1.0 / sqrt(var + (double)eps));
+          const float mu = (float)m, sc = (gamma ? gamma[c] : 1.f) * is, be = beta ? beta[c] : 0.f;
+          const float v1 = (lo - mu) * sc + be, v2 = (hi - mu) * sc + be;
+          b = fmaxf(b, post_relu ? fmaxf(fmaxf(v1, v2), 0.f) : fmaxf(fabsf(v1), fabsf(v2)));
+        }
+      }
+    } else {
+      const float rc = sqrtf((float)count);
+      for (int c = tid; c < C; c += 256) b = fmaxf(b, fabsf(beta ? beta[c] : 0.f) + fabsf(gamma ? gamma[c] : 1.f) * rc);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) b = fmaxf(b, __shfl_xor(b, o, 64));
     if ((tid & 63) == 0) wmax[tid >> 6] = b;
@@ -599,6 +636,9 @@ extern "C" size_t dlio_fire_planes_bytes(int N, int S, int H, int W) {
   return (size_t)N * ((S + 15) / 16) * 3 * (H + 2) * (W + 2) * 16 * sizeof(__bf16);
 }
 
+float* dlio_internal_stats_partials_mm(const float* x, int N, int x_ctot, int x_coff, int C, int HW, void* ws, size_t ws_bytes,
+                                       hipStream_t s, int* rc);      // bn.hip
+
 extern "C" int dlio_bn_split16(const float* x, int N, int x_ctot, int x_coff, int C, int H, int W, int post_relu,
                                const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                                float* running_var, float* mean, float* invstd, float* scale, float* y, int y_ctot,
@@ -619,11 +659,17 @@ extern "C" int dlio_bn_split16(const float* x, int N, int x_ctot, int x_coff, in
   const int HW = H * W;
   const double tensor_bytes = 4.0 * N * (double)C * HW;
   int splits = 0;
+  const float* mm = nullptr;                 // per-split channel ranges behind the partials (two-piece planes: the exact scale)
   if (mode != 3) {
     if (!invstd || !ws) return DLIO_EINVAL;
     splits = dlio_chan_stats_splits(N, C, HW);
     if (ws_bytes < (size_t)C * splits * 2 * sizeof(double)) return DLIO_EWS;
-    if (mode != 2) {
+    static const bool exact = !(getenv("DLIO_SPLIT16_EXACT") && atoi(getenv("DLIO_SPLIT16_EXACT")) == 0);
+    if (mode == 0 && h2 && count_scale == 1.0 && exact) {
+      int rc = DLIO_OK;
+      mm = dlio_internal_stats_partials_mm(x, N, x_ctot, x_coff, C, HW, ws, ws_bytes, s, &rc);
+      if (rc) return rc;
+    } else if (mode != 2) {
       // statistics partials by the BatchNorm path's own reduction (dlio_bn_train_apply phase 1)
       const int rc = dlio_bn_train_apply(x, N, x_ctot, x_coff, C, HW, 0, post_relu, gamma, beta, eps, momentum, running_mean,
                                          running_var, mean, invstd, scale, nullptr, 0, 0, y ? y : const_cast<float*>(x), y_ctot,
@@ -636,7 +682,7 @@ extern "C" int dlio_bn_split16(const float* x, int N, int x_ctot, int x_coff, in
   hipLaunchKernelGGL(bn_split16_kernel, grid, dim3(256), 0, s, x, x_ctot, x_coff,
                      mode == 3 ? (const double*)nullptr : reinterpret_cast<const double*>(ws), splits,
                      (double)N * HW * count_scale, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale,
-                     y, y_ctot, y_coff, reinterpret_cast<__bf16*>(planes), N, C, H, W, post_relu, h2, h2 ? bound_out : nullptr);
+                     y, y_ctot, y_coff, reinterpret_cast<__bf16*>(planes), N, C, H, W, post_relu, h2, h2 ? bound_out : nullptr, mm);
   return dlio_check_launch();
 }
 

@@ -2047,13 +2047,13 @@ def test_two_piece_kernels_per_channel_relative_error_over_six_decades(dev):
     depends on one decade of it (block-diagonal weights for the convolutions; the weight gradient's rows / columns are per
     channel by construction), and the figure north_star words -- relative error, here relative L2 per output channel against
     fp64 -- is asserted:
-      * <= 1e-4 for EVERY channel, the 10^-6 ones included, where the scale comes from the operand's true maximum (data
-        gradients, the gradient operand of the weight gradient: rounding errors of the many products behind one output element
-        average out);
-      * <= 1e-4 for channels down to 10^-4 of the largest and <= 1e-3 below where the scale comes from the squeeze BatchNorm's
-        analytic BOUND (|beta| + |gamma| sqrt(N H W): 2-3 decades of headroom gone before the first element is stored): the
-        activation operand of the fused expand pair and of its weight gradient.  A squeeze channel four decades below its
-        neighbours (gamma_c / max gamma ~ 1e-4) is where the format leaves fp32 behind; DESIGN 5 says so."""
+      * <= 1e-4 for EVERY channel, the 10^-6 ones included: every operand's scale comes from its true maximum -- the data
+        gradients and the gradient operand of the weight gradient from the producing BatchNorm backward's amax_out, the squeeze
+        activation (the fused expand pair's and its weight gradient's operand) from the exact range the statistics pass leaves
+        per channel (round 6: dlio_bn_split16 takes max |BN(min)|, |BN(max)| over the channels instead of the analytic bound
+        |beta| + |gamma| sqrt(N H W), which sat 2^7 ... 2^9 above the maximum and cost the two smallest decades);
+      * what a scale from a bound 100 x too large does is still reported (the weight gradient with such an x scale: the
+        1e-4 ... 1e-6 channels at a few 1e-4) and held to 1e-3."""
     from deeplio_amd import ops
     g = _g(97)
     N, H, W = 2, 64, 512
@@ -2101,9 +2101,13 @@ def test_two_piece_kernels_per_channel_relative_error_over_six_decades(dev):
     dd = ops.conv_desc(N, Ci, H, W, Co, 3, 3, 1, 1, 1, 1, OH=H, OW=W)
     assert ops.conv3x3_wgrad_h2_ok(dd)
     dw = torch.empty(Co, Ci, 3, 3, device=dev)
-    ops.conv3x3_wgrad_h2(ad, (ad.abs().max() * 100.0).reshape(1), dyd, dyd.abs().max().reshape(1), dw, dd)
+    ops.conv3x3_wgrad_h2(ad, ad.abs().max().reshape(1), dyd, dyd.abs().max().reshape(1), dw, dd)
     report("wgrad3x3 rows (dy decades)", _per_channel_rel_l2(dw, ref, 0))
-    report("wgrad3x3 cols (x decades)", _per_channel_rel_l2(dw, ref, 1), from_bound=True)
+    report("wgrad3x3 cols (x decades)", _per_channel_rel_l2(dw, ref, 1))
+    # (a scale taken from a bound 100 x above the largest magnitude -- what the squeeze BatchNorm's analytic bound did until
+    #  round 6 -- loses the two smallest decades: reported, held to 1e-3)
+    ops.conv3x3_wgrad_h2(ad, (ad.abs().max() * 100.0).reshape(1), dyd, dyd.abs().max().reshape(1), dw, dd)
+    report("wgrad3x3 cols, loose bound", _per_channel_rel_l2(dw, ref, 1), from_bound=True)
     # --- the fused Fire expand pair on two-piece planes (fire_expand_fwd_kernel<.., H2>): the squeeze activation's channels
     #     span six decades through gamma / beta (the scale comes from the analytic bound |beta| + |gamma| sqrt(N H W) of the
     #     LARGEST channel), expand output channel o reads squeeze channels 4 (o mod 4) .. + 3
@@ -2115,7 +2119,10 @@ def test_two_piece_kernels_per_channel_relative_error_over_six_decades(dev):
     rm, rv = torch.zeros(S, device=dev), torch.ones(S, device=dev)
     act = torch.empty(N, S, H, W, device=dev)
     planes = ops.fire_planes(N, S, H, W, dev)
-    ops.bn_split16(rawd, S, 0, gd, bd, 1e-5, 0.1, rm, rv, act, S, 0, planes, N, S, H, W, True, fmt=1)
+    bo = torch.zeros(1, device=dev)
+    ops.bn_split16(rawd, S, 0, gd, bd, 1e-5, 0.1, rm, rv, act, S, 0, planes, N, S, H, W, True, fmt=1, bound_out=bo)
+    # the scale's magnitude is the EXACT largest activation (max over channels of BN at the channel's extreme values)
+    assert float(bo) == float(act.abs().max()) > 0
     w3 = torch.zeros(E, S, 3, 3)
     w1 = torch.zeros(E, S, 1, 1)
     for o in range(E):
@@ -2130,8 +2137,8 @@ def test_two_piece_kernels_per_channel_relative_error_over_six_decades(dev):
     r3 = F.conv2d(act.double(), w3d.double(), None, 1, 1)
     e1, e3 = _per_channel_rel_l2(yc[:, :E], r1, 1), _per_channel_rel_l2(yc[:, E:], r3, 1)
     order = torch.argsort(torch.arange(E) % 4, stable=True)           # output channels by the decade group they read
-    report("fire expand1x1 two-piece", e1[order], from_bound=True)
-    report("fire expand3x3 two-piece", e3[order], from_bound=True)
+    report("fire expand1x1 two-piece", e1[order])
+    report("fire expand3x3 two-piece", e3[order])
     for name, (hi, low, low_tol) in worst.items():
         assert hi <= 1e-4 and low <= low_tol, (name, hi, low, low_tol)
 
