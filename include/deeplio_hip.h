@@ -239,9 +239,12 @@ int dlio_fire_expand_fwd(const void* planes, const void* w3t, const void* w1t, c
 /* planes_fmt 1 -- the two-piece format: planes written by dlio_bn_split16 with mode + 16 (train modes 0 / 2 only: two fp16
  * pieces of x 2^k per value, [N][ceil(S/16)][2][H + 2][W + 2][16], 2^-k as a float behind them; same allocation size) and
  * weights from dlio_conv_h2_prep (mode 0; two fp16 pieces of w 2^j, [tap][chunk][2][n][16], then { 2^-j, 2^j }): three
- * v_mfma_f32_32x32x16_f16 per product instead of six bf16 ones, error ~1e-7 of the result.  2^k comes from
- * |BN(x)| <= |beta| + |gamma| sqrt(N H W), which holds for batch statistics (bound_out, nullable: that bound as a device
- * float, for later two-piece consumers of y -- dlio_conv3x3_wgrad_h2); 2^j from the weight tensor's largest magnitude. */
+ * v_mfma_f32_32x32x16_f16 per product instead of six bf16 ones, error ~1e-7 of the result.  2^k comes from the
+ * tensor's EXACT largest magnitude in mode 0 (the statistics pass leaves every channel's min / max behind its partial sums in
+ * ws -- dlio_chan_stats_ws_bytes has room for them --, BatchNorm is monotone per channel: max |BN(x)| = max over channels of
+ * max(|BN(min)|, |BN(max)|)); in mode 2 (partials computed elsewhere) from the bound |beta| + |gamma| sqrt(N H W), which holds
+ * for batch statistics.  bound_out (nullable): that magnitude as a device float, for later two-piece consumers of y
+ * (dlio_conv3x3_wgrad_h2); 2^j from the weight tensor's largest magnitude. */
 /* (the last two of the dlio_conv_h2_prep_floats floats are scratch of the magnitude pass -- several workgroups per tensor
  * meet there -- and must be ZERO before dlio_conv_h2_prep_batched; dlio_conv_h2_prep zeroes them and every launch leaves
  * them zero, so a layout that went through dlio_conv_h2_prep once can be refreshed by the batched call from then on) */
