@@ -895,10 +895,11 @@ def test_headline_encoder_gradients_with_the_decisions_pinned(dev, B):
         for k, e in over:
             e32 = _l2(g32[k], g64[k])
             print("   over 1e-4: %-52s HIP %.2e | torch fp32 with the same decisions %.2e" % (k, e, e32))
-            # (the factor the envelope tests above allow between two fp32 evaluations; measured here: B = 4 2.6x, B = 8 2.0x / 2.9x
-            #  for the two encoders -- the split-operand kernels' errors are relative to the TENSOR's scale, torch's to each
-            #  element, and this sum of 8 M signed terms cancels to ~1e-3 of their magnitude: B = 8 is held to 4x)
-            assert e <= (4.0 if B == 8 else 3.0) * e32, (k, e, e32)
+            # (measured: HIP 1.8e-4 at B = 4, 2.2e-4 at B = 8, the same on every box; the fp32 yardstick itself moves with the
+            #  host's core count -- its reduction tree -- 5.0e-5 .. 7.5e-5 over the boxes this ran on, so the ratio was seen at
+            #  2.0x .. 3.7x.  The split-operand kernels' errors are relative to the TENSOR's scale, torch's to each element, and
+            #  this sum of 4 - 8 M signed terms cancels to ~1e-3 of their magnitude.  Held to 5x the yardstick AND to 3e-4.)
+            assert e <= 5.0 * e32 and e <= 3e-4, (k, e, e32)
         assert len(over) <= 4 and all(k.endswith("conv1a.1.bias") for k, _ in over), over
 
 
@@ -1031,7 +1032,7 @@ def test_other_families_encoder_gradients_with_the_decisions_pinned(dev, lidar, 
         for k, e in over:
             e32 = _l2(g32[k], g64[k])
             print("   over 1e-4: %-52s HIP %.2e | torch fp32 with the same decisions %.2e" % (k, e, e32))
-            assert e <= 4.0 * e32, (k, e, e32)      # (measured: ResNet's stem BatchNorm bias 2.6x, a sum of 0.5 M cancelling terms)
+            assert e <= 5.0 * e32 and e <= 3e-4, (k, e, e32)      # (measured: ResNet's stem BatchNorm bias 2.6x, a sum of 0.5 M cancelling terms; the yardstick moves with the host core count)
         assert len(over) <= 6 and all(".bias" in k or "bn" in k for k, _ in over), over
 
 
