@@ -552,11 +552,21 @@ int launch_fire_fwd(const __bf16* planes, const __bf16* w3t, const __bf16* w1t, 
 //  in tail[2] (integer atomicMax on the bits of a non-negative float: order-independent), tail[3] counts arrivals, the last
 //  workgroup writes the scales and leaves both words zero for the next launch; the host zeroes them once, at allocation.)
 constexpr int H2_AMAX_WGS = 32;
+// (round 6: a tensor takes only as many of its grid.y workgroups as it has 16 k-element slices -- the rest leave at once --
+//  and the arrival counter is a relaxed agent-scope atomic issued when the maximum's atomic has RETURNED: both words live
+//  memory-side, nothing else is exchanged, so no fence.  With all 32 x n_items fat workgroups taking part, each with an
+//  acq_rel fence = an L2 write-back + invalidate, the batched launch took 160 us at the head of every step for 6 MB of weights.)
+__device__ __forceinline__ int h2_amax_wgs(int64_t n) {
+  const int64_t w = (n + 16383) >> 14;
+  return (int)(w < 1 ? 1 : (w > H2_AMAX_WGS ? H2_AMAX_WGS : w));
+}
 __global__ __launch_bounds__(1024) void prep_h2_amax_kernel(const DlioPrepItem* __restrict__ items, DlioPrepItem single) {
   __shared__ float wm[16];
   const DlioPrepItem it = items ? items[blockIdx.x] : single;
   const int64_t n = (int64_t)it.Cout * it.Cin * it.taps;
-  const int64_t t0 = (int64_t)blockIdx.y * 1024 + threadIdx.x, stride = (int64_t)gridDim.y * 1024;
+  const int wgs = h2_amax_wgs(n);
+  if ((int)blockIdx.y >= wgs) return;
+  const int64_t t0 = (int64_t)blockIdx.y * 1024 + threadIdx.x, stride = (int64_t)wgs * 1024;
   float b = 0.f;
   if ((reinterpret_cast<uintptr_t>(it.w) & 15) == 0) {
     const float4* w4 = reinterpret_cast<const float4*>(it.w);
@@ -581,18 +591,20 @@ __global__ __launch_bounds__(1024) void prep_h2_amax_kernel(const DlioPrepItem* 
     float* tail = it.wt + (size_t)it.taps * ((K + 15) >> 4) * Nn * 16;
     unsigned* tu = reinterpret_cast<unsigned*>(tail);
     if (!(b < 3.0e38f)) b = 3.4e38f;                     // NaN / Inf anywhere: the scale falls back to 1
-    __hip_atomic_fetch_max(tu + 2, __float_as_uint(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();
-    const unsigned arrived = __hip_atomic_fetch_add(tu + 3, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (arrived == gridDim.y - 1) {
-      __threadfence();
-      b = __uint_as_float(__hip_atomic_load(tu + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      const float sc = (b > 0.f && b < 3.0e38f) ? exp2f(floorf(log2f(16384.f / b))) : 1.f;
-      tail[0] = 1.f / sc;
-      tail[1] = sc;
+    unsigned top = __float_as_uint(b);
+    if (wgs > 1) {
+      const unsigned old = __hip_atomic_fetch_max(tu + 2, top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::"v"(old) : "memory");     // the maximum is in place before the arrival is counted
+      const unsigned arrived = __hip_atomic_fetch_add(tu + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (arrived != (unsigned)wgs - 1) return;
+      top = __hip_atomic_load(tu + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(tu + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(tu + 3, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    b = __uint_as_float(top);
+    const float sc = (b > 0.f && b < 3.0e38f) ? exp2f(floorf(log2f(16384.f / b))) : 1.f;
+    tail[0] = 1.f / sc;
+    tail[1] = sc;
   }
 }
 
