@@ -608,8 +608,13 @@ __global__ __launch_bounds__(1024) void prep_h2_amax_kernel(const DlioPrepItem* 
   }
 }
 
-__global__ void prep_h2_kernel(const DlioPrepItem* __restrict__ items, int n_items, int64_t total, DlioPrepItem single) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+// (a thread builds 8 consecutive k of one (tap, chunk, n): one search of the item table and two 16-byte stores per 8 elements)
+typedef _Float16 prep_f16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void prep_h2_kernel(const DlioPrepItem* __restrict__ items, int n_items, int64_t total,
+                                                      DlioPrepItem single) {
+  const int64_t total8 = total >> 3;                // (every item's index space is a multiple of 16)
+  for (int64_t i8 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i8 < total8; i8 += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = i8 << 3;
     int lo = 0, hi = n_items - 1;                 // last item with start <= i
     while (items && lo < hi) {
       const int mid = (lo + hi + 1) >> 1;
@@ -619,25 +624,28 @@ __global__ void prep_h2_kernel(const DlioPrepItem* __restrict__ items, int n_ite
     const int64_t e = i - it.start;
     const int K = it.mode == 0 ? it.Cin : it.Cout, Nn = it.mode == 0 ? it.Cout : it.Cin;
     const int KC = (K + 15) >> 4;
-    const int kk = (int)(e & 15);
+    const int kk = (int)(e & 15);                  // 0 or 8
     int64_t t = e >> 4;
     const int n = (int)(t % Nn); t /= Nn;
     const int kc = (int)(t % KC);
     const int tap = (int)(t / KC);
-    const int k = kc * 16 + kk;
-    float v = 0.f;
-    if (k < K) {
-      if (it.mode == 0) v = it.w[((int64_t)n * it.Cin + k) * it.taps + tap];
-      else v = it.w[((int64_t)k * it.Cin + n) * it.taps + (it.taps - 1 - tap)];
-    }
+    const int k0 = kc * 16 + kk;
+    const float* src = it.mode == 0 ? it.w + ((int64_t)n * it.Cin + k0) * it.taps + tap
+                                    : it.w + ((int64_t)k0 * it.Cin + n) * it.taps + (it.taps - 1 - tap);
+    const int64_t ks = it.mode == 0 ? (int64_t)it.taps : (int64_t)it.Cin * it.taps;
     const float sc = it.wt[(size_t)it.taps * KC * Nn * 16 + 1];
-    const float vs = v * sc;
-    const _Float16 h = (_Float16)vs;
-    const _Float16 l = (_Float16)(vs - (float)h);
+    prep_f16x8 h, l;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float vs = (k0 + q < K ? src[q * ks] : 0.f) * sc;
+      const _Float16 hh = (_Float16)vs;
+      h[q] = hh;
+      l[q] = (_Float16)(vs - (float)hh);
+    }
     _Float16* wt = reinterpret_cast<_Float16*>(it.wt);
     const int64_t base = (((int64_t)tap * KC + kc) * 2) * Nn * 16 + (int64_t)n * 16 + kk;
-    wt[base] = h;
-    wt[base + (int64_t)Nn * 16] = l;
+    *reinterpret_cast<prep_f16x8*>(wt + base) = h;
+    *reinterpret_cast<prep_f16x8*>(wt + base + (int64_t)Nn * 16) = l;
   }
 }
 
@@ -706,6 +714,7 @@ extern "C" size_t dlio_conv_h2_prep_floats(int Cout, int Cin, int taps, int mode
 
 extern "C" int dlio_conv_h2_prep(const float* w, void* wt, int Cout, int Cin, int taps, int mode, dlio_stream_t stream) {
   if (!w || !wt || Cout <= 0 || Cin <= 0 || taps <= 0 || (mode != 0 && mode != 1)) return DLIO_EINVAL;
+  if (reinterpret_cast<uintptr_t>(wt) & 15) return DLIO_EUNSUP;          // (the layout is written in 16-byte pieces)
   const int K = mode == 0 ? Cin : Cout, Nn = mode == 0 ? Cout : Cin;
   const int64_t total = (int64_t)taps * ((K + 15) >> 4) * Nn * 16;
   const DlioPrepItem one{w, reinterpret_cast<float*>(wt), Cout, Cin, taps, mode, 0};
@@ -713,16 +722,16 @@ extern "C" int dlio_conv_h2_prep(const float* w, void* wt, int Cout, int Cin, in
   // (the two scratch words behind the scales must be zero: zeroed here for a layout buffer that comes from anywhere)
   if (hipMemsetAsync(reinterpret_cast<float*>(wt) + total + 2, 0, 2 * sizeof(float), s) != hipSuccess) return DLIO_ELAUNCH;
   hipLaunchKernelGGL(prep_h2_amax_kernel, dim3(1, H2_AMAX_WGS), dim3(1024), 0, s, (const DlioPrepItem*)nullptr, one);
-  hipLaunchKernelGGL(prep_h2_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, s, (const DlioPrepItem*)nullptr, 1, total, one);
+  hipLaunchKernelGGL(prep_h2_kernel, dim3(ew_grid(total >> 3, 256)), dim3(256), 0, s, (const DlioPrepItem*)nullptr, 1, total, one);
   return dlio_check_launch();
 }
 
 extern "C" int dlio_conv_h2_prep_batched(const DlioPrepItem* items_dev, int n_items, int64_t total, dlio_stream_t stream) {
-  if (!items_dev || n_items <= 0 || total <= 0) return DLIO_EINVAL;
+  if (!items_dev || n_items <= 0 || total <= 0 || (total & 15)) return DLIO_EINVAL;
   hipStream_t s = as_stream(stream);
   const DlioPrepItem none{nullptr, nullptr, 0, 0, 0, 0, 0};
   hipLaunchKernelGGL(prep_h2_amax_kernel, dim3((unsigned)n_items, H2_AMAX_WGS), dim3(1024), 0, s, items_dev, none);
-  hipLaunchKernelGGL(prep_h2_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, s, items_dev, n_items, total, none);
+  hipLaunchKernelGGL(prep_h2_kernel, dim3(ew_grid(total >> 3, 256)), dim3(256), 0, s, items_dev, n_items, total, none);
   return dlio_check_launch();
 }
 

@@ -247,7 +247,9 @@ int dlio_fire_expand_fwd(const void* planes, const void* w3t, const void* w1t, c
  * (dlio_conv3x3_wgrad_h2); 2^j from the weight tensor's largest magnitude. */
 /* (the last two of the dlio_conv_h2_prep_floats floats are scratch of the magnitude pass -- several workgroups per tensor
  * meet there -- and must be ZERO before dlio_conv_h2_prep_batched; dlio_conv_h2_prep zeroes them and every launch leaves
- * them zero, so a layout that went through dlio_conv_h2_prep once can be refreshed by the batched call from then on) */
+ * them zero, so a layout that went through dlio_conv_h2_prep once can be refreshed by the batched call from then on;
+ * wt -- here and in the items of the two batched calls -- 16-byte aligned: the layouts are written in 16-byte pieces,
+ * DLIO_EUNSUP from dlio_conv_h2_prep otherwise) */
 size_t dlio_conv_h2_prep_floats(int Cout, int Cin, int taps, int mode);
 int dlio_conv_h2_prep(const float* w, void* wt, int Cout, int Cin, int taps, int mode, dlio_stream_t stream);
 int dlio_conv_h2_prep_batched(const DlioPrepItem* items_dev, int n_items, int64_t total, dlio_stream_t stream);

@@ -2025,6 +2025,64 @@ def test_two_piece_weight_layout_scales_single_and_batched(dev):
     assert scales(ws[3])[0] == 1.0 and scales(ws[3])[2] == [0.0, 0.0]
 
 
+def _split_layout_reference(w, mode, pieces):
+    """[tap][chunk][pieces][n][16] 16-bit planes of a conv weight, built with torch: mode 0: k = ci, n = co; mode 1: k = co,
+    n = ci, taps reversed; pieces 3: bf16 hi / mid / lo, 2: fp16 hi / lo of w 2^k (+ the scale 2^k)"""
+    Cout, Cin = w.shape[:2]
+    taps = w.shape[2] * w.shape[3]
+    w3 = w.reshape(Cout, Cin, taps).float().cpu()
+    a = w3.permute(2, 1, 0) if mode == 0 else w3.flip(2).permute(2, 0, 1)          # [tap][k][n]
+    K, Nn = a.shape[1], a.shape[2]
+    KC = (K + 15) // 16
+    pad = torch.zeros(taps, KC * 16, Nn)
+    pad[:, :K] = a
+    v = pad.reshape(taps, KC, 16, Nn).permute(0, 1, 3, 2).contiguous()             # [tap][chunk][n][16]
+    if pieces == 3:
+        h = v.bfloat16(); r = v - h.float(); m = r.bfloat16(); lo = (r - m.float()).bfloat16()
+        return torch.stack([h, m, lo], 2).contiguous().view(torch.int16), None
+    b = float(w.abs().max())
+    sc = 2.0 ** math.floor(math.log2(16384.0 / b))
+    vs = v * sc
+    h = vs.half(); lo = (vs - h.float()).half()
+    return torch.stack([h, lo], 2).contiguous().view(torch.int16), sc
+
+
+@pytest.mark.gpu
+def test_batched_weight_relayouts_match_a_torch_construction(dev):
+    """the two batched re-layout launches at the head of every step (three-piece bf16 and two-piece fp16 planes of every conv
+    weight, a thread = 8 consecutive k written as 16-byte pieces): bit-identical to the layouts built with torch, forward and
+    data-gradient mode, channel counts that are no multiple of 16 or 8 (the stem's 5), 1 / 9 / 15 taps, after an in-place
+    update of the weights (i.e. through the batched path, not the first-use single call)"""
+    from deeplio_amd import ops
+    g = _g(17)
+    shapes = [(64, 5, 3, 5), (16, 64, 1, 1), (64, 16, 3, 3), (24, 40, 3, 3), (7, 19, 1, 1), (256, 48, 3, 3)]
+    ws = [(torch.randn(*sh, generator=g) * (0.3 + i)).to(dev) for i, sh in enumerate(shapes)]
+    use = []
+    for w in ws:
+        for mode in (0, 1):
+            if tuple(w.shape[2:]) == (3, 5) and mode == 1:
+                continue
+            use.append((w, mode, 3))
+            if tuple(w.shape[2:]) != (3, 5):
+                use.append((w, mode, 2))
+    get = lambda w, mode, pc: ops.conv_bx3_prepped(w, mode) if pc == 3 else ops.conv_h2_prepped(w, mode)
+    for u in use:
+        get(*u)                                  # registered (first use: the single-tensor kernels)
+    for rnd in range(2):
+        with torch.no_grad():
+            for i, w in enumerate(ws):
+                w.mul_(1.3 + 0.2 * i).add_(0.01 * rnd)
+        ops.weights_changed()                   # the next fetch refreshes every registered layout in the batched launches
+        for w, mode, pc in use:
+            lay = get(w, mode, pc)
+            ref, sc = _split_layout_reference(w, mode, pc)
+            n16 = ref.numel()
+            got = lay.view(torch.int16)[:n16].cpu().reshape(ref.shape)
+            assert torch.equal(got, ref), (rnd, tuple(w.shape), mode, pc, int((got != ref).sum()))
+            if pc == 2:
+                assert float(lay[n16 // 2 + 1]) == sc and float(lay[n16 // 2]) == 1.0 / sc
+
+
 def _per_channel_rel_l2(y, ref, dim):
     """relative L2 error per output channel (row): ||y_c - ref_c|| / ||ref_c||, reduced over every axis but `dim`"""
     axes = tuple(a for a in range(ref.dim()) if a != dim)
