@@ -863,7 +863,7 @@ int g_coop_cus = 0;
 // launch with whatever else runs, like any ordinary kernel); 0: persistent workgroups with the next item's loads in flight
 int g_coop_mode = -1;
 int coop_mode() {
-  static const int m = getenv("DLIO_BN_COOP_MODE") ? atoi(getenv("DLIO_BN_COOP_MODE")) : 2;
+  static const int m = getenv("DLIO_BN_COOP_MODE") ? atoi(getenv("DLIO_BN_COOP_MODE")) : 3;
   return g_coop_mode >= 0 ? g_coop_mode : m;
 }
 int coop_oneshot() { return coop_mode() != 0; }      // (the one-item-at-a-time kernel variants)
@@ -883,11 +883,25 @@ int coop_occupancy(const void* kernel, int T) {
 }
 // 0: the chip cannot hold 2 NP workgroups of this kernel at once (two launches -- the two encoder streams -- must each find
 // NP resident workgroups): the caller refuses the path
+// Persistent (1) or one item per workgroup (0) for THIS launch of a one-item-at-a-time kernel.  Mode 3: one item per workgroup
+// where that cannot deadlock, persistent otherwise.  In the one-item mode the partners of a channel are whichever workgroups
+// the dispatcher starts next; a workgroup that has drawn its ticket holds its slot until the channel is complete.  The eight
+// XCDs dispatch their shares of a grid independently, so the tickets still to be drawn may all belong to workgroups of ONE XCD,
+// and they start only if that XCD has a free slot: it has S = occupancy x CUs / 8 of them, a launch waits with at most NP - 1
+// workgroups, so up to three concurrent launches are safe when 3 (NP - 1) < S -- at N = 16 the layers of fire_blk2 / blk3
+// (NP = 32 / 16, S = 96); the two encoders' fire_blk1 launches (NP = 64 each) are not: measured in the training step with
+// mode 1, one step in ~150 stalls until the spin limit, both launches at once, and never with one launch at a time.
+int coop_loop(const void* kernel, int NP, int T) {
+  const int m = coop_mode();
+  if (m != 3) return m == 1 ? 0 : 1;
+  const int S = coop_occupancy(kernel, T) * (dlio_num_cus() / 8);
+  return 3 * (NP - 1) < S ? 0 : 1;
+}
 int coop_grid(const void* kernel, int NP, int C, int T, bool oneshot = false) {
   static const int env = getenv("DLIO_BN_COOP_CUS") ? atoi(getenv("DLIO_BN_COOP_CUS")) : 0;
   const int occ = coop_occupancy(kernel, T), cus = dlio_num_cus();
   if ((int64_t)cus * occ < 2 * (int64_t)NP) return 0;
-  if (oneshot && coop_mode() == 1) return (int64_t)C * NP > 0x7fffffff ? 0 : C * NP;      // one item per workgroup
+  if (oneshot && !coop_loop(kernel, NP, T)) return (int64_t)C * NP > 0x7fffffff ? 0 : C * NP;      // one item per workgroup
   if (g_coop_cus < 0) return -g_coop_cus;             // (test hook: an exact grid, also one too small to make progress)
   // default 160 of 256 CUs' worth: in the five-stream step a grid that fills the chip leaves the neighbours' kernels nothing
   // (sweep, mode 2: 48 -> 19.7, 64 -> 19.3, 96 -> 19.5, 128 -> 18.8, 256 -> 19.0 ms per step; alone the launch is fastest at 256)
@@ -955,10 +969,12 @@ extern "C" int dlio_bn_small_bwd(const float* dy, int dy_ctot, int dy_coff, cons
 }
 
 extern "C" int dlio_bn_coop_set_mode(int oneshot) {
-  if (oneshot < -1 || oneshot > 2) return DLIO_EINVAL;
-  g_coop_mode = oneshot;            // -1: the default (DLIO_BN_COOP_MODE, else 2)
+  if (oneshot < -1 || oneshot > 3) return DLIO_EINVAL;
+  g_coop_mode = oneshot;            // -1: the default (DLIO_BN_COOP_MODE, else 3)
   return DLIO_OK;
 }
+
+extern "C" int dlio_bn_coop_get_mode(void) { return coop_mode(); }
 
 extern "C" int dlio_bn_coop_set_cus(int cus) {
   g_coop_cus = cus;                 // 0 = all CUs; < 0: exactly -cus workgroups (tests of the ticket protocol's corner cases)
@@ -997,7 +1013,7 @@ extern "C" int dlio_bn_coop_fwd(const float* x, int N, int x_ctot, int x_coff, i
 #define BNC(TT, PP) do { grid = coop_grid(reinterpret_cast<const void*>(&bn_coop_fwd_kernel<8, TT, PP>), N * P, C, TT, !PP); if (grid > 0) hipLaunchKernelGGL((bn_coop_fwd_kernel<8, TT, PP>), dim3((unsigned)grid), dim3(TT), 0, s, x, x_ctot, x_coff, N, C, C1, s1, s2, \
                                    eps, momentum, mean, invstd, scale, residual, r_ctot, r_coff, r_mean, r_scale, r_shift, y, y_ctot,     \
                                    y_coff, gap_out, gap_ctot, gap_coff, post_relu, reinterpret_cast<double*>(part),                      \
-                                   reinterpret_cast<int*>(sync), P, coop_mode() == 2 ? 1 : 0, amax_out); } while (0)
+                                   reinterpret_cast<int*>(sync), P, coop_loop(reinterpret_cast<const void*>(&bn_coop_fwd_kernel<8, TT, PP>), N * P, TT), amax_out); } while (0)
   if (coop_oneshot()) { if (T == 512) BNC(512, false); else BNC(256, false); }
   else { if (T == 512) BNC(512, true); else BNC(256, true); }
 #undef BNC
@@ -1027,7 +1043,7 @@ extern "C" int dlio_bn_coop_bwd(const float* dy, int dy_ctot, int dy_coff, const
 #define BNC(TT, PP) do { grid = coop_grid(reinterpret_cast<const void*>(&bn_coop_bwd_kernel<8, TT, 0, PP>), N * P, C, TT, !PP); if (grid > 0) hipLaunchKernelGGL((bn_coop_bwd_kernel<8, TT, 0, PP>), dim3((unsigned)grid), dim3(TT), 0, s, dy, dy_ctot, dy_coff, x, x_ctot,  \
                                    x_coff, N, C, C1, s1, s2, mean, invstd, scale, dx1, dx2, accumulate, post_relu,                    \
                                    reinterpret_cast<double*>(part), reinterpret_cast<int*>(sync), P, amax_out, CoopPool{},          \
-                                   coop_mode() == 2 ? 1 : 0); } while (0)
+                                   coop_loop(reinterpret_cast<const void*>(&bn_coop_bwd_kernel<8, TT, 0, PP>), N * P, TT)); } while (0)
   if (coop_oneshot()) { if (T == 512) BNC(512, false); else BNC(256, false); }
   else if (T == 512) BNC(512, true); else BNC(256, true);
 #undef BNC
@@ -1073,7 +1089,7 @@ extern "C" int dlio_bn_coop_bwd_pool(const float* dy, int dy_ctot, int dy_coff, 
   const CoopPool pl{dy_pooled, idx, x_scale, x_add, W, OH, OW};
   DlioProfScope prof(9, s, 0.0, 4.0 * N * (double)C * HW * (dy ? 3.0 : 2.0) + 5.0 * N * (double)C * OH * OW);
   int grid = 0;
-#define BNC(TT, PL, PP) do { grid = coop_grid(reinterpret_cast<const void*>(&bn_coop_bwd_kernel<8, TT, PL, PP>), N * P, C, TT, !PP); if (grid > 0) hipLaunchKernelGGL((bn_coop_bwd_kernel<8, TT, PL, PP>), dim3((unsigned)grid), dim3(TT), 0, s, dy, dy_ctot, dy_coff, x,                                         x_ctot, x_coff, N, C, C1, s1, s2, mean, invstd, scale, dx1, dx2, accumulate, post_relu,                                               reinterpret_cast<double*>(part), reinterpret_cast<int*>(sync), P, amax_out, pl, coop_mode() == 2 ? 1 : 0); } while (0)
+#define BNC(TT, PL, PP) do { grid = coop_grid(reinterpret_cast<const void*>(&bn_coop_bwd_kernel<8, TT, PL, PP>), N * P, C, TT, !PP); if (grid > 0) hipLaunchKernelGGL((bn_coop_bwd_kernel<8, TT, PL, PP>), dim3((unsigned)grid), dim3(TT), 0, s, dy, dy_ctot, dy_coff, x,                                         x_ctot, x_coff, N, C, C1, s1, s2, mean, invstd, scale, dx1, dx2, accumulate, post_relu,                                               reinterpret_cast<double*>(part), reinterpret_cast<int*>(sync), P, amax_out, pl, coop_loop(reinterpret_cast<const void*>(&bn_coop_bwd_kernel<8, TT, PL, PP>), N * P, TT)); } while (0)
   if (coop_oneshot()) {
     if (SH == 1) { if (T == 512) BNC(512, 1, false); else BNC(256, 1, false); }
     else { if (T == 512) BNC(512, 2, false); else BNC(256, 2, false); }

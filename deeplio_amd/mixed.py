@@ -98,10 +98,12 @@ def bn_apply(x, x_ctot, x_coff, gamma, beta, eps, momentum, rmean, rvar, y, y_ct
         # one launch, every operand read once: the workgroups that hold a channel's planes in registers exchange their
         # partial sums (csrc/bn_small.hip, the cooperative kernels over bf16 storage)
         part, sync_ = ops._coop_ws(N, C_, x.device)
+        ops._coop_enter(x.device)
         check(lib.dlio_bn_bf16_coop_fwd(_ptr(x), N, x_ctot, x_coff, C_, HW, int(post_relu), _ptr(gamma), _ptr(beta),
                                         float(eps), float(momentum), _ptr(rmean), _ptr(rvar), _ptr(prm[0]), _ptr(prm[1]),
                                         _ptr(prm[2]), _ptr(residual), r_ctot, r_coff, _ptr(y), y_ctot, y_coff, _ptr(gap_out),
                                         gap_ctot, gap_coff, _ptr(part), _ptr(sync_), _stream()), "bn_bf16_coop_fwd")
+        ops._coop_exit(x.device)
         return prm
     ws = _stats_ws(N, C_, HW, x.device)
 
@@ -125,10 +127,12 @@ def bn_bwd(dy, dy_ctot, dy_coff, x, x_ctot, x_coff, prm, beta, dx, dx_ctot, dx_c
            use_batch_stats, dgamma=None, dbeta=None, accumulate=False):
     if use_batch_stats and _coop16_ok(N, HW, False):
         part, sync_ = ops._coop_ws(N, C_, x.device)
+        ops._coop_enter(x.device)
         check(lib.dlio_bn_bf16_coop_bwd(_ptr(dy), dy_ctot, dy_coff, _ptr(x), x_ctot, x_coff, _ptr(prm[0]), _ptr(prm[1]),
                                         _ptr(prm[2]), _ptr(beta), _ptr(dx), dx_ctot, dx_coff, _ptr(dgamma), _ptr(dbeta),
                                         int(accumulate), N, C_, HW, int(post_relu), _ptr(part), _ptr(sync_), _stream()),
               "bn_bf16_coop_bwd")
+        ops._coop_exit(x.device)
         return dx
     ws = _stats_ws(N, C_, HW, x.device)
 

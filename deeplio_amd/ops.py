@@ -681,15 +681,52 @@ def bn_coop_set_cus(cus):
 
 
 def bn_coop_set_mode(oneshot):
-    """2: persistent workgroups, one item at a time (default); 1: one item per workgroup; 0: persistent, software-pipelined
-    workgroups; -1: the default again (see dlio_bn_coop_set_mode)"""
+    """3 (default): one item per workgroup where concurrent launches cannot fill an XCD with waiting workgroups, persistent
+    otherwise; 2: persistent workgroups, one item at a time; 1: one item per workgroup (launches chained by _coop_enter);
+    0: persistent, software-pipelined workgroups; -1: the default again (see dlio_bn_coop_set_mode)"""
     check(lib.dlio_bn_coop_set_mode(int(oneshot)), "bn_coop_set_mode")
+    _COOP_TOKEN[0] = None              # (decided again from the mode now in force)
 
 
 def bn_coop_gap_ok(N, HW):
     """the cooperative forward kernel can deliver plane averages (gap_out) for this geometry (fp32: any it takes -- the
     parts of a plane exchange their sums; the bf16 kernels ask dlio_bn_coop_gap_ok)"""
     return bn_coop_ok(N, HW)
+
+
+# At most ONE cooperative BatchNorm launch in flight per device (DLIO_BN_COOP_TOKEN, on with the one-item-per-workgroup mode):
+# every launch waits for the previous one -- whatever stream that was on -- and leaves its own event.  In that mode the
+# partners of a channel are whichever workgroups the dispatcher starts next; two such launches (the two encoder streams) can
+# fill an XCD's workgroup slots with waiting workgroups of BOTH while the partners they wait for are not yet dispatched --
+# measured: one step in ~150 stalls until the spin limit, both launches at once.  One launch alone cannot: it waits with fewer
+# than N * parts workgroups, an XCD holds more.  (The persistent mode draws every ticket from resident workgroups: no token.)
+_COOP_TOKEN = [None]
+_COOP_LAST = {}
+
+
+def _coop_token_on():
+    if _COOP_TOKEN[0] is None:
+        env = os.environ.get("DLIO_BN_COOP_TOKEN")
+        _COOP_TOKEN[0] = (env != "0") if env is not None else (lib.dlio_bn_coop_get_mode() == 1)
+    return _COOP_TOKEN[0]
+
+
+def _coop_enter(device):
+    if not _coop_token_on():
+        return
+    dev = device.index if device.index is not None else torch._C._cuda_getDevice()
+    last = _COOP_LAST.get(dev)
+    if last is not None and last[0] != raw_stream():
+        torch.cuda.current_stream().wait_event(last[1])
+
+
+def _coop_exit(device):
+    if not _coop_token_on():
+        return
+    dev = device.index if device.index is not None else torch._C._cuda_getDevice()
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    _COOP_LAST[dev] = (raw_stream(), ev)
 
 
 def _coop_ws(N, C_, device):
@@ -712,6 +749,7 @@ def bn_coop_fwd(x, x_ctot, x_coff, N, C_, C1, HW, set1, set2, eps, momentum, prm
     """bn_small_fwd for large planes (N cooperating workgroups per channel)"""
     g2 = set2 if set2 is not None else (None, None, None, None)
     part, sync = _coop_ws(N, C_, x.device)
+    _coop_enter(x.device)
     check(lib.dlio_bn_coop_fwd(_ptr(x), N, x_ctot, x_coff, C_, C1, HW, int(post_relu), _ptr(set1[0]), _ptr(set1[1]),
                                _ptr(set1[2]), _ptr(set1[3]), _ptr(g2[0]), _ptr(g2[1]), _ptr(g2[2]), _ptr(g2[3]), float(eps),
                                float(momentum), _ptr(prm[0]), _ptr(prm[1]), _ptr(prm[2]), _ptr(residual),
@@ -720,6 +758,7 @@ def bn_coop_fwd(x, x_ctot, x_coff, N, C_, C1, HW, set1, set2, eps, momentum, prm
                                _ptr(y), y_ctot, y_coff, _ptr(gap_out), gap_ctot, gap_coff, _ptr(part), _ptr(sync),
                                _ptr(amax_out), _stream()),
           "bn_coop_fwd")
+    _coop_exit(x.device)
     return prm
 
 
@@ -727,10 +766,12 @@ def bn_coop_bwd(dy, dy_ctot, dy_coff, x, x_ctot, x_coff, prm, beta1, beta2, dx1,
                 C_, C1, HW, post_relu=True, amax_out=None):
     """amax_out: a zeroed one-float tensor (amax_slot) that receives max |dx| (for the two-piece split kernels)"""
     part, sync = _coop_ws(N, C_, x.device)
+    _coop_enter(x.device)
     check(lib.dlio_bn_coop_bwd(_ptr(dy), dy_ctot, dy_coff, _ptr(x), x_ctot, x_coff, _ptr(prm[0]), _ptr(prm[1]), _ptr(prm[2]),
                                _ptr(beta1), _ptr(beta2), _ptr(dx1), _ptr(dx2), _ptr(dg1), _ptr(db1), _ptr(dg2), _ptr(db2),
                                int(accumulate), N, C_, C1, HW, int(post_relu), _ptr(part), _ptr(sync), _ptr(amax_out),
                                _stream()), "bn_coop_bwd")
+    _coop_exit(x.device)
 
 
 def bn_coop_pool_ok(N, H, W, SH):
@@ -743,10 +784,12 @@ def bn_coop_bwd_pool(dy, dy_ctot, dy_coff, pool, x, x_ctot, x_coff, prm, beta1, 
     x_scale, x_add, SH) from the SELayer + max-pool behind the block (the full-resolution gradient is never written)"""
     dyp, idx, xs, xa, SH = pool
     part, sync = _coop_ws(N, C_, x.device)
+    _coop_enter(x.device)
     check(lib.dlio_bn_coop_bwd_pool(_ptr(dy), dy_ctot, dy_coff, _ptr(dyp), _ptr(idx), _ptr(xs), _ptr(xa), H, W, SH, _ptr(x),
                                     x_ctot, x_coff, _ptr(prm[0]), _ptr(prm[1]), _ptr(prm[2]), _ptr(beta1), _ptr(beta2),
                                     _ptr(dx1), _ptr(dx2), _ptr(dg1), _ptr(db1), _ptr(dg2), _ptr(db2), int(accumulate), N, C_,
                                     C1, int(post_relu), _ptr(part), _ptr(sync), _ptr(amax_out), _stream()), "bn_coop_bwd_pool")
+    _coop_exit(x.device)
 
 
 _AMAX = {}

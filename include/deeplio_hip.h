@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 241
+#define DLIO_ABI_VERSION 242
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);
@@ -701,12 +701,22 @@ int dlio_bn_coop_ok(int N, int HW);
  * workgroups per CU).  A cap, not a correctness condition.  cus < 0 (tests): exactly -cus workgroups per launch, whatever the geometry --
  * fewer than half the cooperating workgroups of a channel cannot make progress and end in the error flag. */
 int dlio_bn_coop_set_cus(int cus);
-/* 2 (default): persistent workgroups (grid as above), one item at a time, the next ticket drawn when the item is done;
- * 1: one item per workgroup, the grid covers the items (measured: beside other streams' launches the dispatcher can starve
- * the not yet started partners for > 100 ms -- the spin limit fires; kept for experiments); 0: persistent workgroups that
- * load their next item under the exchange of the current one (twice the registers); -1: back to the default (environment
- * DLIO_BN_COOP_MODE). */
+/* 2: persistent workgroups (grid as above), one item at a time, the next ticket drawn when the item is done;
+ * 1: one item per workgroup, the grid covers the items -- the partners of a channel are then whichever workgroups the
+ * dispatcher starts next, a workgroup that has drawn its ticket keeps its slot until its channel is complete, and the eight
+ * XCDs dispatch their shares of a grid independently: the tickets still to be drawn may all belong to workgroups of ONE XCD,
+ * which start only if that XCD has a free slot.  Two such launches of N * parts = 64 partners (the two encoders' fire_blk1
+ * layers) can fill an XCD's 96 slots with waiting workgroups of both: measured in the training step, one step in ~150 stalls
+ * for the 140 ms of the spin limit, both launches at once, and never when the launches are chained one after the other (the
+ * host mirror does that in mode 1: deeplio_amd/ops.py _coop_enter / _coop_exit -- slower than mode 2);
+ * 3 (default): per launch -- one item per workgroup when 3 (N * parts - 1) < occupancy x CUs / 8, i.e. when up to THREE
+ * concurrent cooperative launches cannot fill an XCD with waiting workgroups, persistent otherwise (at N = 16: fire_blk2 /
+ * blk3 one item per workgroup, fire_blk1 persistent; a caller that keeps more than three cooperative launches in flight at
+ * once uses mode 2);
+ * 0: persistent workgroups that load their next item under the exchange of the current one (twice the registers);
+ * -1: back to the default (environment DLIO_BN_COOP_MODE). */
 int dlio_bn_coop_set_mode(int oneshot);
+int dlio_bn_coop_get_mode(void);                 /* the mode in force (3 / 2 / 1 / 0) */
 int dlio_bn_coop_parts(int N, int HW);
 int dlio_bn_coop_gap_ok(int N, int HW);        /* bf16 kernels with gap_out: the plane in one workgroup, H * W in {8192, 16384, 32768} */
 size_t dlio_bn_coop_ws_bytes(int N, int C);      /* bytes of `part` */

@@ -32,6 +32,24 @@ def test_library_exports_every_declared_symbol():
     assert _lib.strerror(-2) == "unsupported configuration"
 
 
+def test_cooperative_batchnorm_mode_switch_needs_no_device():
+    """dlio_bn_coop_set_mode / _get_mode (host-side state only): the default is mode 3 -- one item per workgroup where
+    concurrent launches cannot fill an XCD with waiting workgroups, persistent otherwise -- unless the environment
+    says otherwise; out-of-range values are refused"""
+    from deeplio_amd import _lib
+    lib = _lib.lib
+    default = int(os.environ.get("DLIO_BN_COOP_MODE", "3"))
+    assert lib.dlio_bn_coop_get_mode() == default
+    try:
+        for m in (0, 1, 2, 3):
+            assert lib.dlio_bn_coop_set_mode(m) == 0 and lib.dlio_bn_coop_get_mode() == m
+        assert lib.dlio_bn_coop_set_mode(4) != 0 and lib.dlio_bn_coop_set_mode(-2) != 0
+        assert lib.dlio_bn_coop_get_mode() == 3
+    finally:
+        assert lib.dlio_bn_coop_set_mode(-1) == 0
+    assert lib.dlio_bn_coop_get_mode() == default
+
+
 def test_error_codes_map_to_reference_style_exceptions():
     from deeplio_amd import _lib
     with pytest.raises(ValueError):

@@ -1701,10 +1701,11 @@ def test_batchnorm_backward_with_the_pool_gradient_routed_on_load(dev, case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode,grid", [(2, 0), (2, -16), (2, -40), (1, 0), (0, 0), (0, -8), (0, -16), (0, -40)])
+@pytest.mark.parametrize("mode,grid", [(3, 0), (2, 0), (2, -16), (2, -40), (1, 0), (0, 0), (0, -8), (0, -16), (0, -40)])
 def test_cooperative_batchnorm_ticket_protocol_corner_cases(dev, mode, grid):
-    """csrc/bn_small.hip, round 5: items are handed out in order by a ticket counter.  mode 2 (default): persistent workgroups,
-    one item at a time; mode 1: one item per workgroup; mode 0: persistent, a workgroup loads its NEXT item under the exchange
+    """csrc/bn_small.hip, round 5: items are handed out in order by a ticket counter.  mode 2: persistent workgroups,
+    one item at a time; mode 1: one item per workgroup; mode 3 (default, round 6): mode 1 for launches with few partners per
+    channel (this one: 16), mode 2 otherwise; mode 0: persistent, a workgroup loads its NEXT item under the exchange
     of the current one.  grid 0: the occupancy-sized grid; grid < 0 (test hook of dlio_bn_coop_set_cus): exactly that many
     workgroups -- with N * parts = 16 cooperating workgroups per channel, 8 pipelined workgroups hold TWO items of a channel
     each (the 'publish both before waiting' path), 16 hold one each, 40 leave a ragged tail; forward (+ residual + plane
@@ -1755,7 +1756,7 @@ def lib_parts(N, HW):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("oneshot", [2, 0])       # (mode 1 -- one item per workgroup -- can stall beside other queues: DESIGN 9)
+@pytest.mark.parametrize("oneshot", [3, 2, 0])    # (mode 1 -- every launch one item per workgroup -- can deadlock two 64-partner launches: DESIGN 9)
 def test_cooperative_batchnorm_launches_on_several_streams_at_once(dev, oneshot):
     """four streams issue cooperative BatchNorm launches of different geometry back to back (round 4 allowed two at a
     time and capped each at 104 CUs; the ticket dispenser needs no co-residency of whole grids): every result equals the one
