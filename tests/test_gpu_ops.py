@@ -1756,7 +1756,8 @@ def lib_parts(N, HW):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("oneshot", [3, 2, 0])    # (mode 1 -- every launch one item per workgroup -- can deadlock two 64-partner launches: DESIGN 9)
+@pytest.mark.parametrize("oneshot", [3, 2, 1, 0])  # (mode 1 -- every launch one item per workgroup -- can deadlock two 64-partner launches,
+                                                    #  ops chains its launches with events, which is what this case exercises)
 def test_cooperative_batchnorm_launches_on_several_streams_at_once(dev, oneshot):
     """four streams issue cooperative BatchNorm launches of different geometry back to back (round 4 allowed two at a
     time and capped each at 104 CUs; the ticket dispenser needs no co-residency of whole grids): every result equals the one
