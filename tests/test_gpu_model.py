@@ -885,7 +885,12 @@ def test_headline_encoder_gradients_with_the_decisions_pinned(dev, B):
     assert len(enc_rows) > 200
     over = [r for r in rows if r[1] > tol]
     if over and not ref64:
-        raise AssertionError("over %.0e against the fp32 pinned oracle: %r" % (tol, over))
+        # (no fp64 yardstick on this host: the one parameter the fp64 branch waives -- the stem's BatchNorm bias, 1.5-2.2e-4 from
+        #  fp64 at B = 8 -- is held to 3e-4 + the fp32 oracle's own 1e-4; anything else over the tolerance fails)
+        bad = [r for r in over if not (r[0].endswith("conv1a.1.bias") and r[1] <= 4e-4)]
+        if bad:
+            raise AssertionError("over %.0e against the fp32 pinned oracle: %r" % (tol, bad))
+        over = []
     if over:
         # A parameter gradient that is a heavily cancelling sum (the stem's BatchNorm bias at N = 8 images: the gradient field
         # behind a BatchNorm backward has zero mean per channel, d loss / d beta sums 4 M signed terms of it) is not computable
