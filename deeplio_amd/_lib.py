@@ -92,6 +92,7 @@ SIGNATURES = {
     "dlio_bn_coop_set_cus": (_i, [_i]),
     "dlio_bn_coop_set_mode": (_i, [_i]),
     "dlio_bn_coop_get_mode": (_i, []),
+    "dlio_bn_coop_one_item": (_i, [_i, _i]),
     "dlio_bn_coop_parts": (_i, [_i, _i]),
     "dlio_bn_coop_gap_ok": (_i, [_i, _i]),
     "dlio_bn_coop_ws_bytes": (_sz, [_i, _i]),

@@ -975,6 +975,16 @@ extern "C" int dlio_bn_coop_set_mode(int oneshot) {
 }
 
 extern "C" int dlio_bn_coop_get_mode(void) { return coop_mode(); }
+// 1: a cooperative launch over N images of H * W = HW runs one item per workgroup under the mode in force (it then takes part in
+// the "at most three in flight" rule of mode 3 / must not overlap another such launch in mode 1), 0: persistent / no such launch
+extern "C" int dlio_bn_coop_one_item(int N, int HW) {
+  int P = 0;
+  const int T = coop_t(N, HW, P);
+  if (!T || !coop_oneshot()) return 0;
+  const void* k = T == 512 ? reinterpret_cast<const void*>(&bn_coop_bwd_kernel<8, 512, 0, false>)
+                           : reinterpret_cast<const void*>(&bn_coop_bwd_kernel<8, 256, 0, false>);
+  return coop_loop(k, N * P, T) ? 0 : 1;
+}
 
 extern "C" int dlio_bn_coop_set_cus(int cus) {
   g_coop_cus = cus;                 // 0 = all CUs; < 0: exactly -cus workgroups (tests of the ticket protocol's corner cases)

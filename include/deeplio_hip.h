@@ -42,7 +42,7 @@ typedef void* dlio_stream_t;
  * at build time (deeplio_amd/build.py passes it in).  The ctypes binding (deeplio_amd/_lib.py)
  * compares both against the header next to it when it loads the library, so a stale .so fails at
  * import instead of being called with a changed signature. */
-#define DLIO_ABI_VERSION 242
+#define DLIO_ABI_VERSION 243
 int dlio_version(void);
 uint32_t dlio_abi_hash(void);
 const char* dlio_arch(void);
@@ -717,6 +717,10 @@ int dlio_bn_coop_set_cus(int cus);
  * -1: back to the default (environment DLIO_BN_COOP_MODE). */
 int dlio_bn_coop_set_mode(int oneshot);
 int dlio_bn_coop_get_mode(void);                 /* the mode in force (3 / 2 / 1 / 0) */
+/* 1: a cooperative launch of this geometry runs one item per workgroup under the mode in force -- it counts towards mode 3's
+ * "at most three in flight" and, in mode 1, must not overlap another such launch; 0: persistent workgroups (or no cooperative
+ * kernel for the geometry).  Needs the device (occupancy query). */
+int dlio_bn_coop_one_item(int N, int HW);
 int dlio_bn_coop_parts(int N, int HW);
 int dlio_bn_coop_gap_ok(int N, int HW);        /* bf16 kernels with gap_out: the plane in one workgroup, H * W in {8192, 16384, 32768} */
 size_t dlio_bn_coop_ws_bytes(int N, int C);      /* bytes of `part` */

@@ -1804,6 +1804,27 @@ def test_cooperative_batchnorm_launches_on_several_streams_at_once(dev, oneshot)
 
 
 @pytest.mark.gpu
+def test_cooperative_batchnorm_mode_3_picks_the_launch_form_by_partner_count(dev):
+    """dlio_bn_coop_one_item: under mode 3 a launch runs one item per workgroup only when three such launches cannot fill an XCD's
+    workgroup slots with waiting workgroups (3 (N parts - 1) < occupancy x CUs / 8 = 96 on MI355X): at N = 16 the 64x128 and
+    64x256 planes (16 / 32 partners per channel) do, the 64x512 planes (64 partners: fire_blk1) stay persistent; mode 2 never,
+    mode 1 always"""
+    from deeplio_amd import ops, _lib
+    q = _lib.lib.dlio_bn_coop_one_item
+    try:
+        ops.bn_coop_set_mode(3)
+        assert [q(16, hw) for hw in (8192, 16384, 32768)] == [1, 1, 0]
+        assert q(8, 32768) == 1 and q(4, 65536) == 1          # 32 partners (B = 4 at fire_blk1), 32 (4 images x 8 parts)
+        assert q(16, 4096) == 0                                 # no cooperative kernel for small planes
+        ops.bn_coop_set_mode(2)
+        assert [q(16, hw) for hw in (8192, 16384, 32768)] == [0, 0, 0]
+        ops.bn_coop_set_mode(1)
+        assert [q(16, hw) for hw in (8192, 16384, 32768)] == [1, 1, 1]
+    finally:
+        ops.bn_coop_set_mode(-1)
+
+
+@pytest.mark.gpu
 def test_cooperative_batchnorm_spin_limit_sets_the_flag_and_the_host_falls_back(dev):
     """a launch that cannot make progress (ONE workgroup for four cooperating ones: test hook) ends -- bounded spin -- with
     the error flag set; ops.bn_coop_check() reports it, re-initialises the workspace and switches the cooperative kernels
