@@ -669,7 +669,11 @@ def main():
                             "companions, IMU branch) share the chip, so per-launch durations include the neighbours' "
                             "share; only the family with the largest OVERLAPPED time is timed there (an event pair "
                             "costs stream time).  'other' = every family in an untimed pass of the same overlapped "
-                            "step with all launches timed; 'isolated' = the same with the stream overlap off")
+                            "step with all launches timed; 'isolated' = the same with the stream overlap off.  The "
+                            "cooperative BatchNorm launches of fire_blk2 / blk3 run one item per workgroup (mode 3, DESIGN 9): "
+                            "their workgroups come and go between the neighbours' instead of holding 3 / 8 of the chip for the "
+                            "launch's length -- each launch takes longer INSIDE the overlapped step (frac 0.27 -> 0.245) while "
+                            "the step and the family alone get faster (isolated.frac 0.45 -> 0.47)")
         if prof_ovl is not None:
             other = {}
             for name, v in prof_ovl.items():
