@@ -1211,6 +1211,41 @@ def test_early_tail_optimizer_step_is_bit_identical(dev, optim):
         assert torch.equal(sa[k], sb[k]), k
 
 
+def test_cooperative_batchnorm_modes_train_bit_identically(dev):
+    """The cooperative BatchNorm mode only decides WHO computes an item and when (persistent workgroups drawing tickets, one
+    workgroup per item, or the per-launch mix of mode 3, the default): the partners' sums are added in slot order either way, so
+    three training steps at the headline geometry (64x2048x5, B = 2: fire_blk1's 64x512 planes have 16 partners per channel, all
+    launches of mode 3 run one item per workgroup) leave BIT-identical losses, parameters and Adam moments under modes 3, 2 and 1
+    (pointseg_modules.py:116-142 in training, trainer.py:263-266)."""
+    from deeplio_amd import functional as Fh, ops
+    from deeplio_amd.config import make_config
+    from deeplio_amd.trainer import TrainStep
+    cfg0 = dict(seq=2, overrides=gc.NO_DROP)
+    batch = tuple(t.to(dev) for t in gc.make_batch(7, 2, 2, 5, 64, 2048, 50))
+    res = []
+    try:
+        for mode in (3, 2, 1):
+            ops.bn_coop_set_mode(mode)
+            Fh.manual_seed(11)
+            torch.manual_seed(5)
+            ts = TrainStep(make_config(**cfg0), (5, 64, 2048), dev, 2)
+            gc.fill_state(ts.model, seed=1000)
+            losses = [float(ts.step(*batch)) for _ in range(3)]
+            ts.check()
+            torch.cuda.synchronize()
+            st = ts.optimizer._state()
+            res.append((losses, ts.optimizer.flat.clone(), {k: v.clone() for k, v in st.items()}))
+            ts.release_gc()
+            del ts
+    finally:
+        ops.bn_coop_set_mode(-1)
+    assert ops.bn_coop_errors() == 0
+    for other in res[1:]:
+        assert other[0] == res[0][0] and torch.equal(other[1], res[0][1])
+        for k in res[0][2]:
+            assert torch.equal(other[2][k], res[0][2][k]), k
+
+
 def test_lstm_gradient_slots_overwritten_instead_of_zeroed(dev):
     """TrainStep marks the odometry LSTM's gradient slots as overwritten by their producer (FlatOptimizer.set_overwritten:
     functional.LstmStackFn writes a layer's weight gradients in one launch, exactly once per backward pass; the discarded
