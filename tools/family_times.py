@@ -5,9 +5,12 @@ roofline.other quote.  Run the trace on `bench.py --serial` for exclusive (isola
 
     python tools/family_times.py <results.db> <steps in the trace> [out.md] [note...]
 """
+import os
 import re
 import sqlite3
 import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _trace_window import step_phase_start
 
 FAMILIES = [
     ("conv3x3 fwd+dgrad (split-bf16 MFMA; fused Fire expand pair)", ("conv3x3_bx3_", "conv3x3_bf16", "fire_expand_fwd_kernel")),
@@ -33,7 +36,11 @@ FAMILIES = [
 
 def main(db, steps, out=None, note=""):
     cur = sqlite3.connect(db).cursor()
-    rows = cur.execute("select name, count(*), sum(end-start)/1e6 from kernels where name not like '%spin_kernel%' group by name").fetchall()
+    t0, before = step_phase_start(cur)
+    rows = cur.execute("select name, count(*), sum(end-start)/1e6 from kernels where name not like '%spin_kernel%' and start >= ? "
+                       "group by name", (t0 if t0 is not None else -1,)).fetchall()
+    if t0 is not None:
+        note = (note + "; the %d launches in front of the first step (model construction) are left out" % before).lstrip("; ")
     fam = {n: [0, 0.0] for n, _ in FAMILIES}
     fam["everything else"] = [0, 0.0]
     for name, c, ms in rows:

@@ -1,19 +1,27 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 --kernel-trace rocpd database (results.db) into a per-kernel table
 (count, total ms, avg us, share) -- the `--stats` view, written as markdown under profiles/."""
+import os
 import re
 import sqlite3
 import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _trace_window import step_phase_start
 
 
 def main(db_path, out_path, steps, note=""):
     cur = sqlite3.connect(db_path).cursor()
+    t0, before = step_phase_start(cur)
     rows = cur.execute("select name, count(*), sum(end-start)/1e6, avg(end-start)/1e3, min(end-start)/1e3, "
-                       "max(end-start)/1e3 from kernels where name not like '%spin_kernel%' group by name order by 3 desc").fetchall()
+                       "max(end-start)/1e3 from kernels where name not like '%spin_kernel%' and start >= ? "
+                       "group by name order by 3 desc", (t0 if t0 is not None else -1,)).fetchall()
     # (spin_kernel: the stream / hardware-queue probe of functional.assign_streams, once per process, not part of a step)
     tot = sum(r[2] for r in rows)
     with open(out_path, "w") as f:
         f.write("# rocprofv3 --kernel-trace --stats summary\n\n%s\n\n" % note)
+        if t0 is not None:
+            f.write("(the stepping phase of the trace: the %d launches in front of the first step -- model construction, parameter "
+                    "initialisation, H2D copies -- are left out)\n\n" % before)
         f.write("total kernel time %.1f ms over %d steps (incl. warm-up) = %.1f ms/step\n\n" % (tot, steps, tot / steps))
         f.write("| kernel | calls | total ms | avg us | min us | max us | % |\n|---|---|---|---|---|---|---|\n")
         for n, c, s, a, mn, mx in rows:
