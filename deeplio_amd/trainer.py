@@ -53,6 +53,9 @@ class TrainStep:
         # copy issued `check_every` steps earlier (long complete) is inspected -- a bad step raises at most 2 x check_every
         # steps later instead of training on until somebody calls check().  0 switches the polling off.
         self.check_every = int(os.environ.get("DLIO_CHECK_EVERY", "8"))
+        # backward on the calling thread instead of the engine's device thread (no hand-over, no second thread taking turns at
+        # the interpreter lock with the one that issues the launches): see DESIGN 9 for the measured host time
+        self.autograd_inline = os.environ.get("DLIO_AUTOGRAD_INLINE", "1") != "0"
         self._poll_pending = None
         self._poll_host = None
         # the optimizer step over the tail bucket issued from inside backward (see _tail_ready); 0: one sweep at the end
@@ -223,7 +226,11 @@ class TrainStep:
             self.optimizer.zero_grad()
         else:
             Fh.current_stream_obj().wait_event(zero_ev)
-        loss.backward(self._one)                   # (an explicit d loss / d loss: no fill launch per step)
+        if self.autograd_inline:
+            with torch.autograd.set_multithreading_enabled(False):
+                loss.backward(self._one)           # (an explicit d loss / d loss: no fill launch per step)
+        else:
+            loss.backward(self._one)
         if self.grad_sync is not None:
             self.grad_sync.all_reduce_grads()
         self.optimizer.step()

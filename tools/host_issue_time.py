@@ -28,7 +28,12 @@ for (W, B) in ((2048, 8), (256, 2)):
         feats = ts.model.forward_features([[imgs, normals], imus]); t.append(time.perf_counter())
         loss = ts._tail(feats, gf, gg); t.append(time.perf_counter())
         ts.optimizer.zero_grad(); t.append(time.perf_counter())
-        loss.backward(); t.append(time.perf_counter())
+        if ts.autograd_inline:
+            with torch.autograd.set_multithreading_enabled(False):
+                loss.backward()
+        else:
+            loss.backward()
+        t.append(time.perf_counter())
         ts.optimizer.step(); t.append(time.perf_counter())
         torch.cuda.synchronize(); t.append(time.perf_counter())
         for i in range(6):
